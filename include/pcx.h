@@ -1,0 +1,274 @@
+/*
+ * pcx.h -- C ABI of the MI355X-native batched gridworld step engine.
+ *
+ * This is the drop-in boundary for pycolab's step path.  The reference has no
+ * FFI of its own (it is pure Python); what a maintainer would bind is its
+ * public stepping API, and every entry point below names the reference
+ * interface it replaces (paths relative to the pycolab checkout):
+ *
+ *   pcx_engine_create   <- ascii_art.ascii_art_to_game()  pycolab/ascii_art.py:31-291
+ *                          + Engine.__init__/add_*/set_*  pycolab/engine.py:98-518
+ *                          (the host has already run the constructors; the
+ *                          template is their result as plain data)
+ *   pcx_engine_reset    <- Engine.its_showtime()          pycolab/engine.py:520-581
+ *   pcx_engine_step     <- Engine.play(actions)           pycolab/engine.py:583-639
+ *                          (= _update_and_render :698-735, _render :737-759,
+ *                          _apply_and_clear_plot :761-847, and the entity
+ *                          update() bodies of the shipped games)
+ *   pcx_engine_buffers  <- the (Observation, reward, discount) triple that
+ *                          play() returns              pycolab/engine.py:639,
+ *                          rendering.Observation       pycolab/rendering.py:28-63,
+ *                          Engine.game_over / the_plot.frame  engine.py:660, plot.py:274
+ *   pcx_cropper_*       <- cropping.ObservationCropper._do_crop  pycolab/cropping.py:118-227,
+ *                          FixedCropper.crop :255-268, ScrollingCropper.crop :393-426
+ *
+ * Conventions: every function returns 0 on success or a negative PCX_E_*
+ * code and leaves a thread-local message for pcx_last_error().  Pointers in
+ * signatures are plain host or device pointers plus sizes; no framework types.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ * An engine is bound to one device and is not re-entrant.
+ */
+#ifndef PCX_H_
+#define PCX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCX_ABI_VERSION 1u
+
+#define PCX_MAX_CHARS 32    /* distinct characters (layers) in one game   */
+#define PCX_MAX_SPRITES 16
+#define PCX_MAX_DRAPES 8
+#define PCX_MAX_THINGS (PCX_MAX_SPRITES + PCX_MAX_DRAPES)
+
+/* Action value that stands for Python's `None` (frame 0, engine.py:581). */
+#define PCX_ACTION_NONE (-1)
+
+/* Error codes. */
+#define PCX_OK 0
+#define PCX_E_INVALID (-1)      /* bad argument / malformed template          */
+#define PCX_E_UNSUPPORTED (-2)  /* template has no device program             */
+#define PCX_E_HIP (-3)          /* a HIP runtime call failed                  */
+#define PCX_E_STATE (-4)        /* call order violation (e.g. step before reset) */
+
+/* Which hand-written device program steps this template's entities. */
+enum pcx_game {
+  PCX_GAME_SCROLLY_MAZE = 1, /* examples/scrolly_maze.py                    */
+  PCX_GAME_MARAUDERS = 2,    /* examples/extraterrestrial_marauders.py      */
+  PCX_GAME_WAREHOUSE = 3,    /* examples/warehouse_manager.py               */
+  PCX_GAME_HELLO_WORLD = 4,  /* examples/hello_world.py                     */
+  PCX_GAME_WALKERS = 5       /* prefab-only games: MazeWalker/Scrolly with
+                                action->motion tables (tests/test_things.py) */
+};
+
+/* Per-entity device program ids (entity `update()` bodies). */
+enum pcx_program {
+  PCX_PROG_NONE = 0,
+  /* examples/scrolly_maze.py */
+  PCX_PROG_SM_PLAYER = 10,    /* PlayerSprite.update     :259-271 */
+  PCX_PROG_SM_PATROLLER = 11, /* PatrollerSprite.update  :284-305 */
+  PCX_PROG_SM_MAZE = 12,      /* MazeDrape.update        :317-329 */
+  PCX_PROG_SM_CASH = 13,      /* CashDrape.update        :341-364 */
+  /* examples/extraterrestrial_marauders.py */
+  PCX_PROG_EM_PLAYER = 20,
+  PCX_PROG_EM_BUNKER = 21,
+  PCX_PROG_EM_MARAUDER = 22,
+  PCX_PROG_EM_UPBOLT = 23,
+  PCX_PROG_EM_DOWNBOLT = 24,
+  /* examples/warehouse_manager.py */
+  PCX_PROG_WM_BOX = 30,
+  PCX_PROG_WM_JUDGE = 31,
+  PCX_PROG_WM_PLAYER = 32,
+  /* examples/hello_world.py */
+  PCX_PROG_HW_ROLLING = 40,
+  PCX_PROG_HW_SLIDING = 41,
+  /* prefab-only entities driven by an action->motion table */
+  PCX_PROG_WALKER = 50,  /* MazeWalker subclass: action a -> motion table  */
+  PCX_PROG_SCROLLY = 51, /* Scrolly subclass: action a -> motion table     */
+  PCX_PROG_STATIC = 52   /* entity whose update() does nothing             */
+};
+
+/* A Sprite as left by its constructor (things.py:273-319; MazeWalker
+ * sprites.py:153-204 when is_walker != 0). */
+typedef struct pcx_sprite_desc {
+  uint8_t ch;           /* character painted                                 */
+  uint8_t is_walker;    /* derives from prefab_parts.sprites.MazeWalker      */
+  uint8_t visible;      /* Sprite._visible after construction                */
+  uint8_t prior_visible;/* MazeWalker._prior_visible (0 when None)           */
+  uint8_t confined;     /* confined_to_board                                 */
+  uint8_t egocentric;   /* egocentric_scroller                               */
+  uint8_t pad0[2];
+  int32_t program;      /* enum pcx_program                                  */
+  int32_t row, col;     /* true position (Sprite.position)                   */
+  int32_t vrow, vcol;   /* MazeWalker virtual position                       */
+  uint8_t impassable[16]; /* 128-bit set of impassable characters            */
+  int32_t param[4];     /* program-specific constants                        */
+} pcx_sprite_desc;
+
+/* A Drape as left by its constructor (things.py:161-247; Scrolly
+ * drapes.py:293-376 when is_scrolly != 0). */
+typedef struct pcx_drape_desc {
+  uint8_t ch;
+  uint8_t is_scrolly;
+  uint8_t have_margins;  /* scroll_margins is not None                       */
+  uint8_t pad0;
+  int32_t program;
+  const uint8_t* curtain;   /* rows*cols bytes, 0/1: initial curtain          */
+  /* Scrolly only: */
+  const uint8_t* pattern;   /* pattern_rows*pattern_cols bytes, 0/1           */
+  int32_t pattern_rows, pattern_cols;
+  int32_t corner_row, corner_col;   /* board_northwest_corner                 */
+  int32_t margin_rows, margin_cols; /* scroll_margins (if have_margins)       */
+  int32_t param[4];
+} pcx_drape_desc;
+
+/* A whole game as built by ascii_art_to_game(), before its_showtime(). */
+typedef struct pcx_template {
+  uint32_t abi_version;   /* PCX_ABI_VERSION                                  */
+  int32_t game;           /* enum pcx_game                                    */
+  int32_t rows, cols;
+  int32_t occlusion_in_layers; /* Engine(..., occlusion_in_layers)            */
+  int32_t n_chars;
+  uint8_t chars[PCX_MAX_CHARS]; /* sorted; order of the layer planes          */
+  const uint8_t* backdrop;      /* rows*cols bytes: Backdrop.curtain          */
+  int32_t n_sprites;
+  pcx_sprite_desc sprites[PCX_MAX_SPRITES];
+  int32_t n_drapes;
+  pcx_drape_desc drapes[PCX_MAX_DRAPES];
+  int32_t n_things;
+  uint8_t z_order[PCX_MAX_THINGS];   /* characters, back to front             */
+  uint8_t schedule[PCX_MAX_THINGS];  /* characters in update order            */
+  uint8_t group_of[PCX_MAX_THINGS];  /* update-group index of schedule[i]     */
+  int32_t n_groups;
+  int32_t n_actions;      /* actions 0..n_actions-1 are "ordinary" (bench/tests) */
+  int32_t param[8];       /* game-specific constants                          */
+} pcx_template;
+
+/* Device (or host, for the oracle) pointers to what play() returns, batched.
+ * Contents are valid until the next reset/step on the same engine -- the same
+ * aliasing rule as the reference (rendering.py:55-63). */
+typedef struct pcx_buffers {
+  int64_t batch;
+  int32_t rows, cols, n_chars;
+  /* planes[b][0] = board (uint8 chars); planes[b][1+k] = layer of chars[k]
+   * (uint8 0/1).  Shape [batch][1+n_chars][rows][cols], contiguous. */
+  uint8_t* planes;
+  int32_t* reward;      /* [batch] summed reward (0 when reward_set == 0)      */
+  uint8_t* reward_set;  /* [batch] 0 => the reference would return None       */
+  float* discount;      /* [batch]                                             */
+  uint8_t* done;        /* [batch] Engine.game_over                            */
+  int32_t* frame;       /* [batch] the_plot.frame                              */
+  uint8_t* error;       /* [batch] 0 ok; else the reference would have raised  */
+} pcx_buffers;
+
+/* Per-entity state readback (Engine.things[...] on the host facade). */
+typedef struct pcx_sprite_state {
+  int32_t row, col, vrow, vcol;
+  uint8_t visible;
+  uint8_t pad[3];
+} pcx_sprite_state;
+
+typedef struct pcx_engine pcx_engine;
+
+/* engine.py:98-518 + ascii_art.py:31-291: upload shared constants, allocate
+ * the SoA state of `batch` environments on `device_id`.  Template pointers
+ * need only stay valid for the duration of the call. */
+int pcx_engine_create(const pcx_template* t, int64_t batch, int device_id,
+                      pcx_engine** out);
+void pcx_engine_destroy(pcx_engine* e);
+
+/* engine.py:520-581 its_showtime(): (re)build every environment selected by
+ * env_mask_dev (device uint8[batch], NULL = all) from the template and run
+ * frame 0 (play(None)). */
+int pcx_engine_reset(pcx_engine* e, const uint8_t* env_mask_dev, void* stream);
+
+/* engine.py:583-639 play(): one step of every environment.  actions_dev is a
+ * device int32[batch] (PCX_ACTION_NONE = None).  With auto_reset != 0 an
+ * environment whose episode is over is rebuilt and runs frame 0 instead
+ * (counted as one env-step); with auto_reset == 0 it is left untouched. */
+int pcx_engine_step(pcx_engine* e, const int32_t* actions_dev, int auto_reset,
+                    void* stream);
+
+/* T consecutive steps from a device action tape int32[T][batch]. Observations
+ * of intermediate steps are overwritten, exactly as T calls to step would. */
+int pcx_engine_step_n(pcx_engine* e, const int32_t* action_tape_dev, int T,
+                      int auto_reset, void* stream);
+
+/* T steps whose actions are generated on device by pcx_action_hash(seed,
+ * global_env, t0 + t) % n_actions (global_env = env_offset + local index). */
+int pcx_engine_step_hashed(pcx_engine* e, uint64_t seed, int64_t env_offset,
+                           int64_t t0, int T, int auto_reset, void* stream);
+
+int pcx_engine_buffers(pcx_engine* e, pcx_buffers* out);
+
+/* Optional, before the first reset: make the engine write its outputs into
+ * caller-owned device arrays (e.g. tensors of the host framework) instead of
+ * allocating its own.  Every pointer in `ext` must be non-NULL and sized for
+ * the engine's batch; batch/rows/cols/n_chars must match. */
+int pcx_engine_bind_buffers(pcx_engine* e, const pcx_buffers* ext);
+
+/* Host readback of entity state for environments [env0, env0+n): sprites as
+ * pcx_sprite_state[n][n_sprites] (template order), drape curtains as
+ * uint8[n][n_drapes][rows*cols].  Either pointer may be NULL. Synchronous. */
+int pcx_engine_read_things(pcx_engine* e, int64_t env0, int64_t n,
+                           pcx_sprite_state* sprites_host,
+                           uint8_t* curtains_host);
+
+/* Convenience synchronous copies (host <-> device) for thin FFI hosts. */
+int pcx_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes);
+int pcx_memcpy_h2d(void* dst_dev, const void* src_host, uint64_t bytes);
+int pcx_device_malloc(void** out_dev, uint64_t bytes);
+int pcx_device_free(void* dev);
+int pcx_stream_synchronize(void* stream);
+
+/* The counter-based action generator shared by host, oracle and device. */
+uint32_t pcx_action_hash(uint64_t seed, uint64_t env, uint64_t t);
+
+/* Algorithmic HBM bytes one env-step of this engine must move (DESIGN.md). */
+int64_t pcx_engine_bytes_per_step(const pcx_engine* e);
+/* Name of the dominant kernel, as rocprofv3 prints it. */
+const char* pcx_engine_kernel_name(const pcx_engine* e);
+
+const char* pcx_last_error(void);
+uint32_t pcx_abi_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* Croppers: cropping.py.  A cropper owns per-environment window state.      */
+
+enum pcx_cropper_kind {
+  PCX_CROP_FIXED = 1,     /* cropping.FixedCropper      :230-268 */
+  PCX_CROP_SCROLLING = 2  /* cropping.ScrollingCropper  :271-598 */
+};
+
+typedef struct pcx_cropper_desc {
+  int32_t kind;
+  int32_t rows, cols;          /* window size                               */
+  int32_t top, left;           /* FixedCropper top_left_corner              */
+  int32_t pad_char;            /* -1 = None                                 */
+  int32_t n_track;             /* ScrollingCropper to_track                 */
+  uint8_t to_track[PCX_MAX_THINGS];
+  int32_t margin_rows, margin_cols; /* resolved scroll_margins (never None) */
+  int32_t initial_offset_rows, initial_offset_cols;
+  int32_t saccade;
+} pcx_cropper_desc;
+
+typedef struct pcx_cropper pcx_cropper;
+
+int pcx_cropper_create(pcx_engine* e, const pcx_cropper_desc* d,
+                       pcx_cropper** out);
+void pcx_cropper_destroy(pcx_cropper* c);
+/* cropping.py:393-426 (or :255-268): crop the engine's current observation.
+ * Environments whose engine was reset this step restart their window. */
+int pcx_cropper_crop(pcx_cropper* c, void* stream);
+/* planes: uint8 [batch][1+n_chars][rows][cols] of the cropped window;
+ * corner: int32 [batch][2] window corner (scrolling croppers). */
+int pcx_cropper_buffers(pcx_cropper* c, uint8_t** planes_dev,
+                        int32_t** corner_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCX_H_ */

@@ -1,0 +1,744 @@
+/*
+ * pcx_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT (see pcx_oracle.h).
+ *
+ * A literal, scalar, one-environment-at-a-time restatement of the reference
+ * algorithm.  It deliberately keeps the reference's own data structures
+ * (a full uint8 board, bool layers, a curtain per drape, a private copy of
+ * every Scrolly pattern, a repaint after every update group) and none of the
+ * tricks of the HIP path, so that the two implementations are independent.
+ *
+ * Each function cites the reference lines it follows (paths under pycolab/).
+ */
+#include "pcx_oracle.h"
+
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static __thread char g_err[512];
+const char* pcxo_last_error(void) { return g_err; }
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+
+/* Error bits reported per environment (the reference would have raised). */
+#define OX_ERR_INDEX 1       /* numpy IndexError                        */
+#define OX_ERR_SCROLL 2      /* scrolling.Error / egocentric RuntimeError */
+#define OX_ERR_AFTER_OVER 4  /* play() after game_over (engine.py:622)   */
+
+/* ---- counter-based action generator (shared definition, see pcx.h) ------ */
+uint32_t pcxo_action_hash(uint64_t seed, uint64_t env, uint64_t t) {
+  uint64_t x = seed ^ (env * 0x9E3779B97F4A7C15ull) ^ (t * 0xBF58476D1CE4E5B9ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+/* ---- per-environment state ---------------------------------------------- */
+
+typedef struct {
+  /* things.Sprite (things.py:309-319) */
+  int row, col, visible;
+  /* sprites.MazeWalker (sprites.py:196-204) */
+  int vrow, vcol, prior_visible;
+  int var[4]; /* program variables (e.g. PatrollerSprite._moving_east) */
+} ox_sprite;
+
+typedef struct {
+  uint8_t* curtain; /* things.Drape.curtain, rows*cols */
+  /* drapes.Scrolly (drapes.py:327-376) */
+  uint8_t* pattern; /* private whole_pattern copy */
+  int corner[2];
+  int prescroll[2];
+  int64_t last_maybe_move_frame; /* INT64_MIN = -inf */
+  int var[4];
+} ox_drape;
+
+/* Entity ids inside one env: sprites 0..15, drapes 16..23. */
+#define OX_DRAPE_ID(i) (PCX_MAX_SPRITES + (i))
+
+typedef struct {
+  int frame; /* plot.py:274 (starts at -1: engine.py:716 makes frame 0) */
+  /* Plot._EngineDirectives (plot.py:69-104) */
+  int reward_set;
+  int64_t reward;
+  float discount;
+  int game_over;
+  /* protocols/scrolling.py state for scrolling group '' (:198-241) */
+  int order_frame_valid, order_frame; /* 'scrolling__order_frame' */
+  int order[2];                       /* 'scrolling__order'       */
+  uint32_t egocentrists;              /* bit per entity id        */
+  int permit_frame_valid[PCX_MAX_THINGS];
+  int permit_frame[PCX_MAX_THINGS];
+  uint16_t permit_mask[PCX_MAX_THINGS]; /* bit per motion index */
+  /* free-form plot entries used by the shipped games */
+  int64_t kv[8];
+} ox_plot;
+
+typedef struct {
+  ox_sprite sprites[PCX_MAX_SPRITES];
+  ox_drape drapes[PCX_MAX_DRAPES];
+  ox_plot plot;
+  int game_over; /* Engine._game_over */
+  int error;
+} ox_env;
+
+struct pcxo_engine {
+  pcx_template t;    /* deep copy */
+  uint8_t* backdrop; /* rows*cols */
+  uint8_t* init_curtain[PCX_MAX_DRAPES];
+  uint8_t* init_pattern[PCX_MAX_DRAPES];
+  int64_t batch;
+  ox_env* envs;
+  int showtime;
+  /* z-order and schedule resolved to entity ids */
+  int z_id[PCX_MAX_THINGS];
+  int sched_id[PCX_MAX_THINGS];
+  /* outputs */
+  uint8_t* planes;
+  int32_t* reward;
+  uint8_t* reward_set;
+  float* discount;
+  uint8_t* done;
+  int32_t* frame;
+  uint8_t* error;
+};
+
+static inline int cells(const pcxo_engine* e) { return e->t.rows * e->t.cols; }
+static inline uint8_t* env_board(pcxo_engine* e, int64_t b) {
+  return e->planes + (size_t)b * (1 + e->t.n_chars) * cells(e);
+}
+static inline uint8_t* env_layer(pcxo_engine* e, int64_t b, int k) {
+  return env_board(e, b) + (size_t)(1 + k) * cells(e);
+}
+static int char_index(const pcxo_engine* e, int ch) {
+  for (int k = 0; k < e->t.n_chars; ++k)
+    if (e->t.chars[k] == ch) return k;
+  return -1;
+}
+/* entity id of the sprite/drape that paints `ch`, or -1 */
+static int thing_id(const pcxo_engine* e, int ch) {
+  for (int i = 0; i < e->t.n_sprites; ++i)
+    if (e->t.sprites[i].ch == ch) return i;
+  for (int i = 0; i < e->t.n_drapes; ++i)
+    if (e->t.drapes[i].ch == ch) return OX_DRAPE_ID(i);
+  return -1;
+}
+
+/* ---- Plot --------------------------------------------------------------- */
+
+/* plot.py:343-353 _clear_engine_directives */
+static void plot_clear_directives(ox_plot* p) {
+  p->reward_set = 0;
+  p->reward = 0;
+  p->discount = 1.0f;
+  p->game_over = 0;
+}
+/* plot.py:176-198 */
+static void plot_terminate(ox_plot* p, float discount) {
+  p->game_over = 1;
+  p->discount = discount;
+}
+/* plot.py:200-226 */
+static void plot_add_reward(ox_plot* p, int64_t r) {
+  if (!p->reward_set) { p->reward_set = 1; p->reward = r; }
+  else p->reward += r;
+}
+
+/* ---- protocols/scrolling.py ---------------------------------------------- */
+
+static inline int motion_index(int dr, int dc) { return (dr + 1) * 3 + (dc + 1); }
+
+/* scrolling.py:287-312 participate_as_egocentric */
+static void scroll_participate(ox_plot* p, int id) { p->egocentrists |= 1u << id; }
+
+/* scrolling.py:339-369 get_order: returns 1 and fills `order` if an order was
+ * issued during the current frame. */
+static int scroll_get_order(const ox_plot* p, int order[2]) {
+  if (!p->order_frame_valid || p->order_frame != p->frame) return 0;
+  order[0] = p->order[0];
+  order[1] = p->order[1];
+  return 1;
+}
+
+/* scrolling.py:372-434 permit */
+static int scroll_permit(ox_plot* p, int id, uint16_t motions) {
+  if (!(p->egocentrists & (1u << id))) return OX_ERR_SCROLL; /* :406-410 */
+  int my_frame = p->frame + 1;                               /* :418 */
+  if (!p->permit_frame_valid[id]) {                          /* setdefault :427 */
+    p->permit_frame_valid[id] = 1;
+    p->permit_frame[id] = my_frame;
+  } else if (p->permit_frame[id] != my_frame) {
+    p->permit_frame[id] = my_frame;
+    p->permit_mask[id] = 0;
+  }
+  p->permit_mask[id] |= motions; /* :431 */
+  return 0;
+}
+
+/* scrolling.py:437-485 is_possible */
+static int scroll_is_possible(const ox_plot* p, int dr, int dc) {
+  for (int id = 0; id < PCX_MAX_THINGS; ++id) {
+    if (!(p->egocentrists & (1u << id))) continue;
+    if (!p->permit_frame_valid[id] || p->permit_frame[id] != p->frame) return 0;
+    if (!(p->permit_mask[id] & (1u << motion_index(dr, dc)))) return 0;
+  }
+  return 1;
+}
+
+/* scrolling.py:488-531 order (check_possible handled by callers) */
+static int scroll_order(ox_plot* p, int dr, int dc) {
+  if (p->order_frame_valid && p->order_frame == p->frame) return OX_ERR_SCROLL;
+  p->order_frame_valid = 1;
+  p->order_frame = p->frame;
+  p->order[0] = dr;
+  p->order[1] = dc;
+  return 0;
+}
+
+/* ---- prefab_parts/sprites.py: MazeWalker --------------------------------- */
+
+/* sprites.py:548-550 */
+static inline int mw_on_board(const pcxo_engine* e, int r, int c) {
+  return 0 <= r && r < e->t.rows && 0 <= c && c < e->t.cols;
+}
+
+/* sprites.py:315-352 _teleport (+ _on_board_exit/_enter :223-275) */
+static void mw_teleport(const pcxo_engine* e, ox_sprite* s, int nr, int nc) {
+  int old_on = mw_on_board(e, s->vrow, s->vcol);
+  int new_on = mw_on_board(e, nr, nc);
+  if (old_on && !new_on) { s->prior_visible = s->visible; s->visible = 0; }
+  s->vrow = nr;
+  s->vcol = nc;
+  if (new_on) { s->row = nr; s->col = nc; }
+  else { s->row = 0; s->col = 0; }
+  if (!old_on && new_on) s->visible = s->prior_visible;
+}
+
+static inline int impassable_has(const pcx_sprite_desc* d, int ch) {
+  return (d->impassable[ch >> 3] >> (ch & 7)) & 1;
+}
+
+/* sprites.py:496-511: at() + is_impassable() for one neighbour */
+static int mw_blocked_at(const pcxo_engine* e, const pcx_sprite_desc* d,
+                         const ox_sprite* s, const uint8_t* board, int dr, int dc) {
+  int r = s->vrow + dr, c = s->vcol + dc;
+  if (!mw_on_board(e, r, c)) return d->confined; /* EDGE */
+  return impassable_has(d, board[r * e->t.cols + c]);
+}
+
+/* sprites.py:479-546 _check_motion: nonzero iff the motion is obstructed */
+static int mw_check_motion(const pcxo_engine* e, const pcx_sprite_desc* d,
+                           const ox_sprite* s, const uint8_t* board, int dr, int dc) {
+  if (dr == 0 && dc == 0) return 0;
+  if (dr != 0 && dc != 0) { /* diagonal :539-541 */
+    /* neighbs = (left of motion vector, ahead, right of it); only whether
+     * the two flanks are both impassable matters for the verdict. */
+    if (mw_blocked_at(e, d, s, board, dr, dc)) return 1;
+    if (mw_blocked_at(e, d, s, board, dr, 0) && mw_blocked_at(e, d, s, board, 0, dc)) return 1;
+    return 0;
+  }
+  return mw_blocked_at(e, d, s, board, dr, dc); /* cardinal :542-543 */
+}
+
+/* sprites.py:413-454 _obey_scrolling_order */
+static void mw_obey_order(const pcxo_engine* e, ox_env* env, int id, int dr, int dc) {
+  const pcx_sprite_desc* d = &e->t.sprites[id];
+  ox_sprite* s = &env->sprites[id];
+  if (d->egocentric) scroll_participate(&env->plot, id);
+  int order[2];
+  if (scroll_get_order(&env->plot, order)) {
+    mw_teleport(e, s, s->vrow - order[0], s->vcol - order[1]); /* _raw_move */
+    if (d->egocentric && order[0] != dr && order[1] != dc) env->error |= OX_ERR_SCROLL;
+  }
+}
+
+/* sprites.py:456-477 _update_scroll_permissions */
+static void mw_update_permits(const pcxo_engine* e, ox_env* env, int id, const uint8_t* board) {
+  const pcx_sprite_desc* d = &e->t.sprites[id];
+  if (!d->egocentric) return;
+  const ox_sprite* s = &env->sprites[id];
+  uint16_t legal = 1u << motion_index(0, 0);
+  for (int dr = -1; dr <= 1; ++dr)
+    for (int dc = -1; dc <= 1; ++dc) {
+      if (dr == 0 && dc == 0) continue;
+      if (!mw_check_motion(e, d, s, board, dr, dc)) legal |= 1u << motion_index(dr, dc);
+    }
+  env->error |= scroll_permit(&env->plot, id, legal);
+}
+
+/* sprites.py:356-389 _move; returns nonzero iff obstructed */
+static int mw_move(const pcxo_engine* e, ox_env* env, int id, const uint8_t* board, int dr, int dc) {
+  const pcx_sprite_desc* d = &e->t.sprites[id];
+  ox_sprite* s = &env->sprites[id];
+  mw_obey_order(e, env, id, dr, dc);
+  int blocked = mw_check_motion(e, d, s, board, dr, dc);
+  if (!blocked) mw_teleport(e, s, s->vrow + dr, s->vcol + dc); /* _raw_move :391-411 */
+  mw_update_permits(e, env, id, board);
+  return blocked;
+}
+
+/* ---- prefab_parts/drapes.py: Scrolly -------------------------------------- */
+
+/* drapes.py:689-695 _update_curtain.  numpy slicing clamps the slice to the
+ * pattern; a window that leaves the pattern would make np.copyto raise. */
+static void sc_update_curtain(const pcxo_engine* e, ox_env* env, int di) {
+  const pcx_drape_desc* d = &e->t.drapes[di];
+  ox_drape* s = &env->drapes[di];
+  int R = e->t.rows, C = e->t.cols;
+  if (s->corner[0] < 0 || s->corner[1] < 0 || s->corner[0] + R > d->pattern_rows ||
+      s->corner[1] + C > d->pattern_cols) { env->error |= OX_ERR_INDEX; return; }
+  for (int r = 0; r < R; ++r)
+    memcpy(s->curtain + r * C,
+           s->pattern + (size_t)(s->corner[0] + r) * d->pattern_cols + s->corner[1], C);
+}
+
+/* drapes.py:378-411 pattern_position_prescroll */
+static void sc_pattern_position_prescroll(ox_env* env, int di, int vr, int vc, int out[2]) {
+  ox_drape* s = &env->drapes[di];
+  if (s->last_maybe_move_frame < env->plot.frame) { /* :407-408 */
+    s->prescroll[0] = s->corner[0];
+    s->prescroll[1] = s->corner[1];
+  }
+  out[0] = vr + s->prescroll[0];
+  out[1] = vc + s->prescroll[1];
+}
+
+/* drapes.py:661-687 _sprite_burrows_into_a_margin */
+static void sc_burrows(const pcxo_engine* e, const pcx_drape_desc* d, const ox_sprite* sp,
+                       int dr, int dc, int* vert, int* horiz) {
+  int margin_north = d->margin_rows - 1;            /* :355 */
+  int margin_south = e->t.rows - d->margin_rows;    /* :356 */
+  int margin_west = d->margin_cols - 1;             /* :357 */
+  int margin_east = e->t.cols - d->margin_cols;     /* :358 */
+  int old_r = sp->row, old_c = sp->col, new_r = old_r + dr, new_c = old_c + dc;
+  *vert = (old_r > new_r && new_r <= margin_north) || (old_r < new_r && new_r >= margin_south);
+  *horiz = (old_c > new_c && new_c <= margin_west) || (old_c < new_c && new_c >= margin_east);
+}
+
+/* drapes.py:487-659 _maybe_move */
+static void sc_maybe_move(const pcxo_engine* e, ox_env* env, int di, int dr, int dc) {
+  const pcx_drape_desc* d = &e->t.drapes[di];
+  ox_drape* s = &env->drapes[di];
+  ox_plot* p = &env->plot;
+  int limit[2] = {d->pattern_rows - e->t.rows, d->pattern_cols - e->t.cols}; /* :342-343 */
+
+  if (s->last_maybe_move_frame < p->frame) { /* :515-517 */
+    s->last_maybe_move_frame = p->frame;
+    s->prescroll[0] = s->corner[0];
+    s->prescroll[1] = s->corner[1];
+  }
+  int order[2];
+  if (scroll_get_order(p, order)) { /* :523-535 (a non-None tuple is truthy) */
+    if (dr != order[0] && dc != order[1]) { env->error |= OX_ERR_SCROLL; return; }
+    s->corner[0] += order[0];
+    s->corner[1] += order[1];
+    sc_update_curtain(e, env, di);
+    return;
+  }
+  if (dr == 0 && dc == 0) { sc_update_curtain(e, env, di); return; } /* :539-541 */
+
+  if (!d->have_margins) { /* case 1 :551-585 */
+    if (scroll_is_possible(p, dr, dc)) {
+      int north = s->corner[0] + dr, west = s->corner[1] + dc;
+      int can_v = 0 <= north && north <= limit[0];
+      int can_h = 0 <= west && west <= limit[1];
+      int o0 = can_v ? dr : 0, o1 = can_h ? dc : 0;
+      s->corner[0] += o0;
+      s->corner[1] += o1;
+      env->error |= scroll_order(p, o0, o1);
+    }
+    sc_update_curtain(e, env, di);
+    return;
+  }
+  /* case 2 :592-659 */
+  int vert = 0, horiz = 0;
+  for (int id = 0; id < PCX_MAX_SPRITES; ++id) { /* only Sprites count :611 */
+    if (!(p->egocentrists & (1u << id))) continue;
+    int v, h;
+    sc_burrows(e, d, &env->sprites[id], dr, dc, &v, &h);
+    vert |= v;
+    horiz |= h;
+  }
+  if (!(vert || horiz)) { sc_update_curtain(e, env, di); return; } /* :620-623 */
+  int o0 = vert ? dr : 0, o1 = horiz ? dc : 0;
+  int pr = s->corner[0] + o0, pc = s->corner[1] + o1;
+  int can = 0 <= pr && pr <= limit[0];
+  can &= 0 <= pc && pc <= limit[1];
+  can &= scroll_is_possible(p, dr, dc); /* the *motion*, not the order :650-651 */
+  if (can) {
+    s->corner[0] = pr;
+    s->corner[1] = pc;
+    env->error |= scroll_order(p, o0, o1);
+  }
+  sc_update_curtain(e, env, di);
+}
+
+/* numpy 2-D indexing arr[r, c]: negative indices wrap once, else IndexError */
+static int np_index(int i, int n, int* err) {
+  if (i < 0) i += n;
+  if (i < 0 || i >= n) { *err |= OX_ERR_INDEX; return 0; }
+  return i;
+}
+
+/* ---- the nine motions ----------------------------------------------------- */
+/* Order used by PCX_PROG_WALKER / PCX_PROG_SCROLLY action tables:
+ * 0 N, 1 NE, 2 E, 3 SE, 4 S, 5 SW, 6 W, 7 NW, 8 STAY */
+static const int MOTION9[9][2] = {{-1, 0}, {-1, 1}, {0, 1}, {1, 1}, {1, 0},
+                                  {1, -1}, {0, -1}, {-1, -1}, {0, 0}};
+
+/* ---- entity programs ------------------------------------------------------- */
+
+typedef struct {
+  pcxo_engine* e;
+  ox_env* env;
+  int64_t b;
+  int action;
+  const uint8_t* board;  /* last repaint */
+} ox_ctx;
+
+/* examples/scrolly_maze.py:259-271 PlayerSprite.update and :317-329
+ * MazeDrape.update share this action table (0 N, 1 S, 2 W, 3 E, 4 stay). */
+static int sm_motion(int action, int m[2]) {
+  static const int T[5][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}, {0, 0}};
+  if (action < 0 || action > 4) return 0;
+  m[0] = T[action][0];
+  m[1] = T[action][1];
+  return 1;
+}
+
+static void prog_sm_player(ox_ctx* x, int id) {
+  int m[2];
+  if (sm_motion(x->action, m)) mw_move(x->e, x->env, id, x->board, m[0], m[1]);
+}
+
+/* examples/scrolly_maze.py:284-305 PatrollerSprite.update */
+static void prog_sm_patroller(ox_ctx* x, int id) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_sprite* s = &env->sprites[id];
+  if (env->plot.frame % 2) { /* :288-290 (Python %, frame >= 0) */
+    mw_move(e, env, id, x->board, 0, 0);
+    return;
+  }
+  int walls = thing_id(e, '#') - PCX_MAX_SPRITES;
+  int pp[2];
+  sc_pattern_position_prescroll(env, walls, s->vrow, s->vcol, pp); /* :295-296 */
+  const pcx_drape_desc* wd = &e->t.drapes[walls];
+  int r = np_index(pp[0], wd->pattern_rows, &env->error);
+  int c = np_index(pp[1] + (s->var[0] ? 1 : -1), wd->pattern_cols, &env->error);
+  if (env->drapes[walls].pattern[(size_t)r * wd->pattern_cols + c]) s->var[0] = !s->var[0]; /* :297-299 */
+  mw_move(e, env, id, x->board, 0, s->var[0] ? 1 : -1); /* :303 */
+  const ox_sprite* P = &env->sprites[thing_id(e, 'P')];
+  if (s->vrow == P->vrow && s->vcol == P->vcol) plot_terminate(&env->plot, 0.0f); /* :304-305 */
+}
+
+static void prog_sm_maze(ox_ctx* x, int di) {
+  int m[2];
+  if (sm_motion(x->action, m)) sc_maybe_move(x->e, x->env, di, m[0], m[1]);
+}
+
+/* examples/scrolly_maze.py:341-364 CashDrape.update */
+static void prog_sm_cash(ox_ctx* x, int di) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  const pcx_drape_desc* d = &e->t.drapes[di];
+  ox_drape* s = &env->drapes[di];
+  const ox_sprite* P = &env->sprites[thing_id(e, 'P')];
+  int pp[2];
+  sc_pattern_position_prescroll(env, di, P->row, P->col, pp); /* :344-345 */
+  int r = np_index(pp[0], d->pattern_rows, &env->error);
+  int c = np_index(pp[1], d->pattern_cols, &env->error);
+  uint8_t* cell = &s->pattern[(size_t)r * d->pattern_cols + c];
+  if (*cell) { /* :347-351 */
+    plot_add_reward(&env->plot, 100);
+    *cell = 0;
+    int any = 0;
+    for (size_t i = 0; i < (size_t)d->pattern_rows * d->pattern_cols; ++i) any |= s->pattern[i];
+    if (!any) plot_terminate(&env->plot, 0.0f);
+  }
+  int m[2];
+  if (sm_motion(x->action, m)) sc_maybe_move(e, env, di, m[0], m[1]);
+  else if (x->action == 5) plot_terminate(&env->plot, 0.0f); /* :363-364 */
+}
+
+/* prefab-only entities: per-entity action = (action >> param[0]) & param[1]
+ * when param[1] != 0 (packed multi-agent actions), else the action itself;
+ * values 0..8 index MOTION9, anything else does nothing.  Restates the test
+ * entities of tests/test_things.py:203-295 with integer actions. */
+static int walker_action(int action, const int32_t* param) {
+  if (action < 0) return -1;
+  return param[1] ? (action >> param[0]) & param[1] : action;
+}
+static void prog_walker(ox_ctx* x, int id) {
+  int a = walker_action(x->action, x->e->t.sprites[id].param);
+  if (a >= 0 && a < 9) {
+    int blocked = mw_move(x->e, x->env, id, x->board, MOTION9[a][0], MOTION9[a][1]);
+    x->env->sprites[id].var[0] = blocked; /* the_plot['walk_result_X'] truthiness */
+  }
+}
+static void prog_scrolly(ox_ctx* x, int di) {
+  int a = walker_action(x->action, x->e->t.drapes[di].param);
+  if (a >= 0 && a < 9) sc_maybe_move(x->e, x->env, di, MOTION9[a][0], MOTION9[a][1]);
+}
+
+static int run_program(ox_ctx* x, int id) {
+  pcxo_engine* e = x->e;
+  int prog = id < PCX_MAX_SPRITES ? e->t.sprites[id].program
+                                  : e->t.drapes[id - PCX_MAX_SPRITES].program;
+  int di = id - PCX_MAX_SPRITES;
+  switch (prog) {
+    case PCX_PROG_SM_PLAYER: prog_sm_player(x, id); break;
+    case PCX_PROG_SM_PATROLLER: prog_sm_patroller(x, id); break;
+    case PCX_PROG_SM_MAZE: prog_sm_maze(x, di); break;
+    case PCX_PROG_SM_CASH: prog_sm_cash(x, di); break;
+    case PCX_PROG_WALKER: prog_walker(x, id); break;
+    case PCX_PROG_SCROLLY: prog_scrolly(x, di); break;
+    case PCX_PROG_STATIC: break;
+    default: return -1;
+  }
+  return 0;
+}
+
+/* ---- rendering.py ---------------------------------------------------------- */
+
+/* engine.py:737-759 _render with rendering.py:85-184 (occluded) or :187-301
+ * (unoccluded) */
+static void render(pcxo_engine* e, int64_t b) {
+  ox_env* env = &e->envs[b];
+  int n = cells(e), C = e->t.cols;
+  uint8_t* board = env_board(e, b);
+  memset(board, 0, n);           /* clear() */
+  memcpy(board, e->backdrop, n); /* paint_all_of */
+  int occl = e->t.occlusion_in_layers;
+  if (!occl) {
+    for (int k = 0; k < e->t.n_chars; ++k) { /* rendering.py:220-233 */
+      uint8_t* layer = env_layer(e, b, k);
+      for (int i = 0; i < n; ++i) layer[i] = e->backdrop[i] == e->t.chars[k];
+    }
+  }
+  for (int z = 0; z < e->t.n_things; ++z) { /* engine.py:751-757 */
+    int id = e->z_id[z];
+    if (id < PCX_MAX_SPRITES) {
+      const ox_sprite* s = &env->sprites[id];
+      if (!s->visible) continue;
+      board[s->row * C + s->col] = e->t.sprites[id].ch;
+      if (!occl) env_layer(e, b, char_index(e, e->t.sprites[id].ch))[s->row * C + s->col] = 1;
+    } else {
+      const ox_drape* d = &env->drapes[id - PCX_MAX_SPRITES];
+      uint8_t ch = e->t.drapes[id - PCX_MAX_SPRITES].ch;
+      for (int i = 0; i < n; ++i)
+        if (d->curtain[i]) board[i] = ch;
+      if (!occl) memcpy(env_layer(e, b, char_index(e, ch)), d->curtain, n);
+    }
+  }
+  if (occl) { /* rendering.py:177-179 */
+    for (int k = 0; k < e->t.n_chars; ++k) {
+      uint8_t* layer = env_layer(e, b, k);
+      for (int i = 0; i < n; ++i) layer[i] = board[i] == e->t.chars[k];
+    }
+  }
+}
+
+/* ---- engine.py -------------------------------------------------------------- */
+
+static void env_init(pcxo_engine* e, int64_t b) {
+  ox_env* env = &e->envs[b];
+  int n = cells(e);
+  for (int i = 0; i < e->t.n_sprites; ++i) {
+    const pcx_sprite_desc* d = &e->t.sprites[i];
+    ox_sprite* s = &env->sprites[i];
+    memset(s, 0, sizeof *s);
+    s->row = d->row; s->col = d->col; s->visible = d->visible;
+    s->vrow = d->vrow; s->vcol = d->vcol; s->prior_visible = d->prior_visible;
+    if (d->program == PCX_PROG_SM_PATROLLER) s->var[0] = d->ch % 2; /* scrolly_maze.py:282 */
+  }
+  for (int i = 0; i < e->t.n_drapes; ++i) {
+    const pcx_drape_desc* d = &e->t.drapes[i];
+    ox_drape* s = &env->drapes[i];
+    memcpy(s->curtain, e->init_curtain[i], n);
+    if (d->is_scrolly)
+      memcpy(s->pattern, e->init_pattern[i], (size_t)d->pattern_rows * d->pattern_cols);
+    s->corner[0] = s->prescroll[0] = d->corner_row;
+    s->corner[1] = s->prescroll[1] = d->corner_col;
+    s->last_maybe_move_frame = INT64_MIN; /* drapes.py:373 */
+    memset(s->var, 0, sizeof s->var);
+  }
+  memset(&env->plot, 0, sizeof env->plot);
+  env->plot.frame = -1;
+  plot_clear_directives(&env->plot);
+  env->game_over = 0;
+  env->error = 0;
+}
+
+static void publish(pcxo_engine* e, int64_t b) {
+  ox_env* env = &e->envs[b];
+  e->reward[b] = (int32_t)env->plot.reward;
+  e->reward_set[b] = (uint8_t)env->plot.reward_set;
+  e->discount[b] = env->plot.discount;
+  e->done[b] = (uint8_t)env->game_over;
+  e->frame[b] = env->plot.frame;
+  e->error[b] = (uint8_t)env->error;
+}
+
+/* engine.py:583-639 play (one environment) */
+static int env_play(pcxo_engine* e, int64_t b, int action) {
+  ox_env* env = &e->envs[b];
+  env->plot.frame += 1; /* :716 */
+  /* backdrop.update: base class no-op (things.py:146-147) */
+  ox_ctx x = {e, env, b, action, env_board(e, b)};
+  int i = 0;
+  for (int g = 0; g < e->t.n_groups; ++g) { /* :726 */
+    for (; i < e->t.n_things && e->t.group_of[i] == g; ++i)
+      if (run_program(&x, e->sched_id[i])) return fail(PCX_E_UNSUPPORTED, "oracle: entity program not implemented");
+    render(e, b); /* :735 */
+  }
+  /* _apply_and_clear_plot :761-847 (no z-order directives on this path) */
+  env->game_over = env->plot.game_over;
+  publish(e, b);
+  plot_clear_directives(&env->plot);
+  return 0;
+}
+
+/* engine.py:520-581 its_showtime (one environment) */
+static int env_showtime(pcxo_engine* e, int64_t b) {
+  env_init(e, b);
+  render(e, b);                          /* :578 */
+  return env_play(e, b, PCX_ACTION_NONE); /* :581 */
+}
+
+int pcxo_engine_create(const pcx_template* t, int64_t batch, pcxo_engine** out) {
+  if (!t || !out || batch <= 0) return fail(PCX_E_INVALID, "oracle: bad arguments");
+  if (t->abi_version != PCX_ABI_VERSION) return fail(PCX_E_INVALID, "oracle: ABI version mismatch");
+  pcxo_engine* e = (pcxo_engine*)calloc(1, sizeof *e);
+  e->t = *t;
+  e->batch = batch;
+  int n = t->rows * t->cols;
+  e->backdrop = (uint8_t*)malloc(n);
+  memcpy(e->backdrop, t->backdrop, n);
+  e->t.backdrop = e->backdrop;
+  for (int i = 0; i < t->n_drapes; ++i) {
+    const pcx_drape_desc* d = &t->drapes[i];
+    e->init_curtain[i] = (uint8_t*)malloc(n);
+    memcpy(e->init_curtain[i], d->curtain, n);
+    e->t.drapes[i].curtain = e->init_curtain[i];
+    if (d->is_scrolly) {
+      size_t pn = (size_t)d->pattern_rows * d->pattern_cols;
+      e->init_pattern[i] = (uint8_t*)malloc(pn);
+      memcpy(e->init_pattern[i], d->pattern, pn);
+      e->t.drapes[i].pattern = e->init_pattern[i];
+    }
+  }
+  for (int z = 0; z < t->n_things; ++z) {
+    e->z_id[z] = thing_id(e, t->z_order[z]);
+    e->sched_id[z] = thing_id(e, t->schedule[z]);
+    if (e->z_id[z] < 0 || e->sched_id[z] < 0) { pcxo_engine_destroy(e); return fail(PCX_E_INVALID, "oracle: z_order/schedule names an unknown character"); }
+  }
+  e->envs = (ox_env*)calloc((size_t)batch, sizeof(ox_env));
+  for (int64_t b = 0; b < batch; ++b)
+    for (int i = 0; i < t->n_drapes; ++i) {
+      e->envs[b].drapes[i].curtain = (uint8_t*)malloc(n);
+      if (t->drapes[i].is_scrolly)
+        e->envs[b].drapes[i].pattern = (uint8_t*)malloc((size_t)t->drapes[i].pattern_rows * t->drapes[i].pattern_cols);
+    }
+  e->planes = (uint8_t*)calloc((size_t)batch * (1 + t->n_chars), n);
+  e->reward = (int32_t*)calloc((size_t)batch, sizeof(int32_t));
+  e->reward_set = (uint8_t*)calloc((size_t)batch, 1);
+  e->discount = (float*)calloc((size_t)batch, sizeof(float));
+  e->done = (uint8_t*)calloc((size_t)batch, 1);
+  e->frame = (int32_t*)calloc((size_t)batch, sizeof(int32_t));
+  e->error = (uint8_t*)calloc((size_t)batch, 1);
+  *out = e;
+  return 0;
+}
+
+void pcxo_engine_destroy(pcxo_engine* e) {
+  if (!e) return;
+  if (e->envs) {
+    for (int64_t b = 0; b < e->batch; ++b)
+      for (int i = 0; i < PCX_MAX_DRAPES; ++i) {
+        free(e->envs[b].drapes[i].curtain);
+        free(e->envs[b].drapes[i].pattern);
+      }
+    free(e->envs);
+  }
+  for (int i = 0; i < PCX_MAX_DRAPES; ++i) { free(e->init_curtain[i]); free(e->init_pattern[i]); }
+  free(e->backdrop); free(e->planes); free(e->reward); free(e->reward_set);
+  free(e->discount); free(e->done); free(e->frame); free(e->error);
+  free(e);
+}
+
+int pcxo_engine_reset(pcxo_engine* e, const uint8_t* env_mask) {
+  for (int64_t b = 0; b < e->batch; ++b)
+    if (!env_mask || env_mask[b]) {
+      int rc = env_showtime(e, b);
+      if (rc) return rc;
+    }
+  e->showtime = 1;
+  return 0;
+}
+
+int pcxo_engine_step(pcxo_engine* e, const int32_t* actions, int auto_reset) {
+  if (!e->showtime) return fail(PCX_E_STATE, "oracle: step before reset");
+  for (int64_t b = 0; b < e->batch; ++b) {
+    ox_env* env = &e->envs[b];
+    int rc = 0;
+    if (env->game_over) {
+      if (auto_reset) rc = env_showtime(e, b);
+      /* else: frozen -- the reference would raise (engine.py:622-624) */
+    } else {
+      rc = env_play(e, b, actions[b]);
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int pcxo_engine_step_hashed(pcxo_engine* e, uint64_t seed, int64_t env_offset,
+                            int64_t t0, int T, int auto_reset) {
+  if (!e->showtime) return fail(PCX_E_STATE, "oracle: step before reset");
+  int n = e->t.n_actions;
+  for (int t = 0; t < T; ++t)
+    for (int64_t b = 0; b < e->batch; ++b) {
+      ox_env* env = &e->envs[b];
+      int rc = 0;
+      if (env->game_over) { if (auto_reset) rc = env_showtime(e, b); }
+      else rc = env_play(e, b, (int)(pcxo_action_hash(seed, (uint64_t)(env_offset + b), (uint64_t)(t0 + t)) % (uint32_t)n));
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+int pcxo_engine_buffers(pcxo_engine* e, pcx_buffers* out) {
+  out->batch = e->batch;
+  out->rows = e->t.rows; out->cols = e->t.cols; out->n_chars = e->t.n_chars;
+  out->planes = e->planes; out->reward = e->reward; out->reward_set = e->reward_set;
+  out->discount = e->discount; out->done = e->done; out->frame = e->frame; out->error = e->error;
+  return 0;
+}
+
+int pcxo_engine_read_things(pcxo_engine* e, int64_t env0, int64_t n,
+                            pcx_sprite_state* sprites, uint8_t* curtains) {
+  if (env0 < 0 || env0 + n > e->batch) return fail(PCX_E_INVALID, "oracle: env range");
+  int nc = cells(e);
+  for (int64_t i = 0; i < n; ++i) {
+    const ox_env* env = &e->envs[env0 + i];
+    if (sprites)
+      for (int s = 0; s < e->t.n_sprites; ++s) {
+        pcx_sprite_state* o = &sprites[i * e->t.n_sprites + s];
+        memset(o, 0, sizeof *o);
+        o->row = env->sprites[s].row; o->col = env->sprites[s].col;
+        o->vrow = env->sprites[s].vrow; o->vcol = env->sprites[s].vcol;
+        o->visible = (uint8_t)env->sprites[s].visible;
+      }
+    if (curtains)
+      for (int d = 0; d < e->t.n_drapes; ++d)
+        memcpy(curtains + ((size_t)i * e->t.n_drapes + d) * nc, env->drapes[d].curtain, nc);
+  }
+  return 0;
+}
+
+/* ---- croppers: see pcx_oracle_crop.c --------------------------------------- */

@@ -1,0 +1,166 @@
+"""ctypes mirror of `include/pcx.h` and the loader of `csrc/libpcx.so`.
+
+The shared library is the product: if it is missing this module raises, there
+is no CPU fallback behind it.
+"""
+
+import ctypes
+import os
+
+c_u8, c_i32, c_i64, c_u32, c_u64 = (ctypes.c_uint8, ctypes.c_int32,
+                                    ctypes.c_int64, ctypes.c_uint32,
+                                    ctypes.c_uint64)
+c_u8_p = ctypes.POINTER(ctypes.c_uint8)
+
+ABI_VERSION = 1
+MAX_CHARS = 32
+MAX_SPRITES = 16
+MAX_DRAPES = 8
+MAX_THINGS = MAX_SPRITES + MAX_DRAPES
+ACTION_NONE = -1
+
+OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_STATE = 0, -1, -2, -3, -4
+
+GAME_SCROLLY_MAZE, GAME_MARAUDERS, GAME_WAREHOUSE, GAME_HELLO_WORLD, GAME_WALKERS = 1, 2, 3, 4, 5
+
+PROG_NONE = 0
+PROG_SM_PLAYER, PROG_SM_PATROLLER, PROG_SM_MAZE, PROG_SM_CASH = 10, 11, 12, 13
+PROG_EM_PLAYER, PROG_EM_BUNKER, PROG_EM_MARAUDER, PROG_EM_UPBOLT, PROG_EM_DOWNBOLT = 20, 21, 22, 23, 24
+PROG_WM_BOX, PROG_WM_JUDGE, PROG_WM_PLAYER = 30, 31, 32
+PROG_HW_ROLLING, PROG_HW_SLIDING = 40, 41
+PROG_WALKER, PROG_SCROLLY, PROG_STATIC = 50, 51, 52
+
+CROP_FIXED, CROP_SCROLLING = 1, 2
+
+
+class SpriteDesc(ctypes.Structure):
+  _fields_ = [('ch', c_u8), ('is_walker', c_u8), ('visible', c_u8),
+              ('prior_visible', c_u8), ('confined', c_u8), ('egocentric', c_u8),
+              ('pad0', c_u8 * 2), ('program', c_i32),
+              ('row', c_i32), ('col', c_i32), ('vrow', c_i32), ('vcol', c_i32),
+              ('impassable', c_u8 * 16), ('param', c_i32 * 4)]
+
+
+class DrapeDesc(ctypes.Structure):
+  _fields_ = [('ch', c_u8), ('is_scrolly', c_u8), ('have_margins', c_u8),
+              ('pad0', c_u8), ('program', c_i32),
+              ('curtain', c_u8_p), ('pattern', c_u8_p),
+              ('pattern_rows', c_i32), ('pattern_cols', c_i32),
+              ('corner_row', c_i32), ('corner_col', c_i32),
+              ('margin_rows', c_i32), ('margin_cols', c_i32),
+              ('param', c_i32 * 4)]
+
+
+class Template(ctypes.Structure):
+  _fields_ = [('abi_version', c_u32), ('game', c_i32),
+              ('rows', c_i32), ('cols', c_i32),
+              ('occlusion_in_layers', c_i32),
+              ('n_chars', c_i32), ('chars', c_u8 * MAX_CHARS),
+              ('backdrop', c_u8_p),
+              ('n_sprites', c_i32), ('sprites', SpriteDesc * MAX_SPRITES),
+              ('n_drapes', c_i32), ('drapes', DrapeDesc * MAX_DRAPES),
+              ('n_things', c_i32),
+              ('z_order', c_u8 * MAX_THINGS), ('schedule', c_u8 * MAX_THINGS),
+              ('group_of', c_u8 * MAX_THINGS),
+              ('n_groups', c_i32), ('n_actions', c_i32),
+              ('param', c_i32 * 8)]
+
+
+class Buffers(ctypes.Structure):
+  _fields_ = [('batch', c_i64), ('rows', c_i32), ('cols', c_i32),
+              ('n_chars', c_i32),
+              ('planes', ctypes.c_void_p), ('reward', ctypes.c_void_p),
+              ('reward_set', ctypes.c_void_p), ('discount', ctypes.c_void_p),
+              ('done', ctypes.c_void_p), ('frame', ctypes.c_void_p),
+              ('error', ctypes.c_void_p)]
+
+
+class SpriteState(ctypes.Structure):
+  _fields_ = [('row', c_i32), ('col', c_i32), ('vrow', c_i32), ('vcol', c_i32),
+              ('visible', c_u8), ('pad', c_u8 * 3)]
+
+
+class CropperDesc(ctypes.Structure):
+  _fields_ = [('kind', c_i32), ('rows', c_i32), ('cols', c_i32),
+              ('top', c_i32), ('left', c_i32), ('pad_char', c_i32),
+              ('n_track', c_i32), ('to_track', c_u8 * MAX_THINGS),
+              ('margin_rows', c_i32), ('margin_cols', c_i32),
+              ('initial_offset_rows', c_i32), ('initial_offset_cols', c_i32),
+              ('saccade', c_i32)]
+
+
+# Every symbol include/pcx.h declares: (name, restype, argtypes).
+_VP = ctypes.c_void_p
+SYMBOLS = [
+    ('pcx_engine_create', c_i32, [ctypes.POINTER(Template), c_i64, c_i32, ctypes.POINTER(_VP)]),
+    ('pcx_engine_destroy', None, [_VP]),
+    ('pcx_engine_reset', c_i32, [_VP, _VP, _VP]),
+    ('pcx_engine_step', c_i32, [_VP, _VP, c_i32, _VP]),
+    ('pcx_engine_step_n', c_i32, [_VP, _VP, c_i32, c_i32, _VP]),
+    ('pcx_engine_step_hashed', c_i32, [_VP, c_u64, c_i64, c_i64, c_i32, c_i32, _VP]),
+    ('pcx_engine_buffers', c_i32, [_VP, ctypes.POINTER(Buffers)]),
+    ('pcx_engine_bind_buffers', c_i32, [_VP, ctypes.POINTER(Buffers)]),
+    ('pcx_engine_read_things', c_i32, [_VP, c_i64, c_i64, _VP, _VP]),
+    ('pcx_memcpy_d2h', c_i32, [_VP, _VP, c_u64]),
+    ('pcx_memcpy_h2d', c_i32, [_VP, _VP, c_u64]),
+    ('pcx_device_malloc', c_i32, [ctypes.POINTER(_VP), c_u64]),
+    ('pcx_device_free', c_i32, [_VP]),
+    ('pcx_stream_synchronize', c_i32, [_VP]),
+    ('pcx_action_hash', c_u32, [c_u64, c_u64, c_u64]),
+    ('pcx_engine_bytes_per_step', c_i64, [_VP]),
+    ('pcx_engine_kernel_name', ctypes.c_char_p, [_VP]),
+    ('pcx_last_error', ctypes.c_char_p, []),
+    ('pcx_abi_version', c_u32, []),
+    ('pcx_cropper_create', c_i32, [_VP, ctypes.POINTER(CropperDesc), ctypes.POINTER(_VP)]),
+    ('pcx_cropper_destroy', None, [_VP]),
+    ('pcx_cropper_crop', c_i32, [_VP, _VP]),
+    ('pcx_cropper_buffers', c_i32, [_VP, ctypes.POINTER(_VP), ctypes.POINTER(_VP)]),
+]
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpcx.so')
+
+
+class NativeLibraryMissing(RuntimeError):
+  pass
+
+
+def bind(lib, symbols, rename=None):
+  """Attach restype/argtypes for every (name, restype, argtypes) entry."""
+  for name, restype, argtypes in symbols:
+    real = rename(name) if rename else name
+    fn = getattr(lib, real)  # AttributeError if the symbol is missing
+    fn.restype = restype
+    fn.argtypes = argtypes
+  return lib
+
+
+_lib = None
+
+
+def lib():
+  """The HIP engine library; raises loudly when it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise NativeLibraryMissing(
+          '{} is missing: build it with `python __graft_entry__.py build` (or '
+          '`make -C pycolab_amd/csrc`). pycolab_amd has no CPU fallback.'.format(
+              LIB_PATH))
+    _lib = bind(ctypes.CDLL(LIB_PATH), SYMBOLS)
+    if _lib.pcx_abi_version() != ABI_VERSION:
+      raise NativeLibraryMissing('libpcx.so ABI version mismatch; rebuild it')
+  return _lib
+
+
+class PcxError(RuntimeError):
+  pass
+
+
+def check(code):
+  if code != 0:
+    message = lib().pcx_last_error().decode('utf-8', 'replace')
+    if code == E_UNSUPPORTED:
+      raise NotImplementedError(message)
+    if code == E_INVALID:
+      raise ValueError(message)
+    raise PcxError('pcx error {}: {}'.format(code, message))

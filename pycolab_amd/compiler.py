@@ -1,0 +1,235 @@
+"""Template compiler: a constructed game -> plain data for the HIP engine.
+
+`GameTemplate` is the host image of `pcx_template` (include/pcx.h): what the
+constructors of the user's Sprite/Drape/Backdrop classes left behind
+(reference: ascii_art.py:243-289, engine.py:248-518), plus the device program
+chosen for each entity.  It round-trips through `.npz` so that benchmark and
+GPU tests can run where the game files themselves are absent.
+"""
+
+import ctypes
+import json
+
+import numpy as np
+
+from pycolab_amd import _native as N
+from pycolab_amd import programs
+from pycolab_amd import things
+from pycolab_amd.prefab_parts import drapes as prefab_drapes
+from pycolab_amd.prefab_parts import sprites as prefab_sprites
+
+
+def _impassable_bits(chars):
+  bits = bytearray(16)
+  for ch in chars:
+    o = ord(ch)
+    if o > 127:
+      raise ValueError('impassable characters must be ASCII')
+    bits[o >> 3] |= 1 << (o & 7)
+  return bytes(bits)
+
+
+class GameTemplate(object):
+  """Plain-data image of a built (not yet started) game."""
+
+  def __init__(self):
+    self.game = 0
+    self.rows = self.cols = 0
+    self.occlusion_in_layers = True
+    self.chars = b''            # sorted characters = layer plane order
+    self.backdrop = None        # uint8 [rows, cols]
+    self.sprites = []           # dicts, engine insertion order
+    self.drapes = []            # dicts
+    self.z_order = b''
+    self.schedule = b''
+    self.group_of = []
+    self.n_groups = 0
+    self.n_actions = 0
+    self.param = [0] * 8
+
+  # -- construction from a host Engine ---------------------------------------
+  @classmethod
+  def from_engine(cls, eng):
+    t = cls()
+    t.rows, t.cols = eng.rows, eng.cols
+    t.occlusion_in_layers = bool(eng._occlusion_in_layers)
+    if eng.backdrop is None:
+      raise RuntimeError('an Engine needs a Backdrop before its_showtime()')
+    t.backdrop = np.ascontiguousarray(eng.backdrop.curtain, dtype=np.uint8)
+    chars = set(eng._sprites_and_drapes.keys()).union(eng.backdrop.palette)
+    t.chars = bytes(sorted(ord(c) for c in chars))
+    if len(t.chars) > N.MAX_CHARS:
+      raise ValueError('at most {} distinct characters'.format(N.MAX_CHARS))
+    progs = [programs.resolve(eng.backdrop)]
+    if progs[0] != N.PROG_STATIC:
+      raise programs.UnsupportedEntityError('only static Backdrops are supported')
+    for ch, ent in eng._sprites_and_drapes.items():
+      prog = programs.resolve(ent)
+      progs.append(prog)
+      if isinstance(ent, things.Sprite):
+        walker = isinstance(ent, prefab_sprites.MazeWalker)
+        pos = ent.position
+        vpos = ent.virtual_position if walker else pos
+        t.sprites.append(dict(
+            ch=ord(ch), is_walker=int(walker), visible=int(bool(ent.visible)),
+            prior_visible=int(bool(getattr(ent, '_prior_visible', None))),
+            confined=int(bool(getattr(ent, '_confined_to_board', False))),
+            egocentric=int(bool(getattr(ent, '_egocentric_scroller', False))),
+            program=prog, row=int(pos[0]), col=int(pos[1]),
+            vrow=int(vpos[0]), vcol=int(vpos[1]),
+            impassable=_impassable_bits(getattr(ent, '_impassable', ())),
+            param=[int(v) for v in getattr(ent, 'pcx_param', (0, 0, 0, 0))]))
+        if getattr(ent, '_scrolling_group', '') != '':
+          raise programs.UnsupportedEntityError('only the default scrolling group is supported')
+      else:
+        scrolly = isinstance(ent, prefab_drapes.Scrolly)
+        d = dict(ch=ord(ch), is_scrolly=int(scrolly), have_margins=0, program=prog,
+                 curtain=np.ascontiguousarray(ent.curtain, dtype=np.uint8),
+                 pattern=None, corner=(0, 0), margins=(0, 0),
+                 param=[int(v) for v in getattr(ent, 'pcx_param', (0, 0, 0, 0))])
+        if scrolly:
+          d['pattern'] = np.ascontiguousarray(ent.whole_pattern, dtype=np.uint8)
+          d['corner'] = (int(ent._northwest_corner[0]), int(ent._northwest_corner[1]))
+          d['have_margins'] = int(ent._have_margins)
+          if ent._have_margins:
+            d['margins'] = (int(ent._scroll_margins[0]), int(ent._scroll_margins[1]))
+          if ent._scrolling_group != '':
+            raise programs.UnsupportedEntityError('only the default scrolling group is supported')
+        t.drapes.append(d)
+    if len(t.sprites) > N.MAX_SPRITES or len(t.drapes) > N.MAX_DRAPES:
+      raise ValueError('too many sprites or drapes for the device engine')
+    t.z_order = bytes(ord(c) for c in eng._sprites_and_drapes.keys())
+    sched, group_of = [], []
+    for gi, (_, entities) in enumerate(eng._frozen_update_groups()):
+      for ent in entities:
+        sched.append(ord(ent.character))
+        group_of.append(gi)
+      t.n_groups = gi + 1
+    t.schedule = bytes(sched)
+    t.group_of = group_of
+    t.game = programs.infer_game(progs)
+    t.n_actions = programs.N_ACTIONS[t.game]
+    return t
+
+  # -- (de)serialisation -------------------------------------------------------
+  def save(self, path):
+    meta = dict(game=self.game, rows=self.rows, cols=self.cols,
+                occlusion_in_layers=self.occlusion_in_layers,
+                chars=list(self.chars), z_order=list(self.z_order),
+                schedule=list(self.schedule), group_of=list(self.group_of),
+                n_groups=self.n_groups, n_actions=self.n_actions,
+                param=list(self.param), sprites=[], drapes=[])
+    arrays = {'backdrop': self.backdrop}
+    for s in self.sprites:
+      m = dict(s)
+      m['impassable'] = list(s['impassable'])
+      meta['sprites'].append(m)
+    for i, d in enumerate(self.drapes):
+      m = {k: v for k, v in d.items() if k not in ('curtain', 'pattern')}
+      m['has_pattern'] = d['pattern'] is not None
+      meta['drapes'].append(m)
+      arrays['curtain_%d' % i] = np.packbits(d['curtain'].astype(bool))
+      if d['pattern'] is not None:
+        arrays['pattern_%d' % i] = np.packbits(d['pattern'].astype(bool))
+        arrays['pattern_shape_%d' % i] = np.array(d['pattern'].shape, np.int32)
+    arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(path, **arrays)
+
+  @classmethod
+  def load(cls, path):
+    z = np.load(path)
+    meta = json.loads(bytes(z['meta']).decode())
+    t = cls()
+    t.game, t.rows, t.cols = meta['game'], meta['rows'], meta['cols']
+    t.occlusion_in_layers = meta['occlusion_in_layers']
+    t.chars = bytes(meta['chars'])
+    t.z_order, t.schedule = bytes(meta['z_order']), bytes(meta['schedule'])
+    t.group_of, t.n_groups = meta['group_of'], meta['n_groups']
+    t.n_actions, t.param = meta['n_actions'], meta['param']
+    t.backdrop = np.ascontiguousarray(z['backdrop'], dtype=np.uint8)
+    n = t.rows * t.cols
+    for s in meta['sprites']:
+      s = dict(s)
+      s['impassable'] = bytes(s['impassable'])
+      t.sprites.append(s)
+    for i, d in enumerate(meta['drapes']):
+      d = dict(d)
+      has_pattern = d.pop('has_pattern')
+      d['corner'], d['margins'] = tuple(d['corner']), tuple(d['margins'])
+      d['curtain'] = np.unpackbits(z['curtain_%d' % i])[:n].reshape(t.rows, t.cols).astype(np.uint8)
+      d['pattern'] = None
+      if has_pattern:
+        shape = tuple(int(v) for v in z['pattern_shape_%d' % i])
+        d['pattern'] = np.unpackbits(z['pattern_%d' % i])[:shape[0] * shape[1]].reshape(shape).astype(np.uint8)
+      t.drapes.append(d)
+    return t
+
+  def __eq__(self, other):
+    if not isinstance(other, GameTemplate):
+      return NotImplemented
+    def norm(t):
+      return (t.game, t.rows, t.cols, bool(t.occlusion_in_layers), t.chars,
+              t.backdrop.tobytes(), t.z_order, t.schedule, list(t.group_of),
+              t.n_groups, t.n_actions, list(t.param),
+              [sorted((k, (v if not isinstance(v, (list, tuple)) else tuple(v)))
+                      for k, v in s.items()) for s in t.sprites],
+              [sorted((k, (v.tobytes() if isinstance(v, np.ndarray) else
+                           (tuple(v) if isinstance(v, (list, tuple)) else v)))
+                      for k, v in d.items()) for d in t.drapes])
+    return norm(self) == norm(other)
+
+  def thing_chars(self):
+    return [chr(c) for c in self.z_order]
+
+  # -- ctypes image --------------------------------------------------------------
+  def to_ctypes(self):
+    """Returns (Template, keepalive) -- keepalive owns the pointed-to arrays."""
+    keep = []
+
+    def ptr(arr):
+      arr = np.ascontiguousarray(arr, dtype=np.uint8)
+      keep.append(arr)
+      return arr.ctypes.data_as(N.c_u8_p)
+
+    ct = N.Template()
+    ct.abi_version = N.ABI_VERSION
+    ct.game = self.game
+    ct.rows, ct.cols = self.rows, self.cols
+    ct.occlusion_in_layers = int(bool(self.occlusion_in_layers))
+    ct.n_chars = len(self.chars)
+    for i, c in enumerate(self.chars):
+      ct.chars[i] = c
+    ct.backdrop = ptr(self.backdrop)
+    ct.n_sprites = len(self.sprites)
+    for i, s in enumerate(self.sprites):
+      cs = ct.sprites[i]
+      for k in ('ch', 'is_walker', 'visible', 'prior_visible', 'confined',
+                'egocentric', 'program', 'row', 'col', 'vrow', 'vcol'):
+        setattr(cs, k, s[k])
+      for j, b in enumerate(s['impassable']):
+        cs.impassable[j] = b
+      for j, v in enumerate(s['param']):
+        cs.param[j] = v
+    ct.n_drapes = len(self.drapes)
+    for i, d in enumerate(self.drapes):
+      cd = ct.drapes[i]
+      cd.ch, cd.is_scrolly, cd.have_margins = d['ch'], d['is_scrolly'], d['have_margins']
+      cd.program = d['program']
+      cd.curtain = ptr(d['curtain'])
+      if d['pattern'] is not None:
+        cd.pattern = ptr(d['pattern'])
+        cd.pattern_rows, cd.pattern_cols = d['pattern'].shape
+      cd.corner_row, cd.corner_col = d['corner']
+      cd.margin_rows, cd.margin_cols = d['margins']
+      for j, v in enumerate(d['param']):
+        cd.param[j] = v
+    ct.n_things = len(self.z_order)
+    for i in range(ct.n_things):
+      ct.z_order[i] = self.z_order[i]
+      ct.schedule[i] = self.schedule[i]
+      ct.group_of[i] = self.group_of[i]
+    ct.n_groups = self.n_groups
+    ct.n_actions = self.n_actions
+    for i, v in enumerate(self.param):
+      ct.param[i] = v
+    return ct, keep

@@ -1,0 +1,500 @@
+"""The batched game engine facade.
+
+Public surface of the reference's `pycolab/engine.py:38-986` (`Engine`,
+`Palette`): the same builder methods, `its_showtime()`, `play()`, and
+properties.  What differs is where the step runs: `its_showtime()` compiles
+the built game into a plain-data template (`pycolab_amd.compiler`), creates a
+HIP engine for `batch` environments through the C ABI (`include/pcx.h`), and
+every `play()` is one launch of the fused step kernel over the whole batch.
+
+Batch semantics.  `configure(batch=B)` selects how many independent copies of
+the game are stepped together (default 1).  With `batch == 1` the return
+values have exactly the reference's types and shapes.  With `batch > 1`
+`Observation.board` is [B, rows, cols], each layer is [B, rows, cols], reward
+is an int32 array [B] (0 where the reference would return `None`; see
+`Engine.reward_set`), discount is a float32 array [B]; all are device tensors
+when PyTorch-ROCm is available, NumPy arrays otherwise.
+"""
+
+import collections
+import ctypes
+
+import numpy as np
+
+from pycolab_amd import _native as N
+from pycolab_amd import compiler
+from pycolab_amd import device as dev
+from pycolab_amd import plot
+from pycolab_amd import rendering
+from pycolab_amd import things
+
+
+class Engine(object):
+  """One game template stepped as `batch` independent environments on a GPU."""
+
+  def __init__(self, rows, cols, occlusion_in_layers=True):
+    self._rows = rows
+    self._cols = cols
+    self._occlusion_in_layers = occlusion_in_layers
+    self._the_plot = plot.Plot(self)
+    self._showtime = False
+    self._backdrop = None
+    self._sprites_and_drapes = collections.OrderedDict()  # z-order, back to front
+    self._update_groups = collections.defaultdict(list)
+    self._current_update_group = ''
+    # batched runtime
+    self._batch = 1
+    self._device_id = 0
+    self._auto_reset = False
+    self._template = None
+    self._native = None
+    self._keepalive = None
+    self._bufs = None
+    self._actions = None
+
+  # ---------------------------------------------------------------- builder API
+  def set_backdrop(self, characters, backdrop_class, *args, **kwargs):
+    """engine.py:248-279."""
+    return self.set_prefilled_backdrop(
+        characters, np.zeros((self._rows, self._cols), dtype=np.uint8),
+        backdrop_class, *args, **kwargs)
+
+  def set_prefilled_backdrop(self, characters, prefill, backdrop_class,
+                             *args, **kwargs):
+    """engine.py:281-337."""
+    self._forbid_after_showtime('set_prefilled_backdrop')
+    self._require_good_characters(characters)
+    self._require_unclaimed(characters)
+    if self._backdrop:
+      raise RuntimeError('A backdrop of type {} has already been supplied to '
+                         'this Engine.'.format(type(self._backdrop)))
+    if not issubclass(backdrop_class, things.Backdrop):
+      raise TypeError('backdrop_class arguments to Engine.set_backdrop must '
+                      'either be a Backdrop class or one of its subclasses.')
+    curtain = np.zeros((self._rows, self._cols), dtype=np.uint8)
+    np.copyto(dst=curtain, src=prefill, casting='equiv')
+    self._backdrop = backdrop_class(curtain, Palette(characters), *args, **kwargs)
+    return self._backdrop
+
+  def add_drape(self, character, drape_class, *args, **kwargs):
+    """engine.py:339-369."""
+    return self.add_prefilled_drape(
+        character, np.zeros((self._rows, self._cols), dtype=np.bool_),
+        drape_class, *args, **kwargs)
+
+  def add_prefilled_drape(self, character, prefill, drape_class,
+                          *args, **kwargs):
+    """engine.py:371-421."""
+    self._forbid_after_showtime('add_prefilled_drape')
+    self._require_good_characters(character, mandatory_len=1)
+    self._require_unclaimed(character)
+    if not issubclass(drape_class, things.Drape):
+      raise TypeError('drape_class arguments to Engine.add_drape must be a '
+                      'subclass of Drape')
+    curtain = np.zeros((self._rows, self._cols), dtype=np.bool_)
+    np.copyto(dst=curtain, src=prefill, casting='equiv')
+    drape = drape_class(curtain, character, *args, **kwargs)
+    self._sprites_and_drapes[character] = drape
+    self._update_groups[self._current_update_group].append(drape)
+    return drape
+
+  def add_sprite(self, character, position, sprite_class, *args, **kwargs):
+    """engine.py:423-470."""
+    self._forbid_after_showtime('add_sprite')
+    self._require_good_characters(character, mandatory_len=1)
+    self._require_unclaimed(character)
+    if not issubclass(sprite_class, things.Sprite):
+      raise TypeError('sprite_class arguments to Engine.add_sprite must be a '
+                      'subclass of Sprite')
+    if (not 0 <= position[0] < self._rows or
+        not 0 <= position[1] < self._cols):
+      raise ValueError('Position {} does not fall inside a {}x{} game board.'
+                       ''.format(position, self._rows, self._cols))
+    corner = things.Sprite.Position(self._rows, self._cols)
+    position = things.Sprite.Position(*position)
+    sprite = sprite_class(corner, position, character, *args, **kwargs)
+    self._sprites_and_drapes[character] = sprite
+    self._update_groups[self._current_update_group].append(sprite)
+    return sprite
+
+  def update_group(self, group_name):
+    """engine.py:472-489."""
+    self._forbid_after_showtime('update_group')
+    self._current_update_group = group_name
+
+  def set_z_order(self, z_order):
+    """engine.py:491-518."""
+    self._forbid_after_showtime('set_z_order')
+    if (set(z_order) != set(self._sprites_and_drapes.keys()) or
+        len(z_order) != len(self._sprites_and_drapes)):
+      raise ValueError('The z_order argument {} to Engine.set_z_order is not a '
+                       'proper permutation of the characters corresponding to '
+                       'Sprites and Drapes in this game, which are {}.'.format(
+                           repr(z_order), self._sprites_and_drapes.keys()))
+    self._sprites_and_drapes = collections.OrderedDict(
+        (c, self._sprites_and_drapes[c]) for c in z_order)
+
+  def _frozen_update_groups(self):
+    """Update groups sorted by name (engine.py:557-558)."""
+    return [(k, self._update_groups[k]) for k in sorted(self._update_groups)]
+
+  # ------------------------------------------------------------ batched runtime
+  def configure(self, batch=None, device=None, auto_reset=None):
+    """Choose how many environments to step, on which GPU, and what happens
+    to environments whose episode has ended (`auto_reset=True`: the next
+    step rebuilds them from the template and runs frame 0; counted as one
+    env-step).  Must be called before `its_showtime()`."""
+    self._forbid_after_showtime('configure')
+    if batch is not None:
+      if int(batch) < 1:
+        raise ValueError('batch must be >= 1')
+      self._batch = int(batch)
+    if device is not None:
+      self._device_id = int(device)
+    if auto_reset is not None:
+      self._auto_reset = bool(auto_reset)
+    return self
+
+  @classmethod
+  def from_template(cls, template, batch=1, device=0, auto_reset=False):
+    """An engine for a pre-compiled `GameTemplate` (no Python entity objects)."""
+    eng = cls(template.rows, template.cols, template.occlusion_in_layers)
+    eng._template = template
+    eng.configure(batch=batch, device=device, auto_reset=auto_reset)
+    return eng
+
+  @property
+  def batch(self):
+    return self._batch
+
+  @property
+  def template(self):
+    if self._template is None:
+      self._template = compiler.GameTemplate.from_engine(self)
+    return self._template
+
+  def its_showtime(self):
+    """engine.py:520-581: start the episode(s); returns the frame-0 triple."""
+    self._forbid_after_showtime('its_showtime')
+    template = self.template  # compile before flipping any state
+    lib = N.lib()
+    ct, keep = template.to_ctypes()
+    handle = ctypes.c_void_p()
+    N.check(lib.pcx_engine_create(ctypes.byref(ct), self._batch,
+                                  self._device_id, ctypes.byref(handle)))
+    self._native, self._keepalive = handle, keep
+    B, L, R, C = self._batch, len(template.chars), self._rows, self._cols
+    mk = lambda shape, dt: dev.DeviceBuffer(shape, dt, self._device_id)
+    self._bufs = dict(
+        planes=mk((B, 1 + L, R, C), np.uint8), reward=mk((B,), np.int32),
+        reward_set=mk((B,), np.uint8), discount=mk((B,), np.float32),
+        done=mk((B,), np.uint8), frame=mk((B,), np.int32),
+        error=mk((B,), np.uint8))
+    self._actions = mk((B,), np.int32)
+    ext = N.Buffers(batch=B, rows=R, cols=C, n_chars=L,
+                    **{k: v.ptr for k, v in self._bufs.items()})
+    N.check(lib.pcx_engine_bind_buffers(self._native, ctypes.byref(ext)))
+    self._showtime = True
+    self._current_update_group = None
+    N.check(lib.pcx_engine_reset(self._native, None, dev.current_stream(self._device_id)))
+    return self._result()
+
+  def play(self, actions):
+    """engine.py:583-639: one step of every environment.
+
+    `actions`: for batch 1 a scalar (or `None`); for batch > 1 `None`, a
+    scalar (broadcast), an int array [B], or an int32 device tensor [B].
+    """
+    if not self._showtime:
+      raise RuntimeError('play() cannot be called until the Engine is placed '
+                         'in "play mode" via the its_showtime() method.')
+    if self._batch == 1 and not self._auto_reset and self.game_over:
+      raise RuntimeError('play() was called after the episode handled by this '
+                         'Engine has terminated.')
+    self.step(actions)
+    return self._result()
+
+  def step(self, actions):
+    """`play()` without materialising return values (no host sync)."""
+    ptr = self._stage_actions(actions)
+    N.check(N.lib().pcx_engine_step(self._native, ptr, int(self._auto_reset),
+                                    dev.current_stream(self._device_id)))
+
+  def step_hashed(self, seed, t0, steps, env_offset=0):
+    """`steps` steps with on-device actions `hash(seed, env, t) % n_actions`."""
+    N.check(N.lib().pcx_engine_step_hashed(
+        self._native, seed, env_offset, t0, steps, int(self._auto_reset),
+        dev.current_stream(self._device_id)))
+
+  def _stage_actions(self, actions):
+    torch = dev.torch_module()
+    if torch is not None and isinstance(actions, torch.Tensor):
+      if (actions.dtype != torch.int32 or not actions.is_cuda or
+          actions.numel() != self._batch or not actions.is_contiguous()):
+        raise ValueError('device actions must be a contiguous int32 CUDA tensor [batch]')
+      return actions.data_ptr()
+    if actions is None:
+      host = np.full((self._batch,), N.ACTION_NONE, np.int32)
+    elif np.isscalar(actions) or np.ndim(actions) == 0:
+      host = np.full((self._batch,), int(actions), np.int32)
+    else:
+      host = np.asarray([N.ACTION_NONE if a is None else int(a) for a in actions]
+                        if isinstance(actions, (list, tuple)) else actions,
+                        dtype=np.int32).reshape(self._batch)
+    self._actions.upload(host)
+    return self._actions.ptr
+
+  def _read_scalars(self):
+    dev.synchronize(self._device_id)
+    return {k: self._bufs[k].numpy() for k in
+            ('reward', 'reward_set', 'discount', 'done', 'frame', 'error')}
+
+  def check_errors(self):
+    """Raise if a device program hit a condition the reference raises for."""
+    err = self._bufs['error'].numpy()
+    if err.any():
+      bad = int(np.flatnonzero(err)[0])
+      code = int(err[bad])
+      kinds = [name for bit, name in ((1, 'IndexError'), (2, 'scrolling.Error'),
+                                      (4, 'play() after game over')) if code & bit]
+      raise RuntimeError('environment {} raised {} on the device'.format(bad, kinds))
+
+  def _result(self):
+    L = self._template.chars
+    planes = self._bufs['planes']
+    if self._batch == 1:
+      sc = self._read_scalars()
+      self.check_errors()
+      p = planes.numpy()[0]
+      layers = {chr(c): p[1 + k].astype(np.bool_) for k, c in enumerate(L)}
+      reward = int(sc['reward'][0]) if sc['reward_set'][0] else None
+      return rendering.Observation(board=p[0], layers=layers), reward, float(sc['discount'][0])
+    arr = planes.tensor if planes.tensor is not None else planes.numpy()
+    layers = {chr(c): arr[:, 1 + k] for k, c in enumerate(L)}
+    pick = lambda k: (self._bufs[k].tensor if self._bufs[k].tensor is not None
+                      else self._bufs[k].numpy())
+    return (rendering.Observation(board=arr[:, 0], layers=layers),
+            pick('reward'), pick('discount'))
+
+  # ---------------------------------------------------------------- properties
+  @property
+  def planes(self):
+    """The raw observation planes buffer [B, 1+n_chars, rows, cols]."""
+    return self._bufs['planes']
+
+  @property
+  def buffers(self):
+    return self._bufs
+
+  @property
+  def reward_set(self):
+    """uint8 [B]: 0 where the reference's reward would be `None`."""
+    b = self._bufs['reward_set']
+    return b.tensor if b.tensor is not None else b.numpy()
+
+  @property
+  def the_plot(self):
+    return self._the_plot
+
+  @property
+  def rows(self):
+    return self._rows
+
+  @property
+  def cols(self):
+    return self._cols
+
+  @property
+  def game_over(self):
+    """bool for batch 1; uint8 array [B] otherwise (engine.py:660-662)."""
+    if self._native is None:
+      return False
+    done = self._read_scalars()['done']
+    return bool(done[0]) if self._batch == 1 else done
+
+  @property
+  def z_order(self):
+    if self._sprites_and_drapes:
+      return list(self._sprites_and_drapes.keys())
+    return self._template.thing_chars()
+
+  @property
+  def backdrop(self):
+    return self._backdrop
+
+  @property
+  def things(self):
+    """char -> entity.  Before showtime: the template objects.  After: live
+    read-only views of device state (`position`, `visible`, `curtain`...)."""
+    if not self._showtime:
+      return dict(self._sprites_and_drapes)
+    t = self._template
+    out = {}
+    for i, s in enumerate(t.sprites):
+      out[chr(s['ch'])] = _SpriteView(self, i, chr(s['ch']))
+    for i, d in enumerate(t.drapes):
+      out[chr(d['ch'])] = _DrapeView(self, i, chr(d['ch']))
+    return out
+
+  def _read_things(self):
+    t = self._template
+    B, ns, nd = self._batch, len(t.sprites), len(t.drapes)
+    sprites = (N.SpriteState * (B * max(ns, 1)))()
+    curtains = np.zeros((B, max(nd, 1), self._rows, self._cols), np.uint8)
+    dev.synchronize(self._device_id)
+    N.check(N.lib().pcx_engine_read_things(
+        self._native, 0, B, ctypes.addressof(sprites) if ns else None,
+        curtains.ctypes.data if nd else None))
+    return sprites, curtains
+
+  def close(self):
+    if self._native is not None:
+      N.lib().pcx_engine_destroy(self._native)
+      self._native = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  # ------------------------------------------------------------------- checks
+  def _forbid_after_showtime(self, method_name):
+    if self._showtime:
+      raise RuntimeError('{} should not be called after its_showtime() '
+                         'has been called'.format(method_name))
+
+  def _require_unclaimed(self, characters):
+    for char in characters:
+      if self._backdrop and char in self._backdrop.palette:
+        raise RuntimeError('Character {} is already being used by '
+                           'the backdrop'.format(repr(char)))
+      if char in self._sprites_and_drapes:
+        raise RuntimeError('Character {} is already being used by a sprite '
+                           'or a drape'.format(repr(char)))
+
+  def _require_good_characters(self, characters, mandatory_len=None):
+    if mandatory_len is not None and len(characters) != mandatory_len:
+      raise ValueError(
+          '{}, a string of length {}, was used where a string of length {} was '
+          'required'.format(repr(characters), len(characters), mandatory_len))
+    for char in characters:
+      try:
+        ord(char)
+      except TypeError:
+        raise ValueError('Character {} is not an ASCII character'.format(char))
+
+
+class _SpriteView(object):
+  """Read-only live view of one sprite across the batch."""
+
+  def __init__(self, eng, index, character):
+    self._eng, self._index, self.character = eng, index, character
+
+  def _states(self):
+    sprites, _ = self._eng._read_things()
+    ns = len(self._eng._template.sprites)
+    return [sprites[b * ns + self._index] for b in range(self._eng.batch)]
+
+  def _pick(self, fn):
+    vals = [fn(s) for s in self._states()]
+    return vals[0] if self._eng.batch == 1 else vals
+
+  @property
+  def position(self):
+    return self._pick(lambda s: things.Sprite.Position(s.row, s.col))
+
+  @property
+  def virtual_position(self):
+    return self._pick(lambda s: things.Sprite.Position(s.vrow, s.vcol))
+
+  @property
+  def visible(self):
+    return self._pick(lambda s: bool(s.visible))
+
+
+class _DrapeView(object):
+  """Read-only live view of one drape's curtain across the batch."""
+
+  def __init__(self, eng, index, character):
+    self._eng, self._index, self.character = eng, index, character
+
+  @property
+  def curtain(self):
+    _, curtains = self._eng._read_things()
+    c = curtains[:, self._index].astype(np.bool_)
+    return c[0] if self._eng.batch == 1 else c
+
+
+_ALIAS_TABLE = """
+` backtick backquote grave | ~ tilde | 0 zero | 1 one | 2 two | 3 three |
+4 four | 5 five | 6 six | 7 seven | 8 eight | 9 nine |
+! bang exclamation exclamation_point exclamation_pt | @ at |
+# hash hashtag octothorpe number_sign pigpen pound |
+$ dollar dollar_sign buck mammon | % percent percent_sign food |
+^ carat circumflex trap | & and_sign ampersand | * asterisk star splat |
+( lbracket left_bracket lparen left_paren |
+) rbracket right_bracket rparen right_paren | - dash hyphen | _ underscore |
++ plus add | = equal equals | [ lsquare left_square_bracket |
+] rsquare right_square_bracket |
+{ lbrace lcurly left_brace left_curly left_curly_brace |
+} rbrace rcurly right_brace right_curly right_curly_brace | PIPE pipe bar |
+\\ backslash back_slash reverse_solidus | ; semicolon | : colon |
+' tick quote inverted_comma prime |
+" quotes double_inverted_commas quotation_mark | z zed | , comma |
+< less_than langle left_angle left_angle_bracket | . period full_stop |
+> greater_than rangle right_angle right_angle_bracket |
+? question question_mark | / slash solidus
+"""
+
+
+def _parse_aliases():
+  table = {}
+  for entry in _ALIAS_TABLE.replace('\n', ' ').split(' | '):
+    words = entry.split()
+    if not words:
+      continue
+    char = '|' if words[0] == 'PIPE' else words[0]
+    for name in words[1:]:
+      table[name] = char
+  return table
+
+
+class Palette(object):
+  """char -> ord helper with attribute aliases (engine.py:877-986)."""
+
+  _ALIASES = _parse_aliases()
+
+  def __init__(self, legal_characters):
+    for char in legal_characters:
+      if len(char) != 1:
+        raise ValueError('Palette constructor requires legal characters to be '
+                         'actual single charaters. "{}" is not.'.format(char))
+    self._legal_characters = set(legal_characters)
+
+  def __getattr__(self, name):
+    if name.startswith('__'):  # keep pickling/copy protocols sane
+      raise AttributeError(name)
+    return self._lookup(name, AttributeError)
+
+  def __getitem__(self, key):
+    return self._lookup(key, IndexError)
+
+  def __getstate__(self):
+    return self._legal_characters
+
+  def __setstate__(self, state):
+    self._legal_characters = set(state)
+
+  def __contains__(self, key):
+    return key in self._legal_characters
+
+  def __iter__(self):
+    return iter(self._legal_characters)
+
+  def _lookup(self, key, error):
+    key = self._ALIASES.get(key, key)
+    if key in self._legal_characters:
+      return ord(key)
+    raise error('{} is not a legal character in this Palette; legal characters '
+                'are {}.'.format(key, list(self._legal_characters)))

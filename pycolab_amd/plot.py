@@ -1,0 +1,39 @@
+"""`Plot`: the per-game blackboard (reference: plot.py:27-385).
+
+On the device the engine-facing part of the Plot (frame counter, summed
+reward, discount, game-over: plot.py:69-104, 274-277) is a handful of
+per-environment scalars in HBM.  The free-form dictionary part stays a host
+dict; device programs keep their own blackboard entries (e.g. the scrolling
+protocol's order/permits) in the per-environment state words.
+"""
+
+
+class Plot(dict):
+
+  def __init__(self, engine=None):
+    super(Plot, self).__init__()
+    self._engine = engine
+    self._update_group = None
+
+  @property
+  def frame(self):
+    """Game iteration counter; an int for batch 1, else an int32 array [B]."""
+    eng = self._engine
+    if eng is None or eng._native is None:
+      return -1
+    frames = eng._read_scalars()['frame']
+    return int(frames[0]) if eng.batch == 1 else frames
+
+  @property
+  def update_group(self):
+    return self._update_group
+
+  def log(self, message):
+    del message  # device programs emit no strings (protocols/logging.py)
+
+  # Step-time directives are issued by device programs, not from the host.
+  def _host_directive(self, *unused_args, **unused_kwargs):
+    raise NotImplementedError(
+        'Plot directives are issued by device programs during the step kernel')
+
+  add_reward = terminate_episode = change_z_order = _host_directive
