@@ -7,7 +7,7 @@
  * interface it replaces (paths relative to the pycolab checkout):
  *
  *   pcx_engine_create   <- ascii_art.ascii_art_to_game()  pycolab/ascii_art.py:31-291
- *                          + Engine.__init__/add_*/set_*  pycolab/engine.py:98-518
+ *                          + Engine.__init__, add_X, set_X  pycolab/engine.py:98-518
  *                          (the host has already run the constructors; the
  *                          template is their result as plain data)
  *   pcx_engine_reset    <- Engine.its_showtime()          pycolab/engine.py:520-581

@@ -1,0 +1,137 @@
+"""TEST INFRASTRUCTURE: ctypes binding of oracle/liboracle.so.
+
+`OracleEngine` mirrors the batched surface of `pycolab_amd.engine.Engine`
+(reset/step/buffers) on host memory so parity tests can feed both the same
+template and actions.  Never imported by the product package.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from pycolab_amd import _native as N
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, 'liboracle.so')
+
+_SYMS = [
+    ('pcxo_engine_create', N.c_i32, [ctypes.POINTER(N.Template), N.c_i64, ctypes.POINTER(ctypes.c_void_p)]),
+    ('pcxo_engine_destroy', None, [ctypes.c_void_p]),
+    ('pcxo_engine_reset', N.c_i32, [ctypes.c_void_p, ctypes.c_void_p]),
+    ('pcxo_engine_step', N.c_i32, [ctypes.c_void_p, ctypes.c_void_p, N.c_i32]),
+    ('pcxo_engine_step_hashed', N.c_i32, [ctypes.c_void_p, N.c_u64, N.c_i64, N.c_i64, N.c_i32, N.c_i32]),
+    ('pcxo_engine_buffers', N.c_i32, [ctypes.c_void_p, ctypes.POINTER(N.Buffers)]),
+    ('pcxo_engine_read_things', N.c_i32, [ctypes.c_void_p, N.c_i64, N.c_i64, ctypes.c_void_p, ctypes.c_void_p]),
+    ('pcxo_action_hash', N.c_u32, [N.c_u64, N.c_u64, N.c_u64]),
+    ('pcxo_last_error', ctypes.c_char_p, []),
+    ('pcxo_cropper_create', N.c_i32, [ctypes.c_void_p, ctypes.POINTER(N.CropperDesc), ctypes.POINTER(ctypes.c_void_p)]),
+    ('pcxo_cropper_destroy', None, [ctypes.c_void_p]),
+    ('pcxo_cropper_crop', N.c_i32, [ctypes.c_void_p]),
+    ('pcxo_cropper_buffers', N.c_i32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
+]
+
+_lib = None
+
+
+def build():
+  subprocess.check_call(['make', '-s', '-C', HERE])
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB):
+      build()
+    _lib = N.bind(ctypes.CDLL(LIB), _SYMS)
+  return _lib
+
+
+def _check(code):
+  if code != 0:
+    raise RuntimeError('oracle error %d: %s' % (code, lib().pcxo_last_error().decode()))
+
+
+def action_hash(seed, env, t):
+  return lib().pcxo_action_hash(seed, env, t)
+
+
+def action_hash_np(seed, env, t):
+  """Vectorised numpy twin of pcx_action_hash (uint64 arithmetic wraps)."""
+  with np.errstate(over='ignore'):
+    env = np.asarray(env, dtype=np.uint64)
+    t = np.asarray(t, dtype=np.uint64)
+    x = (np.uint64(seed) ^ (env * np.uint64(0x9E3779B97F4A7C15))
+         ^ (t * np.uint64(0xBF58476D1CE4E5B9)))
+    x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return (x >> np.uint64(32)).astype(np.uint32)
+
+
+class OracleEngine(object):
+
+  def __init__(self, template, batch):
+    self.template = template
+    self.batch = int(batch)
+    ct, self._keep = template.to_ctypes()
+    self._h = ctypes.c_void_p()
+    _check(lib().pcxo_engine_create(ctypes.byref(ct), self.batch, ctypes.byref(self._h)))
+    b = N.Buffers()
+    _check(lib().pcxo_engine_buffers(self._h, ctypes.byref(b)))
+    B, L, R, C = self.batch, len(template.chars), template.rows, template.cols
+
+    def view(ptr, shape, dtype):
+      n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+      buf = (ctypes.c_uint8 * n).from_address(ptr)
+      return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    self.planes = view(b.planes, (B, 1 + L, R, C), np.uint8)
+    self.reward = view(b.reward, (B,), np.int32)
+    self.reward_set = view(b.reward_set, (B,), np.uint8)
+    self.discount = view(b.discount, (B,), np.float32)
+    self.done = view(b.done, (B,), np.uint8)
+    self.frame = view(b.frame, (B,), np.int32)
+    self.error = view(b.error, (B,), np.uint8)
+
+  def reset(self, mask=None):
+    ptr = None
+    if mask is not None:
+      mask = np.ascontiguousarray(mask, np.uint8)
+      ptr = mask.ctypes.data
+    _check(lib().pcxo_engine_reset(self._h, ptr))
+
+  def step(self, actions, auto_reset=True):
+    actions = np.ascontiguousarray(actions, np.int32).reshape(self.batch)
+    _check(lib().pcxo_engine_step(self._h, actions.ctypes.data, int(auto_reset)))
+
+  def step_hashed(self, seed, t0, steps, env_offset=0, auto_reset=True):
+    _check(lib().pcxo_engine_step_hashed(self._h, seed, env_offset, t0, steps, int(auto_reset)))
+
+  def sprites(self):
+    ns = len(self.template.sprites)
+    arr = (N.SpriteState * (self.batch * max(ns, 1)))()
+    _check(lib().pcxo_engine_read_things(self._h, 0, self.batch, ctypes.addressof(arr), None))
+    out = np.zeros((self.batch, ns, 5), np.int16)
+    for b in range(self.batch):
+      for s in range(ns):
+        st = arr[b * ns + s]
+        out[b, s] = (st.row, st.col, st.vrow, st.vcol, st.visible)
+    return out
+
+  def curtains(self):
+    nd = len(self.template.drapes)
+    out = np.zeros((self.batch, nd, self.template.rows, self.template.cols), np.uint8)
+    _check(lib().pcxo_engine_read_things(self._h, 0, self.batch, None, out.ctypes.data))
+    return out
+
+  def close(self):
+    if self._h:
+      lib().pcxo_engine_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE.  Golden traces from the *imported reference itself*.
+
+Imports google-deepmind/pycolab from /root/reference (read-only), runs the
+unchanged example games on seeded action tapes with the episode policy of
+SURVEY.md section 8(d) (an environment whose episode ended is rebuilt with
+make_game()+its_showtime() at the next step), and records every step's
+board, reward (+ "is None" flag), discount, game_over and sprite states.
+Occluded layers are asserted to equal `board == ord(c)` for every character
+at generation time (rendering.py:177-179), so tests derive expected layers
+from the recorded boards.
+
+Run here (CPU container):  python oracle/gen_golden.py
+Output: tests/golden/traces/*.npz  (committed; the GPU box has no reference).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('PCX_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+warnings.filterwarnings('ignore', category=DeprecationWarning)
+
+NONE = -1
+
+
+def tape(rng, policy, T, n_ordinary, quit_action):
+  """One environment's action tape (int32 [T]; -1 = None)."""
+  a = np.zeros(T, np.int32)
+  cur = rng.randint(n_ordinary)
+  for t in range(T):
+    if policy == 0:
+      cur = rng.randint(n_ordinary)
+    elif policy == 1:
+      if rng.rand() > 0.85:
+        cur = rng.randint(n_ordinary)
+    elif policy == 2:
+      r = rng.rand()
+      if r < 0.01:
+        a[t] = quit_action
+        continue
+      if r < 0.03:
+        a[t] = NONE
+        continue
+      if r < 0.05:
+        a[t] = quit_action + 1 + rng.randint(3)  # garbage actions
+        continue
+      if r > 0.8:
+        cur = rng.randint(n_ordinary)
+    else:
+      if rng.rand() > 0.6:
+        cur = rng.randint(max(1, n_ordinary - 1))
+    a[t] = cur
+  return a
+
+
+def seek_coin_action(game, rng):
+  """Greedy BFS towards the nearest coin in world coordinates (test tapes
+  that actually collect coins and scroll; uses reference internals)."""
+  import collections
+  walls = game.things['#'].whole_pattern
+  coins = game.things['@'].whole_pattern
+  corner = game.things['#']._northwest_corner
+  vp = game.things['P'].virtual_position
+  start = (vp[0] + corner[0], vp[1] + corner[1])
+  if rng.rand() < 0.08 or not coins.any():
+    return rng.randint(5)
+  moves = [(-1, 0), (1, 0), (0, -1), (0, 1)]
+  seen = {start: None}
+  q = collections.deque([start])
+  while q:
+    cur = q.popleft()
+    if coins[cur] and cur != start:
+      while seen[cur][0] != start:
+        cur = seen[cur][0]
+      return seen[cur][1]
+    for a, (dr, dc) in enumerate(moves):
+      nxt = (cur[0] + dr, cur[1] + dc)
+      if (0 <= nxt[0] < walls.shape[0] and 0 <= nxt[1] < walls.shape[1]
+          and not walls[nxt] and nxt not in seen):
+        seen[nxt] = (cur, a)
+        q.append(nxt)
+  return rng.randint(5)
+
+
+def sprite_states(game, sprite_chars):
+  out = np.zeros((len(sprite_chars), 5), np.int16)
+  for i, c in enumerate(sprite_chars):
+    s = game.things[c]
+    vp = getattr(s, 'virtual_position', s.position)
+    out[i] = (s.position[0], s.position[1], vp[0], vp[1], int(bool(s.visible)))
+  return out
+
+
+def record(obs, reward, discount, game, chars, sprite_chars):
+  for c in chars:  # occluded layers are board == c
+    assert np.array_equal(obs.layers[c], obs.board == ord(c)), c
+  assert set(obs.layers.keys()) == set(chars)
+  return (obs.board.copy(), 0 if reward is None else int(reward),
+          0 if reward is None else 1, float(discount), int(game.game_over),
+          sprite_states(game, sprite_chars))
+
+
+def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, seeker=False):
+  boards, rewards, rsets, discounts, dones, sprites = [], [], [], [], [], []
+  actions = np.zeros((T, E), np.int32)
+  chars = sprite_chars = None
+  for e in range(E):
+    rng = np.random.RandomState(seed * 1000 + e)
+    actions[:, e] = tape(rng, e % 4, T, n_ordinary, quit_action)
+    game = make_game()
+    rec = []
+    obs, r, d = game.its_showtime()
+    if chars is None:
+      chars = sorted(obs.layers.keys())
+      sprite_chars = [c for c in game.things if hasattr(game.things[c], 'position')]
+      # template order of sprites = engine insertion (update schedule) order
+      sprite_chars = [c for c in SCHEDULE_ORDER[template_name] if c in sprite_chars]
+    rec.append(record(obs, r, d, game, chars, sprite_chars))
+    for t in range(T):
+      if game.game_over:
+        game = make_game()
+        obs, r, d = game.its_showtime()
+      else:
+        if seeker and e % 8 >= 5:
+          actions[t, e] = seek_coin_action(game, rng)
+        a = int(actions[t, e])
+        obs, r, d = game.play(None if a == NONE else a)
+      rec.append(record(obs, r, d, game, chars, sprite_chars))
+    boards.append([x[0] for x in rec]); rewards.append([x[1] for x in rec])
+    rsets.append([x[2] for x in rec]); discounts.append([x[3] for x in rec])
+    dones.append([x[4] for x in rec]); sprites.append([x[5] for x in rec])
+  sw = lambda x, dt: np.ascontiguousarray(np.swapaxes(np.array(x, dtype=dt), 0, 1))
+  path = os.path.join(ROOT, 'tests', 'golden', 'traces', name + '.npz')
+  np.savez_compressed(
+      path, template=np.frombuffer(template_name.encode(), np.uint8),
+      chars=np.array([ord(c) for c in chars], np.uint8),
+      sprite_chars=np.array([ord(c) for c in sprite_chars], np.uint8),
+      actions=actions, boards=sw(boards, np.uint8), reward=sw(rewards, np.int32),
+      reward_set=sw(rsets, np.uint8), discount=sw(discounts, np.float32),
+      done=sw(dones, np.uint8), sprites=sw(sprites, np.int16))
+  nd = int(np.array(dones).sum())
+  nr = int(np.array(rsets).sum())
+  print('wrote %s: E=%d T=%d episodes_ended=%d rewards=%d size=%d' % (
+      path, E, T, nd, nr, os.path.getsize(path)))
+
+
+SCHEDULE_ORDER = {
+    'scrolly_maze_L0': '#abcP@', 'scrolly_maze_L1': '#abcP@', 'scrolly_maze_L2': '#abcP@',
+}
+
+
+def main():
+  from pycolab.examples import scrolly_maze
+  for level in (0, 1, 2):
+    run('scrolly_maze_L%d' % level, lambda: scrolly_maze.make_game(level),
+        E=32, T=192, n_ordinary=5, quit_action=5, seed=7 + level,
+        template_name='scrolly_maze_L%d' % level, seeker=True)
+
+
+if __name__ == '__main__':
+  main()

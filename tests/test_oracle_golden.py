@@ -1,0 +1,27 @@
+"""Pins the CPU oracle (oracle/pcx_oracle.c) against golden traces recorded
+from the imported reference itself (oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import binding
+from tests import helpers
+
+
+class OracleAdapter(binding.OracleEngine):
+
+  def read(self, name):
+    return np.array(getattr(self, name))
+
+
+@pytest.mark.parametrize('name', ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2'])
+def test_oracle_matches_reference_trace(name):
+  trace = helpers.load_trace(name)
+  helpers.replay_trace(OracleAdapter, trace)
+
+
+def test_action_hash_twins_agree():
+  envs = np.arange(0, 5000, 37, dtype=np.uint64)
+  for t in (0, 1, 999, 2**33):
+    got = binding.action_hash_np(0x5EED, envs, np.uint64(t))
+    want = [binding.action_hash(0x5EED, int(e), t) for e in envs]
+    np.testing.assert_array_equal(got, np.array(want, np.uint32))
