@@ -1,0 +1,213 @@
+// pcx_engine.cpp -- the C ABI of include/pcx.h over the game backends.
+#include "pcx_internal.h"
+
+#include <cstdarg>
+#include <cstring>
+
+namespace pcx {
+
+static thread_local char g_error[1024] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof g_error, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static uint32_t action_hash_host(uint64_t seed, uint64_t env, uint64_t t) {
+  uint64_t x = seed ^ (env * 0x9E3779B97F4A7C15ull) ^ (t * 0xBF58476D1CE4E5B9ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+static void free_own_outputs(pcx_engine* e) {
+  if (!e->own_out) return;
+  (void)hipFree(e->out.planes); (void)hipFree(e->out.reward); (void)hipFree(e->out.reward_set);
+  (void)hipFree(e->out.discount); (void)hipFree(e->out.done); (void)hipFree(e->out.frame);
+  (void)hipFree(e->out.error);
+  e->own_out = false;
+  memset(&e->out, 0, sizeof e->out);
+}
+
+static int ensure_outputs(pcx_engine* e) {
+  if (e->out.planes) return 0;
+  size_t B = (size_t)e->batch;
+  size_t plane_bytes = B * (size_t)(1 + e->t.n_chars) * e->t.rows * e->t.cols;
+  pcx_buffers& o = e->out;
+  o.batch = e->batch; o.rows = e->t.rows; o.cols = e->t.cols; o.n_chars = e->t.n_chars;
+  PCX_HIP(hipMalloc((void**)&o.planes, plane_bytes));
+  PCX_HIP(hipMalloc((void**)&o.reward, B * 4));
+  PCX_HIP(hipMalloc((void**)&o.reward_set, B));
+  PCX_HIP(hipMalloc((void**)&o.discount, B * 4));
+  PCX_HIP(hipMalloc((void**)&o.done, B));
+  PCX_HIP(hipMalloc((void**)&o.frame, B * 4));
+  PCX_HIP(hipMalloc((void**)&o.error, B));
+  PCX_HIP(hipMemset(o.planes, 0, plane_bytes));
+  PCX_HIP(hipMemset(o.reward, 0, B * 4));
+  PCX_HIP(hipMemset(o.reward_set, 0, B));
+  PCX_HIP(hipMemset(o.discount, 0, B * 4));
+  PCX_HIP(hipMemset(o.done, 0, B));
+  PCX_HIP(hipMemset(o.frame, 0, B * 4));
+  PCX_HIP(hipMemset(o.error, 0, B));
+  e->own_out = true;
+  return 0;
+}
+
+}  // namespace pcx
+
+using pcx::set_error;
+
+extern "C" {
+
+uint32_t pcx_abi_version(void) { return PCX_ABI_VERSION; }
+const char* pcx_last_error(void) { return pcx::g_error; }
+uint32_t pcx_action_hash(uint64_t seed, uint64_t env, uint64_t t) { return pcx::action_hash_host(seed, env, t); }
+
+int pcx_engine_create(const pcx_template* t, int64_t batch, int device_id, pcx_engine** out) {
+  if (!t || !out || batch <= 0) return set_error(PCX_E_INVALID, "pcx_engine_create: bad arguments");
+  if (t->abi_version != PCX_ABI_VERSION) return set_error(PCX_E_INVALID, "pcx_engine_create: ABI version mismatch");
+  if (t->n_chars <= 0 || t->n_chars > PCX_MAX_CHARS || t->n_sprites < 0 || t->n_sprites > PCX_MAX_SPRITES ||
+      t->n_drapes < 0 || t->n_drapes > PCX_MAX_DRAPES || t->n_things != t->n_sprites + t->n_drapes ||
+      t->rows <= 0 || t->cols <= 0 || !t->backdrop)
+    return set_error(PCX_E_INVALID, "pcx_engine_create: malformed template");
+  PCX_HIP(hipSetDevice(device_id));
+  pcx::Backend* b = nullptr;
+  switch (t->game) {
+    case PCX_GAME_SCROLLY_MAZE: b = pcx::make_scrolly_maze_backend(); break;
+    default:
+      return set_error(PCX_E_UNSUPPORTED, "pcx_engine_create: no device program for game id %d", t->game);
+  }
+  int rc = b->init(*t, batch);
+  if (rc) { delete b; return rc; }
+  pcx_engine* e = new pcx_engine();
+  e->t = *t;
+  e->t.backdrop = nullptr;
+  for (int i = 0; i < PCX_MAX_DRAPES; ++i) e->t.drapes[i].curtain = e->t.drapes[i].pattern = nullptr;
+  e->batch = batch;
+  e->device = device_id;
+  e->backend = b;
+  *out = e;
+  return 0;
+}
+
+void pcx_engine_destroy(pcx_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  delete e->backend;
+  pcx::free_own_outputs(e);
+  delete e;
+}
+
+int pcx_engine_bind_buffers(pcx_engine* e, const pcx_buffers* ext) {
+  if (!e || !ext) return set_error(PCX_E_INVALID, "pcx_engine_bind_buffers: bad arguments");
+  if (e->showtime) return set_error(PCX_E_STATE, "pcx_engine_bind_buffers: must precede the first reset");
+  if (ext->batch != e->batch || ext->rows != e->t.rows || ext->cols != e->t.cols || ext->n_chars != e->t.n_chars)
+    return set_error(PCX_E_INVALID, "pcx_engine_bind_buffers: shape mismatch");
+  if (!ext->planes || !ext->reward || !ext->reward_set || !ext->discount || !ext->done || !ext->frame || !ext->error)
+    return set_error(PCX_E_INVALID, "pcx_engine_bind_buffers: every output pointer must be non-NULL");
+  pcx::free_own_outputs(e);
+  e->out = *ext;
+  return 0;
+}
+
+int pcx_engine_buffers(pcx_engine* e, pcx_buffers* out) {
+  if (!e || !out) return set_error(PCX_E_INVALID, "pcx_engine_buffers: bad arguments");
+  PCX_HIP(hipSetDevice(e->device));
+  int rc = pcx::ensure_outputs(e);
+  if (rc) return rc;
+  *out = e->out;
+  return 0;
+}
+
+int pcx_engine_reset(pcx_engine* e, const uint8_t* env_mask_dev, void* stream) {
+  if (!e) return set_error(PCX_E_INVALID, "pcx_engine_reset: null engine");
+  PCX_HIP(hipSetDevice(e->device));
+  int rc = pcx::ensure_outputs(e);
+  if (rc) return rc;
+  if (!e->showtime && env_mask_dev)
+    return set_error(PCX_E_STATE, "pcx_engine_reset: the first reset must cover every environment");
+  pcx::StepArgs a;
+  a.mode = 1;
+  a.reset_mask = env_mask_dev;
+  rc = e->backend->launch(a, e->out, (hipStream_t)stream);
+  if (rc) return rc;
+  e->showtime = true;
+  e->epoch++;
+  return 0;
+}
+
+int pcx_engine_step(pcx_engine* e, const int32_t* actions_dev, int auto_reset, void* stream) {
+  if (!e || !actions_dev) return set_error(PCX_E_INVALID, "pcx_engine_step: bad arguments");
+  if (!e->showtime) return set_error(PCX_E_STATE, "pcx_engine_step: call pcx_engine_reset first (its_showtime)");
+  PCX_HIP(hipSetDevice(e->device));
+  pcx::StepArgs a;
+  a.actions = actions_dev;
+  a.auto_reset = auto_reset;
+  int rc = e->backend->launch(a, e->out, (hipStream_t)stream);
+  if (rc) return rc;
+  e->epoch++;
+  return 0;
+}
+
+int pcx_engine_step_n(pcx_engine* e, const int32_t* action_tape_dev, int T, int auto_reset, void* stream) {
+  if (!e || !action_tape_dev || T < 0) return set_error(PCX_E_INVALID, "pcx_engine_step_n: bad arguments");
+  for (int t = 0; t < T; ++t) {
+    int rc = pcx_engine_step(e, action_tape_dev + (size_t)t * e->batch, auto_reset, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int pcx_engine_step_hashed(pcx_engine* e, uint64_t seed, int64_t env_offset, int64_t t0, int T, int auto_reset,
+                           void* stream) {
+  if (!e || T < 0) return set_error(PCX_E_INVALID, "pcx_engine_step_hashed: bad arguments");
+  if (!e->showtime) return set_error(PCX_E_STATE, "pcx_engine_step_hashed: call pcx_engine_reset first");
+  PCX_HIP(hipSetDevice(e->device));
+  for (int t = 0; t < T; ++t) {
+    pcx::StepArgs a;
+    a.hashed = 1; a.seed = seed; a.env_offset = env_offset; a.t = t0 + t; a.auto_reset = auto_reset;
+    int rc = e->backend->launch(a, e->out, (hipStream_t)stream);
+    if (rc) return rc;
+    e->epoch++;
+  }
+  return 0;
+}
+
+int pcx_engine_read_things(pcx_engine* e, int64_t env0, int64_t n, pcx_sprite_state* sprites_host,
+                           uint8_t* curtains_host) {
+  if (!e || env0 < 0 || n < 0 || env0 + n > e->batch) return set_error(PCX_E_INVALID, "pcx_engine_read_things: bad range");
+  PCX_HIP(hipSetDevice(e->device));
+  return e->backend->read_things(env0, n, sprites_host, curtains_host);
+}
+
+int64_t pcx_engine_bytes_per_step(const pcx_engine* e) { return e ? e->backend->bytes_per_step() : 0; }
+const char* pcx_engine_kernel_name(const pcx_engine* e) { return e ? e->backend->kernel_name() : ""; }
+
+int pcx_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes) {
+  PCX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+int pcx_memcpy_h2d(void* dst_dev, const void* src_host, uint64_t bytes) {
+  PCX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int pcx_device_malloc(void** out_dev, uint64_t bytes) {
+  PCX_HIP(hipMalloc(out_dev, bytes));
+  return 0;
+}
+int pcx_device_free(void* dev) {
+  PCX_HIP(hipFree(dev));
+  return 0;
+}
+int pcx_stream_synchronize(void* stream) {
+  PCX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+// Croppers: see pcx_crop.hip.
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// pcx_internal.h -- host-side plumbing shared by the C ABI and the game
+// backends.  One backend = one shipped game family = one fused step kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/pcx.h"
+
+namespace pcx {
+
+int set_error(int code, const char* fmt, ...);
+
+#define PCX_HIP(call)                                                          \
+  do {                                                                         \
+    hipError_t err__ = (call);                                                 \
+    if (err__ != hipSuccess)                                                   \
+      return ::pcx::set_error(PCX_E_HIP, "%s failed: %s (%s:%d)", #call,       \
+                              hipGetErrorString(err__), __FILE__, __LINE__);   \
+  } while (0)
+
+// Error bits reported per environment (the reference would have raised).
+enum : uint8_t { ERR_INDEX = 1, ERR_SCROLL = 2, ERR_AFTER_OVER = 4 };
+
+struct StepArgs {
+  const int32_t* actions = nullptr;  // device int32[batch] or null when hashed
+  const uint8_t* reset_mask = nullptr;  // reset mode: device uint8[batch] or null
+  int mode = 0;                      // 0 step, 1 reset
+  int auto_reset = 0;
+  int hashed = 0;
+  uint64_t seed = 0;
+  int64_t env_offset = 0;
+  int64_t t = 0;
+};
+
+// Device-resident copy of a byte array.
+template <typename T>
+struct DevArray {
+  T* ptr = nullptr;
+  size_t count = 0;
+  ~DevArray() { if (ptr) (void)hipFree(ptr); }
+  int alloc(size_t n) {
+    count = n;
+    PCX_HIP(hipMalloc(reinterpret_cast<void**>(&ptr), (n ? n : 1) * sizeof(T)));
+    PCX_HIP(hipMemset(ptr, 0, (n ? n : 1) * sizeof(T)));
+    return 0;
+  }
+  int upload(const std::vector<T>& host) {
+    int rc = alloc(host.size());
+    if (rc) return rc;
+    if (!host.empty())
+      PCX_HIP(hipMemcpy(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  }
+};
+
+class Backend {
+ public:
+  virtual ~Backend() {}
+  // Validate the template and upload constants / allocate state.
+  virtual int init(const pcx_template& t, int64_t batch) = 0;
+  virtual int launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) = 0;
+  virtual int read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites,
+                          uint8_t* curtains) = 0;
+  virtual int64_t bytes_per_step() const = 0;
+  virtual const char* kernel_name() const = 0;
+  // Sprite state for croppers: device int32 [n_sprites][batch] packed
+  // (row | col << 8 | visible << 16), refreshed by every launch.
+  virtual const int32_t* sprite_track() const { return nullptr; }
+};
+
+Backend* make_scrolly_maze_backend();
+
+}  // namespace pcx
+
+struct pcx_engine {
+  pcx_template t;  // shallow copy; pointer members are NOT valid after create
+  int64_t batch = 0;
+  int device = 0;
+  bool showtime = false;
+  pcx::Backend* backend = nullptr;
+  pcx_buffers out{};       // where the kernels write (own or bound)
+  bool own_out = false;
+  uint64_t epoch = 0;      // bumped by every reset/step (croppers)
+};

@@ -1,0 +1,860 @@
+// pcx_scrolly_maze.hip -- fused step kernel for the scrolly_maze game family
+// (reference: pycolab/examples/scrolly_maze.py driven by engine.py:583-847,
+// prefab_parts/sprites.py MazeWalker, prefab_parts/drapes.py Scrolly and
+// protocols/scrolling.py).  Written for gfx950 only.
+//
+// One launch = one Engine.play() for every environment of the batch.
+//
+// Mapping to the hardware:
+//   * a workgroup is ONE wavefront and owns 64 consecutive environments;
+//   * phase A, lane == environment: the per-environment state (a dozen
+//     32-bit words, SoA over the batch, so every load/store is a coalesced
+//     256-byte wave access) is stepped through the three update groups.  The
+//     intermediate repaints of engine.py:735 are never materialised: the few
+//     board cells MazeWalker._check_motion looks at are evaluated lazily from
+//     a register snapshot of "what the last repaint would have shown";
+//   * phase A leaves, in LDS, each environment's two drape curtains as R
+//     bit-rows and its sprite cells;
+//   * phase B, the wavefront streams the observation: 64 lanes walk the
+//     (environment, 4-cell group) space, each lane composes one board dword
+//     in z-order from LDS, derives the L layer dwords from it with byte-wise
+//     SWAR compares, and stores 1+L dwords; a wave store covers 256
+//     contiguous bytes of one plane.  Nothing is read back from HBM.
+//
+// Shared, immutable template data (wall pattern as bit-rows, backdrop, the
+// coin list) is staged into LDS once per workgroup from L2.  Per-environment
+// coins are a bitmask over the template's coin list (coins only disappear),
+// 12 bytes for level 0 instead of a 4005-cell pattern.
+
+#include "pcx_internal.h"
+
+#include <cstdarg>
+#include <cstring>
+
+namespace pcx {
+namespace sm {
+
+constexpr int WAVE = 64;
+constexpr int MAX_NS = 6;   // sprites (patrollers + player)
+constexpr int MAX_Z = 8;
+constexpr int MAX_L = 16;
+
+// State words (uint32 [NW][batch_padded]).
+enum : int { W_FRAME = 0, W_FLAGS, W_PERMIT_FRAME, W_MAZE, W_CASH, W_STALE, W_SFLAGS, W_SPOS };
+// W_FLAGS bits
+constexpr uint32_t F_OVER = 1u, F_ERR_SHIFT = 1, F_ERR_MASK = 7u << 1, F_REGISTERED = 1u << 4,
+                   F_PERMIT_VALID = 1u << 5;
+constexpr int F_PERMIT_SHIFT = 6;  // 9 bits
+constexpr uint32_t STALE_NONE = 0xFFFFu;
+
+// Everything that is the same for every environment.  Lives in device global
+// memory; all accesses are wave-uniform so they compile to scalar loads.
+struct Consts {
+  int32_t R, C, cells, QW, L, n_things, NS;
+  uint32_t magic_q, magic_c;
+  int32_t PR, PC, WPR;
+  int32_t lim_r, lim_c;
+  int32_t have_margins, margin_n, margin_s, margin_w, margin_e;
+  int32_t n_coins, CW, NW;
+  int32_t ip;  // sprite index of 'P' (PatrollerSprite / CashDrape look it up)
+  int32_t ie;  // index of the (single) egocentric sprite, -1 if none
+  int32_t maze_ch, cash_ch;
+  int32_t n_actions;
+  uint32_t chars[MAX_L];
+  // sprites, in engine insertion order (== update order inside group 1)
+  int32_t prog[MAX_NS], confined[MAX_NS], egocentric[MAX_NS], sprite_ch[MAX_NS];
+  uint32_t imp[MAX_NS][4];
+  uint32_t relevant[MAX_NS];  // presence bits that can change a probe's verdict
+  int32_t relevant_backdrop[MAX_NS];
+  uint32_t init[24];          // initial state words (coin words are derived)
+  // z-order, back to front
+  int32_t z_kind[MAX_Z], z_idx[MAX_Z], z_ch[MAX_Z];
+  // LDS layout (word offsets)
+  int32_t lds_walls, lds_backdrop, lds_rowstart, lds_coincol, lds_drows, lds_scell, lds_cmask,
+      lds_skip, lds_words;
+};
+
+struct Ptrs {
+  const Consts* k;
+  const uint32_t* walls_bits;   // [PR][WPR]
+  const uint32_t* backdrop4;    // [QW] backdrop as dwords
+  const uint16_t* coin_rowstart;  // [PR+1]
+  const uint8_t* coin_col;        // [n_coins]
+  uint32_t* state;                // [NW][bpad]
+  int32_t* track;                 // [NS][bpad] packed true row | col<<8 | visible<<16
+  int64_t batch, bpad;
+};
+
+struct Walker {
+  int vr, vc, vis, prior, var;
+};
+struct Scrolly {
+  int r, c, pre_r, pre_c, moved;
+};
+struct Plot {
+  int frame;
+  uint32_t flags;      // registered / permit bits / error
+  int permit_frame;
+  int order_valid, o0, o1;
+  int reward_set, reward, game_over;
+  float discount;
+};
+
+__device__ __forceinline__ bool on_board(const Consts& k, int r, int c) {
+  return (unsigned)r < (unsigned)k.R && (unsigned)c < (unsigned)k.C;
+}
+__device__ __forceinline__ int motion_bit(int dr, int dc) { return (dr + 1) * 3 + (dc + 1); }
+
+// sprites.py:315-352 _teleport (+ _on_board_exit/_enter :223-275)
+__device__ __forceinline__ void teleport(const Consts& k, Walker& w, int nr, int nc) {
+  bool old_on = on_board(k, w.vr, w.vc), new_on = on_board(k, nr, nc);
+  if (old_on && !new_on) { w.prior = w.vis; w.vis = 0; }
+  w.vr = nr;
+  w.vc = nc;
+  if (!old_on && new_on) w.vis = w.prior;
+}
+// cell index the sprite is painted at (engine.py:752-753), -1 when invisible
+__device__ __forceinline__ int paint_cell(const Consts& k, const Walker& w) {
+  if (!w.vis) return -1;
+  return on_board(k, w.vr, w.vc) ? w.vr * k.C + w.vc : 0;
+}
+
+struct Lds {
+  const uint32_t* walls;
+  const uint32_t* backdrop4;
+  const uint16_t* rowstart;
+  const uint8_t* coincol;
+  uint32_t* drows;  // [2][R+1][64]
+  int32_t* scell;   // [NS][64]
+  uint32_t* cmask;  // [CW][64]
+  uint32_t* skip;   // [64]
+};
+
+__device__ __forceinline__ int wall_at(const Consts& k, const Lds& l, int pr, int pc, uint32_t& err) {
+  if ((unsigned)pr >= (unsigned)k.PR || (unsigned)pc >= (unsigned)k.PC) { err |= ERR_INDEX; return 0; }
+  return (l.walls[pr * k.WPR + (pc >> 5)] >> (pc & 31)) & 1;
+}
+// id of the template coin at pattern cell (pr, pc), or -1
+__device__ __forceinline__ int coin_id_at(const Consts& k, const Lds& l, int pr, int pc) {
+  if ((unsigned)pr >= (unsigned)k.PR) return -1;
+  int k0 = l.rowstart[pr], k1 = l.rowstart[pr + 1];
+  for (int i = k0; i < k1; ++i)
+    if (l.coincol[i] == pc) return i;
+  return -1;
+}
+__device__ __forceinline__ bool coin_alive(const Lds& l, int lane, int id) {
+  return (l.cmask[(id >> 5) * WAVE + lane] >> (id & 31)) & 1;
+}
+
+// What the last repaint showed, for lazy board probes.
+template <int NS>
+struct Snap {
+  int cell[NS];
+  int maze_r, maze_c, cash_r, cash_c;
+  uint32_t stale;
+};
+
+// Is the character on top of board cell (r, c) impassable to walker s?
+// (sprites.py:496-511 at()/is_impassable() over engine.py:737-759 _render.)
+template <int NS>
+__device__ __forceinline__ bool blocked_at(const Consts& k, const Lds& l, const Snap<NS>& sn, int s,
+                                           const Walker& w, int dr, int dc, int lane, uint32_t& err) {
+  int r = w.vr + dr, c = w.vc + dc;
+  if (!on_board(k, r, c)) return k.confined[s] != 0;  // EDGE
+  uint32_t rel = k.relevant[s];
+  uint32_t present = 0;
+  int cell = r * k.C + c;
+#pragma unroll
+  for (int j = 0; j < NS; ++j)
+    if ((rel >> j) & 1) present |= (uint32_t)(sn.cell[j] == cell) << j;
+  if ((rel >> NS) & 1) present |= (uint32_t)wall_at(k, l, sn.maze_r + r, sn.maze_c + c, err) << NS;
+  if ((rel >> (NS + 1)) & 1) {
+    int id = coin_id_at(k, l, sn.cash_r + r, sn.cash_c + c);
+    bool there = id >= 0 && (coin_alive(l, lane, id) || (uint32_t)id == sn.stale);
+    present |= (uint32_t)there << (NS + 1);
+  }
+  int top = -1;
+  for (int z = 0; z < k.n_things; ++z) {  // back to front: the last hit wins
+    int bit = k.z_kind[z] ? NS + k.z_idx[z] : k.z_idx[z];
+    if ((present >> bit) & 1) top = k.z_ch[z];
+  }
+  if (top < 0) {
+    if (!k.relevant_backdrop[s]) return false;
+    top = (l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
+  }
+  return (k.imp[s][top >> 5] >> (top & 31)) & 1;
+}
+
+// sprites.py:479-546 _check_motion
+template <int NS>
+__device__ __forceinline__ bool check_motion(const Consts& k, const Lds& l, const Snap<NS>& sn, int s,
+                                             const Walker& w, int dr, int dc, int lane, uint32_t& err) {
+  if (dr == 0 && dc == 0) return false;
+  if (dr != 0 && dc != 0) {
+    if (blocked_at<NS>(k, l, sn, s, w, dr, dc, lane, err)) return true;
+    return blocked_at<NS>(k, l, sn, s, w, dr, 0, lane, err) && blocked_at<NS>(k, l, sn, s, w, 0, dc, lane, err);
+  }
+  return blocked_at<NS>(k, l, sn, s, w, dr, dc, lane, err);
+}
+
+// sprites.py:356-389 _move (with :413-477 scrolling hooks)
+template <int NS>
+__device__ __forceinline__ bool mw_move(const Consts& k, const Lds& l, const Snap<NS>& sn, int s, Walker& w,
+                                        Plot& p, int dr, int dc, int lane, uint32_t& err) {
+  bool ego = k.egocentric[s] != 0;
+  if (ego) p.flags |= F_REGISTERED;  // scrolling.py:287-312
+  if (p.order_valid) {               // sprites.py:446-454
+    teleport(k, w, w.vr - p.o0, w.vc - p.o1);
+    if (ego && p.o0 != dr && p.o1 != dc) err |= ERR_SCROLL;
+  }
+  bool blocked = check_motion<NS>(k, l, sn, s, w, dr, dc, lane, err);
+  if (!blocked) teleport(k, w, w.vr + dr, w.vc + dc);
+  if (ego) {  // sprites.py:456-477 + scrolling.py:372-434 permit()
+    // the eight neighbours, each probed once
+    bool n = blocked_at<NS>(k, l, sn, s, w, -1, 0, lane, err), so = blocked_at<NS>(k, l, sn, s, w, 1, 0, lane, err);
+    bool we = blocked_at<NS>(k, l, sn, s, w, 0, -1, lane, err), ea = blocked_at<NS>(k, l, sn, s, w, 0, 1, lane, err);
+    bool nw = blocked_at<NS>(k, l, sn, s, w, -1, -1, lane, err), ne = blocked_at<NS>(k, l, sn, s, w, -1, 1, lane, err);
+    bool sw = blocked_at<NS>(k, l, sn, s, w, 1, -1, lane, err), se = blocked_at<NS>(k, l, sn, s, w, 1, 1, lane, err);
+    uint32_t legal = 1u << motion_bit(0, 0);
+    legal |= (uint32_t)!n << motion_bit(-1, 0);
+    legal |= (uint32_t)!so << motion_bit(1, 0);
+    legal |= (uint32_t)!we << motion_bit(0, -1);
+    legal |= (uint32_t)!ea << motion_bit(0, 1);
+    legal |= (uint32_t)!(nw || (n && we)) << motion_bit(-1, -1);
+    legal |= (uint32_t)!(ne || (n && ea)) << motion_bit(-1, 1);
+    legal |= (uint32_t)!(sw || (so && we)) << motion_bit(1, -1);
+    legal |= (uint32_t)!(se || (so && ea)) << motion_bit(1, 1);
+    int my_frame = p.frame + 1;
+    uint32_t mask = (p.flags >> F_PERMIT_SHIFT) & 0x1FF;
+    if (!(p.flags & F_PERMIT_VALID) || p.permit_frame != my_frame) mask = 0;
+    mask |= legal;
+    p.flags = (p.flags & ~(0x1FFu << F_PERMIT_SHIFT)) | (mask << F_PERMIT_SHIFT) | F_PERMIT_VALID;
+    p.permit_frame = my_frame;
+  }
+  return blocked;
+}
+
+// scrolling.py:437-485 is_possible (one egocentric participant at most)
+__device__ __forceinline__ bool is_possible(const Plot& p, int dr, int dc) {
+  if (!(p.flags & F_REGISTERED)) return true;
+  if (!(p.flags & F_PERMIT_VALID) || p.permit_frame != p.frame) return false;
+  return (p.flags >> (F_PERMIT_SHIFT + motion_bit(dr, dc))) & 1;
+}
+
+// drapes.py:487-659 _maybe_move.  `ego` is the egocentric sprite (if any).
+__device__ __forceinline__ void maybe_move(const Consts& k, Scrolly& d, Plot& p, const Walker& ego, int dr,
+                                           int dc, uint32_t& err) {
+  if (!d.moved) { d.moved = 1; d.pre_r = d.r; d.pre_c = d.c; }  // :515-517
+  if (p.order_valid) {                                         // :523-535
+    if (dr != p.o0 && dc != p.o1) { err |= ERR_SCROLL; return; }
+    d.r += p.o0;
+    d.c += p.o1;
+    return;
+  }
+  if (dr == 0 && dc == 0) return;  // :539-541
+  int o0, o1;
+  bool go;
+  if (!k.have_margins) {  // :551-585
+    go = is_possible(p, dr, dc);
+    int north = d.r + dr, west = d.c + dc;
+    o0 = (0 <= north && north <= k.lim_r) ? dr : 0;
+    o1 = (0 <= west && west <= k.lim_c) ? dc : 0;
+  } else {  // :592-659
+    bool vert = false, horiz = false;
+    if (k.ie >= 0 && (p.flags & F_REGISTERED)) {  // :661-687, Sprite.position is the true position
+      bool on = on_board(k, ego.vr, ego.vc);
+      int old_r = on ? ego.vr : 0, old_c = on ? ego.vc : 0;
+      int new_r = old_r + dr, new_c = old_c + dc;
+      vert = (old_r > new_r && new_r <= k.margin_n) || (old_r < new_r && new_r >= k.margin_s);
+      horiz = (old_c > new_c && new_c <= k.margin_w) || (old_c < new_c && new_c >= k.margin_e);
+    }
+    if (!(vert || horiz)) return;
+    o0 = vert ? dr : 0;
+    o1 = horiz ? dc : 0;
+    int pr = d.r + o0, pc = d.c + o1;
+    go = 0 <= pr && pr <= k.lim_r && 0 <= pc && pc <= k.lim_c && is_possible(p, dr, dc);
+  }
+  if (go) {
+    d.r += o0;
+    d.c += o1;
+    p.order_valid = 1;  // scrolling.py:530-531 (we are the first to order this frame)
+    p.o0 = o0;
+    p.o1 = o1;
+  }
+}
+
+// examples/scrolly_maze.py: 0 N, 1 S, 2 W, 3 E, 4 stay
+__device__ __forceinline__ bool sm_motion(int a, int& dr, int& dc) {
+  dr = (a == 0) ? -1 : (a == 1) ? 1 : 0;
+  dc = (a == 2) ? -1 : (a == 3) ? 1 : 0;
+  return (unsigned)a <= 4u;
+}
+
+__device__ __forceinline__ uint32_t action_hash(uint64_t seed, uint64_t env, uint64_t t) {
+  uint64_t x = seed ^ (env * 0x9E3779B97F4A7C15ull) ^ (t * 0xBF58476D1CE4E5B9ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+__device__ __forceinline__ uint32_t pack_pos(int r, int c) { return ((uint32_t)r & 0xFFFFu) | ((uint32_t)c << 16); }
+__device__ __forceinline__ int pos_r(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
+__device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16); }
+
+template <int NS>
+__global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(Ptrs P, StepArgs a, pcx_buffers out) {
+  extern __shared__ uint32_t lds_raw[];
+  const Consts& k = *P.k;
+  const int lane = threadIdx.x;
+  const int64_t env0 = (int64_t)blockIdx.x * WAVE;
+  const int64_t env = env0 + lane;
+
+  Lds l;
+  uint32_t* lw = lds_raw + k.lds_walls;
+  uint32_t* lb = lds_raw + k.lds_backdrop;
+  uint32_t* lr = lds_raw + k.lds_rowstart;
+  uint32_t* lc = lds_raw + k.lds_coincol;
+  l.walls = lw;
+  l.backdrop4 = lb;
+  l.rowstart = reinterpret_cast<const uint16_t*>(lr);
+  l.coincol = reinterpret_cast<const uint8_t*>(lc);
+  l.drows = lds_raw + k.lds_drows;
+  l.scell = reinterpret_cast<int32_t*>(lds_raw + k.lds_scell);
+  l.cmask = lds_raw + k.lds_cmask;
+  l.skip = lds_raw + k.lds_skip;
+
+  // ---- stage the shared template constants into LDS (from L2) -------------
+  for (int i = lane; i < k.PR * k.WPR; i += WAVE) lw[i] = P.walls_bits[i];
+  for (int i = lane; i < k.QW; i += WAVE) lb[i] = P.backdrop4[i];
+  {
+    const uint32_t* rs = reinterpret_cast<const uint32_t*>(P.coin_rowstart);
+    const uint32_t* cc = reinterpret_cast<const uint32_t*>(P.coin_col);
+    for (int i = lane; i < (k.PR + 2) / 2; i += WAVE) lr[i] = rs[i];
+    for (int i = lane; i < (k.n_coins + 3) / 4; i += WAVE) lc[i] = cc[i];
+  }
+
+  // ---- phase A: lane == environment ---------------------------------------
+  const bool live = env < P.batch;
+  uint32_t* st = P.state + env;  // word w at st[w * bpad]
+  const int64_t bp = P.bpad;
+  uint32_t flags = 0;
+  bool skip = !live;
+  bool do_reset = false;
+  int action = PCX_ACTION_NONE;
+  if (live) {
+    flags = st[W_FLAGS * bp];
+    if (a.mode == 1) {
+      do_reset = a.reset_mask ? a.reset_mask[env] != 0 : true;
+      skip = !do_reset;
+    } else if (flags & F_OVER) {
+      do_reset = a.auto_reset != 0;
+      skip = !do_reset;
+    } else {
+      action = a.hashed ? (int)(action_hash(a.seed, (uint64_t)(a.env_offset + env), (uint64_t)a.t) %
+                               (uint32_t)k.n_actions)
+                        : a.actions[env];
+    }
+  }
+  __syncthreads();  // LDS constants visible
+
+  Walker w[NS];
+  Scrolly maze, cash;
+  Plot p;
+  uint32_t stale;
+  uint32_t err = do_reset ? 0u : (flags >> F_ERR_SHIFT) & 7u;  // sticky within an episode
+  bool coins_dirty = false;
+  if (!skip) {
+    // load (or rebuild) the state words
+    uint32_t sflags, spos[NS], mz, cs;
+    if (do_reset) {  // engine.py:520-581 its_showtime: fresh template state
+      p.frame = (int)k.init[W_FRAME];
+      flags = k.init[W_FLAGS];
+      p.permit_frame = (int)k.init[W_PERMIT_FRAME];
+      mz = k.init[W_MAZE];
+      cs = k.init[W_CASH];
+      stale = k.init[W_STALE];
+      sflags = k.init[W_SFLAGS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) spos[s] = k.init[W_SPOS + s];
+      for (int i = 0; i < k.CW; ++i) {
+        int left = k.n_coins - 32 * i;
+        l.cmask[i * WAVE + lane] = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u);
+      }
+      coins_dirty = true;
+      action = PCX_ACTION_NONE;
+    } else {
+      p.frame = (int)st[W_FRAME * bp];
+      p.permit_frame = (int)st[W_PERMIT_FRAME * bp];
+      mz = st[W_MAZE * bp];
+      cs = st[W_CASH * bp];
+      stale = st[W_STALE * bp];
+      sflags = st[W_SFLAGS * bp];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) spos[s] = st[(W_SPOS + s) * bp];
+      for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + lane] = st[(W_SPOS + NS + i) * bp];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      w[s].vr = pos_r(spos[s]);
+      w[s].vc = pos_c(spos[s]);
+      uint32_t f = sflags >> (8 * s);
+      w[s].vis = f & 1;
+      w[s].prior = (f >> 1) & 1;
+      w[s].var = (f >> 2) & 1;
+    }
+    maze = {pos_r(mz), pos_c(mz), 0, 0, 0};
+    cash = {pos_r(cs), pos_c(cs), 0, 0, 0};
+    p.flags = flags & ~(F_OVER | F_ERR_MASK);
+    p.order_valid = 0; p.o0 = 0; p.o1 = 0;
+    p.reward_set = 0; p.reward = 0; p.game_over = 0; p.discount = 1.0f;  // plot.py:98-104
+
+    // ---- Engine.play(): engine.py:698-735 --------------------------------
+    p.frame += 1;
+    int dr, dc;
+    const bool moves = sm_motion(action, dr, dc);
+    Snap<NS> sn;  // the repaint every entity of this frame's groups 0/1 sees
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sn.cell[s] = paint_cell(k, w[s]);
+    sn.cash_r = cash.r; sn.cash_c = cash.c; sn.stale = stale;
+
+    // group 0: MazeDrape.update (scrolly_maze.py:317-329)
+    Walker ego = w[0];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) if (s == k.ie) ego = w[s];
+    if (moves) maybe_move(k, maze, p, ego, dr, dc, err);
+    sn.maze_r = maze.r; sn.maze_c = maze.c;  // repaint #1: walls already scrolled
+
+    // group 1: sprites in insertion order, all reading repaint #1
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (k.prog[s] == PCX_PROG_SM_PATROLLER) {  // scrolly_maze.py:284-305
+        if (p.frame & 1) {
+          mw_move<NS>(k, l, sn, s, w[s], p, 0, 0, lane, err);
+        } else {
+          // drapes.py:405-411 pattern_position_prescroll on the walls drape
+          if (!maze.moved) { maze.pre_r = maze.r; maze.pre_c = maze.c; }
+          int pr = w[s].vr + maze.pre_r, pc = w[s].vc + maze.pre_c + (w[s].var ? 1 : -1);
+          if (pr < 0) pr += k.PR;  // numpy negative-index wrap
+          if (pc < 0) pc += k.PC;
+          if (wall_at(k, l, pr, pc, err)) w[s].var ^= 1;
+          mw_move<NS>(k, l, sn, s, w[s], p, 0, w[s].var ? 1 : -1, lane, err);
+          Walker pl = w[0];
+#pragma unroll
+          for (int j = 0; j < NS; ++j) if (j == k.ip) pl = w[j];
+          if (w[s].vr == pl.vr && w[s].vc == pl.vc) { p.game_over = 1; p.discount = 0.0f; }
+        }
+      } else {  // PlayerSprite.update (scrolly_maze.py:259-271)
+        if (moves) mw_move<NS>(k, l, sn, s, w[s], p, dr, dc, lane, err);
+      }
+    }
+
+    // group 2: CashDrape.update (scrolly_maze.py:341-364)
+    {
+      Walker pl = w[0];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) if (j == k.ip) pl = w[j];
+      bool on = on_board(k, pl.vr, pl.vc);
+      // pattern_position_prescroll: this drape has not scrolled yet this frame
+      int pr = (on ? pl.vr : 0) + cash.r, pc = (on ? pl.vc : 0) + cash.c;
+      if (pr < 0) pr += k.PR;
+      if (pc < 0) pc += k.PC;
+      if ((unsigned)pr >= (unsigned)k.PR || (unsigned)pc >= (unsigned)k.PC) {
+        err |= ERR_INDEX;
+      } else {
+        int id = coin_id_at(k, l, pr, pc);
+        if (id >= 0 && coin_alive(l, lane, id)) {
+          p.reward_set = 1;
+          p.reward += 100;
+          l.cmask[(id >> 5) * WAVE + lane] &= ~(1u << (id & 31));
+          coins_dirty = true;
+          stale = (uint32_t)id;  // still drawn until the curtain is refreshed
+          uint32_t any = 0;
+          for (int i = 0; i < k.CW; ++i) any |= l.cmask[i * WAVE + lane];
+          if (!any) { p.game_over = 1; p.discount = 0.0f; }
+        }
+      }
+      if (moves) {
+        Walker ego2 = w[0];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (s == k.ie) ego2 = w[s];
+        maybe_move(k, cash, p, ego2, dr, dc, err);
+        stale = STALE_NONE;  // every _maybe_move path ends in _update_curtain
+      } else if (action == 5) {
+        p.game_over = 1; p.discount = 0.0f;
+      }
+    }
+
+    // ---- _apply_and_clear_plot (engine.py:761-847) + state write-back ------
+    flags = p.flags | (p.game_over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT);
+    st[W_FRAME * bp] = (uint32_t)p.frame;
+    st[W_FLAGS * bp] = flags;
+    st[W_PERMIT_FRAME * bp] = (uint32_t)p.permit_frame;
+    st[W_MAZE * bp] = pack_pos(maze.r, maze.c);
+    st[W_CASH * bp] = pack_pos(cash.r, cash.c);
+    st[W_STALE * bp] = stale;
+    uint32_t sf = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      st[(W_SPOS + s) * bp] = pack_pos(w[s].vr, w[s].vc);
+      sf |= ((uint32_t)w[s].vis | ((uint32_t)w[s].prior << 1) | ((uint32_t)w[s].var << 2)) << (8 * s);
+    }
+    st[W_SFLAGS * bp] = sf;
+    if (coins_dirty)
+      for (int i = 0; i < k.CW; ++i) st[(W_SPOS + NS + i) * bp] = l.cmask[i * WAVE + lane];
+    out.reward[env] = p.reward;
+    out.reward_set[env] = (uint8_t)p.reward_set;
+    out.discount[env] = p.discount;
+    out.done[env] = (uint8_t)p.game_over;
+    out.frame[env] = p.frame;
+    out.error[env] = (uint8_t)err;
+
+    // ---- render descriptors for phase B ------------------------------------
+    const int R = k.R, C = k.C;
+    const uint32_t cmaskC = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
+    for (int r = 0; r < R; ++r) {
+      // walls curtain row: bits [maze.c, maze.c + C) of pattern row maze.r + r
+      int pr = maze.r + r;
+      uint32_t wbits = 0;
+      if ((unsigned)pr < (unsigned)k.PR && maze.c >= 0 && maze.c + C <= k.PC) {
+        const uint32_t* row = l.walls + pr * k.WPR;
+        int wi = maze.c >> 5, sh = maze.c & 31;
+        uint64_t pair = row[wi];
+        if (wi + 1 < k.WPR) pair |= (uint64_t)row[wi + 1] << 32;
+        wbits = (uint32_t)(pair >> sh) & cmaskC;
+      } else {
+        err |= ERR_INDEX;
+      }
+      l.drows[(0 * (R + 1) + r) * WAVE + lane] = wbits;
+      // coins curtain row
+      int cr = cash.r + r;
+      uint32_t cbits = 0;
+      if ((unsigned)cr < (unsigned)k.PR) {
+        int k0 = l.rowstart[cr], k1 = l.rowstart[cr + 1];
+        for (int i = k0; i < k1; ++i) {
+          int col = (int)l.coincol[i] - cash.c;
+          if ((unsigned)col < (unsigned)C && (coin_alive(l, lane, i) || (uint32_t)i == stale)) cbits |= 1u << col;
+        }
+      }
+      l.drows[(1 * (R + 1) + r) * WAVE + lane] = cbits;
+    }
+    l.drows[(0 * (R + 1) + R) * WAVE + lane] = 0;
+    l.drows[(1 * (R + 1) + R) * WAVE + lane] = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      int cell = paint_cell(k, w[s]);
+      l.scell[s * WAVE + lane] = cell;
+      bool on = on_board(k, w[s].vr, w[s].vc);
+      P.track[s * bp + env] = (on ? w[s].vr : 0) | ((on ? w[s].vc : 0) << 8) | (w[s].vis << 16) |
+                              ((int)do_reset << 24);
+    }
+  }
+  l.skip[lane] = skip;
+  __syncthreads();
+
+  // ---- phase B: the wavefront streams the observation planes ---------------
+  const int QW = k.QW, C = k.C, R = k.R, L = k.L, cells = k.cells, nz = k.n_things;
+  const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)cells;
+  uint8_t* blk = out.planes + (size_t)env0 * env_stride;
+  for (int it = 0; it < QW; ++it) {
+    uint32_t f = (uint32_t)it * WAVE + lane;
+    uint32_t e = (f * k.magic_q) >> 20;
+    uint32_t q = f - e * QW;
+    if (l.skip[e]) continue;
+    uint32_t cell0 = q * 4;
+    uint32_t r0 = (cell0 * k.magic_c) >> 20;
+    uint32_t c0 = cell0 - r0 * C;
+    uint32_t d = l.backdrop4[q];
+    for (int z = 0; z < nz; ++z) {  // engine.py:751-757, back to front
+      uint32_t ch4 = (uint32_t)k.z_ch[z] * 0x01010101u;
+      if (k.z_kind[z] == 0) {
+        int cell = l.scell[k.z_idx[z] * WAVE + e];
+        uint32_t m = (cell >= 0 && (uint32_t)(cell >> 2) == q) ? (0xFFu << ((cell & 3) * 8)) : 0u;
+        d = (d & ~m) | (ch4 & m);
+      } else {
+        const uint32_t* rows = l.drows + (k.z_idx[z] * (R + 1)) * WAVE;
+        uint32_t lo = rows[r0 * WAVE + e], hi = rows[(r0 + 1) * WAVE + e];
+        uint32_t bits = ((lo >> c0) | (uint32_t)((uint64_t)hi << (C - c0))) & 0xFu;
+        uint32_t m = ((bits * 0x00204081u) & 0x01010101u) * 0xFFu;
+        d = (d & ~m) | (ch4 & m);
+      }
+    }
+    uint32_t off = e * env_stride + q * 4;
+    *reinterpret_cast<uint32_t*>(blk + off) = d;
+    for (int pl = 0; pl < L; ++pl) {  // rendering.py:177-179: layer = (board == c)
+      uint32_t x = d ^ (k.chars[pl] * 0x01010101u);
+      uint32_t t = x + 0x7F7F7F7Fu;  // all bytes < 0x80: bit 7 of a byte stays clear iff byte == 0
+      uint32_t m = ((t >> 7) & 0x01010101u) ^ 0x01010101u;
+      off += cells;
+      *reinterpret_cast<uint32_t*>(blk + off) = m;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+
+static uint32_t magic20(uint32_t divisor, uint32_t max_numerator, bool* ok) {
+  uint32_t m = ((1u << 20) + divisor - 1) / divisor;
+  *ok = true;
+  for (uint32_t x = 0; x <= max_numerator; ++x)
+    if (((uint64_t)x * m) >> 20 != x / divisor || (uint64_t)x * m > 0xFFFFFFFFull) { *ok = false; break; }
+  return m;
+}
+
+class ScrollyMazeBackend : public Backend {
+ public:
+  int init(const pcx_template& t, int64_t batch) override;
+  int launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) override;
+  int read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) override;
+  int64_t bytes_per_step() const override {
+    // action 4 + state words read+write 2*4*NW + planes (1+L)*cells + results 4+1+4+1+4+1
+    return 4 + 8 * (int64_t)k_.NW + (int64_t)(1 + k_.L) * k_.cells + 15;
+  }
+  const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
+  const int32_t* sprite_track() const override { return track_.ptr; }
+
+ private:
+  Consts k_{};
+  int64_t batch_ = 0, bpad_ = 0;
+  DevArray<Consts> dk_;
+  DevArray<uint32_t> walls_, backdrop4_, state_;
+  DevArray<uint16_t> rowstart_;
+  DevArray<uint8_t> coincol_;
+  DevArray<int32_t> track_;
+  std::vector<uint8_t> walls_pattern_, coin_pattern_;  // host copies for read_things
+  std::vector<uint16_t> h_rowstart_;
+  std::vector<uint8_t> h_coincol_;
+  int maze_di_ = 0, cash_di_ = 0;
+};
+
+int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
+  Consts& k = k_;
+  batch_ = batch;
+  bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
+  if (!t.occlusion_in_layers)
+    return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: occlusion_in_layers=False is not supported yet");
+  if (t.n_drapes != 2 || t.n_sprites < 1 || t.n_sprites > MAX_NS)
+    return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: expects 2 Scrolly drapes and 1..%d sprites", MAX_NS);
+  k.R = t.rows; k.C = t.cols; k.cells = t.rows * t.cols; k.L = t.n_chars; k.NS = t.n_sprites;
+  k.n_things = t.n_things; k.n_actions = t.n_actions;
+  if (k.C > 32 || k.cells % 4 != 0 || k.L > MAX_L || k.n_things > MAX_Z || k.cells > 4096)
+    return set_error(PCX_E_UNSUPPORTED,
+                     "scrolly_maze backend: needs cols <= 32, rows*cols %% 4 == 0, <= %d characters", MAX_L);
+  k.QW = k.cells / 4;
+  bool ok1, ok2;
+  k.magic_q = magic20(k.QW, WAVE * k.QW, &ok1);
+  k.magic_c = magic20(k.C, k.cells, &ok2);
+  if (!ok1 || !ok2) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: board too large for 20-bit reciprocal");
+  for (int i = 0; i < k.L; ++i) k.chars[i] = t.chars[i];
+
+  maze_di_ = cash_di_ = -1;
+  for (int i = 0; i < 2; ++i) {
+    if (!t.drapes[i].is_scrolly) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: drapes must be Scrolly");
+    if (t.drapes[i].program == PCX_PROG_SM_MAZE) maze_di_ = i;
+    if (t.drapes[i].program == PCX_PROG_SM_CASH) cash_di_ = i;
+  }
+  if (maze_di_ < 0 || cash_di_ < 0) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: need one MazeDrape and one CashDrape");
+  const pcx_drape_desc& md = t.drapes[maze_di_];
+  const pcx_drape_desc& cd = t.drapes[cash_di_];
+  if (md.pattern_rows != cd.pattern_rows || md.pattern_cols != cd.pattern_cols ||
+      md.have_margins != cd.have_margins || md.margin_rows != cd.margin_rows || md.margin_cols != cd.margin_cols)
+    return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: both Scrolly drapes must share pattern size and margins");
+  k.PR = md.pattern_rows; k.PC = md.pattern_cols; k.WPR = (k.PC + 31) / 32 + 1;  // +1: window reads 2 words
+  if (k.PR > 1024 || k.PC > 255) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: pattern larger than 1024x255");
+  k.lim_r = k.PR - k.R; k.lim_c = k.PC - k.C;
+  k.have_margins = md.have_margins;
+  k.margin_n = md.margin_rows - 1; k.margin_s = k.R - md.margin_rows;  // drapes.py:355-358
+  k.margin_w = md.margin_cols - 1; k.margin_e = k.C - md.margin_cols;
+  k.maze_ch = md.ch; k.cash_ch = cd.ch;
+
+  // update schedule must be [maze] [sprites...] [cash]
+  if (t.n_groups != 3 || t.n_things != t.n_sprites + 2 || t.schedule[0] != md.ch || t.group_of[0] != 0 ||
+      t.schedule[t.n_things - 1] != cd.ch || t.group_of[t.n_things - 1] != 2)
+    return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: update schedule must be [[maze],[sprites...],[cash]]");
+  k.ip = k.ie = -1;
+  for (int s = 0; s < t.n_sprites; ++s) {
+    const pcx_sprite_desc& sd = t.sprites[s];
+    if (t.schedule[1 + s] != sd.ch || t.group_of[1 + s] != 1 || !sd.is_walker)
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: sprites must be MazeWalkers scheduled in insertion order in group 1");
+    k.prog[s] = sd.program; k.confined[s] = sd.confined; k.egocentric[s] = sd.egocentric; k.sprite_ch[s] = sd.ch;
+    if (sd.program == PCX_PROG_SM_PLAYER) {
+      if (k.ip >= 0) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: one player only");
+      k.ip = s;
+    } else if (sd.program != PCX_PROG_SM_PATROLLER) {
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: unknown sprite program %d", sd.program);
+    }
+    if (sd.egocentric) {
+      if (k.ie >= 0) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: at most one egocentric sprite");
+      k.ie = s;
+    }
+    for (int j = 0; j < 4; ++j) memcpy(&k.imp[s][j], sd.impassable + 4 * j, 4);
+  }
+  if (k.ip < 0 || t.sprites[k.ip].ch != 'P')
+    return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the player sprite must paint 'P' (things['P'] lookups)");
+  if (md.ch != '#') return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the maze drape must paint '#' (things['#'] lookups)");
+
+  // z-order tables and, per walker, which things can change a probe's verdict
+  auto imp_has = [&](int s, int ch) { return (k.imp[s][ch >> 5] >> (ch & 31)) & 1; };
+  for (int z = 0; z < t.n_things; ++z) {
+    int ch = t.z_order[z], idx = -1, kind = 0;
+    for (int s = 0; s < t.n_sprites; ++s) if (t.sprites[s].ch == ch) { idx = s; kind = 0; }
+    if (ch == md.ch) { idx = 0; kind = 1; }
+    if (ch == cd.ch) { idx = 1; kind = 1; }
+    if (idx < 0) return set_error(PCX_E_INVALID, "z_order names an unknown character");
+    k.z_kind[z] = kind; k.z_idx[z] = idx; k.z_ch[z] = ch;
+  }
+  for (int s = 0; s < t.n_sprites; ++s) {
+    bool back_imp = false;
+    for (int i = 0; i < t.rows * t.cols; ++i) back_imp |= imp_has(s, t.backdrop[i]);
+    k.relevant_backdrop[s] = back_imp;
+    uint32_t rel = 0;
+    bool deeper_matters = back_imp;  // walking back to front
+    for (int z = 0; z < t.n_things; ++z) {
+      int bit = k.z_kind[z] ? t.n_sprites + k.z_idx[z] : k.z_idx[z];
+      bool mine = imp_has(s, k.z_ch[z]);
+      if (mine || deeper_matters) rel |= 1u << bit;
+      deeper_matters |= mine;
+    }
+    k.relevant[s] = rel;
+  }
+
+  // patterns: walls as bit-rows; coins as a row-major list
+  walls_pattern_.assign(md.pattern, md.pattern + (size_t)k.PR * k.PC);
+  coin_pattern_.assign(cd.pattern, cd.pattern + (size_t)k.PR * k.PC);
+  std::vector<uint32_t> wb((size_t)k.PR * k.WPR, 0);
+  for (int r = 0; r < k.PR; ++r)
+    for (int c = 0; c < k.PC; ++c)
+      if (md.pattern[(size_t)r * k.PC + c]) wb[(size_t)r * k.WPR + (c >> 5)] |= 1u << (c & 31);
+  h_rowstart_.assign(k.PR + 2, 0);
+  h_coincol_.clear();
+  for (int r = 0; r < k.PR; ++r) {
+    h_rowstart_[r] = (uint16_t)h_coincol_.size();
+    for (int c = 0; c < k.PC; ++c)
+      if (cd.pattern[(size_t)r * k.PC + c]) h_coincol_.push_back((uint8_t)c);
+  }
+  h_rowstart_[k.PR] = h_rowstart_[k.PR + 1] = (uint16_t)h_coincol_.size();
+  k.n_coins = (int)h_coincol_.size();
+  if (k.n_coins > 65000) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: too many coins");
+  k.CW = (k.n_coins + 31) / 32;
+  k.NW = W_SPOS + k.NS + k.CW;
+  std::vector<uint8_t> cc = h_coincol_;
+  cc.resize((cc.size() + 7) / 4 * 4, 0);
+  std::vector<uint16_t> rs = h_rowstart_;
+  rs.resize((rs.size() + 3) / 2 * 2, 0);
+  std::vector<uint32_t> bd4(k.QW);
+  memcpy(bd4.data(), t.backdrop, k.cells);
+
+  // initial state words (what the constructors left: ascii_art.py:247-277)
+  memset(k.init, 0, sizeof k.init);
+  k.init[W_FRAME] = (uint32_t)-1;  // plot.py: frame starts at -1, play() makes it 0
+  k.init[W_FLAGS] = 0;
+  k.init[W_PERMIT_FRAME] = 0;
+  k.init[W_MAZE] = ((uint32_t)md.corner_row & 0xFFFFu) | ((uint32_t)md.corner_col << 16);
+  k.init[W_CASH] = ((uint32_t)cd.corner_row & 0xFFFFu) | ((uint32_t)cd.corner_col << 16);
+  k.init[W_STALE] = STALE_NONE;
+  uint32_t sf = 0;
+  for (int s = 0; s < t.n_sprites; ++s) {
+    const pcx_sprite_desc& sd = t.sprites[s];
+    k.init[W_SPOS + s] = ((uint32_t)sd.vrow & 0xFFFFu) | ((uint32_t)sd.vcol << 16);
+    uint32_t var = sd.program == PCX_PROG_SM_PATROLLER ? (sd.ch & 1u) : 0u;  // scrolly_maze.py:282
+    sf |= ((uint32_t)(sd.visible != 0) | ((uint32_t)(sd.prior_visible != 0) << 1) | (var << 2)) << (8 * s);
+  }
+  k.init[W_SFLAGS] = sf;
+  // the initial curtains must be the pattern windows the Scrolly ctor made
+  for (int di = 0; di < 2; ++di) {
+    const pcx_drape_desc& d = t.drapes[di];
+    for (int r = 0; r < k.R; ++r)
+      for (int c = 0; c < k.C; ++c)
+        if (d.curtain[r * k.C + c] != d.pattern[(size_t)(d.corner_row + r) * k.PC + d.corner_col + c])
+          return set_error(PCX_E_INVALID, "scrolly_maze backend: drape curtain is not the pattern window");
+  }
+
+  // LDS layout
+  int off = 0;
+  k.lds_walls = off; off += k.PR * k.WPR;
+  k.lds_backdrop = off; off += k.QW;
+  k.lds_rowstart = off; off += (int)rs.size() / 2;
+  k.lds_coincol = off; off += (int)cc.size() / 4;
+  k.lds_drows = off; off += 2 * (k.R + 1) * WAVE;
+  k.lds_scell = off; off += k.NS * WAVE;
+  k.lds_cmask = off; off += (k.CW ? k.CW : 1) * WAVE;
+  k.lds_skip = off; off += WAVE;
+  k.lds_words = off;
+  if (off * 4 > 64 * 1024) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: template needs %d bytes of LDS", off * 4);
+
+  int rc;
+  if ((rc = dk_.upload(std::vector<Consts>(1, k)))) return rc;
+  if ((rc = walls_.upload(wb))) return rc;
+  if ((rc = backdrop4_.upload(bd4))) return rc;
+  if ((rc = rowstart_.upload(rs))) return rc;
+  if ((rc = coincol_.upload(cc))) return rc;
+  if ((rc = state_.alloc((size_t)k.NW * bpad_))) return rc;
+  if ((rc = track_.alloc((size_t)k.NS * bpad_))) return rc;
+  return 0;
+}
+
+int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) {
+  Ptrs P{dk_.ptr, walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, batch_, bpad_};
+  dim3 grid((unsigned)(bpad_ / WAVE)), block(WAVE);
+  size_t lds = (size_t)k_.lds_words * 4;
+  switch (k_.NS) {
+#define PCX_SM_CASE(n) case n: hipLaunchKernelGGL(pcx_scrolly_maze_step<n>, grid, block, lds, s, P, a, out); break;
+    PCX_SM_CASE(1) PCX_SM_CASE(2) PCX_SM_CASE(3) PCX_SM_CASE(4) PCX_SM_CASE(5) PCX_SM_CASE(6)
+#undef PCX_SM_CASE
+    default: return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: %d sprites", k_.NS);
+  }
+  PCX_HIP(hipGetLastError());
+  return 0;
+}
+
+int ScrollyMazeBackend::read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) {
+  const Consts& k = k_;
+  std::vector<uint32_t> st((size_t)k.NW * n);
+  PCX_HIP(hipDeviceSynchronize());
+  for (int w = 0; w < k.NW; ++w)
+    PCX_HIP(hipMemcpy(st.data() + (size_t)w * n, state_.ptr + (size_t)w * bpad_ + env0, n * 4, hipMemcpyDeviceToHost));
+  auto word = [&](int w, int64_t i) { return st[(size_t)w * n + i]; };
+  for (int64_t i = 0; i < n; ++i) {
+    if (sprites)
+      for (int s = 0; s < k.NS; ++s) {
+        pcx_sprite_state& o = sprites[i * k.NS + s];
+        memset(&o, 0, sizeof o);
+        uint32_t pw = word(W_SPOS + s, i);
+        o.vrow = (int16_t)(pw & 0xFFFF); o.vcol = (int16_t)(pw >> 16);
+        bool on = o.vrow >= 0 && o.vrow < k.R && o.vcol >= 0 && o.vcol < k.C;
+        o.row = on ? o.vrow : 0; o.col = on ? o.vcol : 0;
+        o.visible = (word(W_SFLAGS, i) >> (8 * s)) & 1;
+      }
+    if (curtains) {
+      for (int di = 0; di < 2; ++di) {
+        bool is_maze = di == maze_di_;
+        uint32_t cw = word(is_maze ? W_MAZE : W_CASH, i);
+        int cr = (int16_t)(cw & 0xFFFF), cc = (int16_t)(cw >> 16);
+        uint8_t* dst = curtains + ((size_t)i * 2 + di) * k.cells;
+        uint32_t stale = word(W_STALE, i);
+        for (int r = 0; r < k.R; ++r)
+          for (int c = 0; c < k.C; ++c) {
+            int pr = cr + r, pc = cc + c;
+            uint8_t v = 0;
+            if (pr >= 0 && pr < k.PR && pc >= 0 && pc < k.PC) {
+              if (is_maze) v = walls_pattern_[(size_t)pr * k.PC + pc];
+              else
+                for (int id = h_rowstart_[pr]; id < h_rowstart_[pr + 1]; ++id)
+                  if (h_coincol_[id] == pc)
+                    v = ((word(W_SPOS + k.NS + (id >> 5), i) >> (id & 31)) & 1) || (uint32_t)id == stale;
+            }
+            dst[r * k.C + c] = v;
+          }
+      }
+    }
+  }
+  return 0;
+}
+
+}  // namespace sm
+
+Backend* make_scrolly_maze_backend() { return new sm::ScrollyMazeBackend(); }
+
+}  // namespace pcx

@@ -1,0 +1,126 @@
+"""GPU parity tests: the HIP step path (through the C ABI) against
+(1) golden traces recorded from the imported reference, and
+(2) the CPU oracle on seeded inputs, and
+(3) size-independent properties at the BASELINE batch sizes."""
+import numpy as np
+import pytest
+
+from oracle import binding
+from tests import helpers
+from tests.hip_adapter import HipAdapter
+
+pytestmark = pytest.mark.gpu
+
+LEVELS = ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2']
+
+
+class OracleAdapter(binding.OracleEngine):
+
+  def read(self, name):
+    return np.array(getattr(self, name))
+
+
+def assert_same(hip, orc, where):
+  for name in ('planes', 'reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+    np.testing.assert_array_equal(hip.read(name), orc.read(name), err_msg='%s: %s' % (where, name))
+  np.testing.assert_array_equal(hip.sprites(), orc.sprites(), err_msg=where + ': sprites')
+  np.testing.assert_array_equal(hip.curtains(), orc.curtains(), err_msg=where + ': curtains')
+
+
+@pytest.mark.parametrize('name', LEVELS)
+def test_hip_matches_reference_trace(name):
+  helpers.replay_trace(HipAdapter, helpers.load_trace(name))
+
+
+@pytest.mark.parametrize('name', LEVELS)
+def test_hip_matches_oracle_hashed_actions(name):
+  """4096 envs x 256 steps, uniform actions from the shared counter hash,
+  resets included; every output compared every 8 steps and at the end."""
+  t = helpers.load_template(name)
+  B, T = 4096, 256
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  assert_same(hip, orc, 'frame 0')
+  resets = 0
+  for t0 in range(0, T, 8):
+    hip.step_hashed(0x5EED, t0, 8); orc.step_hashed(0x5EED, t0, 8)
+    assert_same(hip, orc, 'after step %d' % (t0 + 8))
+    resets += int(orc.read('done').sum())
+  assert resets > 0  # the reset path was exercised
+
+
+def test_hip_matches_oracle_quirky_actions():
+  """Explicit action tapes with None / quit / out-of-range actions and no
+  auto-reset (finished environments stay frozen)."""
+  t = helpers.load_template('scrolly_maze_L1')
+  B, T = 512, 160
+  rng = np.random.RandomState(3)
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  for step in range(T):
+    a = rng.randint(0, 5, size=B).astype(np.int32)
+    r = rng.rand(B)
+    a[r < 0.04] = -1
+    a[(r >= 0.04) & (r < 0.05)] = 5
+    a[(r >= 0.05) & (r < 0.08)] = rng.randint(6, 40)
+    auto = step % 3 != 0
+    hip.step(a, auto_reset=auto); orc.step(a, auto_reset=auto)
+    assert_same(hip, orc, 'step %d' % step)
+
+
+def test_full_batch_properties():
+  """BASELINE size (scrolly_maze L0, 1,048,576 envs on one GPU): shard
+  invariance against a small oracle run, and layer/board consistency."""
+  import torch
+  t = helpers.load_template('scrolly_maze_L0')
+  B, T, K = 1 << 20, 48, 2048
+  hip = HipAdapter(t, B)
+  orc = OracleAdapter(t, K)
+  hip.reset(); orc.reset()
+  hip.step_hashed(0xC0FFEE, 0, T); orc.step_hashed(0xC0FFEE, 0, T)
+  planes = hip.eng.planes.tensor
+  assert planes is not None and planes.is_cuda
+  # environments are independent: the first K of the big batch == a K batch
+  np.testing.assert_array_equal(planes[:K].cpu().numpy(), orc.read('planes'))
+  for name in ('reward', 'reward_set', 'discount', 'done', 'frame'):
+    np.testing.assert_array_equal(hip.eng.buffers[name].tensor[:K].cpu().numpy(), orc.read(name))
+  # ... and the last K of the big batch == a K batch offset by B-K
+  orc2 = OracleAdapter(t, K)
+  orc2.reset(); orc2.step_hashed(0xC0FFEE, 0, T, env_offset=B - K)
+  np.testing.assert_array_equal(planes[B - K:].cpu().numpy(), orc2.read('planes'))
+  # occluded layers partition the board: exactly one layer set per cell, and
+  # layer k is set exactly where board == chars[k] (rendering.py:177-179)
+  board = planes[:, 0]
+  chars = torch.tensor(list(t.chars), dtype=torch.uint8, device=planes.device)
+  for lo in range(0, B, 1 << 17):
+    chunk = planes[lo:lo + (1 << 17)]
+    want = (chunk[:, :1] == chars.view(1, -1, 1, 1)).to(torch.uint8)
+    assert torch.equal(chunk[:, 1:], want)
+  assert not hip.eng.buffers['error'].tensor.any()
+  del board
+
+
+def test_engine_facade_batch1_matches_trace():
+  """`Engine.play()` with batch 1 returns the reference's types and values."""
+  tr = helpers.load_trace('scrolly_maze_L0')
+  t = helpers.load_template('scrolly_maze_L0')
+  from pycolab_amd.engine import Engine
+  e = 5  # one environment of the trace
+  eng = Engine.from_template(t, batch=1)
+  obs, reward, discount = eng.its_showtime()
+  np.testing.assert_array_equal(obs.board, tr['boards'][0, e])
+  assert reward is None and discount == 1.0 and obs.board.shape == (t.rows, t.cols)
+  assert obs.layers['#'].dtype == np.bool_
+  for step in range(tr['actions'].shape[0]):
+    if eng.game_over:
+      with pytest.raises(RuntimeError):
+        eng.play(0)
+      break
+    a = int(tr['actions'][step, e])
+    obs, reward, discount = eng.play(None if a < 0 else a)
+    np.testing.assert_array_equal(obs.board, tr['boards'][step + 1, e])
+    want_r = int(tr['reward'][step + 1, e]) if tr['reward_set'][step + 1, e] else None
+    assert reward == want_r and discount == float(tr['discount'][step + 1, e])
+    for c in t.chars:
+      np.testing.assert_array_equal(obs.layers[chr(c)], obs.board == c)
+    assert eng.the_plot.frame == step + 1

@@ -1,0 +1,154 @@
+"""CPU tests of the host-side API surface (no GPU, no compute calls)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from pycolab_amd import _native as N
+from pycolab_amd import ascii_art, compat, engine, programs, things
+from pycolab_amd.compiler import GameTemplate
+from pycolab_amd.prefab_parts import drapes as prefab_drapes
+from pycolab_amd.prefab_parts import sprites as prefab_sprites
+from tests import helpers
+
+REF_EXAMPLES = '/root/reference/pycolab/examples'
+needs_reference = pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES),
+                                     reason='reference checkout not present')
+
+
+def test_library_exports_every_declared_symbol():
+  """libpcx.so loads and exports every symbol include/pcx.h declares."""
+  lib = ctypes.CDLL(N.LIB_PATH)
+  header = open(os.path.join(helpers.ROOT, 'include', 'pcx.h')).read()
+  import re
+  declared = set(re.findall(r'\b(pcx_[a-z0-9_]+)\s*\(', header))
+  declared -= {'pcx_cropper_'}
+  bound = {name for name, _, _ in N.SYMBOLS}
+  assert declared == bound, (declared ^ bound)
+  for name in declared:
+    assert hasattr(lib, name), name
+  assert N.lib().pcx_abi_version() == N.ABI_VERSION
+  assert N.lib().pcx_action_hash(1, 2, 3) == __import__('oracle.binding', fromlist=['x']).action_hash(1, 2, 3)
+
+
+def test_ctypes_struct_sizes_match_header():
+  """Compile a probe against include/pcx.h and compare struct sizes."""
+  import subprocess, tempfile
+  src = ('#include "pcx.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+         'sizeof(pcx_sprite_desc),sizeof(pcx_drape_desc),sizeof(pcx_template),sizeof(pcx_buffers),'
+         'sizeof(pcx_sprite_state),sizeof(pcx_cropper_desc));return 0;}')
+  with tempfile.TemporaryDirectory() as d:
+    open(os.path.join(d, 'p.c'), 'w').write(src)
+    subprocess.check_call(['gcc', '-I', os.path.join(helpers.ROOT, 'include'), '-o',
+                           os.path.join(d, 'p'), os.path.join(d, 'p.c')])
+    got = [int(x) for x in subprocess.check_output([os.path.join(d, 'p')]).split()]
+  want = [ctypes.sizeof(c) for c in (N.SpriteDesc, N.DrapeDesc, N.Template, N.Buffers,
+                                     N.SpriteState, N.CropperDesc)]
+  assert got == want
+
+
+def test_ascii_art_errors():
+  """Restates tests/ascii_art_test.py:33-58 plus ascii_art.py:163-212 guards."""
+  ascii_art.ascii_art_to_uint8_nparray(['ab', 'ba'])
+  with pytest.raises(ValueError, match='except for the concatenation axis must match exactly'):
+    ascii_art.ascii_art_to_uint8_nparray(['ab', 'bab'])
+  with pytest.raises(TypeError, match='the argument to ascii_art_to_uint8_nparray must be a list'):
+    ascii_art.ascii_art_to_uint8_nparray(['a', 2])
+  with pytest.raises(TypeError, match='Did you pass a list of list of single characters?'):
+    ascii_art.ascii_art_to_uint8_nparray([['a', 'b'], ['b', 'a']])
+  art = ['ab', 'ba']
+  two = {'a': things.Sprite, 'b': things.Sprite}
+  with pytest.raises(TypeError):   # mixed nesting in update_schedule
+    ascii_art.ascii_art_to_game(art, ' ', sprites=two, update_schedule=[['a'], 7])
+  with pytest.raises(ValueError):  # schedule must list everything once
+    ascii_art.ascii_art_to_game(art, ' ', sprites=two, update_schedule='a')
+  with pytest.raises(ValueError):  # z_order must list everything once
+    ascii_art.ascii_art_to_game(art, ' ', sprites=two, z_order='a')
+  with pytest.raises(ValueError):  # what_lies_beneath: one char or art
+    ascii_art.ascii_art_to_game(art, 'xy', sprites=two)
+  with pytest.raises(ValueError):  # beneath must not be a thing's char
+    ascii_art.ascii_art_to_game(art, 'a', sprites=two)
+  with pytest.raises(ValueError):  # a sprite may appear once
+    ascii_art.ascii_art_to_game(art, ' ', sprites=two)
+  with pytest.raises(TypeError):
+    ascii_art.Partial(int)
+
+
+def test_engine_builder_errors():
+  """engine.py:851-874 guards."""
+  e = engine.Engine(3, 4)
+  e.set_backdrop('. ', things.Backdrop)
+  with pytest.raises(RuntimeError):
+    e.set_backdrop('x', things.Backdrop)          # second backdrop
+  with pytest.raises(RuntimeError):
+    e.add_sprite('.', (0, 0), things.Sprite)      # claimed by backdrop
+  with pytest.raises(TypeError):
+    e.add_sprite('s', (0, 0), things.Drape)
+  with pytest.raises(ValueError):
+    e.add_sprite('s', (3, 0), things.Sprite)      # off-board
+  with pytest.raises(ValueError):
+    e.add_sprite('ss', (0, 0), things.Sprite)
+  e.add_sprite('s', (1, 1), things.Sprite)
+  with pytest.raises(ValueError):
+    e.set_z_order('sx')
+  with pytest.raises(RuntimeError):
+    e.play(0)                                     # before its_showtime
+
+
+def test_unknown_entity_class_fails_loudly():
+  class Mystery(things.Sprite):
+    def update(self, actions, board, layers, backdrop, things, the_plot):
+      self._position = self.Position(0, 0)
+  game = ascii_art.ascii_art_to_game(['m.'], '.', sprites={'m': Mystery})
+  with pytest.raises(programs.UnsupportedEntityError):
+    game.its_showtime()
+
+
+def test_maze_walker_constructor_semantics():
+  corner = things.Sprite.Position(5, 5)
+  with pytest.raises(ValueError):
+    prefab_sprites.MazeWalker(corner, things.Sprite.Position(1, 1), 'x', 'x#')
+  w = prefab_sprites.MazeWalker(corner, things.Sprite.Position(1, 1), 'x', '#')
+  w._teleport((-3, 2))
+  assert w.position == (0, 0) and w.virtual_position == (-3, 2) and not w.visible
+  w._teleport((2, 2))
+  assert w.position == (2, 2) and w.visible and w.on_the_board
+  with pytest.raises(NotImplementedError):
+    w._north(None, None)
+
+
+def test_palette():
+  p = engine.Palette('#. _')
+  assert p.hash == ord('#') and p['.'] == ord('.') and p._ == ord('_') and '#' in p
+  with pytest.raises(AttributeError):
+    p.at  # pylint: disable=pointless-statement
+  with pytest.raises(IndexError):
+    p['@']  # pylint: disable=pointless-statement
+
+
+def test_template_roundtrip(tmp_path):
+  t = helpers.load_template('scrolly_maze_L0')
+  path = str(tmp_path / 't.npz')
+  t.save(path)
+  assert GameTemplate.load(path) == t
+  ct, keep = t.to_ctypes()
+  assert ct.rows == 10 and ct.cols == 30 and ct.n_sprites == 4 and ct.n_drapes == 2
+  assert bytes(ct.z_order[:6]) == b'abc@#P' and bytes(ct.schedule[:6]) == b'#abcP@'
+  assert list(ct.group_of[:6]) == [0, 1, 1, 1, 1, 2] and ct.n_groups == 3
+  assert bytes(ct.chars[:ct.n_chars]) == bytes(sorted(b' #.@Pabc'))
+
+
+@needs_reference
+@pytest.mark.parametrize('level', [0, 1, 2])
+def test_unchanged_reference_example_compiles_to_fixture(level):
+  """The shipped example file, loaded unchanged with `pycolab` aliased to this
+  package, builds the same template as the committed fixture."""
+  mod = compat.load_game_module(os.path.join(REF_EXAMPLES, 'scrolly_maze.py'))
+  game = mod.make_game(level)
+  assert isinstance(game, engine.Engine)
+  assert isinstance(game.things['P'], prefab_sprites.MazeWalker)
+  assert isinstance(game.things['#'], prefab_drapes.Scrolly)
+  t = GameTemplate.from_engine(game)
+  assert t == helpers.load_template('scrolly_maze_L%d' % level)
+  assert t.game == N.GAME_SCROLLY_MAZE and t.n_actions == 5
