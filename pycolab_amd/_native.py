@@ -146,6 +146,8 @@ def lib():
           '{} is missing: build it with `python __graft_entry__.py build` (or '
           '`make -C pycolab_amd/csrc`). pycolab_amd has no CPU fallback.'.format(
               LIB_PATH))
+    from pycolab_amd import _torchprobe
+    _torchprobe.torch_module()  # settle which HIP runtime the process uses first
     _lib = bind(ctypes.CDLL(LIB_PATH), SYMBOLS)
     if _lib.pcx_abi_version() != ABI_VERSION:
       raise NativeLibraryMissing('libpcx.so ABI version mismatch; rebuild it')

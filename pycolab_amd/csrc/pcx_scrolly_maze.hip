@@ -30,6 +30,7 @@
 
 #include <cstdarg>
 #include <cstring>
+#include <type_traits>
 
 namespace pcx {
 namespace sm {
@@ -70,12 +71,12 @@ struct Consts {
   // z-order, back to front
   int32_t z_kind[MAX_Z], z_idx[MAX_Z], z_ch[MAX_Z];
   // LDS layout (word offsets)
-  int32_t lds_walls, lds_backdrop, lds_rowstart, lds_coincol, lds_drows, lds_scell, lds_cmask,
+  int32_t FW;  // words of one flat curtain bit-vector (cells bits + 1 spill word)
+  int32_t lds_walls, lds_backdrop, lds_rowstart, lds_coincol, lds_flat, lds_sdesc, lds_cmask,
       lds_skip, lds_words;
 };
 
 struct Ptrs {
-  const Consts* k;
   const uint32_t* walls_bits;   // [PR][WPR]
   const uint32_t* backdrop4;    // [QW] backdrop as dwords
   const uint16_t* coin_rowstart;  // [PR+1]
@@ -124,8 +125,8 @@ struct Lds {
   const uint32_t* backdrop4;
   const uint16_t* rowstart;
   const uint8_t* coincol;
-  uint32_t* drows;  // [2][R+1][64]
-  int32_t* scell;   // [NS][64]
+  uint32_t* flat;   // [2][FW][64] curtains as flat cell-bit vectors
+  uint2* sdesc;     // [NS][64] sprite paint descriptors {dword index q, byte mask}
   uint32_t* cmask;  // [CW][64]
   uint32_t* skip;   // [64]
 };
@@ -174,7 +175,8 @@ __device__ __forceinline__ bool blocked_at(const Consts& k, const Lds& l, const 
     present |= (uint32_t)there << (NS + 1);
   }
   int top = -1;
-  for (int z = 0; z < k.n_things; ++z) {  // back to front: the last hit wins
+#pragma unroll
+  for (int z = 0; z < NS + 2; ++z) {  // back to front: the last hit wins (n_things == NS + 2)
     int bit = k.z_kind[z] ? NS + k.z_idx[z] : k.z_idx[z];
     if ((present >> bit) & 1) top = k.z_ch[z];
   }
@@ -182,7 +184,11 @@ __device__ __forceinline__ bool blocked_at(const Consts& k, const Lds& l, const 
     if (!k.relevant_backdrop[s]) return false;
     top = (l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
   }
-  return (k.imp[s][top >> 5] >> (top & 31)) & 1;
+  // static word selects: a runtime index into the kernarg struct would force
+  // the compiler to spill the whole struct to scratch
+  const uint32_t hi = (uint32_t)top >> 5;
+  const uint32_t word = hi == 0 ? k.imp[s][0] : hi == 1 ? k.imp[s][1] : hi == 2 ? k.imp[s][2] : k.imp[s][3];
+  return (word >> (top & 31)) & 1;
 }
 
 // sprites.py:479-546 _check_motion
@@ -302,13 +308,42 @@ __device__ __forceinline__ uint32_t pack_pos(int r, int c) { return ((uint32_t)r
 __device__ __forceinline__ int pos_r(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
 __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16); }
 
-template <int NS>
-__global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(Ptrs P, StepArgs a, pcx_buffers out) {
+// Compile-time loop: f(std::integral_constant<int, I>) for I in [0, N).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Walker `FIXED` when it is known at compile time, else a select chain.
+template <int NS, int FIXED>
+__device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
+  if constexpr (FIXED >= 0) {
+    return w[FIXED];
+  } else {
+    Walker r = w[0];
+#pragma unroll
+    for (int j = 1; j < NS; ++j) if (j == dyn) r = w[j];
+    return r;
+  }
+}
+
+// NS sprites.  SR/SC/SL: board rows, cols and layer count when known at
+// compile time (0 = take them from Consts); IP/IE: index of the player and of
+// the egocentric sprite when known at compile time (-1 = from Consts).
+template <int NS, int SR, int SC, int SL, int IP, int IE>
+__global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
+                                                              const pcx_buffers out) {
   extern __shared__ uint32_t lds_raw[];
-  const Consts& k = *P.k;
+  constexpr int NZ = NS + 2;
   const int lane = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * WAVE;
   const int64_t env = env0 + lane;
+  const int R = SR ? SR : k.R, C = SC ? SC : k.C, L = SL ? SL : k.L;
+  const int cells = R * C, QW = cells >> 2;
+  const int FW = SR ? (SR * SC + 31) / 32 + 1 : k.FW;
 
   Lds l;
   uint32_t* lw = lds_raw + k.lds_walls;
@@ -319,14 +354,14 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(Ptrs P, StepArgs a
   l.backdrop4 = lb;
   l.rowstart = reinterpret_cast<const uint16_t*>(lr);
   l.coincol = reinterpret_cast<const uint8_t*>(lc);
-  l.drows = lds_raw + k.lds_drows;
-  l.scell = reinterpret_cast<int32_t*>(lds_raw + k.lds_scell);
+  l.flat = lds_raw + k.lds_flat;
+  l.sdesc = reinterpret_cast<uint2*>(lds_raw + k.lds_sdesc);
   l.cmask = lds_raw + k.lds_cmask;
   l.skip = lds_raw + k.lds_skip;
 
   // ---- stage the shared template constants into LDS (from L2) -------------
   for (int i = lane; i < k.PR * k.WPR; i += WAVE) lw[i] = P.walls_bits[i];
-  for (int i = lane; i < k.QW; i += WAVE) lb[i] = P.backdrop4[i];
+  for (int i = lane; i < QW; i += WAVE) lb[i] = P.backdrop4[i];
   {
     const uint32_t* rs = reinterpret_cast<const uint32_t*>(P.coin_rowstart);
     const uint32_t* cc = reinterpret_cast<const uint32_t*>(P.coin_col);
@@ -358,13 +393,13 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(Ptrs P, StepArgs a
   }
   __syncthreads();  // LDS constants visible
 
-  Walker w[NS];
-  Scrolly maze, cash;
-  Plot p;
-  uint32_t stale;
-  uint32_t err = do_reset ? 0u : (flags >> F_ERR_SHIFT) & 7u;  // sticky within an episode
-  bool coins_dirty = false;
   if (!skip) {
+    Walker w[NS];
+    Scrolly maze, cash;
+    Plot p;
+    uint32_t stale;
+    uint32_t err = do_reset ? 0u : (flags >> F_ERR_SHIFT) & 7u;  // sticky within an episode
+    bool coins_dirty = false;
     // load (or rebuild) the state words
     uint32_t sflags, spos[NS], mz, cs;
     if (do_reset) {  // engine.py:520-581 its_showtime: fresh template state
@@ -419,41 +454,38 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(Ptrs P, StepArgs a
     sn.cash_r = cash.r; sn.cash_c = cash.c; sn.stale = stale;
 
     // group 0: MazeDrape.update (scrolly_maze.py:317-329)
-    Walker ego = w[0];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) if (s == k.ie) ego = w[s];
-    if (moves) maybe_move(k, maze, p, ego, dr, dc, err);
+    if (moves) maybe_move(k, maze, p, pick<NS, IE>(w, k.ie), dr, dc, err);
     sn.maze_r = maze.r; sn.maze_c = maze.c;  // repaint #1: walls already scrolled
 
     // group 1: sprites in insertion order, all reading repaint #1
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (k.prog[s] == PCX_PROG_SM_PATROLLER) {  // scrolly_maze.py:284-305
-        if (p.frame & 1) {
-          mw_move<NS>(k, l, sn, s, w[s], p, 0, 0, lane, err);
-        } else {
-          // drapes.py:405-411 pattern_position_prescroll on the walls drape
-          if (!maze.moved) { maze.pre_r = maze.r; maze.pre_c = maze.c; }
-          int pr = w[s].vr + maze.pre_r, pc = w[s].vc + maze.pre_c + (w[s].var ? 1 : -1);
-          if (pr < 0) pr += k.PR;  // numpy negative-index wrap
-          if (pc < 0) pc += k.PC;
-          if (wall_at(k, l, pr, pc, err)) w[s].var ^= 1;
-          mw_move<NS>(k, l, sn, s, w[s], p, 0, w[s].var ? 1 : -1, lane, err);
-          Walker pl = w[0];
-#pragma unroll
-          for (int j = 0; j < NS; ++j) if (j == k.ip) pl = w[j];
-          if (w[s].vr == pl.vr && w[s].vc == pl.vc) { p.game_over = 1; p.discount = 0.0f; }
-        }
-      } else {  // PlayerSprite.update (scrolly_maze.py:259-271)
-        if (moves) mw_move<NS>(k, l, sn, s, w[s], p, dr, dc, lane, err);
-      }
-    }
+    // One copy of the body per sprite index (a macro, not a loop or a lambda:
+    // the compiler must see compile-time indices into w[] to keep it in VGPRs).
+#define PCX_SM_SPRITE(s)                                                                         \
+  if constexpr ((s) < NS) {                                                                      \
+    if (k.prog[s] == PCX_PROG_SM_PATROLLER) { /* scrolly_maze.py:284-305 */                      \
+      if (p.frame & 1) {                                                                         \
+        mw_move<NS>(k, l, sn, s, w[s], p, 0, 0, lane, err);                                      \
+      } else {                                                                                   \
+        /* drapes.py:405-411 pattern_position_prescroll on the walls drape */                    \
+        if (!maze.moved) { maze.pre_r = maze.r; maze.pre_c = maze.c; }                           \
+        int pr = w[s].vr + maze.pre_r, pc = w[s].vc + maze.pre_c + (w[s].var ? 1 : -1);          \
+        if (pr < 0) pr += k.PR; /* numpy negative-index wrap */                                  \
+        if (pc < 0) pc += k.PC;                                                                  \
+        if (wall_at(k, l, pr, pc, err)) w[s].var ^= 1;                                           \
+        mw_move<NS>(k, l, sn, s, w[s], p, 0, w[s].var ? 1 : -1, lane, err);                      \
+        const Walker pl = pick<NS, IP>(w, k.ip);                                                 \
+        if (w[s].vr == pl.vr && w[s].vc == pl.vc) { p.game_over = 1; p.discount = 0.0f; }        \
+      }                                                                                          \
+    } else { /* PlayerSprite.update (scrolly_maze.py:259-271) */                                 \
+      if (moves) mw_move<NS>(k, l, sn, s, w[s], p, dr, dc, lane, err);                           \
+    }                                                                                            \
+  }
+    PCX_SM_SPRITE(0) PCX_SM_SPRITE(1) PCX_SM_SPRITE(2) PCX_SM_SPRITE(3) PCX_SM_SPRITE(4) PCX_SM_SPRITE(5)
+#undef PCX_SM_SPRITE
 
     // group 2: CashDrape.update (scrolly_maze.py:341-364)
     {
-      Walker pl = w[0];
-#pragma unroll
-      for (int j = 0; j < NS; ++j) if (j == k.ip) pl = w[j];
+      const Walker pl = pick<NS, IP>(w, k.ip);
       bool on = on_board(k, pl.vr, pl.vc);
       // pattern_position_prescroll: this drape has not scrolled yet this frame
       int pr = (on ? pl.vr : 0) + cash.r, pc = (on ? pl.vc : 0) + cash.c;
@@ -475,13 +507,72 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(Ptrs P, StepArgs a
         }
       }
       if (moves) {
-        Walker ego2 = w[0];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) if (s == k.ie) ego2 = w[s];
-        maybe_move(k, cash, p, ego2, dr, dc, err);
+        maybe_move(k, cash, p, pick<NS, IE>(w, k.ie), dr, dc, err);
         stale = STALE_NONE;  // every _maybe_move path ends in _update_curtain
       } else if (action == 5) {
         p.game_over = 1; p.discount = 0.0f;
+      }
+    }
+
+    // ---- render descriptors for phase B ------------------------------------
+    // Both curtains as flat cell-bit vectors (bit i = cell i), so that phase B
+    // finds the 4 bits of a board dword with one aligned LDS read.
+    {
+      constexpr int ACC = SR ? (SR * SC + 31) / 32 + 1 : 1;
+      uint32_t accw[ACC], accc[ACC];
+      if constexpr (SR != 0) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) accw[i] = accc[i] = 0;
+      } else {
+        for (int i = 0; i < FW; ++i) l.flat[(0 * FW + i) * WAVE + lane] = l.flat[(1 * FW + i) * WAVE + lane] = 0;
+      }
+      const uint32_t cmaskC = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
+#pragma unroll
+      for (int r = 0; r < (SR ? SR : R); ++r) {
+        // walls curtain row: bits [maze.c, maze.c + C) of pattern row maze.r + r
+        int pr = maze.r + r;
+        uint32_t wbits = 0;
+        if ((unsigned)pr < (unsigned)k.PR && maze.c >= 0 && maze.c + C <= k.PC) {
+          const uint32_t* row = l.walls + pr * k.WPR;
+          int wi = maze.c >> 5, sh = maze.c & 31;
+          uint64_t pair = (uint64_t)row[wi] | ((uint64_t)row[wi + 1] << 32);  // WPR has a spare word
+          wbits = (uint32_t)(pair >> sh) & cmaskC;
+        } else {
+          err |= ERR_INDEX;
+        }
+        // coins curtain row
+        int cr = cash.r + r;
+        uint32_t cbits = 0;
+        if ((unsigned)cr < (unsigned)k.PR) {
+          int k0 = l.rowstart[cr], k1 = l.rowstart[cr + 1];
+          for (int i = k0; i < k1; ++i) {
+            int col = (int)l.coincol[i] - cash.c;
+            if ((unsigned)col < (unsigned)C && (coin_alive(l, lane, i) || (uint32_t)i == stale)) cbits |= 1u << col;
+          }
+        }
+        const int off = r * C, wi = off >> 5, sh = off & 31;
+        if constexpr (SR != 0) {
+          accw[wi] |= wbits << sh;
+          accc[wi] |= cbits << sh;
+          if (sh + SC > 32) {
+            accw[wi + 1] |= wbits >> (32 - sh);
+            accc[wi + 1] |= cbits >> (32 - sh);
+          }
+        } else {
+          l.flat[(0 * FW + wi) * WAVE + lane] |= wbits << sh;
+          l.flat[(1 * FW + wi) * WAVE + lane] |= cbits << sh;
+          if (sh + C > 32) {
+            l.flat[(0 * FW + wi + 1) * WAVE + lane] |= wbits >> (32 - sh);
+            l.flat[(1 * FW + wi + 1) * WAVE + lane] |= cbits >> (32 - sh);
+          }
+        }
+      }
+      if constexpr (SR != 0) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) {
+          l.flat[(0 * ACC + i) * WAVE + lane] = accw[i];
+          l.flat[(1 * ACC + i) * WAVE + lane] = accc[i];
+        }
       }
     }
 
@@ -498,6 +589,11 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(Ptrs P, StepArgs a
     for (int s = 0; s < NS; ++s) {
       st[(W_SPOS + s) * bp] = pack_pos(w[s].vr, w[s].vc);
       sf |= ((uint32_t)w[s].vis | ((uint32_t)w[s].prior << 1) | ((uint32_t)w[s].var << 2)) << (8 * s);
+      const int cell = paint_cell(k, w[s]);
+      l.sdesc[s * WAVE + lane] = make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
+      const bool on = on_board(k, w[s].vr, w[s].vc);
+      P.track[s * bp + env] = (on ? w[s].vr : 0) | ((on ? w[s].vc : 0) << 8) | (w[s].vis << 16) |
+                              ((int)do_reset << 24);
     }
     st[W_SFLAGS * bp] = sf;
     if (coins_dirty)
@@ -508,83 +604,55 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(Ptrs P, StepArgs a
     out.done[env] = (uint8_t)p.game_over;
     out.frame[env] = p.frame;
     out.error[env] = (uint8_t)err;
-
-    // ---- render descriptors for phase B ------------------------------------
-    const int R = k.R, C = k.C;
-    const uint32_t cmaskC = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
-    for (int r = 0; r < R; ++r) {
-      // walls curtain row: bits [maze.c, maze.c + C) of pattern row maze.r + r
-      int pr = maze.r + r;
-      uint32_t wbits = 0;
-      if ((unsigned)pr < (unsigned)k.PR && maze.c >= 0 && maze.c + C <= k.PC) {
-        const uint32_t* row = l.walls + pr * k.WPR;
-        int wi = maze.c >> 5, sh = maze.c & 31;
-        uint64_t pair = row[wi];
-        if (wi + 1 < k.WPR) pair |= (uint64_t)row[wi + 1] << 32;
-        wbits = (uint32_t)(pair >> sh) & cmaskC;
-      } else {
-        err |= ERR_INDEX;
-      }
-      l.drows[(0 * (R + 1) + r) * WAVE + lane] = wbits;
-      // coins curtain row
-      int cr = cash.r + r;
-      uint32_t cbits = 0;
-      if ((unsigned)cr < (unsigned)k.PR) {
-        int k0 = l.rowstart[cr], k1 = l.rowstart[cr + 1];
-        for (int i = k0; i < k1; ++i) {
-          int col = (int)l.coincol[i] - cash.c;
-          if ((unsigned)col < (unsigned)C && (coin_alive(l, lane, i) || (uint32_t)i == stale)) cbits |= 1u << col;
-        }
-      }
-      l.drows[(1 * (R + 1) + r) * WAVE + lane] = cbits;
-    }
-    l.drows[(0 * (R + 1) + R) * WAVE + lane] = 0;
-    l.drows[(1 * (R + 1) + R) * WAVE + lane] = 0;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      int cell = paint_cell(k, w[s]);
-      l.scell[s * WAVE + lane] = cell;
-      bool on = on_board(k, w[s].vr, w[s].vc);
-      P.track[s * bp + env] = (on ? w[s].vr : 0) | ((on ? w[s].vc : 0) << 8) | (w[s].vis << 16) |
-                              ((int)do_reset << 24);
-    }
   }
   l.skip[lane] = skip;
   __syncthreads();
 
   // ---- phase B: the wavefront streams the observation planes ---------------
-  const int QW = k.QW, C = k.C, R = k.R, L = k.L, cells = k.cells, nz = k.n_things;
+  // Everything wave-uniform is pulled into registers first: nothing in the
+  // loop below depends on a memory load other than LDS.
+  int zk[NZ], zi[NZ];
+  uint32_t zc4[NZ];
+#pragma unroll
+  for (int z = 0; z < NZ; ++z) {
+    zk[z] = k.z_kind[z];
+    zi[z] = k.z_idx[z];
+    zc4[z] = (uint32_t)k.z_ch[z] * 0x01010101u;
+  }
+  constexpr int LL = SL ? SL : MAX_L;
+  uint32_t ch4[LL];
+#pragma unroll
+  for (int pl = 0; pl < LL; ++pl) ch4[pl] = k.chars[pl] * 0x01010101u;
+  const uint32_t magic_q = k.magic_q;
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)cells;
   uint8_t* blk = out.planes + (size_t)env0 * env_stride;
+#pragma unroll 2
   for (int it = 0; it < QW; ++it) {
-    uint32_t f = (uint32_t)it * WAVE + lane;
-    uint32_t e = (f * k.magic_q) >> 20;
-    uint32_t q = f - e * QW;
+    const uint32_t f = (uint32_t)it * WAVE + lane;
+    const uint32_t e = SR ? f / (uint32_t)(SR * SC / 4) : (f * magic_q) >> 20;
+    const uint32_t q = f - e * QW;
     if (l.skip[e]) continue;
-    uint32_t cell0 = q * 4;
-    uint32_t r0 = (cell0 * k.magic_c) >> 20;
-    uint32_t c0 = cell0 - r0 * C;
     uint32_t d = l.backdrop4[q];
-    for (int z = 0; z < nz; ++z) {  // engine.py:751-757, back to front
-      uint32_t ch4 = (uint32_t)k.z_ch[z] * 0x01010101u;
-      if (k.z_kind[z] == 0) {
-        int cell = l.scell[k.z_idx[z] * WAVE + e];
-        uint32_t m = (cell >= 0 && (uint32_t)(cell >> 2) == q) ? (0xFFu << ((cell & 3) * 8)) : 0u;
-        d = (d & ~m) | (ch4 & m);
+#pragma unroll
+    for (int z = 0; z < NZ; ++z) {  // engine.py:751-757, back to front
+      uint32_t m;
+      if (zk[z] == 0) {
+        const uint2 sd = l.sdesc[zi[z] * WAVE + e];
+        m = sd.x == q ? sd.y : 0u;
       } else {
-        const uint32_t* rows = l.drows + (k.z_idx[z] * (R + 1)) * WAVE;
-        uint32_t lo = rows[r0 * WAVE + e], hi = rows[(r0 + 1) * WAVE + e];
-        uint32_t bits = ((lo >> c0) | (uint32_t)((uint64_t)hi << (C - c0))) & 0xFu;
-        uint32_t m = ((bits * 0x00204081u) & 0x01010101u) * 0xFFu;
-        d = (d & ~m) | (ch4 & m);
+        const uint32_t bits = (l.flat[(zi[z] * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
+        m = ((bits * 0x00204081u) & 0x01010101u) * 0xFFu;
       }
+      d = (d & ~m) | (zc4[z] & m);
     }
     uint32_t off = e * env_stride + q * 4;
     *reinterpret_cast<uint32_t*>(blk + off) = d;
-    for (int pl = 0; pl < L; ++pl) {  // rendering.py:177-179: layer = (board == c)
-      uint32_t x = d ^ (k.chars[pl] * 0x01010101u);
-      uint32_t t = x + 0x7F7F7F7Fu;  // all bytes < 0x80: bit 7 of a byte stays clear iff byte == 0
-      uint32_t m = ((t >> 7) & 0x01010101u) ^ 0x01010101u;
+#pragma unroll
+    for (int pl = 0; pl < LL; ++pl) {  // rendering.py:177-179: layer = (board == c)
+      if (!SL && pl >= L) break;
+      const uint32_t x = d ^ ch4[pl];
+      const uint32_t t = x + 0x7F7F7F7Fu;  // all bytes < 0x80: bit 7 stays clear iff the byte is 0
+      const uint32_t m = ((t >> 7) & 0x01010101u) ^ 0x01010101u;
       off += cells;
       *reinterpret_cast<uint32_t*>(blk + off) = m;
     }
@@ -618,7 +686,6 @@ class ScrollyMazeBackend : public Backend {
  private:
   Consts k_{};
   int64_t batch_ = 0, bpad_ = 0;
-  DevArray<Consts> dk_;
   DevArray<uint32_t> walls_, backdrop4_, state_;
   DevArray<uint16_t> rowstart_;
   DevArray<uint8_t> coincol_;
@@ -777,15 +844,16 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   k.lds_backdrop = off; off += k.QW;
   k.lds_rowstart = off; off += (int)rs.size() / 2;
   k.lds_coincol = off; off += (int)cc.size() / 4;
-  k.lds_drows = off; off += 2 * (k.R + 1) * WAVE;
-  k.lds_scell = off; off += k.NS * WAVE;
+  k.FW = (k.cells + 31) / 32 + 1;
+  k.lds_flat = off; off += 2 * k.FW * WAVE;
+  off = (off + 1) & ~1;  // uint2 alignment
+  k.lds_sdesc = off; off += 2 * k.NS * WAVE;
   k.lds_cmask = off; off += (k.CW ? k.CW : 1) * WAVE;
   k.lds_skip = off; off += WAVE;
   k.lds_words = off;
   if (off * 4 > 64 * 1024) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: template needs %d bytes of LDS", off * 4);
 
   int rc;
-  if ((rc = dk_.upload(std::vector<Consts>(1, k)))) return rc;
   if ((rc = walls_.upload(wb))) return rc;
   if ((rc = backdrop4_.upload(bd4))) return rc;
   if ((rc = rowstart_.upload(rs))) return rc;
@@ -796,14 +864,21 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
 }
 
 int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) {
-  Ptrs P{dk_.ptr, walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, batch_, bpad_};
+  Ptrs P{walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, batch_, bpad_};
   dim3 grid((unsigned)(bpad_ / WAVE)), block(WAVE);
   size_t lds = (size_t)k_.lds_words * 4;
-  switch (k_.NS) {
-#define PCX_SM_CASE(n) case n: hipLaunchKernelGGL(pcx_scrolly_maze_step<n>, grid, block, lds, s, P, a, out); break;
-    PCX_SM_CASE(1) PCX_SM_CASE(2) PCX_SM_CASE(3) PCX_SM_CASE(4) PCX_SM_CASE(5) PCX_SM_CASE(6)
+  // Specialised instance for the shipped scrolly_maze shape (10x30 board,
+  // 8 characters, 'abcP' sprites); anything else takes the generic instance.
+  if (k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3) {
+    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3>), grid, block, lds, s, k_, P, a, out);
+  } else {
+    switch (k_.NS) {
+#define PCX_SM_CASE(n) \
+  case n: hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1>), grid, block, lds, s, k_, P, a, out); break;
+      PCX_SM_CASE(1) PCX_SM_CASE(2) PCX_SM_CASE(3) PCX_SM_CASE(4) PCX_SM_CASE(5) PCX_SM_CASE(6)
 #undef PCX_SM_CASE
-    default: return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: %d sprites", k_.NS);
+      default: return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: %d sprites", k_.NS);
+    }
   }
   PCX_HIP(hipGetLastError());
   return 0;

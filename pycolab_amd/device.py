@@ -14,22 +14,7 @@ import numpy as np
 
 from pycolab_amd import _native as N
 
-_torch = None
-
-
-def torch_module():
-  """torch if importable with a usable GPU (and not disabled), else None."""
-  global _torch
-  if _torch is None:
-    _torch = False
-    if os.environ.get('PCX_NO_TORCH', '0') != '1':
-      try:
-        import torch
-        if torch.cuda.is_available():
-          _torch = torch
-      except ImportError:
-        pass
-  return _torch or None
+from pycolab_amd._torchprobe import torch_module  # noqa: F401 (re-exported)
 
 
 _NP_TO_TORCH = {'uint8': 'uint8', 'int32': 'int32', 'float32': 'float32'}
