@@ -2,6 +2,7 @@
 #include "pcx_internal.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 namespace pcx {
@@ -22,6 +23,12 @@ static uint32_t action_hash_host(uint64_t seed, uint64_t env, uint64_t t) {
   x ^= x >> 27; x *= 0x94D049BB133111EBull;
   x ^= x >> 31;
   return (uint32_t)(x >> 32);
+}
+
+static int debug_flags() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PCX_DEBUG"); v = e ? atoi(e) : 0; }
+  return v;
 }
 
 static void free_own_outputs(pcx_engine* e) {
@@ -147,6 +154,7 @@ int pcx_engine_step(pcx_engine* e, const int32_t* actions_dev, int auto_reset, v
   pcx::StepArgs a;
   a.actions = actions_dev;
   a.auto_reset = auto_reset;
+  a.debug = pcx::debug_flags();
   int rc = e->backend->launch(a, e->out, (hipStream_t)stream);
   if (rc) return rc;
   e->epoch++;

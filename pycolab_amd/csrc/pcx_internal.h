@@ -35,6 +35,7 @@ struct StepArgs {
   uint64_t seed = 0;
   int64_t env_offset = 0;
   int64_t t = 0;
+  int debug = 0;  // ablation bits for profiling (PCX_DEBUG env): 1 skip entity updates, 2 skip phase B, 4 skip render descriptors
 };
 
 // Device-resident copy of a byte array.

@@ -29,6 +29,7 @@
 #include "pcx_internal.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -71,14 +72,19 @@ struct Consts {
   // z-order, back to front
   int32_t z_kind[MAX_Z], z_idx[MAX_Z], z_ch[MAX_Z];
   // LDS layout (word offsets)
+  // occlusion, resolved once per environment in phase A (so that phase B paints
+  // in a fixed order): thing bits are sprites 0..NS-1, drapes NS (maze), NS+1 (cash)
+  uint32_t above[MAX_NS + 2];   // things strictly in front of thing t
+  int32_t lay_sprite[MAX_NS], lay_drape[2];  // layer plane index of each thing's character
+  int32_t n_bchars, bchar[MAX_L], lay_bchar[MAX_L];  // characters only the backdrop paints
   int32_t FW;  // words of one flat curtain bit-vector (cells bits + 1 spill word)
   int32_t lds_walls, lds_backdrop, lds_rowstart, lds_coincol, lds_flat, lds_sdesc, lds_cmask,
-      lds_skip, lds_words;
+      lds_skip, lds_bdmask, lds_buf_words, lds_words;
 };
 
 struct Ptrs {
   const uint32_t* walls_bits;   // [PR][WPR]
-  const uint32_t* backdrop4;    // [QW] backdrop as dwords
+  const uint32_t* backdrop4;    // [QW] backdrop as dwords, then [n_bchars][QW] (backdrop == bchar) 0/1 bytes
   const uint16_t* coin_rowstart;  // [PR+1]
   const uint8_t* coin_col;        // [n_coins]
   uint32_t* state;                // [NW][bpad]
@@ -129,6 +135,7 @@ struct Lds {
   uint2* sdesc;     // [NS][64] sprite paint descriptors {dword index q, byte mask}
   uint32_t* cmask;  // [CW][64]
   uint32_t* skip;   // [64]
+  const uint32_t* bdmask;  // [n_bchars][QW]
 };
 
 __device__ __forceinline__ int wall_at(const Consts& k, const Lds& l, int pr, int pc, uint32_t& err) {
@@ -334,13 +341,18 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 // compile time (0 = take them from Consts); IP/IE: index of the player and of
 // the egocentric sprite when known at compile time (-1 = from Consts).
 template <int NS, int SR, int SC, int SL, int IP, int IE>
-__global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                              const pcx_buffers out) {
+__global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
+                                                                  const pcx_buffers out) {
+  // A workgroup is two wavefronts with different jobs, looping over groups of
+  // 64 environments: wave 0 (logic) steps group i+1 and leaves its render
+  // descriptors in one LDS buffer while wave 1 (render) streams the
+  // observation of group i out of the other; they meet at a barrier and swap.
+  // The latency-bound entity logic thus runs under the HBM-bound streaming
+  // instead of in front of it.
   extern __shared__ uint32_t lds_raw[];
-  constexpr int NZ = NS + 2;
-  const int lane = threadIdx.x;
-  const int64_t env0 = (int64_t)blockIdx.x * WAVE;
-  const int64_t env = env0 + lane;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  const int ngroups = (int)(P.bpad / WAVE);
   const int R = SR ? SR : k.R, C = SC ? SC : k.C, L = SL ? SL : k.L;
   const int cells = R * C, QW = cells >> 2;
   const int FW = SR ? (SR * SC + 31) / 32 + 1 : k.FW;
@@ -354,22 +366,40 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(const Consts k, co
   l.backdrop4 = lb;
   l.rowstart = reinterpret_cast<const uint16_t*>(lr);
   l.coincol = reinterpret_cast<const uint8_t*>(lc);
-  l.flat = lds_raw + k.lds_flat;
-  l.sdesc = reinterpret_cast<uint2*>(lds_raw + k.lds_sdesc);
   l.cmask = lds_raw + k.lds_cmask;
-  l.skip = lds_raw + k.lds_skip;
+  uint32_t* lm = lds_raw + k.lds_bdmask;
+  l.bdmask = lm;
 
   // ---- stage the shared template constants into LDS (from L2) -------------
-  for (int i = lane; i < k.PR * k.WPR; i += WAVE) lw[i] = P.walls_bits[i];
-  for (int i = lane; i < QW; i += WAVE) lb[i] = P.backdrop4[i];
+  for (int i = threadIdx.x; i < k.PR * k.WPR; i += blockDim.x) lw[i] = P.walls_bits[i];
+  for (int i = threadIdx.x; i < QW; i += blockDim.x) lb[i] = P.backdrop4[i];
+  for (int i = threadIdx.x; i < k.n_bchars * QW; i += blockDim.x) lm[i] = P.backdrop4[QW + i];
   {
     const uint32_t* rs = reinterpret_cast<const uint32_t*>(P.coin_rowstart);
     const uint32_t* cc = reinterpret_cast<const uint32_t*>(P.coin_col);
-    for (int i = lane; i < (k.PR + 2) / 2; i += WAVE) lr[i] = rs[i];
-    for (int i = lane; i < (k.n_coins + 3) / 4; i += WAVE) lc[i] = cc[i];
+    for (int i = threadIdx.x; i < (k.PR + 2) / 2; i += blockDim.x) lr[i] = rs[i];
+    for (int i = threadIdx.x; i < (k.n_coins + 3) / 4; i += blockDim.x) lc[i] = cc[i];
   }
+  __syncthreads();  // LDS constants visible
 
-  // ---- phase A: lane == environment ---------------------------------------
+  // blockDim.x == 64: one wave does both jobs back to back (no overlap).
+  const bool solo = blockDim.x == WAVE;
+  for (int round = solo ? 0 : -1;; ++round) {
+  const int64_t g_render = (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
+  const int64_t g_logic = solo ? g_render : g_render + gridDim.x;
+  const bool have_render = round >= 0 && g_render < ngroups, have_logic = g_logic < ngroups;
+  if (!have_render && !have_logic) break;
+  {
+    const int buf = solo ? 0 : (wave == 0) ? ((round + 1) & 1) : (round & 1);
+    l.flat = lds_raw + k.lds_flat + buf * k.lds_buf_words;
+    l.sdesc = reinterpret_cast<uint2*>(lds_raw + k.lds_sdesc + buf * k.lds_buf_words);
+    l.skip = lds_raw + k.lds_skip + buf * k.lds_buf_words;
+  }
+  if (wave == 0) {
+  if (have_logic) {
+  // ---- phase A (logic wave): lane == environment ---------------------------
+  const int64_t env0 = g_logic * WAVE;
+  const int64_t env = env0 + lane;
   const bool live = env < P.batch;
   uint32_t* st = P.state + env;  // word w at st[w * bpad]
   const int64_t bp = P.bpad;
@@ -391,8 +421,6 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(const Consts k, co
                         : a.actions[env];
     }
   }
-  __syncthreads();  // LDS constants visible
-
   if (!skip) {
     Walker w[NS];
     Scrolly maze, cash;
@@ -453,6 +481,7 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(const Consts k, co
     for (int s = 0; s < NS; ++s) sn.cell[s] = paint_cell(k, w[s]);
     sn.cash_r = cash.r; sn.cash_c = cash.c; sn.stale = stale;
 
+    if (!(a.debug & 1)) {
     // group 0: MazeDrape.update (scrolly_maze.py:317-329)
     if (moves) maybe_move(k, maze, p, pick<NS, IE>(w, k.ie), dr, dc, err);
     sn.maze_r = maze.r; sn.maze_c = maze.c;  // repaint #1: walls already scrolled
@@ -514,6 +543,8 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(const Consts k, co
       }
     }
 
+    }  // debug & 1
+    if (!(a.debug & 4)) {
     // ---- render descriptors for phase B ------------------------------------
     // Both curtains as flat cell-bit vectors (bit i = cell i), so that phase B
     // finds the 4 bits of a board dword with one aligned LDS read.
@@ -567,15 +598,56 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(const Consts k, co
           }
         }
       }
+      // Resolve occlusion between the two curtains now (engine.py:751-757
+      // paints back to front, so the one in front wins where both are set).
+      const bool cash_in_front = (k.above[NS] >> (NS + 1)) & 1;
       if constexpr (SR != 0) {
 #pragma unroll
         for (int i = 0; i < ACC; ++i) {
-          l.flat[(0 * ACC + i) * WAVE + lane] = accw[i];
-          l.flat[(1 * ACC + i) * WAVE + lane] = accc[i];
+          const uint32_t ww = cash_in_front ? accw[i] & ~accc[i] : accw[i];
+          const uint32_t cc = cash_in_front ? accc[i] : accc[i] & ~accw[i];
+          l.flat[(0 * ACC + i) * WAVE + lane] = ww;
+          l.flat[(1 * ACC + i) * WAVE + lane] = cc;
+        }
+      } else {
+        for (int i = 0; i < FW; ++i) {
+          const uint32_t ww = l.flat[(0 * FW + i) * WAVE + lane], cc = l.flat[(1 * FW + i) * WAVE + lane];
+          l.flat[(0 * FW + i) * WAVE + lane] = cash_in_front ? ww & ~cc : ww;
+          l.flat[(1 * FW + i) * WAVE + lane] = cash_in_front ? cc : cc & ~ww;
         }
       }
     }
+    // A sprite is painted iff nothing in front of it covers its cell; a sprite
+    // that is painted takes its cell away from both curtains.  After this,
+    // every board cell belongs to exactly one of {a sprite, a curtain, the
+    // backdrop} and phase B needs no z-order.
+    {
+      int cellv[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) cellv[s] = paint_cell(k, w[s]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int cell = cellv[s];
+        bool shown = cell >= 0;
+        if (shown) {
+          const uint32_t ab = k.above[s];
+#pragma unroll
+          for (int j = 0; j < NS; ++j)
+            if (j != s && ((ab >> j) & 1) && cellv[j] == cell) shown = false;
+          const int wi = cell >> 5, sh = cell & 31;
+#pragma unroll
+          for (int dd = 0; dd < 2; ++dd)
+            if (((ab >> (NS + dd)) & 1) && ((l.flat[(dd * FW + wi) * WAVE + lane] >> sh) & 1)) shown = false;
+          if (shown) {
+            l.flat[(0 * FW + wi) * WAVE + lane] &= ~(1u << sh);
+            l.flat[(1 * FW + wi) * WAVE + lane] &= ~(1u << sh);
+          }
+        }
+        l.sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
+      }
+    }
 
+    }  // debug & 4
     // ---- _apply_and_clear_plot (engine.py:761-847) + state write-back ------
     flags = p.flags | (p.game_over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT);
     st[W_FRAME * bp] = (uint32_t)p.frame;
@@ -589,8 +661,6 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(const Consts k, co
     for (int s = 0; s < NS; ++s) {
       st[(W_SPOS + s) * bp] = pack_pos(w[s].vr, w[s].vc);
       sf |= ((uint32_t)w[s].vis | ((uint32_t)w[s].prior << 1) | ((uint32_t)w[s].var << 2)) << (8 * s);
-      const int cell = paint_cell(k, w[s]);
-      l.sdesc[s * WAVE + lane] = make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
       const bool on = on_board(k, w[s].vr, w[s].vc);
       P.track[s * bp + env] = (on ? w[s].vr : 0) | ((on ? w[s].vc : 0) << 8) | (w[s].vis << 16) |
                               ((int)do_reset << 24);
@@ -606,57 +676,91 @@ __global__ __launch_bounds__(WAVE) void pcx_scrolly_maze_step(const Consts k, co
     out.error[env] = (uint8_t)err;
   }
   l.skip[lane] = skip;
-  __syncthreads();
+  }  // have_logic
+  }
+  if (solo) __syncthreads();
+  if ((solo || wave == 1) && have_render && !(a.debug & 2)) {
+
 
   // ---- phase B: the wavefront streams the observation planes ---------------
-  // Everything wave-uniform is pulled into registers first: nothing in the
-  // loop below depends on a memory load other than LDS.
-  int zk[NZ], zi[NZ];
-  uint32_t zc4[NZ];
+  // Occlusion was resolved in phase A, so painting is order-free and every
+  // layer is a mask we already hold: nothing here depends on a memory load
+  // other than LDS, and every LDS read of an iteration is issued up front.
+  constexpr int NBS = SL ? SL - NS - 2 : MAX_L;  // backdrop-only characters
+  const int NB = SL ? NBS : k.n_bchars;
+  uint32_t sch4[NS], dch4[2], soff[NS], doff[2], boff[NBS];
 #pragma unroll
-  for (int z = 0; z < NZ; ++z) {
-    zk[z] = k.z_kind[z];
-    zi[z] = k.z_idx[z];
-    zc4[z] = (uint32_t)k.z_ch[z] * 0x01010101u;
+  for (int s = 0; s < NS; ++s) {
+    sch4[s] = (uint32_t)k.sprite_ch[s] * 0x01010101u;
+    soff[s] = (uint32_t)(1 + k.lay_sprite[s]) * (uint32_t)cells;
   }
-  constexpr int LL = SL ? SL : MAX_L;
-  uint32_t ch4[LL];
+  dch4[0] = (uint32_t)k.maze_ch * 0x01010101u;
+  dch4[1] = (uint32_t)k.cash_ch * 0x01010101u;
+  doff[0] = (uint32_t)(1 + k.lay_drape[0]) * (uint32_t)cells;
+  doff[1] = (uint32_t)(1 + k.lay_drape[1]) * (uint32_t)cells;
 #pragma unroll
-  for (int pl = 0; pl < LL; ++pl) ch4[pl] = k.chars[pl] * 0x01010101u;
+  for (int i = 0; i < NBS; ++i) boff[i] = (uint32_t)(1 + k.lay_bchar[i]) * (uint32_t)cells;
   const uint32_t magic_q = k.magic_q;
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)cells;
+  const int64_t env0 = g_render * WAVE;
   uint8_t* blk = out.planes + (size_t)env0 * env_stride;
+
+  // One (environment e, dword q) task: compose the board dword and the layer
+  // dwords and hand each to `put(byte offset inside the env record, value)`.
+  auto render = [&](uint32_t e, uint32_t q, auto&& put) {
+    uint32_t d = l.backdrop4[q];
+    uint32_t md[2], ms[NS], mb[NBS];
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+      const uint32_t bits = (l.flat[(dd * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
+      const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+      md[dd] = (m01 << 8) - m01;  // 0x01 -> 0xFF per byte, without a quarter-rate multiply
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const uint2 sd = l.sdesc[s * WAVE + e];
+      ms[s] = sd.x == q ? sd.y : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NBS; ++i) mb[i] = (SL || i < NB) ? l.bdmask[i * QW + q] : 0u;
+    uint32_t uni = md[0] | md[1];
+    d = (d & ~md[0]) | (dch4[0] & md[0]);
+    d = (d & ~md[1]) | (dch4[1] & md[1]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      uni |= ms[s];
+      d = (d & ~ms[s]) | (sch4[s] & ms[s]);
+    }
+    const uint32_t o = q * 4;
+    put(o, d);
+    // rendering.py:177-179 layer[c] = (board == c): by construction that is
+    // the thing's own mask, or the backdrop's where no thing paints.
+    put(o + doff[0], md[0] & 0x01010101u);
+    put(o + doff[1], md[1] & 0x01010101u);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) put(o + soff[s], ms[s] & 0x01010101u);
+#pragma unroll
+    for (int i = 0; i < NBS; ++i) {
+      if (!SL && i >= NB) break;
+      put(o + boff[i], mb[i] & ~uni);
+    }
+  };
+
+  // Each wave store covers 256 contiguous bytes of one plane of one or two
+  // environment records; all nine planes of a 64-dword span leave together.
+  const bool any_skip = __ballot(l.skip[lane] != 0) != 0ull;
 #pragma unroll 2
   for (int it = 0; it < QW; ++it) {
     const uint32_t f = (uint32_t)it * WAVE + lane;
     const uint32_t e = SR ? f / (uint32_t)(SR * SC / 4) : (f * magic_q) >> 20;
     const uint32_t q = f - e * QW;
-    if (l.skip[e]) continue;
-    uint32_t d = l.backdrop4[q];
-#pragma unroll
-    for (int z = 0; z < NZ; ++z) {  // engine.py:751-757, back to front
-      uint32_t m;
-      if (zk[z] == 0) {
-        const uint2 sd = l.sdesc[zi[z] * WAVE + e];
-        m = sd.x == q ? sd.y : 0u;
-      } else {
-        const uint32_t bits = (l.flat[(zi[z] * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
-        m = ((bits * 0x00204081u) & 0x01010101u) * 0xFFu;
-      }
-      d = (d & ~m) | (zc4[z] & m);
-    }
-    uint32_t off = e * env_stride + q * 4;
-    *reinterpret_cast<uint32_t*>(blk + off) = d;
-#pragma unroll
-    for (int pl = 0; pl < LL; ++pl) {  // rendering.py:177-179: layer = (board == c)
-      if (!SL && pl >= L) break;
-      const uint32_t x = d ^ ch4[pl];
-      const uint32_t t = x + 0x7F7F7F7Fu;  // all bytes < 0x80: bit 7 stays clear iff the byte is 0
-      const uint32_t m = ((t >> 7) & 0x01010101u) ^ 0x01010101u;
-      off += cells;
-      *reinterpret_cast<uint32_t*>(blk + off) = m;
-    }
+    if (any_skip && l.skip[e]) continue;
+    uint8_t* dst = blk + e * env_stride;
+    render(e, q, [&](uint32_t off, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + off) = v; });
   }
+  }  // render wave
+  __syncthreads();  // swap buffers
+  }  // rounds
 }
 
 // ---------------------------------------------------------------------------
@@ -694,6 +798,7 @@ class ScrollyMazeBackend : public Backend {
   std::vector<uint16_t> h_rowstart_;
   std::vector<uint8_t> h_coincol_;
   int maze_di_ = 0, cash_di_ = 0;
+  int num_cus_ = 256;
 };
 
 int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
@@ -787,6 +892,29 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     k.relevant[s] = rel;
   }
 
+  // occlusion tables: which things are in front of each thing; layer planes
+  {
+    int zpos[MAX_NS + 2];
+    for (int z = 0; z < t.n_things; ++z) zpos[k.z_kind[z] ? t.n_sprites + k.z_idx[z] : k.z_idx[z]] = z;
+    for (int a = 0; a < t.n_sprites + 2; ++a) {
+      k.above[a] = 0;
+      for (int b = 0; b < t.n_sprites + 2; ++b)
+        if (zpos[b] > zpos[a]) k.above[a] |= 1u << b;
+    }
+    auto layer_of = [&](int ch) { for (int i = 0; i < k.L; ++i) if ((int)k.chars[i] == ch) return i; return -1; };
+    for (int s = 0; s < t.n_sprites; ++s) k.lay_sprite[s] = layer_of(t.sprites[s].ch);
+    k.lay_drape[0] = layer_of(md.ch);
+    k.lay_drape[1] = layer_of(cd.ch);
+    k.n_bchars = 0;
+    for (int i = 0; i < k.L; ++i) {
+      int ch = (int)k.chars[i];
+      bool thing = ch == md.ch || ch == cd.ch;
+      for (int s = 0; s < t.n_sprites; ++s) thing |= t.sprites[s].ch == ch;
+      if (!thing) { k.bchar[k.n_bchars] = ch; k.lay_bchar[k.n_bchars] = i; k.n_bchars++; }
+    }
+    if (k.n_bchars != k.L - t.n_sprites - 2) return set_error(PCX_E_INVALID, "scrolly_maze backend: inconsistent character set");
+  }
+
   // patterns: walls as bit-rows; coins as a row-major list
   walls_pattern_.assign(md.pattern, md.pattern + (size_t)k.PR * k.PC);
   coin_pattern_.assign(cd.pattern, cd.pattern + (size_t)k.PR * k.PC);
@@ -810,8 +938,12 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   cc.resize((cc.size() + 7) / 4 * 4, 0);
   std::vector<uint16_t> rs = h_rowstart_;
   rs.resize((rs.size() + 3) / 2 * 2, 0);
-  std::vector<uint32_t> bd4(k.QW);
+  std::vector<uint32_t> bd4((size_t)k.QW * (1 + k.n_bchars));
   memcpy(bd4.data(), t.backdrop, k.cells);
+  for (int b = 0; b < k.n_bchars; ++b) {
+    uint8_t* dst = reinterpret_cast<uint8_t*>(bd4.data() + (size_t)k.QW * (1 + b));
+    for (int i = 0; i < k.cells; ++i) dst[i] = t.backdrop[i] == k.bchar[b];
+  }
 
   // initial state words (what the constructors left: ascii_art.py:247-277)
   memset(k.init, 0, sizeof k.init);
@@ -845,14 +977,26 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   k.lds_rowstart = off; off += (int)rs.size() / 2;
   k.lds_coincol = off; off += (int)cc.size() / 4;
   k.FW = (k.cells + 31) / 32 + 1;
+  // per-group render descriptors, double-buffered between the two waves
+  const int buf0 = off;
   k.lds_flat = off; off += 2 * k.FW * WAVE;
   off = (off + 1) & ~1;  // uint2 alignment
   k.lds_sdesc = off; off += 2 * k.NS * WAVE;
-  k.lds_cmask = off; off += (k.CW ? k.CW : 1) * WAVE;
   k.lds_skip = off; off += WAVE;
+  off = (off + 1) & ~1;
+  k.lds_buf_words = off - buf0;
+  off += k.lds_buf_words;  // second buffer
+  k.lds_cmask = off; off += (k.CW ? k.CW : 1) * WAVE;
+  k.lds_bdmask = off; off += k.n_bchars * k.QW;
   k.lds_words = off;
-  if (off * 4 > 64 * 1024) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: template needs %d bytes of LDS", off * 4);
+  if (off * 4 > 160 * 1024) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: template needs %d bytes of LDS", off * 4);
 
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      num_cus_ = prop.multiProcessorCount;
+  }
   int rc;
   if ((rc = walls_.upload(wb))) return rc;
   if ((rc = backdrop4_.upload(bd4))) return rc;
@@ -865,8 +1009,27 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
 
 int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) {
   Ptrs P{walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, batch_, bpad_};
-  dim3 grid((unsigned)(bpad_ / WAVE)), block(WAVE);
+  // Launch shape.  Default: one single-wave workgroup per group of 64
+  // environments (logic, then render), with the LDS footprint padded so that
+  // about 8 waves share a CU -- on MI355X the nine interleaved write streams
+  // per wave thrash less and go faster with 7-9 waves per CU than with 15+
+  // (profiles/r01_tuning.md).  PCX_WAVES_PER_WG=2 selects the two-wave
+  // logic/render pipeline with PCX_WGS_PER_CU persistent workgroups per CU.
+  int64_t groups = bpad_ / WAVE;
+  int wgs_per_cu = 0, waves_per_wg = 1, waves_per_cu = 8;
+  if (const char* e = getenv("PCX_WGS_PER_CU")) wgs_per_cu = atoi(e);
+  if (const char* e = getenv("PCX_WAVES_PER_WG")) waves_per_wg = atoi(e) == 2 ? 2 : 1;
+  if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
+  if (waves_per_wg == 2 && wgs_per_cu == 0) wgs_per_cu = 4;
+  int64_t max_wgs = wgs_per_cu > 0 ? (int64_t)num_cus_ * wgs_per_cu : groups;
+  dim3 grid((unsigned)(groups < max_wgs ? groups : max_wgs)), block(waves_per_wg * WAVE);
   size_t lds = (size_t)k_.lds_words * 4;
+  if (waves_per_wg == 1 && waves_per_cu > 0) {
+    size_t want = (size_t)(160 * 1024) / (size_t)waves_per_cu;
+    want &= ~(size_t)255;
+    if (want > lds) lds = want;
+  }
+  if (const char* pad = getenv("PCX_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   // Specialised instance for the shipped scrolly_maze shape (10x30 board,
   // 8 characters, 'abcP' sprites); anything else takes the generic instance.
   if (k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3) {
