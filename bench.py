@@ -30,10 +30,10 @@ def cpu_worker(args):
   return time.perf_counter() - t0
 
 
-def cpu_baseline(template_path, budget_envs=2048, steps=192):
-  """The C oracle ("port") on this box's host cores, bounded sample."""
+def cpu_baseline(template_path, budget_envs=1024, steps=512, max_procs=64):
+  """The C oracle ("port") on this box's host cores, bounded sample (~10 s)."""
   import multiprocessing as mp
-  cores = max(1, len(os.sched_getaffinity(0)))
+  cores = max(1, min(max_procs, len(os.sched_getaffinity(0))))
   jobs = [(template_path, budget_envs, steps, i * budget_envs) for i in range(cores)]
   with mp.get_context('fork').Pool(cores) as pool:
     times = pool.map(cpu_worker, jobs)

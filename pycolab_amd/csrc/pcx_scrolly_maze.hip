@@ -781,8 +781,12 @@ class ScrollyMazeBackend : public Backend {
   int launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) override;
   int read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) override;
   int64_t bytes_per_step() const override {
-    // action 4 + state words read+write 2*4*NW + planes (1+L)*cells + results 4+1+4+1+4+1
-    return 4 + 8 * (int64_t)k_.NW + (int64_t)(1 + k_.L) * k_.cells + 15;
+    // Algorithmic HBM bytes of one env-step in this layout:
+    // read: action 4 + state words 4*NW; write: state words that change every
+    // step 4*(NW-CW) (the coin mask is rewritten only on a pickup) + planes
+    // (1+L)*cells + results (reward 4, reward_set 1, discount 4, done 1,
+    // frame 4, error 1).
+    return 4 + 4 * (int64_t)k_.NW + 4 * (int64_t)(k_.NW - k_.CW) + (int64_t)(1 + k_.L) * k_.cells + 15;
   }
   const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
   const int32_t* sprite_track() const override { return track_.ptr; }

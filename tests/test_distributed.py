@@ -1,0 +1,60 @@
+"""world_size-2 gloo test of the multi-GPU path's host logic: env sharding by
+rank + the optional scalar gather.  The per-rank engines here are the CPU
+oracle (test infrastructure) standing in for the HIP engine, so the test runs
+without a GPU; the union of the two shards must equal one unsharded run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from pycolab_amd import distributed as pdist
+from tests import helpers
+
+
+def test_shard_range_partitions():
+  for batch in (1, 7, 64, 1000, 1 << 20):
+    for world in (1, 2, 3, 8):
+      spans = [pdist.shard_range(batch, r, world) for r in range(world)]
+      assert spans[0][0] == 0 and spans[-1][1] == batch
+      assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+      sizes = [hi - lo for lo, hi in spans]
+      assert max(sizes) - min(sizes) <= 1
+  with pytest.raises(ValueError):
+    pdist.shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, batch, steps, out_dir):
+  sys.path.insert(0, helpers.ROOT)
+  import torch
+  import torch.distributed as dist
+  from oracle import binding
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  lo, hi = pdist.shard_range(batch, rank, world)
+  eng = binding.OracleEngine(helpers.load_template('scrolly_maze_L0'), hi - lo)
+  eng.reset()
+  eng.step_hashed(0xABCD, 0, steps, env_offset=lo)   # global env index drives the actions
+  got = pdist.gather_scalars(torch.from_numpy(np.array(eng.reward)), torch.from_numpy(np.array(eng.reward_set)),
+                             torch.from_numpy(np.array(eng.discount)), torch.from_numpy(np.array(eng.done)))
+  if rank == 0:
+    np.savez(os.path.join(out_dir, 'gathered.npz'), reward=got[0].numpy(), reward_set=got[1].numpy(),
+             discount=got[2].numpy(), done=got[3].numpy())
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_shards_equal_one_unsharded_run(tmp_path):
+  import torch.multiprocessing as mp
+  from oracle import binding
+  batch, steps, world = 333, 40, 2   # odd batch: shards of different length
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  mp.spawn(_worker, args=(world, port, batch, steps, str(tmp_path)), nprocs=world, join=True)
+  got = np.load(str(tmp_path / 'gathered.npz'))
+  whole = binding.OracleEngine(helpers.load_template('scrolly_maze_L0'), batch)
+  whole.reset()
+  whole.step_hashed(0xABCD, 0, steps)
+  for name in ('reward', 'reward_set', 'discount', 'done'):
+    np.testing.assert_array_equal(got[name], np.array(getattr(whole, name)), err_msg=name)
+  assert got['done'].sum() > 0
