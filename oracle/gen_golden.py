@@ -105,21 +105,46 @@ def record(obs, reward, discount, game, chars, sprite_chars):
           sprite_states(game, sprite_chars))
 
 
-def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, seeker=False):
+def template_sprite_chars(template_name):
+  sys.path.insert(0, ROOT)
+  from pycolab_amd.compiler import GameTemplate
+  t = GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', template_name + '.npz'))
+  return [chr(s['ch']) for s in t.sprites]
+
+
+class ChoicePatch(object):
+  """Replaces numpy's global-RNG `np.random.choice` (used by
+  extraterrestrial_marauders.py:253) with the counter-based draw that the
+  oracle and the kernel implement: arr[hash(seed ^ SALT, env, draw#) % len]."""
+  SALT = 0x4D415241554445
+
+  def __init__(self, seed):
+    from oracle import binding
+    self._hash = binding.action_hash
+    self.seed, self.env, self.draws = seed, 0, {}
+
+  def __call__(self, arr):
+    n = self.draws.get(self.env, 0)
+    self.draws[self.env] = n + 1
+    return arr[self._hash(self.seed ^ self.SALT, self.env, n) % len(arr)]
+
+
+def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, seeker=False, choice=None):
   boards, rewards, rsets, discounts, dones, sprites = [], [], [], [], [], []
   actions = np.zeros((T, E), np.int32)
   chars = sprite_chars = None
   for e in range(E):
     rng = np.random.RandomState(seed * 1000 + e)
     actions[:, e] = tape(rng, e % 4, T, n_ordinary, quit_action)
+    if choice is not None:
+      choice.env = e
     game = make_game()
     rec = []
     obs, r, d = game.its_showtime()
     if chars is None:
       chars = sorted(obs.layers.keys())
-      sprite_chars = [c for c in game.things if hasattr(game.things[c], 'position')]
       # template order of sprites = engine insertion (update schedule) order
-      sprite_chars = [c for c in SCHEDULE_ORDER[template_name] if c in sprite_chars]
+      sprite_chars = template_sprite_chars(template_name)
     rec.append(record(obs, r, d, game, chars, sprite_chars))
     for t in range(T):
       if game.game_over:
@@ -149,17 +174,23 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
       path, E, T, nd, nr, os.path.getsize(path)))
 
 
-SCHEDULE_ORDER = {
-    'scrolly_maze_L0': '#abcP@', 'scrolly_maze_L1': '#abcP@', 'scrolly_maze_L2': '#abcP@',
-}
-
-
 def main():
-  from pycolab.examples import scrolly_maze
+  import numpy.random
+  from pycolab.examples import scrolly_maze, warehouse_manager, hello_world, extraterrestrial_marauders
   for level in (0, 1, 2):
     run('scrolly_maze_L%d' % level, lambda: scrolly_maze.make_game(level),
         E=32, T=192, n_ordinary=5, quit_action=5, seed=7 + level,
         template_name='scrolly_maze_L%d' % level, seeker=True)
+  for level in (0, 1, 2):
+    run('warehouse_L%d' % level, lambda: warehouse_manager.make_game(level),
+        E=32, T=192, n_ordinary=5, quit_action=5, seed=17 + level,
+        template_name='warehouse_L%d' % level)
+  run('hello_world', hello_world.make_game, E=16, T=96, n_ordinary=4, quit_action=4, seed=27,
+      template_name='hello_world')
+  patch = ChoicePatch(seed=0x5EED)   # the engines under test get the same seed (template param)
+  numpy.random.choice = patch
+  run('marauders', extraterrestrial_marauders.make_game, E=32, T=256, n_ordinary=4, quit_action=4,
+      seed=37, template_name='marauders', choice=patch)
 
 
 if __name__ == '__main__':

@@ -84,6 +84,7 @@ typedef struct {
   ox_plot plot;
   int game_over; /* Engine._game_over */
   int error;
+  uint64_t rng_draws; /* marauders: draws so far in this env (survives resets) */
 } ox_env;
 
 struct pcxo_engine {
@@ -465,6 +466,230 @@ static void prog_sm_cash(ox_ctx* x, int di) {
   else if (x->action == 5) plot_terminate(&env->plot, 0.0f); /* :363-364 */
 }
 
+/* ---- examples/warehouse_manager.py ------------------------------------------ */
+
+/* numpy layers[c][r, col] with Python index rules */
+static int layer_at(ox_ctx* x, int ch, int r, int c) {
+  pcxo_engine* e = x->e;
+  int k = char_index(e, ch);
+  if (k < 0) { x->env->error |= OX_ERR_INDEX; return 0; }
+  int err = 0;
+  r = np_index(r, e->t.rows, &err);
+  c = np_index(c, e->t.cols, &err);
+  if (err) { x->env->error |= err; return 0; }
+  return env_layer(e, x->b, k)[r * e->t.cols + c];
+}
+
+/* warehouse_manager.py:214-226 BoxSprite.update */
+static void prog_wm_box(ox_ctx* x, int id) {
+  const ox_sprite* s = &x->env->sprites[id];
+  int r = s->row, c = s->col;
+  switch (x->action) {
+    case 0: if (layer_at(x, 'P', r + 1, c)) mw_move(x->e, x->env, id, x->board, -1, 0); break;
+    case 1: if (layer_at(x, 'P', r - 1, c)) mw_move(x->e, x->env, id, x->board, 1, 0); break;
+    case 2: if (layer_at(x, 'P', r, c + 1)) mw_move(x->e, x->env, id, x->board, 0, -1); break;
+    case 3: if (layer_at(x, 'P', r, c - 1)) mw_move(x->e, x->env, id, x->board, 0, 1); break;
+    default: break;
+  }
+}
+
+/* warehouse_manager.py:245-266 JudgeDrape.update */
+static void prog_wm_judge(ox_ctx* x, int di) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_drape* d = &env->drapes[di];
+  int n = cells(e);
+  memset(d->curtain, 0, n);
+  for (int ch = '0'; ch <= '9'; ++ch) { /* box chars known to the engine (:248) */
+    if (char_index(e, ch) < 0) continue;
+    int id = thing_id(e, ch);
+    if (id < 0 || id >= PCX_MAX_SPRITES) { env->error |= OX_ERR_INDEX; continue; } /* things[c].position */
+    d->curtain[env->sprites[id].row * e->t.cols + env->sprites[id].col] = 1;
+  }
+  int num_boxes = 0, on_goals = 0;
+  for (int i = 0; i < n; ++i) num_boxes += d->curtain[i];
+  for (int i = 0; i < n; ++i) { d->curtain[i] &= e->backdrop[i] == '_'; on_goals += d->curtain[i]; }
+  plot_add_reward(&env->plot, on_goals - d->var[0]); /* :260 */
+  d->var[0] = on_goals;
+  if (x->action == 5 || on_goals == num_boxes) plot_terminate(&env->plot, 0.0f);
+}
+
+/* warehouse_manager.py:285-295 PlayerSprite.update (0 N, 1 S, 2 W, 3 E) */
+static void prog_wm_player(ox_ctx* x, int id) {
+  static const int T[4][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}};
+  if (x->action >= 0 && x->action <= 3) mw_move(x->e, x->env, id, x->board, T[x->action][0], T[x->action][1]);
+}
+
+/* ---- examples/hello_world.py ------------------------------------------------- */
+
+/* hello_world.py:79-91 RollingDrape.update */
+static void prog_hw_rolling(ox_ctx* x, int di) {
+  pcxo_engine* e = x->e;
+  ox_drape* d = &x->env->drapes[di];
+  int a = x->action, R = e->t.rows, C = e->t.cols;
+  if (a < 0) return;                                  /* None */
+  if (a == 4) plot_terminate(&x->env->plot, 0.0f);
+  if (a < 4) {
+    static const int AX[4] = {0, 0, 1, 1}, SH[4] = {-1, 1, -1, 1};
+    uint8_t* tmp = (uint8_t*)malloc((size_t)R * C);
+    for (int r = 0; r < R; ++r)
+      for (int c = 0; c < C; ++c) { /* np.roll: out[(i + shift) % n] = in[i] */
+        int rr = AX[a] == 0 ? ((r + SH[a]) % R + R) % R : r;
+        int cc = AX[a] == 1 ? ((c + SH[a]) % C + C) % C : c;
+        tmp[rr * C + cc] = d->curtain[r * C + c];
+      }
+    memcpy(d->curtain, tmp, (size_t)R * C);
+    free(tmp);
+    plot_add_reward(&x->env->plot, 1);
+  }
+}
+
+/* hello_world.py:117-123 SlidingSprite.update; param[0]/[1] hold _dx/_dy as
+ * four 2-bit fields (value + 1). */
+static void prog_hw_sliding(ox_ctx* x, int id) {
+  pcxo_engine* e = x->e;
+  ox_sprite* s = &x->env->sprites[id];
+  int a = x->action;
+  if (a < 0 || a > 3) return;
+  int dx = ((e->t.sprites[id].param[0] >> (2 * a)) & 3) - 1;
+  int dy = ((e->t.sprites[id].param[1] >> (2 * a)) & 3) - 1;
+  s->col = ((s->col + dx) % e->t.cols + e->t.cols) % e->t.cols;
+  s->row = ((s->row + dy) % e->t.rows + e->t.rows) % e->t.rows;
+  s->vrow = s->row; s->vcol = s->col;
+}
+
+/* ---- examples/extraterrestrial_marauders.py ----------------------------------- */
+
+#define EM_BUNKER_HITTERS 0
+#define EM_MARAUDER_HITTERS 1
+#define EM_LAST_PLAYER_SHOT 2
+#define EM_LAST_MARAUDER_SHOT 3
+#define EM_NEVER INT64_MIN
+
+/* hits = OR(layers[c] for c in chars) & curtain; curtain ^= hits; returns the
+ * number of hits and the set (bit per sprite id) of characters drawn there. */
+static int em_erode(ox_ctx* x, int di, const char* bolt_chars, int64_t* hitters) {
+  pcxo_engine* e = x->e;
+  ox_drape* d = &x->env->drapes[di];
+  int n = cells(e), count = 0;
+  *hitters = 0;
+  for (int i = 0; i < n; ++i) {
+    int bolt = 0;
+    for (const char* c = bolt_chars; *c; ++c) {
+      int k = char_index(e, *c);
+      if (k >= 0) bolt |= env_layer(e, x->b, k)[i];
+    }
+    if (bolt && d->curtain[i]) {
+      d->curtain[i] = 0;
+      ++count;
+      int id = thing_id(e, x->board[i]); /* board[hits] */
+      if (id >= 0) *hitters |= (int64_t)1 << id;
+    }
+  }
+  return count;
+}
+
+/* extraterrestrial_marauders.py:113-120 BunkerDrape.update */
+static void prog_em_bunker(ox_ctx* x, int di) {
+  int64_t hitters;
+  int hits = em_erode(x, di, "abcdyz", &hitters);
+  plot_add_reward(&x->env->plot, -hits);
+  x->env->plot.kv[EM_BUNKER_HITTERS] = hitters;
+}
+
+/* extraterrestrial_marauders.py:141-163 MarauderDrape.update */
+static void prog_em_marauder(ox_ctx* x, int di) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_drape* d = &env->drapes[di];
+  int R = e->t.rows, C = e->t.cols, n = R * C;
+  int64_t hitters;
+  int hits = em_erode(x, di, "abcd", &hitters);
+  plot_add_reward(&env->plot, 10 * hits);
+  env->plot.kv[EM_MARAUDER_HITTERS] = hitters;
+  int total = 0, row10 = 0, edge = 0;
+  for (int i = 0; i < n; ++i) total += d->curtain[i];
+  if (R > 10) for (int c = 0; c < C; ++c) row10 |= d->curtain[10 * C + c];
+  else env->error |= OX_ERR_INDEX;
+  if (total == 0 || row10) { plot_terminate(&env->plot, 0.0f); return; } /* :151-152 */
+  int period = (total - 1) / 8; /* == total // 8.0000001 for 1 <= total (:157) */
+  if (period < 1) period = 1;
+  if (env->plot.frame % period) return;
+  for (int r = 0; r < R; ++r) edge |= d->curtain[r * C] | d->curtain[r * C + C - 1];
+  uint8_t* tmp = (uint8_t*)malloc((size_t)n);
+  if (edge) { /* :160-162 */
+    d->var[0] = -d->var[0];
+    for (int r = 0; r < R; ++r) memcpy(tmp + ((r + 1) % R) * C, d->curtain + r * C, C);
+    memcpy(d->curtain, tmp, n);
+  }
+  int dx = d->var[0];
+  for (int r = 0; r < R; ++r)
+    for (int c = 0; c < C; ++c) tmp[r * C + ((c + dx) % C + C) % C] = d->curtain[r * C + c];
+  memcpy(d->curtain, tmp, n);
+  free(tmp);
+}
+
+/* extraterrestrial_marauders.py:178-186 PlayerSprite.update */
+static void prog_em_player(ox_ctx* x, int id) {
+  if (x->action == 0) mw_move(x->e, x->env, id, x->board, 0, -1);
+  else if (x->action == 1) mw_move(x->e, x->env, id, x->board, 0, 1);
+  else if (x->action == 4) plot_terminate(&x->env->plot, 0.0f);
+}
+
+/* extraterrestrial_marauders.py:198-220 UpwardLaserBoltSprite.update */
+static void prog_em_upbolt(ox_ctx* x, int id) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_sprite* s = &env->sprites[id];
+  if (s->visible) { /* _fly */
+    if (((env->plot.kv[EM_BUNKER_HITTERS] | env->plot.kv[EM_MARAUDER_HITTERS]) >> id) & 1) {
+      mw_teleport(e, s, -1, -1);
+      return;
+    }
+    mw_move(e, env, id, x->board, -1, 0);
+  } else if (x->action == 2) { /* _fire */
+    if (env->plot.kv[EM_LAST_PLAYER_SHOT] == env->plot.frame) return;
+    env->plot.kv[EM_LAST_PLAYER_SHOT] = env->plot.frame;
+    const ox_sprite* P = &env->sprites[thing_id(e, 'P')];
+    mw_teleport(e, s, P->row - 1, P->col);
+  }
+}
+
+/* extraterrestrial_marauders.py:232-256 DownwardLaserBoltSprite.update.  The
+ * reference draws from numpy's global RNG (:253); oracle, golden generator
+ * and kernel all use the same counter-based draw instead:
+ * choice(cols) = cols[pcx_action_hash(seed ^ EM_RNG_SALT, global_env, draw#) % len]. */
+#define EM_RNG_SALT 0x4D415241554445ull
+static void prog_em_downbolt(ox_ctx* x, int id) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_sprite* s = &env->sprites[id];
+  int R = e->t.rows, C = e->t.cols;
+  if (s->visible) { /* _fly */
+    if ((env->plot.kv[EM_BUNKER_HITTERS] >> id) & 1) { mw_teleport(e, s, -1, -1); return; }
+    const ox_sprite* P = &env->sprites[thing_id(e, 'P')];
+    if (s->row == P->row && s->col == P->col) plot_terminate(&env->plot, 0.0f);
+    mw_move(e, env, id, x->board, 1, 0);
+  } else { /* _fire */
+    if (env->plot.kv[EM_LAST_MARAUDER_SHOT] == env->plot.frame) return;
+    env->plot.kv[EM_LAST_MARAUDER_SHOT] = env->plot.frame;
+    const uint8_t* lx = env_layer(e, x->b, char_index(e, 'X'));
+    int cols[256], ncols = 0;
+    for (int c = 0; c < C; ++c) {
+      int any = 0;
+      for (int r = 0; r < R; ++r) any |= lx[r * C + c];
+      if (any) cols[ncols++] = c;
+    }
+    if (ncols == 0) { env->error |= OX_ERR_INDEX; return; } /* np.random.choice([]) raises */
+    uint64_t seed = ((uint64_t)(uint32_t)e->t.param[0] | ((uint64_t)(uint32_t)e->t.param[1] << 32)) ^ EM_RNG_SALT;
+    uint64_t genv = ((uint64_t)(uint32_t)e->t.param[2] | ((uint64_t)(uint32_t)e->t.param[3] << 32)) + (uint64_t)x->b;
+    int col = cols[pcxo_action_hash(seed, genv, env->rng_draws++) % (uint32_t)ncols];
+    int row = 0;
+    for (int r = 0; r < R; ++r) if (lx[r * C + col]) row = r;
+    mw_teleport(e, s, row + 1, col);
+  }
+}
+
 /* prefab-only entities: per-entity action = (action >> param[0]) & param[1]
  * when param[1] != 0 (packed multi-agent actions), else the action itself;
  * values 0..8 index MOTION9, anything else does nothing.  Restates the test
@@ -495,6 +720,16 @@ static int run_program(ox_ctx* x, int id) {
     case PCX_PROG_SM_PATROLLER: prog_sm_patroller(x, id); break;
     case PCX_PROG_SM_MAZE: prog_sm_maze(x, di); break;
     case PCX_PROG_SM_CASH: prog_sm_cash(x, di); break;
+    case PCX_PROG_WM_BOX: prog_wm_box(x, id); break;
+    case PCX_PROG_WM_JUDGE: prog_wm_judge(x, di); break;
+    case PCX_PROG_WM_PLAYER: prog_wm_player(x, id); break;
+    case PCX_PROG_HW_ROLLING: prog_hw_rolling(x, di); break;
+    case PCX_PROG_HW_SLIDING: prog_hw_sliding(x, id); break;
+    case PCX_PROG_EM_PLAYER: prog_em_player(x, id); break;
+    case PCX_PROG_EM_BUNKER: prog_em_bunker(x, di); break;
+    case PCX_PROG_EM_MARAUDER: prog_em_marauder(x, di); break;
+    case PCX_PROG_EM_UPBOLT: prog_em_upbolt(x, id); break;
+    case PCX_PROG_EM_DOWNBOLT: prog_em_downbolt(x, id); break;
     case PCX_PROG_WALKER: prog_walker(x, id); break;
     case PCX_PROG_SCROLLY: prog_scrolly(x, di); break;
     case PCX_PROG_STATIC: break;
@@ -554,7 +789,7 @@ static void env_init(pcxo_engine* e, int64_t b) {
     memset(s, 0, sizeof *s);
     s->row = d->row; s->col = d->col; s->visible = d->visible;
     s->vrow = d->vrow; s->vcol = d->vcol; s->prior_visible = d->prior_visible;
-    if (d->program == PCX_PROG_SM_PATROLLER) s->var[0] = d->ch % 2; /* scrolly_maze.py:282 */
+    if (d->program == PCX_PROG_SM_PATROLLER) s->var[0] = d->param[0]; /* _moving_east, scrolly_maze.py:282 */
   }
   for (int i = 0; i < e->t.n_drapes; ++i) {
     const pcx_drape_desc* d = &e->t.drapes[i];
@@ -566,8 +801,11 @@ static void env_init(pcxo_engine* e, int64_t b) {
     s->corner[1] = s->prescroll[1] = d->corner_col;
     s->last_maybe_move_frame = INT64_MIN; /* drapes.py:373 */
     memset(s->var, 0, sizeof s->var);
+    if (d->program == PCX_PROG_EM_MARAUDER) s->var[0] = d->param[0]; /* _dx, marauders.py:139 */
+    if (d->program == PCX_PROG_WM_JUDGE) s->var[0] = d->param[0];    /* _last_num_boxes_on_goals :243 */
   }
   memset(&env->plot, 0, sizeof env->plot);
+  env->plot.kv[EM_LAST_PLAYER_SHOT] = env->plot.kv[EM_LAST_MARAUDER_SHOT] = EM_NEVER;
   env->plot.frame = -1;
   plot_clear_directives(&env->plot);
   env->game_over = 0;

@@ -78,7 +78,7 @@ class GameTemplate(object):
             program=prog, row=int(pos[0]), col=int(pos[1]),
             vrow=int(vpos[0]), vcol=int(vpos[1]),
             impassable=_impassable_bits(getattr(ent, '_impassable', ())),
-            param=[int(v) for v in getattr(ent, 'pcx_param', (0, 0, 0, 0))]))
+            param=programs.extract_params(ent, prog)))
         if getattr(ent, '_scrolling_group', '') != '':
           raise programs.UnsupportedEntityError('only the default scrolling group is supported')
       else:
@@ -86,7 +86,7 @@ class GameTemplate(object):
         d = dict(ch=ord(ch), is_scrolly=int(scrolly), have_margins=0, program=prog,
                  curtain=np.ascontiguousarray(ent.curtain, dtype=np.uint8),
                  pattern=None, corner=(0, 0), margins=(0, 0),
-                 param=[int(v) for v in getattr(ent, 'pcx_param', (0, 0, 0, 0))])
+                 param=programs.extract_params(ent, prog))
         if scrolly:
           d['pattern'] = np.ascontiguousarray(ent.whole_pattern, dtype=np.uint8)
           d['corner'] = (int(ent._northwest_corner[0]), int(ent._northwest_corner[1]))

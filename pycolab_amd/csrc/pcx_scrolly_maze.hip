@@ -961,7 +961,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   for (int s = 0; s < t.n_sprites; ++s) {
     const pcx_sprite_desc& sd = t.sprites[s];
     k.init[W_SPOS + s] = ((uint32_t)sd.vrow & 0xFFFFu) | ((uint32_t)sd.vcol << 16);
-    uint32_t var = sd.program == PCX_PROG_SM_PATROLLER ? (sd.ch & 1u) : 0u;  // scrolly_maze.py:282
+    uint32_t var = sd.program == PCX_PROG_SM_PATROLLER ? (uint32_t)(sd.param[0] != 0) : 0u;  // _moving_east, scrolly_maze.py:282
     sf |= ((uint32_t)(sd.visible != 0) | ((uint32_t)(sd.prior_visible != 0) << 1) | (var << 2)) << (8 * s);
   }
   k.init[W_SFLAGS] = sf;

@@ -60,6 +60,27 @@ SHIPPED = {
 }
 
 
+def _pack2(values):
+  """Four values in {-1, 0, 1} as 2-bit fields (value + 1)."""
+  return sum(((int(v) + 1) & 3) << (2 * i) for i, v in enumerate(values))
+
+
+# Per-program constants that the entity's constructor left on the object
+# (reference attribute names), delivered to the device program as param[0..3].
+PARAM_EXTRACTORS = {
+    N.PROG_SM_PATROLLER: lambda e: [int(bool(e._moving_east)), 0, 0, 0],     # scrolly_maze.py:282
+    N.PROG_HW_SLIDING: lambda e: [_pack2(e._dx), _pack2(e._dy), 0, 0],      # hello_world.py:114-115
+    N.PROG_EM_MARAUDER: lambda e: [int(e._dx), 0, 0, 0],                    # marauders.py:139
+    N.PROG_WM_JUDGE: lambda e: [int(e._last_num_boxes_on_goals), 0, 0, 0],  # warehouse_manager.py:243
+}
+
+
+def extract_params(entity, program):
+  if program in PARAM_EXTRACTORS:
+    return PARAM_EXTRACTORS[program](entity)
+  return [int(v) for v in getattr(entity, 'pcx_param', (0, 0, 0, 0))]
+
+
 class UnsupportedEntityError(NotImplementedError):
   pass
 

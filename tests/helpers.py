@@ -7,6 +7,7 @@ from pycolab_amd.compiler import GameTemplate
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+GOLDEN_RNG_SEED = 0x5EED
 
 
 def load_template(name):
@@ -33,6 +34,7 @@ def replay_trace(engine_factory, trace):
   return an object with reset(), step(actions, auto_reset), and numpy-able
   attributes planes/reward/reward_set/discount/done (+ sprites())."""
   template = load_template(trace['template'])
+  template.param[0] = GOLDEN_RNG_SEED  # marauders: oracle/gen_golden.py ChoicePatch(seed=...)
   T, E = trace['actions'].shape
   eng = engine_factory(template, E)
   eng.reset()

@@ -13,7 +13,11 @@ class OracleAdapter(binding.OracleEngine):
     return np.array(getattr(self, name))
 
 
-@pytest.mark.parametrize('name', ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2'])
+ALL_TRACES = ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2', 'warehouse_L0', 'warehouse_L1',
+              'warehouse_L2', 'hello_world', 'marauders']
+
+
+@pytest.mark.parametrize('name', ALL_TRACES)
 def test_oracle_matches_reference_trace(name):
   trace = helpers.load_trace(name)
   helpers.replay_trace(OracleAdapter, trace)
