@@ -154,7 +154,8 @@ typedef struct pcx_buffers {
   int64_t batch;
   int32_t rows, cols, n_chars;
   /* planes[b][0] = board (uint8 chars); planes[b][1+k] = layer of chars[k]
-   * (uint8 0/1).  Shape [batch][1+n_chars][rows][cols], contiguous. */
+   * (uint8 0/1).  Shape [batch][1+n_chars][pitch], pitch = pcx_engine_plane_pitch()
+   * (== rows*cols whenever rows*cols is a multiple of 4). */
   uint8_t* planes;
   int32_t* reward;      /* [batch] summed reward (0 when reward_set == 0)      */
   uint8_t* reward_set;  /* [batch] 0 => the reference would return None       */
@@ -226,6 +227,12 @@ int pcx_stream_synchronize(void* stream);
 
 /* The counter-based action generator shared by host, oracle and device. */
 uint32_t pcx_action_hash(uint64_t seed, uint64_t env, uint64_t t);
+
+/* Bytes between consecutive planes of one environment in `planes`: rows*cols
+ * rounded up to a multiple of 4 (planes start dword-aligned; pad bytes are 0).
+ * planes is [batch][1 + n_chars][pitch]; plane p of env b, cell (r, c) is at
+ * ((b * (1 + n_chars) + p) * pitch + r * cols + c). */
+int32_t pcx_engine_plane_pitch(const pcx_engine* e);
 
 /* Algorithmic HBM bytes one env-step of this engine must move. */
 int64_t pcx_engine_bytes_per_step(const pcx_engine* e);

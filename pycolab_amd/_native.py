@@ -107,6 +107,7 @@ SYMBOLS = [
     ('pcx_device_free', c_i32, [_VP]),
     ('pcx_stream_synchronize', c_i32, [_VP]),
     ('pcx_action_hash', c_u32, [c_u64, c_u64, c_u64]),
+    ('pcx_engine_plane_pitch', c_i32, [_VP]),
     ('pcx_engine_bytes_per_step', c_i64, [_VP]),
     ('pcx_engine_kernel_name', ctypes.c_char_p, [_VP]),
     ('pcx_last_error', ctypes.c_char_p, []),

@@ -43,7 +43,7 @@ static void free_own_outputs(pcx_engine* e) {
 static int ensure_outputs(pcx_engine* e) {
   if (e->out.planes) return 0;
   size_t B = (size_t)e->batch;
-  size_t plane_bytes = B * (size_t)(1 + e->t.n_chars) * e->t.rows * e->t.cols;
+  size_t plane_bytes = B * (size_t)(1 + e->t.n_chars) * (size_t)e->backend->plane_pitch();
   pcx_buffers& o = e->out;
   o.batch = e->batch; o.rows = e->t.rows; o.cols = e->t.cols; o.n_chars = e->t.n_chars;
   PCX_HIP(hipMalloc((void**)&o.planes, plane_bytes));
@@ -85,6 +85,9 @@ int pcx_engine_create(const pcx_template* t, int64_t batch, int device_id, pcx_e
   pcx::Backend* b = nullptr;
   switch (t->game) {
     case PCX_GAME_SCROLLY_MAZE: b = pcx::make_scrolly_maze_backend(); break;
+    case PCX_GAME_WAREHOUSE:
+    case PCX_GAME_MARAUDERS:
+    case PCX_GAME_HELLO_WORLD: b = pcx::make_generic_backend(); break;
     default:
       return set_error(PCX_E_UNSUPPORTED, "pcx_engine_create: no device program for game id %d", t->game);
   }
@@ -192,6 +195,7 @@ int pcx_engine_read_things(pcx_engine* e, int64_t env0, int64_t n, pcx_sprite_st
   return e->backend->read_things(env0, n, sprites_host, curtains_host);
 }
 
+int32_t pcx_engine_plane_pitch(const pcx_engine* e) { return e ? e->backend->plane_pitch() : 0; }
 int64_t pcx_engine_bytes_per_step(const pcx_engine* e) { return e ? e->backend->bytes_per_step() : 0; }
 const char* pcx_engine_kernel_name(const pcx_engine* e) { return e ? e->backend->kernel_name() : ""; }
 

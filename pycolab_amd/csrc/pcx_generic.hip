@@ -1,0 +1,793 @@
+// pcx_generic.hip -- table-driven step kernel for games whose entities are
+// plain Sprites, MazeWalkers (no scrolling) and ordinary Drapes:
+//   examples/warehouse_manager.py, examples/extraterrestrial_marauders.py,
+//   examples/hello_world.py  (reference: engine.py:583-847 around them).
+// gfx950 only.
+//
+// Same two-phase shape as pcx_scrolly_maze.hip: a workgroup is one
+// wavefront that owns 64 consecutive environments.
+//   * logic phase, lane == environment: state words are loaded SoA-coalesced,
+//     entity state lives in per-lane LDS columns (so the update schedule, the
+//     z-order and the entity programs can be walked with ordinary loops over
+//     tables), every engine.py:735 repaint is a *snapshot* (sprite cells +
+//     curtains) that board/layer probes evaluate lazily;
+//   * render phase: occlusion is resolved once per environment, then the wave
+//     streams board + layers with coalesced dword stores.
+// Curtains are bit-rows (RW words per row) while the logic runs -- np.roll of
+// a MarauderDrape or RollingDrape is a rotate -- and are flattened to cell-bit
+// vectors for the render phase.
+
+#include "pcx_internal.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace pcx {
+namespace gen {
+
+constexpr int WAVE = 64;
+constexpr int MAX_L = 20;
+
+// per-thing table entry (uint32 words), staged into LDS
+enum : int { T_CH = 0, T_KIND, T_IDX, T_PROG, T_LAYER, T_ABOVE, T_FLAGS, T_P0, T_P1, T_IMP0, T_IMP1, T_IMP2, T_IMP3, T_WORDS };
+constexpr uint32_t TF_WALKER = 1, TF_CONFINED = 2;
+
+// state words
+enum : int { W_FRAME = 0, W_FLAGS, W_V0, W_V1, W_V2, W_V3, W_RNG, W_SPRITES };
+constexpr uint32_t F_OVER = 1u, F_ERR_SHIFT = 1;
+constexpr int64_t NEVER = INT32_MIN;
+
+struct Consts {
+  int32_t game, R, C, cells, pitch, QW, L, NS, ND, NT, n_groups, RW, FW, NW, n_actions, n_bchars;
+  uint32_t magic_q;
+  uint32_t seed_lo, seed_hi, envoff_lo, envoff_hi;
+  int32_t w_sflags, w_drapes;           // state word offsets
+  int32_t ip;                           // thing index of 'P' (-1 if none)
+  int32_t ix, ib;                       // drape index of 'X' / 'B' (-1 if none)
+  int32_t bolt_mask_all, bolt_mask_up;  // marauders: sprite-index masks of 'abcdyz' / 'abcd'
+  int32_t box_mask;                     // warehouse: sprite-index mask of the box sprites
+  // LDS layout (word offsets); per-lane arrays are [i][lane]
+  int32_t l_things, l_z, l_sched, l_backdrop, l_bdmask, l_aux, l_init, l_initd, l_laybc, l_s2t;
+  int32_t l_pos, l_flg, l_snap, l_cur, l_snapd, l_flat, l_sdesc, l_skip, l_words;
+};
+
+struct Ptrs {
+  const uint32_t* tables;  // everything staged into LDS, in l_* order
+  int32_t n_table_words;
+  uint32_t* state;         // [NW][bpad]
+  int32_t* track;          // [NS][bpad]
+  int64_t batch, bpad;
+};
+
+struct L {
+  const uint32_t *things, *z, *sched, *backdrop4, *bdmask, *aux, *init, *initd, *laybc, *s2t;
+  uint32_t *pos, *flg, *cur, *snapd, *flat, *skip;
+  int32_t* snap;
+  uint2* sdesc;
+};
+
+__device__ __forceinline__ uint32_t action_hash(uint64_t seed, uint64_t env, uint64_t t) {
+  uint64_t x = seed ^ (env * 0x9E3779B97F4A7C15ull) ^ (t * 0xBF58476D1CE4E5B9ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+__device__ __forceinline__ uint32_t pack_pos(int r, int c) { return ((uint32_t)r & 0xFFFFu) | ((uint32_t)c << 16); }
+__device__ __forceinline__ int pos_r(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
+__device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16); }
+
+struct Ctx {
+  const Consts& k;
+  const L& l;
+  int lane;
+  int frame, action;
+  uint32_t err;
+  int reward_set, reward, game_over;
+  float discount;
+  int32_t v[4];  // program variables (state words W_V0..3)
+};
+
+__device__ __forceinline__ bool on_board(const Consts& k, int r, int c) {
+  return (unsigned)r < (unsigned)k.R && (unsigned)c < (unsigned)k.C;
+}
+__device__ __forceinline__ uint32_t tfield(const Ctx& x, int thing, int f) { return x.l.things[thing * T_WORDS + f]; }
+
+// ---- sprite state in per-lane LDS columns ---------------------------------
+__device__ __forceinline__ void sprite_get(const Ctx& x, int s, int& vr, int& vc, int& vis, int& prior) {
+  uint32_t p = x.l.pos[s * WAVE + x.lane], f = x.l.flg[s * WAVE + x.lane];
+  vr = pos_r(p); vc = pos_c(p); vis = f & 1; prior = (f >> 1) & 1;
+}
+__device__ __forceinline__ void sprite_put(const Ctx& x, int s, int vr, int vc, int vis, int prior) {
+  x.l.pos[s * WAVE + x.lane] = pack_pos(vr, vc);
+  x.l.flg[s * WAVE + x.lane] = (uint32_t)vis | ((uint32_t)prior << 1);
+}
+// Sprite.position (true position): virtual if on board, else (0, 0) for walkers
+__device__ __forceinline__ void sprite_true(const Ctx& x, int s, int& r, int& c) {
+  uint32_t p = x.l.pos[s * WAVE + x.lane];
+  r = pos_r(p); c = pos_c(p);
+  if (!on_board(x.k, r, c)) { r = 0; c = 0; }
+}
+__device__ __forceinline__ int sprite_cell(const Ctx& x, int s) {  // engine.py:752-753
+  int vr, vc, vis, prior;
+  sprite_get(x, s, vr, vc, vis, prior);
+  if (!vis) return -1;
+  return on_board(x.k, vr, vc) ? vr * x.k.C + vc : 0;
+}
+// sprites.py:315-352 _teleport
+__device__ __forceinline__ void teleport(const Ctx& x, int s, int nr, int nc) {
+  int vr, vc, vis, prior;
+  sprite_get(x, s, vr, vc, vis, prior);
+  bool old_on = on_board(x.k, vr, vc), new_on = on_board(x.k, nr, nc);
+  if (old_on && !new_on) { prior = vis; vis = 0; }
+  if (!old_on && new_on) vis = prior;
+  sprite_put(x, s, nr, nc, vis, prior);
+}
+
+// ---- curtains: bit-rows in per-lane LDS columns ------------------------------
+__device__ __forceinline__ uint32_t* drape_rows(const Ctx& x, uint32_t* base, int d) {
+  return base + (size_t)d * x.k.R * x.k.RW * WAVE + x.lane;  // word i at [i * WAVE]
+}
+__device__ __forceinline__ bool bit_at(const Ctx& x, uint32_t* base, int d, int r, int c) {
+  return (drape_rows(x, base, d)[(r * x.k.RW + (c >> 5)) * WAVE] >> (c & 31)) & 1;
+}
+__device__ __forceinline__ uint64_t row_get(const Ctx& x, uint32_t* base, int d, int r) {
+  const uint32_t* p = drape_rows(x, base, d) + (size_t)(r * x.k.RW) * WAVE;
+  uint64_t v = p[0];
+  if (x.k.RW > 1) v |= (uint64_t)p[WAVE] << 32;
+  return v;
+}
+__device__ __forceinline__ void row_put(const Ctx& x, uint32_t* base, int d, int r, uint64_t v) {
+  uint32_t* p = drape_rows(x, base, d) + (size_t)(r * x.k.RW) * WAVE;
+  p[0] = (uint32_t)v;
+  if (x.k.RW > 1) p[WAVE] = (uint32_t)(v >> 32);
+}
+
+// engine.py:735 repaint == remember what every probe of the next group sees
+__device__ __forceinline__ void snapshot(const Ctx& x) {
+  for (int s = 0; s < x.k.NS; ++s) x.l.snap[s * WAVE + x.lane] = sprite_cell(x, s);
+  const int n = x.k.ND * x.k.R * x.k.RW;
+  for (int i = 0; i < n; ++i) x.l.snapd[i * WAVE + x.lane] = x.l.cur[i * WAVE + x.lane];
+}
+// character on top of board cell (r, c) in the last repaint (rendering.py:85-184)
+__device__ __forceinline__ int top_char(const Ctx& x, int r, int c) {
+  const int cell = r * x.k.C + c;
+  int ch = (x.l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
+  for (int z = 0; z < x.k.NT; ++z) {  // back to front
+    const int t = x.l.z[z];
+    const uint32_t kind = tfield(x, t, T_KIND), idx = tfield(x, t, T_IDX);
+    const bool here = kind == 0 ? x.l.snap[idx * WAVE + x.lane] == cell : bit_at(x, x.l.snapd, idx, r, c);
+    if (here) ch = tfield(x, t, T_CH);
+  }
+  return ch;
+}
+// numpy `layers[ch][r, c]` with Python index rules (negative wraps once)
+__device__ __forceinline__ bool layer_at(Ctx& x, int ch, int r, int c) {
+  if (r < 0) r += x.k.R;
+  if (c < 0) c += x.k.C;
+  if (!on_board(x.k, r, c)) { x.err |= ERR_INDEX; return false; }
+  return top_char(x, r, c) == ch;
+}
+
+// sprites.py:496-511 at()/is_impassable(), :479-546 _check_motion, :356-389 _move
+// (no scrolling group exists in these games, so the protocol hooks are no-ops)
+__device__ __forceinline__ bool blocked_at(Ctx& x, int thing, int vr, int vc, int dr, int dc) {
+  const int r = vr + dr, c = vc + dc;
+  if (!on_board(x.k, r, c)) return (tfield(x, thing, T_FLAGS) & TF_CONFINED) != 0;  // EDGE
+  const int ch = top_char(x, r, c);
+  return (tfield(x, thing, T_IMP0 + (ch >> 5)) >> (ch & 31)) & 1;
+}
+__device__ __forceinline__ bool mw_move(Ctx& x, int thing, int dr, int dc) {
+  const int s = tfield(x, thing, T_IDX);
+  int vr, vc, vis, prior;
+  sprite_get(x, s, vr, vc, vis, prior);
+  bool blocked = false;
+  if (dr != 0 && dc != 0)
+    blocked = blocked_at(x, thing, vr, vc, dr, dc) ||
+              (blocked_at(x, thing, vr, vc, dr, 0) && blocked_at(x, thing, vr, vc, 0, dc));
+  else if (dr != 0 || dc != 0)
+    blocked = blocked_at(x, thing, vr, vc, dr, dc);
+  if (!blocked) teleport(x, s, vr + dr, vc + dc);
+  return blocked;
+}
+
+__device__ __forceinline__ void terminate(Ctx& x) { x.game_over = 1; x.discount = 0.0f; }  // plot.py:176-198
+__device__ __forceinline__ void add_reward(Ctx& x, int r) { x.reward_set = 1; x.reward += r; }  // plot.py:200-226
+
+// ---- examples/warehouse_manager.py ------------------------------------------
+__device__ __forceinline__ void prog_wm_box(Ctx& x, int thing) {  // :214-226
+  const int s = tfield(x, thing, T_IDX);
+  int r, c;
+  sprite_true(x, s, r, c);
+  switch (x.action) {
+    case 0: if (layer_at(x, 'P', r + 1, c)) mw_move(x, thing, -1, 0); break;
+    case 1: if (layer_at(x, 'P', r - 1, c)) mw_move(x, thing, 1, 0); break;
+    case 2: if (layer_at(x, 'P', r, c + 1)) mw_move(x, thing, 0, -1); break;
+    case 3: if (layer_at(x, 'P', r, c - 1)) mw_move(x, thing, 0, 1); break;
+    default: break;
+  }
+}
+__device__ __forceinline__ void prog_wm_judge(Ctx& x, int thing) {  // :245-266
+  const int d = tfield(x, thing, T_IDX);
+  for (int r = 0; r < x.k.R; ++r) row_put(x, x.l.cur, d, r, 0);
+  for (int s = 0; s < x.k.NS; ++s) {
+    if (!((x.k.box_mask >> s) & 1)) continue;
+    int r, c;
+    sprite_true(x, s, r, c);
+    row_put(x, x.l.cur, d, r, row_get(x, x.l.cur, d, r) | (1ull << c));
+  }
+  int boxes = 0, on_goals = 0;
+  for (int r = 0; r < x.k.R; ++r) {
+    uint64_t bits = row_get(x, x.l.cur, d, r);
+    const uint64_t goals = (uint64_t)x.l.aux[r * x.k.RW] | (x.k.RW > 1 ? (uint64_t)x.l.aux[r * x.k.RW + 1] << 32 : 0);
+    boxes += __popcll(bits);
+    bits &= goals;  // backdrop.curtain == backdrop.palette._
+    on_goals += __popcll(bits);
+    row_put(x, x.l.cur, d, r, bits);
+  }
+  add_reward(x, on_goals - x.v[0]);
+  x.v[0] = on_goals;
+  if (x.action == 5 || on_goals == boxes) terminate(x);
+}
+__device__ __forceinline__ void prog_wm_player(Ctx& x, int thing) {  // :285-295
+  const int a = x.action;
+  if ((unsigned)a <= 3u) mw_move(x, thing, a == 0 ? -1 : a == 1 ? 1 : 0, a == 2 ? -1 : a == 3 ? 1 : 0);
+}
+
+// ---- examples/hello_world.py ---------------------------------------------------
+__device__ __forceinline__ uint64_t rot_cols(uint64_t bits, int shift, int C) {  // np.roll along axis 1
+  const uint64_t m = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
+  return shift > 0 ? ((bits << 1) | (bits >> (C - 1))) & m : ((bits >> 1) | (bits << (C - 1))) & m;
+}
+__device__ __forceinline__ void roll_rows(Ctx& x, int d, int shift) {  // np.roll along axis 0
+  const int R = x.k.R;
+  if (shift > 0) {
+    uint64_t carry = row_get(x, x.l.cur, d, R - 1);
+    for (int r = 0; r < R; ++r) { uint64_t t = row_get(x, x.l.cur, d, r); row_put(x, x.l.cur, d, r, carry); carry = t; }
+  } else {
+    uint64_t carry = row_get(x, x.l.cur, d, 0);
+    for (int r = R - 1; r >= 0; --r) { uint64_t t = row_get(x, x.l.cur, d, r); row_put(x, x.l.cur, d, r, carry); carry = t; }
+  }
+}
+__device__ __forceinline__ void prog_hw_rolling(Ctx& x, int thing) {  // :79-91
+  const int d = tfield(x, thing, T_IDX), a = x.action;
+  if (a < 0) return;
+  if (a == 4) terminate(x);
+  if (a < 4) {
+    const int shift = (a & 1) ? 1 : -1;
+    if (a < 2) roll_rows(x, d, shift);
+    else for (int r = 0; r < x.k.R; ++r) row_put(x, x.l.cur, d, r, rot_cols(row_get(x, x.l.cur, d, r), shift, x.k.C));
+    add_reward(x, 1);
+  }
+}
+__device__ __forceinline__ void prog_hw_sliding(Ctx& x, int thing) {  // :117-123
+  const int s = tfield(x, thing, T_IDX), a = x.action;
+  if ((unsigned)a > 3u) return;
+  const int dx = (int)((tfield(x, thing, T_P0) >> (2 * a)) & 3) - 1, dy = (int)((tfield(x, thing, T_P1) >> (2 * a)) & 3) - 1;
+  int vr, vc, vis, prior;
+  sprite_get(x, s, vr, vc, vis, prior);
+  vc = (vc + dx + x.k.C) % x.k.C;
+  vr = (vr + dy + x.k.R) % x.k.R;
+  sprite_put(x, s, vr, vc, vis, prior);
+}
+
+// ---- examples/extraterrestrial_marauders.py --------------------------------------
+// v[0] bunker_hitters, v[1] marauder_hitters (bit per sprite index),
+// v[2] last_player_shot, v[3] last_marauder_shot (frame, NEVER if unset);
+// MarauderDrape._dx and the RNG draw counter live in the flags word.
+__device__ __forceinline__ int em_erode(Ctx& x, int d, int bolt_mask, int& hitters) {
+  int hits = 0;
+  hitters = 0;
+  for (int s = 0; s < x.k.NS; ++s) {
+    if (!((bolt_mask >> s) & 1)) continue;
+    const int cell = x.l.snap[s * WAVE + x.lane];
+    if (cell < 0) continue;
+    const int r = cell / x.k.C, c = cell - r * x.k.C;
+    if (!bit_at(x, x.l.cur, d, r, c)) continue;
+    // layers[ch] is set only where ch is the character on top (rendering.py:177-179)
+    const int thing = x.l.s2t[s];
+    if (top_char(x, r, c) != (int)tfield(x, thing, T_CH)) continue;
+    row_put(x, x.l.cur, d, r, row_get(x, x.l.cur, d, r) & ~(1ull << c));
+    ++hits;
+    hitters |= 1 << s;  // board[hits]
+  }
+  return hits;
+}
+__device__ __forceinline__ void prog_em_bunker(Ctx& x, int thing) {  // :113-120
+  int hitters;
+  const int hits = em_erode(x, tfield(x, thing, T_IDX), x.k.bolt_mask_all, hitters);
+  add_reward(x, -hits);
+  x.v[0] = hitters;
+}
+__device__ __forceinline__ void prog_em_marauder(Ctx& x, int thing, int& dxv) {  // :141-163
+  const int d = tfield(x, thing, T_IDX), R = x.k.R, C = x.k.C;
+  int hitters;
+  const int hits = em_erode(x, d, x.k.bolt_mask_up, hitters);
+  add_reward(x, 10 * hits);
+  x.v[1] = hitters;
+  int total = 0;
+  uint64_t any_edge = 0;
+  for (int r = 0; r < R; ++r) { uint64_t b = row_get(x, x.l.cur, d, r); total += __popcll(b); any_edge |= b; }
+  const bool row10 = R > 10 ? row_get(x, x.l.cur, d, 10) != 0 : false;
+  if (R <= 10) x.err |= ERR_INDEX;
+  if (total == 0 || row10) { terminate(x); return; }
+  int period = (total - 1) / 8;  // total // 8.0000001
+  if (period < 1) period = 1;
+  if (x.frame % period) return;
+  if ((any_edge & 1ull) || ((any_edge >> (C - 1)) & 1ull)) {
+    dxv = -dxv;
+    roll_rows(x, d, 1);
+  }
+  for (int r = 0; r < R; ++r) row_put(x, x.l.cur, d, r, rot_cols(row_get(x, x.l.cur, d, r), dxv, C));
+}
+__device__ __forceinline__ void prog_em_player(Ctx& x, int thing) {  // :178-186
+  if (x.action == 0) mw_move(x, thing, 0, -1);
+  else if (x.action == 1) mw_move(x, thing, 0, 1);
+  else if (x.action == 4) terminate(x);
+}
+__device__ __forceinline__ void prog_em_upbolt(Ctx& x, int thing) {  // :198-220
+  const int s = tfield(x, thing, T_IDX);
+  int vr, vc, vis, prior;
+  sprite_get(x, s, vr, vc, vis, prior);
+  if (vis) {
+    if (((x.v[0] | x.v[1]) >> s) & 1) { teleport(x, s, -1, -1); return; }
+    mw_move(x, thing, -1, 0);
+  } else if (x.action == 2) {
+    if (x.v[2] == x.frame) return;
+    x.v[2] = x.frame;
+    int pr, pc;
+    sprite_true(x, tfield(x, x.k.ip, T_IDX), pr, pc);
+    teleport(x, s, pr - 1, pc);
+  }
+}
+constexpr uint64_t EM_RNG_SALT = 0x4D415241554445ull;
+__device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& draws, int64_t genv) {  // :232-256
+  const int s = tfield(x, thing, T_IDX), R = x.k.R, C = x.k.C;
+  int vr, vc, vis, prior;
+  sprite_get(x, s, vr, vc, vis, prior);
+  if (vis) {
+    if ((x.v[0] >> s) & 1) { teleport(x, s, -1, -1); return; }
+    int r, c, pr, pc;
+    sprite_true(x, s, r, c);
+    sprite_true(x, tfield(x, x.k.ip, T_IDX), pr, pc);
+    if (r == pr && c == pc) terminate(x);
+    mw_move(x, thing, 1, 0);
+  } else {
+    if (x.v[3] == x.frame) return;
+    x.v[3] = x.frame;
+    // columns of the *occluded* layer of 'X' in the last repaint that hold any X
+    uint64_t cols = 0;
+    for (int c = 0; c < C; ++c) {
+      bool any = false;
+      for (int r = 0; r < R && !any; ++r)
+        if (bit_at(x, x.l.snapd, x.k.ix, r, c) && top_char(x, r, c) == 'X') any = true;
+      if (any) cols |= 1ull << c;
+    }
+    const int n = __popcll(cols);
+    if (n == 0) { x.err |= ERR_INDEX; return; }  // np.random.choice([]) raises
+    const uint64_t seed = ((uint64_t)x.k.seed_lo | ((uint64_t)x.k.seed_hi << 32)) ^ EM_RNG_SALT;
+    int pick = (int)(action_hash(seed, (uint64_t)genv, (uint64_t)draws) % (uint32_t)n);
+    ++draws;
+    int col = 0;
+    for (int c = 0; c < C; ++c)
+      if ((cols >> c) & 1) { if (pick == 0) { col = c; break; } --pick; }
+    int row = 0;
+    for (int r = 0; r < R; ++r)
+      if (bit_at(x, x.l.snapd, x.k.ix, r, col) && top_char(x, r, col) == 'X') row = r;
+    teleport(x, s, row + 1, col);
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const Ptrs P, const StepArgs a,
+                                                         const pcx_buffers out) {
+  extern __shared__ uint32_t lds[];
+  const int lane = threadIdx.x;
+  const int64_t env0 = (int64_t)blockIdx.x * WAVE, env = env0 + lane;
+  for (int i = lane; i < P.n_table_words; i += WAVE) lds[i] = P.tables[i];
+  L l;
+  l.things = lds + k.l_things; l.z = lds + k.l_z; l.sched = lds + k.l_sched;
+  l.backdrop4 = lds + k.l_backdrop; l.bdmask = lds + k.l_bdmask; l.aux = lds + k.l_aux;
+  l.init = lds + k.l_init; l.initd = lds + k.l_initd; l.laybc = lds + k.l_laybc; l.s2t = lds + k.l_s2t;
+  l.pos = lds + k.l_pos; l.flg = lds + k.l_flg; l.snap = reinterpret_cast<int32_t*>(lds + k.l_snap);
+  l.cur = lds + k.l_cur; l.snapd = lds + k.l_snapd; l.flat = lds + k.l_flat;
+  l.sdesc = reinterpret_cast<uint2*>(lds + k.l_sdesc); l.skip = lds + k.l_skip;
+  __syncthreads();
+
+  const bool live = env < P.batch;
+  const int64_t bp = P.bpad;
+  uint32_t* st = P.state + env;
+  uint32_t flags = 0;
+  bool skip = !live, do_reset = false;
+  int action = PCX_ACTION_NONE;
+  if (live) {
+    flags = st[W_FLAGS * bp];
+    if (a.mode == 1) { do_reset = a.reset_mask ? a.reset_mask[env] != 0 : true; skip = !do_reset; }
+    else if (flags & F_OVER) { do_reset = a.auto_reset != 0; skip = !do_reset; }
+    else action = a.hashed ? (int)(action_hash(a.seed, (uint64_t)(a.env_offset + env), (uint64_t)a.t) % (uint32_t)k.n_actions)
+                           : a.actions[env];
+    if (action < 0) action = PCX_ACTION_NONE;
+  }
+  const int ndw = k.ND * k.R * k.RW;
+  if (!skip) {
+    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}};
+    // bits 8..15 of the flags word: MarauderDrape._dx + 1; W_RNG: RNG draws so far (survive resets)
+    uint32_t draws = st[W_RNG * bp];
+    int dxv;
+    if (do_reset) {  // engine.py:520-581: fresh template state, pre-showtime render
+      x.frame = (int)l.init[W_FRAME];
+      for (int j = 0; j < 4; ++j) x.v[j] = (int32_t)l.init[W_V0 + j];
+      dxv = (int)((l.init[W_FLAGS] >> 8) & 0xFF) - 1;
+      for (int s = 0; s < k.NS; ++s) {
+        l.pos[s * WAVE + lane] = l.init[W_SPRITES + s];
+        l.flg[s * WAVE + lane] = (l.init[k.w_sflags + (s >> 2)] >> (8 * (s & 3))) & 0xFF;
+      }
+      for (int i = 0; i < ndw; ++i) l.cur[i * WAVE + lane] = l.initd[i];
+      x.action = PCX_ACTION_NONE;
+    } else {
+      x.frame = (int)st[W_FRAME * bp];
+      x.err = (flags >> F_ERR_SHIFT) & 7u;
+      for (int j = 0; j < 4; ++j) x.v[j] = (int32_t)st[(W_V0 + j) * bp];
+      dxv = (int)((flags >> 8) & 0xFF) - 1;
+      for (int s = 0; s < k.NS; ++s) l.pos[s * WAVE + lane] = st[(W_SPRITES + s) * bp];
+      for (int w = 0; w < (k.NS + 3) / 4; ++w) {
+        const uint32_t f = st[(k.w_sflags + w) * bp];
+        for (int j = 0; j < 4 && 4 * w + j < k.NS; ++j) l.flg[(4 * w + j) * WAVE + lane] = (f >> (8 * j)) & 0xFF;
+      }
+      for (int i = 0; i < ndw; ++i) l.cur[i * WAVE + lane] = st[(k.w_drapes + i) * bp];
+    }
+    snapshot(x);  // what the previous frame's last repaint showed
+    // ---- Engine.play(): engine.py:698-735 --------------------------------
+    x.frame += 1;
+    const int64_t genv = ((int64_t)k.envoff_lo | ((int64_t)k.envoff_hi << 32)) + env;
+    int i = 0;
+    for (int g = 0; g < k.n_groups; ++g) {
+      for (; i < k.NT && (int)(l.sched[i] >> 8) == g; ++i) {
+        const int thing = l.sched[i] & 0xFF;
+        switch (tfield(x, thing, T_PROG)) {
+          case PCX_PROG_WM_BOX: prog_wm_box(x, thing); break;
+          case PCX_PROG_WM_JUDGE: prog_wm_judge(x, thing); break;
+          case PCX_PROG_WM_PLAYER: prog_wm_player(x, thing); break;
+          case PCX_PROG_HW_ROLLING: prog_hw_rolling(x, thing); break;
+          case PCX_PROG_HW_SLIDING: prog_hw_sliding(x, thing); break;
+          case PCX_PROG_EM_PLAYER: prog_em_player(x, thing); break;
+          case PCX_PROG_EM_BUNKER: prog_em_bunker(x, thing); break;
+          case PCX_PROG_EM_MARAUDER: prog_em_marauder(x, thing, dxv); break;
+          case PCX_PROG_EM_UPBOLT: prog_em_upbolt(x, thing); break;
+          case PCX_PROG_EM_DOWNBOLT: prog_em_downbolt(x, thing, draws, genv); break;
+          default: break;  // PCX_PROG_STATIC
+        }
+      }
+      if (g + 1 < k.n_groups) snapshot(x);  // engine.py:735 (the last repaint is the render phase)
+    }
+    // ---- _apply_and_clear_plot + state write-back ---------------------------
+    flags = (x.game_over ? F_OVER : 0u) | ((x.err & 7u) << F_ERR_SHIFT) | ((uint32_t)((dxv + 1) & 0xFF) << 8);
+    st[W_RNG * bp] = draws;
+    st[W_FRAME * bp] = (uint32_t)x.frame;
+    st[W_FLAGS * bp] = flags;
+    for (int j = 0; j < 4; ++j) st[(W_V0 + j) * bp] = (uint32_t)x.v[j];
+    for (int s = 0; s < k.NS; ++s) st[(W_SPRITES + s) * bp] = l.pos[s * WAVE + lane];
+    for (int w = 0; w < (k.NS + 3) / 4; ++w) {
+      uint32_t f = 0;
+      for (int j = 0; j < 4 && 4 * w + j < k.NS; ++j) f |= (l.flg[(4 * w + j) * WAVE + lane] & 0xFF) << (8 * j);
+      st[(k.w_sflags + w) * bp] = f;
+    }
+    for (int i2 = 0; i2 < ndw; ++i2) st[(k.w_drapes + i2) * bp] = l.cur[i2 * WAVE + lane];
+    out.reward[env] = x.reward;
+    out.reward_set[env] = (uint8_t)x.reward_set;
+    out.discount[env] = x.discount;
+    out.done[env] = (uint8_t)x.game_over;
+    out.frame[env] = x.frame;
+    out.error[env] = (uint8_t)x.err;
+
+    // ---- occlusion for the final repaint (engine.py:751-757) ----------------
+    // curtains -> flat cell-bit vectors; a curtain loses the cells a curtain in
+    // front of it also covers; a sprite is shown iff nothing in front covers
+    // its cell, and a shown sprite takes its cell from every curtain.
+    const int FW = k.FW, C = k.C;
+    for (int d = 0; d < k.ND; ++d) {
+      for (int w = 0; w < FW; ++w) l.flat[(d * FW + w) * WAVE + lane] = 0;
+      for (int r = 0; r < k.R; ++r) {
+        const uint64_t bits = row_get(x, l.cur, d, r);
+        const int off = r * C, wi = off >> 5, sh = off & 31;
+        const uint32_t w0 = (uint32_t)(bits << sh);
+        const uint32_t w1 = sh ? (uint32_t)(bits >> (32 - sh)) : (uint32_t)(bits >> 32);
+        const uint32_t w2 = sh ? (uint32_t)(bits >> (64 - sh)) : 0u;
+        l.flat[(d * FW + wi) * WAVE + lane] |= w0;
+        if (w1) l.flat[(d * FW + wi + 1) * WAVE + lane] |= w1;
+        if (w2) l.flat[(d * FW + wi + 2) * WAVE + lane] |= w2;
+      }
+    }
+    for (int t = 0; t < k.NT; ++t) {
+      if (tfield(x, t, T_KIND) != 1) continue;
+      const uint32_t d = tfield(x, t, T_IDX), above = tfield(x, t, T_ABOVE);
+      for (int u = 0; u < k.NT; ++u) {
+        if (!((above >> u) & 1) || tfield(x, u, T_KIND) != 1) continue;
+        const uint32_t du = tfield(x, u, T_IDX);
+        for (int w = 0; w < FW; ++w) l.flat[(d * FW + w) * WAVE + lane] &= ~l.flat[(du * FW + w) * WAVE + lane];
+      }
+    }
+    for (int t = 0; t < k.NT; ++t) {
+      if (tfield(x, t, T_KIND) != 0) continue;
+      const int s = tfield(x, t, T_IDX);
+      const int cell = sprite_cell(x, s);
+      bool shown = cell >= 0;
+      if (shown) {
+        const uint32_t above = tfield(x, t, T_ABOVE);
+        const int wi = cell >> 5, sh = cell & 31;
+        for (int u = 0; u < k.NT; ++u) {
+          if (!((above >> u) & 1)) continue;
+          const uint32_t ui = tfield(x, u, T_IDX);
+          if (tfield(x, u, T_KIND) == 0) { if (sprite_cell(x, ui) == cell) shown = false; }
+          else if ((l.flat[(ui * FW + wi) * WAVE + lane] >> sh) & 1) shown = false;
+        }
+        if (shown)
+          for (int d = 0; d < k.ND; ++d) l.flat[(d * FW + wi) * WAVE + lane] &= ~(1u << sh);
+      }
+      l.sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
+      int tr, tc;
+      sprite_true(x, s, tr, tc);
+      P.track[s * bp + env] = tr | (tc << 8) | ((int)(l.flg[s * WAVE + lane] & 1) << 16) | ((int)do_reset << 24);
+    }
+  }
+  l.skip[lane] = skip;
+  __syncthreads();
+  if (a.debug & 2) return;
+
+  // ---- render phase: the wavefront streams board + layers ---------------------
+  const int QW = k.QW, FW = k.FW, pitch = k.pitch;
+  const uint32_t env_stride = (uint32_t)(1 + k.L) * (uint32_t)pitch;
+  uint8_t* blk = out.planes + (size_t)env0 * env_stride;
+  const bool any_skip = __ballot(skip) != 0ull;
+  for (int it = 0; it < QW; ++it) {
+    const uint32_t f = (uint32_t)it * WAVE + lane;
+    const uint32_t e = (f * k.magic_q) >> 20, q = f - e * QW;
+    if (any_skip && l.skip[e]) continue;
+    uint8_t* dst = blk + e * env_stride + q * 4;
+    uint32_t d = l.backdrop4[q], uni = 0;
+    for (int t = 0; t < k.NT; ++t) {
+      const uint32_t kind = l.things[t * T_WORDS + T_KIND], idx = l.things[t * T_WORDS + T_IDX];
+      uint32_t m;
+      if (kind == 0) {
+        const uint2 sd = l.sdesc[idx * WAVE + e];
+        m = sd.x == q ? sd.y : 0u;
+      } else {
+        const uint32_t bits = (l.flat[(idx * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
+        const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+        m = (m01 << 8) - m01;
+      }
+      uni |= m;
+      const uint32_t ch4 = l.things[t * T_WORDS + T_CH] * 0x01010101u;
+      d = (d & ~m) | (ch4 & m);
+      // rendering.py:177-179: after occlusion a thing's layer is its own mask
+      *reinterpret_cast<uint32_t*>(dst + (1 + l.things[t * T_WORDS + T_LAYER]) * pitch) = m & 0x01010101u;
+    }
+    *reinterpret_cast<uint32_t*>(dst) = d;
+    for (int b = 0; b < k.n_bchars; ++b)
+      *reinterpret_cast<uint32_t*>(dst + (1 + l.laybc[b]) * pitch) = l.bdmask[b * QW + q] & ~uni;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+
+class GenericBackend : public Backend {
+ public:
+  int init(const pcx_template& t, int64_t batch) override;
+  int launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) override;
+  int read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) override;
+  int64_t bytes_per_step() const override {
+    return 4 + 8 * (int64_t)k_.NW + (int64_t)(1 + k_.L) * k_.cells + 15;
+  }
+  const char* kernel_name() const override { return "pcx_generic_step"; }
+  const int32_t* sprite_track() const override { return track_.ptr; }
+  int plane_pitch() const override { return k_.pitch; }
+
+ private:
+  Consts k_{};
+  int64_t batch_ = 0, bpad_ = 0;
+  DevArray<uint32_t> tables_, state_;
+  DevArray<int32_t> track_;
+  int n_table_words_ = 0;
+  std::vector<int> walker_;
+};
+
+int GenericBackend::init(const pcx_template& t, int64_t batch) {
+  Consts& k = k_;
+  batch_ = batch;
+  bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
+  if (!t.occlusion_in_layers)
+    return set_error(PCX_E_UNSUPPORTED, "generic backend: occlusion_in_layers=False is not supported yet");
+  k.game = t.game; k.R = t.rows; k.C = t.cols; k.cells = t.rows * t.cols; k.L = t.n_chars;
+  k.NS = t.n_sprites; k.ND = t.n_drapes; k.NT = t.n_things; k.n_groups = t.n_groups; k.n_actions = t.n_actions;
+  if (k.C > 64 || k.L > MAX_L || k.NT > 24 || k.cells > 4096)
+    return set_error(PCX_E_UNSUPPORTED, "generic backend: needs cols <= 64 and <= %d characters", MAX_L);
+  if ((1 + k.L) * k.cells % 4 != 0 && false) return set_error(PCX_E_UNSUPPORTED, "unreachable");
+  k.pitch = (k.cells + 3) & ~3;
+  k.QW = k.pitch / 4;
+  k.RW = (k.C + 31) / 32;
+  k.FW = (k.cells + 31) / 32 + 2;
+  {
+    bool ok = true;
+    uint32_t m = ((1u << 20) + k.QW - 1) / k.QW;
+    for (uint32_t x = 0; x <= (uint32_t)WAVE * k.QW; ++x)
+      if (((uint64_t)x * m) >> 20 != x / k.QW || (uint64_t)x * m > 0xFFFFFFFFull) { ok = false; break; }
+    if (!ok) return set_error(PCX_E_UNSUPPORTED, "generic backend: board too large for the 20-bit reciprocal");
+    k.magic_q = m;
+  }
+  k.seed_lo = (uint32_t)t.param[0]; k.seed_hi = (uint32_t)t.param[1];
+  k.envoff_lo = (uint32_t)t.param[2]; k.envoff_hi = (uint32_t)t.param[3];
+
+  // things, numbered by z-order position (back to front)
+  auto find_sprite = [&](int ch) { for (int s = 0; s < t.n_sprites; ++s) if (t.sprites[s].ch == ch) return s; return -1; };
+  auto find_drape = [&](int ch) { for (int d = 0; d < t.n_drapes; ++d) if (t.drapes[d].ch == ch) return d; return -1; };
+  auto layer_of = [&](int ch) { for (int i = 0; i < k.L; ++i) if (t.chars[i] == ch) return i; return -1; };
+  std::vector<uint32_t> things((size_t)k.NT * T_WORDS, 0), zt(k.NT), sched(k.NT);
+  k.ip = k.ix = k.ib = -1;
+  k.bolt_mask_all = k.bolt_mask_up = k.box_mask = 0;
+  for (int z = 0; z < k.NT; ++z) {
+    const int ch = t.z_order[z];
+    uint32_t* e = &things[(size_t)z * T_WORDS];
+    e[T_CH] = ch;
+    e[T_LAYER] = layer_of(ch);
+    uint32_t above = 0;
+    for (int u = z + 1; u < k.NT; ++u) above |= 1u << u;
+    e[T_ABOVE] = above;
+    int s = find_sprite(ch), d = find_drape(ch);
+    if (s >= 0) {
+      const pcx_sprite_desc& sd = t.sprites[s];
+      e[T_KIND] = 0; e[T_IDX] = s; e[T_PROG] = sd.program;
+      e[T_FLAGS] = (sd.is_walker ? TF_WALKER : 0) | (sd.confined ? TF_CONFINED : 0);
+      e[T_P0] = sd.param[0]; e[T_P1] = sd.param[1];
+      memcpy(&e[T_IMP0], sd.impassable, 16);
+      if (sd.egocentric) return set_error(PCX_E_UNSUPPORTED, "generic backend: egocentric walkers need the scrolly backend");
+      if (ch == 'P') k.ip = z;
+      if (sd.program == PCX_PROG_EM_UPBOLT) { k.bolt_mask_all |= 1 << s; k.bolt_mask_up |= 1 << s; }
+      if (sd.program == PCX_PROG_EM_DOWNBOLT) k.bolt_mask_all |= 1 << s;
+      if (sd.program == PCX_PROG_WM_BOX) k.box_mask |= 1 << s;
+    } else if (d >= 0) {
+      const pcx_drape_desc& dd = t.drapes[d];
+      if (dd.is_scrolly) return set_error(PCX_E_UNSUPPORTED, "generic backend: Scrolly drapes need the scrolly backend");
+      e[T_KIND] = 1; e[T_IDX] = d; e[T_PROG] = dd.program; e[T_P0] = dd.param[0]; e[T_P1] = dd.param[1];
+      if (ch == 'X') k.ix = d;
+      if (ch == 'B') k.ib = d;
+    } else {
+      return set_error(PCX_E_INVALID, "generic backend: z_order names an unknown character");
+    }
+    zt[z] = z;
+    switch (e[T_PROG]) {
+      case PCX_PROG_WM_BOX: case PCX_PROG_WM_JUDGE: case PCX_PROG_WM_PLAYER: case PCX_PROG_HW_ROLLING:
+      case PCX_PROG_HW_SLIDING: case PCX_PROG_EM_PLAYER: case PCX_PROG_EM_BUNKER: case PCX_PROG_EM_MARAUDER:
+      case PCX_PROG_EM_UPBOLT: case PCX_PROG_EM_DOWNBOLT: case PCX_PROG_STATIC: break;
+      default: return set_error(PCX_E_UNSUPPORTED, "generic backend: no device program %u", e[T_PROG]);
+    }
+  }
+  for (int i = 0; i < k.NT; ++i) {
+    int zi = -1;
+    for (int z = 0; z < k.NT; ++z) if (t.z_order[z] == t.schedule[i]) zi = z;
+    if (zi < 0) return set_error(PCX_E_INVALID, "generic backend: schedule names an unknown character");
+    sched[i] = (uint32_t)zi | ((uint32_t)t.group_of[i] << 8);
+  }
+  if (t.game == PCX_GAME_MARAUDERS && (k.ip < 0 || k.ix < 0))
+    return set_error(PCX_E_UNSUPPORTED, "generic backend: marauders needs things 'P' and 'X'");
+  if (t.game == PCX_GAME_WAREHOUSE && k.ip < 0)
+    return set_error(PCX_E_UNSUPPORTED, "generic backend: warehouse needs a 'P' sprite");
+
+  // backdrop, backdrop-only characters, goal cells ('_') as bit-rows
+  std::vector<uint32_t> bd4(k.QW, 0);
+  memcpy(bd4.data(), t.backdrop, k.cells);
+  k.n_bchars = 0;
+  std::vector<uint32_t> bdmask, laybc, s2t(k.NS ? k.NS : 1, 0);
+  for (int z = 0; z < k.NT; ++z) if (things[(size_t)z * T_WORDS + T_KIND] == 0) s2t[things[(size_t)z * T_WORDS + T_IDX]] = z;
+  for (int i = 0; i < k.L; ++i) {
+    const int ch = t.chars[i];
+    if (find_sprite(ch) >= 0 || find_drape(ch) >= 0) continue;
+    laybc.push_back(i); k.n_bchars++;
+    std::vector<uint32_t> m(k.QW, 0);
+    uint8_t* mb = reinterpret_cast<uint8_t*>(m.data());
+    for (int c = 0; c < k.cells; ++c) mb[c] = t.backdrop[c] == ch;
+    bdmask.insert(bdmask.end(), m.begin(), m.end());
+  }
+  std::vector<uint32_t> aux((size_t)k.R * k.RW, 0);
+  for (int r = 0; r < k.R; ++r)
+    for (int c = 0; c < k.C; ++c)
+      if (t.backdrop[r * k.C + c] == '_') aux[r * k.RW + (c >> 5)] |= 1u << (c & 31);
+
+  // state layout + initial words
+  k.w_sflags = W_SPRITES + k.NS;
+  k.w_drapes = k.w_sflags + (k.NS + 3) / 4;
+  const int ndw = k.ND * k.R * k.RW;
+  k.NW = k.w_drapes + ndw;
+  std::vector<uint32_t> init(k.NW, 0), initd(ndw ? ndw : 1, 0);
+  init[W_FRAME] = (uint32_t)-1;
+  uint32_t dx_plus1 = 1;
+  int32_t v[4] = {0, 0, (int32_t)NEVER, (int32_t)NEVER};
+  for (int d = 0; d < k.ND; ++d) {
+    if (t.drapes[d].program == PCX_PROG_EM_MARAUDER) dx_plus1 = (uint32_t)(t.drapes[d].param[0] + 1) & 0xFF;
+    if (t.drapes[d].program == PCX_PROG_WM_JUDGE) v[0] = t.drapes[d].param[0];
+    for (int r = 0; r < k.R; ++r)
+      for (int c = 0; c < k.C; ++c)
+        if (t.drapes[d].curtain[r * k.C + c]) initd[(d * k.R + r) * k.RW + (c >> 5)] |= 1u << (c & 31);
+  }
+  init[W_FLAGS] = dx_plus1 << 8;
+  for (int j = 0; j < 4; ++j) init[W_V0 + j] = (uint32_t)v[j];
+  walker_.assign(k.NS, 0);
+  for (int s = 0; s < k.NS; ++s) {
+    const pcx_sprite_desc& sd = t.sprites[s];
+    walker_[s] = sd.is_walker;
+    const int vr = sd.is_walker ? sd.vrow : sd.row, vc = sd.is_walker ? sd.vcol : sd.col;
+    init[W_SPRITES + s] = ((uint32_t)vr & 0xFFFFu) | ((uint32_t)vc << 16);
+    init[k.w_sflags + (s >> 2)] |= ((uint32_t)(sd.visible != 0) | ((uint32_t)(sd.prior_visible != 0) << 1)) << (8 * (s & 3));
+  }
+
+  // tables -> one buffer staged into LDS, then the per-lane arrays
+  std::vector<uint32_t> tab;
+  auto place = [&](const std::vector<uint32_t>& v2) { int off = (int)tab.size(); tab.insert(tab.end(), v2.begin(), v2.end()); return off; };
+  k.l_things = place(things); k.l_z = place(zt); k.l_sched = place(sched); k.l_backdrop = place(bd4);
+  k.l_bdmask = place(bdmask); k.l_aux = place(aux); k.l_init = place(init); k.l_initd = place(initd);
+  if (laybc.empty()) laybc.push_back(0);
+  k.l_laybc = place(laybc); k.l_s2t = place(s2t);
+  n_table_words_ = (int)tab.size();
+  int off = (n_table_words_ + 1) & ~1;
+  k.l_pos = off; off += k.NS * WAVE;
+  k.l_flg = off; off += k.NS * WAVE;
+  k.l_snap = off; off += k.NS * WAVE;
+  k.l_cur = off; off += ndw * WAVE;
+  k.l_snapd = off; off += ndw * WAVE;
+  k.l_flat = off; off += k.ND * k.FW * WAVE;
+  off = (off + 1) & ~1;
+  k.l_sdesc = off; off += 2 * k.NS * WAVE;
+  k.l_skip = off; off += WAVE;
+  k.l_words = off;
+  if ((size_t)off * 4 > 160 * 1024)
+    return set_error(PCX_E_UNSUPPORTED, "generic backend: template needs %d bytes of LDS per wave", off * 4);
+  int rc;
+  if ((rc = tables_.upload(tab))) return rc;
+  if ((rc = state_.alloc((size_t)k.NW * bpad_))) return rc;
+  if ((rc = track_.alloc((size_t)(k.NS ? k.NS : 1) * bpad_))) return rc;
+  return 0;
+}
+
+int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) {
+  Ptrs P{tables_.ptr, n_table_words_, state_.ptr, track_.ptr, batch_, bpad_};
+  size_t lds = (size_t)k_.l_words * 4;
+  if (lds > 64 * 1024)
+    PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pcx_generic_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(pcx_generic_step, dim3((unsigned)(bpad_ / WAVE)), dim3(WAVE), lds, s, k_, P, a, out);
+  PCX_HIP(hipGetLastError());
+  return 0;
+}
+
+int GenericBackend::read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) {
+  const Consts& k = k_;
+  std::vector<uint32_t> st((size_t)k.NW * n);
+  PCX_HIP(hipDeviceSynchronize());
+  for (int w = 0; w < k.NW; ++w)
+    PCX_HIP(hipMemcpy(st.data() + (size_t)w * n, state_.ptr + (size_t)w * bpad_ + env0, n * 4, hipMemcpyDeviceToHost));
+  auto word = [&](int w, int64_t i) { return st[(size_t)w * n + i]; };
+  for (int64_t i = 0; i < n; ++i) {
+    if (sprites)
+      for (int s = 0; s < k.NS; ++s) {
+        pcx_sprite_state& o = sprites[i * k.NS + s];
+        memset(&o, 0, sizeof o);
+        const uint32_t pw = word(W_SPRITES + s, i);
+        o.vrow = (int16_t)(pw & 0xFFFF); o.vcol = (int16_t)(pw >> 16);
+        const bool on = o.vrow >= 0 && o.vrow < k.R && o.vcol >= 0 && o.vcol < k.C;
+        o.row = on ? o.vrow : 0; o.col = on ? o.vcol : 0;
+        o.visible = (word(k.w_sflags + (s >> 2), i) >> (8 * (s & 3))) & 1;
+      }
+    if (curtains)
+      for (int d = 0; d < k.ND; ++d)
+        for (int r = 0; r < k.R; ++r)
+          for (int c = 0; c < k.C; ++c)
+            curtains[((size_t)i * k.ND + d) * k.cells + r * k.C + c] =
+                (word(k.w_drapes + (d * k.R + r) * k.RW + (c >> 5), i) >> (c & 31)) & 1;
+  }
+  return 0;
+}
+
+}  // namespace gen
+
+Backend* make_generic_backend() { return new gen::GenericBackend(); }
+
+}  // namespace pcx

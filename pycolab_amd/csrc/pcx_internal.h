@@ -72,9 +72,12 @@ class Backend {
   // Sprite state for croppers: device int32 [n_sprites][batch] packed
   // (row | col << 8 | visible << 16), refreshed by every launch.
   virtual const int32_t* sprite_track() const { return nullptr; }
+  // bytes between consecutive planes of one environment (>= rows*cols, multiple of 4)
+  virtual int plane_pitch() const = 0;
 };
 
 Backend* make_scrolly_maze_backend();
+Backend* make_generic_backend();
 
 }  // namespace pcx
 

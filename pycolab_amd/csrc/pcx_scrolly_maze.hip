@@ -790,6 +790,7 @@ class ScrollyMazeBackend : public Backend {
   }
   const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
   const int32_t* sprite_track() const override { return track_.ptr; }
+  int plane_pitch() const override { return k_.cells; }
 
  private:
   Consts k_{};

@@ -46,6 +46,9 @@ class Engine(object):
     self._batch = 1
     self._device_id = 0
     self._auto_reset = False
+    self._seed = 0
+    self._env_offset = 0
+    self._pitch = rows * cols
     self._template = None
     self._native = None
     self._keepalive = None
@@ -139,7 +142,7 @@ class Engine(object):
     return [(k, self._update_groups[k]) for k in sorted(self._update_groups)]
 
   # ------------------------------------------------------------ batched runtime
-  def configure(self, batch=None, device=None, auto_reset=None):
+  def configure(self, batch=None, device=None, auto_reset=None, seed=None, env_offset=None):
     """Choose how many environments to step, on which GPU, and what happens
     to environments whose episode has ended (`auto_reset=True`: the next
     step rebuilds them from the template and runs frame 0; counted as one
@@ -153,14 +156,18 @@ class Engine(object):
       self._device_id = int(device)
     if auto_reset is not None:
       self._auto_reset = bool(auto_reset)
+    if seed is not None:        # games that draw random numbers (marauders)
+      self._seed = int(seed)
+    if env_offset is not None:  # global index of this engine's first environment
+      self._env_offset = int(env_offset)
     return self
 
   @classmethod
-  def from_template(cls, template, batch=1, device=0, auto_reset=False):
+  def from_template(cls, template, batch=1, device=0, auto_reset=False, seed=0, env_offset=0):
     """An engine for a pre-compiled `GameTemplate` (no Python entity objects)."""
     eng = cls(template.rows, template.cols, template.occlusion_in_layers)
     eng._template = template
-    eng.configure(batch=batch, device=device, auto_reset=auto_reset)
+    eng.configure(batch=batch, device=device, auto_reset=auto_reset, seed=seed, env_offset=env_offset)
     return eng
 
   @property
@@ -178,15 +185,19 @@ class Engine(object):
     self._forbid_after_showtime('its_showtime')
     template = self.template  # compile before flipping any state
     lib = N.lib()
+    # param[0..3]: RNG seed and global environment offset (64 bits each)
+    template.param[0], template.param[1] = self._seed & 0xFFFFFFFF, (self._seed >> 32) & 0xFFFFFFFF
+    template.param[2], template.param[3] = self._env_offset & 0xFFFFFFFF, (self._env_offset >> 32) & 0xFFFFFFFF
     ct, keep = template.to_ctypes()
     handle = ctypes.c_void_p()
     N.check(lib.pcx_engine_create(ctypes.byref(ct), self._batch,
                                   self._device_id, ctypes.byref(handle)))
     self._native, self._keepalive = handle, keep
     B, L, R, C = self._batch, len(template.chars), self._rows, self._cols
+    self._pitch = int(lib.pcx_engine_plane_pitch(self._native))
     mk = lambda shape, dt: dev.DeviceBuffer(shape, dt, self._device_id)
     self._bufs = dict(
-        planes=mk((B, 1 + L, R, C), np.uint8), reward=mk((B,), np.int32),
+        planes=mk((B, 1 + L, self._pitch), np.uint8), reward=mk((B,), np.int32),
         reward_set=mk((B,), np.uint8), discount=mk((B,), np.float32),
         done=mk((B,), np.uint8), frame=mk((B,), np.int32),
         error=mk((B,), np.uint8))
@@ -259,17 +270,26 @@ class Engine(object):
                                       (4, 'play() after game over')) if code & bit]
       raise RuntimeError('environment {} raised {} on the device'.format(bad, kinds))
 
+  def planes_view(self, host=False):
+    """Observation planes as [B, 1+n_chars, rows, cols]: a zero-copy strided
+    view of the device tensor (plane pitch may exceed rows*cols), or a NumPy
+    copy with `host=True` / without PyTorch."""
+    planes = self._bufs['planes']
+    B, P, R, C = self._batch, 1 + len(self._template.chars), self._rows, self._cols
+    if planes.tensor is not None and not host:
+      return planes.tensor.as_strided((B, P, R, C), (P * self._pitch, self._pitch, C, 1))
+    return np.ascontiguousarray(planes.numpy()[:, :, :R * C]).reshape(B, P, R, C)
+
   def _result(self):
     L = self._template.chars
-    planes = self._bufs['planes']
     if self._batch == 1:
       sc = self._read_scalars()
       self.check_errors()
-      p = planes.numpy()[0]
+      p = self.planes_view(host=True)[0]
       layers = {chr(c): p[1 + k].astype(np.bool_) for k, c in enumerate(L)}
       reward = int(sc['reward'][0]) if sc['reward_set'][0] else None
       return rendering.Observation(board=p[0], layers=layers), reward, float(sc['discount'][0])
-    arr = planes.tensor if planes.tensor is not None else planes.numpy()
+    arr = self.planes_view()
     layers = {chr(c): arr[:, 1 + k] for k, c in enumerate(L)}
     pick = lambda k: (self._bufs[k].tensor if self._bufs[k].tensor is not None
                       else self._bufs[k].numpy())
@@ -279,7 +299,7 @@ class Engine(object):
   # ---------------------------------------------------------------- properties
   @property
   def planes(self):
-    """The raw observation planes buffer [B, 1+n_chars, rows, cols]."""
+    """The raw observation planes buffer [B, 1+n_chars, pitch] (see planes_view)."""
     return self._bufs['planes']
 
   @property
