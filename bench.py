@@ -51,6 +51,8 @@ def main():
   ap.add_argument('--warmup', type=int, default=20)
   ap.add_argument('--batch', type=int, default=1 << 20, help='environments PER GPU (weak scaling)')
   ap.add_argument('--level', type=int, default=0)
+  ap.add_argument('--game', default='scrolly_maze', choices=['scrolly_maze', 'warehouse', 'marauders', 'hello_world'],
+                  help='scrolly_maze is the headline metric; the others are the parity configs of BASELINE.json')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   args = ap.parse_args()
 
@@ -69,10 +71,12 @@ def main():
   from pycolab_amd.compiler import GameTemplate
   from pycolab_amd.engine import Engine
 
-  template_path = os.path.join(ROOT, 'tests', 'golden', 'templates', 'scrolly_maze_L%d.npz' % args.level)
+  fixture = {'scrolly_maze': 'scrolly_maze_L%d' % args.level, 'warehouse': 'warehouse_L%d' % args.level,
+             'marauders': 'marauders', 'hello_world': 'hello_world'}[args.game]
+  template_path = os.path.join(ROOT, 'tests', 'golden', 'templates', fixture + '.npz')
   template = GameTemplate.load(template_path)
   B = args.batch
-  eng = Engine.from_template(template, batch=B, device=local, auto_reset=True)
+  eng = Engine.from_template(template, batch=B, device=local, auto_reset=True, seed=0x5EED, env_offset=rank * B)
   eng.its_showtime()
 
   # Synthetic action tape, resident in HBM before timing: uniform ordinary
@@ -119,7 +123,8 @@ def main():
       except Exception:  # pylint: disable=broad-except
         pass
     line = {
-        'metric': 'env-steps/sec (whole node), scrolly_maze batch=1M; bit-exact vs CPU',
+        'metric': 'env-steps/sec (whole node), scrolly_maze batch=1M; bit-exact vs CPU' if args.game == 'scrolly_maze'
+                  else 'env-steps/sec (whole node), %s' % fixture,
         'value': world * B * args.steps / wall,
         'unit': 'env-steps/s',
         'n_gpus': world,
@@ -131,9 +136,9 @@ def main():
         'vs_baseline': None,
         'dtype': 'u8',
         'data': 'synthetic',
-        'config': {'workload': 'examples/scrolly_maze.py level %d, %d envs per GPU, uniform actions 0-4, '
+        'config': {'workload': 'examples/%s level %d, %d envs per GPU, uniform actions 0-%d, '
                                'auto-reset episodes, full observation (board + %d layers) every step'
-                               % (args.level, B, len(template.chars)),
+                               % (fixture, args.level, B, template.n_actions - 1, len(template.chars)),
                    'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'env-shard x%d' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

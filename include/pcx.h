@@ -274,6 +274,10 @@ int pcx_cropper_crop(pcx_cropper* c, void* stream);
  * corner: int32 [batch][2] window corner (scrolling croppers). */
 int pcx_cropper_buffers(pcx_cropper* c, uint8_t** planes_dev,
                         int32_t** corner_dev);
+/* Host copy of uint8[batch]: 1 where the reference would raise RuntimeError
+ * (window leaves the observation and there is no pad character,
+ * cropping.py:175-183).  Synchronous. */
+int pcx_cropper_errors(pcx_cropper* c, uint8_t* errors_host);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,7 @@ _SYMS = [
     ('pcxo_cropper_destroy', None, [ctypes.c_void_p]),
     ('pcxo_cropper_crop', N.c_i32, [ctypes.c_void_p]),
     ('pcxo_cropper_buffers', N.c_i32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
+    ('pcxo_cropper_errors', ctypes.c_void_p, [ctypes.c_void_p]),
 ]
 
 _lib = None
@@ -135,3 +136,38 @@ class OracleEngine(object):
       self.close()
     except Exception:  # pylint: disable=broad-except
       pass
+
+
+class OracleCropper(object):
+  """One cropper (a `pycolab_amd.cropping` object supplies the descriptor)
+  over an OracleEngine's batch."""
+
+  def __init__(self, engine, cropper):
+    cropper._engine = _EngineShim(engine)
+    desc = cropper._describe()
+    self.engine, self.rows, self.cols = engine, desc.rows, desc.cols
+    self._h = ctypes.c_void_p()
+    _check(lib().pcxo_cropper_create(engine._h, ctypes.byref(desc), ctypes.byref(self._h)))
+
+  def crop(self):
+    _check(lib().pcxo_cropper_crop(self._h))
+    planes, corner = ctypes.c_void_p(), ctypes.c_void_p()
+    _check(lib().pcxo_cropper_buffers(self._h, ctypes.byref(planes), ctypes.byref(corner)))
+    B, P = self.engine.batch, 1 + len(self.engine.template.chars)
+    n = B * P * self.rows * self.cols
+    arr = np.frombuffer((ctypes.c_uint8 * n).from_address(planes.value), np.uint8).reshape(B, P, self.rows, self.cols)
+    err = np.frombuffer((ctypes.c_uint8 * B).from_address(lib().pcxo_cropper_errors(self._h)), np.uint8)
+    return arr.copy(), err.copy()
+
+  def close(self):
+    if self._h:
+      lib().pcxo_cropper_destroy(self._h)
+      self._h = None
+
+
+class _EngineShim(object):
+  """What a cropper's _describe() looks at."""
+
+  def __init__(self, engine):
+    self.z_order = engine.template.thing_chars()
+    self.rows, self.cols = engine.template.rows, engine.template.cols

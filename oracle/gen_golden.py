@@ -129,8 +129,44 @@ class ChoicePatch(object):
     return arr[self._hash(self.seed ^ self.SALT, self.env, n) % len(arr)]
 
 
+def make_reference_croppers(specs):
+  from pycolab import cropping
+  out = []
+  for sp in specs:
+    if sp['kind'] == 'fixed':
+      out.append(cropping.FixedCropper(tuple(sp['top_left']), sp['rows'], sp['cols'], sp['pad_char']))
+    else:
+      out.append(cropping.ScrollingCropper(
+          sp['rows'], sp['cols'], list(sp['to_track']), pad_char=sp['pad_char'],
+          scroll_margins=tuple(sp['scroll_margins']),
+          initial_offset=None if sp['initial_offset'] is None else tuple(sp['initial_offset']),
+          saccade=sp['saccade']))
+  return out
+
+
+def S(rows, cols, to_track, pad_char=None, scroll_margins=(2, 3), initial_offset=None, saccade=True):
+  return dict(kind='scrolling', rows=rows, cols=cols, to_track=list(to_track), pad_char=pad_char,
+              scroll_margins=list(scroll_margins), initial_offset=initial_offset, saccade=saccade)
+
+
+def F(top_left, rows, cols, pad_char=None):
+  return dict(kind='fixed', top_left=list(top_left), rows=rows, cols=cols, pad_char=pad_char)
+
+
+CROPPERS = {
+    'scrolly_maze_L0': [S(5, 11, 'P', ' ', (1, 2)), S(7, 9, 'aP', None, (2, 3)), F((-2, -3), 8, 20, '#'),
+                        S(5, 5, 'cb', '.', (None, None), (1, -1), False), S(3, 9, '@P', ' ', (1, 3))],
+    'warehouse_L1': [S(5, 5, 'P', None, (1, 1)), S(7, 7, '3P', '.', (2, 2), (0, 1)), F((2, 3), 5, 6),
+                     S(3, 9, 'XP', ' ', (1, 2)), F((8, 9), 6, 7, '#')],
+    'marauders': [S(7, 15, 'P', None, (2, 4)), S(9, 11, 'ayP', ' ', (None, None)), F((10, -5), 8, 20, 'B'),
+                  S(5, 9, 'X', ' ', (1, 3), None, False)],
+}
+
+
 def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, seeker=False, choice=None):
   boards, rewards, rsets, discounts, dones, sprites = [], [], [], [], [], []
+  specs = CROPPERS.get(name, [])
+  crops = [[] for _ in specs]
   actions = np.zeros((T, E), np.int32)
   chars = sprite_chars = None
   for e in range(E):
@@ -140,15 +176,30 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
       choice.env = e
     game = make_game()
     rec = []
+    croppers = make_reference_croppers(specs)
+    env_crops = [[] for _ in specs]
+
+    def crop_all(obs):
+      for i, cr in enumerate(croppers):
+        out = cr.crop(obs)
+        for c in chars:  # cropped layers stay board == c (pad included)
+          assert np.array_equal(out.layers[c], out.board == ord(c)), (name, i, c)
+        env_crops[i].append(out.board.copy())
+
+    for cr in croppers:
+      cr.set_engine(game)
     obs, r, d = game.its_showtime()
     if chars is None:
       chars = sorted(obs.layers.keys())
       # template order of sprites = engine insertion (update schedule) order
       sprite_chars = template_sprite_chars(template_name)
     rec.append(record(obs, r, d, game, chars, sprite_chars))
+    crop_all(obs)
     for t in range(T):
       if game.game_over:
         game = make_game()
+        for cr in croppers:
+          cr.set_engine(game)  # a new Engine: scrolling croppers start over (cropping.py:378-391)
         obs, r, d = game.its_showtime()
       else:
         if seeker and e % 8 >= 5:
@@ -156,18 +207,24 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
         a = int(actions[t, e])
         obs, r, d = game.play(None if a == NONE else a)
       rec.append(record(obs, r, d, game, chars, sprite_chars))
+      crop_all(obs)
+    for i in range(len(specs)):
+      crops[i].append(env_crops[i])
     boards.append([x[0] for x in rec]); rewards.append([x[1] for x in rec])
     rsets.append([x[2] for x in rec]); discounts.append([x[3] for x in rec])
     dones.append([x[4] for x in rec]); sprites.append([x[5] for x in rec])
   sw = lambda x, dt: np.ascontiguousarray(np.swapaxes(np.array(x, dtype=dt), 0, 1))
   path = os.path.join(ROOT, 'tests', 'golden', 'traces', name + '.npz')
+  import json
+  extra = {'crop_%d' % i: sw(crops[i], np.uint8) for i in range(len(specs))}
+  extra['crop_specs'] = np.frombuffer(json.dumps(specs).encode(), np.uint8)
   np.savez_compressed(
       path, template=np.frombuffer(template_name.encode(), np.uint8),
       chars=np.array([ord(c) for c in chars], np.uint8),
       sprite_chars=np.array([ord(c) for c in sprite_chars], np.uint8),
       actions=actions, boards=sw(boards, np.uint8), reward=sw(rewards, np.int32),
       reward_set=sw(rsets, np.uint8), discount=sw(discounts, np.float32),
-      done=sw(dones, np.uint8), sprites=sw(sprites, np.int16))
+      done=sw(dones, np.uint8), sprites=sw(sprites, np.int16), **extra)
   nd = int(np.array(dones).sum())
   nr = int(np.array(rsets).sum())
   print('wrote %s: E=%d T=%d episodes_ended=%d rewards=%d size=%d' % (

@@ -980,3 +980,44 @@ int pcxo_engine_read_things(pcxo_engine* e, int64_t env0, int64_t n,
 }
 
 /* ---- croppers: see pcx_oracle_crop.c --------------------------------------- */
+
+/* ---- accessors for pcx_oracle_crop.c ----------------------------------------- */
+int pcxo__rows(const pcxo_engine* e) { return e->t.rows; }
+int pcxo__cols(const pcxo_engine* e) { return e->t.cols; }
+int pcxo__n_chars(const pcxo_engine* e) { return e->t.n_chars; }
+int pcxo__char(const pcxo_engine* e, int k) { return e->t.chars[k]; }
+int64_t pcxo__batch(const pcxo_engine* e) { return e->batch; }
+const uint8_t* pcxo__planes(const pcxo_engine* e, int64_t b) { return env_board((pcxo_engine*)e, b); }
+int pcxo__frame(const pcxo_engine* e, int64_t b) { return e->frame[b]; }
+int pcxo__valid_char(const pcxo_engine* e, int ch) { return char_index(e, ch) >= 0; }
+
+static int cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+/* int(np.median(v)): mean of the two middle values for even counts, truncated */
+static int median_int(int* v, int n) {
+  qsort(v, n, sizeof(int), cmp_int);
+  if (n & 1) return v[n / 2];
+  return (int)((v[n / 2 - 1] + v[n / 2]) / 2.0);
+}
+/* cropping.py:551-598 _centroid */
+int pcxo__centroid(const pcxo_engine* e, int64_t b, int ch, int* row, int* col) {
+  int id = thing_id(e, ch);
+  if (id < 0) return 0; /* the reference raises RuntimeError; callers validate */
+  const ox_env* env = &e->envs[b];
+  if (id < PCX_MAX_SPRITES) {
+    const ox_sprite* s = &env->sprites[id];
+    if (!s->visible) return 0;
+    *row = s->row; *col = s->col;
+    return 1;
+  }
+  const uint8_t* cur = env->drapes[id - PCX_MAX_SPRITES].curtain;
+  int n = cells(e), m = 0;
+  int* rs = (int*)malloc(sizeof(int) * n * 2);
+  int* cs = rs + n;
+  for (int i = 0; i < n; ++i)
+    if (cur[i]) { rs[m] = i / e->t.cols; cs[m] = i % e->t.cols; ++m; }
+  if (m == 0) { free(rs); return 0; }
+  *row = median_int(rs, m);
+  *col = median_int(cs, m);
+  free(rs);
+  return 1;
+}

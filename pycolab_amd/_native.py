@@ -116,6 +116,7 @@ SYMBOLS = [
     ('pcx_cropper_destroy', None, [_VP]),
     ('pcx_cropper_crop', c_i32, [_VP, _VP]),
     ('pcx_cropper_buffers', c_i32, [_VP, ctypes.POINTER(_VP), ctypes.POINTER(_VP)]),
+    ('pcx_cropper_errors', c_i32, [_VP, _VP]),
 ]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpcx.so')

@@ -1,0 +1,220 @@
+"""Observation croppers (reference: pycolab/cropping.py:30-598).
+
+Same classes, constructor arguments, validation and error types as the
+reference.  `crop()` runs on the device: a cropper owns one window per
+environment of the engine's batch (`csrc/pcx_crop.hip`), and the returned
+`Observation` holds [rows, cols] arrays for batch 1 or [B, rows, cols] device
+tensors otherwise -- valid until the next `crop()`, like the reference's
+pre-allocated output (cropping.py:131-134).
+"""
+
+import copy
+import ctypes
+
+import numpy as np
+
+from pycolab_amd import _native as N
+from pycolab_amd import device as dev
+from pycolab_amd import rendering
+
+
+class ObservationCropper(object):
+  """The identity cropper (cropping.py:30-227)."""
+
+  def __init__(self):
+    self._engine = None
+    self._native = None
+    self._pad_char = None
+
+  def set_engine(self, engine):
+    if engine is not self._engine:
+      self._release()
+    self._engine = engine
+    register = getattr(engine, '_register_cropper', None)
+    if register is not None:  # lets its_showtime() attach device croppers before frame 0
+      register(self)
+
+  def crop(self, observation):
+    return observation
+
+  @property
+  def rows(self):
+    return self._engine.rows
+
+  @property
+  def cols(self):
+    return self._engine.cols
+
+  # -- device plumbing shared by the real croppers -------------------------------
+  def _describe(self):
+    raise NotImplementedError
+
+  def _release(self):
+    if self._native is not None:
+      N.lib().pcx_cropper_destroy(self._native)
+      self._native = None
+
+  def __del__(self):
+    try:
+      self._release()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def _device_crop(self):
+    eng = self._engine
+    if eng is None or eng._native is None:
+      raise RuntimeError('crop() needs set_engine() with an engine that is in play')
+    if self._native is None:
+      self._create_native()
+    N.check(N.lib().pcx_cropper_crop(self._native, dev.current_stream(eng._device_id)))
+    return self._fetch()
+
+  def _create_native(self):
+    eng = self._engine
+    if self._native is None and type(self) is not ObservationCropper:
+      valid = set(eng.z_order) | {chr(c) for c in eng.template.chars}
+      if self._pad_char is not None and self._pad_char not in valid:
+        raise ValueError(
+            'An `ObservationCropper` tried to fill empty space with a character '
+            'that isn\'t used by the current game engine.')
+      desc = self._describe()
+      handle = ctypes.c_void_p()
+      N.check(N.lib().pcx_cropper_create(eng._native, ctypes.byref(desc), ctypes.byref(handle)))
+      self._native = handle
+
+  def _fetch(self):
+    eng = self._engine
+    planes, corner, err = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    N.check(N.lib().pcx_cropper_buffers(self._native, ctypes.byref(planes), ctypes.byref(corner)))
+    B, P, r, c = eng.batch, 1 + len(eng.template.chars), self._rows, self._cols
+    host = np.empty((B, P, r, c), np.uint8)
+    dev.synchronize(eng._device_id)
+    N.check(N.lib().pcx_memcpy_d2h(host.ctypes.data, planes, host.nbytes))
+    errs = np.empty((B,), np.uint8)
+    N.check(N.lib().pcx_cropper_errors(self._native, errs.ctypes.data))
+    if errs.any():
+      raise RuntimeError(
+          'An ObservationCropper attempted to crop a region that extends '
+          'beyond the observation without specifying a character to fill the '
+          'void that exists out there.')
+    return host
+
+  def _observation(self, host):
+    chars = self._engine.template.chars
+    if self._engine.batch == 1:
+      return rendering.Observation(
+          board=host[0, 0], layers={chr(ch): host[0, 1 + k].astype(np.bool_) for k, ch in enumerate(chars)})
+    return rendering.Observation(
+        board=host[:, 0], layers={chr(ch): host[:, 1 + k] for k, ch in enumerate(chars)})
+
+
+class FixedCropper(ObservationCropper):
+  """A constant window (cropping.py:230-268)."""
+
+  def __init__(self, top_left_corner, rows, cols, pad_char=None):
+    super(FixedCropper, self).__init__()
+    self._top_row, self._left_col = top_left_corner
+    self._rows = rows
+    self._cols = cols
+    self._pad_char = pad_char
+
+  def crop(self, observation):
+    del observation  # the device crops the engine's current observation
+    return self._observation(self._device_crop())
+
+  def _describe(self):
+    d = N.CropperDesc()
+    d.kind, d.rows, d.cols = N.CROP_FIXED, self._rows, self._cols
+    d.top, d.left = self._top_row, self._left_col
+    d.pad_char = -1 if self._pad_char is None else ord(self._pad_char)
+    return d
+
+  @property
+  def rows(self):
+    return self._rows
+
+  @property
+  def cols(self):
+    return self._cols
+
+
+class ScrollingCropper(ObservationCropper):
+  """A window that follows game entities (cropping.py:271-598)."""
+
+  def __init__(self, rows, cols, to_track, pad_char=None,
+               scroll_margins=(2, 3), initial_offset=None, saccade=True):
+    super(ScrollingCropper, self).__init__()
+    self._rows = rows
+    self._cols = cols
+    self._to_track = copy.copy(to_track)
+    self._pad_char = pad_char
+    if ((scroll_margins[0] is None and (rows % 2 == 0)) or
+        (scroll_margins[1] is None and (cols % 2 == 0))):
+      raise ValueError(
+          'A ScrollingCropper can\'t perform perfectly-egocentric scrolling '
+          'with a window that has an even number of rows or columns. Either '
+          'specify looser scroll margins or use a window with odd dimensions.')
+    scroll_margins = (
+        (rows // 2) if scroll_margins[0] is None else scroll_margins[0],
+        (cols // 2) if scroll_margins[1] is None else scroll_margins[1])
+    if (2 * scroll_margins[0]) >= rows or (2 * scroll_margins[1]) >= cols:
+      raise ValueError(
+          'A ScrollingCropper can\'t use scroll margins which extend to or '
+          'beyond the very centre of the scrolling window. (Note that if you '
+          'haven\'t specified scroll margins and your window is very small or '
+          'thin, the default scroll_margins argument might be too big!)')
+    self._scroll_margins = scroll_margins
+    self._initial_offset = initial_offset if initial_offset is not None else (0, 0)
+    self._saccade = saccade
+
+  def set_engine(self, engine):
+    prior = self._engine
+    super(ScrollingCropper, self).set_engine(engine)
+    if engine is not prior:
+      if ((engine.rows < self._rows or engine.cols < self._cols)
+          and self._pad_char is None):
+        raise ValueError(
+            'A ScrollingCropper with a size of {} and no pad character '
+            'can\'t be used with a pycolab engine that produces smaller '
+            'observations in any dimension (in this case, {})'.format(
+                (self._rows, self._cols), (engine.rows, engine.cols)))
+
+  def crop(self, observation):
+    del observation
+    return self._observation(self._device_crop())
+
+  def _describe(self):
+    things = set(self._engine.z_order)
+    for entity in self._to_track:
+      if entity not in things:
+        raise RuntimeError('ScrollingCropper was told to track a nonexistent game entity '
+                           '{!r}.'.format(entity))
+    d = N.CropperDesc()
+    d.kind, d.rows, d.cols = N.CROP_SCROLLING, self._rows, self._cols
+    d.pad_char = -1 if self._pad_char is None else ord(self._pad_char)
+    d.n_track = len(self._to_track)
+    for i, ch in enumerate(self._to_track):
+      d.to_track[i] = ord(ch)
+    d.margin_rows, d.margin_cols = self._scroll_margins
+    d.initial_offset_rows, d.initial_offset_cols = self._initial_offset
+    d.saccade = int(bool(self._saccade))
+    return d
+
+  @property
+  def rows(self):
+    return self._rows
+
+  @property
+  def cols(self):
+    return self._cols
+
+
+def cropper_from_spec(spec):
+  """Build a cropper from the dict form used by the golden fixtures."""
+  if spec['kind'] == 'fixed':
+    return FixedCropper(tuple(spec['top_left']), spec['rows'], spec['cols'], spec['pad_char'])
+  return ScrollingCropper(
+      spec['rows'], spec['cols'], list(spec['to_track']), pad_char=spec['pad_char'],
+      scroll_margins=tuple(spec['scroll_margins']),
+      initial_offset=None if spec['initial_offset'] is None else tuple(spec['initial_offset']),
+      saccade=spec['saccade'])

@@ -1,18 +1,251 @@
-// pcx_crop.hip -- device croppers (cropping.py).  Placeholder entry points;
-// the kernels land with SURVEY.md section 8 rows a15-a17.
+// pcx_crop.hip -- device croppers (reference: pycolab/cropping.py).
+//   pcx_crop_update: one thread per environment moves the window
+//     (ScrollingCropper.crop :393-426, _initialise :438-458, _can_pan_to
+//     :460-506, _pan_to :508-534, _rectify :536-542, _centroid :551-598);
+//   pcx_crop_copy: one thread per output dword gathers the window from the
+//     engine's observation planes (_do_crop :118-227), padding included.
+// Sprite positions come from the step kernel's per-step `track` words, drape
+// curtains (only for drape-tracking croppers) from its raw curtain export.
 #include "pcx_internal.h"
+
+#include <cstring>
 
 using pcx::set_error;
 
-struct pcx_cropper {};
+namespace {
+
+struct CropParams {
+  int32_t kind, rows, cols, top, left, pad_char;
+  int32_t n_track;
+  int32_t track_kind[PCX_MAX_THINGS];  // 0 sprite, 1 drape
+  int32_t track_idx[PCX_MAX_THINGS];
+  int32_t margin_rows, margin_cols, off_rows, off_cols, saccade;
+  int32_t R, C, L, in_pitch, out_pitch, FW;
+  uint32_t chars[PCX_MAX_CHARS];
+  int64_t batch, bpad;
+};
+
+__device__ inline int imax(int a, int b) { return a > b ? a : b; }
+__device__ inline int imin(int a, int b) { return a < b ? a : b; }
+
+// int(np.median(indices)) over the set cells of one curtain, along one axis
+__device__ int median_axis(const uint32_t* bits, int64_t stride, int R, int C, int n, bool rows_axis) {
+  // the two middle order statistics (0-based) of the sorted index list
+  const int lo_rank = (n - 1) / 2, hi_rank = n / 2;
+  int seen = 0, lo = -1, hi = -1;
+  const int outer = rows_axis ? R : C, inner = rows_axis ? C : R;
+  for (int o = 0; o < outer && hi < 0; ++o) {
+    int cnt = 0;
+    for (int i = 0; i < inner; ++i) {
+      const int cell = rows_axis ? o * C + i : i * C + o;
+      cnt += (bits[(size_t)(cell >> 5) * stride] >> (cell & 31)) & 1;
+    }
+    if (lo < 0 && seen + cnt > lo_rank) lo = o;
+    if (seen + cnt > hi_rank) hi = o;
+    seen += cnt;
+  }
+  return (int)((lo + hi) / 2.0);
+}
+
+__global__ void pcx_crop_update(CropParams p, const int32_t* track, const uint32_t* curtains, const int32_t* frame,
+                                int32_t* corner, uint8_t* has_corner, uint8_t* error) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.batch) return;
+  int top = p.top, left = p.left;
+  if (p.kind == PCX_CROP_SCROLLING) {
+    if (frame[b] == 0) has_corner[b] = 0;  // a new episode is a new Engine (cropping.py:378-391)
+    int crow = 0, ccol = 0;
+    bool have = false;
+    for (int i = 0; i < p.n_track && !have; ++i) {  // :544-549
+      if (p.track_kind[i] == 0) {
+        const int32_t w = track[(size_t)p.track_idx[i] * p.bpad + b];
+        if ((w >> 16) & 1) { crow = w & 0xFF; ccol = (w >> 8) & 0xFF; have = true; }
+      } else {
+        const uint32_t* bits = curtains + (size_t)p.track_idx[i] * p.FW * p.bpad + b;
+        int n = 0;
+        for (int wd = 0; wd < p.FW; ++wd) n += __popc(bits[(size_t)wd * p.bpad]);
+        if (n) {
+          crow = median_axis(bits, p.bpad, p.R, p.C, n, true);
+          ccol = median_axis(bits, p.bpad, p.R, p.C, n, false);
+          have = true;
+        }
+      }
+    }
+    int wrow = corner[2 * b], wcol = corner[2 * b + 1];
+    const int rows = p.rows, cols = p.cols, mrow = p.margin_rows, mcol = p.margin_cols;
+    auto rectify = [&]() {  // :539-542
+      wrow = imax(0, wrow) - imax(0, wrow + rows - p.R);
+      wcol = imax(0, wcol) - imax(0, wcol + cols - p.C);
+    };
+    auto initialise = [&](int off_r, int off_c) {  // :438-458
+      if (!have) { wrow = 0; wcol = 0; return; }
+      wrow = crow - off_r;
+      wcol = ccol - off_c;
+      if (p.pad_char < 0) rectify();
+    };
+    if (!has_corner[b]) {
+      initialise(rows / 2 + p.off_rows, cols / 2 + p.off_cols);
+      has_corner[b] = 1;
+    } else if (have) {
+      bool can_vert = (mrow - 1) <= (crow - wrow) && (crow - wrow) <= (rows - mrow);
+      bool can_horiz = (mcol - 1) <= (ccol - wcol) && (ccol - wcol) <= (cols - mcol);
+      if (p.pad_char < 0) {  // :491-504, including the `elif not can_horiz`
+        if (!can_vert) {
+          if (wrow <= 0) can_vert = crow <= mrow;
+          else if (wrow >= p.R - rows) can_vert = crow >= wrow + rows - mrow;
+        } else if (!can_horiz) {
+          if (wcol <= 0) can_horiz = ccol <= mcol;
+          else if (wcol >= p.C - cols) can_horiz = ccol >= wcol + cols - mcol;
+        }
+      }
+      if (can_vert && can_horiz) {  // _pan_to
+        int drow = imin(0, crow - wrow - mrow), dcol = imin(0, ccol - wcol - mcol);
+        if (drow == 0) drow += imax(0, crow - wrow - rows + mrow + 1);
+        if (dcol == 0) dcol += imax(0, ccol - wcol - cols + mcol + 1);
+        wrow += drow;
+        wcol += dcol;
+        if (p.pad_char < 0) rectify();
+      } else if (p.saccade) {
+        initialise(rows / 2, cols / 2);
+      }
+    }
+    corner[2 * b] = wrow;
+    corner[2 * b + 1] = wcol;
+    top = wrow;
+    left = wcol;
+  } else {
+    corner[2 * b] = top;
+    corner[2 * b + 1] = left;
+  }
+  error[b] = p.pad_char < 0 && (top < 0 || left < 0 || top + p.rows > p.R || left + p.cols > p.C);
+}
+
+__global__ void pcx_crop_copy(CropParams p, const uint8_t* in, const int32_t* corner, const uint8_t* error,
+                              uint8_t* out) {
+  const int planes = 1 + p.L, qw = p.out_pitch / 4;
+  const int64_t total = p.batch * planes * qw;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i % qw);
+  const int pl = (int)((i / qw) % planes);
+  const int64_t b = i / ((int64_t)qw * planes);
+  if (error[b]) return;
+  const int top = corner[2 * b], left = corner[2 * b + 1];
+  const uint8_t* src = in + ((size_t)b * planes + pl) * p.in_pitch;
+  const uint32_t pad = pl == 0 ? (uint32_t)p.pad_char : (uint32_t)((uint32_t)p.pad_char == p.chars[pl - 1]);
+  uint32_t v = 0;
+  for (int j = 0; j < 4; ++j) {
+    const int cell = q * 4 + j;
+    uint32_t byte = 0;
+    if (cell < p.rows * p.cols) {
+      const int r = cell / p.cols + top, c = cell % p.cols + left;
+      byte = ((unsigned)r < (unsigned)p.R && (unsigned)c < (unsigned)p.C) ? src[r * p.C + c] : pad;
+    }
+    v |= (byte & 0xFF) << (8 * j);
+  }
+  reinterpret_cast<uint32_t*>(out + ((size_t)b * planes + pl) * p.out_pitch)[q] = v;
+}
+
+}  // namespace
+
+struct pcx_cropper {
+  pcx_engine* e = nullptr;
+  CropParams p{};
+  pcx::DevArray<uint8_t> planes, has_corner, error, dense;
+  pcx::DevArray<int32_t> corner;
+  bool tracks_drape = false;
+};
 
 extern "C" {
-int pcx_cropper_create(pcx_engine*, const pcx_cropper_desc*, pcx_cropper**) {
-  return set_error(PCX_E_UNSUPPORTED, "pcx_cropper_create: croppers are not built yet");
+
+int pcx_cropper_create(pcx_engine* e, const pcx_cropper_desc* d, pcx_cropper** out) {
+  if (!e || !d || !out || d->rows <= 0 || d->cols <= 0 || (d->kind != PCX_CROP_FIXED && d->kind != PCX_CROP_SCROLLING))
+    return set_error(PCX_E_INVALID, "pcx_cropper_create: bad arguments");
+  const pcx_template& t = e->t;
+  auto known = [&](int ch) { for (int i = 0; i < t.n_chars; ++i) if (t.chars[i] == ch) return true; return false; };
+  if (d->pad_char >= 0 && !known(d->pad_char))
+    return set_error(PCX_E_INVALID, "An `ObservationCropper` tried to fill empty space with a character that isn't "
+                                    "used by the current game engine.");
+  if (d->kind == PCX_CROP_SCROLLING && d->pad_char < 0 && (t.rows < d->rows || t.cols < d->cols))
+    return set_error(PCX_E_INVALID, "A ScrollingCropper with no pad character can't be larger than the board");
+  if (t.rows > 255 || t.cols > 255) return set_error(PCX_E_UNSUPPORTED, "croppers: board larger than 255x255");
+  PCX_HIP(hipSetDevice(e->device));
+  pcx_cropper* c = new pcx_cropper();
+  c->e = e;
+  CropParams& p = c->p;
+  p.kind = d->kind; p.rows = d->rows; p.cols = d->cols; p.top = d->top; p.left = d->left; p.pad_char = d->pad_char;
+  p.margin_rows = d->margin_rows; p.margin_cols = d->margin_cols;
+  p.off_rows = d->initial_offset_rows; p.off_cols = d->initial_offset_cols; p.saccade = d->saccade;
+  p.R = t.rows; p.C = t.cols; p.L = t.n_chars; p.in_pitch = e->backend->plane_pitch();
+  p.out_pitch = (d->rows * d->cols + 3) & ~3;
+  p.FW = e->backend->curtain_words();
+  p.batch = e->batch; p.bpad = e->backend->batch_pad();
+  for (int i = 0; i < t.n_chars; ++i) p.chars[i] = t.chars[i];
+  p.n_track = d->kind == PCX_CROP_SCROLLING ? d->n_track : 0;
+  for (int i = 0; i < p.n_track; ++i) {
+    int kind = -1, idx = -1;
+    for (int s = 0; s < t.n_sprites; ++s) if (t.sprites[s].ch == d->to_track[i]) { kind = 0; idx = s; }
+    for (int dd = 0; dd < t.n_drapes; ++dd) if (t.drapes[dd].ch == d->to_track[i]) { kind = 1; idx = dd; }
+    if (kind < 0) { delete c; return set_error(PCX_E_INVALID, "ScrollingCropper was told to track a nonexistent game entity"); }
+    p.track_kind[i] = kind; p.track_idx[i] = idx;
+    c->tracks_drape |= kind == 1;
+  }
+  if (c->tracks_drape) {
+    if (e->showtime && !e->curtains_fresh) {
+      delete c;
+      return set_error(PCX_E_STATE, "a cropper that tracks a drape must be attached (set_engine) before its_showtime()");
+    }
+    e->want_curtains = true;
+  }
+  int rc;
+  if ((rc = c->planes.alloc((size_t)e->batch * (1 + p.L) * p.out_pitch)) || (rc = c->has_corner.alloc(e->batch)) ||
+      (rc = c->error.alloc(e->batch)) || (rc = c->corner.alloc((size_t)e->batch * 2)) ||
+      (rc = c->dense.alloc((size_t)e->batch * (1 + p.L) * d->rows * d->cols))) { delete c; return rc; }
+  *out = c;
+  return 0;
 }
-void pcx_cropper_destroy(pcx_cropper*) {}
-int pcx_cropper_crop(pcx_cropper*, void*) { return set_error(PCX_E_UNSUPPORTED, "croppers are not built yet"); }
-int pcx_cropper_buffers(pcx_cropper*, uint8_t**, int32_t**) {
-  return set_error(PCX_E_UNSUPPORTED, "croppers are not built yet");
+
+void pcx_cropper_destroy(pcx_cropper* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->e->device);
+  delete c;
 }
+
+int pcx_cropper_crop(pcx_cropper* c, void* stream) {
+  if (!c) return set_error(PCX_E_INVALID, "pcx_cropper_crop: null cropper");
+  pcx_engine* e = c->e;
+  if (!e->showtime) return set_error(PCX_E_STATE, "pcx_cropper_crop: the engine is not in play");
+  if (c->tracks_drape && !e->curtains_fresh)
+    return set_error(PCX_E_STATE, "pcx_cropper_crop: curtains were not exported by the last step");
+  PCX_HIP(hipSetDevice(e->device));
+  hipStream_t s = (hipStream_t)stream;
+  const CropParams& p = c->p;
+  hipLaunchKernelGGL(pcx_crop_update, dim3((unsigned)((p.batch + 255) / 256)), dim3(256), 0, s, p,
+                     e->backend->sprite_track(), e->backend->curtain_bits(), e->out.frame, c->corner.ptr,
+                     c->has_corner.ptr, c->error.ptr);
+  const int64_t total = p.batch * (1 + p.L) * (p.out_pitch / 4);
+  hipLaunchKernelGGL(pcx_crop_copy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, e->out.planes,
+                     c->corner.ptr, c->error.ptr, c->planes.ptr);
+  // dense [batch][1+L][rows*cols] copy for hosts (2-D strided copy on the same stream)
+  PCX_HIP(hipMemcpy2DAsync(c->dense.ptr, (size_t)p.rows * p.cols, c->planes.ptr, p.out_pitch, (size_t)p.rows * p.cols,
+                           (size_t)p.batch * (1 + p.L), hipMemcpyDeviceToDevice, s));
+  PCX_HIP(hipGetLastError());
+  return 0;
 }
+
+int pcx_cropper_buffers(pcx_cropper* c, uint8_t** planes_dev, int32_t** corner_dev) {
+  if (!c) return set_error(PCX_E_INVALID, "pcx_cropper_buffers: null cropper");
+  if (planes_dev) *planes_dev = c->dense.ptr;  // dense [batch][1+n_chars][rows][cols]
+  if (corner_dev) *corner_dev = c->corner.ptr;
+  return 0;
+}
+
+int pcx_cropper_errors(pcx_cropper* c, uint8_t* errors_host) {
+  if (!c || !errors_host) return set_error(PCX_E_INVALID, "pcx_cropper_errors: bad arguments");
+  PCX_HIP(hipSetDevice(c->e->device));
+  PCX_HIP(hipDeviceSynchronize());
+  PCX_HIP(hipMemcpy(errors_host, c->error.ptr, (size_t)c->e->batch, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

@@ -143,10 +143,12 @@ int pcx_engine_reset(pcx_engine* e, const uint8_t* env_mask_dev, void* stream) {
   pcx::StepArgs a;
   a.mode = 1;
   a.reset_mask = env_mask_dev;
+  a.export_curtains = e->want_curtains;
   rc = e->backend->launch(a, e->out, (hipStream_t)stream);
   if (rc) return rc;
   e->showtime = true;
   e->epoch++;
+  e->curtains_fresh = e->want_curtains && !env_mask_dev;
   return 0;
 }
 
@@ -157,10 +159,12 @@ int pcx_engine_step(pcx_engine* e, const int32_t* actions_dev, int auto_reset, v
   pcx::StepArgs a;
   a.actions = actions_dev;
   a.auto_reset = auto_reset;
+  a.export_curtains = e->want_curtains;
   a.debug = pcx::debug_flags();
   int rc = e->backend->launch(a, e->out, (hipStream_t)stream);
   if (rc) return rc;
   e->epoch++;
+  e->curtains_fresh = e->want_curtains;
   return 0;
 }
 
@@ -181,9 +185,11 @@ int pcx_engine_step_hashed(pcx_engine* e, uint64_t seed, int64_t env_offset, int
   for (int t = 0; t < T; ++t) {
     pcx::StepArgs a;
     a.hashed = 1; a.seed = seed; a.env_offset = env_offset; a.t = t0 + t; a.auto_reset = auto_reset;
+    a.export_curtains = e->want_curtains;
     int rc = e->backend->launch(a, e->out, (hipStream_t)stream);
     if (rc) return rc;
     e->epoch++;
+    e->curtains_fresh = e->want_curtains;
   }
   return 0;
 }

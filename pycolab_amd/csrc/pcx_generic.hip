@@ -56,6 +56,7 @@ struct Ptrs {
   int32_t n_table_words;
   uint32_t* state;         // [NW][bpad]
   int32_t* track;          // [NS][bpad]
+  uint32_t* curtains;      // [ND][FW][bpad] raw curtain bits (export_curtains)
   int64_t batch, bpad;
 };
 
@@ -497,6 +498,8 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
         if (w2) l.flat[(d * FW + wi + 2) * WAVE + lane] |= w2;
       }
     }
+    if (a.export_curtains)
+      for (int i2 = 0; i2 < k.ND * FW; ++i2) P.curtains[(size_t)i2 * bp + env] = l.flat[i2 * WAVE + lane];
     for (int t = 0; t < k.NT; ++t) {
       if (tfield(x, t, T_KIND) != 1) continue;
       const uint32_t d = tfield(x, t, T_IDX), above = tfield(x, t, T_ABOVE);
@@ -581,12 +584,15 @@ class GenericBackend : public Backend {
   }
   const char* kernel_name() const override { return "pcx_generic_step"; }
   const int32_t* sprite_track() const override { return track_.ptr; }
+  const uint32_t* curtain_bits() const override { return curtains_.ptr; }
+  int curtain_words() const override { return k_.FW; }
+  int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return k_.pitch; }
 
  private:
   Consts k_{};
   int64_t batch_ = 0, bpad_ = 0;
-  DevArray<uint32_t> tables_, state_;
+  DevArray<uint32_t> tables_, state_, curtains_;
   DevArray<int32_t> track_;
   int n_table_words_ = 0;
   std::vector<int> walker_;
@@ -749,7 +755,11 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
 }
 
 int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) {
-  Ptrs P{tables_.ptr, n_table_words_, state_.ptr, track_.ptr, batch_, bpad_};
+  if (a.export_curtains && !curtains_.ptr) {
+    int rc = curtains_.alloc((size_t)(k_.ND ? k_.ND : 1) * k_.FW * bpad_);
+    if (rc) return rc;
+  }
+  Ptrs P{tables_.ptr, n_table_words_, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
   size_t lds = (size_t)k_.l_words * 4;
   if (lds > 64 * 1024)
     PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pcx_generic_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

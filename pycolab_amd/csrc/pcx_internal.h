@@ -35,6 +35,7 @@ struct StepArgs {
   uint64_t seed = 0;
   int64_t env_offset = 0;
   int64_t t = 0;
+  int export_curtains = 0;  // write every drape's raw curtain bits to curtain_bits() (drape-tracking croppers)
   int debug = 0;  // ablation bits for profiling (PCX_DEBUG env): 1 skip entity updates, 2 skip phase B, 4 skip render descriptors
 };
 
@@ -72,6 +73,11 @@ class Backend {
   // Sprite state for croppers: device int32 [n_sprites][batch] packed
   // (row | col << 8 | visible << 16), refreshed by every launch.
   virtual const int32_t* sprite_track() const { return nullptr; }
+  // Raw (pre-occlusion) curtains as flat cell-bit vectors, uint32 [n_drapes][curtain_words()][bpad],
+  // template drape order; refreshed by launches with StepArgs::export_curtains.
+  virtual const uint32_t* curtain_bits() const { return nullptr; }
+  virtual int curtain_words() const { return 0; }
+  virtual int64_t batch_pad() const = 0;
   // bytes between consecutive planes of one environment (>= rows*cols, multiple of 4)
   virtual int plane_pitch() const = 0;
 };
@@ -90,4 +96,6 @@ struct pcx_engine {
   pcx_buffers out{};       // where the kernels write (own or bound)
   bool own_out = false;
   uint64_t epoch = 0;      // bumped by every reset/step (croppers)
+  bool want_curtains = false;   // a drape-tracking cropper exists
+  bool curtains_fresh = false;  // the last launch exported curtains
 };

@@ -89,6 +89,8 @@ struct Ptrs {
   const uint8_t* coin_col;        // [n_coins]
   uint32_t* state;                // [NW][bpad]
   int32_t* track;                 // [NS][bpad] packed true row | col<<8 | visible<<16
+  uint32_t* curtains;             // [2][FW][bpad] raw curtain bits, template drape order (export_curtains)
+  int32_t maze_slot;              // template drape index of the maze drape (0 or 1)
   int64_t batch, bpad;
 };
 
@@ -601,6 +603,21 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
       // Resolve occlusion between the two curtains now (engine.py:751-757
       // paints back to front, so the one in front wins where both are set).
       const bool cash_in_front = (k.above[NS] >> (NS + 1)) & 1;
+      if (a.export_curtains) {  // raw curtains for drape-tracking croppers
+        const int ms = P.maze_slot, cs2 = 1 - P.maze_slot;
+        if constexpr (SR != 0) {
+#pragma unroll
+          for (int i = 0; i < ACC; ++i) {
+            P.curtains[((size_t)ms * ACC + i) * bp + env] = accw[i];
+            P.curtains[((size_t)cs2 * ACC + i) * bp + env] = accc[i];
+          }
+        } else {
+          for (int i = 0; i < FW; ++i) {
+            P.curtains[((size_t)ms * FW + i) * bp + env] = l.flat[(0 * FW + i) * WAVE + lane];
+            P.curtains[((size_t)cs2 * FW + i) * bp + env] = l.flat[(1 * FW + i) * WAVE + lane];
+          }
+        }
+      }
       if constexpr (SR != 0) {
 #pragma unroll
         for (int i = 0; i < ACC; ++i) {
@@ -790,12 +807,15 @@ class ScrollyMazeBackend : public Backend {
   }
   const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
   const int32_t* sprite_track() const override { return track_.ptr; }
+  const uint32_t* curtain_bits() const override { return curtains_.ptr; }
+  int curtain_words() const override { return k_.FW; }
+  int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return k_.cells; }
 
  private:
   Consts k_{};
   int64_t batch_ = 0, bpad_ = 0;
-  DevArray<uint32_t> walls_, backdrop4_, state_;
+  DevArray<uint32_t> walls_, backdrop4_, state_, curtains_;
   DevArray<uint16_t> rowstart_;
   DevArray<uint8_t> coincol_;
   DevArray<int32_t> track_;
@@ -1013,7 +1033,11 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
 }
 
 int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) {
-  Ptrs P{walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, batch_, bpad_};
+  if (a.export_curtains && !curtains_.ptr) {
+    int rc = curtains_.alloc((size_t)2 * k_.FW * bpad_);
+    if (rc) return rc;
+  }
+  Ptrs P{walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_};
   // Launch shape.  Default: one single-wave workgroup per group of 64
   // environments (logic, then render), with the LDS footprint padded so that
   // about 8 waves share a CU -- on MI355X the nine interleaved write streams

@@ -54,6 +54,13 @@ class Engine(object):
     self._keepalive = None
     self._bufs = None
     self._actions = None
+    self._croppers = []
+
+  def _register_cropper(self, cropper):
+    if cropper not in self._croppers:
+      self._croppers.append(cropper)
+    if self._native is not None:
+      cropper._create_native()
 
   # ---------------------------------------------------------------- builder API
   def set_backdrop(self, characters, backdrop_class, *args, **kwargs):
@@ -207,6 +214,8 @@ class Engine(object):
     N.check(lib.pcx_engine_bind_buffers(self._native, ctypes.byref(ext)))
     self._showtime = True
     self._current_update_group = None
+    for cropper in self._croppers:  # croppers attached with set_engine() before showtime
+      cropper._create_native()
     N.check(lib.pcx_engine_reset(self._native, None, dev.current_stream(self._device_id)))
     return self._result()
 

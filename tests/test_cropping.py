@@ -1,0 +1,94 @@
+"""Croppers: the oracle (CPU) and the device kernels (GPU) against cropped
+observations recorded from the reference's own croppers (oracle/gen_golden.py),
+plus the constructor guards of cropping.py."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import binding
+from pycolab_amd import cropping
+from tests import helpers
+
+CROPPED = ['scrolly_maze_L0', 'warehouse_L1', 'marauders']
+
+
+def specs_of(trace):
+  return json.loads(bytes(trace['crop_specs']).decode())
+
+
+@pytest.mark.parametrize('name', CROPPED)
+def test_oracle_croppers_match_reference(name):
+  tr = helpers.load_trace(name)
+  t = helpers.load_template(tr['template'])
+  t.param[0] = helpers.GOLDEN_RNG_SEED
+  T, E = tr['actions'].shape
+  eng = binding.OracleEngine(t, E)
+  crops = [binding.OracleCropper(eng, cropping.cropper_from_spec(sp)) for sp in specs_of(tr)]
+  chars = list(tr['chars'])
+  eng.reset()
+  for step in range(T + 1):
+    if step:
+      eng.step(tr['actions'][step - 1], auto_reset=True)
+    for i, cr in enumerate(crops):
+      planes, err = cr.crop()
+      assert not err.any()
+      want = tr['crop_%d' % i][step]
+      np.testing.assert_array_equal(planes, helpers.expected_planes(want, chars), err_msg='cropper %d frame %d' % (i, step))
+
+
+def test_constructor_guards():
+  """cropping.py:343-358, 381-390."""
+  with pytest.raises(ValueError):
+    cropping.ScrollingCropper(4, 5, ['P'], scroll_margins=(None, 1))    # even rows, egocentric
+  with pytest.raises(ValueError):
+    cropping.ScrollingCropper(5, 5, ['P'], scroll_margins=(3, 1))       # margins reach the centre
+  c = cropping.ScrollingCropper(5, 7, ['P'], scroll_margins=(None, None))
+  assert c._scroll_margins == (2, 3) and c.rows == 5 and c.cols == 7
+
+  class Small(object):
+    rows, cols = 4, 4
+  with pytest.raises(ValueError):
+    cropping.ScrollingCropper(5, 5, ['P']).set_engine(Small())          # bigger than the board, no pad
+  ident = cropping.ObservationCropper()
+  assert ident.crop('anything') == 'anything'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CROPPED)
+def test_device_croppers_match_reference(name):
+  from pycolab_amd.engine import Engine
+  tr = helpers.load_trace(name)
+  t = helpers.load_template(tr['template'])
+  T, E = tr['actions'].shape
+  eng = Engine.from_template(t, batch=E, auto_reset=True, seed=helpers.GOLDEN_RNG_SEED)
+  crops = [cropping.cropper_from_spec(sp) for sp in specs_of(tr)]
+  for cr in crops:
+    cr.set_engine(eng)
+  chars = list(tr['chars'])
+  obs = eng.its_showtime()[0]
+  for step in range(T + 1):
+    if step:
+      obs = eng.play(tr['actions'][step - 1])[0]
+    for i, cr in enumerate(crops):
+      out = cr.crop(obs)
+      want = tr['crop_%d' % i][step]
+      np.testing.assert_array_equal(np.asarray(out.board), want, err_msg='cropper %d frame %d board' % (i, step))
+      for k, ch in enumerate(chars):
+        np.testing.assert_array_equal(np.asarray(out.layers[chr(ch)]).astype(np.uint8), (want == ch).astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_device_cropper_without_pad_raises_outside():
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('warehouse_L0')
+  eng = Engine.from_template(t, batch=4)
+  cr = cropping.FixedCropper((8, 8), 5, 5)  # leaves the 11x10 board, no pad character
+  cr.set_engine(eng)
+  obs = eng.its_showtime()[0]
+  with pytest.raises(RuntimeError):
+    cr.crop(obs)
+  with pytest.raises(ValueError):
+    bad = cropping.FixedCropper((0, 0), 3, 3, pad_char='?')
+    bad.set_engine(eng)
+    bad.crop(obs)
