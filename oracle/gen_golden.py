@@ -96,13 +96,18 @@ def sprite_states(game, sprite_chars):
   return out
 
 
+UNOCCLUDED = False  # set by run(..., unoccluded=True)
+
+
 def record(obs, reward, discount, game, chars, sprite_chars):
-  for c in chars:  # occluded layers are board == c
-    assert np.array_equal(obs.layers[c], obs.board == ord(c)), c
+  if not UNOCCLUDED:
+    for c in chars:  # occluded layers are board == c
+      assert np.array_equal(obs.layers[c], obs.board == ord(c)), c
   assert set(obs.layers.keys()) == set(chars)
   return (obs.board.copy(), 0 if reward is None else int(reward),
           0 if reward is None else 1, float(discount), int(game.game_over),
-          sprite_states(game, sprite_chars))
+          sprite_states(game, sprite_chars),
+          np.stack([obs.layers[c] for c in chars]).astype(np.uint8) if UNOCCLUDED else None)
 
 
 def template_sprite_chars(template_name):
@@ -153,7 +158,8 @@ def F(top_left, rows, cols, pad_char=None):
   return dict(kind='fixed', top_left=list(top_left), rows=rows, cols=cols, pad_char=pad_char)
 
 
-CROPPERS = {
+CROPPERS = {  # keyed by trace name
+
     'scrolly_maze_L0': [S(5, 11, 'P', ' ', (1, 2)), S(7, 9, 'aP', None, (2, 3)), F((-2, -3), 8, 20, '#'),
                         S(5, 5, 'cb', '.', (None, None), (1, -1), False), S(3, 9, '@P', ' ', (1, 3))],
     'warehouse_L1': [S(5, 5, 'P', None, (1, 1)), S(7, 7, '3P', '.', (2, 2), (0, 1)), F((2, 3), 5, 6),
@@ -163,8 +169,11 @@ CROPPERS = {
 }
 
 
-def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, seeker=False, choice=None):
-  boards, rewards, rsets, discounts, dones, sprites = [], [], [], [], [], []
+def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, seeker=False, choice=None,
+        unoccluded=False):
+  global UNOCCLUDED
+  UNOCCLUDED = unoccluded
+  boards, rewards, rsets, discounts, dones, sprites, layers = [], [], [], [], [], [], []
   specs = CROPPERS.get(name, [])
   crops = [[] for _ in specs]
   actions = np.zeros((T, E), np.int32)
@@ -213,11 +222,15 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
     boards.append([x[0] for x in rec]); rewards.append([x[1] for x in rec])
     rsets.append([x[2] for x in rec]); discounts.append([x[3] for x in rec])
     dones.append([x[4] for x in rec]); sprites.append([x[5] for x in rec])
+    if unoccluded:
+      layers.append([x[6] for x in rec])
   sw = lambda x, dt: np.ascontiguousarray(np.swapaxes(np.array(x, dtype=dt), 0, 1))
   path = os.path.join(ROOT, 'tests', 'golden', 'traces', name + '.npz')
   import json
   extra = {'crop_%d' % i: sw(crops[i], np.uint8) for i in range(len(specs))}
   extra['crop_specs'] = np.frombuffer(json.dumps(specs).encode(), np.uint8)
+  if unoccluded:
+    extra['layers'] = sw(layers, np.uint8)  # [T+1, E, L, R, C]
   np.savez_compressed(
       path, template=np.frombuffer(template_name.encode(), np.uint8),
       chars=np.array([ord(c) for c in chars], np.uint8),
@@ -244,6 +257,23 @@ def main():
         template_name='warehouse_L%d' % level)
   run('hello_world', hello_world.make_game, E=16, T=96, n_ordinary=4, quit_action=4, seed=27,
       template_name='hello_world')
+  # occlusion_in_layers=False variants: the example files do not expose the
+  # flag, so the call they make into ascii_art is wrapped (files unchanged).
+  import functools
+  from pycolab import ascii_art as ref_ascii_art
+  real = ref_ascii_art.ascii_art_to_game
+  ref_ascii_art.ascii_art_to_game = functools.partial(real, occlusion_in_layers=False)
+  try:
+    run('scrolly_maze_L1_unoccluded', lambda: scrolly_maze.make_game(1), E=16, T=128, n_ordinary=5,
+        quit_action=5, seed=41, template_name='scrolly_maze_L1_unoccluded', seeker=True, unoccluded=True)
+    run('warehouse_L0_unoccluded', lambda: warehouse_manager.make_game(0), E=16, T=128, n_ordinary=5,
+        quit_action=5, seed=42, template_name='warehouse_L0_unoccluded', unoccluded=True)
+    patch_u = ChoicePatch(seed=0x5EED)
+    numpy.random.choice = patch_u
+    run('marauders_unoccluded', extraterrestrial_marauders.make_game, E=16, T=192, n_ordinary=4,
+        quit_action=4, seed=43, template_name='marauders_unoccluded', choice=patch_u, unoccluded=True)
+  finally:
+    ref_ascii_art.ascii_art_to_game = real
   patch = ChoicePatch(seed=0x5EED)   # the engines under test get the same seed (template param)
   numpy.random.choice = patch
   run('marauders', extraterrestrial_marauders.make_game, E=32, T=256, n_ordinary=4, quit_action=4,

@@ -39,16 +39,17 @@ constexpr int64_t NEVER = INT32_MIN;
 
 struct Consts {
   int32_t game, R, C, cells, pitch, QW, L, NS, ND, NT, n_groups, RW, FW, NW, n_actions, n_bchars;
+  int32_t occl;  // Engine(..., occlusion_in_layers)
   uint32_t magic_q;
   uint32_t seed_lo, seed_hi, envoff_lo, envoff_hi;
   int32_t w_sflags, w_drapes;           // state word offsets
   int32_t ip;                           // thing index of 'P' (-1 if none)
-  int32_t ix, ib;                       // drape index of 'X' / 'B' (-1 if none)
+  int32_t ix, ib, tx;                   // drape index of 'X' / 'B', thing index of 'X' (-1 if none)
   int32_t bolt_mask_all, bolt_mask_up;  // marauders: sprite-index masks of 'abcdyz' / 'abcd'
   int32_t box_mask;                     // warehouse: sprite-index mask of the box sprites
   // LDS layout (word offsets); per-lane arrays are [i][lane]
   int32_t l_things, l_z, l_sched, l_backdrop, l_bdmask, l_aux, l_init, l_initd, l_laybc, l_s2t;
-  int32_t l_pos, l_flg, l_snap, l_cur, l_snapd, l_flat, l_sdesc, l_skip, l_words;
+  int32_t l_pos, l_flg, l_snap, l_cur, l_snapd, l_flat, l_sdesc, l_skip, l_flatraw, l_sdescraw, l_words;
 };
 
 struct Ptrs {
@@ -62,9 +63,9 @@ struct Ptrs {
 
 struct L {
   const uint32_t *things, *z, *sched, *backdrop4, *bdmask, *aux, *init, *initd, *laybc, *s2t;
-  uint32_t *pos, *flg, *cur, *snapd, *flat, *skip;
+  uint32_t *pos, *flg, *cur, *snapd, *flat, *skip, *flatraw;
   int32_t* snap;
-  uint2* sdesc;
+  uint2 *sdesc, *sdescraw;
 };
 
 __device__ __forceinline__ uint32_t action_hash(uint64_t seed, uint64_t env, uint64_t t) {
@@ -162,12 +163,21 @@ __device__ __forceinline__ int top_char(const Ctx& x, int r, int c) {
   }
   return ch;
 }
-// numpy `layers[ch][r, c]` with Python index rules (negative wraps once)
-__device__ __forceinline__ bool layer_at(Ctx& x, int ch, int r, int c) {
+// layers[thing's char][r, c] in the last repaint: with occlusion the thing must
+// be the one on top (rendering.py:177-179); without, its own mask counts
+// (rendering.py:236-278).
+__device__ __forceinline__ bool thing_layer(const Ctx& x, int thing, int r, int c) {
+  const uint32_t kind = tfield(x, thing, T_KIND), idx = tfield(x, thing, T_IDX);
+  const bool raw = kind == 0 ? x.l.snap[idx * WAVE + x.lane] == r * x.k.C + c : bit_at(x, x.l.snapd, idx, r, c);
+  if (!x.k.occl || !raw) return raw;
+  return top_char(x, r, c) == (int)tfield(x, thing, T_CH);
+}
+// numpy `layers[c][r, col]` with Python index rules (negative wraps once)
+__device__ __forceinline__ bool layer_at(Ctx& x, int thing, int r, int c) {
   if (r < 0) r += x.k.R;
   if (c < 0) c += x.k.C;
   if (!on_board(x.k, r, c)) { x.err |= ERR_INDEX; return false; }
-  return top_char(x, r, c) == ch;
+  return thing_layer(x, thing, r, c);
 }
 
 // sprites.py:496-511 at()/is_impassable(), :479-546 _check_motion, :356-389 _move
@@ -201,10 +211,10 @@ __device__ __forceinline__ void prog_wm_box(Ctx& x, int thing) {  // :214-226
   int r, c;
   sprite_true(x, s, r, c);
   switch (x.action) {
-    case 0: if (layer_at(x, 'P', r + 1, c)) mw_move(x, thing, -1, 0); break;
-    case 1: if (layer_at(x, 'P', r - 1, c)) mw_move(x, thing, 1, 0); break;
-    case 2: if (layer_at(x, 'P', r, c + 1)) mw_move(x, thing, 0, -1); break;
-    case 3: if (layer_at(x, 'P', r, c - 1)) mw_move(x, thing, 0, 1); break;
+    case 0: if (layer_at(x, x.k.ip, r + 1, c)) mw_move(x, thing, -1, 0); break;
+    case 1: if (layer_at(x, x.k.ip, r - 1, c)) mw_move(x, thing, 1, 0); break;
+    case 2: if (layer_at(x, x.k.ip, r, c + 1)) mw_move(x, thing, 0, -1); break;
+    case 3: if (layer_at(x, x.k.ip, r, c - 1)) mw_move(x, thing, 0, 1); break;
     default: break;
   }
 }
@@ -285,12 +295,14 @@ __device__ __forceinline__ int em_erode(Ctx& x, int d, int bolt_mask, int& hitte
     if (cell < 0) continue;
     const int r = cell / x.k.C, c = cell - r * x.k.C;
     if (!bit_at(x, x.l.cur, d, r, c)) continue;
-    // layers[ch] is set only where ch is the character on top (rendering.py:177-179)
-    const int thing = x.l.s2t[s];
-    if (top_char(x, r, c) != (int)tfield(x, thing, T_CH)) continue;
+    if (!thing_layer(x, x.l.s2t[s], r, c)) continue;
     row_put(x, x.l.cur, d, r, row_get(x, x.l.cur, d, r) & ~(1ull << c));
     ++hits;
-    hitters |= 1 << s;  // board[hits]
+    // board[hits]: the character drawn on top of the hit cell (with occlusion
+    // that is this bolt; without, a bolt in front of it may be the one named)
+    const int top = top_char(x, r, c);
+    for (int j = 0; j < x.k.NS; ++j)
+      if ((int)tfield(x, x.l.s2t[j], T_CH) == top) hitters |= 1 << j;
   }
   return hits;
 }
@@ -361,7 +373,7 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
     for (int c = 0; c < C; ++c) {
       bool any = false;
       for (int r = 0; r < R && !any; ++r)
-        if (bit_at(x, x.l.snapd, x.k.ix, r, c) && top_char(x, r, c) == 'X') any = true;
+        if (thing_layer(x, x.k.tx, r, c)) any = true;
       if (any) cols |= 1ull << c;
     }
     const int n = __popcll(cols);
@@ -374,7 +386,7 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
       if ((cols >> c) & 1) { if (pick == 0) { col = c; break; } --pick; }
     int row = 0;
     for (int r = 0; r < R; ++r)
-      if (bit_at(x, x.l.snapd, x.k.ix, r, col) && top_char(x, r, col) == 'X') row = r;
+      if (thing_layer(x, x.k.tx, r, col)) row = r;
     teleport(x, s, row + 1, col);
   }
 }
@@ -392,6 +404,7 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
   l.pos = lds + k.l_pos; l.flg = lds + k.l_flg; l.snap = reinterpret_cast<int32_t*>(lds + k.l_snap);
   l.cur = lds + k.l_cur; l.snapd = lds + k.l_snapd; l.flat = lds + k.l_flat;
   l.sdesc = reinterpret_cast<uint2*>(lds + k.l_sdesc); l.skip = lds + k.l_skip;
+  l.flatraw = lds + k.l_flatraw; l.sdescraw = reinterpret_cast<uint2*>(lds + k.l_sdescraw);
   __syncthreads();
 
   const bool live = env < P.batch;
@@ -500,6 +513,8 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
     }
     if (a.export_curtains)
       for (int i2 = 0; i2 < k.ND * FW; ++i2) P.curtains[(size_t)i2 * bp + env] = l.flat[i2 * WAVE + lane];
+    if (!k.occl)  // unoccluded layers are the raw masks (rendering.py:236-278)
+      for (int i2 = 0; i2 < k.ND * FW; ++i2) l.flatraw[i2 * WAVE + lane] = l.flat[i2 * WAVE + lane];
     for (int t = 0; t < k.NT; ++t) {
       if (tfield(x, t, T_KIND) != 1) continue;
       const uint32_t d = tfield(x, t, T_IDX), above = tfield(x, t, T_ABOVE);
@@ -527,6 +542,7 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
           for (int d = 0; d < k.ND; ++d) l.flat[(d * FW + wi) * WAVE + lane] &= ~(1u << sh);
       }
       l.sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
+      if (!k.occl) l.sdescraw[s * WAVE + lane] = make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
       int tr, tc;
       sprite_true(x, s, tr, tc);
       P.track[s * bp + env] = tr | (tc << 8) | ((int)(l.flg[s * WAVE + lane] & 1) << 16) | ((int)do_reset << 24);
@@ -561,12 +577,22 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
       uni |= m;
       const uint32_t ch4 = l.things[t * T_WORDS + T_CH] * 0x01010101u;
       d = (d & ~m) | (ch4 & m);
-      // rendering.py:177-179: after occlusion a thing's layer is its own mask
-      *reinterpret_cast<uint32_t*>(dst + (1 + l.things[t * T_WORDS + T_LAYER]) * pitch) = m & 0x01010101u;
+      uint32_t lay = m;  // rendering.py:177-179: after occlusion a thing's layer is its own mask
+      if (!k.occl) {     // rendering.py:236-278: the raw mask
+        if (kind == 0) {
+          const uint2 sd = l.sdescraw[idx * WAVE + e];
+          lay = sd.x == q ? sd.y : 0u;
+        } else {
+          const uint32_t bits = (l.flatraw[(idx * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
+          const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+          lay = (m01 << 8) - m01;
+        }
+      }
+      *reinterpret_cast<uint32_t*>(dst + (1 + l.things[t * T_WORDS + T_LAYER]) * pitch) = lay & 0x01010101u;
     }
     *reinterpret_cast<uint32_t*>(dst) = d;
     for (int b = 0; b < k.n_bchars; ++b)
-      *reinterpret_cast<uint32_t*>(dst + (1 + l.laybc[b]) * pitch) = l.bdmask[b * QW + q] & ~uni;
+      *reinterpret_cast<uint32_t*>(dst + (1 + l.laybc[b]) * pitch) = k.occl ? l.bdmask[b * QW + q] & ~uni : l.bdmask[b * QW + q];
   }
 }
 
@@ -602,8 +628,7 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   Consts& k = k_;
   batch_ = batch;
   bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
-  if (!t.occlusion_in_layers)
-    return set_error(PCX_E_UNSUPPORTED, "generic backend: occlusion_in_layers=False is not supported yet");
+  k.occl = t.occlusion_in_layers != 0;
   k.game = t.game; k.R = t.rows; k.C = t.cols; k.cells = t.rows * t.cols; k.L = t.n_chars;
   k.NS = t.n_sprites; k.ND = t.n_drapes; k.NT = t.n_things; k.n_groups = t.n_groups; k.n_actions = t.n_actions;
   if (k.C > 64 || k.L > MAX_L || k.NT > 24 || k.cells > 4096)
@@ -629,7 +654,7 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   auto find_drape = [&](int ch) { for (int d = 0; d < t.n_drapes; ++d) if (t.drapes[d].ch == ch) return d; return -1; };
   auto layer_of = [&](int ch) { for (int i = 0; i < k.L; ++i) if (t.chars[i] == ch) return i; return -1; };
   std::vector<uint32_t> things((size_t)k.NT * T_WORDS, 0), zt(k.NT), sched(k.NT);
-  k.ip = k.ix = k.ib = -1;
+  k.ip = k.ix = k.ib = k.tx = -1;
   k.bolt_mask_all = k.bolt_mask_up = k.box_mask = 0;
   for (int z = 0; z < k.NT; ++z) {
     const int ch = t.z_order[z];
@@ -655,7 +680,7 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
       const pcx_drape_desc& dd = t.drapes[d];
       if (dd.is_scrolly) return set_error(PCX_E_UNSUPPORTED, "generic backend: Scrolly drapes need the scrolly backend");
       e[T_KIND] = 1; e[T_IDX] = d; e[T_PROG] = dd.program; e[T_P0] = dd.param[0]; e[T_P1] = dd.param[1];
-      if (ch == 'X') k.ix = d;
+      if (ch == 'X') { k.ix = d; k.tx = z; }
       if (ch == 'B') k.ib = d;
     } else {
       return set_error(PCX_E_INVALID, "generic backend: z_order names an unknown character");
@@ -744,6 +769,9 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   off = (off + 1) & ~1;
   k.l_sdesc = off; off += 2 * k.NS * WAVE;
   k.l_skip = off; off += WAVE;
+  k.l_flatraw = off; if (!k.occl) off += k.ND * k.FW * WAVE;
+  off = (off + 1) & ~1;
+  k.l_sdescraw = off; if (!k.occl) off += 2 * k.NS * WAVE;
   k.l_words = off;
   if ((size_t)off * 4 > 160 * 1024)
     return set_error(PCX_E_UNSUPPORTED, "generic backend: template needs %d bytes of LDS per wave", off * 4);

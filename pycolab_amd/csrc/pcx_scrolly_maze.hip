@@ -79,7 +79,7 @@ struct Consts {
   int32_t n_bchars, bchar[MAX_L], lay_bchar[MAX_L];  // characters only the backdrop paints
   int32_t FW;  // words of one flat curtain bit-vector (cells bits + 1 spill word)
   int32_t lds_walls, lds_backdrop, lds_rowstart, lds_coincol, lds_flat, lds_sdesc, lds_cmask,
-      lds_skip, lds_bdmask, lds_buf_words, lds_words;
+      lds_skip, lds_bdmask, lds_buf_words, lds_flatraw, lds_sdescraw, lds_words;
 };
 
 struct Ptrs {
@@ -342,7 +342,7 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 // NS sprites.  SR/SC/SL: board rows, cols and layer count when known at
 // compile time (0 = take them from Consts); IP/IE: index of the player and of
 // the egocentric sprite when known at compile time (-1 = from Consts).
-template <int NS, int SR, int SC, int SL, int IP, int IE>
+template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC>
 __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out) {
   // A workgroup is two wavefronts with different jobs, looping over groups of
@@ -629,6 +629,10 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
       } else {
         for (int i = 0; i < FW; ++i) {
           const uint32_t ww = l.flat[(0 * FW + i) * WAVE + lane], cc = l.flat[(1 * FW + i) * WAVE + lane];
+          if constexpr (UNOCC) {  // unoccluded layers are the raw curtains (rendering.py:236-278)
+            (lds_raw + k.lds_flatraw)[(0 * FW + i) * WAVE + lane] = ww;
+            (lds_raw + k.lds_flatraw)[(1 * FW + i) * WAVE + lane] = cc;
+          }
           l.flat[(0 * FW + i) * WAVE + lane] = cash_in_front ? ww & ~cc : ww;
           l.flat[(1 * FW + i) * WAVE + lane] = cash_in_front ? cc : cc & ~ww;
         }
@@ -661,6 +665,9 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
           }
         }
         l.sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
+        if constexpr (UNOCC)
+          reinterpret_cast<uint2*>(lds_raw + k.lds_sdescraw)[s * WAVE + lane] =
+              make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
       }
     }
 
@@ -750,6 +757,20 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
     }
     const uint32_t o = q * 4;
     put(o, d);
+    if constexpr (UNOCC) {  // layers are the raw masks, the backdrop's included
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) {
+        const uint32_t bits = ((lds_raw + k.lds_flatraw)[(dd * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
+        const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+        md[dd] = (m01 << 8) - m01;
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const uint2 sd = reinterpret_cast<const uint2*>(lds_raw + k.lds_sdescraw)[s * WAVE + e];
+        ms[s] = sd.x == q ? sd.y : 0u;
+      }
+      uni = 0;
+    }
     // rendering.py:177-179 layer[c] = (board == c): by construction that is
     // the thing's own mask, or the backdrop's where no thing paints.
     put(o + doff[0], md[0] & 0x01010101u);
@@ -824,14 +845,14 @@ class ScrollyMazeBackend : public Backend {
   std::vector<uint8_t> h_coincol_;
   int maze_di_ = 0, cash_di_ = 0;
   int num_cus_ = 256;
+  bool unoccluded_ = false;
 };
 
 int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   Consts& k = k_;
   batch_ = batch;
   bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
-  if (!t.occlusion_in_layers)
-    return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: occlusion_in_layers=False is not supported yet");
+  unoccluded_ = !t.occlusion_in_layers;
   if (t.n_drapes != 2 || t.n_sprites < 1 || t.n_sprites > MAX_NS)
     return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: expects 2 Scrolly drapes and 1..%d sprites", MAX_NS);
   k.R = t.rows; k.C = t.cols; k.cells = t.rows * t.cols; k.L = t.n_chars; k.NS = t.n_sprites;
@@ -1013,6 +1034,9 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   off += k.lds_buf_words;  // second buffer
   k.lds_cmask = off; off += (k.CW ? k.CW : 1) * WAVE;
   k.lds_bdmask = off; off += k.n_bchars * k.QW;
+  k.lds_flatraw = off; if (unoccluded_) off += 2 * k.FW * WAVE;
+  off = (off + 1) & ~1;
+  k.lds_sdescraw = off; if (unoccluded_) off += 2 * k.NS * WAVE;
   k.lds_words = off;
   if (off * 4 > 160 * 1024) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: template needs %d bytes of LDS", off * 4);
 
@@ -1061,12 +1085,15 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   if (const char* pad = getenv("PCX_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   // Specialised instance for the shipped scrolly_maze shape (10x30 board,
   // 8 characters, 'abcP' sprites); anything else takes the generic instance.
-  if (k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3) {
-    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3>), grid, block, lds, s, k_, P, a, out);
+  if (!unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3) {
+    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out);
   } else {
     switch (k_.NS) {
-#define PCX_SM_CASE(n) \
-  case n: hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1>), grid, block, lds, s, k_, P, a, out); break;
+#define PCX_SM_CASE(n)                                                                                          \
+  case n:                                                                                                       \
+    if (unoccluded_) hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, true>), grid, block, lds, s, k_, P, a, out); \
+    else hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, false>), grid, block, lds, s, k_, P, a, out);            \
+    break;
       PCX_SM_CASE(1) PCX_SM_CASE(2) PCX_SM_CASE(3) PCX_SM_CASE(4) PCX_SM_CASE(5) PCX_SM_CASE(6)
 #undef PCX_SM_CASE
       default: return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: %d sprites", k_.NS);

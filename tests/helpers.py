@@ -43,7 +43,11 @@ def replay_trace(engine_factory, trace):
 
   def check(t):
     where = 'frame index %d' % t
-    np.testing.assert_array_equal(eng.read('planes'), expected_planes(trace['boards'][t], chars), err_msg=where)
+    if 'layers' in trace:  # occlusion_in_layers=False: layers were recorded
+      want = np.concatenate([trace['boards'][t][:, None], trace['layers'][t]], axis=1)
+    else:
+      want = expected_planes(trace['boards'][t], chars)
+    np.testing.assert_array_equal(eng.read('planes'), want, err_msg=where)
     np.testing.assert_array_equal(eng.read('reward_set'), trace['reward_set'][t], err_msg=where)
     np.testing.assert_array_equal(eng.read('reward'), trace['reward'][t], err_msg=where)
     np.testing.assert_array_equal(eng.read('discount'), trace['discount'][t], err_msg=where)
