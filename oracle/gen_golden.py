@@ -170,7 +170,7 @@ CROPPERS = {  # keyed by trace name
 
 
 def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, seeker=False, choice=None,
-        unoccluded=False):
+        unoccluded=False, ref_action=None, tapes=None):
   global UNOCCLUDED
   UNOCCLUDED = unoccluded
   boards, rewards, rsets, discounts, dones, sprites, layers = [], [], [], [], [], [], []
@@ -180,7 +180,7 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
   chars = sprite_chars = None
   for e in range(E):
     rng = np.random.RandomState(seed * 1000 + e)
-    actions[:, e] = tape(rng, e % 4, T, n_ordinary, quit_action)
+    actions[:, e] = tapes(rng, T) if tapes else tape(rng, e % 4, T, n_ordinary, quit_action)
     if choice is not None:
       choice.env = e
     game = make_game()
@@ -214,7 +214,7 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
         if seeker and e % 8 >= 5:
           actions[t, e] = seek_coin_action(game, rng)
         a = int(actions[t, e])
-        obs, r, d = game.play(None if a == NONE else a)
+        obs, r, d = game.play(None if a == NONE else (ref_action(a) if ref_action else a))
       rec.append(record(obs, r, d, game, chars, sprite_chars))
       crop_all(obs)
     for i in range(len(specs)):
@@ -257,6 +257,26 @@ def main():
         template_name='warehouse_L%d' % level)
   run('hello_world', hello_world.make_game, E=16, T=96, n_ordinary=4, quit_action=4, seed=27,
       template_name='hello_world')
+  # prefab-only scenarios built from the reference's own test entities
+  sys.path.insert(0, ROOT)
+  from oracle import walker_scenarios
+  from pycolab import ascii_art as ref_art
+  from pycolab.tests import test_things as tt
+  names = walker_scenarios.MOTION_NAMES
+  for i, (name, spec) in enumerate(sorted(walker_scenarios.SCENARIOS.items())):
+    chars = sorted(spec['walkers'])
+    if spec['n_fields']:
+      fields = {ch: spec['walkers'][ch]['field'] for ch in chars}
+      ref_action = lambda a, fields=fields: {ch: names[min((a >> sh) & mk, 8)] for ch, (sh, mk) in fields.items()}
+      tapes = lambda rng, T, n=spec['n_fields']: sum(
+          (walker_scenarios.field_tape(rng, T) << (4 * f) for f in range(n)), np.zeros(T, np.int32)).astype(np.int32)
+    else:
+      ref_action = lambda a: names[min(a, 8)]
+      tapes = lambda rng, T, c=spec.get('cardinal_only', False): walker_scenarios.field_tape(rng, T, c)
+    run(name, lambda spec=spec: walker_scenarios.build(spec, ref_art, tt.TestMazeWalker, tt.TestScrolly, False),
+        E=24, T=160, n_ordinary=9, quit_action=99, seed=51 + i, template_name=name,
+        ref_action=ref_action, tapes=tapes)
+
   # occlusion_in_layers=False variants: the example files do not expose the
   # flag, so the call they make into ascii_art is wrapped (files unchanged).
   import functools

@@ -692,22 +692,22 @@ static void prog_em_downbolt(ox_ctx* x, int id) {
 
 /* prefab-only entities: per-entity action = (action >> param[0]) & param[1]
  * when param[1] != 0 (packed multi-agent actions), else the action itself;
- * values 0..8 index MOTION9, anything else does nothing.  Restates the test
- * entities of tests/test_things.py:203-295 with integer actions. */
+ * values 0..7 index MOTION9, anything else -- None included -- is `_stay`.
+ * Restates the test entities of tests/test_things.py:203-295 with integer
+ * actions. */
 static int walker_action(int action, const int32_t* param) {
-  if (action < 0) return -1;
-  return param[1] ? (action >> param[0]) & param[1] : action;
+  if (action < 0) return 8;
+  unsigned a = param[1] ? ((unsigned)action >> param[0]) & (unsigned)param[1] : (unsigned)action;
+  return a > 8u ? 8 : (int)a;
 }
 static void prog_walker(ox_ctx* x, int id) {
   int a = walker_action(x->action, x->e->t.sprites[id].param);
-  if (a >= 0 && a < 9) {
-    int blocked = mw_move(x->e, x->env, id, x->board, MOTION9[a][0], MOTION9[a][1]);
-    x->env->sprites[id].var[0] = blocked; /* the_plot['walk_result_X'] truthiness */
-  }
+  int blocked = mw_move(x->e, x->env, id, x->board, MOTION9[a][0], MOTION9[a][1]);
+  x->env->sprites[id].var[0] = blocked; /* the_plot['walk_result_X'] truthiness */
 }
 static void prog_scrolly(ox_ctx* x, int di) {
   int a = walker_action(x->action, x->e->t.drapes[di].param);
-  if (a >= 0 && a < 9) sc_maybe_move(x->e, x->env, di, MOTION9[a][0], MOTION9[a][1]);
+  sc_maybe_move(x->e, x->env, di, MOTION9[a][0], MOTION9[a][1]);
 }
 
 static int run_program(ox_ctx* x, int id) {

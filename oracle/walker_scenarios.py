@@ -1,0 +1,120 @@
+"""TEST INFRASTRUCTURE: small prefab-only games (MazeWalkers, Scrollys) that
+exercise what the config games do not: diagonal motion rules, confinement,
+walking off and back onto the board, scroll_margins=None, several egocentric
+walkers, a Scrolly that follows another's orders.  The same description builds
+the game with the reference's own test entities (oracle/gen_golden.py) and
+with pycolab_amd's tabled prefabs (oracle/gen_templates.py)."""
+
+ROOM = ['...........',
+        '.wwww.wwww.',
+        '.w  w    w.',
+        '.w     Q w.',
+        '.  ww    w.',
+        '.w   P   ..',
+        '.w  w  www.',
+        '.w    x  w.',
+        '.wwwwwwwww.']
+
+WORLD = ['#############################',
+         '#     #         #      #    #',
+         '#  #  #  ####   #  ##  #  # #',
+         '#  #        #         ##  # #',
+         '#  ####  #  #####  #      # #',
+         '#        #      +     ###   #',
+         '####  ####  ##     ##     ###',
+         '#        a   #  P   #  #    #',
+         '#  ####      #      #  #### #',
+         '#     #  ###    ##          #',
+         '## #  #    #  Q  #  ####  # #',
+         '#  #     #    #       #   # #',
+         '#  ####  ######  ##   #  ## #',
+         '#                 #         #',
+         '#############################']
+
+SCENARIOS = {
+    # three independently steered walkers: action = aP | aQ << 4 | ax << 8
+    'walkers_room': dict(
+        kind='room', art=ROOM, beneath=' ',
+        walkers={'P': dict(impassable='w', field=(0, 15)),
+                 'Q': dict(impassable='', confined=True, field=(4, 15)),
+                 'x': dict(impassable='wP', field=(8, 15))},
+        schedule=[['P'], ['Q', 'x']], z_order='xQP', n_fields=3),
+    # Scrolly with margins, one egocentric walker, one wanderer; one shared action
+    'walkers_scroll_margins': dict(
+        kind='scroll', world=WORLD, board=(7, 11), mark='+', beneath=' ',
+        scrollies={'#': dict(margins=(2, 3))},
+        walkers={'P': dict(impassable='#', egocentric=True), 'a': dict(impassable='#')},
+        schedule=[['#'], ['a', 'P']], z_order='a#P', n_fields=0),
+    # scroll_margins=None (scroll whenever possible), two egocentric walkers
+    'walkers_scroll_always': dict(
+        kind='scroll', world=WORLD, board=(7, 11), mark='+', beneath=' ',
+        scrollies={'#': dict(margins=None)},
+        walkers={'P': dict(impassable='#', egocentric=True), 'Q': dict(impassable='#', egocentric=True),
+                 'a': dict(impassable='')},
+        schedule=[['#'], ['a', 'P', 'Q']], z_order='a#QP', n_fields=0,
+        # at the pattern's corner a diagonal motion meets an order of (0, 0) and the
+        # reference raises (sprites.py:449-454); keep this tape to cardinal moves
+        cardinal_only=True),
+}
+
+
+def build(spec, ascii_art, walker_cls, scrolly_cls, use_fields):
+  """make_game() for one scenario with the given module/classes.
+  `use_fields`: pass action_field=... (pycolab_amd tabled prefabs only)."""
+  P = ascii_art.Partial
+  if spec['kind'] == 'room':
+    sprites = {}
+    for ch, w in spec['walkers'].items():
+      kw = dict(impassable=w['impassable'], confined_to_board=w.get('confined', False))
+      if use_fields:
+        kw['action_field'] = w['field']
+      sprites[ch] = P(walker_cls, **kw)
+    return ascii_art.ascii_art_to_game(spec['art'], spec['beneath'], sprites=sprites,
+                                       update_schedule=spec['schedule'], z_order=spec['z_order'])
+  info = scrolly_cls.PatternInfo(spec['world'], spec['board'], spec['mark'], spec['beneath'])
+  rows, cols = spec['board']
+  art = [' ' * cols] * rows
+  drapes, sprites = {}, {}
+  for ch, d in spec['scrollies'].items():
+    drapes[ch] = P(scrolly_cls, scroll_margins=d['margins'], **info.kwargs(ch))
+  for ch, w in spec['walkers'].items():
+    vp = info.virtual_position(ch)
+    sprites[ch] = P(_positioned(walker_cls), vp, impassable=w['impassable'],
+                    egocentric_scroller=w.get('egocentric', False))
+  return ascii_art.ascii_art_to_game(art, ' ', sprites=sprites, drapes=drapes,
+                                     update_schedule=spec['schedule'], z_order=spec['z_order'])
+
+
+_CACHE = {}
+
+
+def _positioned(walker_cls):
+  """walker_cls, but teleported to a virtual position right after construction
+  (the idiom of examples/scrolly_maze.py:253-257)."""
+  if walker_cls not in _CACHE:
+    class Positioned(walker_cls):
+
+      def __init__(self, corner, position, character, virtual_position, **kwargs):
+        super(Positioned, self).__init__(corner, position, character, **kwargs)
+        self._teleport(virtual_position)
+    Positioned.__name__ = 'Positioned' + walker_cls.__name__
+    _CACHE[walker_cls] = Positioned
+  return _CACHE[walker_cls]
+
+
+MOTION_NAMES = ['n', 'ne', 'e', 'se', 's', 'sw', 'w', 'nw', 'stay']
+
+
+def field_tape(rng, T, cardinal_only=False):
+  """One entity's action field over time: persistent headings with turns,
+  occasional explicit stays and out-of-table values (9 -> `_stay`)."""
+  import numpy as np
+  out = np.zeros(T, np.int32)
+  pick = (lambda: 2 * rng.randint(4)) if cardinal_only else (lambda: rng.randint(8))
+  cur = pick()
+  for t in range(T):
+    r = rng.rand()
+    if r < 0.25:
+      cur = pick()
+    out[t] = 8 if r > 0.93 else (9 if r > 0.9 else cur)
+  return out

@@ -30,7 +30,10 @@ constexpr int MAX_L = 20;
 
 // per-thing table entry (uint32 words), staged into LDS
 enum : int { T_CH = 0, T_KIND, T_IDX, T_PROG, T_LAYER, T_ABOVE, T_FLAGS, T_P0, T_P1, T_IMP0, T_IMP1, T_IMP2, T_IMP3, T_WORDS };
-constexpr uint32_t TF_WALKER = 1, TF_CONFINED = 2;
+constexpr uint32_t TF_WALKER = 1, TF_CONFINED = 2, TF_EGO = 4, TF_SCROLLY = 8;
+// Scrolly drapes reuse the impassable words: pattern table offset, PR | PC << 16,
+// have_margins | margin_rows << 8 | margin_cols << 16, words per pattern row
+enum : int { T_PAT = T_IMP0, T_PDIM = T_IMP1, T_MARG = T_IMP2, T_PRW = T_IMP3 };
 
 // state words
 enum : int { W_FRAME = 0, W_FLAGS, W_V0, W_V1, W_V2, W_V3, W_RNG, W_SPRITES };
@@ -40,6 +43,7 @@ constexpr int64_t NEVER = INT32_MIN;
 struct Consts {
   int32_t game, R, C, cells, pitch, QW, L, NS, ND, NT, n_groups, RW, FW, NW, n_actions, n_bchars;
   int32_t occl;  // Engine(..., occlusion_in_layers)
+  int32_t has_scroll, w_scroll;  // any Scrolly drape / egocentric walker; state offset of the protocol words
   uint32_t magic_q;
   uint32_t seed_lo, seed_hi, envoff_lo, envoff_hi;
   int32_t w_sflags, w_drapes;           // state word offsets
@@ -49,7 +53,7 @@ struct Consts {
   int32_t box_mask;                     // warehouse: sprite-index mask of the box sprites
   // LDS layout (word offsets); per-lane arrays are [i][lane]
   int32_t l_things, l_z, l_sched, l_backdrop, l_bdmask, l_aux, l_init, l_initd, l_laybc, l_s2t;
-  int32_t l_pos, l_flg, l_snap, l_cur, l_snapd, l_flat, l_sdesc, l_skip, l_flatraw, l_sdescraw, l_words;
+  int32_t l_pos, l_flg, l_snap, l_cur, l_snapd, l_flat, l_sdesc, l_skip, l_flatraw, l_sdescraw, l_corner, l_pmask, l_pframe, l_words;
 };
 
 struct Ptrs {
@@ -63,7 +67,7 @@ struct Ptrs {
 
 struct L {
   const uint32_t *things, *z, *sched, *backdrop4, *bdmask, *aux, *init, *initd, *laybc, *s2t;
-  uint32_t *pos, *flg, *cur, *snapd, *flat, *skip, *flatraw;
+  uint32_t *pos, *flg, *cur, *snapd, *flat, *skip, *flatraw, *corner, *pmask, *pframe;
   int32_t* snap;
   uint2 *sdesc, *sdescraw;
 };
@@ -88,6 +92,9 @@ struct Ctx {
   int reward_set, reward, game_over;
   float discount;
   int32_t v[4];  // program variables (state words W_V0..3)
+  // protocols/scrolling.py, scrolling group '': the order lives one frame only
+  int order_valid, o0, o1;
+  uint32_t registered;  // bit per sprite index: 'scrolling__egocentrists'
 };
 
 __device__ __forceinline__ bool on_board(const Consts& k, int r, int c) {
@@ -188,18 +195,142 @@ __device__ __forceinline__ bool blocked_at(Ctx& x, int thing, int vr, int vc, in
   const int ch = top_char(x, r, c);
   return (tfield(x, thing, T_IMP0 + (ch >> 5)) >> (ch & 31)) & 1;
 }
+__device__ __forceinline__ bool check_motion(Ctx& x, int thing, int vr, int vc, int dr, int dc) {
+  if (dr != 0 && dc != 0)
+    return blocked_at(x, thing, vr, vc, dr, dc) ||
+           (blocked_at(x, thing, vr, vc, dr, 0) && blocked_at(x, thing, vr, vc, 0, dc));
+  if (dr != 0 || dc != 0) return blocked_at(x, thing, vr, vc, dr, dc);
+  return false;
+}
+__device__ __forceinline__ int motion_bit(int dr, int dc) { return (dr + 1) * 3 + (dc + 1); }
 __device__ __forceinline__ bool mw_move(Ctx& x, int thing, int dr, int dc) {
   const int s = tfield(x, thing, T_IDX);
+  const bool ego = x.k.has_scroll && (tfield(x, thing, T_FLAGS) & TF_EGO);
   int vr, vc, vis, prior;
+  if (x.k.has_scroll) {  // sprites.py:413-454 _obey_scrolling_order
+    if (ego) x.registered |= 1u << s;
+    if (x.order_valid) {
+      sprite_get(x, s, vr, vc, vis, prior);
+      teleport(x, s, vr - x.o0, vc - x.o1);
+      if (ego && x.o0 != dr && x.o1 != dc) x.err |= ERR_SCROLL;
+    }
+  }
   sprite_get(x, s, vr, vc, vis, prior);
-  bool blocked = false;
-  if (dr != 0 && dc != 0)
-    blocked = blocked_at(x, thing, vr, vc, dr, dc) ||
-              (blocked_at(x, thing, vr, vc, dr, 0) && blocked_at(x, thing, vr, vc, 0, dc));
-  else if (dr != 0 || dc != 0)
-    blocked = blocked_at(x, thing, vr, vc, dr, dc);
-  if (!blocked) teleport(x, s, vr + dr, vc + dc);
+  const bool blocked = check_motion(x, thing, vr, vc, dr, dc);
+  if (!blocked) { teleport(x, s, vr + dr, vc + dc); vr += dr; vc += dc; }
+  if (ego) {  // sprites.py:456-477 + scrolling.py:372-434 permit()
+    uint32_t legal = 1u << motion_bit(0, 0);
+    for (int a = -1; a <= 1; ++a)
+      for (int b = -1; b <= 1; ++b)
+        if ((a || b) && !check_motion(x, thing, vr, vc, a, b)) legal |= 1u << motion_bit(a, b);
+    const uint32_t my_frame = (uint32_t)(x.frame + 1);
+    uint32_t mask = x.l.pmask[s * WAVE + x.lane];
+    if (!(mask & 0x80000000u) || x.l.pframe[s * WAVE + x.lane] != my_frame) mask = 0;
+    x.l.pmask[s * WAVE + x.lane] = mask | legal | 0x80000000u;  // bit 31: a permit frame exists
+    x.l.pframe[s * WAVE + x.lane] = my_frame;
+  }
   return blocked;
+}
+
+// ---- prefab_parts/drapes.py: Scrolly ----------------------------------------------
+// scrolling.py:437-485 is_possible
+__device__ __forceinline__ bool is_possible(const Ctx& x, int dr, int dc) {
+  for (int s = 0; s < x.k.NS; ++s) {
+    if (!((x.registered >> s) & 1)) continue;
+    const uint32_t mask = x.l.pmask[s * WAVE + x.lane];
+    if (!(mask & 0x80000000u) || x.l.pframe[s * WAVE + x.lane] != (uint32_t)x.frame) return false;
+    if (!((mask >> motion_bit(dr, dc)) & 1)) return false;
+  }
+  return true;
+}
+// drapes.py:689-695 _update_curtain: cur rows <- pattern window at the corner
+__device__ __forceinline__ void update_curtain(Ctx& x, int thing) {
+  const int d = tfield(x, thing, T_IDX), C = x.k.C;
+  const uint32_t* pat = x.l.things - x.k.l_things + tfield(x, thing, T_PAT);  // tables base + offset
+  const int PR = tfield(x, thing, T_PDIM) & 0xFFFF, PC = tfield(x, thing, T_PDIM) >> 16, PRW = tfield(x, thing, T_PRW);
+  const uint32_t cw = x.l.corner[d * WAVE + x.lane];
+  const int cr = pos_r(cw), cc = pos_c(cw);
+  if (cr < 0 || cc < 0 || cr + x.k.R > PR || cc + C > PC) { x.err |= ERR_INDEX; return; }
+  const uint64_t m = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
+  for (int r = 0; r < x.k.R; ++r) {
+    const uint32_t* row = pat + (cr + r) * PRW;
+    const int wi = cc >> 5, sh = cc & 31;
+    const uint64_t lo = (uint64_t)row[wi] | ((uint64_t)row[wi + 1] << 32);
+    uint64_t bits = lo >> sh;
+    if (sh) bits |= (uint64_t)row[wi + 2] << (64 - sh);
+    row_put(x, x.l.cur, d, r, bits & m);
+  }
+}
+// drapes.py:487-659 _maybe_move
+__device__ __forceinline__ void maybe_move(Ctx& x, int thing, int dr, int dc) {
+  const int d = tfield(x, thing, T_IDX);
+  const int PR = tfield(x, thing, T_PDIM) & 0xFFFF, PC = tfield(x, thing, T_PDIM) >> 16;
+  const int lim_r = PR - x.k.R, lim_c = PC - x.k.C;
+  const uint32_t marg = tfield(x, thing, T_MARG);
+  uint32_t cw = x.l.corner[d * WAVE + x.lane];
+  int cr = pos_r(cw), cc = pos_c(cw);
+  if (x.order_valid) {  // :523-535
+    if (dr != x.o0 && dc != x.o1) { x.err |= ERR_SCROLL; return; }
+    x.l.corner[d * WAVE + x.lane] = pack_pos(cr + x.o0, cc + x.o1);
+    update_curtain(x, thing);
+    return;
+  }
+  if (dr == 0 && dc == 0) { update_curtain(x, thing); return; }  // :539-541
+  int o0, o1;
+  bool go;
+  if (!(marg & 1)) {  // scroll_margins=None :551-585
+    go = is_possible(x, dr, dc);
+    const int north = cr + dr, west = cc + dc;
+    o0 = (0 <= north && north <= lim_r) ? dr : 0;
+    o1 = (0 <= west && west <= lim_c) ? dc : 0;
+  } else {  // :592-659
+    const int mrows = (marg >> 8) & 0xFF, mcols = (marg >> 16) & 0xFF;
+    const int margin_n = mrows - 1, margin_s = x.k.R - mrows, margin_w = mcols - 1, margin_e = x.k.C - mcols;
+    bool vert = false, horiz = false;
+    for (int s = 0; s < x.k.NS; ++s) {  // registered egocentric *sprites* (:611)
+      if (!((x.registered >> s) & 1)) continue;
+      int old_r, old_c;
+      sprite_true(x, s, old_r, old_c);
+      const int new_r = old_r + dr, new_c = old_c + dc;
+      vert |= (old_r > new_r && new_r <= margin_n) || (old_r < new_r && new_r >= margin_s);
+      horiz |= (old_c > new_c && new_c <= margin_w) || (old_c < new_c && new_c >= margin_e);
+    }
+    if (!(vert || horiz)) { update_curtain(x, thing); return; }
+    o0 = vert ? dr : 0;
+    o1 = horiz ? dc : 0;
+    const int pr = cr + o0, pc = cc + o1;
+    go = 0 <= pr && pr <= lim_r && 0 <= pc && pc <= lim_c && is_possible(x, dr, dc);
+  }
+  if (go) {
+    x.l.corner[d * WAVE + x.lane] = pack_pos(cr + o0, cc + o1);
+    x.order_valid = 1; x.o0 = o0; x.o1 = o1;  // scrolling.py:530-531
+  }
+  update_curtain(x, thing);
+}
+
+// Prefab-only entities (tests/test_things.py:203-295 restated with integer
+// actions): per-entity action = (action >> P0) & P1 when P1 != 0, else the
+// action; 0..7 = N NE E SE S SW W NW; anything else, None included, is
+// `_stay` (which still takes part in the scrolling protocol).
+__device__ __forceinline__ int entity_action(const Ctx& x, int thing) {
+  if (x.action < 0) return 8;
+  const uint32_t sh = tfield(x, thing, T_P0), mk = tfield(x, thing, T_P1);
+  const uint32_t a = mk ? ((uint32_t)x.action >> sh) & mk : (uint32_t)x.action;
+  return a > 8u ? 8 : (int)a;
+}
+__device__ __forceinline__ void motion9(int a, int& dr, int& dc) {
+  dr = (a == 0 || a == 1 || a == 7) ? -1 : (a == 3 || a == 4 || a == 5) ? 1 : 0;
+  dc = (a == 1 || a == 2 || a == 3) ? 1 : (a == 5 || a == 6 || a == 7) ? -1 : 0;
+}
+__device__ __forceinline__ void prog_walker(Ctx& x, int thing) {
+  int dr, dc;
+  motion9(entity_action(x, thing), dr, dc);
+  mw_move(x, thing, dr, dc);
+}
+__device__ __forceinline__ void prog_scrolly(Ctx& x, int thing) {
+  int dr, dc;
+  motion9(entity_action(x, thing), dr, dc);
+  maybe_move(x, thing, dr, dc);
 }
 
 __device__ __forceinline__ void terminate(Ctx& x) { x.game_over = 1; x.discount = 0.0f; }  // plot.py:176-198
@@ -404,6 +535,7 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
   l.pos = lds + k.l_pos; l.flg = lds + k.l_flg; l.snap = reinterpret_cast<int32_t*>(lds + k.l_snap);
   l.cur = lds + k.l_cur; l.snapd = lds + k.l_snapd; l.flat = lds + k.l_flat;
   l.sdesc = reinterpret_cast<uint2*>(lds + k.l_sdesc); l.skip = lds + k.l_skip;
+  l.corner = lds + k.l_corner; l.pmask = lds + k.l_pmask; l.pframe = lds + k.l_pframe;
   l.flatraw = lds + k.l_flatraw; l.sdescraw = reinterpret_cast<uint2*>(lds + k.l_sdescraw);
   __syncthreads();
 
@@ -423,7 +555,7 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
   }
   const int ndw = k.ND * k.R * k.RW;
   if (!skip) {
-    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}};
+    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}, 0, 0, 0, 0};
     // bits 8..15 of the flags word: MarauderDrape._dx + 1; W_RNG: RNG draws so far (survive resets)
     uint32_t draws = st[W_RNG * bp];
     int dxv;
@@ -436,6 +568,11 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
         l.flg[s * WAVE + lane] = (l.init[k.w_sflags + (s >> 2)] >> (8 * (s & 3))) & 0xFF;
       }
       for (int i = 0; i < ndw; ++i) l.cur[i * WAVE + lane] = l.initd[i];
+      if (k.has_scroll) {
+        x.registered = 0;
+        for (int d = 0; d < k.ND; ++d) l.corner[d * WAVE + lane] = l.init[k.w_scroll + 1 + d];
+        for (int s = 0; s < k.NS; ++s) { l.pmask[s * WAVE + lane] = 0; l.pframe[s * WAVE + lane] = 0; }
+      }
       x.action = PCX_ACTION_NONE;
     } else {
       x.frame = (int)st[W_FRAME * bp];
@@ -448,6 +585,14 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
         for (int j = 0; j < 4 && 4 * w + j < k.NS; ++j) l.flg[(4 * w + j) * WAVE + lane] = (f >> (8 * j)) & 0xFF;
       }
       for (int i = 0; i < ndw; ++i) l.cur[i * WAVE + lane] = st[(k.w_drapes + i) * bp];
+      if (k.has_scroll) {
+        x.registered = st[k.w_scroll * bp];
+        for (int d = 0; d < k.ND; ++d) l.corner[d * WAVE + lane] = st[(k.w_scroll + 1 + d) * bp];
+        for (int s = 0; s < k.NS; ++s) {
+          l.pmask[s * WAVE + lane] = st[(k.w_scroll + 1 + k.ND + 2 * s) * bp];
+          l.pframe[s * WAVE + lane] = st[(k.w_scroll + 2 + k.ND + 2 * s) * bp];
+        }
+      }
     }
     snapshot(x);  // what the previous frame's last repaint showed
     // ---- Engine.play(): engine.py:698-735 --------------------------------
@@ -468,6 +613,8 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
           case PCX_PROG_EM_MARAUDER: prog_em_marauder(x, thing, dxv); break;
           case PCX_PROG_EM_UPBOLT: prog_em_upbolt(x, thing); break;
           case PCX_PROG_EM_DOWNBOLT: prog_em_downbolt(x, thing, draws, genv); break;
+          case PCX_PROG_WALKER: prog_walker(x, thing); break;
+          case PCX_PROG_SCROLLY: prog_scrolly(x, thing); break;
           default: break;  // PCX_PROG_STATIC
         }
       }
@@ -486,6 +633,14 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
       st[(k.w_sflags + w) * bp] = f;
     }
     for (int i2 = 0; i2 < ndw; ++i2) st[(k.w_drapes + i2) * bp] = l.cur[i2 * WAVE + lane];
+    if (k.has_scroll) {
+      st[k.w_scroll * bp] = x.registered;
+      for (int d = 0; d < k.ND; ++d) st[(k.w_scroll + 1 + d) * bp] = l.corner[d * WAVE + lane];
+      for (int s = 0; s < k.NS; ++s) {
+        st[(k.w_scroll + 1 + k.ND + 2 * s) * bp] = l.pmask[s * WAVE + lane];
+        st[(k.w_scroll + 2 + k.ND + 2 * s) * bp] = l.pframe[s * WAVE + lane];
+      }
+    }
     out.reward[env] = x.reward;
     out.reward_set[env] = (uint8_t)x.reward_set;
     out.discount[env] = x.discount;
@@ -653,7 +808,8 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   auto find_sprite = [&](int ch) { for (int s = 0; s < t.n_sprites; ++s) if (t.sprites[s].ch == ch) return s; return -1; };
   auto find_drape = [&](int ch) { for (int d = 0; d < t.n_drapes; ++d) if (t.drapes[d].ch == ch) return d; return -1; };
   auto layer_of = [&](int ch) { for (int i = 0; i < k.L; ++i) if (t.chars[i] == ch) return i; return -1; };
-  std::vector<uint32_t> things((size_t)k.NT * T_WORDS, 0), zt(k.NT), sched(k.NT);
+  std::vector<uint32_t> things((size_t)k.NT * T_WORDS, 0), zt(k.NT), sched(k.NT), patterns;
+  k.has_scroll = 0;
   k.ip = k.ix = k.ib = k.tx = -1;
   k.bolt_mask_all = k.bolt_mask_up = k.box_mask = 0;
   for (int z = 0; z < k.NT; ++z) {
@@ -671,15 +827,33 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
       e[T_FLAGS] = (sd.is_walker ? TF_WALKER : 0) | (sd.confined ? TF_CONFINED : 0);
       e[T_P0] = sd.param[0]; e[T_P1] = sd.param[1];
       memcpy(&e[T_IMP0], sd.impassable, 16);
-      if (sd.egocentric) return set_error(PCX_E_UNSUPPORTED, "generic backend: egocentric walkers need the scrolly backend");
+      if (sd.egocentric) { e[T_FLAGS] |= TF_EGO; k.has_scroll = 1; }
       if (ch == 'P') k.ip = z;
       if (sd.program == PCX_PROG_EM_UPBOLT) { k.bolt_mask_all |= 1 << s; k.bolt_mask_up |= 1 << s; }
       if (sd.program == PCX_PROG_EM_DOWNBOLT) k.bolt_mask_all |= 1 << s;
       if (sd.program == PCX_PROG_WM_BOX) k.box_mask |= 1 << s;
     } else if (d >= 0) {
       const pcx_drape_desc& dd = t.drapes[d];
-      if (dd.is_scrolly) return set_error(PCX_E_UNSUPPORTED, "generic backend: Scrolly drapes need the scrolly backend");
       e[T_KIND] = 1; e[T_IDX] = d; e[T_PROG] = dd.program; e[T_P0] = dd.param[0]; e[T_P1] = dd.param[1];
+      if (dd.is_scrolly) {
+        if (dd.pattern_rows > 4096 || dd.pattern_cols > 4096 || dd.margin_rows > 255 || dd.margin_cols > 255)
+          return set_error(PCX_E_UNSUPPORTED, "generic backend: Scrolly pattern too large");
+        const int PRW = (dd.pattern_cols + 31) / 32 + 2;
+        e[T_FLAGS] = TF_SCROLLY;
+        e[T_PDIM] = (uint32_t)dd.pattern_rows | ((uint32_t)dd.pattern_cols << 16);
+        e[T_MARG] = (uint32_t)(dd.have_margins != 0) | ((uint32_t)dd.margin_rows << 8) | ((uint32_t)dd.margin_cols << 16);
+        e[T_PRW] = PRW;
+        e[T_PAT] = 0x80000000u | (uint32_t)patterns.size();  // relocated once the table layout is known
+        for (int r = 0; r < dd.pattern_rows; ++r) {
+          std::vector<uint32_t> row(PRW, 0);
+          for (int c = 0; c < dd.pattern_cols; ++c)
+            if (dd.pattern[(size_t)r * dd.pattern_cols + c]) row[c >> 5] |= 1u << (c & 31);
+          patterns.insert(patterns.end(), row.begin(), row.end());
+        }
+        k.has_scroll = 1;
+      } else if (dd.program == PCX_PROG_SCROLLY) {
+        return set_error(PCX_E_INVALID, "generic backend: the 'scrolly' program needs a Scrolly drape");
+      }
       if (ch == 'X') { k.ix = d; k.tx = z; }
       if (ch == 'B') k.ib = d;
     } else {
@@ -689,7 +863,8 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
     switch (e[T_PROG]) {
       case PCX_PROG_WM_BOX: case PCX_PROG_WM_JUDGE: case PCX_PROG_WM_PLAYER: case PCX_PROG_HW_ROLLING:
       case PCX_PROG_HW_SLIDING: case PCX_PROG_EM_PLAYER: case PCX_PROG_EM_BUNKER: case PCX_PROG_EM_MARAUDER:
-      case PCX_PROG_EM_UPBOLT: case PCX_PROG_EM_DOWNBOLT: case PCX_PROG_STATIC: break;
+      case PCX_PROG_EM_UPBOLT: case PCX_PROG_EM_DOWNBOLT: case PCX_PROG_STATIC: case PCX_PROG_WALKER:
+      case PCX_PROG_SCROLLY: break;
       default: return set_error(PCX_E_UNSUPPORTED, "generic backend: no device program %u", e[T_PROG]);
     }
   }
@@ -728,7 +903,8 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.w_sflags = W_SPRITES + k.NS;
   k.w_drapes = k.w_sflags + (k.NS + 3) / 4;
   const int ndw = k.ND * k.R * k.RW;
-  k.NW = k.w_drapes + ndw;
+  k.w_scroll = k.w_drapes + ndw;
+  k.NW = k.w_scroll + (k.has_scroll ? 1 + k.ND + 2 * k.NS : 0);
   std::vector<uint32_t> init(k.NW, 0), initd(ndw ? ndw : 1, 0);
   init[W_FRAME] = (uint32_t)-1;
   uint32_t dx_plus1 = 1;
@@ -741,6 +917,9 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
         if (t.drapes[d].curtain[r * k.C + c]) initd[(d * k.R + r) * k.RW + (c >> 5)] |= 1u << (c & 31);
   }
   init[W_FLAGS] = dx_plus1 << 8;
+  if (k.has_scroll)
+    for (int d = 0; d < k.ND; ++d)
+      init[k.w_scroll + 1 + d] = ((uint32_t)t.drapes[d].corner_row & 0xFFFFu) | ((uint32_t)t.drapes[d].corner_col << 16);
   for (int j = 0; j < 4; ++j) init[W_V0 + j] = (uint32_t)v[j];
   walker_.assign(k.NS, 0);
   for (int s = 0; s < k.NS; ++s) {
@@ -758,6 +937,13 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.l_bdmask = place(bdmask); k.l_aux = place(aux); k.l_init = place(init); k.l_initd = place(initd);
   if (laybc.empty()) laybc.push_back(0);
   k.l_laybc = place(laybc); k.l_s2t = place(s2t);
+  {
+    const int pat0 = place(patterns);
+    for (int z = 0; z < k.NT; ++z) {
+      uint32_t& off = tab[k.l_things + (size_t)z * T_WORDS + T_PAT];
+      if (tab[k.l_things + (size_t)z * T_WORDS + T_KIND] == 1 && (off & 0x80000000u)) off = pat0 + (off & 0x7FFFFFFFu);
+    }
+  }
   n_table_words_ = (int)tab.size();
   int off = (n_table_words_ + 1) & ~1;
   k.l_pos = off; off += k.NS * WAVE;
@@ -769,6 +955,9 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   off = (off + 1) & ~1;
   k.l_sdesc = off; off += 2 * k.NS * WAVE;
   k.l_skip = off; off += WAVE;
+  k.l_corner = off; if (k.has_scroll) off += k.ND * WAVE;
+  k.l_pmask = off; if (k.has_scroll) off += k.NS * WAVE;
+  k.l_pframe = off; if (k.has_scroll) off += k.NS * WAVE;
   k.l_flatraw = off; if (!k.occl) off += k.ND * k.FW * WAVE;
   off = (off + 1) & ~1;
   k.l_sdescraw = off; if (!k.occl) off += 2 * k.NS * WAVE;

@@ -43,4 +43,4 @@ class HipAdapter(object):
 
   def curtains(self):
     _, cur = self.eng._read_things()
-    return cur
+    return cur[:, :len(self.template.drapes)]

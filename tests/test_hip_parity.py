@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 LEVELS = ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2']
 ALL_GAMES = LEVELS + ['warehouse_L0', 'warehouse_L1', 'warehouse_L2', 'hello_world', 'marauders',
-                      'scrolly_maze_L1_unoccluded', 'warehouse_L0_unoccluded', 'marauders_unoccluded']
+                      'scrolly_maze_L1_unoccluded', 'warehouse_L0_unoccluded', 'marauders_unoccluded',
+                      'walkers_room', 'walkers_scroll_margins', 'walkers_scroll_always']
 
 
 class OracleAdapter(binding.OracleEngine):
