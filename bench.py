@@ -63,7 +63,8 @@ def main():
   if args.gpus != world and world > 1:
     raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
   torch.cuda.set_device(local)
-  if world > 1:
+  distributed = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ  # launched by torch.distributed.run
+  if distributed:
     import torch.distributed as dist
     dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
@@ -87,7 +88,7 @@ def main():
   tape = torch.randint(0, template.n_actions, (total, B), dtype=torch.int32, device='cuda', generator=g)
 
   def barrier():
-    if world > 1:
+    if distributed:
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -104,7 +105,7 @@ def main():
   wall = time.perf_counter() - t0
   kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg launch duration on the launch stream
 
-  if world > 1:
+  if distributed:
     w = torch.tensor([wall], dtype=torch.float64, device='cuda')
     dist.all_reduce(w, op=dist.ReduceOp.MAX)
     wall = float(w.item())
@@ -148,7 +149,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(template_path)
     print(json.dumps(line))
-  if world > 1:
+  if distributed:
     dist.destroy_process_group()
 
 

@@ -66,8 +66,12 @@ struct Consts {
   // sprites, in engine insertion order (== update order inside group 1)
   int32_t prog[MAX_NS], confined[MAX_NS], egocentric[MAX_NS], sprite_ch[MAX_NS];
   uint32_t imp[MAX_NS][4];
-  uint32_t relevant[MAX_NS];  // presence bits that can change a probe's verdict
+  // Probes number the things by z-order position (bit z = the z-th thing from the
+  // back), so the character on top of a cell is the highest set presence bit.
+  uint32_t relevant[MAX_NS];  // z-bits that can change a probe's verdict for walker s
+  uint32_t imp_z[MAX_NS];     // z-bits of the things whose character is impassable to walker s
   int32_t relevant_backdrop[MAX_NS];
+  int32_t zpos_sprite[MAX_NS], zpos_maze, zpos_cash;
   uint32_t init[24];          // initial state words (coin words are derived)
   // z-order, back to front
   int32_t z_kind[MAX_Z], z_idx[MAX_Z], z_ch[MAX_Z];
@@ -171,28 +175,21 @@ __device__ __forceinline__ bool blocked_at(const Consts& k, const Lds& l, const 
                                            const Walker& w, int dr, int dc, int lane, uint32_t& err) {
   int r = w.vr + dr, c = w.vc + dc;
   if (!on_board(k, r, c)) return k.confined[s] != 0;  // EDGE
-  uint32_t rel = k.relevant[s];
+  const uint32_t rel = k.relevant[s];
   uint32_t present = 0;
-  int cell = r * k.C + c;
+  const int cell = r * k.C + c;
 #pragma unroll
   for (int j = 0; j < NS; ++j)
-    if ((rel >> j) & 1) present |= (uint32_t)(sn.cell[j] == cell) << j;
-  if ((rel >> NS) & 1) present |= (uint32_t)wall_at(k, l, sn.maze_r + r, sn.maze_c + c, err) << NS;
-  if ((rel >> (NS + 1)) & 1) {
-    int id = coin_id_at(k, l, sn.cash_r + r, sn.cash_c + c);
-    bool there = id >= 0 && (coin_alive(l, lane, id) || (uint32_t)id == sn.stale);
-    present |= (uint32_t)there << (NS + 1);
+    if ((rel >> k.zpos_sprite[j]) & 1) present |= (uint32_t)(sn.cell[j] == cell) << k.zpos_sprite[j];
+  if ((rel >> k.zpos_maze) & 1) present |= (uint32_t)wall_at(k, l, sn.maze_r + r, sn.maze_c + c, err) << k.zpos_maze;
+  if ((rel >> k.zpos_cash) & 1) {
+    const int id = coin_id_at(k, l, sn.cash_r + r, sn.cash_c + c);
+    const bool there = id >= 0 && (coin_alive(l, lane, id) || (uint32_t)id == sn.stale);
+    present |= (uint32_t)there << k.zpos_cash;
   }
-  int top = -1;
-#pragma unroll
-  for (int z = 0; z < NS + 2; ++z) {  // back to front: the last hit wins (n_things == NS + 2)
-    int bit = k.z_kind[z] ? NS + k.z_idx[z] : k.z_idx[z];
-    if ((present >> bit) & 1) top = k.z_ch[z];
-  }
-  if (top < 0) {
-    if (!k.relevant_backdrop[s]) return false;
-    top = (l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
-  }
+  if (present) return (k.imp_z[s] >> (31 - __clz((int)present))) & 1;  // the thing in front decides
+  if (!k.relevant_backdrop[s]) return false;
+  const int top = (l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
   // static word selects: a runtime index into the kernarg struct would force
   // the compiler to spill the whole struct to scratch
   const uint32_t hi = (uint32_t)top >> 5;
@@ -358,6 +355,11 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
   const int R = SR ? SR : k.R, C = SC ? SC : k.C, L = SL ? SL : k.L;
   const int cells = R * C, QW = cells >> 2;
   const int FW = SR ? (SR * SC + 31) / 32 + 1 : k.FW;
+  // curtain word w of drape d of environment e.  Environment-major with an odd
+  // pitch: the logic phase (lane == e, same w) and the render phase (same e,
+  // consecutive w) both touch 32 different banks.
+  const int FWP = FW | 1;
+#define FLAT(d, w, e) (((d) * WAVE + (e)) * FWP + (w))
 
   Lds l;
   uint32_t* lw = lds_raw + k.lds_walls;
@@ -494,16 +496,19 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
 #define PCX_SM_SPRITE(s)                                                                         \
   if constexpr ((s) < NS) {                                                                      \
     if (k.prog[s] == PCX_PROG_SM_PATROLLER) { /* scrolly_maze.py:284-305 */                      \
-      if (p.frame & 1) {                                                                         \
-        mw_move<NS>(k, l, sn, s, w[s], p, 0, 0, lane, err);                                      \
-      } else {                                                                                   \
+      const bool walks = !(p.frame & 1); /* odd frames: _stay */                                 \
+      int mdc = 0;                                                                               \
+      if (walks) {                                                                               \
         /* drapes.py:405-411 pattern_position_prescroll on the walls drape */                    \
         if (!maze.moved) { maze.pre_r = maze.r; maze.pre_c = maze.c; }                           \
         int pr = w[s].vr + maze.pre_r, pc = w[s].vc + maze.pre_c + (w[s].var ? 1 : -1);          \
         if (pr < 0) pr += k.PR; /* numpy negative-index wrap */                                  \
         if (pc < 0) pc += k.PC;                                                                  \
         if (wall_at(k, l, pr, pc, err)) w[s].var ^= 1;                                           \
-        mw_move<NS>(k, l, sn, s, w[s], p, 0, w[s].var ? 1 : -1, lane, err);                      \
+        mdc = w[s].var ? 1 : -1;                                                                 \
+      }                                                                                          \
+      mw_move<NS>(k, l, sn, s, w[s], p, 0, mdc, lane, err); /* one call site for both */         \
+      if (walks) {                                                                               \
         const Walker pl = pick<NS, IP>(w, k.ip);                                                 \
         if (w[s].vr == pl.vr && w[s].vc == pl.vc) { p.game_over = 1; p.discount = 0.0f; }        \
       }                                                                                          \
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
 #pragma unroll
         for (int i = 0; i < ACC; ++i) accw[i] = accc[i] = 0;
       } else {
-        for (int i = 0; i < FW; ++i) l.flat[(0 * FW + i) * WAVE + lane] = l.flat[(1 * FW + i) * WAVE + lane] = 0;
+        for (int i = 0; i < FW; ++i) l.flat[FLAT(0, i, lane)] = l.flat[FLAT(1, i, lane)] = 0;
       }
       const uint32_t cmaskC = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
 #pragma unroll
@@ -592,11 +597,11 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
             accc[wi + 1] |= cbits >> (32 - sh);
           }
         } else {
-          l.flat[(0 * FW + wi) * WAVE + lane] |= wbits << sh;
-          l.flat[(1 * FW + wi) * WAVE + lane] |= cbits << sh;
+          l.flat[FLAT(0, wi, lane)] |= wbits << sh;
+          l.flat[FLAT(1, wi, lane)] |= cbits << sh;
           if (sh + C > 32) {
-            l.flat[(0 * FW + wi + 1) * WAVE + lane] |= wbits >> (32 - sh);
-            l.flat[(1 * FW + wi + 1) * WAVE + lane] |= cbits >> (32 - sh);
+            l.flat[FLAT(0, wi + 1, lane)] |= wbits >> (32 - sh);
+            l.flat[FLAT(1, wi + 1, lane)] |= cbits >> (32 - sh);
           }
         }
       }
@@ -613,8 +618,8 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
           }
         } else {
           for (int i = 0; i < FW; ++i) {
-            P.curtains[((size_t)ms * FW + i) * bp + env] = l.flat[(0 * FW + i) * WAVE + lane];
-            P.curtains[((size_t)cs2 * FW + i) * bp + env] = l.flat[(1 * FW + i) * WAVE + lane];
+            P.curtains[((size_t)ms * FW + i) * bp + env] = l.flat[FLAT(0, i, lane)];
+            P.curtains[((size_t)cs2 * FW + i) * bp + env] = l.flat[FLAT(1, i, lane)];
           }
         }
       }
@@ -623,18 +628,18 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
         for (int i = 0; i < ACC; ++i) {
           const uint32_t ww = cash_in_front ? accw[i] & ~accc[i] : accw[i];
           const uint32_t cc = cash_in_front ? accc[i] : accc[i] & ~accw[i];
-          l.flat[(0 * ACC + i) * WAVE + lane] = ww;
-          l.flat[(1 * ACC + i) * WAVE + lane] = cc;
+          l.flat[FLAT(0, i, lane)] = ww;
+          l.flat[FLAT(1, i, lane)] = cc;
         }
       } else {
         for (int i = 0; i < FW; ++i) {
-          const uint32_t ww = l.flat[(0 * FW + i) * WAVE + lane], cc = l.flat[(1 * FW + i) * WAVE + lane];
+          const uint32_t ww = l.flat[FLAT(0, i, lane)], cc = l.flat[FLAT(1, i, lane)];
           if constexpr (UNOCC) {  // unoccluded layers are the raw curtains (rendering.py:236-278)
-            (lds_raw + k.lds_flatraw)[(0 * FW + i) * WAVE + lane] = ww;
-            (lds_raw + k.lds_flatraw)[(1 * FW + i) * WAVE + lane] = cc;
+            (lds_raw + k.lds_flatraw)[FLAT(0, i, lane)] = ww;
+            (lds_raw + k.lds_flatraw)[FLAT(1, i, lane)] = cc;
           }
-          l.flat[(0 * FW + i) * WAVE + lane] = cash_in_front ? ww & ~cc : ww;
-          l.flat[(1 * FW + i) * WAVE + lane] = cash_in_front ? cc : cc & ~ww;
+          l.flat[FLAT(0, i, lane)] = cash_in_front ? ww & ~cc : ww;
+          l.flat[FLAT(1, i, lane)] = cash_in_front ? cc : cc & ~ww;
         }
       }
     }
@@ -658,10 +663,10 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
           const int wi = cell >> 5, sh = cell & 31;
 #pragma unroll
           for (int dd = 0; dd < 2; ++dd)
-            if (((ab >> (NS + dd)) & 1) && ((l.flat[(dd * FW + wi) * WAVE + lane] >> sh) & 1)) shown = false;
+            if (((ab >> (NS + dd)) & 1) && ((l.flat[FLAT(dd, wi, lane)] >> sh) & 1)) shown = false;
           if (shown) {
-            l.flat[(0 * FW + wi) * WAVE + lane] &= ~(1u << sh);
-            l.flat[(1 * FW + wi) * WAVE + lane] &= ~(1u << sh);
+            l.flat[FLAT(0, wi, lane)] &= ~(1u << sh);
+            l.flat[FLAT(1, wi, lane)] &= ~(1u << sh);
           }
         }
         l.sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
@@ -712,33 +717,75 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
   // other than LDS, and every LDS read of an iteration is issued up front.
   constexpr int NBS = SL ? SL - NS - 2 : MAX_L;  // backdrop-only characters
   const int NB = SL ? NBS : k.n_bchars;
-  uint32_t sch4[NS], dch4[2], soff[NS], doff[2], boff[NBS];
+  uint32_t sch4[NS], dch4[2];
+  const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)cells;
+  const int64_t env0 = g_render * WAVE;
+  // Uniform per-plane base pointers: every store below is `scalar base +
+  // 32-bit lane offset`, and the lane offset is the same for all nine planes.
+  auto uniform_ptr = [](uint8_t* p) {  // pin a wave-uniform pointer to an SGPR pair
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<uint8_t*>(((uint64_t)hi << 32) | lo);
+  };
+  uint8_t* const pb_board = uniform_ptr(out.planes + (size_t)env0 * env_stride);
+  uint8_t* pb_s[NS];
+  uint8_t* pb_d[2];
+  uint8_t* pb_b[NBS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     sch4[s] = (uint32_t)k.sprite_ch[s] * 0x01010101u;
-    soff[s] = (uint32_t)(1 + k.lay_sprite[s]) * (uint32_t)cells;
+    pb_s[s] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_sprite[s]) * (uint32_t)cells);
   }
   dch4[0] = (uint32_t)k.maze_ch * 0x01010101u;
   dch4[1] = (uint32_t)k.cash_ch * 0x01010101u;
-  doff[0] = (uint32_t)(1 + k.lay_drape[0]) * (uint32_t)cells;
-  doff[1] = (uint32_t)(1 + k.lay_drape[1]) * (uint32_t)cells;
+  pb_d[0] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_drape[0]) * (uint32_t)cells);
+  pb_d[1] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_drape[1]) * (uint32_t)cells);
 #pragma unroll
-  for (int i = 0; i < NBS; ++i) boff[i] = (uint32_t)(1 + k.lay_bchar[i]) * (uint32_t)cells;
+  for (int i = 0; i < NBS; ++i) pb_b[i] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_bchar[i]) * (uint32_t)cells);
   const uint32_t magic_q = k.magic_q;
-  const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)cells;
-  const int64_t env0 = g_render * WAVE;
-  uint8_t* blk = out.planes + (size_t)env0 * env_stride;
+  const uint32_t e_skew = env_stride - 4u * (uint32_t)QW;  // voff = 4 f + e * e_skew
+  const uint32_t* const flat_raw = lds_raw + k.lds_flatraw;
+  const uint2* const sdesc_raw = reinterpret_cast<const uint2*>(lds_raw + k.lds_sdescraw);
 
-  // One (environment e, dword q) task: compose the board dword and the layer
-  // dwords and hand each to `put(byte offset inside the env record, value)`.
-  auto render = [&](uint32_t e, uint32_t q, auto&& put) {
+  // Each wave store covers 256 contiguous bytes of one plane of one or two
+  // environment records; all nine planes of a 64-dword span leave together.
+  const bool any_skip = __ballot(l.skip[lane] != 0) != 0ull;
+  // Drain the logic phase's own loads/stores once, here: the loop's stores are
+  // inline asm the compiler cannot count, and without this it protects a
+  // register of an older store with a vmcnt(0) *inside* the loop, which would
+  // serialise every iteration behind all outstanding plane stores.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+  // (e, q) = the environment and the board dword this lane composes; both and
+  // every address derived from them advance incrementally -- no multiplies or
+  // divisions in the loop (v_mul_lo/_hi are quarter rate).
+  uint32_t e = 0, q = lane, voff = 4u * lane, eF = 0;
+  while (q >= (uint32_t)QW) { q -= QW; e += 1; voff += e_skew; eF += FWP; }  // boards narrower than 64 dwords
+#pragma unroll 1
+  for (int it = 0; it < QW; ++it) {
+    const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF;
+    q += WAVE; voff += 4u * WAVE;
+    while (q >= (uint32_t)QW) { q -= QW; e += 1; voff += e_skew; eF += FWP; }
+    if (any_skip && l.skip[e_now]) continue;
+    {
+    const uint32_t e = e_now, q = q_now, voff = voff_now, eF = eF_now;
+    // scalar base (pinned above) + 32-bit lane offset: one `global_store_dword
+    // voffset, data, sbase` per plane, no per-store address arithmetic
+    auto put = [&](uint8_t* plane_base, uint32_t v) {
+      if constexpr (SL != 0) {  // the static-shape instance keeps all nine bases in SGPRs
+        asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(plane_base));
+      }
+      else
+        *reinterpret_cast<uint32_t*>(plane_base + voff) = v;
+    };
     uint32_t d = l.backdrop4[q];
     uint32_t md[2], ms[NS], mb[NBS];
 #pragma unroll
     for (int dd = 0; dd < 2; ++dd) {
-      const uint32_t bits = (l.flat[(dd * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
+      const uint32_t bits = (l.flat[dd * WAVE * FWP + eF + (q >> 3)] >> ((q & 7) * 4)) & 0xFu;
       const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
-      md[dd] = (m01 << 8) - m01;  // 0x01 -> 0xFF per byte, without a quarter-rate multiply
+      uint32_t hi8 = m01 << 8;
+      asm("" : "+v"(hi8));  // keep LLVM from folding (x << 8) - x back into a quarter-rate x * 255
+      md[dd] = hi8 - m01;   // 0x01 -> 0xFF per byte
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -755,50 +802,38 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
       uni |= ms[s];
       d = (d & ~ms[s]) | (sch4[s] & ms[s]);
     }
-    const uint32_t o = q * 4;
-    put(o, d);
+    put(pb_board, d);
     if constexpr (UNOCC) {  // layers are the raw masks, the backdrop's included
 #pragma unroll
       for (int dd = 0; dd < 2; ++dd) {
-        const uint32_t bits = ((lds_raw + k.lds_flatraw)[(dd * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
+        const uint32_t bits = (flat_raw[dd * WAVE * FWP + eF + (q >> 3)] >> ((q & 7) * 4)) & 0xFu;
         const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
         md[dd] = (m01 << 8) - m01;
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const uint2 sd = reinterpret_cast<const uint2*>(lds_raw + k.lds_sdescraw)[s * WAVE + e];
+        const uint2 sd = sdesc_raw[s * WAVE + e];
         ms[s] = sd.x == q ? sd.y : 0u;
       }
       uni = 0;
     }
     // rendering.py:177-179 layer[c] = (board == c): by construction that is
     // the thing's own mask, or the backdrop's where no thing paints.
-    put(o + doff[0], md[0] & 0x01010101u);
-    put(o + doff[1], md[1] & 0x01010101u);
+    put(pb_d[0], md[0] & 0x01010101u);
+    put(pb_d[1], md[1] & 0x01010101u);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) put(o + soff[s], ms[s] & 0x01010101u);
+    for (int s = 0; s < NS; ++s) put(pb_s[s], ms[s] & 0x01010101u);
 #pragma unroll
     for (int i = 0; i < NBS; ++i) {
       if (!SL && i >= NB) break;
-      put(o + boff[i], mb[i] & ~uni);
+      put(pb_b[i], mb[i] & ~uni);
     }
-  };
-
-  // Each wave store covers 256 contiguous bytes of one plane of one or two
-  // environment records; all nine planes of a 64-dword span leave together.
-  const bool any_skip = __ballot(l.skip[lane] != 0) != 0ull;
-#pragma unroll 2
-  for (int it = 0; it < QW; ++it) {
-    const uint32_t f = (uint32_t)it * WAVE + lane;
-    const uint32_t e = SR ? f / (uint32_t)(SR * SC / 4) : (f * magic_q) >> 20;
-    const uint32_t q = f - e * QW;
-    if (any_skip && l.skip[e]) continue;
-    uint8_t* dst = blk + e * env_stride;
-    render(e, q, [&](uint32_t off, uint32_t v) { *reinterpret_cast<uint32_t*>(dst + off) = v; });
+    }
   }
   }  // render wave
   __syncthreads();  // swap buffers
   }  // rounds
+#undef FLAT
 }
 
 // ---------------------------------------------------------------------------
@@ -923,19 +958,25 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     if (idx < 0) return set_error(PCX_E_INVALID, "z_order names an unknown character");
     k.z_kind[z] = kind; k.z_idx[z] = idx; k.z_ch[z] = ch;
   }
+  for (int z = 0; z < t.n_things; ++z) {
+    if (k.z_kind[z] == 0) k.zpos_sprite[k.z_idx[z]] = z;
+    else if (k.z_idx[z] == 0) k.zpos_maze = z;
+    else k.zpos_cash = z;
+  }
   for (int s = 0; s < t.n_sprites; ++s) {
     bool back_imp = false;
     for (int i = 0; i < t.rows * t.cols; ++i) back_imp |= imp_has(s, t.backdrop[i]);
     k.relevant_backdrop[s] = back_imp;
-    uint32_t rel = 0;
+    uint32_t rel = 0, impz = 0;
     bool deeper_matters = back_imp;  // walking back to front
     for (int z = 0; z < t.n_things; ++z) {
-      int bit = k.z_kind[z] ? t.n_sprites + k.z_idx[z] : k.z_idx[z];
       bool mine = imp_has(s, k.z_ch[z]);
-      if (mine || deeper_matters) rel |= 1u << bit;
+      if (mine) impz |= 1u << z;
+      if (mine || deeper_matters) rel |= 1u << z;
       deeper_matters |= mine;
     }
     k.relevant[s] = rel;
+    k.imp_z[s] = impz;
   }
 
   // occlusion tables: which things are in front of each thing; layer planes
@@ -1025,7 +1066,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   k.FW = (k.cells + 31) / 32 + 1;
   // per-group render descriptors, double-buffered between the two waves
   const int buf0 = off;
-  k.lds_flat = off; off += 2 * k.FW * WAVE;
+  k.lds_flat = off; off += 2 * (k.FW | 1) * WAVE;
   off = (off + 1) & ~1;  // uint2 alignment
   k.lds_sdesc = off; off += 2 * k.NS * WAVE;
   k.lds_skip = off; off += WAVE;
@@ -1034,7 +1075,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   off += k.lds_buf_words;  // second buffer
   k.lds_cmask = off; off += (k.CW ? k.CW : 1) * WAVE;
   k.lds_bdmask = off; off += k.n_bchars * k.QW;
-  k.lds_flatraw = off; if (unoccluded_) off += 2 * k.FW * WAVE;
+  k.lds_flatraw = off; if (unoccluded_) off += 2 * (k.FW | 1) * WAVE;
   off = (off + 1) & ~1;
   k.lds_sdescraw = off; if (unoccluded_) off += 2 * k.NS * WAVE;
   k.lds_words = off;
