@@ -279,6 +279,62 @@ int pcx_cropper_buffers(pcx_cropper* c, uint8_t** planes_dev,
  * cropping.py:175-183).  Synchronous. */
 int pcx_cropper_errors(pcx_cropper* c, uint8_t* errors_host);
 
+/* ------------------------------------------------------------------------ */
+/* Observation post-processors: rendering.py:304-661.  They read a planes array
+ * (an engine's or a cropper's) and write their own device output.           */
+
+typedef struct pcx_planes_view {
+  const uint8_t* planes;  /* [batch][1 + n_chars][pitch], plane 0 = board    */
+  int64_t batch;
+  int32_t rows, cols, pitch, n_chars;
+  uint8_t chars[PCX_MAX_CHARS];
+} pcx_planes_view;
+
+int pcx_engine_planes_view(pcx_engine* e, pcx_planes_view* out);
+int pcx_cropper_planes_view(pcx_cropper* c, pcx_planes_view* out);
+
+enum pcx_post_kind {
+  PCX_POST_TO_ARRAY = 1,       /* rendering.ObservationToArray            :409-542 */
+  PCX_POST_FEATURE_ARRAY = 2,  /* rendering.ObservationToFeatureArray     :545-661 */
+  PCX_POST_REPAINT = 3         /* rendering.ObservationCharacterRepainter :304-406 */
+};
+enum pcx_post_dtype { PCX_U8 = 1, PCX_I32 = 2, PCX_F32 = 3, PCX_I64 = 4, PCX_F64 = 5 };
+
+#define PCX_POST_MAX_DEPTH 32
+
+typedef struct pcx_post_desc {
+  int32_t kind;
+  int32_t dtype;   /* TO_ARRAY: element type of the output (FEATURE_ARRAY is f32,
+                      REPAINT is u8)                                          */
+  int32_t depth;   /* TO_ARRAY: length of the value vectors (1 for scalars);
+                      FEATURE_ARRAY: number of layers; REPAINT: output chars  */
+  /* TO_ARRAY: lut[d][ch] = d-th component of value_mapping[chr(ch)], as the
+   * raw little-endian bytes of `dtype` in a 64-bit cell; mapped[ch] != 0 iff
+   * chr(ch) is a key.  REPAINT: lut[0][ch] = repainted character.            */
+  uint64_t lut[PCX_POST_MAX_DEPTH][128];
+  uint8_t mapped[128];
+  /* FEATURE_ARRAY: the characters whose layers are stacked (a character the
+   * observation does not have yields zeros).  REPAINT: the output layer
+   * characters, in plane order.                                              */
+  uint8_t chars[PCX_POST_MAX_DEPTH];
+  /* output element (d, r, c) of environment b lives at index
+   * b * depth * rows * cols + d * stride[0] + r * stride[1] + c * stride[2]
+   * (np.transpose(..., permute) of the reference, made contiguous).          */
+  int64_t stride[3];
+} pcx_post_desc;
+
+typedef struct pcx_post pcx_post;
+
+int pcx_post_create(const pcx_planes_view* src, const pcx_post_desc* d, int device_id, pcx_post** out);
+void pcx_post_destroy(pcx_post* p);
+int pcx_post_run(pcx_post* p, void* stream);
+/* out_dev: TO_ARRAY/FEATURE_ARRAY [batch][depth*rows*cols] elements; REPAINT a
+ * planes array [batch][1 + depth][rows*cols] (pitch == rows*cols). */
+int pcx_post_output(pcx_post* p, void** out_dev, uint64_t* bytes);
+/* Host copy of uint8[batch]: 1 where a board character had no mapping
+ * (rendering.py:503-507 RuntimeError).  Synchronous. */
+int pcx_post_errors(pcx_post* p, uint8_t* errors_host);
+
 #ifdef __cplusplus
 }
 #endif

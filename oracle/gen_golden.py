@@ -158,6 +158,36 @@ def F(top_left, rows, cols, pad_char=None):
   return dict(kind='fixed', top_left=list(top_left), rows=rows, cols=cols, pad_char=pad_char)
 
 
+POST = {  # keyed by trace name: post-processor specs (JSON-able)
+    'marauders': [
+        dict(kind='repaint', mapping={'a': '^', 'b': '^', 'c': '^', 'd': '^', 'y': '|', 'z': '|'}),
+        dict(kind='to_array', mapping={' ': [0, 0, 0], 'B': [400, 50, 30], 'P': [0, 999, 0], 'X': [999, 999, 999],
+                                       'a': [0, 999, 999], 'b': [0, 999, 999], 'c': [0, 999, 999],
+                                       'd': [0, 999, 999], 'y': [7, 8, 9], 'z': [7, 8, 9]},
+             dtype='float32', permute=[1, 2, 0]),
+        dict(kind='to_array', mapping={' ': 0, 'B': 1, 'P': 2, 'X': 3, 'a': 4, 'b': 4, 'c': 4, 'd': 4, 'y': 5, 'z': 5},
+             dtype='uint8', permute=[1, 0]),
+        dict(kind='features', layers='PXBq', permute=[2, 0, 1]),
+    ],
+    'warehouse_L1': [
+        dict(kind='repaint', mapping={c: 'x' for c in '0123456789'}),
+        dict(kind='features', layers='P_#12', permute=None),
+        dict(kind='to_array', mapping={c: [i, 2 * i] for i, c in enumerate(' #._1234567PX')}, dtype='int32',
+             permute=None),
+    ],
+}
+POST_EVERY = 8  # frames between recorded post-processor outputs
+
+
+def make_reference_post(spec):
+  from pycolab import rendering
+  if spec['kind'] == 'repaint':
+    return rendering.ObservationCharacterRepainter(dict(spec['mapping']))
+  if spec['kind'] == 'features':
+    return rendering.ObservationToFeatureArray(list(spec['layers']), permute=spec['permute'])
+  return rendering.ObservationToArray(dict(spec['mapping']), dtype=np.dtype(spec['dtype']), permute=spec['permute'])
+
+
 CROPPERS = {  # keyed by trace name
 
     'scrolly_maze_L0': [S(5, 11, 'P', ' ', (1, 2)), S(7, 9, 'aP', None, (2, 3)), F((-2, -3), 8, 20, '#'),
@@ -176,6 +206,8 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
   boards, rewards, rsets, discounts, dones, sprites, layers = [], [], [], [], [], [], []
   specs = CROPPERS.get(name, [])
   crops = [[] for _ in specs]
+  post_specs = POST.get(name, [])
+  posts = [[] for _ in post_specs]
   actions = np.zeros((T, E), np.int32)
   chars = sprite_chars = None
   for e in range(E):
@@ -195,6 +227,20 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
           assert np.array_equal(out.layers[c], out.board == ord(c)), (name, i, c)
         env_crops[i].append(out.board.copy())
 
+    post_objs = [make_reference_post(sp) for sp in post_specs]
+    env_posts = [[] for _ in post_specs]
+
+    def post_all(obs):
+      for i, (sp, po) in enumerate(zip(post_specs, post_objs)):
+        out = po(obs)
+        if sp['kind'] == 'repaint':
+          keys = sorted(out.layers)
+          for c in keys:
+            assert np.array_equal(out.layers[c], out.board == ord(c))
+          env_posts[i].append(out.board.copy())
+        else:
+          env_posts[i].append(np.array(out).copy())
+
     for cr in croppers:
       cr.set_engine(game)
     obs, r, d = game.its_showtime()
@@ -204,6 +250,7 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
       sprite_chars = template_sprite_chars(template_name)
     rec.append(record(obs, r, d, game, chars, sprite_chars))
     crop_all(obs)
+    post_all(obs)
     for t in range(T):
       if game.game_over:
         game = make_game()
@@ -217,6 +264,10 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
         obs, r, d = game.play(None if a == NONE else (ref_action(a) if ref_action else a))
       rec.append(record(obs, r, d, game, chars, sprite_chars))
       crop_all(obs)
+      if (t + 1) % POST_EVERY == 0:
+        post_all(obs)
+    for i in range(len(post_specs)):
+      posts[i].append(env_posts[i])
     for i in range(len(specs)):
       crops[i].append(env_crops[i])
     boards.append([x[0] for x in rec]); rewards.append([x[1] for x in rec])
@@ -229,6 +280,10 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
   import json
   extra = {'crop_%d' % i: sw(crops[i], np.uint8) for i in range(len(specs))}
   extra['crop_specs'] = np.frombuffer(json.dumps(specs).encode(), np.uint8)
+  for i in range(len(post_specs)):
+    extra['post_%d' % i] = np.ascontiguousarray(np.swapaxes(np.array(posts[i]), 0, 1))  # [frames, E, ...]
+  extra['post_specs'] = np.frombuffer(json.dumps(post_specs).encode(), np.uint8)
+  extra['post_every'] = np.array([POST_EVERY])
   if unoccluded:
     extra['layers'] = sw(layers, np.uint8)  # [T+1, E, L, R, C]
   np.savez_compressed(

@@ -89,6 +89,22 @@ class CropperDesc(ctypes.Structure):
               ('saccade', c_i32)]
 
 
+POST_TO_ARRAY, POST_FEATURE_ARRAY, POST_REPAINT = 1, 2, 3
+U8, I32, F32, I64, F64 = 1, 2, 3, 4, 5
+POST_MAX_DEPTH = 32
+
+
+class PlanesView(ctypes.Structure):
+  _fields_ = [('planes', ctypes.c_void_p), ('batch', c_i64), ('rows', c_i32), ('cols', c_i32),
+              ('pitch', c_i32), ('n_chars', c_i32), ('chars', c_u8 * MAX_CHARS)]
+
+
+class PostDesc(ctypes.Structure):
+  _fields_ = [('kind', c_i32), ('dtype', c_i32), ('depth', c_i32),
+              ('lut', (c_u64 * 128) * POST_MAX_DEPTH), ('mapped', c_u8 * 128),
+              ('chars', c_u8 * POST_MAX_DEPTH), ('stride', c_i64 * 3)]
+
+
 # Every symbol include/pcx.h declares: (name, restype, argtypes).
 _VP = ctypes.c_void_p
 SYMBOLS = [
@@ -117,6 +133,13 @@ SYMBOLS = [
     ('pcx_cropper_crop', c_i32, [_VP, _VP]),
     ('pcx_cropper_buffers', c_i32, [_VP, ctypes.POINTER(_VP), ctypes.POINTER(_VP)]),
     ('pcx_cropper_errors', c_i32, [_VP, _VP]),
+    ('pcx_engine_planes_view', c_i32, [_VP, ctypes.POINTER(PlanesView)]),
+    ('pcx_cropper_planes_view', c_i32, [_VP, ctypes.POINTER(PlanesView)]),
+    ('pcx_post_create', c_i32, [ctypes.POINTER(PlanesView), ctypes.POINTER(PostDesc), c_i32, ctypes.POINTER(_VP)]),
+    ('pcx_post_destroy', None, [_VP]),
+    ('pcx_post_run', c_i32, [_VP, _VP]),
+    ('pcx_post_output', c_i32, [_VP, ctypes.POINTER(_VP), ctypes.POINTER(c_u64)]),
+    ('pcx_post_errors', c_i32, [_VP, _VP]),
 ]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpcx.so')

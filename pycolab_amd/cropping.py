@@ -102,10 +102,18 @@ class ObservationCropper(object):
   def _observation(self, host):
     chars = self._engine.template.chars
     if self._engine.batch == 1:
-      return rendering.Observation(
+      obs = rendering.Observation(
           board=host[0, 0], layers={chr(ch): host[0, 1 + k].astype(np.bool_) for k, ch in enumerate(chars)})
-    return rendering.Observation(
-        board=host[:, 0], layers={chr(ch): host[:, 1 + k] for k, ch in enumerate(chars)})
+    else:
+      obs = rendering.Observation(
+          board=host[:, 0], layers={chr(ch): host[:, 1 + k] for k, ch in enumerate(chars)})
+    obs._source = self
+    return obs
+
+  def _planes_view(self):
+    view = N.PlanesView()
+    N.check(N.lib().pcx_cropper_planes_view(self._native, ctypes.byref(view)))
+    return view, self._engine._device_id
 
 
 class FixedCropper(ObservationCropper):

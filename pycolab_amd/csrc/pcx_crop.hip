@@ -240,6 +240,15 @@ int pcx_cropper_buffers(pcx_cropper* c, uint8_t** planes_dev, int32_t** corner_d
   return 0;
 }
 
+int pcx_cropper_planes_view(pcx_cropper* c, pcx_planes_view* out) {
+  if (!c || !out) return set_error(PCX_E_INVALID, "pcx_cropper_planes_view: bad arguments");
+  memset(out, 0, sizeof *out);
+  out->planes = c->dense.ptr; out->batch = c->e->batch; out->rows = c->p.rows; out->cols = c->p.cols;
+  out->pitch = c->p.rows * c->p.cols; out->n_chars = c->p.L;
+  memcpy(out->chars, c->e->t.chars, PCX_MAX_CHARS);
+  return 0;
+}
+
 int pcx_cropper_errors(pcx_cropper* c, uint8_t* errors_host) {
   if (!c || !errors_host) return set_error(PCX_E_INVALID, "pcx_cropper_errors: bad arguments");
   PCX_HIP(hipSetDevice(c->e->device));

@@ -297,13 +297,22 @@ class Engine(object):
       p = self.planes_view(host=True)[0]
       layers = {chr(c): p[1 + k].astype(np.bool_) for k, c in enumerate(L)}
       reward = int(sc['reward'][0]) if sc['reward_set'][0] else None
-      return rendering.Observation(board=p[0], layers=layers), reward, float(sc['discount'][0])
+      return self._tag(rendering.Observation(board=p[0], layers=layers)), reward, float(sc['discount'][0])
     arr = self.planes_view()
     layers = {chr(c): arr[:, 1 + k] for k, c in enumerate(L)}
     pick = lambda k: (self._bufs[k].tensor if self._bufs[k].tensor is not None
                       else self._bufs[k].numpy())
-    return (rendering.Observation(board=arr[:, 0], layers=layers),
+    return (self._tag(rendering.Observation(board=arr[:, 0], layers=layers)),
             pick('reward'), pick('discount'))
+
+  def _tag(self, observation):
+    observation._source = self
+    return observation
+
+  def _planes_view(self):
+    view = N.PlanesView()
+    N.check(N.lib().pcx_engine_planes_view(self._native, ctypes.byref(view)))
+    return view, self._device_id
 
   # ---------------------------------------------------------------- properties
   @property

@@ -1,12 +1,219 @@
-"""Observation containers (reference: rendering.py:28-63).
+"""Observations and observation post-processors.
 
-`Observation` is the reference's namedtuple.  In batched mode `board` has
-shape [B, rows, cols] and every `layers[c]` has shape [B, rows, cols]; all of
-them are zero-copy views of the engine's `planes` array
-([B, 1 + n_chars, rows, cols] uint8 in HBM), valid until the next step --
-the same aliasing rule as the reference.
+`Observation` is the reference's namedtuple (rendering.py:28-63).  In batched
+mode `board` has shape [B, rows, cols] and every `layers[c]` has shape
+[B, rows, cols]; all are zero-copy views of a planes array in HBM
+([B, 1 + n_chars, pitch] uint8), valid until the next step -- the
+reference's own aliasing rule.
+
+`ObservationToArray`, `ObservationToFeatureArray` and
+`ObservationCharacterRepainter` keep the reference's constructors
+(rendering.py:304-661) and run as streaming epilogue kernels
+(csrc/pcx_post.hip) over the planes the engine or a cropper just wrote.
+They accept observations produced by this package (those know where their
+planes live); anything else is rejected -- there is no host path.
 """
 
 import collections
+import ctypes
 
-Observation = collections.namedtuple('Observation', ['board', 'layers'])
+import numpy as np
+
+from pycolab_amd import _native as N
+from pycolab_amd import device as dev
+
+
+class Observation(collections.namedtuple('Observation', ['board', 'layers'])):
+  """board + layers; instances made by engines/croppers remember their source."""
+  _source = None
+
+
+_DTYPES = {'uint8': N.U8, 'int32': N.I32, 'float32': N.F32, 'int64': N.I64, 'float64': N.F64}
+
+
+class _Post(object):
+  """One device post-processor bound to one planes source."""
+
+  def __init__(self, source, desc, out_dtype, out_shape):
+    self.source = source
+    self.view, self.device_id = source._planes_view()
+    self.desc = desc
+    self.out_dtype, self.out_shape = np.dtype(out_dtype), tuple(out_shape)
+    handle = ctypes.c_void_p()
+    N.check(N.lib().pcx_post_create(ctypes.byref(self.view), ctypes.byref(desc), self.device_id, ctypes.byref(handle)))
+    self.handle = handle
+
+  def run(self):
+    N.check(N.lib().pcx_post_run(self.handle, dev.current_stream(self.device_id)))
+    ptr, nbytes = ctypes.c_void_p(), N.c_u64()
+    N.check(N.lib().pcx_post_output(self.handle, ctypes.byref(ptr), ctypes.byref(nbytes)))
+    host = np.empty(self.out_shape, self.out_dtype)
+    assert host.nbytes == nbytes.value, (host.nbytes, nbytes.value)
+    dev.synchronize(self.device_id)
+    N.check(N.lib().pcx_memcpy_d2h(host.ctypes.data, ptr, host.nbytes))
+    return host
+
+  def errors(self):
+    errs = np.empty((int(self.view.batch),), np.uint8)
+    N.check(N.lib().pcx_post_errors(self.handle, errs.ctypes.data))
+    return errs
+
+  def __del__(self):
+    try:
+      N.lib().pcx_post_destroy(self.handle)
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+
+def _source_of(observation):
+  source = getattr(observation, '_source', None)
+  if source is None:
+    raise TypeError('this post-processor runs on the device and needs an Observation returned by a '
+                    'pycolab_amd Engine or cropper')
+  return source
+
+
+def _strides(shape3, permute):
+  """Element strides of (d, r, c) in the contiguous array whose axes are
+  `permute` of (d, r, c) -- np.transpose(result, permute) made contiguous."""
+  permute = (0, 1, 2) if permute is None else tuple(permute)
+  out_shape = [shape3[a] for a in permute]
+  out_strides = [int(np.prod(out_shape[i + 1:])) for i in range(3)]
+  stride = [0, 0, 0]
+  for out_axis, a in enumerate(permute):
+    stride[a] = out_strides[out_axis]
+  return stride, out_shape
+
+
+class ObservationToArray(object):
+  """board characters -> values or value vectors (rendering.py:409-542)."""
+
+  def __init__(self, value_mapping, dtype=None, permute=None):
+    self._value_mapping = value_mapping
+    first = next(iter(value_mapping.values()))
+    self._dtype = np.dtype(dtype if dtype is not None else np.array(first).dtype)
+    try:
+      self._depth = len(first)
+      self._is_3d = True
+    except TypeError:
+      self._depth = 1
+      self._is_3d = False
+    self._permute = tuple(permute) if permute is not None else None
+    if permute is not None:
+      if self._is_3d and set(permute) != {0, 1, 2}:
+        raise ValueError('When the value mapping contains 1-D vectors, the '
+                         'permute argument to the ObservationToArray '
+                         'constructor must be a list or tuple containing some '
+                         'permutation of the integers 0, 1, and 2.')
+      elif not self._is_3d and set(permute) != {0, 1}:
+        raise ValueError('When the value mapping contains scalars, the permute '
+                         'argument to the ObservationToArray constructor must '
+                         'be a list or tuple containing some permutation of '
+                         'the integers 0 and 1.')
+    if self._dtype.name not in _DTYPES:
+      raise NotImplementedError('ObservationToArray on the device supports dtypes {}'.format(sorted(_DTYPES)))
+    if self._depth > N.POST_MAX_DEPTH:
+      raise NotImplementedError('value vectors longer than {}'.format(N.POST_MAX_DEPTH))
+    self._post = None
+
+  def __call__(self, observation):
+    source = _source_of(observation)
+    if self._post is None or self._post.source is not source:
+      view, _ = source._planes_view()
+      R, C = view.rows, view.cols
+      d = N.PostDesc()
+      d.kind, d.dtype, d.depth = N.POST_TO_ARRAY, _DTYPES[self._dtype.name], self._depth
+      for key, value in self._value_mapping.items():
+        ch = ord(key)
+        if ch > 127:
+          continue
+        d.mapped[ch] = 1
+        comps = np.atleast_1d(np.array(value)).astype(self._dtype)
+        for i in range(self._depth):
+          d.lut[i][ch] = int.from_bytes(comps[i].tobytes().ljust(8, b'\0'), 'little')
+      if self._is_3d:
+        perm3 = self._permute
+      else:  # (rows, cols) permutation of the 2-D result
+        perm3 = None if self._permute is None else (0,) + tuple(1 + a for a in self._permute)
+      stride, shape = _strides((self._depth, R, C), perm3)
+      d.stride[0], d.stride[1], d.stride[2] = stride
+      if not self._is_3d:
+        shape = shape[1:]
+      self._post = _Post(source, d, self._dtype, (int(view.batch),) + tuple(shape))
+    out = self._post.run()
+    if self._post.errors().any():
+      raise RuntimeError(
+          'This ObservationToArray only knows array values for the '
+          'characters {}, but it received an observation with a character '
+          'not in that set'.format(str(''.join(self._value_mapping.keys()))))
+    return out[0] if out.shape[0] == 1 else out
+
+
+class ObservationToFeatureArray(object):
+  """float32 stack of selected layers (rendering.py:545-661)."""
+
+  def __init__(self, layers, permute=None):
+    self._layers = layers
+    self._depth = len(layers)
+    self._permute = tuple(permute) if permute is not None else None
+    if permute is not None and sorted(permute) != [0, 1, 2]:
+      raise ValueError('The permute argument to the ObservationToFeatureArray '
+                       'constructor must be a list or tuple containing some '
+                       'permutation of the integers 0, 1, and 2.')
+    if self._depth > N.POST_MAX_DEPTH:
+      raise NotImplementedError('more than {} layers'.format(N.POST_MAX_DEPTH))
+    self._post = None
+
+  def __call__(self, observation):
+    if not any(l in observation.layers for l in self._layers):
+      raise RuntimeError(
+          'The layers argument to this ObservationToFeatureArray, {}, has no '
+          'entry that refers to an actual feature in the input observation. '
+          'Actual features in the observation are {}.'.format(
+              repr(self._layers), repr(''.join(sorted(observation.layers)))))
+    source = _source_of(observation)
+    if self._post is None or self._post.source is not source:
+      view, _ = source._planes_view()
+      d = N.PostDesc()
+      d.kind, d.dtype, d.depth = N.POST_FEATURE_ARRAY, N.F32, self._depth
+      for i, ch in enumerate(self._layers):
+        d.chars[i] = ord(ch) if ord(ch) < 256 else 255
+      stride, shape = _strides((self._depth, view.rows, view.cols), self._permute)
+      d.stride[0], d.stride[1], d.stride[2] = stride
+      self._post = _Post(source, d, np.float32, (int(view.batch),) + tuple(shape))
+    out = self._post.run()
+    return out[0] if out.shape[0] == 1 else out
+
+
+class ObservationCharacterRepainter(object):
+  """Repaints characters through a fixed mapping (rendering.py:304-406)."""
+
+  def __init__(self, character_mapping):
+    self._character_mapping = character_mapping
+    self._post = None
+    self._out_chars = None
+
+  def __call__(self, original_observation):
+    source = _source_of(original_observation)
+    if self._post is None or self._post.source is not source:
+      view, _ = source._planes_view()
+      self._out_chars = sorted((set(original_observation.layers) - set(self._character_mapping))
+                               .union(self._character_mapping.values()))
+      d = N.PostDesc()
+      d.kind, d.dtype, d.depth = N.POST_REPAINT, N.U8, len(self._out_chars)
+      for ch in range(128):
+        d.lut[0][ch] = ch
+        d.mapped[ch] = 1
+      for k, v in self._character_mapping.items():
+        d.lut[0][ord(k)] = ord(v)
+      for i, ch in enumerate(self._out_chars):
+        d.chars[i] = ord(ch)
+      self._post = _Post(source, d, np.uint8,
+                         (int(view.batch), 1 + len(self._out_chars), view.rows, view.cols))
+    planes = self._post.run()
+    if planes.shape[0] == 1:
+      obs = Observation(board=planes[0, 0],
+                        layers={c: planes[0, 1 + i].astype(np.bool_) for i, c in enumerate(self._out_chars)})
+    else:
+      obs = Observation(board=planes[:, 0], layers={c: planes[:, 1 + i] for i, c in enumerate(self._out_chars)})
+    return obs

@@ -1,0 +1,111 @@
+"""Observation post-processors (rendering.py:304-661): the numpy oracle (CPU)
+and the device kernels (GPU) against outputs of the reference's own classes
+recorded in the golden traces."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import postprocess as opost
+from pycolab_amd import rendering
+from tests import helpers
+
+POSTED = ['marauders', 'warehouse_L1']
+
+
+def specs_of(trace):
+  return json.loads(bytes(trace['post_specs']).decode()), int(trace['post_every'][0])
+
+
+def frames_of(T, every):
+  return [0] + [t for t in range(1, T + 1) if t % every == 0]
+
+
+def make_post(spec):
+  if spec['kind'] == 'repaint':
+    return rendering.ObservationCharacterRepainter(dict(spec['mapping']))
+  if spec['kind'] == 'features':
+    return rendering.ObservationToFeatureArray(list(spec['layers']), permute=spec['permute'])
+  return rendering.ObservationToArray(dict(spec['mapping']), dtype=np.dtype(spec['dtype']), permute=spec['permute'])
+
+
+@pytest.mark.parametrize('name', POSTED)
+def test_oracle_postprocessors_match_reference(name):
+  tr = helpers.load_trace(name)
+  specs, every = specs_of(tr)
+  chars = [chr(c) for c in tr['chars']]
+  T, E = tr['actions'].shape
+  for fi, t in enumerate(frames_of(T, every)):
+    for e in range(0, E, 5):
+      board = tr['boards'][t, e]
+      layers = {c: board == ord(c) for c in chars}
+      for i, sp in enumerate(specs):
+        want = tr['post_%d' % i][fi, e]
+        if sp['kind'] == 'repaint':
+          got, _ = opost.repaint(board, chars, sp['mapping'])
+        elif sp['kind'] == 'features':
+          got = opost.feature_array(layers, list(sp['layers']), board.shape, sp['permute'])
+        else:
+          got = opost.to_array(board, sp['mapping'], sp['dtype'], sp['permute'])
+        assert got.dtype == want.dtype and got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+
+
+def test_constructor_guards():
+  with pytest.raises(ValueError):
+    rendering.ObservationToArray({'a': [1, 2]}, permute=(0, 1))
+  with pytest.raises(ValueError):
+    rendering.ObservationToArray({'a': 1}, permute=(0, 1, 2))
+  with pytest.raises(ValueError):
+    rendering.ObservationToFeatureArray('ab', permute=(0, 1))
+  with pytest.raises(TypeError):   # needs an observation that knows its planes
+    rendering.ObservationToFeatureArray('ab')(rendering.Observation(board=np.zeros((2, 2)), layers={'a': 0}))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', POSTED)
+def test_device_postprocessors_match_reference(name):
+  from pycolab_amd.engine import Engine
+  tr = helpers.load_trace(name)
+  specs, every = specs_of(tr)
+  t = helpers.load_template(tr['template'])
+  T, E = tr['actions'].shape
+  eng = Engine.from_template(t, batch=E, auto_reset=True, seed=helpers.GOLDEN_RNG_SEED)
+  posts = [make_post(sp) for sp in specs]
+  obs = eng.its_showtime()[0]
+  fi = 0
+  for step in range(T + 1):
+    if step:
+      obs = eng.play(tr['actions'][step - 1])[0]
+    if step == 0 or step % every == 0:
+      for i, (sp, po) in enumerate(zip(specs, posts)):
+        want = tr['post_%d' % i][fi]
+        out = po(obs)
+        if sp['kind'] == 'repaint':
+          np.testing.assert_array_equal(np.asarray(out.board), want)
+          for c, layer in out.layers.items():
+            np.testing.assert_array_equal(np.asarray(layer).astype(bool), want == ord(c))
+          assert sorted(out.layers) == sorted((set(chr(c) for c in tr['chars']) - set(sp['mapping'])) | set(sp['mapping'].values()))
+        else:
+          out = np.asarray(out)
+          assert out.dtype == want.dtype and out.shape == want.shape, (out.shape, want.shape)
+          np.testing.assert_array_equal(out, want)
+      fi += 1
+
+
+@pytest.mark.gpu
+def test_device_to_array_unmapped_character_raises_and_croppers_chain():
+  from pycolab_amd import cropping
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('warehouse_L0')
+  eng = Engine.from_template(t, batch=3)
+  crop = cropping.FixedCropper((1, 1), 4, 5, pad_char='#')
+  crop.set_engine(eng)
+  obs = eng.its_showtime()[0]
+  with pytest.raises(RuntimeError):
+    rendering.ObservationToArray({' ': 0, '#': 1})(obs)     # '.' and others unmapped
+  # post-processing a cropped observation uses the cropper's planes
+  cropped = crop.crop(obs)
+  feats = rendering.ObservationToFeatureArray('#P')(cropped)
+  assert feats.shape == (3, 2, 4, 5) and feats.dtype == np.float32
+  np.testing.assert_array_equal(feats[:, 0], (np.asarray(cropped.board) == ord('#')).astype(np.float32))
