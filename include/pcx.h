@@ -60,8 +60,9 @@ enum pcx_game {
   PCX_GAME_MARAUDERS = 2,    /* examples/extraterrestrial_marauders.py      */
   PCX_GAME_WAREHOUSE = 3,    /* examples/warehouse_manager.py               */
   PCX_GAME_HELLO_WORLD = 4,  /* examples/hello_world.py                     */
-  PCX_GAME_WALKERS = 5       /* prefab-only games: MazeWalker/Scrolly with
+  PCX_GAME_WALKERS = 5,      /* prefab-only games: MazeWalker/Scrolly with
                                 action->motion tables (tests/test_things.py) */
+  PCX_GAME_BETTER_SCROLLY = 6 /* examples/better_scrolly_maze.py             */
 };
 
 /* Per-entity device program ids (entity `update()` bodies). */
@@ -85,6 +86,10 @@ enum pcx_program {
   /* examples/hello_world.py */
   PCX_PROG_HW_ROLLING = 40,
   PCX_PROG_HW_SLIDING = 41,
+  /* examples/better_scrolly_maze.py */
+  PCX_PROG_BS_PLAYER = 60,    /* PlayerSprite.update    :258-272 */
+  PCX_PROG_BS_PATROLLER = 61, /* PatrollerSprite.update :284-301 */
+  PCX_PROG_BS_CASH = 62,      /* CashDrape.update       :311-320 */
   /* prefab-only entities driven by an action->motion table */
   PCX_PROG_WALKER = 50,  /* MazeWalker subclass: action a -> motion table  */
   PCX_PROG_SCROLLY = 51, /* Scrolly subclass: action a -> motion table     */

@@ -310,6 +310,15 @@ def main():
     run('warehouse_L%d' % level, lambda: warehouse_manager.make_game(level),
         E=32, T=192, n_ordinary=5, quit_action=5, seed=17 + level,
         template_name='warehouse_L%d' % level)
+  from pycolab.examples import better_scrolly_maze as bsm
+  for level in (0, 1, 2):
+    name = 'better_scrolly_maze_L%d' % level
+    # the example's own make_croppers(level) (better_scrolly_maze.py:224-247), as specs
+    CROPPERS[name] = [S(10, 30, 'P', None, (2, 3), list(bsm.STARTER_OFFSET[level])),
+                      S(7, 10, 'c', ' ', (None, 3)),
+                      F(bsm.TEASER_CORNER[level], 12, 20, ' ')]
+    run(name, lambda: bsm.make_game(level), E=12, T=160, n_ordinary=5, quit_action=5, seed=61 + level,
+        template_name=name)
   run('hello_world', hello_world.make_game, E=16, T=96, n_ordinary=4, quit_action=4, seed=27,
       template_name='hello_world')
   # prefab-only scenarios built from the reference's own test entities

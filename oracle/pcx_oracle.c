@@ -466,6 +466,15 @@ static void prog_sm_cash(ox_ctx* x, int di) {
   else if (x->action == 5) plot_terminate(&env->plot, 0.0f); /* :363-364 */
 }
 
+/* ---- examples/better_scrolly_maze.py ----------------------------------------- */
+
+/* better_scrolly_maze.py:258-272 PlayerSprite.update */
+static void prog_bs_player(ox_ctx* x, int id) {
+  int m[2];
+  if (sm_motion(x->action, m)) mw_move(x->e, x->env, id, x->board, m[0], m[1]);
+  if (x->action == 5) plot_terminate(&x->env->plot, 0.0f);
+}
+
 /* ---- examples/warehouse_manager.py ------------------------------------------ */
 
 /* numpy layers[c][r, col] with Python index rules */
@@ -479,6 +488,41 @@ static int layer_at(ox_ctx* x, int ch, int r, int c) {
   if (err) { x->env->error |= err; return 0; }
   return env_layer(e, x->b, k)[r * e->t.cols + c];
 }
+
+/* layers[ch][r, c] for any character of the game (backdrop ones included) */
+static int layer_char_at(ox_ctx* x, int ch, int r, int c);
+
+/* better_scrolly_maze.py:284-301 PatrollerSprite.update */
+static void prog_bs_patroller(ox_ctx* x, int id) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_sprite* s = &env->sprites[id];
+  if (env->plot.frame % 2) { mw_move(e, env, id, x->board, 0, 0); return; }
+  int row = s->row, col = s->col;
+  if (layer_char_at(x, '#', row, col - 1)) s->var[0] = 1;
+  if (layer_char_at(x, '#', row, col + 1)) s->var[0] = 0;
+  mw_move(e, env, id, x->board, 0, s->var[0] ? 1 : -1);
+  const ox_sprite* P = &env->sprites[thing_id(e, 'P')];
+  if (s->row == P->row && s->col == P->col) plot_terminate(&env->plot, 0.0f);
+}
+
+/* better_scrolly_maze.py:311-320 CashDrape.update */
+static void prog_bs_cash(ox_ctx* x, int di) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_drape* d = &env->drapes[di];
+  const ox_sprite* P = &env->sprites[thing_id(e, 'P')];
+  uint8_t* cell = &d->curtain[P->row * e->t.cols + P->col];
+  if (*cell) {
+    plot_add_reward(&env->plot, 100);
+    *cell = 0;
+    int any = 0;
+    for (int i = 0; i < cells(e); ++i) any |= d->curtain[i];
+    if (!any) plot_terminate(&env->plot, 0.0f);
+  }
+}
+
+static int layer_char_at(ox_ctx* x, int ch, int r, int c) { return layer_at(x, ch, r, c); }
 
 /* warehouse_manager.py:214-226 BoxSprite.update */
 static void prog_wm_box(ox_ctx* x, int id) {
@@ -720,6 +764,9 @@ static int run_program(ox_ctx* x, int id) {
     case PCX_PROG_SM_PATROLLER: prog_sm_patroller(x, id); break;
     case PCX_PROG_SM_MAZE: prog_sm_maze(x, di); break;
     case PCX_PROG_SM_CASH: prog_sm_cash(x, di); break;
+    case PCX_PROG_BS_PLAYER: prog_bs_player(x, id); break;
+    case PCX_PROG_BS_PATROLLER: prog_bs_patroller(x, id); break;
+    case PCX_PROG_BS_CASH: prog_bs_cash(x, di); break;
     case PCX_PROG_WM_BOX: prog_wm_box(x, id); break;
     case PCX_PROG_WM_JUDGE: prog_wm_judge(x, di); break;
     case PCX_PROG_WM_PLAYER: prog_wm_player(x, id); break;
@@ -789,7 +836,8 @@ static void env_init(pcxo_engine* e, int64_t b) {
     memset(s, 0, sizeof *s);
     s->row = d->row; s->col = d->col; s->visible = d->visible;
     s->vrow = d->vrow; s->vcol = d->vcol; s->prior_visible = d->prior_visible;
-    if (d->program == PCX_PROG_SM_PATROLLER) s->var[0] = d->param[0]; /* _moving_east, scrolly_maze.py:282 */
+    if (d->program == PCX_PROG_SM_PATROLLER || d->program == PCX_PROG_BS_PATROLLER)
+      s->var[0] = d->param[0]; /* _moving_east, scrolly_maze.py:282 / better_scrolly_maze.py:282 */
   }
   for (int i = 0; i < e->t.n_drapes; ++i) {
     const pcx_drape_desc* d = &e->t.drapes[i];

@@ -22,6 +22,7 @@ ACTION_NONE = -1
 OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_STATE = 0, -1, -2, -3, -4
 
 GAME_SCROLLY_MAZE, GAME_MARAUDERS, GAME_WAREHOUSE, GAME_HELLO_WORLD, GAME_WALKERS = 1, 2, 3, 4, 5
+GAME_BETTER_SCROLLY = 6
 
 PROG_NONE = 0
 PROG_SM_PLAYER, PROG_SM_PATROLLER, PROG_SM_MAZE, PROG_SM_CASH = 10, 11, 12, 13
@@ -29,6 +30,7 @@ PROG_EM_PLAYER, PROG_EM_BUNKER, PROG_EM_MARAUDER, PROG_EM_UPBOLT, PROG_EM_DOWNBO
 PROG_WM_BOX, PROG_WM_JUDGE, PROG_WM_PLAYER = 30, 31, 32
 PROG_HW_ROLLING, PROG_HW_SLIDING = 40, 41
 PROG_WALKER, PROG_SCROLLY, PROG_STATIC = 50, 51, 52
+PROG_BS_PLAYER, PROG_BS_PATROLLER, PROG_BS_CASH = 60, 61, 62
 
 CROP_FIXED, CROP_SCROLLING = 1, 2
 

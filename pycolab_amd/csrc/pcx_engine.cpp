@@ -88,7 +88,8 @@ int pcx_engine_create(const pcx_template* t, int64_t batch, int device_id, pcx_e
     case PCX_GAME_WAREHOUSE:
     case PCX_GAME_MARAUDERS:
     case PCX_GAME_HELLO_WORLD:
-    case PCX_GAME_WALKERS: b = pcx::make_generic_backend(); break;
+    case PCX_GAME_WALKERS:
+    case PCX_GAME_BETTER_SCROLLY: b = pcx::make_generic_backend(); break;
     default:
       return set_error(PCX_E_UNSUPPORTED, "pcx_engine_create: no device program for game id %d", t->game);
   }

@@ -109,7 +109,7 @@ __device__ __forceinline__ void sprite_get(const Ctx& x, int s, int& vr, int& vc
 }
 __device__ __forceinline__ void sprite_put(const Ctx& x, int s, int vr, int vc, int vis, int prior) {
   x.l.pos[s * WAVE + x.lane] = pack_pos(vr, vc);
-  x.l.flg[s * WAVE + x.lane] = (uint32_t)vis | ((uint32_t)prior << 1);
+  x.l.flg[s * WAVE + x.lane] = (x.l.flg[s * WAVE + x.lane] & ~3u) | (uint32_t)vis | ((uint32_t)prior << 1);
 }
 // Sprite.position (true position): virtual if on board, else (0, 0) for walkers
 __device__ __forceinline__ void sprite_true(const Ctx& x, int s, int& r, int& c) {
@@ -335,6 +335,53 @@ __device__ __forceinline__ void prog_scrolly(Ctx& x, int thing) {
 
 __device__ __forceinline__ void terminate(Ctx& x) { x.game_over = 1; x.discount = 0.0f; }  // plot.py:176-198
 __device__ __forceinline__ void add_reward(Ctx& x, int r) { x.reward_set = 1; x.reward += r; }  // plot.py:200-226
+
+// layers[ch][r, c] for any character, backdrop ones included
+__device__ __forceinline__ bool char_layer_at(Ctx& x, int ch, int r, int c) {
+  if (r < 0) r += x.k.R;
+  if (c < 0) c += x.k.C;
+  if (!on_board(x.k, r, c)) { x.err |= ERR_INDEX; return false; }
+  for (int t = 0; t < x.k.NT; ++t)
+    if ((int)tfield(x, t, T_CH) == ch) return thing_layer(x, t, r, c);
+  if (x.k.occl) return top_char(x, r, c) == ch;
+  const int cell = r * x.k.C + c;
+  return (int)((x.l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF) == ch;
+}
+
+// ---- examples/better_scrolly_maze.py -------------------------------------------
+__device__ __forceinline__ void prog_bs_player(Ctx& x, int thing) {  // :258-272
+  const int a = x.action;
+  if ((unsigned)a <= 4u) mw_move(x, thing, a == 0 ? -1 : a == 1 ? 1 : 0, a == 2 ? -1 : a == 3 ? 1 : 0);
+  if (a == 5) terminate(x);
+}
+__device__ __forceinline__ void prog_bs_patroller(Ctx& x, int thing) {  // :284-301
+  const int s = tfield(x, thing, T_IDX);
+  if (x.frame & 1) { mw_move(x, thing, 0, 0); return; }
+  int r, c;
+  sprite_true(x, s, r, c);
+  uint32_t f = x.l.flg[s * WAVE + x.lane];  // bit 2: _moving_east
+  if (char_layer_at(x, '#', r, c - 1)) f |= 4u;
+  if (char_layer_at(x, '#', r, c + 1)) f &= ~4u;
+  x.l.flg[s * WAVE + x.lane] = f;
+  mw_move(x, thing, 0, (f & 4u) ? 1 : -1);
+  int pr, pc;
+  sprite_true(x, s, r, c);
+  sprite_true(x, tfield(x, x.k.ip, T_IDX), pr, pc);
+  if (r == pr && c == pc) terminate(x);
+}
+__device__ __forceinline__ void prog_bs_cash(Ctx& x, int thing) {  // :311-320
+  const int d = tfield(x, thing, T_IDX);
+  int pr, pc;
+  sprite_true(x, tfield(x, x.k.ip, T_IDX), pr, pc);
+  uint32_t* w = drape_rows(x, x.l.cur, d) + (size_t)(pr * x.k.RW + (pc >> 5)) * WAVE;
+  if ((*w >> (pc & 31)) & 1) {
+    add_reward(x, 100);
+    *w &= ~(1u << (pc & 31));
+    uint32_t any = 0;
+    for (int i = 0; i < x.k.R * x.k.RW; ++i) any |= drape_rows(x, x.l.cur, d)[(size_t)i * WAVE];
+    if (!any) terminate(x);
+  }
+}
 
 // ---- examples/warehouse_manager.py ------------------------------------------
 __device__ __forceinline__ void prog_wm_box(Ctx& x, int thing) {  // :214-226
@@ -613,6 +660,9 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
           case PCX_PROG_EM_MARAUDER: prog_em_marauder(x, thing, dxv); break;
           case PCX_PROG_EM_UPBOLT: prog_em_upbolt(x, thing); break;
           case PCX_PROG_EM_DOWNBOLT: prog_em_downbolt(x, thing, draws, genv); break;
+          case PCX_PROG_BS_PLAYER: prog_bs_player(x, thing); break;
+          case PCX_PROG_BS_PATROLLER: prog_bs_patroller(x, thing); break;
+          case PCX_PROG_BS_CASH: prog_bs_cash(x, thing); break;
           case PCX_PROG_WALKER: prog_walker(x, thing); break;
           case PCX_PROG_SCROLLY: prog_scrolly(x, thing); break;
           default: break;  // PCX_PROG_STATIC
@@ -655,16 +705,14 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
     const int FW = k.FW, C = k.C;
     for (int d = 0; d < k.ND; ++d) {
       for (int w = 0; w < FW; ++w) l.flat[(d * FW + w) * WAVE + lane] = 0;
-      for (int r = 0; r < k.R; ++r) {
-        const uint64_t bits = row_get(x, l.cur, d, r);
-        const int off = r * C, wi = off >> 5, sh = off & 31;
-        const uint32_t w0 = (uint32_t)(bits << sh);
-        const uint32_t w1 = sh ? (uint32_t)(bits >> (32 - sh)) : (uint32_t)(bits >> 32);
-        const uint32_t w2 = sh ? (uint32_t)(bits >> (64 - sh)) : 0u;
-        l.flat[(d * FW + wi) * WAVE + lane] |= w0;
-        if (w1) l.flat[(d * FW + wi + 1) * WAVE + lane] |= w1;
-        if (w2) l.flat[(d * FW + wi + 2) * WAVE + lane] |= w2;
-      }
+      for (int r = 0; r < k.R; ++r)
+        for (int w = 0; w < k.RW; ++w) {  // 32 columns of row r at a time
+          const uint32_t bits = drape_rows(x, l.cur, d)[(size_t)(r * k.RW + w) * WAVE];
+          if (!bits) continue;
+          const int off = r * C + 32 * w, wi = off >> 5, sh = off & 31;
+          l.flat[(d * FW + wi) * WAVE + lane] |= bits << sh;
+          if (sh) l.flat[(d * FW + wi + 1) * WAVE + lane] |= bits >> (32 - sh);
+        }
     }
     if (a.export_curtains)
       for (int i2 = 0; i2 < k.ND * FW; ++i2) P.curtains[(size_t)i2 * bp + env] = l.flat[i2 * WAVE + lane];
@@ -714,7 +762,7 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
   const bool any_skip = __ballot(skip) != 0ull;
   for (int it = 0; it < QW; ++it) {
     const uint32_t f = (uint32_t)it * WAVE + lane;
-    const uint32_t e = (f * k.magic_q) >> 20, q = f - e * QW;
+    const uint32_t e = __umulhi(f, k.magic_q), q = f - e * QW;  // f / QW by 32-bit reciprocal
     if (any_skip && l.skip[e]) continue;
     uint8_t* dst = blk + e * env_stride + q * 4;
     uint32_t d = l.backdrop4[q], uni = 0;
@@ -786,8 +834,8 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.occl = t.occlusion_in_layers != 0;
   k.game = t.game; k.R = t.rows; k.C = t.cols; k.cells = t.rows * t.cols; k.L = t.n_chars;
   k.NS = t.n_sprites; k.ND = t.n_drapes; k.NT = t.n_things; k.n_groups = t.n_groups; k.n_actions = t.n_actions;
-  if (k.C > 64 || k.L > MAX_L || k.NT > 24 || k.cells > 4096)
-    return set_error(PCX_E_UNSUPPORTED, "generic backend: needs cols <= 64 and <= %d characters", MAX_L);
+  if (k.C > 255 || k.R > 255 || k.L > MAX_L || k.NT > 24 || k.cells > 8192)
+    return set_error(PCX_E_UNSUPPORTED, "generic backend: board larger than 255x255 / 8192 cells or more than %d characters", MAX_L);
   if ((1 + k.L) * k.cells % 4 != 0 && false) return set_error(PCX_E_UNSUPPORTED, "unreachable");
   k.pitch = (k.cells + 3) & ~3;
   k.QW = k.pitch / 4;
@@ -795,10 +843,10 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.FW = (k.cells + 31) / 32 + 2;
   {
     bool ok = true;
-    uint32_t m = ((1u << 20) + k.QW - 1) / k.QW;
+    const uint32_t m = (uint32_t)(((1ull << 32) + k.QW - 1) / k.QW);
     for (uint32_t x = 0; x <= (uint32_t)WAVE * k.QW; ++x)
-      if (((uint64_t)x * m) >> 20 != x / k.QW || (uint64_t)x * m > 0xFFFFFFFFull) { ok = false; break; }
-    if (!ok) return set_error(PCX_E_UNSUPPORTED, "generic backend: board too large for the 20-bit reciprocal");
+      if ((uint32_t)(((uint64_t)x * m) >> 32) != x / k.QW) { ok = false; break; }
+    if (!ok) return set_error(PCX_E_UNSUPPORTED, "generic backend: board too large for the 32-bit reciprocal");
     k.magic_q = m;
   }
   k.seed_lo = (uint32_t)t.param[0]; k.seed_hi = (uint32_t)t.param[1];
@@ -860,11 +908,19 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
       return set_error(PCX_E_INVALID, "generic backend: z_order names an unknown character");
     }
     zt[z] = z;
+    if (k.C > 64)  // whole-row rotates and window copies hold a row in 64 bits
+      switch (e[T_PROG]) {
+        case PCX_PROG_WM_JUDGE: case PCX_PROG_HW_ROLLING: case PCX_PROG_EM_MARAUDER: case PCX_PROG_SCROLLY:
+          return set_error(PCX_E_UNSUPPORTED, "generic backend: program %u needs cols <= 64", e[T_PROG]);
+        default: break;
+      }
+    if (k.C > 64 && d >= 0 && t.drapes[d].is_scrolly)
+      return set_error(PCX_E_UNSUPPORTED, "generic backend: Scrolly drapes need cols <= 64");
     switch (e[T_PROG]) {
       case PCX_PROG_WM_BOX: case PCX_PROG_WM_JUDGE: case PCX_PROG_WM_PLAYER: case PCX_PROG_HW_ROLLING:
       case PCX_PROG_HW_SLIDING: case PCX_PROG_EM_PLAYER: case PCX_PROG_EM_BUNKER: case PCX_PROG_EM_MARAUDER:
       case PCX_PROG_EM_UPBOLT: case PCX_PROG_EM_DOWNBOLT: case PCX_PROG_STATIC: case PCX_PROG_WALKER:
-      case PCX_PROG_SCROLLY: break;
+      case PCX_PROG_SCROLLY: case PCX_PROG_BS_PLAYER: case PCX_PROG_BS_PATROLLER: case PCX_PROG_BS_CASH: break;
       default: return set_error(PCX_E_UNSUPPORTED, "generic backend: no device program %u", e[T_PROG]);
     }
   }
@@ -927,7 +983,8 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
     walker_[s] = sd.is_walker;
     const int vr = sd.is_walker ? sd.vrow : sd.row, vc = sd.is_walker ? sd.vcol : sd.col;
     init[W_SPRITES + s] = ((uint32_t)vr & 0xFFFFu) | ((uint32_t)vc << 16);
-    init[k.w_sflags + (s >> 2)] |= ((uint32_t)(sd.visible != 0) | ((uint32_t)(sd.prior_visible != 0) << 1)) << (8 * (s & 3));
+    init[k.w_sflags + (s >> 2)] |= ((uint32_t)(sd.visible != 0) | ((uint32_t)(sd.prior_visible != 0) << 1) |
+                                    ((uint32_t)(sd.program == PCX_PROG_BS_PATROLLER && sd.param[0]) << 2)) << (8 * (s & 3));
   }
 
   // tables -> one buffer staged into LDS, then the per-lane arrays

@@ -31,6 +31,9 @@ NAMES = {
     'warehouse.player': N.PROG_WM_PLAYER,
     'hello_world.rolling': N.PROG_HW_ROLLING,
     'hello_world.sliding': N.PROG_HW_SLIDING,
+    'better_scrolly_maze.player': N.PROG_BS_PLAYER,
+    'better_scrolly_maze.patroller': N.PROG_BS_PATROLLER,
+    'better_scrolly_maze.cash': N.PROG_BS_CASH,
     'walker': N.PROG_WALKER,
     'scrolly': N.PROG_SCROLLY,
     'static': N.PROG_STATIC,
@@ -45,11 +48,13 @@ GAME_OF_PROGRAM = {
     N.PROG_WM_BOX: N.GAME_WAREHOUSE, N.PROG_WM_JUDGE: N.GAME_WAREHOUSE,
     N.PROG_WM_PLAYER: N.GAME_WAREHOUSE,
     N.PROG_HW_ROLLING: N.GAME_HELLO_WORLD, N.PROG_HW_SLIDING: N.GAME_HELLO_WORLD,
+    N.PROG_BS_PLAYER: N.GAME_BETTER_SCROLLY, N.PROG_BS_PATROLLER: N.GAME_BETTER_SCROLLY,
+    N.PROG_BS_CASH: N.GAME_BETTER_SCROLLY,
 }
 
 # Number of "ordinary" actions per game (quit excluded): SURVEY.md section 8(d).
 N_ACTIONS = {N.GAME_SCROLLY_MAZE: 5, N.GAME_MARAUDERS: 4, N.GAME_WAREHOUSE: 5,
-             N.GAME_HELLO_WORLD: 4, N.GAME_WALKERS: 9}
+             N.GAME_HELLO_WORLD: 4, N.GAME_WALKERS: 9, N.GAME_BETTER_SCROLLY: 5}
 
 # (class name, fingerprint of update()) of the reference's shipped game
 # classes -> program name.  Fingerprints are produced by
@@ -69,6 +74,7 @@ def _pack2(values):
 # (reference attribute names), delivered to the device program as param[0..3].
 PARAM_EXTRACTORS = {
     N.PROG_SM_PATROLLER: lambda e: [int(bool(e._moving_east)), 0, 0, 0],     # scrolly_maze.py:282
+    N.PROG_BS_PATROLLER: lambda e: [int(bool(e._moving_east)), 0, 0, 0],     # better_scrolly_maze.py:282
     N.PROG_HW_SLIDING: lambda e: [_pack2(e._dx), _pack2(e._dy), 0, 0],      # hello_world.py:114-115
     N.PROG_EM_MARAUDER: lambda e: [int(e._dx), 0, 0, 0],                    # marauders.py:139
     N.PROG_WM_JUDGE: lambda e: [int(e._last_num_boxes_on_goals), 0, 0, 0],  # warehouse_manager.py:243

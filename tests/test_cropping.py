@@ -10,7 +10,8 @@ from oracle import binding
 from pycolab_amd import cropping
 from tests import helpers
 
-CROPPED = ['scrolly_maze_L0', 'warehouse_L1', 'marauders']
+CROPPED = ['scrolly_maze_L0', 'warehouse_L1', 'marauders', 'better_scrolly_maze_L0', 'better_scrolly_maze_L1',
+           'better_scrolly_maze_L2']
 
 
 def specs_of(trace):

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 LEVELS = ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2']
 ALL_GAMES = LEVELS + ['warehouse_L0', 'warehouse_L1', 'warehouse_L2', 'hello_world', 'marauders',
                       'scrolly_maze_L1_unoccluded', 'warehouse_L0_unoccluded', 'marauders_unoccluded',
-                      'walkers_room', 'walkers_scroll_margins', 'walkers_scroll_always']
+                      'walkers_room', 'walkers_scroll_margins', 'walkers_scroll_always',
+                      'better_scrolly_maze_L0', 'better_scrolly_maze_L1', 'better_scrolly_maze_L2']
 
 
 class OracleAdapter(binding.OracleEngine):
@@ -41,7 +42,7 @@ def test_hip_matches_oracle_hashed_actions(name):
   resets included; every output compared every 8 steps and at the end."""
   t = helpers.load_template(name)
   t.param[0] = 0xBEEF  # RNG seed (marauders)
-  B, T = (4096, 256) if name in LEVELS else (2048, 192)
+  B, T = (4096, 256) if name in LEVELS else (512, 96) if name.startswith('better') else (2048, 192)
   hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
   hip.reset(); orc.reset()
   assert_same(hip, orc, 'frame 0')
