@@ -240,6 +240,26 @@ class Engine(object):
     N.check(N.lib().pcx_engine_step(self._native, ptr, int(self._auto_reset),
                                     dev.current_stream(self._device_id)))
 
+  def step_n(self, action_tape):
+    """`len(action_tape)` consecutive steps from a device int32 tensor (or host
+    array) of shape [T, batch]; only the last step's observation survives."""
+    torch = dev.torch_module()
+    if torch is not None and isinstance(action_tape, torch.Tensor):
+      if action_tape.dtype != torch.int32 or not action_tape.is_cuda or not action_tape.is_contiguous():
+        raise ValueError('device action tape must be a contiguous int32 CUDA tensor [T, batch]')
+      tape, ptr = action_tape, action_tape.data_ptr()
+    else:
+      host = np.ascontiguousarray(action_tape, np.int32)
+      tape = dev.DeviceBuffer(host.shape, np.int32, self._device_id)
+      tape.upload(host)
+      ptr = tape.ptr
+    steps, batch = tape.shape
+    if batch != self._batch:
+      raise ValueError('action tape must have shape [T, batch]')
+    N.check(N.lib().pcx_engine_step_n(self._native, ptr, int(steps), int(self._auto_reset),
+                                      dev.current_stream(self._device_id)))
+    dev.synchronize(self._device_id)  # the staging buffer may be freed after this call
+
   def step_hashed(self, seed, t0, steps, env_offset=0):
     """`steps` steps with on-device actions `hash(seed, env, t) % n_actions`."""
     N.check(N.lib().pcx_engine_step_hashed(

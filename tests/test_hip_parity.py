@@ -129,3 +129,19 @@ def test_engine_facade_batch1_matches_trace():
     for c in t.chars:
       np.testing.assert_array_equal(obs.layers[chr(c)], obs.board == c)
     assert eng.the_plot.frame == step + 1
+
+
+def test_step_n_tape_equals_single_steps():
+  """pcx_engine_step_n over a [T, B] tape == T calls of pcx_engine_step."""
+  t = helpers.load_template('scrolly_maze_L1')
+  B, T = 300, 40   # batch not a multiple of 64: the tail wave is partly idle
+  rng = np.random.RandomState(11)
+  tape = rng.randint(0, 5, size=(T, B)).astype(np.int32)
+  a, b, orc = HipAdapter(t, B), HipAdapter(t, B), OracleAdapter(t, B)
+  a.reset(); b.reset(); orc.reset()
+  a.eng._auto_reset = True
+  a.eng.step_n(tape)
+  for step in range(T):
+    b.step(tape[step]); orc.step(tape[step])
+  assert_same(a, orc, 'step_n')
+  assert_same(b, orc, 'single steps')
