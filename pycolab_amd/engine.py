@@ -234,6 +234,24 @@ class Engine(object):
     self.step(actions)
     return self._result()
 
+  def reset(self, env_mask=None):
+    """Restart environments in place (a new episode = a new Engine in the
+    reference): all of them, or those where `env_mask` (uint8/bool [batch],
+    host array or device tensor) is nonzero."""
+    ptr, keep = None, None
+    if env_mask is not None:
+      torch = dev.torch_module()
+      if torch is not None and isinstance(env_mask, torch.Tensor):
+        keep = env_mask.to(dtype=torch.uint8).contiguous()
+        ptr = keep.data_ptr()
+      else:
+        keep = dev.DeviceBuffer((self._batch,), np.uint8, self._device_id)
+        keep.upload(np.asarray(env_mask, np.uint8))
+        ptr = keep.ptr
+    N.check(N.lib().pcx_engine_reset(self._native, ptr, dev.current_stream(self._device_id)))
+    dev.synchronize(self._device_id)
+    return self._result()
+
   def step(self, actions):
     """`play()` without materialising return values (no host sync)."""
     ptr = self._stage_actions(actions)

@@ -145,3 +145,31 @@ def test_step_n_tape_equals_single_steps():
     b.step(tape[step]); orc.step(tape[step])
   assert_same(a, orc, 'step_n')
   assert_same(b, orc, 'single steps')
+
+
+@pytest.mark.parametrize('name', ['scrolly_maze_L1', 'marauders'])
+def test_partial_reset_and_things_views(name):
+  """pcx_engine_reset with a mask restarts only the chosen environments; the
+  facade's live `things` views agree with the oracle's entity state."""
+  t = helpers.load_template(name)
+  t.param[0] = 99
+  B = 200
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  hip.step_hashed(5, 0, 30); orc.step_hashed(5, 0, 30)
+  mask = (np.arange(B) % 3 == 0).astype(np.uint8)
+  hip.eng.reset(mask); orc.reset(mask)
+  assert_same(hip, orc, 'after masked reset')
+  assert (hip.read('frame')[mask == 1] == 0).all()
+  hip.step_hashed(5, 30, 20); orc.step_hashed(5, 30, 20)
+  assert_same(hip, orc, 'after stepping on')
+  things = hip.eng.things
+  want = orc.sprites()
+  for i, sp in enumerate(t.sprites):
+    view = things[chr(sp['ch'])]
+    pos, vis = view.position, view.visible
+    for b in (0, 1, B - 1):
+      assert tuple(pos[b]) == (want[b, i, 0], want[b, i, 1]) and vis[b] == bool(want[b, i, 4])
+  cur = orc.curtains()
+  for i, d in enumerate(t.drapes):
+    np.testing.assert_array_equal(things[chr(d['ch'])].curtain.astype(np.uint8), cur[:, i])
