@@ -388,13 +388,14 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
 
   // blockDim.x == 64: one wave does both jobs back to back (no overlap).
   const bool solo = blockDim.x == WAVE;
-  for (int round = solo ? 0 : -1;; ++round) {
+  const bool single = solo;  // logic and render of the same group in the same round
+  for (int round = single ? 0 : -1;; ++round) {
   const int64_t g_render = (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
-  const int64_t g_logic = solo ? g_render : g_render + gridDim.x;
+  const int64_t g_logic = single ? g_render : g_render + gridDim.x;
   const bool have_render = round >= 0 && g_render < ngroups, have_logic = g_logic < ngroups;
   if (!have_render && !have_logic) break;
   {
-    const int buf = solo ? 0 : (wave == 0) ? ((round + 1) & 1) : (round & 1);
+    const int buf = single ? 0 : (wave == 0) ? ((round + 1) & 1) : (round & 1);
     l.flat = lds_raw + k.lds_flat + buf * k.lds_buf_words;
     l.sdesc = reinterpret_cast<uint2*>(lds_raw + k.lds_sdesc + buf * k.lds_buf_words);
     l.skip = lds_raw + k.lds_skip + buf * k.lds_buf_words;
@@ -707,8 +708,8 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
   l.skip[lane] = skip;
   }  // have_logic
   }
-  if (solo) __syncthreads();
-  if ((solo || wave == 1) && have_render && !(a.debug & 2)) {
+  if (single) __syncthreads();
+  if ((single || wave == 1) && have_render && !(a.debug & 2)) {
 
 
   // ---- phase B: the wavefront streams the observation planes ---------------
@@ -747,36 +748,23 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
   const uint32_t* const flat_raw = lds_raw + k.lds_flatraw;
   const uint2* const sdesc_raw = reinterpret_cast<const uint2*>(lds_raw + k.lds_sdescraw);
 
-  // Each wave store covers 256 contiguous bytes of one plane of one or two
-  // environment records; all nine planes of a 64-dword span leave together.
-  const bool any_skip = __ballot(l.skip[lane] != 0) != 0ull;
-  // Drain the logic phase's own loads/stores once, here: the loop's stores are
-  // inline asm the compiler cannot count, and without this it protects a
-  // register of an older store with a vmcnt(0) *inside* the loop, which would
-  // serialise every iteration behind all outstanding plane stores.
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
-  // (e, q) = the environment and the board dword this lane composes; both and
-  // every address derived from them advance incrementally -- no multiplies or
-  // divisions in the loop (v_mul_lo/_hi are quarter rate).
-  uint32_t e = 0, q = lane, voff = 4u * lane, eF = 0;
-  while (q >= (uint32_t)QW) { q -= QW; e += 1; voff += e_skew; eF += FWP; }  // boards narrower than 64 dwords
-#pragma unroll 1
-  for (int it = 0; it < QW; ++it) {
-    const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF;
-    q += WAVE; voff += 4u * WAVE;
-    while (q >= (uint32_t)QW) { q -= QW; e += 1; voff += e_skew; eF += FWP; }
-    if (any_skip && l.skip[e_now]) continue;
-    {
-    const uint32_t e = e_now, q = q_now, voff = voff_now, eF = eF_now;
-    // scalar base (pinned above) + 32-bit lane offset: one `global_store_dword
-    // voffset, data, sbase` per plane, no per-store address arithmetic
-    auto put = [&](uint8_t* plane_base, uint32_t v) {
-      if constexpr (SL != 0) {  // the static-shape instance keeps all nine bases in SGPRs
-        asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(plane_base));
-      }
-      else
-        *reinterpret_cast<uint32_t*>(plane_base + voff) = v;
-    };
+  // Plane tags for compose(): 0 board, 1..2 curtains, 3..3+NS-1 sprites, then
+  // the backdrop-only characters.  pb[] = uniform global base, po[] = uniform
+  // byte offset of the plane inside an environment record.
+  constexpr int NPL = 3 + NS + NBS;
+  uint8_t* pb[NPL];
+  uint32_t po[NPL];
+  pb[0] = pb_board; po[0] = 0;
+#pragma unroll
+  for (int dd = 0; dd < 2; ++dd) { pb[1 + dd] = pb_d[dd]; po[1 + dd] = (uint32_t)(1 + k.lay_drape[dd]) * (uint32_t)cells; }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { pb[3 + s] = pb_s[s]; po[3 + s] = (uint32_t)(1 + k.lay_sprite[s]) * (uint32_t)cells; }
+#pragma unroll
+  for (int i = 0; i < NBS; ++i) { pb[3 + NS + i] = pb_b[i]; po[3 + NS + i] = (uint32_t)(1 + k.lay_bchar[i]) * (uint32_t)cells; }
+
+  // One (environment e, board dword q) task: compose the board dword and hand
+  // it and the layer dwords to put(plane tag, value).
+  auto compose = [&](uint32_t e, uint32_t q, uint32_t eF, auto&& put) {
     uint32_t d = l.backdrop4[q];
     uint32_t md[2], ms[NS], mb[NBS];
 #pragma unroll
@@ -802,7 +790,7 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
       uni |= ms[s];
       d = (d & ~ms[s]) | (sch4[s] & ms[s]);
     }
-    put(pb_board, d);
+    put(0, d);
     if constexpr (UNOCC) {  // layers are the raw masks, the backdrop's included
 #pragma unroll
       for (int dd = 0; dd < 2; ++dd) {
@@ -819,16 +807,47 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
     }
     // rendering.py:177-179 layer[c] = (board == c): by construction that is
     // the thing's own mask, or the backdrop's where no thing paints.
-    put(pb_d[0], md[0] & 0x01010101u);
-    put(pb_d[1], md[1] & 0x01010101u);
+    put(1, md[0] & 0x01010101u);
+    put(2, md[1] & 0x01010101u);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) put(pb_s[s], ms[s] & 0x01010101u);
+    for (int s = 0; s < NS; ++s) put(3 + s, ms[s] & 0x01010101u);
 #pragma unroll
     for (int i = 0; i < NBS; ++i) {
       if (!SL && i >= NB) break;
-      put(pb_b[i], mb[i] & ~uni);
+      put(3 + NS + i, mb[i] & ~uni);
     }
-    }
+  };
+
+  const bool any_skip = __ballot(l.skip[lane] != 0) != 0ull;  // same in both waves of a workgroup
+  {
+  // Direct path.  Each wave store covers 256 contiguous bytes of one plane of
+  // one or two environment records; all nine planes of a 64-dword span leave
+  // together.
+  // Drain the logic phase's own loads/stores once, here: the loop's stores are
+  // inline asm the compiler cannot count, and without this it protects a
+  // register of an older store with a vmcnt(0) *inside* the loop, which would
+  // serialise every iteration behind all outstanding plane stores.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+  // (e, q) = the environment and the board dword this lane composes; both and
+  // every address derived from them advance incrementally -- no multiplies or
+  // divisions in the loop (v_mul_lo/_hi are quarter rate).
+  uint32_t e = 0, q = lane, voff = 4u * lane, eF = 0;
+  while (q >= (uint32_t)QW) { q -= QW; e += 1; voff += e_skew; eF += FWP; }  // boards narrower than 64 dwords
+#pragma unroll 1
+  for (int it = 0; it < QW; ++it) {
+    const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF;
+    q += WAVE; voff += 4u * WAVE;
+    while (q >= (uint32_t)QW) { q -= QW; e += 1; voff += e_skew; eF += FWP; }
+    if (any_skip && l.skip[e_now]) continue;
+    // scalar base (pinned above) + 32-bit lane offset: one `global_store_dword
+    // voffset, data, sbase` per plane, no per-store address arithmetic
+    compose(e_now, q_now, eF_now, [&](int plane, uint32_t v) {
+      if constexpr (SL != 0)  // the static-shape instance keeps all nine bases in SGPRs
+        asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(pb[plane]));
+      else
+        *reinterpret_cast<uint32_t*>(pb[plane] + voff_now) = v;
+    });
+  }
   }
   }  // render wave
   __syncthreads();  // swap buffers
@@ -1102,7 +1121,6 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     int rc = curtains_.alloc((size_t)2 * k_.FW * bpad_);
     if (rc) return rc;
   }
-  Ptrs P{walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_};
   // Launch shape.  Default: one single-wave workgroup per group of 64
   // environments (logic, then render), with the LDS footprint padded so that
   // about 8 waves share a CU -- on MI355X the nine interleaved write streams
@@ -1124,6 +1142,8 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     if (want > lds) lds = want;
   }
   if (const char* pad = getenv("PCX_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
+  if (lds > 64 * 1024) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds);
+  Ptrs P{walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_};
   // Specialised instance for the shipped scrolly_maze shape (10x30 board,
   // 8 characters, 'abcP' sprites); anything else takes the generic instance.
   if (!unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3) {
