@@ -144,7 +144,8 @@ SYMBOLS = [
     ('pcx_post_errors', c_i32, [_VP, _VP]),
 ]
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpcx.so')
+# PCX_LIB selects another build of the same library (A/B kernel experiments).
+LIB_PATH = os.environ.get('PCX_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpcx.so')
 
 
 class NativeLibraryMissing(RuntimeError):

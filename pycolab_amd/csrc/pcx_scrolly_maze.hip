@@ -831,13 +831,28 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
   // (e, q) = the environment and the board dword this lane composes; both and
   // every address derived from them advance incrementally -- no multiplies or
   // divisions in the loop (v_mul_lo/_hi are quarter rate).
+  // Static shape with at least 64 dwords per board: a lane wraps into the next
+  // environment at most once per iteration, so the update is four selects.
+  constexpr bool INCR = SR != 0 && (SR * SC / 4) >= WAVE;
   uint32_t e = 0, q = lane, voff = 4u * lane, eF = 0;
-  while (q >= (uint32_t)QW) { q -= QW; e += 1; voff += e_skew; eF += FWP; }  // boards narrower than 64 dwords
 #pragma unroll 1
   for (int it = 0; it < QW; ++it) {
-    const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF;
-    q += WAVE; voff += 4u * WAVE;
-    while (q >= (uint32_t)QW) { q -= QW; e += 1; voff += e_skew; eF += FWP; }
+    uint32_t e_now, q_now, voff_now, eF_now;
+    if constexpr (INCR) {
+      e_now = e; q_now = q; voff_now = voff; eF_now = eF;
+      q += WAVE; voff += 4u * WAVE;
+      const bool wrap = q >= (uint32_t)QW;
+      q = wrap ? q - QW : q;
+      e = wrap ? e + 1 : e;
+      voff = wrap ? voff + e_skew : voff;
+      eF = wrap ? eF + FWP : eF;
+    } else {
+      const uint32_t f = (uint32_t)it * WAVE + lane;
+      e_now = (f * magic_q) >> 20;
+      q_now = f - e_now * QW;
+      voff_now = 4u * f + e_now * e_skew;
+      eF_now = e_now * FWP;
+    }
     if (any_skip && l.skip[e_now]) continue;
     // scalar base (pinned above) + 32-bit lane offset: one `global_store_dword
     // voffset, data, sbase` per plane, no per-store address arithmetic
