@@ -1,0 +1,82 @@
+"""TEST INFRASTRUCTURE: scrolly_maze levels that the reference does not ship.
+
+The three shipped levels all have a 10x30 board, four sprites and the z-order
+'abc@#P', so they exercise one shape of the step kernel only.  These levels use
+the example file's own, unchanged classes (PlayerSprite, PatrollerSprite,
+MazeDrape, CashDrape; scrolly_maze.py:238-357) with other board shapes, sprite
+sets and z-orders.  `make_game(level, example, ascii_art, prefab_drapes)` builds
+one the way scrolly_maze.make_game does (scrolly_maze.py:213-235), with the
+example module and the pycolab packages passed in: oracle/gen_golden.py passes
+the reference's, oracle/gen_templates.py passes pycolab_amd's.
+
+The art is drawn once from a fixed seed (no randomness at test time).
+"""
+import numpy as np
+
+
+def _draw(seed, rows, cols, board, sprites, wall_p, coin_p, mark_beneath):
+  """A walled maze of rows x cols with random interior walls and coins, a
+  board-corner mark such that `board` fits, and the sprites on free cells (the
+  player inside the board window)."""
+  rng = np.random.RandomState(seed)
+  br, bc = board
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  art[0, :] = art[-1, :] = art[:, 0] = art[:, -1] = '#'
+  inner = rng.rand(rows - 2, cols - 2)
+  art[1:-1, 1:-1][inner < wall_p] = '#'
+  art[1:-1, 1:-1][(inner >= wall_p) & (inner < wall_p + coin_p)] = '@'
+  cr = int(rng.randint(0, rows - br + 1))
+  cc = int(rng.randint(0, cols - bc + 1))
+  free = lambda r, c: art[r, c] == ' ' and (r, c) != (cr, cc)
+  for ch in sprites:
+    for _ in range(10000):
+      if ch == 'P':  # the egocentric player starts inside the window, away from its rim
+        r = int(rng.randint(cr + 1, cr + br - 1)); c = int(rng.randint(cc + 1, cc + bc - 1))
+      else:
+        r = int(rng.randint(1, rows - 1)); c = int(rng.randint(1, cols - 1))
+      if 0 < r < rows - 1 and 0 < c < cols - 1 and free(r, c):
+        art[r, c] = ch
+        break
+    else:
+      raise RuntimeError('no room for sprite ' + ch)
+  beneath = art[cr, cc] if art[cr, cc] in mark_beneath else mark_beneath[0]
+  art[cr, cc] = '+'
+  stars = np.full((br, bc), ' ', dtype='<U1')
+  stars[rng.rand(br, bc) < 0.1] = '.'
+  return [''.join(row) for row in art], [''.join(row) for row in stars], str(beneath)
+
+
+# name -> (seed, maze rows, maze cols, board (rows, cols), sprites in update order, z_order)
+# Board shapes: 18 dwords per board (less than one wavefront's 64), exactly 64,
+# 60, and 10; one to four sprites; the player at the back, the middle and the
+# front of the z-order.
+SPECS = {
+    'scrolly_custom_A': (101, 14, 25, (6, 12), 'aP', 'a@#P'),
+    'scrolly_custom_B': (102, 20, 40, (8, 32), 'abcP', 'P#@cba'),
+    'scrolly_custom_C': (103, 12, 20, (12, 20), 'P', '#P@'),
+    'scrolly_custom_D': (104, 9, 31, (5, 8), 'bP', '@bP#'),
+    'scrolly_custom_E': (105, 30, 24, (10, 24), 'cbP', 'c#Pb@'),
+}
+NAMES = sorted(SPECS)
+
+
+def level_art(name):
+  seed, rows, cols, board, sprites, _ = SPECS[name]
+  return _draw(seed, rows, cols, board, sprites, wall_p=0.22, coin_p=0.08, mark_beneath='# ')
+
+
+def make_game(name, example, ascii_art, prefab_drapes):
+  """scrolly_maze.make_game (scrolly_maze.py:213-235) for a level of SPECS."""
+  _, _, _, _, sprites, z_order = SPECS[name]
+  maze, stars, beneath = level_art(name)
+  info = prefab_drapes.Scrolly.PatternInfo(maze, stars, board_northwest_corner_mark='+',
+                                           what_lies_beneath=beneath)
+  parts = {}
+  for ch in sprites:
+    cls = example.PlayerSprite if ch == 'P' else example.PatrollerSprite
+    parts[ch] = ascii_art.Partial(cls, info.virtual_position(ch))
+  return ascii_art.ascii_art_to_game(
+      stars, what_lies_beneath=' ', sprites=parts,
+      drapes={'#': ascii_art.Partial(example.MazeDrape, **info.kwargs('#')),
+              '@': ascii_art.Partial(example.CashDrape, **info.kwargs('@'))},
+      update_schedule=[['#'], list(sprites), ['@']], z_order=z_order)

@@ -65,6 +65,7 @@ struct Consts {
   uint32_t chars[MAX_L];
   // sprites, in engine insertion order (== update order inside group 1)
   int32_t prog[MAX_NS], confined[MAX_NS], egocentric[MAX_NS], sprite_ch[MAX_NS];
+  int32_t tmpl_index[MAX_NS];  // sprite s here (update order) is sprite tmpl_index[s] of the template (insertion order)
   uint32_t imp[MAX_NS][4];
   // Probes number the things by z-order position (bit z = the z-th thing from the
   // back), so the character on top of a cell is the highest set presence bit.
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
       st[(W_SPOS + s) * bp] = pack_pos(w[s].vr, w[s].vc);
       sf |= ((uint32_t)w[s].vis | ((uint32_t)w[s].prior << 1) | ((uint32_t)w[s].var << 2)) << (8 * s);
       const bool on = on_board(k, w[s].vr, w[s].vc);
-      P.track[s * bp + env] = (on ? w[s].vr : 0) | ((on ? w[s].vc : 0) << 8) | (w[s].vis << 16) |
+      P.track[k.tmpl_index[s] * bp + env] = (on ? w[s].vr : 0) | ((on ? w[s].vc : 0) << 8) | (w[s].vis << 16) |
                               ((int)do_reset << 24);
     }
     st[W_SFLAGS * bp] = sf;
@@ -960,11 +961,24 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   if (t.n_groups != 3 || t.n_things != t.n_sprites + 2 || t.schedule[0] != md.ch || t.group_of[0] != 0 ||
       t.schedule[t.n_things - 1] != cd.ch || t.group_of[t.n_things - 1] != 2)
     return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: update schedule must be [[maze],[sprites...],[cash]]");
+  // The kernel numbers the sprites in update order (their order inside group
+  // 1); the template lists them in engine insertion order, which is the z-order
+  // for ascii_art games (ascii_art.py:278-283).  sp[s] = the template's
+  // description of sprite s, tmpl_index[s] = its place in the template.
+  const pcx_sprite_desc* sp[MAX_NS] = {};
+  for (int s = 0; s < t.n_sprites; ++s) {
+    k.tmpl_index[s] = -1;
+    for (int j = 0; j < t.n_sprites; ++j)
+      if (t.sprites[j].ch == t.schedule[1 + s]) k.tmpl_index[s] = j;
+    if (k.tmpl_index[s] < 0 || t.group_of[1 + s] != 1)
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: update group 1 must hold exactly the sprites");
+    sp[s] = &t.sprites[k.tmpl_index[s]];
+  }
   k.ip = k.ie = -1;
   for (int s = 0; s < t.n_sprites; ++s) {
-    const pcx_sprite_desc& sd = t.sprites[s];
-    if (t.schedule[1 + s] != sd.ch || t.group_of[1 + s] != 1 || !sd.is_walker)
-      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: sprites must be MazeWalkers scheduled in insertion order in group 1");
+    const pcx_sprite_desc& sd = *sp[s];
+    if (!sd.is_walker)
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: sprites must be MazeWalkers");
     k.prog[s] = sd.program; k.confined[s] = sd.confined; k.egocentric[s] = sd.egocentric; k.sprite_ch[s] = sd.ch;
     if (sd.program == PCX_PROG_SM_PLAYER) {
       if (k.ip >= 0) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: one player only");
@@ -978,7 +992,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     }
     for (int j = 0; j < 4; ++j) memcpy(&k.imp[s][j], sd.impassable + 4 * j, 4);
   }
-  if (k.ip < 0 || t.sprites[k.ip].ch != 'P')
+  if (k.ip < 0 || sp[k.ip]->ch != 'P')
     return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the player sprite must paint 'P' (things['P'] lookups)");
   if (md.ch != '#') return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the maze drape must paint '#' (things['#'] lookups)");
 
@@ -986,7 +1000,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   auto imp_has = [&](int s, int ch) { return (k.imp[s][ch >> 5] >> (ch & 31)) & 1; };
   for (int z = 0; z < t.n_things; ++z) {
     int ch = t.z_order[z], idx = -1, kind = 0;
-    for (int s = 0; s < t.n_sprites; ++s) if (t.sprites[s].ch == ch) { idx = s; kind = 0; }
+    for (int s = 0; s < t.n_sprites; ++s) if (sp[s]->ch == ch) { idx = s; kind = 0; }
     if (ch == md.ch) { idx = 0; kind = 1; }
     if (ch == cd.ch) { idx = 1; kind = 1; }
     if (idx < 0) return set_error(PCX_E_INVALID, "z_order names an unknown character");
@@ -1023,14 +1037,14 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
         if (zpos[b] > zpos[a]) k.above[a] |= 1u << b;
     }
     auto layer_of = [&](int ch) { for (int i = 0; i < k.L; ++i) if ((int)k.chars[i] == ch) return i; return -1; };
-    for (int s = 0; s < t.n_sprites; ++s) k.lay_sprite[s] = layer_of(t.sprites[s].ch);
+    for (int s = 0; s < t.n_sprites; ++s) k.lay_sprite[s] = layer_of(sp[s]->ch);
     k.lay_drape[0] = layer_of(md.ch);
     k.lay_drape[1] = layer_of(cd.ch);
     k.n_bchars = 0;
     for (int i = 0; i < k.L; ++i) {
       int ch = (int)k.chars[i];
       bool thing = ch == md.ch || ch == cd.ch;
-      for (int s = 0; s < t.n_sprites; ++s) thing |= t.sprites[s].ch == ch;
+      for (int s = 0; s < t.n_sprites; ++s) thing |= sp[s]->ch == ch;
       if (!thing) { k.bchar[k.n_bchars] = ch; k.lay_bchar[k.n_bchars] = i; k.n_bchars++; }
     }
     if (k.n_bchars != k.L - t.n_sprites - 2) return set_error(PCX_E_INVALID, "scrolly_maze backend: inconsistent character set");
@@ -1076,7 +1090,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   k.init[W_STALE] = STALE_NONE;
   uint32_t sf = 0;
   for (int s = 0; s < t.n_sprites; ++s) {
-    const pcx_sprite_desc& sd = t.sprites[s];
+    const pcx_sprite_desc& sd = *sp[s];
     k.init[W_SPOS + s] = ((uint32_t)sd.vrow & 0xFFFFu) | ((uint32_t)sd.vcol << 16);
     uint32_t var = sd.program == PCX_PROG_SM_PATROLLER ? (uint32_t)(sd.param[0] != 0) : 0u;  // _moving_east, scrolly_maze.py:282
     sf |= ((uint32_t)(sd.visible != 0) | ((uint32_t)(sd.prior_visible != 0) << 1) | (var << 2)) << (8 * s);
@@ -1189,7 +1203,7 @@ int ScrollyMazeBackend::read_things(int64_t env0, int64_t n, pcx_sprite_state* s
   for (int64_t i = 0; i < n; ++i) {
     if (sprites)
       for (int s = 0; s < k.NS; ++s) {
-        pcx_sprite_state& o = sprites[i * k.NS + s];
+        pcx_sprite_state& o = sprites[i * k.NS + k.tmpl_index[s]];
         memset(&o, 0, sizeof o);
         uint32_t pw = word(W_SPOS + s, i);
         o.vrow = (int16_t)(pw & 0xFFFF); o.vcol = (int16_t)(pw >> 16);

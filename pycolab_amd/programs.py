@@ -91,9 +91,26 @@ class UnsupportedEntityError(NotImplementedError):
   pass
 
 
+def _digest_code(h, code):
+  """Feeds what identifies a code object's behaviour -- not where it lives in
+  memory or how a set constant happens to be ordered in this process."""
+  h.update(code.co_code)
+  h.update(repr(code.co_names).encode())
+  for c in code.co_consts:
+    if hasattr(c, 'co_code'):           # nested lambda / comprehension
+      h.update(b'<code>')
+      _digest_code(h, c)
+    elif isinstance(c, frozenset):      # `x in {..}` constants: iteration order is per-process
+      h.update(repr(sorted(repr(e) for e in c)).encode())
+    elif isinstance(c, str) and len(c) >= 40:
+      continue                          # docstrings
+    else:
+      h.update(repr(c).encode())
+
+
 def fingerprint(cls):
   """Stable digest of the bytecode of every method the class itself defines
-  (same interpreter only)."""
+  (same interpreter version only; identical across processes)."""
   h = hashlib.sha1()
   found = False
   for name in sorted(vars(cls)):
@@ -102,10 +119,7 @@ def fingerprint(cls):
       continue
     found = True
     h.update(name.encode())
-    h.update(code.co_code)
-    h.update(repr(code.co_names).encode())
-    h.update(repr(tuple(c for c in code.co_consts
-                        if not isinstance(c, str) or len(c) < 40)).encode())
+    _digest_code(h, code)
   return h.hexdigest()[:16] if found else None
 
 
