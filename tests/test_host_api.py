@@ -152,3 +152,40 @@ def test_unchanged_reference_example_compiles_to_fixture(level):
   t = GameTemplate.from_engine(game)
   assert t == helpers.load_template('scrolly_maze_L%d' % level)
   assert t.game == N.GAME_SCROLLY_MAZE and t.n_actions == 5
+
+
+_ALL_EXAMPLES = [('scrolly_maze.py', (0,), 'scrolly_maze_L0'), ('warehouse_manager.py', (0,), 'warehouse_L0'),
+                 ('warehouse_manager.py', (1,), 'warehouse_L1'), ('warehouse_manager.py', (2,), 'warehouse_L2'),
+                 ('extraterrestrial_marauders.py', (), 'marauders'), ('hello_world.py', (), 'hello_world'),
+                 ('better_scrolly_maze.py', (0,), 'better_scrolly_maze_L0'),
+                 ('better_scrolly_maze.py', (1,), 'better_scrolly_maze_L1'),
+                 ('better_scrolly_maze.py', (2,), 'better_scrolly_maze_L2')]
+
+
+@needs_reference
+@pytest.mark.parametrize('hashseed', ['1', '4242'])
+def test_every_shipped_example_resolves_in_a_fresh_process(hashseed):
+  """Class -> device program matching must not depend on the process (string
+  hash seed, object addresses): each example file of the config games loads
+  unchanged and compiles to its committed fixture in a new interpreter."""
+  import subprocess
+  import sys
+  script = r'''
+import os, sys
+sys.path.insert(0, %r)
+from pycolab_amd import compat
+from pycolab_amd.compiler import GameTemplate
+from tests import helpers
+for fname, args, fixture in %r:
+  mod = compat.load_game_module(os.path.join(%r, fname))
+  t = GameTemplate.from_engine(mod.make_game(*args))
+  want = helpers.load_template(fixture)
+  if fixture == 'hello_world':  # its update schedule iterates a set of characters (hello_world.py:90)
+    assert sorted(t.schedule) == sorted(want.schedule) and t.game == want.game, fixture
+  else:
+    assert t == want, fixture
+print('ok')
+''' % (helpers.ROOT, _ALL_EXAMPLES, REF_EXAMPLES)
+  env = dict(os.environ, PYTHONHASHSEED=hashseed, PCX_NO_TORCH='1')
+  out = subprocess.run([sys.executable, '-c', script], env=env, capture_output=True, text=True, timeout=300)
+  assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
