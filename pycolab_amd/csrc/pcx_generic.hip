@@ -179,6 +179,26 @@ __device__ __forceinline__ bool thing_layer(const Ctx& x, int thing, int r, int 
   if (!x.k.occl || !raw) return raw;
   return top_char(x, r, c) == (int)tfield(x, thing, T_CH);
 }
+// Row r of a drape's layer in the last repaint, 64 columns at once: its
+// snapshot row, and with occlusion minus every cell a thing in front of it
+// covers (the same rule as thing_layer, without a per-cell z-order walk).
+__device__ __forceinline__ uint64_t drape_layer_row(const Ctx& x, int thing, int r) {
+  uint64_t bits = row_get(x, x.l.snapd, tfield(x, thing, T_IDX), r);
+  if (!x.k.occl || !bits) return bits;
+  const uint32_t above = tfield(x, thing, T_ABOVE);
+  const int lo = r * x.k.C, hi = lo + x.k.C;
+  for (int u = 0; u < x.k.NT; ++u) {
+    if (!((above >> u) & 1)) continue;
+    const uint32_t idx = tfield(x, u, T_IDX);
+    if (tfield(x, u, T_KIND) == 1) {
+      bits &= ~row_get(x, x.l.snapd, idx, r);
+    } else {
+      const int cell = x.l.snap[idx * WAVE + x.lane];
+      if (cell >= lo && cell < hi) bits &= ~(1ull << (cell - lo));
+    }
+  }
+  return bits;
+}
 // numpy `layers[c][r, col]` with Python index rules (negative wraps once)
 __device__ __forceinline__ bool layer_at(Ctx& x, int thing, int r, int c) {
   if (r < 0) r += x.k.R;
@@ -546,35 +566,104 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
   } else {
     if (x.v[3] == x.frame) return;
     x.v[3] = x.frame;
-    // columns of the *occluded* layer of 'X' in the last repaint that hold any X
+    // columns of the layer of 'X' in the last repaint that hold any X
+    // (np.flatnonzero(layers['X'].any(axis=0)), :246)
     uint64_t cols = 0;
-    for (int c = 0; c < C; ++c) {
-      bool any = false;
-      for (int r = 0; r < R && !any; ++r)
-        if (thing_layer(x, x.k.tx, r, c)) any = true;
-      if (any) cols |= 1ull << c;
-    }
+    for (int r = 0; r < R; ++r) cols |= drape_layer_row(x, x.k.tx, r);
     const int n = __popcll(cols);
     if (n == 0) { x.err |= ERR_INDEX; return; }  // np.random.choice([]) raises
     const uint64_t seed = ((uint64_t)x.k.seed_lo | ((uint64_t)x.k.seed_hi << 32)) ^ EM_RNG_SALT;
     int pick = (int)(action_hash(seed, (uint64_t)genv, (uint64_t)draws) % (uint32_t)n);
     ++draws;
-    int col = 0;
-    for (int c = 0; c < C; ++c)
-      if ((cols >> c) & 1) { if (pick == 0) { col = c; break; } --pick; }
-    int row = 0;
+    // the pick-th set column: drop the pick lowest set bits
+    uint64_t rest = cols;
+    for (int j = 0; j < pick; ++j) rest &= rest - 1;
+    const int col = __ffsll((unsigned long long)rest) - 1;
+    int row = 0;  // the lowest X of that column (np.max(np.flatnonzero(layers['X'][:, col])), :248)
     for (int r = 0; r < R; ++r)
-      if (thing_layer(x, x.k.tx, r, col)) row = r;
+      if ((drape_layer_row(x, x.k.tx, r) >> col) & 1) row = r;
+    (void)C;
     teleport(x, s, row + 1, col);
   }
 }
 
-__global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const Ptrs P, const StepArgs a,
+// Render phase (rendering.py:85-184, :187-301).  Occlusion was resolved per
+// environment in the logic phase, so every thing's layer is a mask already in
+// LDS and painting is order-free.  One iteration = one board dword (4 cells)
+// per lane, consecutive lanes = consecutive dwords of one or two environments,
+// so every plane store of a wave covers 256 contiguous bytes; the workgroup's
+// waves take the iterations round-robin.  NTC = the thing count rounded up:
+// the per-thing loop is unrolled and what describes a thing (where its mask
+// lives, its character, its layer plane) is read once, into scalar registers.
+template <int NTC>
+__device__ __forceinline__ void render_planes(const Consts& k, const L& l, const pcx_buffers& out, int64_t env0, int lane,
+                                              int wave, int nwaves, bool any_skip) {
+  const int QW = k.QW, FWP = k.FW | 1, pitch = k.pitch, NT = k.NT;
+  const uint32_t env_stride = (uint32_t)(1 + k.L) * (uint32_t)pitch;
+  uint8_t* const blk = out.planes + (size_t)env0 * env_stride;
+  auto uni32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  uint32_t src[NTC], ch4[NTC], plane[NTC];  // src: LDS word offset of the mask source, bit 31 = sprite
+#pragma unroll
+  for (int t = 0; t < NTC; ++t) {
+    src[t] = ch4[t] = plane[t] = 0;
+    if (t >= NT) continue;
+    const uint32_t kind = l.things[t * T_WORDS + T_KIND], idx = l.things[t * T_WORDS + T_IDX];
+    src[t] = uni32(kind == 0 ? (0x80000000u | (idx * WAVE)) : idx * WAVE * (uint32_t)FWP);
+    ch4[t] = uni32(l.things[t * T_WORDS + T_CH] * 0x01010101u);
+    plane[t] = uni32((1 + l.things[t * T_WORDS + T_LAYER]) * (uint32_t)pitch);
+  }
+  const bool occl = k.occl != 0;
+#pragma unroll 1
+  for (int it = wave; it < QW; it += nwaves) {
+    const uint32_t f = (uint32_t)it * WAVE + lane;
+    const uint32_t e = __umulhi(f, k.magic_q), q = f - e * QW;  // f / QW by 32-bit reciprocal
+    if (any_skip && l.skip[e]) continue;
+    uint8_t* const dst = blk + e * env_stride + q * 4;
+    const uint32_t flat_at = e * FWP + (q >> 3), sh = (q & 7) * 4;
+    uint32_t d = l.backdrop4[q], uni = 0;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      if (t >= NT) break;
+      uint32_t m, lay;
+      if (src[t] & 0x80000000u) {
+        const uint32_t at = (src[t] & 0x7FFFFFFFu) + e;
+        const uint2 sd = l.sdesc[at];
+        m = sd.x == q ? sd.y : 0u;
+        lay = m;
+        if (!occl) {  // rendering.py:236-278: the raw mask
+          const uint2 sr = l.sdescraw[at];
+          lay = sr.x == q ? sr.y : 0u;
+        }
+      } else {
+        const uint32_t bits = (l.flat[src[t] + flat_at] >> sh) & 0xFu;
+        const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+        m = (m01 << 8) - m01;
+        lay = m;
+        if (!occl) {
+          const uint32_t rb = (l.flatraw[src[t] + flat_at] >> sh) & 0xFu;
+          const uint32_t r01 = (rb * 0x00204081u) & 0x01010101u;
+          lay = (r01 << 8) - r01;
+        }
+      }
+      uni |= m;
+      d = (d & ~m) | (ch4[t] & m);
+      // rendering.py:177-179: after occlusion a thing's layer is its own mask
+      *reinterpret_cast<uint32_t*>(dst + plane[t]) = lay & 0x01010101u;
+    }
+    *reinterpret_cast<uint32_t*>(dst) = d;
+    for (int b = 0; b < k.n_bchars; ++b)
+      *reinterpret_cast<uint32_t*>(dst + (1 + l.laybc[b]) * pitch) = occl ? l.bdmask[b * QW + q] & ~uni : l.bdmask[b * QW + q];
+  }
+}
+
+__global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, const Ptrs P, const StepArgs a,
                                                          const pcx_buffers out) {
   extern __shared__ uint32_t lds[];
-  const int lane = threadIdx.x;
+  // A workgroup is 1, 2 or 4 waves around one group of 64 environments: wave 0
+  // steps them (lane == environment), then all waves share the render loop.
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int64_t env0 = (int64_t)blockIdx.x * WAVE, env = env0 + lane;
-  for (int i = lane; i < P.n_table_words; i += WAVE) lds[i] = P.tables[i];
+  for (int i = threadIdx.x; i < P.n_table_words; i += blockDim.x) lds[i] = P.tables[i];
   L l;
   l.things = lds + k.l_things; l.z = lds + k.l_z; l.sched = lds + k.l_sched;
   l.backdrop4 = lds + k.l_backdrop; l.bdmask = lds + k.l_bdmask; l.aux = lds + k.l_aux;
@@ -586,7 +675,7 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
   l.flatraw = lds + k.l_flatraw; l.sdescraw = reinterpret_cast<uint2*>(lds + k.l_sdescraw);
   __syncthreads();
 
-  const bool live = env < P.batch;
+  const bool live = wave == 0 && env < P.batch;  // the logic phase is wave 0's
   const int64_t bp = P.bpad;
   uint32_t* st = P.state + env;
   uint32_t flags = 0;
@@ -702,29 +791,35 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
     // curtains -> flat cell-bit vectors; a curtain loses the cells a curtain in
     // front of it also covers; a sprite is shown iff nothing in front covers
     // its cell, and a shown sprite takes its cell from every curtain.
-    const int FW = k.FW, C = k.C;
+    // flat word w of drape d of environment e: environment-major with an odd
+    // pitch, so that this phase (lane == e, same w) and the render phase (same
+    // e, consecutive w) both touch 32 different banks
+    const int FW = k.FW, FWP = k.FW | 1, C = k.C;
+#define GFLAT(d, w, e) ((((d) * WAVE) + (e)) * FWP + (w))
     for (int d = 0; d < k.ND; ++d) {
-      for (int w = 0; w < FW; ++w) l.flat[(d * FW + w) * WAVE + lane] = 0;
+      for (int w = 0; w < FW; ++w) l.flat[GFLAT(d, w, lane)] = 0;
       for (int r = 0; r < k.R; ++r)
         for (int w = 0; w < k.RW; ++w) {  // 32 columns of row r at a time
           const uint32_t bits = drape_rows(x, l.cur, d)[(size_t)(r * k.RW + w) * WAVE];
           if (!bits) continue;
           const int off = r * C + 32 * w, wi = off >> 5, sh = off & 31;
-          l.flat[(d * FW + wi) * WAVE + lane] |= bits << sh;
-          if (sh) l.flat[(d * FW + wi + 1) * WAVE + lane] |= bits >> (32 - sh);
+          l.flat[GFLAT(d, wi, lane)] |= bits << sh;
+          if (sh) l.flat[GFLAT(d, wi + 1, lane)] |= bits >> (32 - sh);
         }
     }
     if (a.export_curtains)
-      for (int i2 = 0; i2 < k.ND * FW; ++i2) P.curtains[(size_t)i2 * bp + env] = l.flat[i2 * WAVE + lane];
+      for (int d = 0; d < k.ND; ++d)
+        for (int w = 0; w < FW; ++w) P.curtains[(size_t)(d * FW + w) * bp + env] = l.flat[GFLAT(d, w, lane)];
     if (!k.occl)  // unoccluded layers are the raw masks (rendering.py:236-278)
-      for (int i2 = 0; i2 < k.ND * FW; ++i2) l.flatraw[i2 * WAVE + lane] = l.flat[i2 * WAVE + lane];
+      for (int d = 0; d < k.ND; ++d)
+        for (int w = 0; w < FW; ++w) l.flatraw[GFLAT(d, w, lane)] = l.flat[GFLAT(d, w, lane)];
     for (int t = 0; t < k.NT; ++t) {
       if (tfield(x, t, T_KIND) != 1) continue;
       const uint32_t d = tfield(x, t, T_IDX), above = tfield(x, t, T_ABOVE);
       for (int u = 0; u < k.NT; ++u) {
         if (!((above >> u) & 1) || tfield(x, u, T_KIND) != 1) continue;
         const uint32_t du = tfield(x, u, T_IDX);
-        for (int w = 0; w < FW; ++w) l.flat[(d * FW + w) * WAVE + lane] &= ~l.flat[(du * FW + w) * WAVE + lane];
+        for (int w = 0; w < FW; ++w) l.flat[GFLAT(d, w, lane)] &= ~l.flat[GFLAT(du, w, lane)];
       }
     }
     for (int t = 0; t < k.NT; ++t) {
@@ -739,10 +834,10 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
           if (!((above >> u) & 1)) continue;
           const uint32_t ui = tfield(x, u, T_IDX);
           if (tfield(x, u, T_KIND) == 0) { if (sprite_cell(x, ui) == cell) shown = false; }
-          else if ((l.flat[(ui * FW + wi) * WAVE + lane] >> sh) & 1) shown = false;
+          else if ((l.flat[GFLAT(ui, wi, lane)] >> sh) & 1) shown = false;
         }
         if (shown)
-          for (int d = 0; d < k.ND; ++d) l.flat[(d * FW + wi) * WAVE + lane] &= ~(1u << sh);
+          for (int d = 0; d < k.ND; ++d) l.flat[GFLAT(d, wi, lane)] &= ~(1u << sh);
       }
       l.sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
       if (!k.occl) l.sdescraw[s * WAVE + lane] = make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
@@ -751,52 +846,19 @@ __global__ __launch_bounds__(WAVE) void pcx_generic_step(const Consts k, const P
       P.track[s * bp + env] = tr | (tc << 8) | ((int)(l.flg[s * WAVE + lane] & 1) << 16) | ((int)do_reset << 24);
     }
   }
-  l.skip[lane] = skip;
+  if (wave == 0) l.skip[lane] = skip;
   __syncthreads();
   if (a.debug & 2) return;
 
-  // ---- render phase: the wavefront streams board + layers ---------------------
-  const int QW = k.QW, FW = k.FW, pitch = k.pitch;
-  const uint32_t env_stride = (uint32_t)(1 + k.L) * (uint32_t)pitch;
-  uint8_t* blk = out.planes + (size_t)env0 * env_stride;
-  const bool any_skip = __ballot(skip) != 0ull;
-  for (int it = 0; it < QW; ++it) {
-    const uint32_t f = (uint32_t)it * WAVE + lane;
-    const uint32_t e = __umulhi(f, k.magic_q), q = f - e * QW;  // f / QW by 32-bit reciprocal
-    if (any_skip && l.skip[e]) continue;
-    uint8_t* dst = blk + e * env_stride + q * 4;
-    uint32_t d = l.backdrop4[q], uni = 0;
-    for (int t = 0; t < k.NT; ++t) {
-      const uint32_t kind = l.things[t * T_WORDS + T_KIND], idx = l.things[t * T_WORDS + T_IDX];
-      uint32_t m;
-      if (kind == 0) {
-        const uint2 sd = l.sdesc[idx * WAVE + e];
-        m = sd.x == q ? sd.y : 0u;
-      } else {
-        const uint32_t bits = (l.flat[(idx * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
-        const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
-        m = (m01 << 8) - m01;
-      }
-      uni |= m;
-      const uint32_t ch4 = l.things[t * T_WORDS + T_CH] * 0x01010101u;
-      d = (d & ~m) | (ch4 & m);
-      uint32_t lay = m;  // rendering.py:177-179: after occlusion a thing's layer is its own mask
-      if (!k.occl) {     // rendering.py:236-278: the raw mask
-        if (kind == 0) {
-          const uint2 sd = l.sdescraw[idx * WAVE + e];
-          lay = sd.x == q ? sd.y : 0u;
-        } else {
-          const uint32_t bits = (l.flatraw[(idx * FW + (q >> 3)) * WAVE + e] >> ((q & 7) * 4)) & 0xFu;
-          const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
-          lay = (m01 << 8) - m01;
-        }
-      }
-      *reinterpret_cast<uint32_t*>(dst + (1 + l.things[t * T_WORDS + T_LAYER]) * pitch) = lay & 0x01010101u;
-    }
-    *reinterpret_cast<uint32_t*>(dst) = d;
-    for (int b = 0; b < k.n_bchars; ++b)
-      *reinterpret_cast<uint32_t*>(dst + (1 + l.laybc[b]) * pitch) = k.occl ? l.bdmask[b * QW + q] & ~uni : l.bdmask[b * QW + q];
+  // ---- render phase: every wave of the workgroup streams board + layers ---------
+  const bool any_skip = __ballot(l.skip[lane] != 0) != 0ull;
+  switch ((k.NT + 3) / 4) {
+    case 0: case 1: render_planes<4>(k, l, out, env0, lane, wave, nwaves, any_skip); break;
+    case 2: render_planes<8>(k, l, out, env0, lane, wave, nwaves, any_skip); break;
+    case 3: render_planes<12>(k, l, out, env0, lane, wave, nwaves, any_skip); break;
+    default: render_planes<16>(k, l, out, env0, lane, wave, nwaves, any_skip); break;
   }
+#undef GFLAT
 }
 
 // ---------------------------------------------------------------------------
@@ -821,6 +883,7 @@ class GenericBackend : public Backend {
  private:
   Consts k_{};
   int64_t batch_ = 0, bpad_ = 0;
+  int num_cus_ = 256;
   DevArray<uint32_t> tables_, state_, curtains_;
   DevArray<int32_t> track_;
   int n_table_words_ = 0;
@@ -1008,17 +1071,23 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.l_snap = off; off += k.NS * WAVE;
   k.l_cur = off; off += ndw * WAVE;
   k.l_snapd = off; off += ndw * WAVE;
-  k.l_flat = off; off += k.ND * k.FW * WAVE;
+  k.l_flat = off; off += k.ND * (k.FW | 1) * WAVE;
   off = (off + 1) & ~1;
   k.l_sdesc = off; off += 2 * k.NS * WAVE;
   k.l_skip = off; off += WAVE;
   k.l_corner = off; if (k.has_scroll) off += k.ND * WAVE;
   k.l_pmask = off; if (k.has_scroll) off += k.NS * WAVE;
   k.l_pframe = off; if (k.has_scroll) off += k.NS * WAVE;
-  k.l_flatraw = off; if (!k.occl) off += k.ND * k.FW * WAVE;
+  k.l_flatraw = off; if (!k.occl) off += k.ND * (k.FW | 1) * WAVE;
   off = (off + 1) & ~1;
   k.l_sdescraw = off; if (!k.occl) off += 2 * k.NS * WAVE;
   k.l_words = off;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      num_cus_ = prop.multiProcessorCount;
+  }
   if ((size_t)off * 4 > 160 * 1024)
     return set_error(PCX_E_UNSUPPORTED, "generic backend: template needs %d bytes of LDS per wave", off * 4);
   int rc;
@@ -1037,7 +1106,15 @@ int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_
   size_t lds = (size_t)k_.l_words * 4;
   if (lds > 64 * 1024)
     PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pcx_generic_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(pcx_generic_step, dim3((unsigned)(bpad_ / WAVE)), dim3(WAVE), lds, s, k_, P, a, out);
+  // Waves per workgroup (they share the render loop of the group's 64
+  // environments): more when LDS lets only a few workgroups onto a CU, or when
+  // the batch has fewer groups than the chip has room for.
+  const int64_t groups = bpad_ / WAVE;
+  const int fit = (int)((160 * 1024) / (lds ? lds : 1)) > 0 ? (int)((160 * 1024) / (lds ? lds : 1)) : 1;
+  int nwaves = fit * 4 <= 32 ? 4 : fit * 2 <= 32 ? 2 : 1;  // a CU holds 32 waves (measured best: profiles/r01_tuning.md)
+  if (groups < (int64_t)num_cus_ * fit) nwaves = 4;
+  if (const char* e = getenv("PCX_GENERIC_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nwaves = v; }
+  hipLaunchKernelGGL(pcx_generic_step, dim3((unsigned)groups), dim3(nwaves * WAVE), lds, s, k_, P, a, out);
   PCX_HIP(hipGetLastError());
   return 0;
 }

@@ -340,8 +340,10 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 // NS sprites.  SR/SC/SL: board rows, cols and layer count when known at
 // compile time (0 = take them from Consts); IP/IE: index of the player and of
 // the egocentric sprite when known at compile time (-1 = from Consts).
-template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC>
-__global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
+// COOP: small batches.  A workgroup is four waves around one group: wave 0
+// steps it, then all four share the render loop (iterations round-robin).
+template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false>
+__global__ __launch_bounds__(COOP ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out) {
   // A workgroup is two wavefronts with different jobs, looping over groups of
   // 64 environments: wave 0 (logic) steps group i+1 and leaves its render
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
 
   // blockDim.x == 64: one wave does both jobs back to back (no overlap).
   const bool solo = blockDim.x == WAVE;
-  const bool single = solo;  // logic and render of the same group in the same round
+  const bool single = solo || COOP;  // logic and render of the same group in the same round
   for (int round = single ? 0 : -1;; ++round) {
   const int64_t g_render = (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
   const int64_t g_logic = single ? g_render : g_render + gridDim.x;
@@ -834,10 +836,10 @@ __global__ __launch_bounds__(2 * WAVE) void pcx_scrolly_maze_step(const Consts k
   // divisions in the loop (v_mul_lo/_hi are quarter rate).
   // Static shape with at least 64 dwords per board: a lane wraps into the next
   // environment at most once per iteration, so the update is four selects.
-  constexpr bool INCR = SR != 0 && (SR * SC / 4) >= WAVE;
+  constexpr bool INCR = !COOP && SR != 0 && (SR * SC / 4) >= WAVE;
   uint32_t e = 0, q = lane, voff = 4u * lane, eF = 0;
 #pragma unroll 1
-  for (int it = 0; it < QW; ++it) {
+  for (int it = COOP ? wave : 0; it < QW; it += COOP ? (int)(blockDim.x >> 6) : 1) {
     uint32_t e_now, q_now, voff_now, eF_now;
     if constexpr (INCR) {
       e_now = e; q_now = q; voff_now = voff; eF_now = eF;
@@ -1175,7 +1177,15 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   Ptrs P{walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_};
   // Specialised instance for the shipped scrolly_maze shape (10x30 board,
   // 8 characters, 'abcP' sprites); anything else takes the generic instance.
-  if (!unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3) {
+  const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
+  // Small batches leave most CUs with one wave or none: let four waves share
+  // each group's render loop (COOP instance), one group per workgroup.
+  int coop_below = 5;  // groups per CU (measured crossover: profiles/r01_tuning.md)
+  if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
+  if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
+    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3((unsigned)groups), dim3(4 * WAVE),
+                       (size_t)k_.lds_words * 4, s, k_, P, a, out);
+  } else if (shipped_shape) {
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out);
   } else {
     switch (k_.NS) {

@@ -56,6 +56,22 @@ def test_hip_matches_oracle_hashed_actions(name):
   assert resets > 0 or not name.startswith(('scrolly_maze_L0', 'scrolly_maze_L1', 'marauders'))  # reset path exercised (L2 patrollers are boxed in)
 
 
+@pytest.mark.parametrize('name', LEVELS)
+def test_hip_matches_oracle_single_wave_launch_shape(name, monkeypatch):
+  """Small batches take the cooperative launch shape (four waves share a
+  group's render loop); BASELINE-size batches take single-wave workgroups.
+  Force the latter at test size and compare with the oracle as above."""
+  monkeypatch.setenv('PCX_COOP_BELOW', '0')
+  t = helpers.load_template(name)
+  B, T = 4096, 128
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  assert_same(hip, orc, 'frame 0')
+  for t0 in range(0, T, 16):
+    hip.step_hashed(0xC0FFEE, t0, 16); orc.step_hashed(0xC0FFEE, t0, 16)
+    assert_same(hip, orc, 'after step %d' % (t0 + 16))
+
+
 def test_hip_matches_oracle_quirky_actions():
   """Explicit action tapes with None / quit / out-of-range actions and no
   auto-reset (finished environments stay frozen)."""
