@@ -7,7 +7,6 @@ chosen for each entity.  It round-trips through `.npz` so that benchmark and
 GPU tests can run where the game files themselves are absent.
 """
 
-import ctypes
 import json
 
 import numpy as np

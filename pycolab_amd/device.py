@@ -8,7 +8,6 @@ in csrc/ -- nothing here computes.
 """
 
 import ctypes
-import os
 
 import numpy as np
 

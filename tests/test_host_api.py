@@ -2,7 +2,6 @@
 import ctypes
 import os
 
-import numpy as np
 import pytest
 
 from pycolab_amd import _native as N

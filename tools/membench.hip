@@ -492,6 +492,39 @@ __global__ __launch_bounds__(64) void fill_burst_rotate(uint8_t* planes) {
     }
   }
 }
+// Store pattern with cache-policy bits on the stores (gfx94x/gfx950: sc0, sc1, nt).
+#define MB_POLICY_KERNEL(NAME, BITS)                                                              \
+  template <int VALU>                                                                             \
+  __global__ __launch_bounds__(64) void NAME(uint8_t* planes) {                                   \
+    const int lane = threadIdx.x & 63;                                                            \
+    uint8_t* blk = planes + (size_t)blockIdx.x * 64 * 2700;                                       \
+    _Pragma("unroll 1") for (int it = 0; it < 75; ++it) {                                         \
+      uint32_t f = it * 64 + lane, e = f / 75, q = f - e * 75;                                    \
+      uint32_t v = f;                                                                             \
+      _Pragma("unroll") for (int j = 0; j < VALU; ++j) v = (v << 3) ^ (v >> 5) ^ 0x9E3779B1u;     \
+      uint8_t* dst = blk + e * 2700 + q * 4;                                                      \
+      uint32_t d[9];                                                                              \
+      _Pragma("unroll") for (int p = 0; p < 9; ++p) d[p] = v + p;                                 \
+      asm volatile("global_store_dword %0, %1, off " BITS "\n\t"                                   \
+                   "global_store_dword %0, %2, off offset:300 " BITS "\n\t"                        \
+                   "global_store_dword %0, %3, off offset:600 " BITS "\n\t"                        \
+                   "global_store_dword %0, %4, off offset:900 " BITS "\n\t"                        \
+                   "global_store_dword %0, %5, off offset:1200 " BITS "\n\t"                       \
+                   "global_store_dword %0, %6, off offset:1500 " BITS "\n\t"                       \
+                   "global_store_dword %0, %7, off offset:1800 " BITS "\n\t"                       \
+                   "global_store_dword %0, %8, off offset:2100 " BITS "\n\t"                       \
+                   "global_store_dword %0, %9, off offset:2400 " BITS                              \
+                   : : "v"(dst), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), \
+                       "v"(d[6]), "v"(d[7]), "v"(d[8]) : "memory");                                \
+    }                                                                                             \
+  }
+MB_POLICY_KERNEL(fill_pol_nt, "nt")
+MB_POLICY_KERNEL(fill_pol_sc1, "sc1")
+MB_POLICY_KERNEL(fill_pol_sc0sc1, "sc0 sc1")
+MB_POLICY_KERNEL(fill_pol_sc0, "sc0")
+MB_POLICY_KERNEL(fill_pol_ntsc1, "sc1 nt")
+MB_POLICY_KERNEL(fill_pol_all, "sc0 sc1 nt")
+
 // Role-specialised pipeline prototype: 256-thread workgroup = 3 worker waves +
 // 1 streamer wave, padded records (stride 2736 B).  Each worker owns a group of
 // 64 envs and fills an LDS slot with the records of CH envs per step (VALU work
@@ -583,11 +616,12 @@ int main() {
  "calib 16 ops, VALU only", "calib 45 ops, VALU only", "calib 90 ops, VALU only", "calib 0 ops, stores to L2", "calib 16 ops, stores to L2", "calib 45 ops, stores to L2", "calib 90 ops, stores to L2",
  "ring W=3 R=2, 20 ops", "ring W=3 R=4, 20 ops", "ring W=3 R=2, 45 ops", "ring W=3 R=4, 45 ops", "ring W=3 R=4, 0 ops", "ring W=4 R=2, 20 ops", "ring W=2 R=4, 20 ops", "ring W=7 R=2, 20 ops", "ring W=3 R=8, 20 ops",
  "ring W=3 R=4, 20 ops, lds 56000", "ring W=3 R=8, 45 ops, lds 55552", "ring W=3 R=8, 0 ops, lds 55552", "ring W=3 R=16, 20 ops, lds 110848", "ring W=4 R=8, 20 ops, lds 73984", "ring W=7 R=4, 20 ops, lds 64768", "ring W=7 R=8, 20 ops, lds 129280", "ring W=3 R=8, 20 ops, lds 80000", "ring W=5 R=8, 20 ops, lds 92416", "ring W=3 R=12, 20 ops, lds 83200",
- "burst unroll V=16 U=1", "burst unroll V=16 U=2", "burst unroll V=16 U=3", "burst unroll V=16 U=5", "burst unroll V=45 U=3", "burst unroll V=45 U=5", "burst rotate V=16 U=3", "burst rotate V=16 U=5", "burst rotate V=45 U=5"};
-  const int lds_bytes[] = {0, 0, 0, 0, 0, 4096, 8192, 10752, 16384, 4096, 4096, 4096, 0, 20480, 20480, 20480, 0, 0, 0, 0, 6 * 3 * 2736, 6 * 4 * 2736, 6 * 3 * 2736, 6 * 2 * 2736, 0,0,0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0,20480,20480,20480,20480,20480,10240,10240,10240,10240, 0,0,0,0,0,0,0, 14080,27904,14080,27904,27904,18688,18688,32512,55552, 56000,55552,55552,110848,73984,64768,129280,80000,92416,83200, 0,0,0,0,0,0,0,0,0};
+ "burst unroll V=16 U=1", "burst unroll V=16 U=2", "burst unroll V=16 U=3", "burst unroll V=16 U=5", "burst unroll V=45 U=3", "burst unroll V=45 U=5", "burst rotate V=16 U=3", "burst rotate V=16 U=5", "burst rotate V=45 U=5",
+ "stores nt, 0 ops", "stores nt, 16 ops", "stores sc1, 0 ops", "stores sc1, 16 ops", "stores sc0 sc1, 0 ops", "stores sc0 sc1, 16 ops", "stores sc0, 0 ops", "stores sc0, 16 ops", "stores sc1 nt, 0 ops", "stores sc1 nt, 16 ops", "stores sc0 sc1 nt, 0 ops", "stores sc0 sc1 nt, 16 ops"};
+  const int lds_bytes[] = {0, 0, 0, 0, 0, 4096, 8192, 10752, 16384, 4096, 4096, 4096, 0, 20480, 20480, 20480, 0, 0, 0, 0, 6 * 3 * 2736, 6 * 4 * 2736, 6 * 3 * 2736, 6 * 2 * 2736, 0,0,0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,0, 0,0,0,0,0, 0,0,0,0,0,20480,20480,20480,20480,20480,10240,10240,10240,10240, 0,0,0,0,0,0,0, 14080,27904,14080,27904,27904,18688,18688,32512,55552, 56000,55552,55552,110848,73984,64768,129280,80000,92416,83200, 0,0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,0,0,0,0};
   uint32_t* sink; CK(hipMalloc(&sink, 4096)); CK(hipMemset(sink, 0, 4096));
   const int first = getenv("MB_FIRST") ? atoi(getenv("MB_FIRST")) : 0;
-  for (int mode = first; mode < 110; ++mode) {
+  for (int mode = first; mode < 122; ++mode) {
     float best = 1e9;
     for (int rep = 0; rep < 12; ++rep) {
       CK(hipEventRecord(e0));
@@ -698,6 +732,18 @@ int main() {
         case 107: fill_burst_rotate<16, 3><<<envs / 64, 64>>>(a); break;
         case 108: fill_burst_rotate<16, 5><<<envs / 64, 64>>>(a); break;
         case 109: fill_burst_rotate<45, 5><<<envs / 64, 64>>>(a); break;
+        case 110: fill_pol_nt<0><<<envs / 64, 64>>>(a); break;
+        case 111: fill_pol_nt<16><<<envs / 64, 64>>>(a); break;
+        case 112: fill_pol_sc1<0><<<envs / 64, 64>>>(a); break;
+        case 113: fill_pol_sc1<16><<<envs / 64, 64>>>(a); break;
+        case 114: fill_pol_sc0sc1<0><<<envs / 64, 64>>>(a); break;
+        case 115: fill_pol_sc0sc1<16><<<envs / 64, 64>>>(a); break;
+        case 116: fill_pol_sc0<0><<<envs / 64, 64>>>(a); break;
+        case 117: fill_pol_sc0<16><<<envs / 64, 64>>>(a); break;
+        case 118: fill_pol_ntsc1<0><<<envs / 64, 64>>>(a); break;
+        case 119: fill_pol_ntsc1<16><<<envs / 64, 64>>>(a); break;
+        case 120: fill_pol_all<0><<<envs / 64, 64>>>(a); break;
+        case 121: fill_pol_all<16><<<envs / 64, 64>>>(a); break;
         default: fill_pattern_lds<<<envs / 64, 64, lds_bytes[mode]>>>(a); break;
       }
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
