@@ -44,7 +44,7 @@ struct Consts {
   int32_t game, R, C, cells, pitch, QW, L, NS, ND, NT, n_groups, RW, FW, NW, n_actions, n_bchars;
   int32_t occl;  // Engine(..., occlusion_in_layers)
   int32_t has_scroll, w_scroll;  // any Scrolly drape / egocentric walker; state offset of the protocol words
-  uint32_t magic_q;
+  uint32_t magic_q, magic_c;  // 32-bit reciprocals of QW and C (exhaustively checked on the host)
   uint32_t seed_lo, seed_hi, envoff_lo, envoff_hi;
   int32_t w_sflags, w_drapes;           // state word offsets
   int32_t ip;                           // thing index of 'P' (-1 if none)
@@ -63,6 +63,7 @@ struct Ptrs {
   int32_t* track;          // [NS][bpad]
   uint32_t* curtains;      // [ND][FW][bpad] raw curtain bits (export_curtains)
   int64_t batch, bpad;
+  unsigned long long* stats;  // PCX_DEBUG & 8: cycles per program id (64 slots) and per section (64..)
 };
 
 struct L {
@@ -568,8 +569,9 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
     x.v[3] = x.frame;
     // columns of the layer of 'X' in the last repaint that hold any X
     // (np.flatnonzero(layers['X'].any(axis=0)), :246)
+    auto layer_row = [&](int r) { return drape_layer_row(x, x.k.tx, r); };
     uint64_t cols = 0;
-    for (int r = 0; r < R; ++r) cols |= drape_layer_row(x, x.k.tx, r);
+    for (int r = 0; r < R; ++r) cols |= layer_row(r);
     const int n = __popcll(cols);
     if (n == 0) { x.err |= ERR_INDEX; return; }  // np.random.choice([]) raises
     const uint64_t seed = ((uint64_t)x.k.seed_lo | ((uint64_t)x.k.seed_hi << 32)) ^ EM_RNG_SALT;
@@ -581,8 +583,7 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
     const int col = __ffsll((unsigned long long)rest) - 1;
     int row = 0;  // the lowest X of that column (np.max(np.flatnonzero(layers['X'][:, col])), :248)
     for (int r = 0; r < R; ++r)
-      if ((drape_layer_row(x, x.k.tx, r) >> col) & 1) row = r;
-    (void)C;
+      if ((layer_row(r) >> col) & 1) row = r;
     teleport(x, s, row + 1, col);
   }
 }
@@ -656,7 +657,7 @@ __device__ __forceinline__ void render_planes(const Consts& k, const L& l, const
   }
 }
 
-__global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, const Ptrs P, const StepArgs a,
+__global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))) void pcx_generic_step(const Consts k, const Ptrs P, const StepArgs a,
                                                          const pcx_buffers out) {
   extern __shared__ uint32_t lds[];
   // A workgroup is 1, 2 or 4 waves around one group of 64 environments: wave 0
@@ -675,6 +676,9 @@ __global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, con
   l.flatraw = lds + k.l_flatraw; l.sdescraw = reinterpret_cast<uint2*>(lds + k.l_sdescraw);
   __syncthreads();
 
+  const bool timing = (a.debug & 8) != 0 && P.stats != nullptr;
+  const unsigned long long t_start = timing ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long c_sec[4] = {0, 0, 0, 0}, c_prog[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool live = wave == 0 && env < P.batch;  // the logic phase is wave 0's
   const int64_t bp = P.bpad;
   uint32_t* st = P.state + env;
@@ -715,12 +719,25 @@ __global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, con
       x.err = (flags >> F_ERR_SHIFT) & 7u;
       for (int j = 0; j < 4; ++j) x.v[j] = (int32_t)st[(W_V0 + j) * bp];
       dxv = (int)((flags >> 8) & 0xFF) - 1;
-      for (int s = 0; s < k.NS; ++s) l.pos[s * WAVE + lane] = st[(W_SPRITES + s) * bp];
+      for (int s0 = 0; s0 < k.NS; s0 += 4) {  // four loads in flight per round trip
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = s0 + j < k.NS ? st[(W_SPRITES + s0 + j) * bp] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (s0 + j < k.NS) l.pos[(s0 + j) * WAVE + lane] = v[j];
+      }
       for (int w = 0; w < (k.NS + 3) / 4; ++w) {
         const uint32_t f = st[(k.w_sflags + w) * bp];
         for (int j = 0; j < 4 && 4 * w + j < k.NS; ++j) l.flg[(4 * w + j) * WAVE + lane] = (f >> (8 * j)) & 0xFF;
       }
-      for (int i = 0; i < ndw; ++i) l.cur[i * WAVE + lane] = st[(k.w_drapes + i) * bp];
+      // four loads in flight per round trip (a plain copy loop waits for each one)
+      for (int i0 = 0; i0 < ndw; i0 += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = i0 + j < ndw ? st[(k.w_drapes + i0 + j) * bp] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (i0 + j < ndw) l.cur[(i0 + j) * WAVE + lane] = v[j];
+      }
       if (k.has_scroll) {
         x.registered = st[k.w_scroll * bp];
         for (int d = 0; d < k.ND; ++d) l.corner[d * WAVE + lane] = st[(k.w_scroll + 1 + d) * bp];
@@ -731,6 +748,8 @@ __global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, con
       }
     }
     snapshot(x);  // what the previous frame's last repaint showed
+    if (timing) c_sec[0] = __builtin_readcyclecounter() - t_start;  // state load
+    const unsigned long long t_play = timing ? __builtin_readcyclecounter() : 0ull;
     // ---- Engine.play(): engine.py:698-735 --------------------------------
     x.frame += 1;
     const int64_t genv = ((int64_t)k.envoff_lo | ((int64_t)k.envoff_hi << 32)) + env;
@@ -738,6 +757,7 @@ __global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, con
     for (int g = 0; g < k.n_groups; ++g) {
       for (; i < k.NT && (int)(l.sched[i] >> 8) == g; ++i) {
         const int thing = l.sched[i] & 0xFF;
+        const unsigned long long tp0 = timing ? __builtin_readcyclecounter() : 0ull;
         switch (tfield(x, thing, T_PROG)) {
           case PCX_PROG_WM_BOX: prog_wm_box(x, thing); break;
           case PCX_PROG_WM_JUDGE: prog_wm_judge(x, thing); break;
@@ -756,9 +776,17 @@ __global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, con
           case PCX_PROG_SCROLLY: prog_scrolly(x, thing); break;
           default: break;  // PCX_PROG_STATIC
         }
+        if (timing) {
+          const unsigned long long dt = __builtin_readcyclecounter() - tp0;
+          const int slot = (int)(tfield(x, thing, T_PROG) & 7);
+#pragma unroll
+          for (int b2 = 0; b2 < 8; ++b2) c_prog[b2] += slot == b2 ? dt : 0ull;
+        }
       }
       if (g + 1 < k.n_groups) snapshot(x);  // engine.py:735 (the last repaint is the render phase)
     }
+    if (timing) c_sec[1] = __builtin_readcyclecounter() - t_play;  // update groups
+    const unsigned long long t_wb = timing ? __builtin_readcyclecounter() : 0ull;
     // ---- _apply_and_clear_plot + state write-back ---------------------------
     flags = (x.game_over ? F_OVER : 0u) | ((x.err & 7u) << F_ERR_SHIFT) | ((uint32_t)((dxv + 1) & 0xFF) << 8);
     st[W_RNG * bp] = draws;
@@ -787,6 +815,8 @@ __global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, con
     out.frame[env] = x.frame;
     out.error[env] = (uint8_t)x.err;
 
+    if (timing) c_sec[2] = __builtin_readcyclecounter() - t_wb;  // write-back
+    const unsigned long long t_occ = timing ? __builtin_readcyclecounter() : 0ull;
     // ---- occlusion for the final repaint (engine.py:751-757) ----------------
     // curtains -> flat cell-bit vectors; a curtain loses the cells a curtain in
     // front of it also covers; a sprite is shown iff nothing in front covers
@@ -797,15 +827,20 @@ __global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, con
     const int FW = k.FW, FWP = k.FW | 1, C = k.C;
 #define GFLAT(d, w, e) ((((d) * WAVE) + (e)) * FWP + (w))
     for (int d = 0; d < k.ND; ++d) {
-      for (int w = 0; w < FW; ++w) l.flat[GFLAT(d, w, lane)] = 0;
+      // the rows' bits, concatenated: stream them through a 64-bit register so
+      // that every flat word is written once (no read-modify-write of LDS)
+      uint64_t acc = 0;
+      int have = 0, wi = 0;
       for (int r = 0; r < k.R; ++r)
-        for (int w = 0; w < k.RW; ++w) {  // 32 columns of row r at a time
-          const uint32_t bits = drape_rows(x, l.cur, d)[(size_t)(r * k.RW + w) * WAVE];
-          if (!bits) continue;
-          const int off = r * C + 32 * w, wi = off >> 5, sh = off & 31;
-          l.flat[GFLAT(d, wi, lane)] |= bits << sh;
-          if (sh) l.flat[GFLAT(d, wi + 1, lane)] |= bits >> (32 - sh);
+        for (int w = 0; w < k.RW; ++w) {  // up to 32 columns of row r at a time
+          const int nb = C - 32 * w < 32 ? C - 32 * w : 32;
+          uint32_t bits = drape_rows(x, l.cur, d)[(size_t)(r * k.RW + w) * WAVE];
+          if (nb < 32) bits &= (1u << nb) - 1u;
+          acc |= (uint64_t)bits << have;
+          have += nb;
+          if (have >= 32) { l.flat[GFLAT(d, wi, lane)] = (uint32_t)acc; ++wi; acc >>= 32; have -= 32; }
         }
+      for (; wi < FW; ++wi) { l.flat[GFLAT(d, wi, lane)] = (uint32_t)acc; acc = 0; }
     }
     if (a.export_curtains)
       for (int d = 0; d < k.ND; ++d)
@@ -845,6 +880,14 @@ __global__ __launch_bounds__(4 * WAVE) void pcx_generic_step(const Consts k, con
       sprite_true(x, s, tr, tc);
       P.track[s * bp + env] = tr | (tc << 8) | ((int)(l.flg[s * WAVE + lane] & 1) << 16) | ((int)do_reset << 24);
     }
+    if (timing) c_sec[3] = __builtin_readcyclecounter() - t_occ;  // occlusion + descriptors
+  }
+  if (timing && wave == 0 && lane == 0) {
+    atomicAdd(P.stats + 67, __builtin_readcyclecounter() - t_start);  // whole logic phase
+    atomicAdd(P.stats + 69, 1ull);
+    atomicAdd(P.stats + 64, c_sec[0]); atomicAdd(P.stats + 65, c_sec[1]);
+    atomicAdd(P.stats + 66, c_sec[2]); atomicAdd(P.stats + 68, c_sec[3]);
+    for (int b2 = 0; b2 < 8; ++b2) atomicAdd(P.stats + b2, c_prog[b2]);
   }
   if (wave == 0) l.skip[lane] = skip;
   __syncthreads();
@@ -885,6 +928,7 @@ class GenericBackend : public Backend {
   int64_t batch_ = 0, bpad_ = 0;
   int num_cus_ = 256;
   DevArray<uint32_t> tables_, state_, curtains_;
+  DevArray<unsigned long long> stats_;  // PCX_DEBUG & 8
   DevArray<int32_t> track_;
   int n_table_words_ = 0;
   std::vector<int> walker_;
@@ -899,7 +943,6 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.NS = t.n_sprites; k.ND = t.n_drapes; k.NT = t.n_things; k.n_groups = t.n_groups; k.n_actions = t.n_actions;
   if (k.C > 255 || k.R > 255 || k.L > MAX_L || k.NT > 24 || k.cells > 8192)
     return set_error(PCX_E_UNSUPPORTED, "generic backend: board larger than 255x255 / 8192 cells or more than %d characters", MAX_L);
-  if ((1 + k.L) * k.cells % 4 != 0 && false) return set_error(PCX_E_UNSUPPORTED, "unreachable");
   k.pitch = (k.cells + 3) & ~3;
   k.QW = k.pitch / 4;
   k.RW = (k.C + 31) / 32;
@@ -911,6 +954,11 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
       if ((uint32_t)(((uint64_t)x * m) >> 32) != x / k.QW) { ok = false; break; }
     if (!ok) return set_error(PCX_E_UNSUPPORTED, "generic backend: board too large for the 32-bit reciprocal");
     k.magic_q = m;
+    const uint32_t mc = (uint32_t)(((1ull << 32) + k.C - 1) / k.C);
+    for (uint32_t x = 0; x < (uint32_t)k.cells; ++x)
+      if ((uint32_t)(((uint64_t)x * mc) >> 32) != x / k.C) { ok = false; break; }
+    if (!ok) return set_error(PCX_E_UNSUPPORTED, "generic backend: board too large for the 32-bit reciprocal");
+    k.magic_c = mc;
   }
   k.seed_lo = (uint32_t)t.param[0]; k.seed_hi = (uint32_t)t.param[1];
   k.envoff_lo = (uint32_t)t.param[2]; k.envoff_hi = (uint32_t)t.param[3];
@@ -1102,7 +1150,12 @@ int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_
     int rc = curtains_.alloc((size_t)(k_.ND ? k_.ND : 1) * k_.FW * bpad_);
     if (rc) return rc;
   }
-  Ptrs P{tables_.ptr, n_table_words_, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
+  if ((a.debug & 8) && !stats_.ptr) {
+    int rc = stats_.alloc(128);
+    if (rc) return rc;
+  }
+  if (stats_.ptr) PCX_HIP(hipMemsetAsync(stats_.ptr, 0, 128 * sizeof(unsigned long long), s));
+  Ptrs P{tables_.ptr, n_table_words_, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_, stats_.ptr};
   size_t lds = (size_t)k_.l_words * 4;
   if (lds > 64 * 1024)
     PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pcx_generic_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1116,6 +1169,19 @@ int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_
   if (const char* e = getenv("PCX_GENERIC_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nwaves = v; }
   hipLaunchKernelGGL(pcx_generic_step, dim3((unsigned)groups), dim3(nwaves * WAVE), lds, s, k_, P, a, out);
   PCX_HIP(hipGetLastError());
+  if (stats_.ptr) {  // debugging aid: where the logic phase spends its cycles (lane 0 of every group)
+    unsigned long long h[128];
+    PCX_HIP(hipStreamSynchronize(s));
+    PCX_HIP(hipMemcpy(h, stats_.ptr, sizeof h, hipMemcpyDeviceToHost));
+    static int printed = 0;
+    if (printed++ % 32 == 8) {
+      const double n = (double)(h[69] ? h[69] : 1);
+      fprintf(stderr, "[pcx generic] cycles per group: load %.0f, update groups %.0f, write-back %.0f, occlusion %.0f, logic total %.0f; by program id mod 8:",
+              h[64] / n, h[65] / n, h[66] / n, h[68] / n, h[67] / n);
+      for (int p = 0; p < 8; ++p) if (h[p]) fprintf(stderr, " %d:%.0f", p, h[p] / n);
+      fprintf(stderr, "\n");
+    }
+  }
   return 0;
 }
 
