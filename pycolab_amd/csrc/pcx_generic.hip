@@ -29,7 +29,9 @@ constexpr int WAVE = 64;
 constexpr int MAX_L = 20;
 
 // per-thing table entry (uint32 words), staged into LDS
-enum : int { T_CH = 0, T_KIND, T_IDX, T_PROG, T_LAYER, T_ABOVE, T_FLAGS, T_P0, T_P1, T_IMP0, T_IMP1, T_IMP2, T_IMP3, T_WORDS };
+enum : int { T_CH = 0, T_KIND, T_IDX, T_PROG, T_LAYER, T_ABOVE, T_FLAGS, T_P0, T_P1, T_IMP0, T_IMP1, T_IMP2, T_IMP3,
+             T_ABOVE_S, T_ABOVE_D,  // the things in front, as a sprite-index mask and a drape-index mask
+             T_WORDS };
 constexpr uint32_t TF_WALKER = 1, TF_CONFINED = 2, TF_EGO = 4, TF_SCROLLY = 8;
 // Scrolly drapes reuse the impassable words: pattern table offset, PR | PC << 16,
 // have_margins | margin_rows << 8 | margin_cols << 16, words per pattern row
@@ -409,13 +411,13 @@ __device__ __forceinline__ void prog_wm_box(Ctx& x, int thing) {  // :214-226
   const int s = tfield(x, thing, T_IDX);
   int r, c;
   sprite_true(x, s, r, c);
-  switch (x.action) {
-    case 0: if (layer_at(x, x.k.ip, r + 1, c)) mw_move(x, thing, -1, 0); break;
-    case 1: if (layer_at(x, x.k.ip, r - 1, c)) mw_move(x, thing, 1, 0); break;
-    case 2: if (layer_at(x, x.k.ip, r, c + 1)) mw_move(x, thing, 0, -1); break;
-    case 3: if (layer_at(x, x.k.ip, r, c - 1)) mw_move(x, thing, 0, 1); break;
-    default: break;
-  }
+  // actions 0..3 = N, S, W, E: the box moves that way iff the player stands on
+  // its other side (one probe and one move for all four, not four code paths
+  // that a wave with mixed actions would walk one after the other)
+  const int a = x.action;
+  if ((unsigned)a > 3u) return;
+  const int dr = a == 0 ? -1 : a == 1 ? 1 : 0, dc = a == 2 ? -1 : a == 3 ? 1 : 0;
+  if (layer_at(x, x.k.ip, r - dr, c - dc)) mw_move(x, thing, dr, dc);
 }
 __device__ __forceinline__ void prog_wm_judge(Ctx& x, int thing) {  // :245-266
   const int d = tfield(x, thing, T_IDX);
@@ -533,8 +535,7 @@ __device__ __forceinline__ void prog_em_marauder(Ctx& x, int thing, int& dxv) { 
   for (int r = 0; r < R; ++r) row_put(x, x.l.cur, d, r, rot_cols(row_get(x, x.l.cur, d, r), dxv, C));
 }
 __device__ __forceinline__ void prog_em_player(Ctx& x, int thing) {  // :178-186
-  if (x.action == 0) mw_move(x, thing, 0, -1);
-  else if (x.action == 1) mw_move(x, thing, 0, 1);
+  if (x.action == 0 || x.action == 1) mw_move(x, thing, 0, x.action == 0 ? -1 : 1);
   else if (x.action == 4) terminate(x);
 }
 __device__ __forceinline__ void prog_em_upbolt(Ctx& x, int thing) {  // :198-220
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
 
   const bool timing = (a.debug & 8) != 0 && P.stats != nullptr;
   const unsigned long long t_start = timing ? __builtin_readcyclecounter() : 0ull;
-  unsigned long long c_sec[4] = {0, 0, 0, 0}, c_prog[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long c_sec[7] = {0, 0, 0, 0, 0, 0, 0}, c_prog[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool live = wave == 0 && env < P.batch;  // the logic phase is wave 0's
   const int64_t bp = P.bpad;
   uint32_t* st = P.state + env;
@@ -842,6 +843,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
         }
       for (; wi < FW; ++wi) { l.flat[GFLAT(d, wi, lane)] = (uint32_t)acc; acc = 0; }
     }
+    if (timing) c_sec[4] = __builtin_readcyclecounter() - t_occ;  // flat vectors built
     if (a.export_curtains)
       for (int d = 0; d < k.ND; ++d)
         for (int w = 0; w < FW; ++w) P.curtains[(size_t)(d * FW + w) * bp + env] = l.flat[GFLAT(d, w, lane)];
@@ -857,24 +859,29 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
         for (int w = 0; w < FW; ++w) l.flat[GFLAT(d, w, lane)] &= ~l.flat[GFLAT(du, w, lane)];
       }
     }
-    for (int t = 0; t < k.NT; ++t) {
+    if (timing) c_sec[5] = __builtin_readcyclecounter() - t_occ;  // + curtains over curtains
+    // every sprite's cell once (sdesc doubles as the scratch: x = cell, y = shown)
+    for (int s = 0; s < k.NS; ++s) l.sdesc[s * WAVE + lane] = make_uint2((uint32_t)sprite_cell(x, s), 0u);
+    for (int t = 0; t < k.NT; ++t) {  // back to front
       if (tfield(x, t, T_KIND) != 0) continue;
       const int s = tfield(x, t, T_IDX);
-      const int cell = sprite_cell(x, s);
+      const int cell = (int)l.sdesc[s * WAVE + lane].x;
       bool shown = cell >= 0;
       if (shown) {
-        const uint32_t above = tfield(x, t, T_ABOVE);
         const int wi = cell >> 5, sh = cell & 31;
-        for (int u = 0; u < k.NT; ++u) {
-          if (!((above >> u) & 1)) continue;
-          const uint32_t ui = tfield(x, u, T_IDX);
-          if (tfield(x, u, T_KIND) == 0) { if (sprite_cell(x, ui) == cell) shown = false; }
-          else if ((l.flat[GFLAT(ui, wi, lane)] >> sh) & 1) shown = false;
-        }
+        for (uint32_t m = tfield(x, t, T_ABOVE_S); m; m &= m - 1)
+          if ((int)l.sdesc[(__ffs((int)m) - 1) * WAVE + lane].x == cell) shown = false;
+        for (uint32_t m = tfield(x, t, T_ABOVE_D); m; m &= m - 1)
+          if ((l.flat[GFLAT(__ffs((int)m) - 1, wi, lane)] >> sh) & 1) shown = false;
         if (shown)
           for (int d = 0; d < k.ND; ++d) l.flat[GFLAT(d, wi, lane)] &= ~(1u << sh);
       }
-      l.sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
+      l.sdesc[s * WAVE + lane].y = shown ? 1u : 0u;
+    }
+    for (int s = 0; s < k.NS; ++s) {
+      const uint2 cs = l.sdesc[s * WAVE + lane];
+      const int cell = (int)cs.x;
+      l.sdesc[s * WAVE + lane] = make_uint2(cs.y ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
       if (!k.occl) l.sdescraw[s * WAVE + lane] = make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
       int tr, tc;
       sprite_true(x, s, tr, tc);
@@ -887,6 +894,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     atomicAdd(P.stats + 69, 1ull);
     atomicAdd(P.stats + 64, c_sec[0]); atomicAdd(P.stats + 65, c_sec[1]);
     atomicAdd(P.stats + 66, c_sec[2]); atomicAdd(P.stats + 68, c_sec[3]);
+    atomicAdd(P.stats + 70, c_sec[4]); atomicAdd(P.stats + 71, c_sec[5]);
     for (int b2 = 0; b2 < 8; ++b2) atomicAdd(P.stats + b2, c_prog[b2]);
   }
   if (wave == 0) l.skip[lane] = skip;
@@ -1052,6 +1060,11 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.n_bchars = 0;
   std::vector<uint32_t> bdmask, laybc, s2t(k.NS ? k.NS : 1, 0);
   for (int z = 0; z < k.NT; ++z) if (things[(size_t)z * T_WORDS + T_KIND] == 0) s2t[things[(size_t)z * T_WORDS + T_IDX]] = z;
+  for (int z = 0; z < k.NT; ++z)
+    for (int u = z + 1; u < k.NT; ++u) {
+      const uint32_t* f = &things[(size_t)u * T_WORDS];
+      things[(size_t)z * T_WORDS + (f[T_KIND] == 0 ? T_ABOVE_S : T_ABOVE_D)] |= 1u << f[T_IDX];
+    }
   for (int i = 0; i < k.L; ++i) {
     const int ch = t.chars[i];
     if (find_sprite(ch) >= 0 || find_drape(ch) >= 0) continue;
@@ -1176,8 +1189,8 @@ int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_
     static int printed = 0;
     if (printed++ % 32 == 8) {
       const double n = (double)(h[69] ? h[69] : 1);
-      fprintf(stderr, "[pcx generic] cycles per group: load %.0f, update groups %.0f, write-back %.0f, occlusion %.0f, logic total %.0f; by program id mod 8:",
-              h[64] / n, h[65] / n, h[66] / n, h[68] / n, h[67] / n);
+      fprintf(stderr, "[pcx generic] cycles per group: load %.0f, update groups %.0f, write-back %.0f, occlusion %.0f (flat vectors %.0f, curtain pairs %.0f, sprites %.0f), logic total %.0f; by program id mod 8:",
+              h[64] / n, h[65] / n, h[66] / n, h[68] / n, h[70] / n, (h[71] - h[70]) / n, (h[68] - h[71]) / n, h[67] / n);
       for (int p = 0; p < 8; ++p) if (h[p]) fprintf(stderr, " %d:%.0f", p, h[p] / n);
       fprintf(stderr, "\n");
     }
