@@ -570,7 +570,20 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
     x.v[3] = x.frame;
     // columns of the layer of 'X' in the last repaint that hold any X
     // (np.flatnonzero(layers['X'].any(axis=0)), :246)
-    auto layer_row = [&](int r) { return drape_layer_row(x, x.k.tx, r); };
+    // Few rows hold a bolt in front of X: note which (one bit per row), and
+    // every other row of the layer is just its snapshot row.
+    uint32_t busy_rows = 0;
+    if (x.k.occl) {
+      if (tfield(x, x.k.tx, T_ABOVE_D) != 0 || R > 32) busy_rows = 0xFFFFFFFFu;
+      for (uint32_t m = tfield(x, x.k.tx, T_ABOVE_S); m; m &= m - 1) {
+        const int cell = x.l.snap[(__ffs((int)m) - 1) * WAVE + x.lane];
+        if (cell >= 0) busy_rows |= 1u << (__umulhi((uint32_t)cell, x.k.magic_c) & 31u);
+      }
+    }
+    const uint32_t dx = tfield(x, x.k.tx, T_IDX);
+    auto layer_row = [&](int r) {
+      return ((busy_rows >> (r & 31)) & 1) ? drape_layer_row(x, x.k.tx, r) : row_get(x, x.l.snapd, dx, r);
+    };
     uint64_t cols = 0;
     for (int r = 0; r < R; ++r) cols |= layer_row(r);
     const int n = __popcll(cols);
