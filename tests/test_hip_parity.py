@@ -72,11 +72,14 @@ def test_hip_matches_oracle_single_wave_launch_shape(name, monkeypatch):
     assert_same(hip, orc, 'after step %d' % (t0 + 16))
 
 
-def test_hip_matches_oracle_quirky_actions():
+@pytest.mark.parametrize('name', ['scrolly_maze_L1', 'scrolly_custom_B', 'warehouse_L1', 'marauders', 'hello_world',
+                                  'better_scrolly_maze_L1', 'walkers_scroll_margins', 'marauders_unoccluded'])
+def test_hip_matches_oracle_quirky_actions(name):
   """Explicit action tapes with None / quit / out-of-range actions and no
   auto-reset (finished environments stay frozen)."""
-  t = helpers.load_template('scrolly_maze_L1')
-  B, T = 512, 160
+  t = helpers.load_template(name)
+  t.param[0] = 0xFACE  # RNG seed (marauders)
+  B, T = (512, 160) if name == 'scrolly_maze_L1' else (192, 96)
   rng = np.random.RandomState(3)
   hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
   hip.reset(); orc.reset()
