@@ -172,9 +172,22 @@ int pcx_engine_step(pcx_engine* e, const int32_t* actions_dev, int auto_reset, v
 
 int pcx_engine_step_n(pcx_engine* e, const int32_t* action_tape_dev, int T, int auto_reset, void* stream) {
   if (!e || !action_tape_dev || T < 0) return set_error(PCX_E_INVALID, "pcx_engine_step_n: bad arguments");
-  for (int t = 0; t < T; ++t) {
-    int rc = pcx_engine_step(e, action_tape_dev + (size_t)t * e->batch, auto_reset, stream);
+  if (!e->showtime) return set_error(PCX_E_STATE, "pcx_engine_step_n: call pcx_engine_reset first (its_showtime)");
+  PCX_HIP(hipSetDevice(e->device));
+  const int fuse = e->backend->max_fused_steps();
+  for (int t = 0; t < T;) {
+    const int n = T - t < fuse ? T - t : fuse;
+    pcx::StepArgs a;
+    a.actions = action_tape_dev + (size_t)t * e->batch;
+    a.n_steps = n; a.action_stride = e->batch;
+    a.auto_reset = auto_reset;
+    a.export_curtains = e->want_curtains;
+    a.debug = pcx::debug_flags();
+    int rc = e->backend->launch(a, e->out, (hipStream_t)stream);
     if (rc) return rc;
+    e->epoch += n;
+    e->curtains_fresh = e->want_curtains;
+    t += n;
   }
   return 0;
 }
@@ -184,14 +197,19 @@ int pcx_engine_step_hashed(pcx_engine* e, uint64_t seed, int64_t env_offset, int
   if (!e || T < 0) return set_error(PCX_E_INVALID, "pcx_engine_step_hashed: bad arguments");
   if (!e->showtime) return set_error(PCX_E_STATE, "pcx_engine_step_hashed: call pcx_engine_reset first");
   PCX_HIP(hipSetDevice(e->device));
-  for (int t = 0; t < T; ++t) {
+  const int fuse = e->backend->max_fused_steps();
+  for (int t = 0; t < T;) {
+    const int n = T - t < fuse ? T - t : fuse;
     pcx::StepArgs a;
     a.hashed = 1; a.seed = seed; a.env_offset = env_offset; a.t = t0 + t; a.auto_reset = auto_reset;
+    a.n_steps = n;
     a.export_curtains = e->want_curtains;
+    a.debug = pcx::debug_flags();
     int rc = e->backend->launch(a, e->out, (hipStream_t)stream);
     if (rc) return rc;
-    e->epoch++;
+    e->epoch += n;
     e->curtains_fresh = e->want_curtains;
+    t += n;
   }
   return 0;
 }

@@ -35,6 +35,10 @@ struct StepArgs {
   uint64_t seed = 0;
   int64_t env_offset = 0;
   int64_t t = 0;
+  // several consecutive steps in one launch (backends that can: max_fused_steps):
+  // step i takes actions + i * action_stride, or hash step t + i
+  int n_steps = 1;
+  int64_t action_stride = 0;
   int export_curtains = 0;  // write every drape's raw curtain bits to curtain_bits() (drape-tracking croppers)
   int debug = 0;  // ablation bits for profiling (PCX_DEBUG env): 1 skip entity updates, 2 skip phase B, 4 skip render descriptors
 };
@@ -66,6 +70,8 @@ class Backend {
   // Validate the template and upload constants / allocate state.
   virtual int init(const pcx_template& t, int64_t batch) = 0;
   virtual int launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) = 0;
+  // how many consecutive steps one launch() may take (StepArgs::n_steps)
+  virtual int max_fused_steps() const { return 1; }
   virtual int read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites,
                           uint8_t* curtains) = 0;
   virtual int64_t bytes_per_step() const = 0;

@@ -342,8 +342,11 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 // the egocentric sprite when known at compile time (-1 = from Consts).
 // COOP: small batches.  A workgroup is four waves around one group: wave 0
 // steps it, then all four share the render loop (iterations round-robin).
-template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false>
-__global__ __launch_bounds__(COOP ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
+// TFUSE: small batches, several consecutive steps in one launch
+// (StepArgs::n_steps): wave 0 steps the group for step i + 1 while waves 1-3
+// render step i out of the other descriptor buffer; one barrier per step.
+template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false>
+__global__ __launch_bounds__((COOP || TFUSE) ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out) {
   // A workgroup is two wavefronts with different jobs, looping over groups of
   // 64 environments: wave 0 (logic) steps group i+1 and leaves its render
@@ -393,9 +396,12 @@ __global__ __launch_bounds__(COOP ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_s
   const bool solo = blockDim.x == WAVE;
   const bool single = solo || COOP;  // logic and render of the same group in the same round
   for (int round = single ? 0 : -1;; ++round) {
-  const int64_t g_render = (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
-  const int64_t g_logic = single ? g_render : g_render + gridDim.x;
-  const bool have_render = round >= 0 && g_render < ngroups, have_logic = g_logic < ngroups;
+  // TFUSE: the rounds are the launch's steps of one and the same group
+  const int64_t g_render = TFUSE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
+  const int64_t g_logic = (single || TFUSE) ? g_render : g_render + gridDim.x;
+  const int tstep = TFUSE ? round + 1 : 0;  // which of the launch's steps the logic wave is on
+  const bool have_render = round >= 0 && g_render < ngroups && (!TFUSE || round < a.n_steps);
+  const bool have_logic = g_logic < ngroups && (!TFUSE || tstep < a.n_steps);
   if (!have_render && !have_logic) break;
   {
     const int buf = single ? 0 : (wave == 0) ? ((round + 1) & 1) : (round & 1);
@@ -424,9 +430,9 @@ __global__ __launch_bounds__(COOP ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_s
       do_reset = a.auto_reset != 0;
       skip = !do_reset;
     } else {
-      action = a.hashed ? (int)(action_hash(a.seed, (uint64_t)(a.env_offset + env), (uint64_t)a.t) %
+      action = a.hashed ? (int)(action_hash(a.seed, (uint64_t)(a.env_offset + env), (uint64_t)(a.t + tstep)) %
                                (uint32_t)k.n_actions)
-                        : a.actions[env];
+                        : a.actions[(int64_t)tstep * a.action_stride + env];
     }
   }
   if (!skip) {
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(COOP ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_s
   }  // have_logic
   }
   if (single) __syncthreads();
-  if ((single || wave == 1) && have_render && !(a.debug & 2)) {
+  if ((single || (TFUSE ? wave >= 1 : wave == 1)) && have_render && !(a.debug & 2)) {
 
 
   // ---- phase B: the wavefront streams the observation planes ---------------
@@ -836,10 +842,11 @@ __global__ __launch_bounds__(COOP ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_s
   // divisions in the loop (v_mul_lo/_hi are quarter rate).
   // Static shape with at least 64 dwords per board: a lane wraps into the next
   // environment at most once per iteration, so the update is four selects.
-  constexpr bool INCR = !COOP && SR != 0 && (SR * SC / 4) >= WAVE;
+  constexpr bool INCR = !COOP && !TFUSE && SR != 0 && (SR * SC / 4) >= WAVE;
   uint32_t e = 0, q = lane, voff = 4u * lane, eF = 0;
 #pragma unroll 1
-  for (int it = COOP ? wave : 0; it < QW; it += COOP ? (int)(blockDim.x >> 6) : 1) {
+  for (int it = COOP ? wave : TFUSE ? wave - 1 : 0; it < QW;
+       it += COOP ? (int)(blockDim.x >> 6) : TFUSE ? (int)(blockDim.x >> 6) - 1 : 1) {
     uint32_t e_now, q_now, voff_now, eF_now;
     if constexpr (INCR) {
       e_now = e; q_now = q; voff_now = voff; eF_now = eF;
@@ -899,6 +906,7 @@ class ScrollyMazeBackend : public Backend {
     return 4 + 4 * (int64_t)k_.NW + 4 * (int64_t)(k_.NW - k_.CW) + (int64_t)(1 + k_.L) * k_.cells + 15;
   }
   const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
+  int max_fused_steps() const override { return fused_ok_ ? 256 : 1; }
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
   int curtain_words() const override { return k_.FW; }
@@ -907,6 +915,7 @@ class ScrollyMazeBackend : public Backend {
 
  private:
   Consts k_{};
+  bool fused_ok_ = false;  // shipped shape and a batch small enough for the four-wave shapes
   int64_t batch_ = 0, bpad_ = 0;
   DevArray<uint32_t> walls_, backdrop4_, state_, curtains_;
   DevArray<uint16_t> rowstart_;
@@ -1137,6 +1146,15 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       num_cus_ = prop.multiProcessorCount;
   }
+  {
+    // several steps per launch (pcx_engine_step_n / _step_hashed) pay off where one
+    // wave per group cannot fill the chip; PCX_FUSE_STEPS=0 turns them off
+    int below = 5;
+    if (const char* e = getenv("PCX_COOP_BELOW")) below = atoi(e);
+    const char* f = getenv("PCX_FUSE_STEPS");
+    fused_ok_ = !(f && atoi(f) == 0) && !unoccluded_ && k.NS == 4 && k.R == 10 && k.C == 30 && k.L == 8 && k.ip == 3 &&
+                k.ie == 3 && bpad_ / WAVE < (int64_t)num_cus_ * below;
+  }
   int rc;
   if ((rc = walls_.upload(wb))) return rc;
   if ((rc = backdrop4_.upload(bd4))) return rc;
@@ -1182,7 +1200,11 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   // each group's render loop (COOP instance), one group per workgroup.
   int coop_below = 5;  // groups per CU (measured crossover: profiles/r01_tuning.md)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
-  if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
+  if (shipped_shape && waves_per_wg == 1 && a.n_steps > 1 && a.mode == 0) {
+    // several steps in this launch: the logic wave runs ahead of the render waves
+    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), dim3((unsigned)groups),
+                       dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out);
+  } else if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3((unsigned)groups), dim3(4 * WAVE),
                        (size_t)k_.lds_words * 4, s, k_, P, a, out);
   } else if (shipped_shape) {

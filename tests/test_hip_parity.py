@@ -72,6 +72,29 @@ def test_hip_matches_oracle_single_wave_launch_shape(name, monkeypatch):
     assert_same(hip, orc, 'after step %d' % (t0 + 16))
 
 
+@pytest.mark.parametrize('fuse', ['0', '1'])
+def test_hip_step_n_fused_and_unfused_match_oracle(fuse, monkeypatch):
+  """pcx_engine_step_n / _step_hashed take several steps per launch at small
+  batches (logic wave one step ahead of the render waves); PCX_FUSE_STEPS=0 is
+  the one-launch-per-step path.  Both against the oracle, odd chunk lengths."""
+  monkeypatch.setenv('PCX_FUSE_STEPS', fuse)
+  t = helpers.load_template('scrolly_maze_L0')
+  B = 1000
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  t0 = 0
+  for n in (1, 2, 3, 7, 64, 5, 300):
+    hip.step_hashed(0xABCD, t0, n); orc.step_hashed(0xABCD, t0, n)
+    t0 += n
+    assert_same(hip, orc, 'after %d steps (chunk %d)' % (t0, n))
+  rng = np.random.RandomState(11)
+  tape = rng.randint(0, 5, size=(37, B)).astype(np.int32)
+  hip.eng.step_n(tape)
+  for row in tape:
+    orc.step(row, auto_reset=True)
+  assert_same(hip, orc, 'after the tape')
+
+
 @pytest.mark.parametrize('name', ['scrolly_maze_L1', 'scrolly_custom_B', 'warehouse_L1', 'marauders', 'hello_world',
                                   'better_scrolly_maze_L1', 'walkers_scroll_margins', 'marauders_unoccluded'])
 def test_hip_matches_oracle_quirky_actions(name):
