@@ -1200,8 +1200,10 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   // each group's render loop (COOP instance), one group per workgroup.
   int coop_below = 5;  // groups per CU (measured crossover: profiles/r01_tuning.md)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
-  if (shipped_shape && waves_per_wg == 1 && a.n_steps > 1 && a.mode == 0) {
+  if (a.n_steps > 1) {
     // several steps in this launch: the logic wave runs ahead of the render waves
+    if (!shipped_shape || !fused_ok_ || a.mode != 0)
+      return set_error(PCX_E_INVALID, "scrolly_maze backend: %d steps in one launch are not available here", a.n_steps);
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), dim3((unsigned)groups),
                        dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out);
   } else if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
