@@ -627,6 +627,11 @@ __device__ __forceinline__ void render_planes(const Consts& k, const L& l, const
     ch4[t] = uni32(l.things[t * T_WORDS + T_CH] * 0x01010101u);
     plane[t] = uni32((1 + l.things[t * T_WORDS + T_LAYER]) * (uint32_t)pitch);
   }
+  constexpr int MAXB = 8;
+  const int NB = k.n_bchars;
+  uint32_t bplane[MAXB];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) bplane[b] = b < NB ? uni32((1 + l.laybc[b]) * (uint32_t)pitch) : 0u;
   const bool occl = k.occl != 0;
 #pragma unroll 1
   for (int it = wave; it < QW; it += nwaves) {
@@ -666,7 +671,15 @@ __device__ __forceinline__ void render_planes(const Consts& k, const L& l, const
       *reinterpret_cast<uint32_t*>(dst + plane[t]) = lay & 0x01010101u;
     }
     *reinterpret_cast<uint32_t*>(dst) = d;
-    for (int b = 0; b < k.n_bchars; ++b)
+    // characters only the backdrop paints: their layer is the precomputed mask,
+    // minus (with occlusion) whatever a thing covers
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+      if (b >= NB) break;
+      const uint32_t m = l.bdmask[b * QW + q];
+      *reinterpret_cast<uint32_t*>(dst + bplane[b]) = occl ? m & ~uni : m;
+    }
+    for (int b = MAXB; b < NB; ++b)
       *reinterpret_cast<uint32_t*>(dst + (1 + l.laybc[b]) * pitch) = occl ? l.bdmask[b * QW + q] & ~uni : l.bdmask[b * QW + q];
   }
 }
