@@ -58,3 +58,33 @@ def test_two_rank_shards_equal_one_unsharded_run(tmp_path):
   for name in ('reward', 'reward_set', 'discount', 'done'):
     np.testing.assert_array_equal(got[name], np.array(getattr(whole, name)), err_msg=name)
   assert got['done'].sum() > 0
+
+
+@pytest.mark.gpu
+def test_rccl_gather_of_device_scalars_single_rank():
+  """The gather runs on the engine's own device tensors over the "nccl"
+  backend (= RCCL on ROCm).  One GPU here, so the group has one rank; two
+  engines stand in for two shards (env_offset carries the global index) and
+  their concatenation must equal one unsharded engine."""
+  import torch
+  import torch.distributed as dist
+  from tests.hip_adapter import HipAdapter
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  torch.cuda.set_device(0)
+  dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+  try:
+    t = helpers.load_template('scrolly_maze_L0')
+    batch, steps = 1000, 48
+    whole = HipAdapter(t, batch); whole.reset(); whole.step_hashed(0xABCD, 0, steps)
+    parts = []
+    for rank in range(2):
+      lo, hi = pdist.shard_range(batch, rank, 2)
+      eng = HipAdapter(t, hi - lo, env_offset=lo); eng.reset(); eng.step_hashed(0xABCD, 0, steps, env_offset=lo)
+      tensors = [eng.eng.buffers[n].tensor for n in ('reward', 'reward_set', 'discount', 'done')]
+      assert all(x.is_cuda for x in tensors)
+      parts.append([g.cpu().numpy() for g in pdist.gather_scalars(*tensors)])  # world of 1: returns this shard
+    for i, name in enumerate(('reward', 'reward_set', 'discount', 'done')):
+      np.testing.assert_array_equal(np.concatenate([parts[0][i], parts[1][i]]), whole.read(name), err_msg=name)
+  finally:
+    dist.destroy_process_group()
