@@ -684,10 +684,10 @@ __device__ __forceinline__ void render_planes(const Consts& k, const L& l, const
   }
 }
 
-__global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))) void pcx_generic_step(const Consts k, const Ptrs P, const StepArgs a,
+__global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))) void pcx_generic_step(const Consts k, const Ptrs P, const StepArgs a,
                                                          const pcx_buffers out) {
   extern __shared__ uint32_t lds[];
-  // A workgroup is 1, 2 or 4 waves around one group of 64 environments: wave 0
+  // A workgroup is 1, 2, 4 or 8 waves around one group of 64 environments: wave 0
   // steps them (lane == environment), then all waves share the render loop.
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int64_t env0 = (int64_t)blockIdx.x * WAVE, env = env0 + lane;
@@ -1203,9 +1203,9 @@ int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_
   // the batch has fewer groups than the chip has room for.
   const int64_t groups = bpad_ / WAVE;
   const int fit = (int)((160 * 1024) / (lds ? lds : 1)) > 0 ? (int)((160 * 1024) / (lds ? lds : 1)) : 1;
-  int nwaves = fit * 4 <= 32 ? 4 : fit * 2 <= 32 ? 2 : 1;  // a CU holds 32 waves (measured best: profiles/r01_tuning.md)
-  if (groups < (int64_t)num_cus_ * fit) nwaves = 4;
-  if (const char* e = getenv("PCX_GENERIC_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nwaves = v; }
+  int nwaves = fit * 8 <= 16 ? 8 : fit * 4 <= 32 ? 4 : fit * 2 <= 32 ? 2 : 1;  // a CU holds 32 waves (measured best: profiles/r01_tuning.md)
+  if (groups < (int64_t)num_cus_ * (fit < 4 ? fit : 4)) nwaves = 8;  // the chip is underfilled: split the render loop further
+  if (const char* e = getenv("PCX_GENERIC_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nwaves = v; }
   hipLaunchKernelGGL(pcx_generic_step, dim3((unsigned)groups), dim3(nwaves * WAVE), lds, s, k_, P, a, out);
   PCX_HIP(hipGetLastError());
   if (stats_.ptr) {  // debugging aid: where the logic phase spends its cycles (lane 0 of every group)
