@@ -340,13 +340,13 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 // NS sprites.  SR/SC/SL: board rows, cols and layer count when known at
 // compile time (0 = take them from Consts); IP/IE: index of the player and of
 // the egocentric sprite when known at compile time (-1 = from Consts).
-// COOP: small batches.  A workgroup is four waves around one group: wave 0
-// steps it, then all four share the render loop (iterations round-robin).
+// COOP: small batches.  A workgroup is four or eight waves around one group:
+// wave 0 steps it, then all of them share the render loop (iterations round-robin).
 // TFUSE: small batches, several consecutive steps in one launch
 // (StepArgs::n_steps): wave 0 steps the group for step i + 1 while waves 1-3
 // render step i out of the other descriptor buffer; one barrier per step.
 template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false>
-__global__ __launch_bounds__((COOP || TFUSE) ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
+__global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out) {
   // A workgroup is two wavefronts with different jobs, looping over groups of
   // 64 environments: wave 0 (logic) steps group i+1 and leaves its render
@@ -1207,8 +1207,10 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), dim3((unsigned)groups),
                        dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out);
   } else if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
-    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3((unsigned)groups), dim3(4 * WAVE),
-                       (size_t)k_.lds_words * 4, s, k_, P, a, out);
+    int coop_waves = groups <= num_cus_ ? 8 : 4;  // at most one group per CU: split the render loop eight ways
+    if (const char* e = getenv("PCX_COOP_WAVES")) coop_waves = atoi(e) == 4 ? 4 : 8;
+    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3((unsigned)groups),
+                       dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out);
   } else if (shipped_shape) {
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out);
   } else {
