@@ -58,6 +58,8 @@ SPECS = {
     'scrolly_custom_E': (105, 30, 24, (10, 24), 'cbP', 'c#Pb@'),
 }
 NAMES = sorted(SPECS)
+# also recorded with Engine(occlusion_in_layers=False): one, two and three sprites
+UNOCCLUDED = ['scrolly_custom_A', 'scrolly_custom_C', 'scrolly_custom_E']
 
 
 def level_art(name):

@@ -365,6 +365,10 @@ def main():
         quit_action=5, seed=41, template_name='scrolly_maze_L1_unoccluded', seeker=True, unoccluded=True)
     run('warehouse_L0_unoccluded', lambda: warehouse_manager.make_game(0), E=16, T=128, n_ordinary=5,
         quit_action=5, seed=42, template_name='warehouse_L0_unoccluded', unoccluded=True)
+    for i, base in enumerate(custom_levels.UNOCCLUDED):
+      run(base + '_unoccluded', lambda: custom_levels.make_game(base, scrolly_maze, ref_ascii_art, ref_drapes),
+          E=12, T=128, n_ordinary=5, quit_action=5, seed=91 + i, template_name=base + '_unoccluded', seeker=True,
+          unoccluded=True)
     patch_u = ChoicePatch(seed=0x5EED)
     numpy.random.choice = patch_u
     run('marauders_unoccluded', extraterrestrial_marauders.make_game, E=16, T=192, n_ordinary=4,
