@@ -48,14 +48,16 @@ def _draw(seed, rows, cols, board, sprites, wall_p, coin_p, mark_beneath):
 
 # name -> (seed, maze rows, maze cols, board (rows, cols), sprites in update order, z_order)
 # Board shapes: 18 dwords per board (less than one wavefront's 64), exactly 64,
-# 60, and 10; one to four sprites; the player at the back, the middle and the
-# front of the z-order.
+# 60, and 10 (and 40, 36); one to six sprites; the player at the back, the
+# middle and the front of the z-order.
 SPECS = {
     'scrolly_custom_A': (101, 14, 25, (6, 12), 'aP', 'a@#P'),
     'scrolly_custom_B': (102, 20, 40, (8, 32), 'abcP', 'P#@cba'),
     'scrolly_custom_C': (103, 12, 20, (12, 20), 'P', '#P@'),
     'scrolly_custom_D': (104, 9, 31, (5, 8), 'bP', '@bP#'),
     'scrolly_custom_E': (105, 30, 24, (10, 24), 'cbP', 'c#Pb@'),
+    'scrolly_custom_F': (106, 16, 40, (8, 20), 'abcdP', 'dcba@#P'),
+    'scrolly_custom_G': (107, 18, 30, (9, 16), 'abcdeP', 'Pe@d#cba'),
 }
 NAMES = sorted(SPECS)
 # also recorded with Engine(occlusion_in_layers=False): one, two and three sprites

@@ -37,7 +37,8 @@ namespace pcx {
 namespace sm {
 
 constexpr int WAVE = 64;
-constexpr int MAX_NS = 6;   // sprites (patrollers + player)
+constexpr int MAX_NS = 6;   // sprites (patrollers + player); their flag nibbles share one state word
+static_assert(MAX_NS * 4 <= 32, "sprite flag nibbles must fit the W_SFLAGS word");
 constexpr int MAX_Z = 8;
 constexpr int MAX_L = 16;
 
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     for (int s = 0; s < NS; ++s) {
       w[s].vr = pos_r(spos[s]);
       w[s].vc = pos_c(spos[s]);
-      uint32_t f = sflags >> (8 * s);
+      uint32_t f = sflags >> (4 * s);  // four bits per sprite (MAX_NS * 4 <= 32)
       w[s].vis = f & 1;
       w[s].prior = (f >> 1) & 1;
       w[s].var = (f >> 2) & 1;
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       st[(W_SPOS + s) * bp] = pack_pos(w[s].vr, w[s].vc);
-      sf |= ((uint32_t)w[s].vis | ((uint32_t)w[s].prior << 1) | ((uint32_t)w[s].var << 2)) << (8 * s);
+      sf |= ((uint32_t)w[s].vis | ((uint32_t)w[s].prior << 1) | ((uint32_t)w[s].var << 2)) << (4 * s);
       const bool on = on_board(k, w[s].vr, w[s].vc);
       P.track[k.tmpl_index[s] * bp + env] = (on ? w[s].vr : 0) | ((on ? w[s].vc : 0) << 8) | (w[s].vis << 16) |
                               ((int)do_reset << 24);
@@ -1104,7 +1105,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     const pcx_sprite_desc& sd = *sp[s];
     k.init[W_SPOS + s] = ((uint32_t)sd.vrow & 0xFFFFu) | ((uint32_t)sd.vcol << 16);
     uint32_t var = sd.program == PCX_PROG_SM_PATROLLER ? (uint32_t)(sd.param[0] != 0) : 0u;  // _moving_east, scrolly_maze.py:282
-    sf |= ((uint32_t)(sd.visible != 0) | ((uint32_t)(sd.prior_visible != 0) << 1) | (var << 2)) << (8 * s);
+    sf |= ((uint32_t)(sd.visible != 0) | ((uint32_t)(sd.prior_visible != 0) << 1) | (var << 2)) << (4 * s);
   }
   k.init[W_SFLAGS] = sf;
   // the initial curtains must be the pattern windows the Scrolly ctor made
@@ -1245,7 +1246,7 @@ int ScrollyMazeBackend::read_things(int64_t env0, int64_t n, pcx_sprite_state* s
         o.vrow = (int16_t)(pw & 0xFFFF); o.vcol = (int16_t)(pw >> 16);
         bool on = o.vrow >= 0 && o.vrow < k.R && o.vcol >= 0 && o.vcol < k.C;
         o.row = on ? o.vrow : 0; o.col = on ? o.vcol : 0;
-        o.visible = (word(W_SFLAGS, i) >> (8 * s)) & 1;
+        o.visible = (word(W_SFLAGS, i) >> (4 * s)) & 1;
       }
     if (curtains) {
       for (int di = 0; di < 2; ++di) {
