@@ -74,6 +74,23 @@ def test_hip_matches_oracle_single_wave_launch_shape(name, monkeypatch):
     assert_same(hip, orc, 'after step %d' % (t0 + 16))
 
 
+@pytest.mark.parametrize('waves', ['1', '2', '4'])
+@pytest.mark.parametrize('name', ['marauders', 'warehouse_L2'])
+def test_hip_table_driven_kernel_waves_per_workgroup(name, waves, monkeypatch):
+  """The table-driven kernel picks 1, 2, 4 or 8 waves per workgroup from the
+  batch and the LDS footprint; test-size batches always get 8.  Force the
+  others (what BASELINE-size batches run) and compare with the oracle."""
+  monkeypatch.setenv('PCX_GENERIC_WAVES', waves)
+  t = helpers.load_template(name)
+  t.param[0] = 0xD1CE
+  B = 320
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  for t0 in range(0, 96, 16):
+    hip.step_hashed(0x5EED, t0, 16); orc.step_hashed(0x5EED, t0, 16)
+    assert_same(hip, orc, 'after step %d' % (t0 + 16))
+
+
 @pytest.mark.parametrize('fuse', ['0', '1'])
 def test_hip_step_n_fused_and_unfused_match_oracle(fuse, monkeypatch):
   """pcx_engine_step_n / _step_hashed take several steps per launch at small
