@@ -188,3 +188,16 @@ print('ok')
   env = dict(os.environ, PYTHONHASHSEED=hashseed, PCX_NO_TORCH='1')
   out = subprocess.run([sys.executable, '-c', script], env=env, capture_output=True, text=True, timeout=300)
   assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+@needs_reference
+def test_reference_ascii_art_test_file_passes_unchanged():
+  """The reference's own tests/ascii_art_test.py, loaded unchanged with
+  `pycolab` aliased to this package, passes (it is the one reference test file
+  that needs no Python-side entity stepping)."""
+  import unittest
+  mod = compat.load_game_module('/root/reference/pycolab/tests/ascii_art_test.py')
+  suite = unittest.defaultTestLoader.loadTestsFromModule(mod)
+  assert suite.countTestCases() >= 1
+  result = unittest.TextTestRunner(verbosity=0).run(suite)
+  assert result.wasSuccessful(), result.failures + result.errors
