@@ -199,7 +199,9 @@ int pcx_engine_step(pcx_engine* e, const int32_t* actions_dev, int auto_reset,
                     void* stream);
 
 /* T consecutive steps from a device action tape int32[T][batch]. Observations
- * of intermediate steps are overwritten, exactly as T calls to step would. */
+ * of intermediate steps are overwritten, exactly as T calls to step would.
+ * The engine may take several of the steps in one kernel launch (small
+ * batches); the results are the same either way. */
 int pcx_engine_step_n(pcx_engine* e, const int32_t* action_tape_dev, int T,
                       int auto_reset, void* stream);
 
