@@ -74,6 +74,20 @@ def test_hip_matches_oracle_single_wave_launch_shape(name, monkeypatch):
     assert_same(hip, orc, 'after step %d' % (t0 + 16))
 
 
+def test_hip_two_wave_pipeline_shape_matches_oracle(monkeypatch):
+  """PCX_WAVES_PER_WG=2: persistent two-wave workgroups, wave 0 steps group
+  i + 1 while wave 1 renders group i (an opt-in launch shape)."""
+  monkeypatch.setenv('PCX_WAVES_PER_WG', '2')
+  monkeypatch.setenv('PCX_WGS_PER_CU', '1')  # fewer workgroups than groups: every workgroup loops
+  t = helpers.load_template('scrolly_maze_L2')
+  B = 64 * 700 + 5
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  for t0 in range(0, 48, 12):
+    hip.step_hashed(0xBEE, t0, 12); orc.step_hashed(0xBEE, t0, 12)
+    assert_same(hip, orc, 'after step %d' % (t0 + 12))
+
+
 @pytest.mark.parametrize('waves', ['1', '2', '4'])
 @pytest.mark.parametrize('name', ['marauders', 'warehouse_L2'])
 def test_hip_table_driven_kernel_waves_per_workgroup(name, waves, monkeypatch):
