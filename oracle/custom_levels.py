@@ -84,3 +84,44 @@ def make_game(name, example, ascii_art, prefab_drapes):
       drapes={'#': ascii_art.Partial(example.MazeDrape, **info.kwargs('#')),
               '@': ascii_art.Partial(example.CashDrape, **info.kwargs('@'))},
       update_schedule=[['#'], list(sprites), ['@']], z_order=z_order)
+
+
+# ---- warehouse_manager levels that the reference does not ship -------------------
+# The example's own classes (BoxSprite, JudgeDrape, PlayerSprite;
+# warehouse_manager.py:181-295) built the way warehouse_manager.make_game does
+# (:139-178): two boxes on a 7x9 board, and all ten box characters on a 12x18
+# board (twelve things, sixteen characters).
+WAREHOUSE_ART = {
+    'warehouse_custom_A': ['.........',
+                           '.#######.',
+                           '.# _   #.',
+                           '.# 1 2 #.',
+                           '.#  P _#.',
+                           '.#######.',
+                           '.........'],
+    'warehouse_custom_B': ['..................',
+                           '.################.',
+                           '.#   _  #  _    #.',
+                           '.# 1   2#   3 _ #.',
+                           '.#   #     #    #.',
+                           '.# _ # 4 5 #  6 #.',
+                           '.#   #     #    #.',
+                           '.#  7   P    8  #.',
+                           '.# _    ##   _  #.',
+                           '.#  9  _  0  _  #.',
+                           '.################.',
+                           '..................'],
+}
+WAREHOUSE_NAMES = sorted(WAREHOUSE_ART)
+for _name, _art in WAREHOUSE_ART.items():
+  assert len(set(len(_row) for _row in _art)) == 1, _name
+
+
+def make_warehouse(name, example, ascii_art):
+  """warehouse_manager.make_game (warehouse_manager.py:139-178) for WAREHOUSE_ART[name]."""
+  art = WAREHOUSE_ART[name]
+  boxes = [c for c in '1234567890' if c in ''.join(art)]
+  sprites = {c: example.BoxSprite for c in boxes}
+  sprites['P'] = example.PlayerSprite
+  return ascii_art.ascii_art_to_game(art, ' ', sprites, {'X': example.JudgeDrape},
+                                     update_schedule=[boxes, ['X'], ['P']])

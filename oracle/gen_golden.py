@@ -319,6 +319,9 @@ def main():
   for i, name in enumerate(custom_levels.NAMES):  # other board shapes / sprite sets / z-orders
     run(name, lambda: custom_levels.make_game(name, scrolly_maze, ref_ascii_art, ref_drapes),
         E=24, T=160, n_ordinary=5, quit_action=5, seed=81 + i, template_name=name, seeker=True)
+  for i, name in enumerate(custom_levels.WAREHOUSE_NAMES):
+    run(name, lambda: custom_levels.make_warehouse(name, warehouse_manager, ref_ascii_art),
+        E=24, T=160, n_ordinary=5, quit_action=5, seed=71 + i, template_name=name)
   for level in (0, 1, 2):
     run('warehouse_L%d' % level, lambda: warehouse_manager.make_game(level),
         E=32, T=192, n_ordinary=5, quit_action=5, seed=17 + level,
