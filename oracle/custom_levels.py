@@ -125,3 +125,40 @@ def make_warehouse(name, example, ascii_art):
   sprites['P'] = example.PlayerSprite
   return ascii_art.ascii_art_to_game(art, ' ', sprites, {'X': example.JudgeDrape},
                                      update_schedule=[boxes, ['X'], ['P']])
+
+
+# ---- an extraterrestrial_marauders board that the reference does not ship -----------
+# Same entity set (the example's classes read the module's bolt character lists),
+# on a 14x27 board: rows of one 32-bit word instead of two, three marauder rows,
+# three bunkers.  Row 10 stays the invasion line (extraterrestrial_marauders.py:147).
+MARAUDERS_ART = {
+    'marauders_custom_A': ['   X  X  X  X  X  X  X     ',
+                           '    X  X  X  X  X  X  X    ',
+                           '   X  X  X  X  X  X  X     ',
+                           '                           ',
+                           '                           ',
+                           '                           ',
+                           '                           ',
+                           '                           ',
+                           '                           ',
+                           '                           ',
+                           '   BBB     BBB     BBB     ',
+                           '   BBB     BBB     BBB     ',
+                           '                           ',
+                           '  P                        '],
+}
+MARAUDERS_NAMES = sorted(MARAUDERS_ART)
+for _name, _art in MARAUDERS_ART.items():
+  assert len(set(len(_row) for _row in _art)) == 1, _name
+
+
+def make_marauders(name, example, ascii_art):
+  """extraterrestrial_marauders.make_game (:91-101) for MARAUDERS_ART[name]."""
+  bolts = example.UPWARD_BOLT_CHARS + example.DOWNWARD_BOLT_CHARS
+  return ascii_art.ascii_art_to_game(
+      MARAUDERS_ART[name], what_lies_beneath=' ',
+      sprites=dict([('P', example.PlayerSprite)] +
+                   [(c, example.UpwardLaserBoltSprite) for c in example.UPWARD_BOLT_CHARS] +
+                   [(c, example.DownwardLaserBoltSprite) for c in example.DOWNWARD_BOLT_CHARS]),
+      drapes=dict(X=example.MarauderDrape, B=example.BunkerDrape),
+      update_schedule=['P', 'B', 'X'] + list(bolts))

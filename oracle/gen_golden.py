@@ -382,6 +382,11 @@ def main():
   numpy.random.choice = patch
   run('marauders', extraterrestrial_marauders.make_game, E=32, T=256, n_ordinary=4, quit_action=4,
       seed=37, template_name='marauders', choice=patch)
+  for i, name in enumerate(custom_levels.MARAUDERS_NAMES):
+    patch_c = ChoicePatch(seed=0x5EED)
+    numpy.random.choice = patch_c
+    run(name, lambda: custom_levels.make_marauders(name, extraterrestrial_marauders, ref_ascii_art),
+        E=24, T=224, n_ordinary=4, quit_action=4, seed=131 + i, template_name=name, choice=patch_c)
 
 
 if __name__ == '__main__':
