@@ -162,3 +162,33 @@ def make_marauders(name, example, ascii_art):
                    [(c, example.DownwardLaserBoltSprite) for c in example.DOWNWARD_BOLT_CHARS]),
       drapes=dict(X=example.MarauderDrape, B=example.BunkerDrape),
       update_schedule=['P', 'B', 'X'] + list(bolts))
+
+
+# ---- a hello_world board that the reference does not ship ---------------------------
+# 8x33: curtain rows of 33 bits (one bit into the second word), another z-order,
+# sprites with the four direction sets in another order.
+HELLO_ART = {
+    'hello_custom_A': ['                                 ',
+                       ' @@@  @   @   1     #   #        ',
+                       ' @  @ @@ @@         ## ##     2  ',
+                       ' @@@  @ @ @    3    # # #        ',
+                       ' @    @   @         #   #    @@@@',
+                       ' @    @   @  4      #   #        ',
+                       '@                               @',
+                       '                                 '],
+}
+HELLO_NAMES = sorted(HELLO_ART)
+for _name, _art in HELLO_ART.items():
+  assert len(set(len(_row) for _row in _art)) == 1, _name
+
+
+def make_hello(name, example, ascii_art):
+  """hello_world.make_game (hello_world.py:59-69) for HELLO_ART[name]."""
+  return ascii_art.ascii_art_to_game(
+      HELLO_ART[name], what_lies_beneath=' ',
+      sprites={'1': ascii_art.Partial(example.SlidingSprite, 3),
+               '2': ascii_art.Partial(example.SlidingSprite, 0),
+               '3': ascii_art.Partial(example.SlidingSprite, 2),
+               '4': ascii_art.Partial(example.SlidingSprite, 1)},
+      drapes={'@': example.RollingDrape},
+      z_order='4@321')

@@ -337,6 +337,9 @@ def main():
         template_name=name)
   run('hello_world', hello_world.make_game, E=16, T=96, n_ordinary=4, quit_action=4, seed=27,
       template_name='hello_world')
+  for i, name in enumerate(custom_levels.HELLO_NAMES):
+    run(name, lambda: custom_levels.make_hello(name, hello_world, ref_ascii_art), E=16, T=96, n_ordinary=4,
+        quit_action=4, seed=141 + i, template_name=name)
   # prefab-only scenarios built from the reference's own test entities
   sys.path.insert(0, ROOT)
   from oracle import walker_scenarios
