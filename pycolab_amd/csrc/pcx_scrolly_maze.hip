@@ -422,8 +422,21 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   bool skip = !live;
   bool do_reset = false;
   int action = PCX_ACTION_NONE;
+  // every state word (and the tape action) is requested up front, next to the
+  // flags word that decides what happens to the environment: one memory round
+  // trip for the whole logic phase instead of two or three in a row
+  uint32_t ld_frame = 0, ld_permit = 0, ld_mz = 0, ld_cs = 0, ld_stale = 0, ld_sflags = 0, ld_spos[NS] = {};
+  int ld_action = PCX_ACTION_NONE;
   if (live) {
     flags = st[W_FLAGS * bp];
+    if (a.mode != 1) {
+      ld_frame = st[W_FRAME * bp]; ld_permit = st[W_PERMIT_FRAME * bp];
+      ld_mz = st[W_MAZE * bp]; ld_cs = st[W_CASH * bp];
+      ld_stale = st[W_STALE * bp]; ld_sflags = st[W_SFLAGS * bp];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ld_spos[s] = st[(W_SPOS + s) * bp];
+      if (!a.hashed) ld_action = a.actions[(int64_t)tstep * a.action_stride + env];
+    }
     if (a.mode == 1) {
       do_reset = a.reset_mask ? a.reset_mask[env] != 0 : true;
       skip = !do_reset;
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     } else {
       action = a.hashed ? (int)(action_hash(a.seed, (uint64_t)(a.env_offset + env), (uint64_t)(a.t + tstep)) %
                                (uint32_t)k.n_actions)
-                        : a.actions[(int64_t)tstep * a.action_stride + env];
+                        : ld_action;
     }
   }
   if (!skip) {
@@ -462,14 +475,14 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       coins_dirty = true;
       action = PCX_ACTION_NONE;
     } else {
-      p.frame = (int)st[W_FRAME * bp];
-      p.permit_frame = (int)st[W_PERMIT_FRAME * bp];
-      mz = st[W_MAZE * bp];
-      cs = st[W_CASH * bp];
-      stale = st[W_STALE * bp];
-      sflags = st[W_SFLAGS * bp];
+      p.frame = (int)ld_frame;
+      p.permit_frame = (int)ld_permit;
+      mz = ld_mz;
+      cs = ld_cs;
+      stale = ld_stale;
+      sflags = ld_sflags;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) spos[s] = st[(W_SPOS + s) * bp];
+      for (int s = 0; s < NS; ++s) spos[s] = ld_spos[s];
       for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + lane] = st[(W_SPOS + NS + i) * bp];
     }
 #pragma unroll
