@@ -51,9 +51,15 @@ def test_hip_matches_oracle_hashed_actions(name):
   hip.reset(); orc.reset()
   assert_same(hip, orc, 'frame 0')
   resets = 0
-  for t0 in range(0, T, 8):
-    hip.step_hashed(0x5EED, t0, 8); orc.step_hashed(0x5EED, t0, 8)
-    assert_same(hip, orc, 'after step %d' % (t0 + 8))
+  # the first 32 steps (and 16 more in the middle) are compared after every
+  # single step -- a transient wrong observation cannot hide between checks --
+  # the rest every 8 steps
+  t0 = 0
+  while t0 < T:
+    n = 1 if (t0 < 32 or T // 2 <= t0 < T // 2 + 16) else 8
+    hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
+    t0 += n
+    assert_same(hip, orc, 'after step %d' % t0)
     resets += int(orc.read('done').sum())
   assert resets > 0 or not name.startswith(('scrolly_maze_L0', 'scrolly_maze_L1', 'marauders'))  # reset path exercised (L2 patrollers are boxed in)
 
@@ -181,6 +187,48 @@ def test_full_batch_properties():
     assert torch.equal(chunk[:, 1:], want)
   assert not hip.eng.buffers['error'].tensor.any()
   del board
+
+
+@pytest.mark.parametrize('name,B,T', [('marauders', 32768, 160), ('warehouse_L0', 262144, 64)])
+def test_full_batch_properties_configs_3_and_4(name, B, T):
+  """BASELINE configs 3 and 4 at their full batch sizes (marauders 32,768;
+  warehouse_manager level 0 262,144): the first and the last K environments
+  against the oracle (with the matching env_offset, which also feeds the
+  marauders' RNG draws), layer == (board == c) over the whole batch, and no
+  error bits, checked at several points of the run (episodes end and restart
+  inside it)."""
+  import torch
+  t = helpers.load_template(name)
+  t.param[0] = 0xBEEF
+  K = 1024
+  hip = HipAdapter(t, B)
+  head = OracleAdapter(t, K)
+  tt = helpers.load_template(name)
+  tt.param[0] = 0xBEEF
+  tt.param[2], tt.param[3] = (B - K) & 0xFFFFFFFF, (B - K) >> 32  # global index of the tail's first environment
+  tail = OracleAdapter(tt, K)
+  hip.reset(); head.reset(); tail.reset()
+  chars = torch.tensor(list(t.chars), dtype=torch.uint8, device='cuda')
+  done_seen = 0
+  for t0 in range(0, T, T // 4):
+    n = T // 4
+    hip.step_hashed(0xC0FFEE, t0, n); head.step_hashed(0xC0FFEE, t0, n)
+    tail.step_hashed(0xC0FFEE, t0, n, env_offset=B - K)
+    planes = hip.eng.planes_view()
+    where = '%s after step %d' % (name, t0 + n)
+    np.testing.assert_array_equal(planes[:K].cpu().numpy(), head.read('planes'), err_msg=where + ' (head)')
+    np.testing.assert_array_equal(planes[B - K:].cpu().numpy(), tail.read('planes'), err_msg=where + ' (tail)')
+    for key in ('reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+      got = hip.eng.buffers[key].tensor
+      np.testing.assert_array_equal(got[:K].cpu().numpy(), head.read(key), err_msg=where + ' head ' + key)
+      np.testing.assert_array_equal(got[B - K:].cpu().numpy(), tail.read(key), err_msg=where + ' tail ' + key)
+    for lo in range(0, B, 1 << 15):
+      chunk = planes[lo:lo + (1 << 15)]
+      want = (chunk[:, :1] == chars.view(1, -1, 1, 1)).to(torch.uint8)
+      assert torch.equal(chunk[:, 1:], want), where
+    assert not hip.eng.buffers['error'].tensor.any(), where
+    done_seen += int(hip.eng.buffers['done'].tensor.sum().item())
+  assert done_seen > 0 or name != 'marauders'  # marauders episodes end (and restart) inside the run; random play never solves a warehouse
 
 
 def test_engine_facade_batch1_matches_trace():
