@@ -194,7 +194,11 @@ int pcx_engine_reset(pcx_engine* e, const uint8_t* env_mask_dev, void* stream);
 /* engine.py:583-639 play(): one step of every environment.  actions_dev is a
  * device int32[batch] (PCX_ACTION_NONE = None).  With auto_reset != 0 an
  * environment whose episode is over is rebuilt and runs frame 0 instead
- * (counted as one env-step); with auto_reset == 0 it is left untouched. */
+ * (counted as one env-step); with auto_reset == 0 its state and observation
+ * are left untouched (the reference raises RuntimeError, engine.py:622-624)
+ * and the step reports reward 0 / reward_set 0 / discount 0 for it, so that
+ * a consumer summing rewards over the batch does not count the terminal
+ * reward again; done stays 1. */
 int pcx_engine_step(pcx_engine* e, const int32_t* actions_dev, int auto_reset,
                     void* stream);
 

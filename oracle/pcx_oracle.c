@@ -870,6 +870,15 @@ static void publish(pcxo_engine* e, int64_t b) {
   e->error[b] = (uint8_t)env->error;
 }
 
+/* Batch rule (include/pcx.h, pcx_engine_step): a finished environment that is
+ * stepped without auto_reset is left untouched -- the reference would raise
+ * (engine.py:622-624) -- and reports an empty step: no reward, discount 0. */
+static void frozen_step(pcxo_engine* e, int64_t b) {
+  e->reward[b] = 0;
+  e->reward_set[b] = 0;
+  e->discount[b] = 0.0f;
+}
+
 /* engine.py:583-639 play (one environment) */
 static int env_play(pcxo_engine* e, int64_t b, int action) {
   ox_env* env = &e->envs[b];
@@ -974,7 +983,7 @@ int pcxo_engine_step(pcxo_engine* e, const int32_t* actions, int auto_reset) {
     int rc = 0;
     if (env->game_over) {
       if (auto_reset) rc = env_showtime(e, b);
-      /* else: frozen -- the reference would raise (engine.py:622-624) */
+      else frozen_step(e, b);
     } else {
       rc = env_play(e, b, actions[b]);
     }
@@ -991,7 +1000,7 @@ int pcxo_engine_step_hashed(pcxo_engine* e, uint64_t seed, int64_t env_offset,
     for (int64_t b = 0; b < e->batch; ++b) {
       ox_env* env = &e->envs[b];
       int rc = 0;
-      if (env->game_over) { if (auto_reset) rc = env_showtime(e, b); }
+      if (env->game_over) { if (auto_reset) rc = env_showtime(e, b); else frozen_step(e, b); }
       else rc = env_play(e, b, (int)(pcxo_action_hash(seed, (uint64_t)(env_offset + b), (uint64_t)(t0 + t)) % (uint32_t)n));
       if (rc) return rc;
     }

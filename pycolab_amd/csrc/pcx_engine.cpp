@@ -85,8 +85,10 @@ int pcx_engine_create(const pcx_template* t, int64_t batch, int device_id, pcx_e
   pcx::Backend* b = nullptr;
   switch (t->game) {
     case PCX_GAME_SCROLLY_MAZE: b = pcx::make_scrolly_maze_backend(); break;
-    case PCX_GAME_WAREHOUSE:
-    case PCX_GAME_MARAUDERS:
+    // hand-written kernels for the shipped shapes; anything else of the same
+    // game (other boards, occlusion_in_layers=False) takes the table-driven one
+    case PCX_GAME_WAREHOUSE: b = pcx::make_warehouse_backend(); break;
+    case PCX_GAME_MARAUDERS: b = pcx::make_marauders_backend(); break;
     case PCX_GAME_HELLO_WORLD:
     case PCX_GAME_WALKERS:
     case PCX_GAME_BETTER_SCROLLY: b = pcx::make_generic_backend(); break;
@@ -94,6 +96,11 @@ int pcx_engine_create(const pcx_template* t, int64_t batch, int device_id, pcx_e
       return set_error(PCX_E_UNSUPPORTED, "pcx_engine_create: no device program for game id %d", t->game);
   }
   int rc = b->init(*t, batch);
+  if (rc == PCX_E_UNSUPPORTED && (t->game == PCX_GAME_WAREHOUSE || t->game == PCX_GAME_MARAUDERS)) {
+    delete b;
+    b = pcx::make_generic_backend();
+    rc = b->init(*t, batch);
+  }
   if (rc) { delete b; return rc; }
   pcx_engine* e = new pcx_engine();
   e->t = *t;

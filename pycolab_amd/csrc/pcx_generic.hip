@@ -715,7 +715,10 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
   if (live) {
     flags = st[W_FLAGS * bp];
     if (a.mode == 1) { do_reset = a.reset_mask ? a.reset_mask[env] != 0 : true; skip = !do_reset; }
-    else if (flags & F_OVER) { do_reset = a.auto_reset != 0; skip = !do_reset; }
+    else if (flags & F_OVER) {
+      do_reset = a.auto_reset != 0; skip = !do_reset;
+      if (skip) { out.reward[env] = 0; out.reward_set[env] = 0; out.discount[env] = 0.0f; }  // a finished environment left alone reports an empty step (pcx.h)
+    }
     else action = a.hashed ? (int)(action_hash(a.seed, (uint64_t)(a.env_offset + env), (uint64_t)a.t) % (uint32_t)k.n_actions)
                            : a.actions[env];
     if (action < 0) action = PCX_ACTION_NONE;

@@ -443,6 +443,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     } else if (flags & F_OVER) {
       do_reset = a.auto_reset != 0;
       skip = !do_reset;
+      if (skip) { out.reward[env] = 0; out.reward_set[env] = 0; out.discount[env] = 0.0f; }  // a finished environment left alone reports an empty step (pcx.h)
     } else {
       action = a.hashed ? (int)(action_hash(a.seed, (uint64_t)(a.env_offset + env), (uint64_t)(a.t + tstep)) %
                                (uint32_t)k.n_actions)

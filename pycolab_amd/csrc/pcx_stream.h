@@ -1,0 +1,180 @@
+// pcx_stream.h -- the render phase shared by the hand-written game kernels
+// (pcx_warehouse.hip, pcx_marauders.hip): occlusion resolved once per
+// environment, then the wavefront streams board + layer planes.
+// Reference: engine.py:737-759 _render, rendering.py:85-184
+// BaseObservationRenderer (paint back to front; layers[c] = board == c).
+// gfx950 only.
+//
+// Contract with the logic phase (lane == environment).  For the group's 64
+// environments it leaves in LDS
+//   flat  [ND][64][FWP]  every drape's curtain as a flat cell-bit vector (bit i =
+//                        cell i), environment-major with an odd pitch so that the
+//                        logic phase (same word, 64 environments) and the
+//                        streaming phase (same environment, consecutive words)
+//                        both spread over the banks;
+//   sdesc [NS][64]       per sprite {board dword it is painted in, byte mask},
+//                        dword 0xFFFFFFFF when the sprite is not painted;
+//   skip  [64]           environments this launch leaves untouched.
+// After resolve_sprites() every board cell belongs to exactly one painter (a
+// sprite, one curtain, or the backdrop), so painting is order-free and every
+// layer is a mask already at hand: nothing is read back from HBM.
+#pragma once
+
+#include "pcx_internal.h"
+
+namespace pcx {
+namespace stream {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ uint8_t* uniform_ptr(uint8_t* p) {  // pin a wave-uniform pointer to an SGPR pair
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<uint8_t*>(((uint64_t)hi << 32) | lo);
+}
+
+// engine.py:751-757 for the last repaint of a step: a sprite is painted iff it
+// is visible and nothing in front of it covers its cell; a painted sprite takes
+// its cell away from every curtain (those in front do not have it, those behind
+// lose it).  cell[s] = the cell sprite s is painted at, -1 when invisible.
+// above[s]: bit j < NS = sprite j is in front of sprite s, bit NS + d = drape d is.
+// Curtain-over-curtain occlusion must already be applied to `flat`.
+template <int NS, int ND>
+__device__ __forceinline__ void resolve_sprites(const int (&cell)[NS], const uint32_t (&above)[NS], uint32_t* flat,
+                                                int FWP, int lane, uint2* sdesc) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int c = cell[s];
+    bool shown = c >= 0;
+    if (shown) {
+      const uint32_t ab = above[s];
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+        if (j != s && ((ab >> j) & 1) && cell[j] == c) shown = false;
+      const int wi = c >> 5, sh = c & 31;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        if (((ab >> (NS + d)) & 1) && ((flat[(d * WAVE + lane) * FWP + wi] >> sh) & 1)) shown = false;
+      if (shown) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) flat[(d * WAVE + lane) * FWP + wi] &= ~(1u << sh);
+      }
+    }
+    sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(c >> 2) : 0xFFFFFFFFu, 0xFFu << ((c & 3) * 8));
+  }
+}
+
+// What the streaming loop needs besides LDS: all wave-uniform.
+template <int NS, int ND, int NB>
+struct PlaneMap {
+  uint32_t sprite_off[NS], drape_off[ND], bchar_off[NB];  // byte offset of the thing's layer plane in an environment record
+  uint32_t sprite_ch4[NS], drape_ch4[ND];                 // character replicated into four bytes
+};
+
+// The wavefront streams board + layers of the group's 64 environments.
+// One (environment e, board dword q) task per lane and iteration; consecutive
+// lanes take consecutive dwords, so every plane store of a wave covers 256
+// contiguous bytes of that plane (split over two or three environment records
+// when a plane is shorter than 64 dwords).  Every store is `scalar plane base +
+// one shared 32-bit lane offset`; indices advance incrementally (no multiplies
+// or divisions in the loop).  NWAVES waves of a workgroup share the loop,
+// iterations round-robin.
+//   QW: dwords per plane (plane pitch / 4); record = (1 + L) planes.
+template <int NS, int ND, int NB, int QW, int NWAVES>
+__device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
+                                              const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
+                                              const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave) {
+  uint8_t* const pb_board = uniform_ptr(group_base);
+  uint8_t* pb_s[NS];
+  uint8_t* pb_d[ND];
+  uint8_t* pb_b[NB];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) pb_s[s] = uniform_ptr(pb_board + pm.sprite_off[s]);
+#pragma unroll
+  for (int d = 0; d < ND; ++d) pb_d[d] = uniform_ptr(pb_board + pm.drape_off[d]);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) pb_b[b] = uniform_ptr(pb_board + pm.bchar_off[b]);
+
+  const bool any_skip = __ballot(skip[lane] != 0) != 0ull;
+  // Drain the logic phase's own loads/stores once, here: the loop's stores are
+  // inline asm the compiler cannot count, and without this it would protect a
+  // register of an older store with a vmcnt(0) inside the loop.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt/lgkmcnt untouched
+
+  constexpr int ADV = NWAVES * WAVE;          // tasks between a wave's consecutive iterations
+  constexpr int DE = ADV / QW, DQ = ADV % QW;  // ... as whole environments + dwords
+  const uint32_t f0 = (uint32_t)(wave * WAVE + lane);
+  uint32_t e = f0 / (uint32_t)QW, q = f0 % (uint32_t)QW;  // compile-time divisor, once
+  uint32_t voff = e * env_stride + 4u * q, eF = e * (uint32_t)FWP;
+  const uint32_t dvoff = (uint32_t)DE * env_stride + 4u * (uint32_t)DQ, dF = (uint32_t)DE * (uint32_t)FWP;
+  const uint32_t wrap_voff = env_stride - 4u * (uint32_t)QW;
+#pragma unroll 1
+  for (int it = wave; it < QW; it += NWAVES) {
+    const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF;
+    q += DQ; e += DE; voff += dvoff; eF += dF;
+    {
+      const bool wrap = q >= (uint32_t)QW;
+      q = wrap ? q - QW : q;
+      e = wrap ? e + 1 : e;
+      voff = wrap ? voff + wrap_voff : voff;
+      eF = wrap ? eF + FWP : eF;
+    }
+    if (any_skip && skip[e_now]) continue;
+    auto put = [&](uint8_t* base, uint32_t v) {
+      asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(base));
+    };
+    // every LDS read of the iteration is issued up front
+    uint32_t d = backdrop4[q_now];
+    uint32_t md[ND > 0 ? ND : 1], ms[NS > 0 ? NS : 1], mb[NB > 0 ? NB : 1];
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+      const uint32_t bits = (flat[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;
+      const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;  // bit i -> byte i
+      uint32_t hi8 = m01 << 8;
+      asm("" : "+v"(hi8));  // keep LLVM from folding (x << 8) - x into a quarter-rate x * 255
+      md[dd] = hi8 - m01;   // 0x01 -> 0xFF per byte
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const uint2 sd = sdesc[s * WAVE + e_now];
+      ms[s] = sd.x == q_now ? sd.y : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) mb[b] = bdmask[b * QW + q_now];
+    uint32_t uni = 0;
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+      uni |= md[dd];
+      d = (d & ~md[dd]) | (pm.drape_ch4[dd] & md[dd]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      uni |= ms[s];
+      d = (d & ~ms[s]) | (pm.sprite_ch4[s] & ms[s]);
+    }
+    put(pb_board, d);
+    // rendering.py:177-179 layers[c] = (board == c): by construction the thing's
+    // own mask, or the backdrop's precomputed mask where no thing paints
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) put(pb_d[dd], md[dd] & 0x01010101u);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) put(pb_s[s], ms[s] & 0x01010101u);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) put(pb_b[b], mb[b] & ~uni);
+  }
+}
+
+// Constants of the streaming phase every backend derives the same way.
+struct Layout {
+  int cells = 0, pitch = 0, QW = 0, FW = 0, FWP = 0;
+  void set(int rows, int cols) {
+    cells = rows * cols;
+    pitch = (cells + 3) & ~3;
+    QW = pitch / 4;
+    FW = (cells + 31) / 32;
+    FWP = FW | 1;
+  }
+};
+
+}  // namespace stream
+}  // namespace pcx
