@@ -50,5 +50,6 @@ def load_game_module(path, name=None):
   with aliased():
     spec = importlib.util.spec_from_file_location(name, path)
     module = importlib.util.module_from_spec(spec)
+    sys.modules[name] = module  # inspect.getsource(cls) finds a class through its module
     spec.loader.exec_module(module)
   return module

@@ -216,6 +216,7 @@ __device__ __forceinline__ bool blocked_at(Ctx& x, int thing, int vr, int vc, in
   const int r = vr + dr, c = vc + dc;
   if (!on_board(x.k, r, c)) return (tfield(x, thing, T_FLAGS) & TF_CONFINED) != 0;  // EDGE
   const int ch = top_char(x, r, c);
+  if (ch >= 128) return false;  // impassable sets are ASCII (compiler.py); anything else is passable
   return (tfield(x, thing, T_IMP0 + (ch >> 5)) >> (ch & 31)) & 1;
 }
 __device__ __forceinline__ bool check_motion(Ctx& x, int thing, int vr, int vc, int dr, int dc) {
@@ -978,8 +979,10 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.occl = t.occlusion_in_layers != 0;
   k.game = t.game; k.R = t.rows; k.C = t.cols; k.cells = t.rows * t.cols; k.L = t.n_chars;
   k.NS = t.n_sprites; k.ND = t.n_drapes; k.NT = t.n_things; k.n_groups = t.n_groups; k.n_actions = t.n_actions;
-  if (k.C > 255 || k.R > 255 || k.L > MAX_L || k.NT > 24 || k.cells > 8192)
+  if (k.C > 255 || k.R > 255 || k.L > MAX_L || k.cells > 8192)
     return set_error(PCX_E_UNSUPPORTED, "generic backend: board larger than 255x255 / 8192 cells or more than %d characters", MAX_L);
+  if (k.NT > 16)  // the render loop is instantiated for up to 16 things (render_planes<16>)
+    return set_error(PCX_E_UNSUPPORTED, "generic backend: %d sprites and drapes, at most 16 are supported", k.NT);
   k.pitch = (k.cells + 3) & ~3;
   k.QW = k.pitch / 4;
   k.RW = (k.C + 31) / 32;
@@ -1077,6 +1080,14 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
     for (int z = 0; z < k.NT; ++z) if (t.z_order[z] == t.schedule[i]) zi = z;
     if (zi < 0) return set_error(PCX_E_INVALID, "generic backend: schedule names an unknown character");
     sched[i] = (uint32_t)zi | ((uint32_t)t.group_of[i] << 8);
+  }
+  for (int z = 0; z < k.NT; ++z) {  // programs that look up things['P']
+    const uint32_t prog = things[(size_t)z * T_WORDS + T_PROG];
+    if ((prog == PCX_PROG_BS_PATROLLER || prog == PCX_PROG_BS_CASH || prog == PCX_PROG_EM_UPBOLT ||
+         prog == PCX_PROG_EM_DOWNBOLT || prog == PCX_PROG_WM_BOX) && k.ip < 0)
+      return set_error(PCX_E_UNSUPPORTED, "generic backend: program %u needs a sprite 'P'", prog);
+    if ((prog == PCX_PROG_EM_DOWNBOLT) && k.tx < 0)
+      return set_error(PCX_E_UNSUPPORTED, "generic backend: program %u needs a drape 'X'", prog);
   }
   if (t.game == PCX_GAME_MARAUDERS && (k.ip < 0 || k.ix < 0))
     return set_error(PCX_E_UNSUPPORTED, "generic backend: marauders needs things 'P' and 'X'");

@@ -41,6 +41,20 @@ class DeviceBuffer(object):
       self.ptr = p.value
       self.upload(np.zeros(self.shape, self.dtype))
 
+  @classmethod
+  def view_of(cls, tensor, dtype, device_id):
+    """A typed buffer over (a slice of) an existing device tensor: no allocation."""
+    self = cls.__new__(cls)
+    self.dtype = np.dtype(dtype)
+    torch = torch_module()
+    self.tensor = tensor.view(getattr(torch, _NP_TO_TORCH[self.dtype.name]))
+    self.shape = tuple(self.tensor.shape)
+    self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+    self.device_id = device_id
+    self._raw = None
+    self.ptr = self.tensor.data_ptr()
+    return self
+
   def numpy(self):
     if self.tensor is not None:
       return self.tensor.cpu().numpy()

@@ -4,9 +4,11 @@ Environments never interact (reference: one `Engine` per environment,
 engine.py:102-104), so the batch is cut into contiguous ranges and every rank
 steps its own range with no data-path collective.  The only optional exchange
 is a gather of the per-environment scalars `play()` returns (reward,
-reward_set, discount, done: 10 bytes per environment), done with
-`torch.distributed` -- RCCL over xGMI on GPUs (backend "nccl"), gloo in the
-CPU tests.
+reward_set, discount, done: 10 bytes per environment).  The engine keeps those
+four arrays in ONE device allocation (`Engine.scalars_packed`), so the gather
+is a single `all_gather_into_tensor` of that buffer -- RCCL over xGMI on GPUs
+(backend "nccl"), gloo in the CPU tests -- with no packing pass, no host
+synchronisation and no per-call allocation.
 """
 
 import os
@@ -27,26 +29,73 @@ def env_world():
           int(os.environ.get('LOCAL_RANK', '0')))
 
 
-def gather_scalars(reward, reward_set, discount, done, group=None):
-  """All-gather the per-environment step results of every rank.
-
-  Arguments are 1-D torch tensors of this rank's shard (any device the
-  process group supports).  Shards may differ in length.  Returns the four
-  tensors concatenated in rank order -- element i is global environment i.
-  """
+def pack_scalars(reward, reward_set, discount, done):
+  """The engine's packed layout [reward i32 | discount f32 | reward_set u8 |
+  done u8] from four separate 1-D tensors (one concatenation)."""
   import torch
-  import torch.distributed as dist
-  world = dist.get_world_size(group)
-  n = torch.tensor([reward.numel()], dtype=torch.int64, device=reward.device)
-  sizes = [torch.zeros_like(n) for _ in range(world)]
-  dist.all_gather(sizes, n, group=group)
-  sizes = [int(s.item()) for s in sizes]
-  longest = max(sizes)
-  out = []
-  for t in (reward, reward_set, discount, done):
-    padded = torch.zeros(longest, dtype=t.dtype, device=t.device)
-    padded[:t.numel()] = t
-    parts = [torch.zeros_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    out.append(torch.cat([p[:s] for p, s in zip(parts, sizes)]))
-  return tuple(out)
+  return torch.cat([reward.contiguous().view(torch.uint8), discount.contiguous().view(torch.uint8),
+                    reward_set.contiguous().view(torch.uint8), done.contiguous().view(torch.uint8)])
+
+
+def unpack_scalars(packed, n):
+  """Typed zero-copy views (reward, reward_set, discount, done) of one packed
+  block of `n` environments."""
+  import torch
+  return (packed[0:4 * n].view(torch.int32), packed[8 * n:9 * n],
+          packed[4 * n:8 * n].view(torch.float32), packed[9 * n:10 * n])
+
+
+class ScalarGather(object):
+  """All-gather of every rank's packed step results, one collective per call.
+
+  `packed`: this rank's uint8 tensor [10 * n_local] (`Engine.scalars_packed`);
+  it is read in place at every `gather()`.  `global_batch` fixes every rank's
+  shard length through `shard_range` (no size exchange); when omitted all
+  shards have this rank's length.  The receive buffer is allocated once.
+  """
+
+  def __init__(self, packed, global_batch=None, group=None):
+    import torch
+    import torch.distributed as dist
+    self._dist, self._group = dist, group
+    self.world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local = packed.numel() // 10
+    if global_batch is None:
+      self.sizes = [n_local] * self.world
+    else:
+      self.sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, self.world) for r in range(self.world))]
+      if self.sizes[rank] != n_local:
+        raise ValueError('rank {} holds {} environments, shard_range says {}'.format(rank, n_local, self.sizes[rank]))
+    self._local = packed
+    self._slot = (10 * max(self.sizes) + 15) // 16 * 16  # bytes per rank in the receive buffer (typed views stay aligned)
+    self._send = packed
+    if packed.numel() != self._slot:   # a shorter (or oddly sized) shard sends a padded copy of its block
+      self._send = torch.zeros(self._slot, dtype=torch.uint8, device=packed.device)
+    self.out = torch.empty(self.world * self._slot, dtype=torch.uint8, device=packed.device)
+
+  def gather(self):
+    """Issues the collective on the current stream; returns the raw receive
+    buffer [world, slot] (asynchronous on GPUs: no host sync here)."""
+    if self._send is not self._local:
+      self._send[:self._local.numel()].copy_(self._local)
+    self._dist.all_gather_into_tensor(self.out, self._send, group=self._group)
+    return self.out.view(self.world, self._slot)
+
+  def unpack(self):
+    """(reward, reward_set, discount, done) of the whole batch in global
+    environment order, from the last `gather()`."""
+    import torch
+    blocks = self.out.view(self.world, self._slot)
+    parts = [unpack_scalars(blocks[r], n) for r, n in enumerate(self.sizes)]
+    return tuple(torch.cat([p[i] for p in parts]) for i in range(4))
+
+
+def gather_scalars(reward, reward_set, discount, done, group=None, global_batch=None):
+  """One-shot form for four separate tensors: packs them (one concatenation),
+  gathers with ONE collective and returns the four arrays of the whole batch
+  in global environment order.  Shards of different length need
+  `global_batch` (sizes then follow `shard_range`)."""
+  g = ScalarGather(pack_scalars(reward, reward_set, discount, done), global_batch=global_batch, group=group)
+  g.gather()
+  return g.unpack()

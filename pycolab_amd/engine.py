@@ -53,6 +53,7 @@ class Engine(object):
     self._native = None
     self._keepalive = None
     self._bufs = None
+    self._packed = None
     self._actions = None
     self._croppers = []
 
@@ -203,11 +204,22 @@ class Engine(object):
     B, L, R, C = self._batch, len(template.chars), self._rows, self._cols
     self._pitch = int(lib.pcx_engine_plane_pitch(self._native))
     mk = lambda shape, dt: dev.DeviceBuffer(shape, dt, self._device_id)
-    self._bufs = dict(
-        planes=mk((B, 1 + L, self._pitch), np.uint8), reward=mk((B,), np.int32),
-        reward_set=mk((B,), np.uint8), discount=mk((B,), np.float32),
-        done=mk((B,), np.uint8), frame=mk((B,), np.int32),
-        error=mk((B,), np.uint8))
+    self._bufs = dict(planes=mk((B, 1 + L, self._pitch), np.uint8), frame=mk((B,), np.int32),
+                      error=mk((B,), np.uint8))
+    # what play() returns besides the observation, 10 bytes per environment, in
+    # ONE allocation [reward i32 B | discount f32 B | reward_set u8 B | done u8 B]:
+    # a multi-GPU consumer gathers it with a single collective and no packing
+    # pass (pycolab_amd.distributed.ScalarGather)
+    self._packed = None
+    if dev.torch_module() is not None:
+      self._packed = mk((10 * B,), np.uint8)
+      cut = self._packed.tensor
+      view = lambda lo, hi, dt: dev.DeviceBuffer.view_of(cut[lo:hi], dt, self._device_id)
+      self._bufs.update(reward=view(0, 4 * B, np.int32), discount=view(4 * B, 8 * B, np.float32),
+                        reward_set=view(8 * B, 9 * B, np.uint8), done=view(9 * B, 10 * B, np.uint8))
+    else:
+      self._bufs.update(reward=mk((B,), np.int32), discount=mk((B,), np.float32),
+                        reward_set=mk((B,), np.uint8), done=mk((B,), np.uint8))
     self._actions = mk((B,), np.int32)
     ext = N.Buffers(batch=B, rows=R, cols=C, n_chars=L,
                     **{k: v.ptr for k, v in self._bufs.items()})
@@ -278,8 +290,11 @@ class Engine(object):
                                       dev.current_stream(self._device_id)))
     dev.synchronize(self._device_id)  # the staging buffer may be freed after this call
 
-  def step_hashed(self, seed, t0, steps, env_offset=0):
-    """`steps` steps with on-device actions `hash(seed, env, t) % n_actions`."""
+  def step_hashed(self, seed, t0, steps, env_offset=None):
+    """`steps` steps with on-device actions `hash(seed, env, t) % n_actions`,
+    env = `env_offset` (default: the engine's configured offset) + local index."""
+    if env_offset is None:
+      env_offset = self._env_offset
     N.check(N.lib().pcx_engine_step_hashed(
         self._native, seed, env_offset, t0, steps, int(self._auto_reset),
         dev.current_stream(self._device_id)))
@@ -361,6 +376,12 @@ class Engine(object):
   @property
   def buffers(self):
     return self._bufs
+
+  @property
+  def scalars_packed(self):
+    """uint8 device tensor [10 * batch]: reward (int32) | discount (float32) |
+    reward_set | done, the storage behind `buffers[...]` (None without PyTorch)."""
+    return None if self._packed is None else self._packed.tensor
 
   @property
   def reward_set(self):

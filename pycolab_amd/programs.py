@@ -5,8 +5,10 @@ device program per entity instead.  A class is matched either
 
 * explicitly: the class (or a base) carries `pcx_program = '<name>'`, or
 * by identity with a shipped reference game class: same class name and the
-  same `update()` bytecode fingerprint as the class in the reference's
-  `examples/*.py` (so an edited copy is *not* silently mis-simulated).
+  same source (digest of the normalised AST of the class body: comments,
+  formatting, docstrings and the interpreter version do not matter) as the
+  class in the reference's `examples/*.py` -- so an edited copy is *not*
+  silently mis-simulated.
 
 Anything else raises `UnsupportedEntityError` -- there is no CPU fallback.
 """
@@ -56,10 +58,9 @@ GAME_OF_PROGRAM = {
 N_ACTIONS = {N.GAME_SCROLLY_MAZE: 5, N.GAME_MARAUDERS: 4, N.GAME_WAREHOUSE: 5,
              N.GAME_HELLO_WORLD: 4, N.GAME_WALKERS: 9, N.GAME_BETTER_SCROLLY: 5}
 
-# (class name, fingerprint of update()) of the reference's shipped game
-# classes -> program name.  Fingerprints are produced by
-# `oracle/gen_templates.py --fingerprints` from /root/reference on the pinned
-# interpreter (CPython 3.10).
+# (class name, source fingerprint) of the reference's shipped game classes ->
+# program name.  Produced by `oracle/gen_templates.py` from /root/reference;
+# independent of the interpreter that runs it.
 SHIPPED = {
     # filled in by oracle/gen_templates.py; see SHIPPED_FINGERPRINTS below
 }
@@ -91,36 +92,87 @@ class UnsupportedEntityError(NotImplementedError):
   pass
 
 
-def _digest_code(h, code):
-  """Feeds what identifies a code object's behaviour -- not where it lives in
-  memory or how a set constant happens to be ordered in this process."""
-  h.update(code.co_code)
-  h.update(repr(code.co_names).encode())
-  for c in code.co_consts:
-    if hasattr(c, 'co_code'):           # nested lambda / comprehension
-      h.update(b'<code>')
-      _digest_code(h, c)
-    elif isinstance(c, frozenset):      # `x in {..}` constants: iteration order is per-process
-      h.update(repr(sorted(repr(e) for e in c)).encode())
-    elif isinstance(c, str) and len(c) >= 40:
-      continue                          # docstrings
-    else:
-      h.update(repr(c).encode())
+def _canonical(node, out):
+  """Feeds a version-independent serialisation of an AST into `out`: node
+  type names and field values only -- no line numbers, no docstrings, and the
+  node kinds that older interpreters spell differently folded together
+  (Num/Str/Bytes/NameConstant -> Constant, Index unwrapped), so CPython 3.8
+  through 3.13 agree on the digest of the same source text."""
+  import ast
+  if isinstance(node, ast.AST):
+    name = type(node).__name__
+    if name == 'Index':                      # py < 3.9: Subscript(slice=Index(value))
+      return _canonical(node.value, out)
+    if name in ('Num', 'Str', 'Bytes', 'NameConstant', 'Ellipsis'):  # py < 3.8 spellings
+      value = getattr(node, 'n', getattr(node, 's', getattr(node, 'value', Ellipsis)))
+      out.append('Constant(%r)' % (value,))
+      return
+    if name == 'Constant':
+      out.append('Constant(%r)' % (node.value,))
+      return
+    out.append(name + '(')
+    for field in node._fields:
+      if field in ('ctx', 'type_comment', 'kind', 'type_ignores', 'type_params'):
+        continue
+      value = getattr(node, field, None)
+      if field == 'body' and isinstance(value, list) and value and name in ('FunctionDef', 'ClassDef', 'Module'):
+        first = value[0]  # drop the docstring
+        if isinstance(first, ast.Expr) and type(first.value).__name__ in ('Constant', 'Str') and isinstance(
+            getattr(first.value, 'value', getattr(first.value, 's', None)), str):
+          value = value[1:] or [ast.Pass()]
+      out.append(field + '=')
+      _canonical(value, out)
+    out.append(')')
+  elif isinstance(node, list):
+    out.append('[')
+    for item in node:
+      _canonical(item, out)
+      out.append(',')
+    out.append(']')
+  else:
+    out.append(repr(node))
 
 
 def fingerprint(cls):
-  """Stable digest of the bytecode of every method the class itself defines
-  (same interpreter version only; identical across processes)."""
-  h = hashlib.sha1()
-  found = False
-  for name in sorted(vars(cls)):
-    code = getattr(vars(cls)[name], '__code__', None)
-    if code is None:
-      continue
-    found = True
-    h.update(name.encode())
-    _digest_code(h, code)
-  return h.hexdigest()[:16] if found else None
+  """Digest of the class's own source text, as a normalised AST (comments,
+  formatting, docstrings and the interpreter version do not matter; any change
+  to the code does).  None when the source is not available."""
+  import ast
+  import inspect
+  import textwrap
+  node = None
+  try:
+    tree = ast.parse(textwrap.dedent(inspect.getsource(cls)))
+    node = tree.body[0] if tree.body else None
+  except (OSError, TypeError, SyntaxError, IndentationError):
+    # a module loaded by path and never entered into sys.modules: find the
+    # file through one of the class's own functions and pick the ClassDef
+    for member in vars(cls).values():
+      code = getattr(member, '__code__', None)
+      if code is None:
+        continue
+      try:
+        with open(code.co_filename, 'rb') as f:
+          tree = ast.parse(f.read())
+      except (OSError, SyntaxError, ValueError):
+        break
+      scope = tree.body
+      for part in cls.__qualname__.split('.'):
+        if part == '<locals>':
+          continue
+        found = [n for n in scope if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name == part]
+        if not found:
+          scope = None
+          break
+        node, scope = found[-1], found[-1].body
+      if scope is None:
+        node = None
+      break
+  if not isinstance(node, ast.ClassDef):
+    return None
+  out = []
+  _canonical(node, out)
+  return hashlib.sha1(''.join(out).encode('utf-8')).hexdigest()[:16]
 
 
 def resolve(entity):
@@ -139,8 +191,9 @@ def resolve(entity):
     if cls.update is things.Backdrop.update:
       return N.PROG_STATIC
   raise UnsupportedEntityError(
-      'No device program is registered for entity class {}.{} (update() '
-      'fingerprint {}). pycolab_amd steps games on the GPU only; give the '
+      'No device program is registered for entity class {}.{} (source '
+      'fingerprint {}: it is not one of the reference\'s shipped example classes, or '
+      'it has been edited). pycolab_amd steps games on the GPU only; give the '
       'class a `pcx_program` attribute naming one of {} or add a program to '
       'pycolab_amd/csrc.'.format(cls.__module__, cls.__name__, key[1],
                                  sorted(NAMES)))

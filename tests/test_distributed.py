@@ -37,7 +37,8 @@ def _worker(rank, world, port, batch, steps, out_dir):
   eng.reset()
   eng.step_hashed(0xABCD, 0, steps, env_offset=lo)   # global env index drives the actions
   got = pdist.gather_scalars(torch.from_numpy(np.array(eng.reward)), torch.from_numpy(np.array(eng.reward_set)),
-                             torch.from_numpy(np.array(eng.discount)), torch.from_numpy(np.array(eng.done)))
+                             torch.from_numpy(np.array(eng.discount)), torch.from_numpy(np.array(eng.done)),
+                             global_batch=batch)
   if rank == 0:
     np.savez(os.path.join(out_dir, 'gathered.npz'), reward=got[0].numpy(), reward_set=got[1].numpy(),
              discount=got[2].numpy(), done=got[3].numpy())
@@ -86,5 +87,66 @@ def test_rccl_gather_of_device_scalars_single_rank():
       parts.append([g.cpu().numpy() for g in pdist.gather_scalars(*tensors)])  # world of 1: returns this shard
     for i, name in enumerate(('reward', 'reward_set', 'discount', 'done')):
       np.testing.assert_array_equal(np.concatenate([parts[0][i], parts[1][i]]), whole.read(name), err_msg=name)
+  finally:
+    dist.destroy_process_group()
+
+
+def _run_bench(*flags):
+  import subprocess
+  env = dict(os.environ)
+  for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.pop(k, None)
+  return subprocess.run([sys.executable, os.path.join(helpers.ROOT, 'bench.py')] + list(flags), env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+  """`bench.py --gpus N` spawns its own N ranks; with fewer devices it must
+  fail loudly instead of benchmarking one GPU and printing n_gpus: 1."""
+  import torch
+  n = torch.cuda.device_count() + 1 if torch.cuda.device_count() else 2
+  r = _run_bench('--gpus', str(max(n, 2)), '--steps', '2', '--warmup', '1', '--no-cpu-baseline')
+  assert r.returncode != 0
+  assert 'GPU(s)' in r.stderr and '"n_gpus"' not in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl():
+  """Two ranks spawned by bench.py itself, weak and strong scaling, with the
+  packed scalar all-gather timed (needs a node with at least two GPUs)."""
+  import json
+  import torch
+  if torch.cuda.device_count() < 2:
+    pytest.skip('needs two GPUs')
+  for scaling, per_gpu in (('weak', 8192), ('strong', 4096)):
+    r = _run_bench('--gpus', '2', '--steps', '6', '--warmup', '2', '--batch', '8192', '--scaling', scaling,
+                   '--gather', '--no-cpu-baseline')
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == scaling
+    assert line['config']['batch_per_gpu'] == per_gpu and line['config']['global_batch'] == 2 * per_gpu
+    assert line['gather']['bytes_per_rank_per_step'] == 10 * per_gpu
+
+
+@pytest.mark.gpu
+def test_packed_scalars_gather_matches_buffers():
+  """Engine.scalars_packed is the storage behind reward/discount/reward_set/
+  done: one all-gather of it (world of one here) unpacks to the same arrays."""
+  import torch
+  import torch.distributed as dist
+  from tests.hip_adapter import HipAdapter
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  torch.cuda.set_device(0)
+  dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+  try:
+    hip = HipAdapter(helpers.load_template('scrolly_maze_L0'), 1003)  # odd size: the send block is padded
+    hip.reset(); hip.step_hashed(0xABCD, 0, 64)
+    sg = pdist.ScalarGather(hip.eng.scalars_packed, global_batch=1003)
+    sg.gather()
+    got = sg.unpack()
+    for i, name in enumerate(('reward', 'reward_set', 'discount', 'done')):
+      np.testing.assert_array_equal(got[i].cpu().numpy(), hip.read(name), err_msg=name)
+    assert hip.read('reward_set').any()
   finally:
     dist.destroy_process_group()

@@ -201,3 +201,51 @@ def test_reference_ascii_art_test_file_passes_unchanged():
   assert suite.countTestCases() >= 1
   result = unittest.TextTestRunner(verbosity=0).run(suite)
   assert result.wasSuccessful(), result.failures + result.errors
+
+
+_WALKER_SRC = '''
+from pycolab_amd.prefab_parts import sprites as prefab_sprites
+
+
+class PlayerSprite(prefab_sprites.MazeWalker):
+  """%(doc)s"""
+
+  def __init__(self, corner, position, character):
+    super(PlayerSprite, self).__init__(corner, position, character, impassable='#')
+
+  def update(self, actions, board, layers, backdrop, things, the_plot):%(comment)s
+    if actions == 0:
+      self._north(board, the_plot)
+    elif actions == %(south)s:
+      self._south(   board,
+                     the_plot)
+'''
+
+
+def _load_source(tmp_path, name, **subst):
+  import importlib.util
+  path = tmp_path / (name + '.py')
+  path.write_text(_WALKER_SRC % subst)
+  spec = importlib.util.spec_from_file_location(name, str(path))
+  mod = importlib.util.module_from_spec(spec)  # deliberately NOT entered into sys.modules
+  spec.loader.exec_module(mod)
+  return mod.PlayerSprite
+
+
+def test_class_fingerprint_is_of_the_normalised_source(tmp_path):
+  """programs.fingerprint hashes the class's normalised AST: docstrings,
+  comments, formatting and the interpreter do not matter; the code does.  It
+  is not a bytecode digest, so it does not tie the package to one CPython."""
+  from pycolab_amd import programs
+  a = _load_source(tmp_path, 'game_a', doc='A player.', comment='', south='1')
+  b = _load_source(tmp_path, 'game_b', doc='Something else entirely.\n\n  Longer.', comment='  # a remark', south='1')
+  c = _load_source(tmp_path, 'game_c', doc='A player.', comment='', south='2')
+  fa, fb, fc = programs.fingerprint(a), programs.fingerprint(b), programs.fingerprint(c)
+  assert fa is not None and fa == fb and fa != fc
+  # an edited copy of a shipped class name must not be matched to a device program
+  with pytest.raises(programs.UnsupportedEntityError) as err:
+    programs.resolve(c(things.Sprite.Position(5, 5), things.Sprite.Position(1, 1), 'P'))
+  assert 'edited' in str(err.value)
+  # every digest in the shipped table has the AST form (16 hex digits) and no bytecode dependence
+  from pycolab_amd._shipped_fingerprints import SHIPPED_FINGERPRINTS
+  assert all(isinstance(fp, str) and len(fp) == 16 for _, fp in SHIPPED_FINGERPRINTS)
