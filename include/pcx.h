@@ -229,6 +229,13 @@ int pcx_engine_read_things(pcx_engine* e, int64_t env0, int64_t n,
                            pcx_sprite_state* sprites_host,
                            uint8_t* curtains_host);
 
+/* "Did any environment raise?" without waiting for the device: enqueues, on
+ * `stream`, a reduction of the error array and its copy into pinned host
+ * memory, and stores in *seen what an EARLIER poll found (0 until one has
+ * completed; nonzero = take the synchronous path and look at `error`).  The
+ * cropper and post-processor polls below work the same way. */
+int pcx_engine_error_poll(pcx_engine* e, void* stream, int32_t* seen);
+
 /* Convenience synchronous copies (host <-> device) for thin FFI hosts. */
 int pcx_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes);
 int pcx_memcpy_h2d(void* dst_dev, const void* src_host, uint64_t bytes);
@@ -281,10 +288,21 @@ void pcx_cropper_destroy(pcx_cropper* c);
 /* cropping.py:393-426 (or :255-268): crop the engine's current observation.
  * Environments whose engine was reset this step restart their window. */
 int pcx_cropper_crop(pcx_cropper* c, void* stream);
-/* planes: uint8 [batch][1+n_chars][rows][cols] of the cropped window;
+/* planes: uint8 [batch][1+n_chars][pitch] of the cropped window, pitch =
+ * pcx_cropper_plane_pitch() = rows*cols rounded up to a multiple of 4 (pad
+ * bytes are 0) -- the cropper's own array, or the one the caller bound;
  * corner: int32 [batch][2] window corner (scrolling croppers). */
 int pcx_cropper_buffers(pcx_cropper* c, uint8_t** planes_dev,
                         int32_t** corner_dev);
+int32_t pcx_cropper_plane_pitch(const pcx_cropper* c);
+/* Optional: make crop() write into a caller-owned device array (e.g. a tensor
+ * of the host framework) of batch * (1+n_chars) * pitch bytes, dword-aligned;
+ * the reference's croppers likewise write a pre-allocated output
+ * (cropping.py:131-134).  No copy, no synchronisation on the way out. */
+int pcx_cropper_bind_output(pcx_cropper* c, uint8_t* planes_dev);
+/* Device uint8[batch] behind pcx_cropper_errors (read it on the caller's stream). */
+int pcx_cropper_error_buffer(pcx_cropper* c, const uint8_t** errors_dev);
+int pcx_cropper_error_poll(pcx_cropper* c, void* stream, int32_t* seen);
 /* Host copy of uint8[batch]: 1 where the reference would raise RuntimeError
  * (window leaves the observation and there is no pad character,
  * cropping.py:175-183).  Synchronous. */
@@ -340,10 +358,19 @@ int pcx_post_create(const pcx_planes_view* src, const pcx_post_desc* d, int devi
 void pcx_post_destroy(pcx_post* p);
 int pcx_post_run(pcx_post* p, void* stream);
 /* out_dev: TO_ARRAY/FEATURE_ARRAY [batch][depth*rows*cols] elements; REPAINT a
- * planes array [batch][1 + depth][rows*cols] (pitch == rows*cols). */
+ * planes array [batch][1 + depth][pitch], pitch = pcx_post_plane_pitch() =
+ * rows*cols rounded up to a multiple of 4 (pad bytes are 0). */
 int pcx_post_output(pcx_post* p, void** out_dev, uint64_t* bytes);
+int32_t pcx_post_plane_pitch(const pcx_post* p);
+/* Optional: write into a caller-owned, 16-byte aligned device array of exactly
+ * the size pcx_post_output reports (a tensor of the host framework: the
+ * observation-to-tensor hand-off is then zero-copy). */
+int pcx_post_bind_output(pcx_post* p, void* out_dev, uint64_t bytes);
+/* Device uint8[batch] behind pcx_post_errors (read it on the caller's stream). */
+int pcx_post_error_buffer(pcx_post* p, const uint8_t** errors_dev);
+int pcx_post_error_poll(pcx_post* p, void* stream, int32_t* seen);
 /* Host copy of uint8[batch]: 1 where a board character had no mapping
- * (rendering.py:503-507 RuntimeError).  Synchronous. */
+ * (rendering.py:503-507 RuntimeError) or was not ASCII.  Synchronous. */
 int pcx_post_errors(pcx_post* p, uint8_t* errors_host);
 
 #ifdef __cplusplus

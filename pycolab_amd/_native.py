@@ -119,6 +119,7 @@ SYMBOLS = [
     ('pcx_engine_buffers', c_i32, [_VP, ctypes.POINTER(Buffers)]),
     ('pcx_engine_bind_buffers', c_i32, [_VP, ctypes.POINTER(Buffers)]),
     ('pcx_engine_read_things', c_i32, [_VP, c_i64, c_i64, _VP, _VP]),
+    ('pcx_engine_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
     ('pcx_memcpy_d2h', c_i32, [_VP, _VP, c_u64]),
     ('pcx_memcpy_h2d', c_i32, [_VP, _VP, c_u64]),
     ('pcx_device_malloc', c_i32, [ctypes.POINTER(_VP), c_u64]),
@@ -135,6 +136,10 @@ SYMBOLS = [
     ('pcx_cropper_crop', c_i32, [_VP, _VP]),
     ('pcx_cropper_buffers', c_i32, [_VP, ctypes.POINTER(_VP), ctypes.POINTER(_VP)]),
     ('pcx_cropper_errors', c_i32, [_VP, _VP]),
+    ('pcx_cropper_plane_pitch', c_i32, [_VP]),
+    ('pcx_cropper_bind_output', c_i32, [_VP, _VP]),
+    ('pcx_cropper_error_buffer', c_i32, [_VP, ctypes.POINTER(_VP)]),
+    ('pcx_cropper_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
     ('pcx_engine_planes_view', c_i32, [_VP, ctypes.POINTER(PlanesView)]),
     ('pcx_cropper_planes_view', c_i32, [_VP, ctypes.POINTER(PlanesView)]),
     ('pcx_post_create', c_i32, [ctypes.POINTER(PlanesView), ctypes.POINTER(PostDesc), c_i32, ctypes.POINTER(_VP)]),
@@ -142,6 +147,10 @@ SYMBOLS = [
     ('pcx_post_run', c_i32, [_VP, _VP]),
     ('pcx_post_output', c_i32, [_VP, ctypes.POINTER(_VP), ctypes.POINTER(c_u64)]),
     ('pcx_post_errors', c_i32, [_VP, _VP]),
+    ('pcx_post_plane_pitch', c_i32, [_VP]),
+    ('pcx_post_bind_output', c_i32, [_VP, _VP, c_u64]),
+    ('pcx_post_error_buffer', c_i32, [_VP, ctypes.POINTER(_VP)]),
+    ('pcx_post_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
 ]
 
 # PCX_LIB selects another build of the same library (A/B kernel experiments).

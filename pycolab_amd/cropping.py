@@ -3,9 +3,11 @@
 Same classes, constructor arguments, validation and error types as the
 reference.  `crop()` runs on the device: a cropper owns one window per
 environment of the engine's batch (`csrc/pcx_crop.hip`), and the returned
-`Observation` holds [rows, cols] arrays for batch 1 or [B, rows, cols] device
-tensors otherwise -- valid until the next `crop()`, like the reference's
-pre-allocated output (cropping.py:131-134).
+`Observation` holds [rows, cols] NumPy arrays for batch 1 or, for batch > 1,
+[B, rows, cols] device tensors that are zero-copy views of the cropper's
+output planes -- nothing is copied to the host and nothing waits for the
+device; valid until the next `crop()`, like the reference's pre-allocated
+output (cropping.py:131-134).
 """
 
 import copy
@@ -25,6 +27,9 @@ class ObservationCropper(object):
     self._engine = None
     self._native = None
     self._pad_char = None
+    self._out = None        # output planes [B, 1 + n_chars, pitch] (a device tensor with PyTorch)
+    self._pitch = 0
+    self._generation = 0    # bumped whenever the native cropper (and its buffers) is rebuilt
 
   def set_engine(self, engine):
     if engine is not self._engine:
@@ -53,6 +58,8 @@ class ObservationCropper(object):
     if self._native is not None:
       N.lib().pcx_cropper_destroy(self._native)
       self._native = None
+      self._out = None
+      self._generation += 1
 
   def __del__(self):
     try:
@@ -61,13 +68,59 @@ class ObservationCropper(object):
       pass
 
   def _device_crop(self):
+    """Launches the window update and the copy on the current stream and returns
+    the cropped observation: device tensors (zero-copy views of the cropper's
+    output planes, no synchronisation) for batch > 1, NumPy arrays of the
+    reference's shapes for batch 1."""
     eng = self._engine
     if eng is None or eng._native is None:
       raise RuntimeError('crop() needs set_engine() with an engine that is in play')
     if self._native is None:
       self._create_native()
-    N.check(N.lib().pcx_cropper_crop(self._native, dev.current_stream(eng._device_id)))
-    return self._fetch()
+    lib = N.lib()
+    N.check(lib.pcx_cropper_crop(self._native, dev.current_stream(eng._device_id)))
+    chars = eng.template.chars
+    B, P, r, c = eng.batch, 1 + len(chars), self._rows, self._cols
+    if B == 1 or self._out is None or self._out.tensor is None:
+      self.check_errors()  # synchronises; batch 1 raises at once, as the reference does (cropping.py:175-183)
+      if self._out is not None:
+        host = self._out.numpy()
+      else:
+        planes = ctypes.c_void_p()
+        N.check(lib.pcx_cropper_buffers(self._native, ctypes.byref(planes), None))
+        host = np.empty((B, P, self._pitch), np.uint8)
+        N.check(lib.pcx_memcpy_d2h(host.ctypes.data, planes, host.nbytes))
+      host = np.ascontiguousarray(host[:, :, :r * c]).reshape(B, P, r, c)
+      if B == 1:
+        obs = rendering.Observation(
+            board=host[0, 0], layers={chr(ch): host[0, 1 + k].astype(np.bool_) for k, ch in enumerate(chars)})
+      else:
+        obs = rendering.Observation(
+            board=host[:, 0], layers={chr(ch): host[:, 1 + k] for k, ch in enumerate(chars)})
+    else:
+      seen = N.c_i32(0)
+      N.check(lib.pcx_cropper_error_poll(self._native, dev.current_stream(eng._device_id), ctypes.byref(seen)))
+      if seen.value:  # an earlier crop() left the observation without a pad character
+        self.check_errors()
+      view = self._out.tensor.as_strided((B, P, r, c), (P * self._pitch, self._pitch, c, 1))
+      obs = rendering.Observation(board=view[:, 0], layers={chr(ch): view[:, 1 + k] for k, ch in enumerate(chars)})
+    obs._source = self
+    return obs
+
+  def check_errors(self):
+    """Synchronises and raises where the reference raises: the window left the
+    observation and there is no pad character (cropping.py:175-183).  With
+    batch > 1 `crop()` itself does not wait for the device; it reports such an
+    error at a later call, or here."""
+    if self._native is None:
+      return
+    errs = np.empty((self._engine.batch,), np.uint8)
+    N.check(N.lib().pcx_cropper_errors(self._native, errs.ctypes.data))
+    if errs.any():
+      raise RuntimeError(
+          'An ObservationCropper attempted to crop a region that extends '
+          'beyond the observation without specifying a character to fill the '
+          'void that exists out there.')
 
   def _create_native(self):
     eng = self._engine
@@ -79,36 +132,15 @@ class ObservationCropper(object):
             'that isn\'t used by the current game engine.')
       desc = self._describe()
       handle = ctypes.c_void_p()
-      N.check(N.lib().pcx_cropper_create(eng._native, ctypes.byref(desc), ctypes.byref(handle)))
+      lib = N.lib()
+      N.check(lib.pcx_cropper_create(eng._native, ctypes.byref(desc), ctypes.byref(handle)))
       self._native = handle
-
-  def _fetch(self):
-    eng = self._engine
-    planes, corner, err = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
-    N.check(N.lib().pcx_cropper_buffers(self._native, ctypes.byref(planes), ctypes.byref(corner)))
-    B, P, r, c = eng.batch, 1 + len(eng.template.chars), self._rows, self._cols
-    host = np.empty((B, P, r, c), np.uint8)
-    dev.synchronize(eng._device_id)
-    N.check(N.lib().pcx_memcpy_d2h(host.ctypes.data, planes, host.nbytes))
-    errs = np.empty((B,), np.uint8)
-    N.check(N.lib().pcx_cropper_errors(self._native, errs.ctypes.data))
-    if errs.any():
-      raise RuntimeError(
-          'An ObservationCropper attempted to crop a region that extends '
-          'beyond the observation without specifying a character to fill the '
-          'void that exists out there.')
-    return host
-
-  def _observation(self, host):
-    chars = self._engine.template.chars
-    if self._engine.batch == 1:
-      obs = rendering.Observation(
-          board=host[0, 0], layers={chr(ch): host[0, 1 + k].astype(np.bool_) for k, ch in enumerate(chars)})
-    else:
-      obs = rendering.Observation(
-          board=host[:, 0], layers={chr(ch): host[:, 1 + k] for k, ch in enumerate(chars)})
-    obs._source = self
-    return obs
+      self._generation += 1
+      self._pitch = int(lib.pcx_cropper_plane_pitch(handle))
+      self._out = None
+      if dev.torch_module() is not None:  # the output planes are a tensor of ours: crop() hands out views of it
+        self._out = dev.DeviceBuffer((eng.batch, 1 + len(eng.template.chars), self._pitch), np.uint8, eng._device_id)
+        N.check(lib.pcx_cropper_bind_output(handle, self._out.ptr))
 
   def _planes_view(self):
     view = N.PlanesView()
@@ -128,7 +160,7 @@ class FixedCropper(ObservationCropper):
 
   def crop(self, observation):
     del observation  # the device crops the engine's current observation
-    return self._observation(self._device_crop())
+    return self._device_crop()
 
   def _describe(self):
     d = N.CropperDesc()
@@ -189,7 +221,7 @@ class ScrollingCropper(ObservationCropper):
 
   def crop(self, observation):
     del observation
-    return self._observation(self._device_crop())
+    return self._device_crop()
 
   def _describe(self):
     things = set(self._engine.z_order)

@@ -2,8 +2,10 @@
 //   pcx_crop_update: one thread per environment moves the window
 //     (ScrollingCropper.crop :393-426, _initialise :438-458, _can_pan_to
 //     :460-506, _pan_to :508-534, _rectify :536-542, _centroid :551-598);
-//   pcx_crop_copy: one thread per output dword gathers the window from the
-//     engine's observation planes (_do_crop :118-227), padding included.
+//   pcx_crop_copy: one lane per (environment, output dword) gathers the window
+//     from the engine's observation planes (_do_crop :118-227), padding
+//     included, plane after plane, with aligned dword loads and 256-byte
+//     wave stores.
 // Sprite positions come from the step kernel's per-step `track` words, drape
 // curtains (only for drape-tracking croppers) from its raw curtain export.
 #include "pcx_internal.h"
@@ -120,30 +122,60 @@ __global__ void pcx_crop_update(CropParams p, const int32_t* track, const uint32
   error[b] = p.pad_char < 0 && (top < 0 || left < 0 || top + p.rows > p.R || left + p.cols > p.C);
 }
 
+// _do_crop (cropping.py:118-227).  One lane per (environment, output dword);
+// the window's place in the observation is the same for every plane, so a lane
+// works out its source once and then walks the 1 + L planes: consecutive lanes
+// write consecutive dwords of one output plane (256-byte wave stores), and read
+// their four cells as two aligned source dwords funnelled by the window's byte
+// phase -- no per-byte loads on the common path.  Cells outside the observation
+// take the pad character (or its layer bit); a dword that straddles two window
+// rows, or touches the observation's edge, takes the byte path.
 __global__ void pcx_crop_copy(CropParams p, const uint8_t* in, const int32_t* corner, const uint8_t* error,
                               uint8_t* out) {
   const int planes = 1 + p.L, qw = p.out_pitch / 4;
-  const int64_t total = p.batch * planes * qw;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int q = (int)(i % qw);
-  const int pl = (int)((i / qw) % planes);
-  const int64_t b = i / ((int64_t)qw * planes);
-  if (error[b]) return;
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;  // < batch * qw (checked on the host)
+  const uint32_t b = f / (uint32_t)qw, q = f - b * (uint32_t)qw;
+  if ((int64_t)b >= p.batch || error[b]) return;
   const int top = corner[2 * b], left = corner[2 * b + 1];
-  const uint8_t* src = in + ((size_t)b * planes + pl) * p.in_pitch;
-  const uint32_t pad = pl == 0 ? (uint32_t)p.pad_char : (uint32_t)((uint32_t)p.pad_char == p.chars[pl - 1]);
-  uint32_t v = 0;
-  for (int j = 0; j < 4; ++j) {
-    const int cell = q * 4 + j;
-    uint32_t byte = 0;
-    if (cell < p.rows * p.cols) {
-      const int r = cell / p.cols + top, c = cell % p.cols + left;
-      byte = ((unsigned)r < (unsigned)p.R && (unsigned)c < (unsigned)p.C) ? src[r * p.C + c] : pad;
+  const int cell0 = (int)q * 4, orow = cell0 / p.cols, ocol = cell0 - orow * p.cols;
+  const int sr = orow + top, sc = left + ocol;
+  const bool fast = ocol + 3 < p.cols && (unsigned)sr < (unsigned)p.R && sc >= 0 && sc + 3 < p.C;
+  const uint8_t* src = in + (size_t)b * planes * p.in_pitch;
+  uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)b * planes * p.out_pitch) + q;
+  if (fast) {
+    const uint32_t a = (uint32_t)(sr * p.C + sc), phase = a & 3u;
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src) + (a >> 2);
+    for (int pl = 0; pl < planes; ++pl) {
+      const uint32_t lo = s32[0], hi = phase ? s32[1] : 0u;
+      *dst = __builtin_amdgcn_alignbyte(hi, lo, phase);
+      s32 += p.in_pitch / 4;
+      dst += qw;
     }
-    v |= (byte & 0xFF) << (8 * j);
+    return;
   }
-  reinterpret_cast<uint32_t*>(out + ((size_t)b * planes + pl) * p.out_pitch)[q] = v;
+  int rr[4], cc[4];
+  bool inside[4], real[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cell = cell0 + j;
+    real[j] = cell < p.rows * p.cols;  // cells past the window are plane padding (zeros)
+    const int r = cell / p.cols;
+    rr[j] = r + top;
+    cc[j] = cell - r * p.cols + left;
+    inside[j] = (unsigned)rr[j] < (unsigned)p.R && (unsigned)cc[j] < (unsigned)p.C;
+  }
+  for (int pl = 0; pl < planes; ++pl) {
+    const uint32_t pad = pl == 0 ? (uint32_t)p.pad_char : (uint32_t)((uint32_t)p.pad_char == p.chars[pl - 1]);
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t byte = !real[j] ? 0u : inside[j] ? src[rr[j] * p.C + cc[j]] : pad;
+      v |= (byte & 0xFFu) << (8 * j);
+    }
+    *dst = v;
+    src += p.in_pitch;
+    dst += qw;
+  }
 }
 
 }  // namespace
@@ -151,9 +183,16 @@ __global__ void pcx_crop_copy(CropParams p, const uint8_t* in, const int32_t* co
 struct pcx_cropper {
   pcx_engine* e = nullptr;
   CropParams p{};
-  pcx::DevArray<uint8_t> planes, has_corner, error, dense;
+  pcx::DevArray<uint8_t> planes, has_corner, error;
   pcx::DevArray<int32_t> corner;
+  pcx::ErrorPoll error_poll;
+  uint8_t* bound = nullptr;  // caller-owned output planes (pcx_cropper_bind_output)
   bool tracks_drape = false;
+  uint8_t* out_planes() const { return bound ? bound : planes.ptr; }
+  int ensure_planes() {  // own output planes only when the caller bound none
+    if (bound || planes.ptr) return 0;
+    return planes.alloc((size_t)e->batch * (1 + p.L) * p.out_pitch);
+  }
 };
 
 extern "C" {
@@ -198,9 +237,12 @@ int pcx_cropper_create(pcx_engine* e, const pcx_cropper_desc* d, pcx_cropper** o
     e->want_curtains = true;
   }
   int rc;
-  if ((rc = c->planes.alloc((size_t)e->batch * (1 + p.L) * p.out_pitch)) || (rc = c->has_corner.alloc(e->batch)) ||
-      (rc = c->error.alloc(e->batch)) || (rc = c->corner.alloc((size_t)e->batch * 2)) ||
-      (rc = c->dense.alloc((size_t)e->batch * (1 + p.L) * d->rows * d->cols))) { delete c; return rc; }
+  if ((rc = c->has_corner.alloc(e->batch)) ||
+      (rc = c->error.alloc(e->batch)) || (rc = c->corner.alloc((size_t)e->batch * 2))) { delete c; return rc; }
+  if ((uint64_t)e->batch * (uint64_t)(p.out_pitch / 4) >= (1ull << 32)) {
+    delete c;
+    return set_error(PCX_E_UNSUPPORTED, "croppers: batch x window too large for 32-bit task indices");
+  }
   *out = c;
   return 0;
 }
@@ -218,35 +260,55 @@ int pcx_cropper_crop(pcx_cropper* c, void* stream) {
   if (c->tracks_drape && !e->curtains_fresh)
     return set_error(PCX_E_STATE, "pcx_cropper_crop: curtains were not exported by the last step");
   PCX_HIP(hipSetDevice(e->device));
+  if (int rc = c->ensure_planes()) return rc;
   hipStream_t s = (hipStream_t)stream;
   const CropParams& p = c->p;
   hipLaunchKernelGGL(pcx_crop_update, dim3((unsigned)((p.batch + 255) / 256)), dim3(256), 0, s, p,
                      e->backend->sprite_track(), e->backend->curtain_bits(), e->out.frame, c->corner.ptr,
                      c->has_corner.ptr, c->error.ptr);
-  const int64_t total = p.batch * (1 + p.L) * (p.out_pitch / 4);
+  const int64_t total = p.batch * (p.out_pitch / 4);
   hipLaunchKernelGGL(pcx_crop_copy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, e->out.planes,
-                     c->corner.ptr, c->error.ptr, c->planes.ptr);
-  // dense [batch][1+L][rows*cols] copy for hosts (2-D strided copy on the same stream)
-  PCX_HIP(hipMemcpy2DAsync(c->dense.ptr, (size_t)p.rows * p.cols, c->planes.ptr, p.out_pitch, (size_t)p.rows * p.cols,
-                           (size_t)p.batch * (1 + p.L), hipMemcpyDeviceToDevice, s));
+                     c->corner.ptr, c->error.ptr, c->out_planes());
   PCX_HIP(hipGetLastError());
   return 0;
 }
 
 int pcx_cropper_buffers(pcx_cropper* c, uint8_t** planes_dev, int32_t** corner_dev) {
   if (!c) return set_error(PCX_E_INVALID, "pcx_cropper_buffers: null cropper");
-  if (planes_dev) *planes_dev = c->dense.ptr;  // dense [batch][1+n_chars][rows][cols]
+  if (int rc = c->ensure_planes()) return rc;
+  if (planes_dev) *planes_dev = c->out_planes();  // [batch][1+n_chars][pitch]
   if (corner_dev) *corner_dev = c->corner.ptr;
   return 0;
 }
 
 int pcx_cropper_planes_view(pcx_cropper* c, pcx_planes_view* out) {
   if (!c || !out) return set_error(PCX_E_INVALID, "pcx_cropper_planes_view: bad arguments");
+  if (int rc = c->ensure_planes()) return rc;
   memset(out, 0, sizeof *out);
-  out->planes = c->dense.ptr; out->batch = c->e->batch; out->rows = c->p.rows; out->cols = c->p.cols;
-  out->pitch = c->p.rows * c->p.cols; out->n_chars = c->p.L;
+  out->planes = c->out_planes(); out->batch = c->e->batch; out->rows = c->p.rows; out->cols = c->p.cols;
+  out->pitch = c->p.out_pitch; out->n_chars = c->p.L;
   memcpy(out->chars, c->e->t.chars, PCX_MAX_CHARS);
   return 0;
+}
+
+int32_t pcx_cropper_plane_pitch(const pcx_cropper* c) { return c ? c->p.out_pitch : 0; }
+
+int pcx_cropper_bind_output(pcx_cropper* c, uint8_t* planes_dev) {
+  if (!c || !planes_dev) return set_error(PCX_E_INVALID, "pcx_cropper_bind_output: bad arguments");
+  c->bound = planes_dev;
+  return 0;
+}
+
+int pcx_cropper_error_buffer(pcx_cropper* c, const uint8_t** errors_dev) {
+  if (!c || !errors_dev) return set_error(PCX_E_INVALID, "pcx_cropper_error_buffer: bad arguments");
+  *errors_dev = c->error.ptr;
+  return 0;
+}
+
+int pcx_cropper_error_poll(pcx_cropper* c, void* stream, int32_t* seen) {
+  if (!c) return set_error(PCX_E_INVALID, "pcx_cropper_error_poll: null cropper");
+  PCX_HIP(hipSetDevice(c->e->device));
+  return c->error_poll.poll(c->error.ptr, c->e->batch, (hipStream_t)stream, seen);
 }
 
 int pcx_cropper_errors(pcx_cropper* c, uint8_t* errors_host) {

@@ -64,6 +64,39 @@ static int ensure_outputs(pcx_engine* e) {
   return 0;
 }
 
+__global__ void pcx_any_nonzero(const uint8_t* v, int64_t n, uint32_t* flag) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i >= n) return;
+  uint32_t any = 0;
+  if (i + 16 <= n && (reinterpret_cast<uintptr_t>(v) & 15u) == 0) {
+    const uint4 w = *reinterpret_cast<const uint4*>(v + i);
+    any = w.x | w.y | w.z | w.w;
+  } else {
+    for (int64_t j = i; j < n && j < i + 16; ++j) any |= v[j];
+  }
+  if (any) atomicOr(flag, 1u);
+}
+
+ErrorPoll::~ErrorPoll() {
+  if (dev) (void)hipFree(dev);
+  if (host) (void)hipHostFree(host);
+}
+
+int ErrorPoll::poll(const uint8_t* errors_dev, int64_t n, hipStream_t s, int32_t* seen) {
+  if (!dev) {
+    PCX_HIP(hipMalloc(reinterpret_cast<void**>(&dev), 4));
+    PCX_HIP(hipHostMalloc(reinterpret_cast<void**>(&host), 4, hipHostMallocDefault));
+    *host = 0;
+  }
+  if (seen) *seen = (int32_t)*reinterpret_cast<volatile uint32_t*>(host);
+  PCX_HIP(hipMemsetAsync(dev, 0, 4, s));
+  const int64_t threads = (n + 15) / 16;
+  hipLaunchKernelGGL(pcx_any_nonzero, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, errors_dev, n, dev);
+  PCX_HIP(hipGetLastError());
+  PCX_HIP(hipMemcpyAsync(host, dev, 4, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
 }  // namespace pcx
 
 using pcx::set_error;
@@ -219,6 +252,12 @@ int pcx_engine_step_hashed(pcx_engine* e, uint64_t seed, int64_t env_offset, int
     t += n;
   }
   return 0;
+}
+
+int pcx_engine_error_poll(pcx_engine* e, void* stream, int32_t* seen) {
+  if (!e || !e->out.error) return set_error(PCX_E_INVALID, "pcx_engine_error_poll: bad arguments");
+  PCX_HIP(hipSetDevice(e->device));
+  return e->error_poll.poll(e->out.error, e->batch, (hipStream_t)stream, seen);
 }
 
 int pcx_engine_read_things(pcx_engine* e, int64_t env0, int64_t n, pcx_sprite_state* sprites_host,

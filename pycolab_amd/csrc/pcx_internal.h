@@ -64,6 +64,17 @@ struct DevArray {
   }
 };
 
+// "Did any environment raise?" without a host synchronisation: poll() enqueues
+// a reduction of a device uint8[n] error array into one word and its copy into
+// pinned host memory, and reports what an EARLIER poll found (0 until one has
+// completed).  The caller that sees nonzero then takes the synchronous path.
+struct ErrorPoll {
+  uint32_t* dev = nullptr;
+  uint32_t* host = nullptr;
+  ~ErrorPoll();
+  int poll(const uint8_t* errors_dev, int64_t n, hipStream_t s, int32_t* seen);
+};
+
 class Backend {
  public:
   virtual ~Backend() {}
@@ -104,6 +115,7 @@ struct pcx_engine {
   pcx_buffers out{};       // where the kernels write (own or bound)
   bool own_out = false;
   uint64_t epoch = 0;      // bumped by every reset/step (croppers)
+  pcx::ErrorPoll error_poll;
   bool want_curtains = false;   // a drape-tracking cropper exists
   bool curtains_fresh = false;  // the last launch exported curtains
 };

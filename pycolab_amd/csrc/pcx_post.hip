@@ -1,6 +1,12 @@
 // pcx_post.hip -- observation post-processors as streaming epilogue kernels
-// (reference: pycolab/rendering.py:304-661).  One thread per output element
-// group; inputs are the planes an engine or a cropper just wrote (L2-hot).
+// (reference: pycolab/rendering.py:304-661).  Inputs are the planes an engine
+// or a cropper just wrote (L2 / Infinity-Cache hot); one lane per board dword
+// (four cells), so plane reads are coalesced dwords and -- in the reference's
+// default axis order -- every store is a 4-, 16- or 32-byte vector per lane
+// (256 B to 2 KiB contiguous per wave).  Permuted outputs (`permute=`) fall
+// back to strided element stores.  The output array belongs to the caller
+// when one was bound (pcx_post_bind_output): the host hands it on as a device
+// tensor, no copy and no synchronisation.
 #include "pcx_internal.h"
 
 #include <cstring>
@@ -10,55 +16,145 @@ using pcx::set_error;
 namespace {
 
 struct PostParams {
-  int32_t kind, dtype, esize, depth, R, C, cells, pitch, n_planes;
+  int32_t kind, dtype, esize, depth, R, C, cells, pitch, n_planes, out_pitch, linear;
   int64_t batch, stride[3];
   int32_t layer_plane[PCX_POST_MAX_DEPTH];  // FEATURE_ARRAY: source plane per output layer, -1 = absent
   uint32_t out_char[PCX_POST_MAX_DEPTH];    // REPAINT: output layer characters
 };
 
-// ObservationToArray: out[b][perm(d, r, c)] = lut[d][board[b][r][c]]
+template <typename T>
+__device__ __forceinline__ void store4(T* dst, T a, T b, T c, T d);
+template <>
+__device__ __forceinline__ void store4<uint8_t>(uint8_t* dst, uint8_t a, uint8_t b, uint8_t c, uint8_t d) {
+  *reinterpret_cast<uint32_t*>(dst) = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+}
+template <>
+__device__ __forceinline__ void store4<uint32_t>(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  *reinterpret_cast<uint4*>(dst) = make_uint4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4<uint64_t>(uint64_t* dst, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+  reinterpret_cast<ulonglong2*>(dst)[0] = make_ulonglong2(a, b);
+  reinterpret_cast<ulonglong2*>(dst)[1] = make_ulonglong2(c, d);
+}
+
+// ObservationToArray (rendering.py:409-542): out[b][perm(d, r, c)] = lut[d][board[b][r][c]]
+template <typename T>
 __global__ void pcx_post_to_array(PostParams p, const uint8_t* planes, const uint64_t* lut, const uint8_t* mapped,
-                                  uint8_t* out, uint8_t* error) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.batch * p.cells) return;
-  const int64_t b = i / p.cells;
-  const int cell = (int)(i - b * p.cells), r = cell / p.C, c = cell - r * p.C;
-  const uint32_t ch = planes[(size_t)b * p.n_planes * p.pitch + cell] & 127u;
-  if (!mapped[ch]) { error[b] = 1; return; }
-  for (int d = 0; d < p.depth; ++d) {
-    const uint64_t v = lut[d * 128 + ch];
-    const int64_t o = b * (int64_t)p.depth * p.cells + d * p.stride[0] + r * p.stride[1] + c * p.stride[2];
-    switch (p.esize) {
-      case 1: out[o] = (uint8_t)v; break;
-      case 4: reinterpret_cast<uint32_t*>(out)[o] = (uint32_t)v; break;
-      default: reinterpret_cast<uint64_t*>(out)[o] = v; break;
+                                  T* out, uint8_t* error) {
+  extern __shared__ uint64_t lds_lut[];  // [depth][128] values, then 128 mapped bytes
+  uint8_t* lds_mapped = reinterpret_cast<uint8_t*>(lds_lut + p.depth * 128);
+  for (int i = threadIdx.x; i < p.depth * 128; i += blockDim.x) lds_lut[i] = lut[i];
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) lds_mapped[i] = mapped[i];
+  __syncthreads();
+  // the table is staged once per workgroup, so a workgroup takes many dwords
+  // (grid-stride): one lane per board dword and trip
+  const int qw = p.pitch / 4;
+  const uint32_t total = (uint32_t)p.batch * (uint32_t)qw;
+  for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < total; f += gridDim.x * blockDim.x) {
+    const uint32_t b = f / (uint32_t)qw, q = f - b * (uint32_t)qw;
+    const uint32_t d4 = reinterpret_cast<const uint32_t*>(planes + (size_t)b * p.n_planes * p.pitch)[q];
+    const int cell0 = (int)q * 4, n = p.cells - cell0 < 4 ? p.cells - cell0 : 4;
+    uint32_t ch[4];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ch[j] = (d4 >> (8 * j)) & 0xFFu;
+      if (j < n && (ch[j] >= 128u || !lds_mapped[ch[j]])) bad = true;  // rendering.py:503-507
+      ch[j] &= 127u;
+    }
+    if (bad) { error[b] = 1; continue; }
+    T* const o = out + (size_t)b * p.depth * p.cells;
+    if (p.linear && n == 4) {  // default axis order: (d, r, c) row-major, four consecutive elements per layer
+      for (int d = 0; d < p.depth; ++d)
+        store4<T>(o + (size_t)d * p.cells + cell0, (T)lds_lut[d * 128 + ch[0]], (T)lds_lut[d * 128 + ch[1]],
+                  (T)lds_lut[d * 128 + ch[2]], (T)lds_lut[d * 128 + ch[3]]);
+      continue;
+    }
+    for (int j = 0; j < n; ++j) {
+      const int cell = cell0 + j, r = cell / p.C, c = cell - r * p.C;
+      for (int d = 0; d < p.depth; ++d)
+        o[d * p.stride[0] + r * p.stride[1] + c * p.stride[2]] = (T)lds_lut[d * 128 + ch[j]];
     }
   }
 }
 
-// ObservationToFeatureArray: float32 stack of chosen layer planes
+// ObservationToFeatureArray (rendering.py:545-661): float32 stack of chosen layer planes
 __global__ void pcx_post_features(PostParams p, const uint8_t* planes, float* out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.batch * p.depth * p.cells) return;
-  const int cell = (int)(i % p.cells);
-  const int d = (int)((i / p.cells) % p.depth);
-  const int64_t b = i / ((int64_t)p.cells * p.depth);
-  const int r = cell / p.C, c = cell - r * p.C;
-  const int plane = p.layer_plane[d];
-  const float v = plane < 0 ? 0.0f : (float)planes[((size_t)b * p.n_planes + plane) * p.pitch + cell];
-  out[b * (int64_t)p.depth * p.cells + d * p.stride[0] + r * p.stride[1] + c * p.stride[2]] = v;
+  const int qw = p.pitch / 4;
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = f / (uint32_t)qw, q = f - b * (uint32_t)qw;
+  if ((int64_t)b >= p.batch) return;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(planes + (size_t)b * p.n_planes * p.pitch) + q;
+  const int cell0 = (int)q * 4, n = p.cells - cell0 < 4 ? p.cells - cell0 : 4;
+  float* const o = out + (size_t)b * p.depth * p.cells;
+  if (p.linear == 2 && n == 4) {
+    // permute=(1, 2, 0), "channels last": a cell's depth values are adjacent, so
+    // the lane's four cells are one run of 4 * depth floats = depth 16-byte
+    // stores; element e of the run is layer e % depth of cell e / depth (the
+    // layer dwords are re-read from L1/L2 rather than kept in registers)
+    float4* const run = reinterpret_cast<float4*>(o + (size_t)cell0 * p.depth);
+    for (int i = 0; i < p.depth; ++i) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = 4 * i + k, j = e / p.depth, d = e - j * p.depth;
+        const int plane = p.layer_plane[d];
+        const uint32_t m = plane < 0 ? 0u : src[(size_t)plane * qw];
+        v[k] = (float)((m >> (8 * j)) & 0xFFu);
+      }
+      run[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return;
+  }
+  for (int d = 0; d < p.depth; ++d) {
+    const int plane = p.layer_plane[d];
+    const uint32_t m = plane < 0 ? 0u : src[(size_t)plane * qw];
+    const float v0 = (float)(m & 0xFFu), v1 = (float)((m >> 8) & 0xFFu), v2 = (float)((m >> 16) & 0xFFu), v3 = (float)(m >> 24);
+    if (p.linear == 1 && n == 4) {
+      *reinterpret_cast<float4*>(o + (size_t)d * p.cells + cell0) = make_float4(v0, v1, v2, v3);
+    } else {
+      const float v[4] = {v0, v1, v2, v3};
+      for (int j = 0; j < n; ++j) {
+        const int cell = cell0 + j, r = cell / p.C, c = cell - r * p.C;
+        o[d * p.stride[0] + r * p.stride[1] + c * p.stride[2]] = v[j];
+      }
+    }
+  }
 }
 
-// ObservationCharacterRepainter: board through a 128-entry table, layers = board == c
-__global__ void pcx_post_repaint(PostParams p, const uint8_t* planes, const uint64_t* lut, uint8_t* out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.batch * p.cells) return;
-  const int64_t b = i / p.cells;
-  const int cell = (int)(i - b * p.cells);
-  const uint32_t ch = (uint32_t)lut[planes[(size_t)b * p.n_planes * p.pitch + cell] & 127u] & 0xFFu;
-  uint8_t* o = out + (size_t)b * (1 + p.depth) * p.cells + cell;
-  o[0] = (uint8_t)ch;
-  for (int d = 0; d < p.depth; ++d) o[(size_t)(1 + d) * p.cells] = ch == p.out_char[d];
+// ObservationCharacterRepainter (rendering.py:304-406): board through a
+// 128-entry table, then layers[c] = (board == c) by a byte-wise SWAR compare.
+__global__ void pcx_post_repaint(PostParams p, const uint8_t* planes, const uint64_t* lut, uint8_t* out, uint8_t* error) {
+  __shared__ uint8_t table[128];
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) table[i] = (uint8_t)lut[i];
+  __syncthreads();
+  const int qw = p.pitch / 4, oqw = p.out_pitch / 4;
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = f / (uint32_t)qw, q = f - b * (uint32_t)qw;
+  if ((int64_t)b >= p.batch) return;
+  const uint32_t d4 = reinterpret_cast<const uint32_t*>(planes + (size_t)b * p.n_planes * p.pitch)[q];
+  const int cell0 = (int)q * 4, n = p.cells - cell0 < 4 ? p.cells - cell0 : 4;
+  uint32_t v = 0, valid = 0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t ch = (d4 >> (8 * j)) & 0xFFu;
+    if (j < n) {
+      bad |= ch >= 128u;
+      v |= (uint32_t)table[ch & 127u] << (8 * j);
+      valid |= 0x01u << (8 * j);
+    }
+  }
+  if (bad) error[b] = 1;
+  uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)b * (1 + p.depth) * p.out_pitch) + q;
+  *o = v;
+  for (int d = 0; d < p.depth; ++d) {
+    o += oqw;
+    const uint32_t x = v ^ (p.out_char[d] * 0x01010101u);  // a zero byte where the board shows this character
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    *o = ((~(t | x | 0x7F7F7F7Fu)) >> 7) & valid;
+  }
 }
 
 }  // namespace
@@ -69,7 +165,14 @@ struct pcx_post {
   const uint8_t* planes = nullptr;
   pcx::DevArray<uint64_t> lut;
   pcx::DevArray<uint8_t> mapped, out, error;
+  pcx::ErrorPoll error_poll;
+  void* bound = nullptr;  // caller-owned output (pcx_post_bind_output)
   uint64_t out_bytes = 0;
+  int ensure_out() {
+    if (bound || out.ptr) return 0;
+    return out.alloc(out_bytes);
+  }
+  void* out_ptr() const { return bound ? bound : (void*)out.ptr; }
 };
 
 extern "C" {
@@ -87,6 +190,10 @@ int pcx_engine_planes_view(pcx_engine* e, pcx_planes_view* out) {
 int pcx_post_create(const pcx_planes_view* src, const pcx_post_desc* d, int device_id, pcx_post** out) {
   if (!src || !d || !out || !src->planes || src->batch <= 0 || d->depth < 1 || d->depth > PCX_POST_MAX_DEPTH)
     return set_error(PCX_E_INVALID, "pcx_post_create: bad arguments");
+  if (src->pitch % 4 != 0 || src->pitch < src->rows * src->cols)
+    return set_error(PCX_E_INVALID, "pcx_post_create: plane pitch must be a multiple of 4 that covers rows*cols");
+  if ((uint64_t)src->batch * (uint64_t)(src->pitch / 4) >= (1ull << 32))
+    return set_error(PCX_E_UNSUPPORTED, "pcx_post_create: batch x board too large for 32-bit task indices");
   PCX_HIP(hipSetDevice(device_id));
   pcx_post* q = new pcx_post();
   q->device = device_id;
@@ -94,7 +201,10 @@ int pcx_post_create(const pcx_planes_view* src, const pcx_post_desc* d, int devi
   PostParams& p = q->p;
   p.kind = d->kind; p.dtype = d->dtype; p.depth = d->depth; p.R = src->rows; p.C = src->cols;
   p.cells = src->rows * src->cols; p.pitch = src->pitch; p.n_planes = 1 + src->n_chars; p.batch = src->batch;
+  p.out_pitch = (p.cells + 3) & ~3;
   for (int i = 0; i < 3; ++i) p.stride[i] = d->stride[i];
+  // the reference's default axis order: element (d, r, c) at d * cells + r * C + c
+  p.linear = d->stride[0] == p.cells && d->stride[1] == p.C && d->stride[2] == 1;
   int rc = 0;
   switch (d->kind) {
     case PCX_POST_TO_ARRAY:
@@ -111,16 +221,22 @@ int pcx_post_create(const pcx_planes_view* src, const pcx_post_desc* d, int devi
       break;
     case PCX_POST_REPAINT:
       p.esize = 1;
-      q->out_bytes = (uint64_t)p.batch * (1 + p.depth) * p.cells;
+      q->out_bytes = (uint64_t)p.batch * (1 + p.depth) * p.out_pitch;
       for (int i = 0; i < p.depth; ++i) p.out_char[i] = d->chars[i];
       break;
     default: delete q; return set_error(PCX_E_INVALID, "pcx_post_create: unknown kind");
   }
+  // vector stores need the per-environment block to keep the vector's alignment
+  if (p.linear && ((uint64_t)p.depth * p.cells * p.esize) % (4u * p.esize) != 0) p.linear = 0;
+  if (p.linear && p.cells % 4 != 0) p.linear = 0;
+  // "channels last" (permute=(1, 2, 0)): element (d, r, c) at (r * C + c) * depth + d
+  if (d->kind == PCX_POST_FEATURE_ARRAY && d->stride[0] == 1 && d->stride[2] == p.depth &&
+      d->stride[1] == (int64_t)p.C * p.depth && p.cells % 4 == 0)
+    p.linear = 2;
   std::vector<uint64_t> lut((size_t)PCX_POST_MAX_DEPTH * 128);
   memcpy(lut.data(), d->lut, sizeof d->lut);
   std::vector<uint8_t> mapped(d->mapped, d->mapped + 128);
-  if ((rc = q->lut.upload(lut)) || (rc = q->mapped.upload(mapped)) || (rc = q->out.alloc(q->out_bytes)) ||
-      (rc = q->error.alloc(p.batch))) { delete q; return rc; }
+  if ((rc = q->lut.upload(lut)) || (rc = q->mapped.upload(mapped)) || (rc = q->error.alloc(p.batch))) { delete q; return rc; }
   *out = q;
   return 0;
 }
@@ -131,24 +247,40 @@ void pcx_post_destroy(pcx_post* p) {
   delete p;
 }
 
+int pcx_post_bind_output(pcx_post* p, void* out_dev, uint64_t bytes) {
+  if (!p || !out_dev) return set_error(PCX_E_INVALID, "pcx_post_bind_output: bad arguments");
+  if (bytes != p->out_bytes) return set_error(PCX_E_INVALID, "pcx_post_bind_output: the output needs %llu bytes", (unsigned long long)p->out_bytes);
+  if ((reinterpret_cast<uintptr_t>(out_dev) & 15u) != 0) return set_error(PCX_E_INVALID, "pcx_post_bind_output: the output must be 16-byte aligned");
+  p->bound = out_dev;
+  return 0;
+}
+
 int pcx_post_run(pcx_post* q, void* stream) {
   if (!q) return set_error(PCX_E_INVALID, "pcx_post_run: null");
   PCX_HIP(hipSetDevice(q->device));
+  if (int rc = q->ensure_out()) return rc;
   hipStream_t s = (hipStream_t)stream;
   const PostParams& p = q->p;
   PCX_HIP(hipMemsetAsync(q->error.ptr, 0, p.batch, s));
+  const int64_t n = p.batch * (p.pitch / 4);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (p.kind == PCX_POST_TO_ARRAY) {
-    const int64_t n = p.batch * p.cells;
-    hipLaunchKernelGGL(pcx_post_to_array, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, q->planes, q->lut.ptr,
-                       q->mapped.ptr, q->out.ptr, q->error.ptr);
+    const size_t lds = (size_t)p.depth * 128 * 8 + 128;
+    const dim3 grid((unsigned)((n + 255) / 256 < 256 * 16 ? (n + 255) / 256 : 256 * 16));  // 16 workgroups per CU stage the table once each
+    if (p.esize == 1)
+      hipLaunchKernelGGL(pcx_post_to_array<uint8_t>, grid, block, lds, s, p, q->planes, q->lut.ptr, q->mapped.ptr,
+                         reinterpret_cast<uint8_t*>(q->out_ptr()), q->error.ptr);
+    else if (p.esize == 4)
+      hipLaunchKernelGGL(pcx_post_to_array<uint32_t>, grid, block, lds, s, p, q->planes, q->lut.ptr, q->mapped.ptr,
+                         reinterpret_cast<uint32_t*>(q->out_ptr()), q->error.ptr);
+    else
+      hipLaunchKernelGGL(pcx_post_to_array<uint64_t>, grid, block, lds, s, p, q->planes, q->lut.ptr, q->mapped.ptr,
+                         reinterpret_cast<uint64_t*>(q->out_ptr()), q->error.ptr);
   } else if (p.kind == PCX_POST_FEATURE_ARRAY) {
-    const int64_t n = p.batch * p.depth * p.cells;
-    hipLaunchKernelGGL(pcx_post_features, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, q->planes,
-                       reinterpret_cast<float*>(q->out.ptr));
+    hipLaunchKernelGGL(pcx_post_features, grid, block, 0, s, p, q->planes, reinterpret_cast<float*>(q->out_ptr()));
   } else {
-    const int64_t n = p.batch * p.cells;
-    hipLaunchKernelGGL(pcx_post_repaint, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, q->planes, q->lut.ptr,
-                       q->out.ptr);
+    hipLaunchKernelGGL(pcx_post_repaint, grid, block, 0, s, p, q->planes, q->lut.ptr, reinterpret_cast<uint8_t*>(q->out_ptr()),
+                       q->error.ptr);
   }
   PCX_HIP(hipGetLastError());
   return 0;
@@ -156,9 +288,26 @@ int pcx_post_run(pcx_post* q, void* stream) {
 
 int pcx_post_output(pcx_post* p, void** out_dev, uint64_t* bytes) {
   if (!p) return set_error(PCX_E_INVALID, "pcx_post_output: null");
-  if (out_dev) *out_dev = p->out.ptr;
+  if (out_dev) {
+    if (int rc = p->ensure_out()) return rc;
+    *out_dev = p->out_ptr();
+  }
   if (bytes) *bytes = p->out_bytes;
   return 0;
+}
+
+int32_t pcx_post_plane_pitch(const pcx_post* p) { return p ? p->p.out_pitch : 0; }
+
+int pcx_post_error_buffer(pcx_post* p, const uint8_t** errors_dev) {
+  if (!p || !errors_dev) return set_error(PCX_E_INVALID, "pcx_post_error_buffer: bad arguments");
+  *errors_dev = p->error.ptr;
+  return 0;
+}
+
+int pcx_post_error_poll(pcx_post* p, void* stream, int32_t* seen) {
+  if (!p) return set_error(PCX_E_INVALID, "pcx_post_error_poll: null");
+  PCX_HIP(hipSetDevice(p->device));
+  return p->error_poll.poll(p->error.ptr, p->p.batch, (hipStream_t)stream, seen);
 }
 
 int pcx_post_errors(pcx_post* p, uint8_t* errors_host) {

@@ -16,7 +16,7 @@ from pycolab_amd import _native as N
 from pycolab_amd._torchprobe import torch_module  # noqa: F401 (re-exported)
 
 
-_NP_TO_TORCH = {'uint8': 'uint8', 'int32': 'int32', 'float32': 'float32'}
+_NP_TO_TORCH = {'uint8': 'uint8', 'int32': 'int32', 'float32': 'float32', 'int64': 'int64', 'float64': 'float64'}
 
 
 class DeviceBuffer(object):

@@ -244,6 +244,13 @@ class Engine(object):
       raise RuntimeError('play() was called after the episode handled by this '
                          'Engine has terminated.')
     self.step(actions)
+    if self._batch > 1:
+      # no host synchronisation per step: ask (asynchronously) whether any
+      # environment raised, and act on what an earlier step's poll found
+      seen = N.c_i32(0)
+      N.check(N.lib().pcx_engine_error_poll(self._native, dev.current_stream(self._device_id), ctypes.byref(seen)))
+      if seen.value:
+        self.check_errors()
     return self._result()
 
   def reset(self, env_mask=None):
@@ -323,14 +330,17 @@ class Engine(object):
             ('reward', 'reward_set', 'discount', 'done', 'frame', 'error')}
 
   def check_errors(self):
-    """Raise if a device program hit a condition the reference raises for."""
+    """Synchronises and raises if a device program hit a condition the
+    reference raises for (the bits are sticky within an episode).  `play()`
+    with batch 1 checks every step; with batch > 1 it polls asynchronously and
+    raises one or two steps late; `step()` never checks."""
     err = self._bufs['error'].numpy()
     if err.any():
       bad = int(np.flatnonzero(err)[0])
       code = int(err[bad])
-      kinds = [name for bit, name in ((1, 'IndexError'), (2, 'scrolling.Error'),
-                                      (4, 'play() after game over')) if code & bit]
-      raise RuntimeError('environment {} raised {} on the device'.format(bad, kinds))
+      kinds = [name for bit, name in ((1, 'IndexError'), (2, 'scrolling.Error')) if code & bit]
+      raise RuntimeError('environment {} raised {} on the device ({} of {} environments affected)'.format(
+          bad, kinds, int(np.count_nonzero(err)), err.size))
 
   def planes_view(self, host=False):
     """Observation planes as [B, 1+n_chars, rows, cols]: a zero-copy strided
@@ -406,7 +416,8 @@ class Engine(object):
     """bool for batch 1; uint8 array [B] otherwise (engine.py:660-662)."""
     if self._native is None:
       return False
-    done = self._read_scalars()['done']
+    dev.synchronize(self._device_id)
+    done = self._bufs['done'].numpy()  # this one array only
     return bool(done[0]) if self._batch == 1 else done
 
   @property
@@ -433,16 +444,19 @@ class Engine(object):
       out[chr(d['ch'])] = _DrapeView(self, i, chr(d['ch']))
     return out
 
-  def _read_things(self):
+  def _read_things(self, sprites=True, curtains=True):
+    """Entity state of every environment, only what is asked for: sprites as a
+    structured NumPy array [B, n_sprites] (fields row, col, vrow, vcol,
+    visible), curtains as uint8 [B, n_drapes, rows, cols]."""
     t = self._template
     B, ns, nd = self._batch, len(t.sprites), len(t.drapes)
-    sprites = (N.SpriteState * (B * max(ns, 1)))()
-    curtains = np.zeros((B, max(nd, 1), self._rows, self._cols), np.uint8)
+    sp = np.zeros((B, max(ns, 1)), _SPRITE_DTYPE) if sprites else None
+    cu = np.zeros((B, max(nd, 1), self._rows, self._cols), np.uint8) if curtains else None
     dev.synchronize(self._device_id)
     N.check(N.lib().pcx_engine_read_things(
-        self._native, 0, B, ctypes.addressof(sprites) if ns else None,
-        curtains.ctypes.data if nd else None))
-    return sprites, curtains
+        self._native, 0, B, sp.ctypes.data if (sprites and ns) else None,
+        cu.ctypes.data if (curtains and nd) else None))
+    return sp, cu
 
   def close(self):
     if self._native is not None:
@@ -482,32 +496,43 @@ class Engine(object):
         raise ValueError('Character {} is not an ASCII character'.format(char))
 
 
+# host image of pcx_sprite_state (include/pcx.h)
+_SPRITE_DTYPE = np.dtype([('row', np.int32), ('col', np.int32), ('vrow', np.int32), ('vcol', np.int32),
+                          ('visible', np.uint8), ('pad', np.uint8, (3,))])
+assert _SPRITE_DTYPE.itemsize == ctypes.sizeof(N.SpriteState)
+
+
 class _SpriteView(object):
-  """Read-only live view of one sprite across the batch."""
+  """Read-only live view of one sprite across the batch.  Batch 1 returns the
+  reference's types (`Position`, bool); batch > 1 returns arrays: positions
+  int32 [B, 2] (row, col), visibility bool [B] -- one readback of the sprite
+  words, no curtains, no Python loop over the batch."""
 
   def __init__(self, eng, index, character):
     self._eng, self._index, self.character = eng, index, character
 
-  def _states(self):
-    sprites, _ = self._eng._read_things()
-    ns = len(self._eng._template.sprites)
-    return [sprites[b * ns + self._index] for b in range(self._eng.batch)]
+  def _state(self):
+    sprites, _ = self._eng._read_things(sprites=True, curtains=False)
+    return sprites[:, self._index]
 
-  def _pick(self, fn):
-    vals = [fn(s) for s in self._states()]
-    return vals[0] if self._eng.batch == 1 else vals
+  def _positions(self, row, col):
+    st = self._state()
+    if self._eng.batch == 1:
+      return things.Sprite.Position(int(st[row][0]), int(st[col][0]))
+    return np.stack([st[row], st[col]], axis=1)
 
   @property
   def position(self):
-    return self._pick(lambda s: things.Sprite.Position(s.row, s.col))
+    return self._positions('row', 'col')
 
   @property
   def virtual_position(self):
-    return self._pick(lambda s: things.Sprite.Position(s.vrow, s.vcol))
+    return self._positions('vrow', 'vcol')
 
   @property
   def visible(self):
-    return self._pick(lambda s: bool(s.visible))
+    vis = self._state()['visible'].astype(np.bool_)
+    return bool(vis[0]) if self._eng.batch == 1 else vis
 
 
 class _DrapeView(object):
@@ -518,7 +543,7 @@ class _DrapeView(object):
 
   @property
   def curtain(self):
-    _, curtains = self._eng._read_things()
+    _, curtains = self._eng._read_things(sprites=False, curtains=True)
     c = curtains[:, self._index].astype(np.bool_)
     return c[0] if self._eng.batch == 1 else c
 

@@ -9,9 +9,12 @@ reference's own aliasing rule.
 `ObservationToArray`, `ObservationToFeatureArray` and
 `ObservationCharacterRepainter` keep the reference's constructors
 (rendering.py:304-661) and run as streaming epilogue kernels
-(csrc/pcx_post.hip) over the planes the engine or a cropper just wrote.
-They accept observations produced by this package (those know where their
-planes live); anything else is rejected -- there is no host path.
+(csrc/pcx_post.hip) over the planes the engine, a cropper or a repainter
+just wrote.  With batch > 1 their results are device tensors the kernel wrote
+in place (no copy, no synchronisation; `torch.utils.dlpack.to_dlpack(t)`
+exports them to any DLPack consumer); batch 1 returns the reference's NumPy
+types.  They accept observations produced by this package (those know where
+their planes live); anything else is rejected -- there is no host path.
 """
 
 import collections
@@ -32,26 +35,44 @@ _DTYPES = {'uint8': N.U8, 'int32': N.I32, 'float32': N.F32, 'int64': N.I64, 'flo
 
 
 class _Post(object):
-  """One device post-processor bound to one planes source."""
+  """One device post-processor bound to one planes source.
+
+  The output array is a device tensor of ours that the C side writes into
+  (`pcx_post_bind_output`): `run()` enqueues one kernel on the current stream
+  and returns that tensor -- no copy and no wait (batch 1, or no PyTorch: a
+  NumPy copy, after a synchronisation, in the reference's shapes).
+  """
 
   def __init__(self, source, desc, out_dtype, out_shape):
-    self.source = source
     self.view, self.device_id = source._planes_view()
+    self.key = _view_key(self.view)
     self.desc = desc
     self.out_dtype, self.out_shape = np.dtype(out_dtype), tuple(out_shape)
     handle = ctypes.c_void_p()
-    N.check(N.lib().pcx_post_create(ctypes.byref(self.view), ctypes.byref(desc), self.device_id, ctypes.byref(handle)))
+    lib = N.lib()
+    N.check(lib.pcx_post_create(ctypes.byref(self.view), ctypes.byref(desc), self.device_id, ctypes.byref(handle)))
     self.handle = handle
+    self.out = None
+    if dev.torch_module() is not None:
+      self.out = dev.DeviceBuffer(self.out_shape, self.out_dtype, self.device_id)
+      N.check(lib.pcx_post_bind_output(handle, self.out.ptr, self.out.nbytes))
 
-  def run(self):
-    N.check(N.lib().pcx_post_run(self.handle, dev.current_stream(self.device_id)))
-    ptr, nbytes = ctypes.c_void_p(), N.c_u64()
-    N.check(N.lib().pcx_post_output(self.handle, ctypes.byref(ptr), ctypes.byref(nbytes)))
-    host = np.empty(self.out_shape, self.out_dtype)
-    assert host.nbytes == nbytes.value, (host.nbytes, nbytes.value)
+  def run(self, host):
+    lib = N.lib()
+    N.check(lib.pcx_post_run(self.handle, dev.current_stream(self.device_id)))
+    if self.out is not None and self.out.tensor is not None and not host:
+      seen = N.c_i32(0)
+      N.check(lib.pcx_post_error_poll(self.handle, dev.current_stream(self.device_id), ctypes.byref(seen)))
+      return self.out.tensor, bool(seen.value)
     dev.synchronize(self.device_id)
-    N.check(N.lib().pcx_memcpy_d2h(host.ctypes.data, ptr, host.nbytes))
-    return host
+    if self.out is not None:
+      return self.out.numpy(), self.errors().any()
+    ptr, nbytes = ctypes.c_void_p(), N.c_u64()
+    N.check(lib.pcx_post_output(self.handle, ctypes.byref(ptr), ctypes.byref(nbytes)))
+    out = np.empty(self.out_shape, self.out_dtype)
+    assert out.nbytes == nbytes.value, (out.nbytes, nbytes.value)
+    N.check(lib.pcx_memcpy_d2h(out.ctypes.data, ptr, out.nbytes))
+    return out, self.errors().any()
 
   def errors(self):
     errs = np.empty((int(self.view.batch),), np.uint8)
@@ -63,6 +84,21 @@ class _Post(object):
       N.lib().pcx_post_destroy(self.handle)
     except Exception:  # pylint: disable=broad-except
       pass
+
+
+def _view_key(view):
+  """What a cached post-processor depends on: where the source planes live and
+  their shape.  A cropper re-attached to another engine, or an engine that was
+  closed and rebuilt, shows up as a different key (the old planes are gone)."""
+  return (view.planes, int(view.batch), view.rows, view.cols, view.pitch, view.n_chars, bytes(view.chars))
+
+
+def _bound(post, source):
+  """The cached `_Post` if it still reads the planes `source` has now."""
+  if post is None:
+    return None
+  view, _ = source._planes_view()
+  return post if post.key == _view_key(view) else None
 
 
 def _source_of(observation):
@@ -117,8 +153,13 @@ class ObservationToArray(object):
     self._post = None
 
   def __call__(self, observation):
+    """Batch 1: a NumPy array as in the reference.  Batch > 1: a device tensor
+    [B, ...] written in place by the kernel (no copy, no synchronisation); an
+    unmapped character is then reported at a later call or by
+    `check_errors()`."""
     source = _source_of(observation)
-    if self._post is None or self._post.source is not source:
+    self._post = _bound(self._post, source)
+    if self._post is None:
       view, _ = source._planes_view()
       R, C = view.rows, view.cols
       d = N.PostDesc()
@@ -140,13 +181,19 @@ class ObservationToArray(object):
       if not self._is_3d:
         shape = shape[1:]
       self._post = _Post(source, d, self._dtype, (int(view.batch),) + tuple(shape))
-    out = self._post.run()
-    if self._post.errors().any():
+    single = self._post.out_shape[0] == 1
+    out, bad = self._post.run(host=single)
+    if bad:
+      self.check_errors()
+    return out[0] if single else out
+
+  def check_errors(self):
+    """Synchronises; raises if an observation held a character without a value."""
+    if self._post is not None and self._post.errors().any():
       raise RuntimeError(
           'This ObservationToArray only knows array values for the '
           'characters {}, but it received an observation with a character '
           'not in that set'.format(str(''.join(self._value_mapping.keys()))))
-    return out[0] if out.shape[0] == 1 else out
 
 
 class ObservationToFeatureArray(object):
@@ -172,7 +219,8 @@ class ObservationToFeatureArray(object):
           'Actual features in the observation are {}.'.format(
               repr(self._layers), repr(''.join(sorted(observation.layers)))))
     source = _source_of(observation)
-    if self._post is None or self._post.source is not source:
+    self._post = _bound(self._post, source)
+    if self._post is None:
       view, _ = source._planes_view()
       d = N.PostDesc()
       d.kind, d.dtype, d.depth = N.POST_FEATURE_ARRAY, N.F32, self._depth
@@ -181,8 +229,9 @@ class ObservationToFeatureArray(object):
       stride, shape = _strides((self._depth, view.rows, view.cols), self._permute)
       d.stride[0], d.stride[1], d.stride[2] = stride
       self._post = _Post(source, d, np.float32, (int(view.batch),) + tuple(shape))
-    out = self._post.run()
-    return out[0] if out.shape[0] == 1 else out
+    single = self._post.out_shape[0] == 1
+    out, _ = self._post.run(host=single)  # float32 device tensor [B, ...] for batch > 1 (zero-copy hand-off)
+    return out[0] if single else out
 
 
 class ObservationCharacterRepainter(object):
@@ -192,28 +241,66 @@ class ObservationCharacterRepainter(object):
     self._character_mapping = character_mapping
     self._post = None
     self._out_chars = None
+    self._repainted = None
 
   def __call__(self, original_observation):
     source = _source_of(original_observation)
-    if self._post is None or self._post.source is not source:
-      view, _ = source._planes_view()
+    self._post = _bound(self._post, source)
+    if self._post is None:
+      view, device_id = source._planes_view()
       self._out_chars = sorted((set(original_observation.layers) - set(self._character_mapping))
                                .union(self._character_mapping.values()))
+      if len(self._out_chars) > N.POST_MAX_DEPTH:
+        raise NotImplementedError('a repainted observation with more than {} characters'.format(N.POST_MAX_DEPTH))
       d = N.PostDesc()
       d.kind, d.dtype, d.depth = N.POST_REPAINT, N.U8, len(self._out_chars)
       for ch in range(128):
         d.lut[0][ch] = ch
         d.mapped[ch] = 1
       for k, v in self._character_mapping.items():
+        if ord(k) > 127 or ord(v) > 127:
+          raise ValueError('ObservationCharacterRepainter on the device repaints ASCII characters only')
         d.lut[0][ord(k)] = ord(v)
       for i, ch in enumerate(self._out_chars):
         d.chars[i] = ord(ch)
-      self._post = _Post(source, d, np.uint8,
-                         (int(view.batch), 1 + len(self._out_chars), view.rows, view.cols))
-    planes = self._post.run()
-    if planes.shape[0] == 1:
-      obs = Observation(board=planes[0, 0],
-                        layers={c: planes[0, 1 + i].astype(np.bool_) for i, c in enumerate(self._out_chars)})
+      pitch = (view.rows * view.cols + 3) & ~3
+      self._post = _Post(source, d, np.uint8, (int(view.batch), 1 + len(self._out_chars), pitch))
+      self._repainted = _RepaintedPlanes(self._post, self._out_chars, view.rows, view.cols, pitch, device_id)
+    B = self._post.out_shape[0]
+    planes, bad = self._post.run(host=B == 1)
+    if bad and self._post.errors().any():
+      raise RuntimeError('ObservationCharacterRepainter met a character outside ASCII')
+    R, C, pitch = self._repainted.rows, self._repainted.cols, self._repainted.pitch
+    if B == 1:
+      planes = np.ascontiguousarray(planes[0, :, :R * C]).reshape(-1, R, C)
+      obs = Observation(board=planes[0],
+                        layers={c: planes[1 + i].astype(np.bool_) for i, c in enumerate(self._out_chars)})
     else:
-      obs = Observation(board=planes[:, 0], layers={c: planes[:, 1 + i] for i, c in enumerate(self._out_chars)})
+      P = 1 + len(self._out_chars)
+      if hasattr(planes, 'as_strided'):   # device tensor: zero-copy [B, P, rows, cols] view of the pitched planes
+        view4 = planes.as_strided((B, P, R, C), (P * pitch, pitch, C, 1))
+      else:
+        view4 = np.ascontiguousarray(planes[:, :, :R * C]).reshape(B, P, R, C)
+      obs = Observation(board=view4[:, 0], layers={c: view4[:, 1 + i] for i, c in enumerate(self._out_chars)})
+    obs._source = self._repainted  # lets ObservationToArray / ToFeatureArray run on the repainted planes
     return obs
+
+
+class _RepaintedPlanes(object):
+  """The planes a repainter wrote, as a source for further post-processors."""
+
+  def __init__(self, post, out_chars, rows, cols, pitch, device_id):
+    self._post, self._out_chars = post, out_chars
+    self.rows, self.cols, self.pitch, self._device_id = rows, cols, pitch, device_id
+
+  def _planes_view(self):
+    ptr, nbytes = ctypes.c_void_p(), N.c_u64()
+    N.check(N.lib().pcx_post_output(self._post.handle, ctypes.byref(ptr), ctypes.byref(nbytes)))
+    view = N.PlanesView()
+    view.planes = ptr.value
+    view.batch = self._post.out_shape[0]
+    view.rows, view.cols, view.pitch = self.rows, self.cols, self.pitch
+    view.n_chars = len(self._out_chars)
+    for i, ch in enumerate(self._out_chars):
+      view.chars[i] = ord(ch)
+    return view, self._device_id

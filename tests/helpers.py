@@ -10,6 +10,11 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 GOLDEN_RNG_SEED = 0x5EED
 
 
+def to_np(x):
+  """NumPy copy of a NumPy array or a (device) tensor."""
+  return x.detach().cpu().numpy() if hasattr(x, 'detach') else np.asarray(x)
+
+
 def load_template(name):
   return GameTemplate.load(os.path.join(GOLDEN, 'templates', name + '.npz'))
 

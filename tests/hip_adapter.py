@@ -32,15 +32,13 @@ class HipAdapter(object):
     return self.eng.buffers[name].numpy()
 
   def sprites(self):
-    st, _ = self.eng._read_things()
+    st, _ = self.eng._read_things(sprites=True, curtains=False)
     ns = len(self.template.sprites)
     out = np.zeros((self.batch, ns, 5), np.int16)
-    for b in range(self.batch):
-      for s in range(ns):
-        x = st[b * ns + s]
-        out[b, s] = (x.row, x.col, x.vrow, x.vcol, x.visible)
+    for i, f in enumerate(('row', 'col', 'vrow', 'vcol', 'visible')):
+      out[:, :, i] = st[f][:, :ns]
     return out
 
   def curtains(self):
-    _, cur = self.eng._read_things()
+    _, cur = self.eng._read_things(sprites=False, curtains=True)
     return cur[:, :len(self.template.drapes)]

@@ -74,9 +74,9 @@ def test_device_croppers_match_reference(name):
     for i, cr in enumerate(crops):
       out = cr.crop(obs)
       want = tr['crop_%d' % i][step]
-      np.testing.assert_array_equal(np.asarray(out.board), want, err_msg='cropper %d frame %d board' % (i, step))
+      np.testing.assert_array_equal(helpers.to_np(out.board), want, err_msg='cropper %d frame %d board' % (i, step))
       for k, ch in enumerate(chars):
-        np.testing.assert_array_equal(np.asarray(out.layers[chr(ch)]).astype(np.uint8), (want == ch).astype(np.uint8))
+        np.testing.assert_array_equal(helpers.to_np(out.layers[chr(ch)]).astype(np.uint8), (want == ch).astype(np.uint8))
 
 
 @pytest.mark.gpu
@@ -88,8 +88,60 @@ def test_device_cropper_without_pad_raises_outside():
   cr.set_engine(eng)
   obs = eng.its_showtime()[0]
   with pytest.raises(RuntimeError):
-    cr.crop(obs)
+    cr.crop(obs)          # batch > 1: crop() does not wait for the device ...
+    cr.check_errors()     # ... the error surfaces here (or at a later crop())
+  with pytest.raises(RuntimeError):
+    for _ in range(3):    # the asynchronous poll of an earlier crop() reports it
+      cr.crop(obs)
+      eng._bufs['done'].numpy()  # let the device catch up
+  one = Engine.from_template(t, batch=1)
+  cr1 = cropping.FixedCropper((8, 8), 5, 5)
+  cr1.set_engine(one)
+  obs1 = one.its_showtime()[0]
+  with pytest.raises(RuntimeError):   # batch 1 raises at once, as the reference does
+    cr1.crop(obs1)
   with pytest.raises(ValueError):
     bad = cropping.FixedCropper((0, 0), 3, 3, pad_char='?')
     bad.set_engine(eng)
     bad.crop(obs)
+
+
+@pytest.mark.gpu
+def test_device_cropper_outputs_are_zero_copy_device_tensors_and_survive_a_new_engine():
+  """batch > 1: crop() returns views of the cropper's own output tensor (no
+  host copy); a post-processor cached on a cropper follows it to a new engine
+  (`set_engine`), whose planes live elsewhere."""
+  import torch
+  from pycolab_amd import rendering
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('better_scrolly_maze_L0')
+  crop = cropping.ScrollingCropper(7, 10, ['P'], pad_char='#', scroll_margins=(None, 3))  # 70 cells: pitch 72
+  feats = rendering.ObservationToFeatureArray('#P@')
+  for B in (5, 9):
+    eng = Engine.from_template(t, batch=B, auto_reset=True)
+    crop.set_engine(eng)
+    obs = eng.its_showtime()[0]
+    for step in range(6):
+      out = crop.crop(obs)
+      assert isinstance(out.board, torch.Tensor) and out.board.is_cuda and out.board.shape == (B, 7, 10)
+      assert out.board.data_ptr() == crop._out.ptr   # plane 0 of environment 0 of the bound tensor
+      f = feats(out)
+      assert isinstance(f, torch.Tensor) and f.is_cuda and f.dtype == torch.float32 and f.shape == (B, 3, 7, 10)
+      board = helpers.to_np(out.board)
+      for i, ch in enumerate('#P@'):
+        np.testing.assert_array_equal(helpers.to_np(f[:, i]), (board == ord(ch)).astype(np.float32))
+        np.testing.assert_array_equal(helpers.to_np(out.layers[ch]), (board == ord(ch)).astype(np.uint8))
+      # the window is the engine's board around the player
+      full = helpers.to_np(obs.board)
+      pr, pc = np.argwhere(full[0] == ord('P'))[0]
+      assert (board[0] == ord('P')).sum() == 1
+      wr, wc = np.argwhere(board[0] == ord('P'))[0]
+      top, left = pr - wr, pc - wc
+      ref = np.full((7, 10), ord('#'), np.uint8)
+      for r in range(7):
+        for c in range(10):
+          if 0 <= top + r < full.shape[1] and 0 <= left + c < full.shape[2]:
+            ref[r, c] = full[0, top + r, left + c]
+      np.testing.assert_array_equal(board[0], ref)
+      obs = eng.play(np.full((B,), step % 4, np.int32))[0]
+    eng.close()

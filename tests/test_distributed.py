@@ -140,7 +140,7 @@ def test_packed_scalars_gather_matches_buffers():
   torch.cuda.set_device(0)
   dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
   try:
-    hip = HipAdapter(helpers.load_template('scrolly_maze_L0'), 1003)  # odd size: the send block is padded
+    hip = HipAdapter(helpers.load_template('marauders'), 1003)  # odd size: the send block is padded
     hip.reset(); hip.step_hashed(0xABCD, 0, 64)
     sg = pdist.ScalarGather(hip.eng.scalars_packed, global_batch=1003)
     sg.gather()

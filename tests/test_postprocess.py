@@ -82,12 +82,12 @@ def test_device_postprocessors_match_reference(name):
         want = tr['post_%d' % i][fi]
         out = po(obs)
         if sp['kind'] == 'repaint':
-          np.testing.assert_array_equal(np.asarray(out.board), want)
+          np.testing.assert_array_equal(helpers.to_np(out.board), want)
           for c, layer in out.layers.items():
-            np.testing.assert_array_equal(np.asarray(layer).astype(bool), want == ord(c))
+            np.testing.assert_array_equal(helpers.to_np(layer).astype(bool), want == ord(c))
           assert sorted(out.layers) == sorted((set(chr(c) for c in tr['chars']) - set(sp['mapping'])) | set(sp['mapping'].values()))
         else:
-          out = np.asarray(out)
+          out = helpers.to_np(out)
           assert out.dtype == want.dtype and out.shape == want.shape, (out.shape, want.shape)
           np.testing.assert_array_equal(out, want)
       fi += 1
@@ -103,9 +103,59 @@ def test_device_to_array_unmapped_character_raises_and_croppers_chain():
   crop.set_engine(eng)
   obs = eng.its_showtime()[0]
   with pytest.raises(RuntimeError):
-    rendering.ObservationToArray({' ': 0, '#': 1})(obs)     # '.' and others unmapped
+    bad = rendering.ObservationToArray({' ': 0, '#': 1})    # '.' and others unmapped
+    bad(obs)              # batch > 1: no wait for the device ...
+    bad.check_errors()    # ... the error surfaces here (or at a later call)
   # post-processing a cropped observation uses the cropper's planes
   cropped = crop.crop(obs)
-  feats = rendering.ObservationToFeatureArray('#P')(cropped)
+  feats = helpers.to_np(rendering.ObservationToFeatureArray('#P')(cropped))
   assert feats.shape == (3, 2, 4, 5) and feats.dtype == np.float32
-  np.testing.assert_array_equal(feats[:, 0], (np.asarray(cropped.board) == ord('#')).astype(np.float32))
+  np.testing.assert_array_equal(feats[:, 0], (helpers.to_np(cropped.board) == ord('#')).astype(np.float32))
+  # a repainted observation is a source too: repainter -> array / feature array (rendering.py:304-406 chained)
+  repainted = rendering.ObservationCharacterRepainter({c: 'x' for c in '12345'})(obs)
+  board = helpers.to_np(repainted.board)
+  assert set(repainted.layers) == set(' #.xPX_') and (board == ord('x')).sum() == 3 * 5
+  arr = helpers.to_np(rendering.ObservationToArray({' ': 0, '#': 1, '.': 2, 'x': 3, 'P': 4, 'X': 5, '_': 6}, dtype=np.int32)(repainted))
+  lut = np.zeros(128, np.int32)
+  for i, ch in enumerate(' #.xPX_'):
+    lut[ord(ch)] = i
+  np.testing.assert_array_equal(arr, lut[board])
+  f2 = helpers.to_np(rendering.ObservationToFeatureArray('x_', permute=(1, 2, 0))(repainted))
+  assert f2.shape == (3, 11, 10, 2)
+  np.testing.assert_array_equal(f2[..., 0], (board == ord('x')).astype(np.float32))
+  one = Engine.from_template(t, batch=1)
+  obs1 = one.its_showtime()[0]
+  with pytest.raises(RuntimeError):   # batch 1 raises at once, as the reference does
+    rendering.ObservationToArray({' ': 0, '#': 1})(obs1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['marauders', 'warehouse_L0'])
+def test_device_feature_and_value_arrays_in_every_axis_order(name):
+  """Every `permute` of ObservationToFeatureArray / ObservationToArray equals
+  np.transpose of the default order (rendering.py:520-542, 640-661); the
+  default and the channels-last orders take vector-store paths when the board
+  is a whole number of dwords (marauders), element stores otherwise."""
+  import itertools
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template(name)
+  eng = Engine.from_template(t, batch=70, auto_reset=True, seed=3)
+  eng.its_showtime()
+  eng.step_hashed(11, 0, 25)
+  obs = eng.play(np.zeros(70, np.int32))[0]
+  chars = ''.join(chr(c) for c in t.chars)
+  base = helpers.to_np(rendering.ObservationToFeatureArray(chars)(obs))
+  board = helpers.to_np(obs.board)
+  for k, ch in enumerate(chars):
+    np.testing.assert_array_equal(base[:, k], (board == ord(ch)).astype(np.float32))
+  values = {ch: (i, 3 * i + 1, 250 - i) for i, ch in enumerate(chars)}
+  rgb = helpers.to_np(rendering.ObservationToArray(values, dtype=np.uint8)(obs))
+  lut = np.zeros((128, 3), np.uint8)
+  for ch, v in values.items():
+    lut[ord(ch)] = v
+  np.testing.assert_array_equal(rgb, np.transpose(lut[board], (0, 3, 1, 2)))
+  for perm in itertools.permutations(range(3)):
+    got = helpers.to_np(rendering.ObservationToFeatureArray(chars, permute=perm)(obs))
+    np.testing.assert_array_equal(got, np.transpose(base, (0,) + tuple(1 + a for a in perm)), err_msg=str(perm))
+    got = helpers.to_np(rendering.ObservationToArray(values, dtype=np.uint8, permute=perm)(obs))
+    np.testing.assert_array_equal(got, np.transpose(rgb, (0,) + tuple(1 + a for a in perm)), err_msg=str(perm))
