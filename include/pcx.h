@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PCX_ABI_VERSION 1u
+#define PCX_ABI_VERSION 2u
 
 #define PCX_MAX_CHARS 32    /* distinct characters (layers) in one game   */
 #define PCX_MAX_SPRITES 16
@@ -130,6 +130,30 @@ typedef struct pcx_drape_desc {
   int32_t param[4];
 } pcx_drape_desc;
 
+/* Plot directives a tabled entity issues from inside its update()
+ * (plot.py:136-226): an entity whose program is WALKER, SCROLLY or STATIC reads
+ * its "directive field" of the action, (action >> param[2]) & param[3], and
+ * issues -- before it moves -- every directive of the table below that names
+ * it and that value, in table order.  (The reference's tests inject the same
+ * calls as Python callables, tests/engine_test.py:169-295; on this path an
+ * entity's update() is a device program, so the calls are data.) */
+#define PCX_MAX_DIRECTIVES 32
+enum pcx_directive_kind {
+  PCX_DIR_ADD_REWARD = 1, /* the_plot.add_reward(reward)              plot.py:200-226 */
+  PCX_DIR_TERMINATE = 2,  /* the_plot.terminate_episode(discount)     plot.py:176-198 */
+  PCX_DIR_Z_ORDER = 3     /* the_plot.change_z_order(move_this, in_front_of)  plot.py:136-174,
+                             applied by engine.py:796-835 after the last update group */
+};
+typedef struct pcx_directive {
+  uint8_t ch;          /* the entity that issues it                          */
+  uint8_t kind;        /* enum pcx_directive_kind                            */
+  uint8_t move_this;   /* Z_ORDER                                            */
+  uint8_t in_front_of; /* Z_ORDER: a thing's character, 0 = None (to the back) */
+  int32_t selector;    /* value of the entity's directive field that triggers it (> 0) */
+  int32_t reward;      /* ADD_REWARD                                         */
+  float discount;      /* TERMINATE, in [0, 1]                               */
+} pcx_directive;
+
 /* A whole game as built by ascii_art_to_game(), before its_showtime(). */
 typedef struct pcx_template {
   uint32_t abi_version;   /* PCX_ABI_VERSION                                  */
@@ -150,6 +174,8 @@ typedef struct pcx_template {
   int32_t n_groups;
   int32_t n_actions;      /* actions 0..n_actions-1 are "ordinary" (bench/tests) */
   int32_t param[8];       /* game-specific constants                          */
+  int32_t n_directives;
+  pcx_directive directives[PCX_MAX_DIRECTIVES];
 } pcx_template;
 
 /* Device (or host, for the oracle) pointers to what play() returns, batched.

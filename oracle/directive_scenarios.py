@@ -1,0 +1,128 @@
+"""TEST INFRASTRUCTURE: games whose entities issue Plot directives --
+add_reward, terminate_episode(discount), change_z_order -- the calls the
+reference's tests/engine_test.py:169-295 injects into its test entities with
+`tt.pre_update`.  The same description builds
+
+  * the reference game (its own `tt.TestMazeWalker` / `tt.TestSprite` /
+    `tt.TestDrape`; `inject()` registers, before every `play()`, the
+    `tt.pre_update` callables the action's directive fields select), and
+  * the pycolab_amd twin (tabled prefabs carrying the calls as data).
+
+An action packs, per entity, a 4-bit motion field (walkers) and a 2-bit
+directive field.
+"""
+
+# name -> dict(art, beneath, z_order, schedule, entities={ch: dict(kind, motion=(shift, mask)|None,
+#   directive=(shift, mask), calls={value: [call, ...]}, **ctor kwargs)})
+SCENARIOS = {
+    # engine_test.py:244-295 testChangingZOrdering, on a board with room to
+    # walk: three walkers that pile up and a drape, all re-ordered at run time
+    'directives_z_order': dict(
+        art=['.......',
+             '.abc.D.',
+             '...D...'],
+        beneath='.', z_order='aDbc', schedule=[['a', 'b'], ['c', 'D']],
+        entities={
+            'a': dict(kind='walker', impassable='', confined=True, motion=(0, 15), directive=(12, 3),
+                      calls={1: [('change_z_order', 'a', 'c')], 2: [('change_z_order', 'a', None)],
+                             3: [('change_z_order', 'a', 'D'), ('add_reward', 2)]}),
+            'b': dict(kind='walker', impassable='', confined=True, motion=(4, 15), directive=(14, 3),
+                      calls={1: [('change_z_order', 'b', 'c')], 2: [('change_z_order', 'b', None)],
+                             3: [('change_z_order', 'D', 'b'), ('change_z_order', 'b', 'a')]}),
+            'c': dict(kind='walker', impassable='', confined=True, motion=(8, 15), directive=(16, 3),
+                      calls={1: [('change_z_order', 'c', None)], 2: [('change_z_order', 'c', 'a')],
+                             3: [('add_reward', -1)]}),
+            'D': dict(kind='drape', motion=None, directive=(18, 3),
+                      calls={1: [('change_z_order', 'D', None)], 2: [('change_z_order', 'D', 'c')],
+                             3: [('terminate_episode', 0.25), ('add_reward', 10)]}),
+        }),
+    # engine_test.py:169-242 testRewardAndEpisodeEndWith{Default,Custom}Discount:
+    # two sprites that only talk to the Plot (integer rewards instead of strings)
+    'directives_reward_discount': dict(
+        art=['.........',
+             '...Q.R...',
+             '.........'],
+        beneath='.', z_order='QR', schedule=[['Q', 'R']],
+        entities={
+            'Q': dict(kind='sprite', motion=None, directive=(0, 3),
+                      calls={1: [('add_reward', 5)], 2: [('terminate_episode',)], 3: [('terminate_episode', 0.5)]}),
+            'R': dict(kind='sprite', motion=None, directive=(2, 3),
+                      calls={1: [('add_reward', 7)], 2: [('add_reward', 11)], 3: [('add_reward', -3), ('add_reward', 4)]}),
+        }),
+}
+
+MOTION_NAMES = ['n', 'ne', 'e', 'se', 's', 'sw', 'w', 'nw', 'stay']
+
+
+def build_twin(spec, ascii_art, tabled):
+  """The game with pycolab_amd's tabled prefabs."""
+  P = ascii_art.Partial
+  sprites, drapes = {}, {}
+  for ch, e in spec['entities'].items():
+    kw = dict(directive_field=e['directive'], directives=e['calls'])
+    if e['kind'] == 'walker':
+      sprites[ch] = P(tabled.TabledWalker, impassable=e['impassable'], confined_to_board=e['confined'],
+                      action_field=e['motion'], **kw)
+    elif e['kind'] == 'sprite':
+      sprites[ch] = P(tabled.StaticSprite, **kw)
+    else:
+      drapes[ch] = P(tabled.StaticDrape, **kw)
+  return ascii_art.ascii_art_to_game(spec['art'], spec['beneath'], sprites=sprites, drapes=drapes,
+                                     update_schedule=spec['schedule'], z_order=spec['z_order'])
+
+
+def build_reference(spec, ascii_art, tt):
+  """The game with the reference's own test entities."""
+  P = ascii_art.Partial
+  sprites, drapes = {}, {}
+  for ch, e in spec['entities'].items():
+    if e['kind'] == 'walker':
+      sprites[ch] = P(tt.TestMazeWalker, impassable=e['impassable'], confined_to_board=e['confined'])
+    elif e['kind'] == 'sprite':
+      sprites[ch] = tt.TestSprite
+    else:
+      drapes[ch] = tt.TestDrape
+  return ascii_art.ascii_art_to_game(spec['art'], spec['beneath'], sprites=sprites, drapes=drapes,
+                                     update_schedule=spec['schedule'], z_order=spec['z_order'])
+
+
+def reference_action(spec, a):
+  """The packed action as the dict of compass directions TestMazeWalker obeys."""
+  out = {}
+  for ch, e in spec['entities'].items():
+    if e['motion'] is not None:
+      out[ch] = MOTION_NAMES[min((a >> e['motion'][0]) & e['motion'][1], 8)]
+  return out
+
+
+def inject(spec, game, a, tt):
+  """Registers the pre-update callables action `a` selects (tests/test_things.py:57-76)."""
+  for ch, e in spec['entities'].items():
+    sel = (a >> e['directive'][0]) & e['directive'][1]
+    calls = e['calls'].get(sel)
+    if not calls:
+      continue
+
+    def thing_to_do(actions, board, layers, backdrop, things, the_plot, calls=calls):
+      for call in calls:
+        getattr(the_plot, call[0])(*call[1:])
+    tt.pre_update(game, ch, thing_to_do)
+
+
+def tape(spec, rng, T):
+  """One environment's packed actions: persistent headings for the walkers,
+  directive fields mostly 0."""
+  import numpy as np
+  out = np.zeros(T, np.int32)
+  heading = {ch: rng.randint(9) for ch, e in spec['entities'].items() if e['motion'] is not None}
+  for t in range(T):
+    a = 0
+    for ch, e in spec['entities'].items():
+      if e['motion'] is not None:
+        if rng.rand() < 0.35:
+          heading[ch] = rng.randint(9)
+        a |= heading[ch] << e['motion'][0]
+      if rng.rand() < 0.3:
+        a |= rng.randint(1, e['directive'][1] + 1) << e['directive'][0]
+    out[t] = a
+  return out

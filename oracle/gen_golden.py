@@ -205,9 +205,14 @@ CROPPERS = {  # keyed by trace name
 }
 
 
+ONLY = set(a for a in sys.argv[1:] if not a.startswith('-'))  # trace names to (re)generate; empty = all
+
+
 def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, seeker=False, choice=None,
-        unoccluded=False, ref_action=None, tapes=None):
+        unoccluded=False, ref_action=None, tapes=None, before_play=None):
   global UNOCCLUDED
+  if ONLY and name not in ONLY:
+    return
   UNOCCLUDED = unoccluded
   boards, rewards, rsets, discounts, dones, sprites, layers = [], [], [], [], [], [], []
   specs = CROPPERS.get(name, [])
@@ -267,6 +272,8 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
         if seeker and e % 8 >= 5:
           actions[t, e] = seek_coin_action(game, rng)
         a = int(actions[t, e])
+        if before_play is not None and a != NONE:
+          before_play(game, a)
         obs, r, d = game.play(None if a == NONE else (ref_action(a) if ref_action else a))
       rec.append(record(obs, r, d, game, chars, sprite_chars))
       crop_all(obs)
@@ -359,6 +366,15 @@ def main():
     run(name, lambda spec=spec: walker_scenarios.build(spec, ref_art, tt.TestMazeWalker, tt.TestScrolly, False),
         E=24, T=160, n_ordinary=9, quit_action=99, seed=51 + i, template_name=name,
         ref_action=ref_action, tapes=tapes)
+
+  # Plot directives (add_reward / terminate_episode(discount) / change_z_order)
+  # issued by the reference's own test entities: tests/engine_test.py:169-295
+  from oracle import directive_scenarios as ds
+  for i, (name, spec) in enumerate(sorted(ds.SCENARIOS.items())):
+    run(name, lambda spec=spec: ds.build_reference(spec, ref_art, tt), E=24, T=160, n_ordinary=9, quit_action=99,
+        seed=151 + i, template_name=name, ref_action=lambda a, spec=spec: ds.reference_action(spec, a),
+        tapes=lambda rng, T, spec=spec: ds.tape(spec, rng, T),
+        before_play=lambda game, a, spec=spec: ds.inject(spec, game, a, tt))
 
   # occlusion_in_layers=False variants: the example files do not expose the
   # flag, so the call they make into ascii_art is wrapped (files unchanged).

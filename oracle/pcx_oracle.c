@@ -76,6 +76,9 @@ typedef struct {
   uint16_t permit_mask[PCX_MAX_THINGS]; /* bit per motion index */
   /* free-form plot entries used by the shipped games */
   int64_t kv[8];
+  /* Plot._EngineDirectives.z_updates (plot.py:136-174): entity ids, -1 = None */
+  int n_z_updates;
+  int z_move[PCX_MAX_DIRECTIVES], z_front[PCX_MAX_DIRECTIVES];
 } ox_plot;
 
 typedef struct {
@@ -83,6 +86,7 @@ typedef struct {
   ox_drape drapes[PCX_MAX_DRAPES];
   ox_plot plot;
   int game_over; /* Engine._game_over */
+  int z_id[PCX_MAX_THINGS]; /* Engine._sprites_and_drapes order (engine.py:796-835 edits it) */
   int error;
   uint64_t rng_draws; /* marauders: draws so far in this env (survives resets) */
 } ox_env;
@@ -137,6 +141,7 @@ static void plot_clear_directives(ox_plot* p) {
   p->reward = 0;
   p->discount = 1.0f;
   p->game_over = 0;
+  p->n_z_updates = 0;
 }
 /* plot.py:176-198 */
 static void plot_terminate(ox_plot* p, float discount) {
@@ -754,11 +759,41 @@ static void prog_scrolly(ox_ctx* x, int di) {
   sc_maybe_move(x->e, x->env, di, MOTION9[a][0], MOTION9[a][1]);
 }
 
+/* include/pcx.h pcx_directive: a tabled entity issues, before it moves, the
+ * plot directives its directive field of the action selects (what the
+ * reference's tests inject with tt.pre_update, tests/engine_test.py:169-295). */
+static void issue_directives(ox_ctx* x, int id, int ch, const int32_t* param) {
+  pcxo_engine* e = x->e;
+  if (!e->t.n_directives || x->action < 0 || !param[3]) return;
+  int sel = (int)(((unsigned)x->action >> param[2]) & (unsigned)param[3]);
+  if (!sel) return;
+  (void)id;
+  for (int i = 0; i < e->t.n_directives; ++i) {
+    const pcx_directive* d = &e->t.directives[i];
+    if (d->ch != ch || d->selector != sel) continue;
+    ox_plot* p = &x->env->plot;
+    switch (d->kind) {
+      case PCX_DIR_ADD_REWARD: plot_add_reward(p, d->reward); break;
+      case PCX_DIR_TERMINATE: plot_terminate(p, d->discount); break;
+      case PCX_DIR_Z_ORDER: /* plot.py:173-174: appended, applied after the last group */
+        p->z_move[p->n_z_updates] = thing_id(e, d->move_this);
+        p->z_front[p->n_z_updates] = d->in_front_of ? thing_id(e, d->in_front_of) : -1;
+        p->n_z_updates++;
+        break;
+      default: break;
+    }
+  }
+}
+
 static int run_program(ox_ctx* x, int id) {
   pcxo_engine* e = x->e;
   int prog = id < PCX_MAX_SPRITES ? e->t.sprites[id].program
                                   : e->t.drapes[id - PCX_MAX_SPRITES].program;
   int di = id - PCX_MAX_SPRITES;
+  if (prog == PCX_PROG_WALKER || prog == PCX_PROG_SCROLLY || prog == PCX_PROG_STATIC) {
+    if (id < PCX_MAX_SPRITES) issue_directives(x, id, e->t.sprites[id].ch, e->t.sprites[id].param);
+    else issue_directives(x, id, e->t.drapes[di].ch, e->t.drapes[di].param);
+  }
   switch (prog) {
     case PCX_PROG_SM_PLAYER: prog_sm_player(x, id); break;
     case PCX_PROG_SM_PATROLLER: prog_sm_patroller(x, id); break;
@@ -803,7 +838,7 @@ static void render(pcxo_engine* e, int64_t b) {
     }
   }
   for (int z = 0; z < e->t.n_things; ++z) { /* engine.py:751-757 */
-    int id = e->z_id[z];
+    int id = env->z_id[z];
     if (id < PCX_MAX_SPRITES) {
       const ox_sprite* s = &env->sprites[id];
       if (!s->visible) continue;
@@ -856,6 +891,7 @@ static void env_init(pcxo_engine* e, int64_t b) {
   env->plot.kv[EM_LAST_PLAYER_SHOT] = env->plot.kv[EM_LAST_MARAUDER_SHOT] = EM_NEVER;
   env->plot.frame = -1;
   plot_clear_directives(&env->plot);
+  memcpy(env->z_id, e->z_id, sizeof env->z_id);
   env->game_over = 0;
   env->error = 0;
 }
@@ -891,7 +927,20 @@ static int env_play(pcxo_engine* e, int64_t b, int action) {
       if (run_program(&x, e->sched_id[i])) return fail(PCX_E_UNSUPPORTED, "oracle: entity program not implemented");
     render(e, b); /* :735 */
   }
-  /* _apply_and_clear_plot :761-847 (no z-order directives on this path) */
+  /* _apply_and_clear_plot :761-847 */
+  for (int u = 0; u < env->plot.n_z_updates; ++u) { /* :796-835, one directive at a time */
+    int move = env->plot.z_move[u], front = env->plot.z_front[u];
+    int order[PCX_MAX_THINGS], n = 0;
+    if (front < 0) order[n++] = move; /* all the way to the back */
+    for (int z = 0; z < e->t.n_things; ++z) {
+      int id = env->z_id[z];
+      if (id == move) continue;
+      order[n++] = id;
+      if (id == front) order[n++] = move;
+    }
+    memcpy(env->z_id, order, sizeof(int) * e->t.n_things);
+  }
+  if (env->plot.n_z_updates) render(e, b); /* engine.py:632-637 should_rerender */
   env->game_over = env->plot.game_over;
   publish(e, b);
   plot_clear_directives(&env->plot);

@@ -12,7 +12,7 @@ c_u8, c_i32, c_i64, c_u32, c_u64 = (ctypes.c_uint8, ctypes.c_int32,
                                     ctypes.c_uint64)
 c_u8_p = ctypes.POINTER(ctypes.c_uint8)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_CHARS = 32
 MAX_SPRITES = 16
 MAX_DRAPES = 8
@@ -53,6 +53,15 @@ class DrapeDesc(ctypes.Structure):
               ('param', c_i32 * 4)]
 
 
+MAX_DIRECTIVES = 32
+DIR_ADD_REWARD, DIR_TERMINATE, DIR_Z_ORDER = 1, 2, 3
+
+
+class Directive(ctypes.Structure):
+  _fields_ = [('ch', c_u8), ('kind', c_u8), ('move_this', c_u8), ('in_front_of', c_u8),
+              ('selector', c_i32), ('reward', c_i32), ('discount', ctypes.c_float)]
+
+
 class Template(ctypes.Structure):
   _fields_ = [('abi_version', c_u32), ('game', c_i32),
               ('rows', c_i32), ('cols', c_i32),
@@ -65,7 +74,8 @@ class Template(ctypes.Structure):
               ('z_order', c_u8 * MAX_THINGS), ('schedule', c_u8 * MAX_THINGS),
               ('group_of', c_u8 * MAX_THINGS),
               ('n_groups', c_i32), ('n_actions', c_i32),
-              ('param', c_i32 * 8)]
+              ('param', c_i32 * 8),
+              ('n_directives', c_i32), ('directives', Directive * MAX_DIRECTIVES)]
 
 
 class Buffers(ctypes.Structure):

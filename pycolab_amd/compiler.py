@@ -28,6 +28,38 @@ def _impassable_bits(chars):
   return bytes(bits)
 
 
+def _directive(ch, selector, call, things_by_char):
+  """One ('add_reward', r) / ('terminate_episode'[, d]) / ('change_z_order', a, b)
+  entry as a pcx_directive tuple, checked the way plot.py and engine.py check it."""
+  name, args = call[0], tuple(call[1:])
+  if name == 'add_reward':
+    (reward,) = args
+    if int(reward) != reward:
+      raise ValueError('device rewards are integers')
+    return (ch, N.DIR_ADD_REWARD, 0, 0, selector, int(reward), 0.0)
+  if name == 'terminate_episode':
+    discount = float(args[0]) if args else 0.0
+    if not 0.0 <= discount <= 1.0:  # plot.py:192-193
+      raise ValueError('Discount must be in range [0,1].')
+    return (ch, N.DIR_TERMINATE, 0, 0, selector, 0, discount)
+  if name == 'change_z_order':
+    move_this, in_front_of = args
+    if move_this not in things_by_char:  # engine.py:804-808 raises when the directive is applied
+      raise RuntimeError(
+          'A z-order change directive said to move a Sprite or Drape '
+          'corresponding to character {}, but no such Sprite or Drape '
+          'exists'.format(repr(move_this)))
+    if in_front_of is not None and in_front_of not in things_by_char:  # engine.py:809-814
+      raise RuntimeError(
+          'A z-order change directive said to move a Sprite or Drape in '
+          'front of a Sprite or Drape corresponding to character {}, but '
+          'no such Sprite or Drape exists'.format(repr(in_front_of)))
+    if move_this == in_front_of:
+      raise ValueError('a z-order change directive cannot move {} in front of itself'.format(repr(move_this)))
+    return (ch, N.DIR_Z_ORDER, ord(move_this), 0 if in_front_of is None else ord(in_front_of), selector, 0, 0.0)
+  raise ValueError('unknown plot directive {!r}'.format(name))
+
+
 class GameTemplate(object):
   """Plain-data image of a built (not yet started) game."""
 
@@ -45,6 +77,7 @@ class GameTemplate(object):
     self.n_groups = 0
     self.n_actions = 0
     self.param = [0] * 8
+    self.directives = []        # (ch, kind, move_this, in_front_of, selector, reward, discount)
 
   # -- construction from a host Engine ---------------------------------------
   @classmethod
@@ -95,6 +128,15 @@ class GameTemplate(object):
           if ent._scrolling_group != '':
             raise programs.UnsupportedEntityError('only the default scrolling group is supported')
         t.drapes.append(d)
+    # plot directives of tabled entities (prefab_parts/tabled.py), in z-order of the entities
+    for ch, ent in eng._sprites_and_drapes.items():
+      for selector, calls in sorted(getattr(ent, 'pcx_directives', {}).items()):
+        if int(selector) <= 0:
+          raise ValueError('directive selector values must be positive (0 means "no directive")')
+        for call in calls:
+          t.directives.append(_directive(ord(ch), int(selector), call, eng._sprites_and_drapes))
+    if len(t.directives) > N.MAX_DIRECTIVES:
+      raise ValueError('at most {} plot directives per game'.format(N.MAX_DIRECTIVES))
     if len(t.sprites) > N.MAX_SPRITES or len(t.drapes) > N.MAX_DRAPES:
       raise ValueError('too many sprites or drapes for the device engine')
     t.z_order = bytes(ord(c) for c in eng._sprites_and_drapes.keys())
@@ -108,6 +150,17 @@ class GameTemplate(object):
     t.group_of = group_of
     t.game = programs.infer_game(progs)
     t.n_actions = programs.N_ACTIONS[t.game]
+    if t.game == N.GAME_WALKERS:
+      # tabled entities read bit fields of the action: "ordinary" actions (what
+      # the benchmark / hashed-action tests draw from) cover every field
+      top = 0
+      for ent in list(t.sprites) + list(t.drapes):
+        prm = ent['param']
+        for shift, mask in ((prm[0], prm[1]), (prm[2], prm[3])):
+          if mask:
+            top = max(top, shift + int(mask).bit_length())
+      if top:
+        t.n_actions = 1 << min(top, 30)
     return t
 
   # -- (de)serialisation -------------------------------------------------------
@@ -117,7 +170,7 @@ class GameTemplate(object):
                 chars=list(self.chars), z_order=list(self.z_order),
                 schedule=list(self.schedule), group_of=list(self.group_of),
                 n_groups=self.n_groups, n_actions=self.n_actions,
-                param=list(self.param), sprites=[], drapes=[])
+                param=list(self.param), directives=[list(d) for d in self.directives], sprites=[], drapes=[])
     arrays = {'backdrop': self.backdrop}
     for s in self.sprites:
       m = dict(s)
@@ -145,6 +198,7 @@ class GameTemplate(object):
     t.z_order, t.schedule = bytes(meta['z_order']), bytes(meta['schedule'])
     t.group_of, t.n_groups = meta['group_of'], meta['n_groups']
     t.n_actions, t.param = meta['n_actions'], meta['param']
+    t.directives = [tuple(d) for d in meta.get('directives', [])]
     t.backdrop = np.ascontiguousarray(z['backdrop'], dtype=np.uint8)
     n = t.rows * t.cols
     for s in meta['sprites']:
@@ -169,7 +223,7 @@ class GameTemplate(object):
     def norm(t):
       return (t.game, t.rows, t.cols, bool(t.occlusion_in_layers), t.chars,
               t.backdrop.tobytes(), t.z_order, t.schedule, list(t.group_of),
-              t.n_groups, t.n_actions, list(t.param),
+              t.n_groups, t.n_actions, list(t.param), [tuple(d) for d in t.directives],
               [sorted((k, (v if not isinstance(v, (list, tuple)) else tuple(v)))
                       for k, v in s.items()) for s in t.sprites],
               [sorted((k, (v.tobytes() if isinstance(v, np.ndarray) else
@@ -231,4 +285,9 @@ class GameTemplate(object):
     ct.n_actions = self.n_actions
     for i, v in enumerate(self.param):
       ct.param[i] = v
+    ct.n_directives = len(self.directives)
+    for i, (ch, kind, move_this, in_front_of, selector, reward, discount) in enumerate(self.directives):
+      d = ct.directives[i]
+      d.ch, d.kind, d.move_this, d.in_front_of = ch, kind, move_this, in_front_of
+      d.selector, d.reward, d.discount = selector, reward, discount
     return ct, keep

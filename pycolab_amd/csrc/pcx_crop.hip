@@ -11,6 +11,7 @@
 #include "pcx_internal.h"
 
 #include <cstring>
+#include <vector>
 
 using pcx::set_error;
 
@@ -180,6 +181,36 @@ __global__ void pcx_crop_copy(CropParams p, const uint8_t* in, const int32_t* co
 
 }  // namespace
 
+// Raw curtains [n_drapes][FW][bpad] as cell-bit vectors, rebuilt on the host from
+// pcx_engine_read_things (synchronous; only when a drape-tracking cropper joins
+// an engine that is already in play).
+static int refresh_curtains(pcx_engine* e) {
+  pcx::Backend* b = e->backend;
+  const int nd = e->t.n_drapes, cells = e->t.rows * e->t.cols, FW = b->curtain_words();
+  if (int rc = b->ensure_curtains()) return rc;
+  uint32_t* dev = const_cast<uint32_t*>(b->curtain_bits());
+  if (!dev || nd <= 0 || FW <= 0) return set_error(PCX_E_UNSUPPORTED, "croppers: this engine cannot export curtains");
+  const int64_t bpad = b->batch_pad(), chunk = 1 << 14;
+  std::vector<uint8_t> host((size_t)chunk * nd * cells);
+  std::vector<uint32_t> bits((size_t)chunk);
+  for (int64_t b0 = 0; b0 < e->batch; b0 += chunk) {
+    const int64_t n = e->batch - b0 < chunk ? e->batch - b0 : chunk;
+    if (int rc = b->read_things(b0, n, nullptr, host.data())) return rc;
+    for (int d = 0; d < nd; ++d)
+      for (int w = 0; w < FW; ++w) {
+        for (int64_t i = 0; i < n; ++i) {
+          uint32_t v = 0;
+          const uint8_t* cur = host.data() + ((size_t)i * nd + d) * cells;
+          for (int bit = 0; bit < 32 && 32 * w + bit < cells; ++bit) v |= (uint32_t)(cur[32 * w + bit] != 0) << bit;
+          bits[i] = v;
+        }
+        PCX_HIP(hipMemcpy(dev + ((size_t)d * FW + w) * bpad + b0, bits.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      }
+  }
+  e->curtains_fresh = true;
+  return 0;
+}
+
 struct pcx_cropper {
   pcx_engine* e = nullptr;
   CropParams p{};
@@ -231,8 +262,11 @@ int pcx_cropper_create(pcx_engine* e, const pcx_cropper_desc* d, pcx_cropper** o
   }
   if (c->tracks_drape) {
     if (e->showtime && !e->curtains_fresh) {
-      delete c;
-      return set_error(PCX_E_STATE, "a cropper that tracks a drape must be attached (set_engine) before its_showtime()");
+      // attached after its_showtime() (as tests/cropping_test.py does): the step
+      // kernels have not exported raw curtains so far; rebuild them once from
+      // the entity state, from now on every launch exports them
+      int rc = refresh_curtains(e);
+      if (rc) { delete c; return rc; }
     }
     e->want_curtains = true;
   }

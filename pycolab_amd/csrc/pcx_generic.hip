@@ -31,7 +31,12 @@ constexpr int MAX_L = 20;
 // per-thing table entry (uint32 words), staged into LDS
 enum : int { T_CH = 0, T_KIND, T_IDX, T_PROG, T_LAYER, T_ABOVE, T_FLAGS, T_P0, T_P1, T_IMP0, T_IMP1, T_IMP2, T_IMP3,
              T_ABOVE_S, T_ABOVE_D,  // the things in front, as a sprite-index mask and a drape-index mask
+             T_P2, T_P3,            // tabled entities: directive field of the action (shift, mask)
              T_WORDS };
+// plot directives (include/pcx.h pcx_directive), four words each, staged into LDS
+enum : int { D_WHO = 0 /* thing | kind << 8 | move_this thing << 16 | in_front_of thing << 24 (0xFF = None) */, D_SEL, D_REWARD,
+             D_DISCOUNT, D_WORDS };
+constexpr int MAX_ZQ = 8;  // z-order changes one environment may queue in one frame
 constexpr uint32_t TF_WALKER = 1, TF_CONFINED = 2, TF_EGO = 4, TF_SCROLLY = 8;
 // Scrolly drapes reuse the impassable words: pattern table offset, PR | PC << 16,
 // have_margins | margin_rows << 8 | margin_cols << 16, words per pattern row
@@ -45,6 +50,8 @@ constexpr int64_t NEVER = INT32_MIN;
 struct Consts {
   int32_t game, R, C, cells, pitch, QW, L, NS, ND, NT, n_groups, RW, FW, NW, n_actions, n_bchars;
   int32_t occl;  // Engine(..., occlusion_in_layers)
+  int32_t n_dir, zdyn, w_z;  // plot directives; any change_z_order among them; state offset of the z-order words
+  int32_t l_dir, l_zord, l_zabove, l_zabove_s, l_zabove_d, l_zq, l_ztmp;
   int32_t has_scroll, w_scroll;  // any Scrolly drape / egocentric walker; state offset of the protocol words
   uint32_t magic_q, magic_c;  // 32-bit reciprocals of QW and C (exhaustively checked on the host)
   uint32_t seed_lo, seed_hi, envoff_lo, envoff_hi;
@@ -71,6 +78,8 @@ struct Ptrs {
 struct L {
   const uint32_t *things, *z, *sched, *backdrop4, *bdmask, *aux, *init, *initd, *laybc, *s2t;
   uint32_t *pos, *flg, *cur, *snapd, *flat, *skip, *flatraw, *corner, *pmask, *pframe;
+  const uint32_t* dir;
+  uint32_t *zord, *zabove, *zabove_s, *zabove_d, *zq, *ztmp;  // per-lane z-order (only when a game changes it)
   int32_t* snap;
   uint2 *sdesc, *sdescraw;
 };
@@ -98,12 +107,32 @@ struct Ctx {
   // protocols/scrolling.py, scrolling group '': the order lives one frame only
   int order_valid, o0, o1;
   uint32_t registered;  // bit per sprite index: 'scrolling__egocentrists'
+  int nzq;              // queued change_z_order directives (plot.py:173-174)
 };
 
 __device__ __forceinline__ bool on_board(const Consts& k, int r, int c) {
   return (unsigned)r < (unsigned)k.R && (unsigned)c < (unsigned)k.C;
 }
 __device__ __forceinline__ uint32_t tfield(const Ctx& x, int thing, int f) { return x.l.things[thing * T_WORDS + f]; }
+// The z-order (engine.py:751-757 paints `_sprites_and_drapes` in order).  Things
+// are numbered by their place in the template's order; a game whose entities
+// issue change_z_order keeps every environment's current order, and the
+// "who is in front of whom" masks derived from it, in per-lane LDS columns.
+__device__ __forceinline__ int thing_at_z(const Ctx& x, int z) { return x.k.zdyn ? (int)x.l.zord[z * WAVE + x.lane] : (int)x.l.z[z]; }
+__device__ __forceinline__ uint32_t above_things(const Ctx& x, int t) { return x.k.zdyn ? x.l.zabove[t * WAVE + x.lane] : tfield(x, t, T_ABOVE); }
+__device__ __forceinline__ uint32_t above_sprites(const Ctx& x, int t) { return x.k.zdyn ? x.l.zabove_s[t * WAVE + x.lane] : tfield(x, t, T_ABOVE_S); }
+__device__ __forceinline__ uint32_t above_drapes(const Ctx& x, int t) { return x.k.zdyn ? x.l.zabove_d[t * WAVE + x.lane] : tfield(x, t, T_ABOVE_D); }
+__device__ __forceinline__ void derive_above(const Ctx& x) {  // masks from the order, front to back
+  uint32_t all = 0, sp = 0, dr = 0;
+  for (int z = x.k.NT - 1; z >= 0; --z) {
+    const int t = (int)x.l.zord[z * WAVE + x.lane];
+    x.l.zabove[t * WAVE + x.lane] = all;
+    x.l.zabove_s[t * WAVE + x.lane] = sp;
+    x.l.zabove_d[t * WAVE + x.lane] = dr;
+    all |= 1u << t;
+    if (tfield(x, t, T_KIND) == 0) sp |= 1u << tfield(x, t, T_IDX); else dr |= 1u << tfield(x, t, T_IDX);
+  }
+}
 
 // ---- sprite state in per-lane LDS columns ---------------------------------
 __device__ __forceinline__ void sprite_get(const Ctx& x, int s, int& vr, int& vc, int& vis, int& prior) {
@@ -166,7 +195,7 @@ __device__ __forceinline__ int top_char(const Ctx& x, int r, int c) {
   const int cell = r * x.k.C + c;
   int ch = (x.l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
   for (int z = 0; z < x.k.NT; ++z) {  // back to front
-    const int t = x.l.z[z];
+    const int t = thing_at_z(x, z);
     const uint32_t kind = tfield(x, t, T_KIND), idx = tfield(x, t, T_IDX);
     const bool here = kind == 0 ? x.l.snap[idx * WAVE + x.lane] == cell : bit_at(x, x.l.snapd, idx, r, c);
     if (here) ch = tfield(x, t, T_CH);
@@ -188,7 +217,7 @@ __device__ __forceinline__ bool thing_layer(const Ctx& x, int thing, int r, int 
 __device__ __forceinline__ uint64_t drape_layer_row(const Ctx& x, int thing, int r) {
   uint64_t bits = row_get(x, x.l.snapd, tfield(x, thing, T_IDX), r);
   if (!x.k.occl || !bits) return bits;
-  const uint32_t above = tfield(x, thing, T_ABOVE);
+  const uint32_t above = above_things(x, thing);
   const int lo = r * x.k.C, hi = lo + x.k.C;
   for (int u = 0; u < x.k.NT; ++u) {
     if (!((above >> u) & 1)) continue;
@@ -357,8 +386,49 @@ __device__ __forceinline__ void prog_scrolly(Ctx& x, int thing) {
   maybe_move(x, thing, dr, dc);
 }
 
-__device__ __forceinline__ void terminate(Ctx& x) { x.game_over = 1; x.discount = 0.0f; }  // plot.py:176-198
+__device__ __forceinline__ void terminate(Ctx& x, float discount = 0.0f) { x.game_over = 1; x.discount = discount; }  // plot.py:176-198
 __device__ __forceinline__ void add_reward(Ctx& x, int r) { x.reward_set = 1; x.reward += r; }  // plot.py:200-226
+
+// Plot directives of a tabled entity (include/pcx.h pcx_directive): issued
+// before it moves, in table order, when its directive field of the action
+// selects them (tests/engine_test.py:169-295 injects the same calls).
+__device__ __forceinline__ void issue_directives(Ctx& x, int thing) {
+  const uint32_t mask = tfield(x, thing, T_P3);
+  if (x.action < 0 || !mask) return;
+  const uint32_t sel = ((uint32_t)x.action >> tfield(x, thing, T_P2)) & mask;
+  if (!sel) return;
+  for (int i = 0; i < x.k.n_dir; ++i) {
+    const uint32_t* d = x.l.dir + i * D_WORDS;
+    if ((int)(d[D_WHO] & 0xFF) != thing || d[D_SEL] != sel) continue;
+    switch ((d[D_WHO] >> 8) & 0xFF) {
+      case PCX_DIR_ADD_REWARD: add_reward(x, (int)d[D_REWARD]); break;
+      case PCX_DIR_TERMINATE: terminate(x, __uint_as_float(d[D_DISCOUNT])); break;
+      case PCX_DIR_Z_ORDER:
+        if (x.nzq < MAX_ZQ) x.l.zq[x.nzq++ * WAVE + x.lane] = d[D_WHO] >> 16;  // move_this | in_front_of << 8
+        else x.err |= ERR_INDEX;
+        break;
+      default: break;
+    }
+  }
+}
+// engine.py:796-835: one directive at a time, the moving thing is taken out and
+// put back behind everything (in_front_of None) or right in front of another
+__device__ __forceinline__ void apply_z_updates(Ctx& x) {
+  for (int u = 0; u < x.nzq; ++u) {
+    const uint32_t w = x.l.zq[u * WAVE + x.lane];
+    const int move = (int)(w & 0xFF), front = (int)((w >> 8) & 0xFF);
+    int n = 0;
+    if (front == 0xFF) x.l.ztmp[n++ * WAVE + x.lane] = (uint32_t)move;
+    for (int z = 0; z < x.k.NT; ++z) {
+      const int id = (int)x.l.zord[z * WAVE + x.lane];
+      if (id == move) continue;
+      x.l.ztmp[n++ * WAVE + x.lane] = (uint32_t)id;
+      if (id == front) x.l.ztmp[n++ * WAVE + x.lane] = (uint32_t)move;
+    }
+    for (int z = 0; z < x.k.NT; ++z) x.l.zord[z * WAVE + x.lane] = x.l.ztmp[z * WAVE + x.lane];
+  }
+  if (x.nzq) derive_above(x);
+}
 
 // layers[ch][r, c] for any character, backdrop ones included
 __device__ __forceinline__ bool char_layer_at(Ctx& x, int ch, int r, int c) {
@@ -575,8 +645,8 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
     // every other row of the layer is just its snapshot row.
     uint32_t busy_rows = 0;
     if (x.k.occl) {
-      if (tfield(x, x.k.tx, T_ABOVE_D) != 0 || R > 32) busy_rows = 0xFFFFFFFFu;
-      for (uint32_t m = tfield(x, x.k.tx, T_ABOVE_S); m; m &= m - 1) {
+      if (above_drapes(x, x.k.tx) != 0 || R > 32) busy_rows = 0xFFFFFFFFu;
+      for (uint32_t m = above_sprites(x, x.k.tx); m; m &= m - 1) {
         const int cell = x.l.snap[(__ffs((int)m) - 1) * WAVE + x.lane];
         if (cell >= 0) busy_rows |= 1u << (__umulhi((uint32_t)cell, x.k.magic_c) & 31u);
       }
@@ -702,6 +772,8 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
   l.sdesc = reinterpret_cast<uint2*>(lds + k.l_sdesc); l.skip = lds + k.l_skip;
   l.corner = lds + k.l_corner; l.pmask = lds + k.l_pmask; l.pframe = lds + k.l_pframe;
   l.flatraw = lds + k.l_flatraw; l.sdescraw = reinterpret_cast<uint2*>(lds + k.l_sdescraw);
+  l.dir = lds + k.l_dir; l.zord = lds + k.l_zord; l.zabove = lds + k.l_zabove; l.zabove_s = lds + k.l_zabove_s;
+  l.zabove_d = lds + k.l_zabove_d; l.zq = lds + k.l_zq; l.ztmp = lds + k.l_ztmp;
   __syncthreads();
 
   const bool timing = (a.debug & 8) != 0 && P.stats != nullptr;
@@ -726,7 +798,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
   }
   const int ndw = k.ND * k.R * k.RW;
   if (!skip) {
-    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}, 0, 0, 0, 0};
+    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}, 0, 0, 0, 0, 0};
     // bits 8..15 of the flags word: MarauderDrape._dx + 1; W_RNG: RNG draws so far (survive resets)
     uint32_t draws = st[W_RNG * bp];
     int dxv;
@@ -744,6 +816,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
         for (int d = 0; d < k.ND; ++d) l.corner[d * WAVE + lane] = l.init[k.w_scroll + 1 + d];
         for (int s = 0; s < k.NS; ++s) { l.pmask[s * WAVE + lane] = 0; l.pframe[s * WAVE + lane] = 0; }
       }
+      if (k.zdyn) for (int z = 0; z < k.NT; ++z) l.zord[z * WAVE + lane] = (uint32_t)z;  // the template's order
       x.action = PCX_ACTION_NONE;
     } else {
       x.frame = (int)st[W_FRAME * bp];
@@ -778,6 +851,13 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
         }
       }
     }
+    if (k.zdyn) {  // four bits per place: the thing at place z
+      if (!do_reset) {
+        const uint32_t z0 = st[k.w_z * bp], z1 = st[(k.w_z + 1) * bp];
+        for (int z = 0; z < k.NT; ++z) l.zord[z * WAVE + lane] = ((z < 8 ? z0 : z1) >> (4 * (z & 7))) & 0xFu;
+      }
+      derive_above(x);
+    }
     snapshot(x);  // what the previous frame's last repaint showed
     if (timing) c_sec[0] = __builtin_readcyclecounter() - t_start;  // state load
     const unsigned long long t_play = timing ? __builtin_readcyclecounter() : 0ull;
@@ -789,6 +869,10 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
       for (; i < k.NT && (int)(l.sched[i] >> 8) == g; ++i) {
         const int thing = l.sched[i] & 0xFF;
         const unsigned long long tp0 = timing ? __builtin_readcyclecounter() : 0ull;
+        if (k.n_dir) {
+          const uint32_t prog = tfield(x, thing, T_PROG);
+          if (prog == PCX_PROG_WALKER || prog == PCX_PROG_SCROLLY || prog == PCX_PROG_STATIC) issue_directives(x, thing);
+        }
         switch (tfield(x, thing, T_PROG)) {
           case PCX_PROG_WM_BOX: prog_wm_box(x, thing); break;
           case PCX_PROG_WM_JUDGE: prog_wm_judge(x, thing); break;
@@ -819,6 +903,16 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     if (timing) c_sec[1] = __builtin_readcyclecounter() - t_play;  // update groups
     const unsigned long long t_wb = timing ? __builtin_readcyclecounter() : 0ull;
     // ---- _apply_and_clear_plot + state write-back ---------------------------
+    if (k.zdyn) {  // engine.py:796-835; the repaint it asks for (:632-637) is the render phase below
+      apply_z_updates(x);
+      uint32_t z0 = 0, z1 = 0;
+      for (int z = 0; z < k.NT; ++z) {
+        const uint32_t t = l.zord[z * WAVE + lane] & 0xFu;
+        if (z < 8) z0 |= t << (4 * z); else z1 |= t << (4 * (z - 8));
+      }
+      st[k.w_z * bp] = z0;
+      st[(k.w_z + 1) * bp] = z1;
+    }
     flags = (x.game_over ? F_OVER : 0u) | ((x.err & 7u) << F_ERR_SHIFT) | ((uint32_t)((dxv + 1) & 0xFF) << 8);
     st[W_RNG * bp] = draws;
     st[W_FRAME * bp] = (uint32_t)x.frame;
@@ -882,7 +976,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
         for (int w = 0; w < FW; ++w) l.flatraw[GFLAT(d, w, lane)] = l.flat[GFLAT(d, w, lane)];
     for (int t = 0; t < k.NT; ++t) {
       if (tfield(x, t, T_KIND) != 1) continue;
-      const uint32_t d = tfield(x, t, T_IDX), above = tfield(x, t, T_ABOVE);
+      const uint32_t d = tfield(x, t, T_IDX), above = above_things(x, t);
       for (int u = 0; u < k.NT; ++u) {
         if (!((above >> u) & 1) || tfield(x, u, T_KIND) != 1) continue;
         const uint32_t du = tfield(x, u, T_IDX);
@@ -899,9 +993,9 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
       bool shown = cell >= 0;
       if (shown) {
         const int wi = cell >> 5, sh = cell & 31;
-        for (uint32_t m = tfield(x, t, T_ABOVE_S); m; m &= m - 1)
+        for (uint32_t m = above_sprites(x, t); m; m &= m - 1)
           if ((int)l.sdesc[(__ffs((int)m) - 1) * WAVE + lane].x == cell) shown = false;
-        for (uint32_t m = tfield(x, t, T_ABOVE_D); m; m &= m - 1)
+        for (uint32_t m = above_drapes(x, t); m; m &= m - 1)
           if ((l.flat[GFLAT(__ffs((int)m) - 1, wi, lane)] >> sh) & 1) shown = false;
         if (shown)
           for (int d = 0; d < k.ND; ++d) l.flat[GFLAT(d, wi, lane)] &= ~(1u << sh);
@@ -957,6 +1051,7 @@ class GenericBackend : public Backend {
   const char* kernel_name() const override { return "pcx_generic_step"; }
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
+  int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)(k_.ND ? k_.ND : 1) * k_.FW * bpad_); }
   int curtain_words() const override { return k_.FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return k_.pitch; }
@@ -1024,7 +1119,7 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
       const pcx_sprite_desc& sd = t.sprites[s];
       e[T_KIND] = 0; e[T_IDX] = s; e[T_PROG] = sd.program;
       e[T_FLAGS] = (sd.is_walker ? TF_WALKER : 0) | (sd.confined ? TF_CONFINED : 0);
-      e[T_P0] = sd.param[0]; e[T_P1] = sd.param[1];
+      e[T_P0] = sd.param[0]; e[T_P1] = sd.param[1]; e[T_P2] = sd.param[2]; e[T_P3] = sd.param[3];
       memcpy(&e[T_IMP0], sd.impassable, 16);
       if (sd.egocentric) { e[T_FLAGS] |= TF_EGO; k.has_scroll = 1; }
       if (ch == 'P') k.ip = z;
@@ -1034,6 +1129,7 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
     } else if (d >= 0) {
       const pcx_drape_desc& dd = t.drapes[d];
       e[T_KIND] = 1; e[T_IDX] = d; e[T_PROG] = dd.program; e[T_P0] = dd.param[0]; e[T_P1] = dd.param[1];
+      e[T_P2] = dd.param[2]; e[T_P3] = dd.param[3];
       if (dd.is_scrolly) {
         if (dd.pattern_rows > 4096 || dd.pattern_cols > 4096 || dd.margin_rows > 255 || dd.margin_cols > 255)
           return set_error(PCX_E_UNSUPPORTED, "generic backend: Scrolly pattern too large");
@@ -1124,7 +1220,40 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.w_drapes = k.w_sflags + (k.NS + 3) / 4;
   const int ndw = k.ND * k.R * k.RW;
   k.w_scroll = k.w_drapes + ndw;
-  k.NW = k.w_scroll + (k.has_scroll ? 1 + k.ND + 2 * k.NS : 0);
+  // plot directives: the issuing / moved things as thing ids; a game that changes
+  // the z-order keeps it per environment (two state words)
+  std::vector<uint32_t> dirs;
+  k.n_dir = t.n_directives; k.zdyn = 0;
+  if (k.n_dir < 0 || k.n_dir > PCX_MAX_DIRECTIVES) return set_error(PCX_E_INVALID, "generic backend: bad directive count");
+  auto thing_of = [&](int ch) { for (int z = 0; z < k.NT; ++z) if (t.z_order[z] == ch) return z; return -1; };
+  for (int i = 0; i < k.n_dir; ++i) {
+    const pcx_directive& dv = t.directives[i];
+    const int who = thing_of(dv.ch);
+    int move = 0, front = 0xFF;
+    if (who < 0 || dv.selector <= 0) return set_error(PCX_E_INVALID, "generic backend: malformed directive %d", i);
+    const uint32_t wprog = things[(size_t)who * T_WORDS + T_PROG];
+    if (wprog != PCX_PROG_WALKER && wprog != PCX_PROG_SCROLLY && wprog != PCX_PROG_STATIC)
+      return set_error(PCX_E_UNSUPPORTED, "generic backend: only tabled entities issue plot directives");
+    if (dv.kind == PCX_DIR_Z_ORDER) {
+      move = thing_of(dv.move_this);
+      front = dv.in_front_of ? thing_of(dv.in_front_of) : 0xFF;
+      if (move < 0 || front < 0 || move == front)
+        return set_error(PCX_E_INVALID, "generic backend: a z-order directive names no Sprite or Drape of this game");
+      k.zdyn = 1;
+    } else if (dv.kind == PCX_DIR_TERMINATE) {
+      if (!(dv.discount >= 0.0f && dv.discount <= 1.0f)) return set_error(PCX_E_INVALID, "Discount must be in range [0,1].");
+    } else if (dv.kind != PCX_DIR_ADD_REWARD) {
+      return set_error(PCX_E_INVALID, "generic backend: unknown directive kind %d", dv.kind);
+    }
+    uint32_t dbits;
+    memcpy(&dbits, &dv.discount, 4);
+    dirs.push_back((uint32_t)who | ((uint32_t)dv.kind << 8) | ((uint32_t)move << 16) | ((uint32_t)front << 24));
+    dirs.push_back((uint32_t)dv.selector);
+    dirs.push_back((uint32_t)dv.reward);
+    dirs.push_back(dbits);
+  }
+  k.w_z = k.w_scroll + (k.has_scroll ? 1 + k.ND + 2 * k.NS : 0);
+  k.NW = k.w_z + (k.zdyn ? 2 : 0);
   std::vector<uint32_t> init(k.NW, 0), initd(ndw ? ndw : 1, 0);
   init[W_FRAME] = (uint32_t)-1;
   uint32_t dx_plus1 = 1;
@@ -1158,6 +1287,7 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.l_bdmask = place(bdmask); k.l_aux = place(aux); k.l_init = place(init); k.l_initd = place(initd);
   if (laybc.empty()) laybc.push_back(0);
   k.l_laybc = place(laybc); k.l_s2t = place(s2t);
+  k.l_dir = place(dirs);
   {
     const int pat0 = place(patterns);
     for (int z = 0; z < k.NT; ++z) {
@@ -1179,6 +1309,12 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.l_corner = off; if (k.has_scroll) off += k.ND * WAVE;
   k.l_pmask = off; if (k.has_scroll) off += k.NS * WAVE;
   k.l_pframe = off; if (k.has_scroll) off += k.NS * WAVE;
+  k.l_zord = off; if (k.zdyn) off += k.NT * WAVE;
+  k.l_zabove = off; if (k.zdyn) off += k.NT * WAVE;
+  k.l_zabove_s = off; if (k.zdyn) off += k.NT * WAVE;
+  k.l_zabove_d = off; if (k.zdyn) off += k.NT * WAVE;
+  k.l_ztmp = off; if (k.zdyn) off += (k.NT + 1) * WAVE;
+  k.l_zq = off; if (k.zdyn) off += MAX_ZQ * WAVE;
   k.l_flatraw = off; if (!k.occl) off += k.ND * (k.FW | 1) * WAVE;
   off = (off + 1) & ~1;
   k.l_sdescraw = off; if (!k.occl) off += 2 * k.NS * WAVE;

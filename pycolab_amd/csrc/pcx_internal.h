@@ -93,6 +93,9 @@ class Backend {
   // Raw (pre-occlusion) curtains as flat cell-bit vectors, uint32 [n_drapes][curtain_words()][bpad],
   // template drape order; refreshed by launches with StepArgs::export_curtains.
   virtual const uint32_t* curtain_bits() const { return nullptr; }
+  // allocates the curtain export buffer if this backend has not yet (a
+  // drape-tracking cropper attached after its_showtime(): pcx_crop.hip)
+  virtual int ensure_curtains() { return 0; }
   virtual int curtain_words() const { return 0; }
   virtual int64_t batch_pad() const = 0;
   // bytes between consecutive planes of one environment (>= rows*cols, multiple of 4)

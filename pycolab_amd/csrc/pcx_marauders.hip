@@ -459,6 +459,7 @@ class MaraudersBackend : public Backend {
   const char* kernel_name() const override { return "pcx_marauders_step"; }
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
+  int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)ND * FW * bpad_); }
   int curtain_words() const override { return FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return pitch; }
@@ -477,6 +478,7 @@ int MaraudersBackend::init(const pcx_template& t, int64_t batch) {
   bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
   if (const char* e = getenv("PCX_FORCE_GENERIC")) if (atoi(e)) return set_error(PCX_E_UNSUPPORTED, "marauders backend: PCX_FORCE_GENERIC");
   if (!t.occlusion_in_layers) return set_error(PCX_E_UNSUPPORTED, "marauders backend: occlusion_in_layers=False");
+  if (t.n_directives) return set_error(PCX_E_UNSUPPORTED, "marauders backend: plot directives");
   if (t.rows != R || t.cols != C || t.n_sprites != NS || t.n_drapes != ND || t.n_chars != L || t.n_groups != 1)
     return set_error(PCX_E_UNSUPPORTED, "marauders backend: the shipped 16x39 board and cast only");
   // sprites in template order: P, four upward bolts, two downward bolts; no impassable characters

@@ -924,6 +924,7 @@ class ScrollyMazeBackend : public Backend {
   int max_fused_steps() const override { return fused_ok_ ? 256 : 1; }
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
+  int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)2 * k_.FW * bpad_); }
   int curtain_words() const override { return k_.FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return k_.cells; }
@@ -949,6 +950,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   batch_ = batch;
   bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
   unoccluded_ = !t.occlusion_in_layers;
+  if (t.n_directives) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: plot directives belong to tabled entities");
   if (t.n_drapes != 2 || t.n_sprites < 1 || t.n_sprites > MAX_NS)
     return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: expects 2 Scrolly drapes and 1..%d sprites", MAX_NS);
   k.R = t.rows; k.C = t.cols; k.cells = t.rows * t.cols; k.L = t.n_chars; k.NS = t.n_sprites;

@@ -317,6 +317,7 @@ class WarehouseBackend : public Backend {
   const char* kernel_name() const override { return "pcx_warehouse_step"; }
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
+  int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)lay_.FW * bpad_); }
   int curtain_words() const override { return lay_.FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return lay_.pitch; }
@@ -338,6 +339,7 @@ int WarehouseBackend::init(const pcx_template& t, int64_t batch) {
   bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
   if (const char* e = getenv("PCX_FORCE_GENERIC")) if (atoi(e)) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: PCX_FORCE_GENERIC");
   if (!t.occlusion_in_layers) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: occlusion_in_layers=False");
+  if (t.n_directives) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: plot directives");
   NS_ = t.n_sprites; R_ = t.rows; C_ = t.cols; L_ = t.n_chars;
   NB_ = L_ - NS_ - 1;
   bool shape_ok = false;

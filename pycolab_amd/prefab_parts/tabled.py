@@ -11,10 +11,28 @@ packing: an entity built with `action_field=(shift, mask)` obeys
 `(action >> shift) & mask`.  Games made only of these (plus static things)
 need no hand-written device program: the table-driven kernel
 (csrc/pcx_generic.hip) runs them as they are.
+
+Plot directives.  What the reference's tests inject into their test entities
+as Python callables (`tt.pre_update(engine, 'Q', lambda ...:
+the_plot.terminate_episode(0.5))`, tests/engine_test.py:169-295) is data here:
+an entity built with `directive_field=(shift, mask)` and
+`directives={value: [call, ...]}` issues, before it moves, the calls listed
+under the value its directive field of the action holds (0 = none):
+
+    ('add_reward', 5)                    the_plot.add_reward(5)            plot.py:200-226
+    ('terminate_episode',)               the_plot.terminate_episode()      plot.py:176-198
+    ('terminate_episode', 0.5)           ... with a custom discount
+    ('change_z_order', 'b', 'c')         the_plot.change_z_order('b', 'c') plot.py:136-174
+    ('change_z_order', 'c', None)        ... all the way to the back
 """
 
 from pycolab_amd.prefab_parts import drapes
 from pycolab_amd.prefab_parts import sprites
+
+
+def _params(action_field, directive_field):
+  return (int(action_field[0]), int(action_field[1]), int(directive_field[0]), int(directive_field[1]))
+
 
 MOTIONS = ['n', 'ne', 'e', 'se', 's', 'sw', 'w', 'nw', 'stay']
 
@@ -24,11 +42,12 @@ class TabledWalker(sprites.MazeWalker):
 
   def __init__(self, corner, position, character, impassable,
                confined_to_board=False, egocentric_scroller=False,
-               scrolling_group='', action_field=(0, 0)):
+               scrolling_group='', action_field=(0, 0), directive_field=(0, 0), directives=None):
     super(TabledWalker, self).__init__(
         corner, position, character, impassable, confined_to_board,
         egocentric_scroller, scrolling_group)
-    self.pcx_param = (int(action_field[0]), int(action_field[1]), 0, 0)
+    self.pcx_param = _params(action_field, directive_field)
+    self.pcx_directives = directives or {}
 
 
 class TabledScrolly(drapes.Scrolly):
@@ -36,13 +55,30 @@ class TabledScrolly(drapes.Scrolly):
 
   def __init__(self, curtain, character, board_shape, whole_pattern,
                board_northwest_corner, scroll_margins=(2, 3),
-               scrolling_group='', action_field=(0, 0)):
+               scrolling_group='', action_field=(0, 0), directive_field=(0, 0), directives=None):
     super(TabledScrolly, self).__init__(
         curtain, character, board_shape, whole_pattern,
         board_northwest_corner, scroll_margins, scrolling_group)
-    self.pcx_param = (int(action_field[0]), int(action_field[1]), 0, 0)
+    self.pcx_param = _params(action_field, directive_field)
+    self.pcx_directives = directives or {}
 
 
 class StaticDrape(drapes.things.Drape):
-  """A drape that never changes."""
+  """A drape that never changes (it may still issue plot directives)."""
   pcx_program = 'static'
+
+  def __init__(self, curtain, character, directive_field=(0, 0), directives=None):
+    super(StaticDrape, self).__init__(curtain, character)
+    self.pcx_param = _params((0, 0), directive_field)
+    self.pcx_directives = directives or {}
+
+
+class StaticSprite(sprites.things.Sprite):
+  """A sprite that never moves (it may still issue plot directives): the
+  reference's `tt.TestSprite` (tests/test_things.py:133-164)."""
+  pcx_program = 'static'
+
+  def __init__(self, corner, position, character, directive_field=(0, 0), directives=None):
+    super(StaticSprite, self).__init__(corner, position, character)
+    self.pcx_param = _params((0, 0), directive_field)
+    self.pcx_directives = directives or {}

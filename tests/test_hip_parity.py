@@ -19,7 +19,9 @@ ALL_GAMES = LEVELS + ['warehouse_L0', 'warehouse_L1', 'warehouse_L2', 'hello_wor
                       # the step kernel's shape-generic instances (oracle/custom_levels.py)
                       'scrolly_custom_A', 'scrolly_custom_B', 'scrolly_custom_C', 'scrolly_custom_D', 'scrolly_custom_E',
                       'scrolly_custom_A_unoccluded', 'scrolly_custom_C_unoccluded', 'scrolly_custom_E_unoccluded',
-                      'scrolly_custom_F', 'scrolly_custom_G', 'warehouse_custom_A', 'warehouse_custom_B', 'marauders_custom_A', 'hello_custom_A']
+                      'scrolly_custom_F', 'scrolly_custom_G', 'warehouse_custom_A', 'warehouse_custom_B', 'marauders_custom_A', 'hello_custom_A',
+                      # Plot directives incl. change_z_order on the device (engine.py:796-835)
+                      'directives_z_order', 'directives_reward_discount']
 
 
 class OracleAdapter(binding.OracleEngine):
