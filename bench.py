@@ -59,6 +59,20 @@ def cpu_baseline(template_path, budget_envs=1024, steps=512, max_procs=64):
                     % (cores, budget_envs, steps, wall)}
 
 
+def pmc_traffic(game, level, batch):
+  """HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json:
+  WRITE_SIZE + corrected FETCH_SIZE, collected as MI355X_MICROARCH.md prescribes),
+  or None when no record matches this workload."""
+  path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+  try:
+    for rec in json.load(open(path)).get('records', []):
+      if rec.get('game') == game and rec.get('level') == level and rec.get('batch') == batch:
+        return rec['bytes_per_launch']
+  except Exception:  # pylint: disable=broad-except
+    pass
+  return None
+
+
 def spawn_ranks(n, argv):
   """`--gpus N` without a launcher: become `torch.distributed.run` with N ranks."""
   import torch
@@ -112,7 +126,8 @@ def measure_config(game, level, batch, steps, warmup, device):
   out = {'workload': 'examples/%s, %d envs' % (fixture, batch), 'ms_per_step': kernel_ms,
          'env_steps_per_s': batch / (kernel_ms * 1e-3),
          'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(), 'algorithmic_bytes_per_env_step': bps,
-         'hbm_frac': bps * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+         'hbm_frac': bps * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+         'traffic': pmc_traffic(game, level, batch)}
   eng.close()
   return out
 
@@ -208,15 +223,7 @@ def main():
   if rank == 0:
     bytes_per_step = int(N.lib().pcx_engine_bytes_per_step(eng._native))
     achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(pmc):
-      try:
-        rec = json.load(open(pmc))
-        if rec.get('batch') == B and rec.get('level') == args.level and rec.get('game', 'scrolly_maze') == args.game:
-          traffic = rec['bytes_per_launch']
-      except Exception:  # pylint: disable=broad-except
-        pass
+    traffic = pmc_traffic(args.game, args.level, B)
     line = {
         'metric': 'env-steps/sec (whole node), scrolly_maze batch=1M; bit-exact vs CPU' if args.game == 'scrolly_maze'
                   else 'env-steps/sec (whole node), %s' % fixture,
