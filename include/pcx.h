@@ -43,6 +43,7 @@ extern "C" {
 #define PCX_MAX_SPRITES 16
 #define PCX_MAX_DRAPES 8
 #define PCX_MAX_THINGS (PCX_MAX_SPRITES + PCX_MAX_DRAPES)
+#define PCX_MAX_SCROLL_GROUPS 4 /* distinct scrolling_group names in one game */
 
 /* Action value that stands for Python's `None` (frame 0, engine.py:581). */
 #define PCX_ACTION_NONE (-1)
@@ -105,7 +106,9 @@ typedef struct pcx_sprite_desc {
   uint8_t prior_visible;/* MazeWalker._prior_visible (0 when None)           */
   uint8_t confined;     /* confined_to_board                                 */
   uint8_t egocentric;   /* egocentric_scroller                               */
-  uint8_t pad0[2];
+  uint8_t scrolling_group; /* index of its scrolling_group among the game's distinct
+                              group names, sorted; '' alone gives 0 (sprites.py:194) */
+  uint8_t pad0;
   int32_t program;      /* enum pcx_program                                  */
   int32_t row, col;     /* true position (Sprite.position)                   */
   int32_t vrow, vcol;   /* MazeWalker virtual position                       */
@@ -119,7 +122,7 @@ typedef struct pcx_drape_desc {
   uint8_t ch;
   uint8_t is_scrolly;
   uint8_t have_margins;  /* scroll_margins is not None                       */
-  uint8_t pad0;
+  uint8_t scrolling_group; /* same numbering as the sprites' field; drapes.py:337 */
   int32_t program;
   const uint8_t* curtain;   /* rows*cols bytes, 0/1: initial curtain          */
   /* Scrolly only: */

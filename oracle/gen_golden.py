@@ -353,7 +353,21 @@ def main():
   from pycolab import ascii_art as ref_art
   from pycolab.tests import test_things as tt
   names = walker_scenarios.MOTION_NAMES
-  for i, (name, spec) in enumerate(sorted(walker_scenarios.SCENARIOS.items())):
+  seeds = {'walkers_room': 51, 'walkers_scroll_always': 52, 'walkers_scroll_margins': 53, 'walkers_scroll_groups': 54}
+  for name, spec in sorted(walker_scenarios.SCENARIOS.items()):
+    i = seeds[name] - 51  # fixed per scenario: adding a scenario must not move the others' tapes
+    if spec['kind'] == 'scroll2':  # two scrolling groups, one action field each
+      fields = {}
+      for w in spec['worlds']:
+        for ch in list(w['scrollies']) + list(w['walkers']):
+          fields[ch] = w['field']
+      ref_action = lambda a, fields=fields: {ch: names[min((a >> sh) & mk, 8)] for ch, (sh, mk) in fields.items()}
+      tapes = lambda rng, T, n=spec['n_fields']: sum(
+          (walker_scenarios.field_tape(rng, T, True) << (4 * f) for f in range(n)), np.zeros(T, np.int32)).astype(np.int32)
+      run(name, lambda spec=spec: walker_scenarios.build(spec, ref_art, tt.TestMazeWalker, tt.TestScrolly, False),
+          E=24, T=160, n_ordinary=9, quit_action=99, seed=51 + i, template_name=name,
+          ref_action=ref_action, tapes=tapes)
+      continue
     chars = sorted(spec['walkers'])
     if spec['n_fields']:
       fields = {ch: spec['walkers'][ch]['field'] for ch in chars}

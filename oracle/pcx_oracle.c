@@ -67,10 +67,16 @@ typedef struct {
   int64_t reward;
   float discount;
   int game_over;
-  /* protocols/scrolling.py state for scrolling group '' (:198-241) */
-  int order_frame_valid, order_frame; /* 'scrolling__order_frame' */
-  int order[2];                       /* 'scrolling__order'       */
-  uint32_t egocentrists;              /* bit per entity id        */
+  /* protocols/scrolling.py state (:198-241), one set per scrolling group X;
+   * every prefab entity belongs to the group its constructor named
+   * (sprites.py:194, drapes.py:337) and `cur` is the group of the entity
+   * whose update() is running */
+  struct {
+    int order_frame_valid, order_frame; /* 'scrolling_X_order_frame' */
+    int order[2];                       /* 'scrolling_X_order'       */
+    uint32_t egocentrists;              /* 'scrolling_X_egocentrists', bit per entity id */
+  } sg[PCX_MAX_SCROLL_GROUPS];
+  int cur;
   int permit_frame_valid[PCX_MAX_THINGS];
   int permit_frame[PCX_MAX_THINGS];
   uint16_t permit_mask[PCX_MAX_THINGS]; /* bit per motion index */
@@ -159,20 +165,20 @@ static void plot_add_reward(ox_plot* p, int64_t r) {
 static inline int motion_index(int dr, int dc) { return (dr + 1) * 3 + (dc + 1); }
 
 /* scrolling.py:287-312 participate_as_egocentric */
-static void scroll_participate(ox_plot* p, int id) { p->egocentrists |= 1u << id; }
+static void scroll_participate(ox_plot* p, int id) { p->sg[p->cur].egocentrists |= 1u << id; }
 
 /* scrolling.py:339-369 get_order: returns 1 and fills `order` if an order was
  * issued during the current frame. */
 static int scroll_get_order(const ox_plot* p, int order[2]) {
-  if (!p->order_frame_valid || p->order_frame != p->frame) return 0;
-  order[0] = p->order[0];
-  order[1] = p->order[1];
+  if (!p->sg[p->cur].order_frame_valid || p->sg[p->cur].order_frame != p->frame) return 0;
+  order[0] = p->sg[p->cur].order[0];
+  order[1] = p->sg[p->cur].order[1];
   return 1;
 }
 
 /* scrolling.py:372-434 permit */
 static int scroll_permit(ox_plot* p, int id, uint16_t motions) {
-  if (!(p->egocentrists & (1u << id))) return OX_ERR_SCROLL; /* :406-410 */
+  if (!(p->sg[p->cur].egocentrists & (1u << id))) return OX_ERR_SCROLL; /* :406-410 */
   int my_frame = p->frame + 1;                               /* :418 */
   if (!p->permit_frame_valid[id]) {                          /* setdefault :427 */
     p->permit_frame_valid[id] = 1;
@@ -188,7 +194,7 @@ static int scroll_permit(ox_plot* p, int id, uint16_t motions) {
 /* scrolling.py:437-485 is_possible */
 static int scroll_is_possible(const ox_plot* p, int dr, int dc) {
   for (int id = 0; id < PCX_MAX_THINGS; ++id) {
-    if (!(p->egocentrists & (1u << id))) continue;
+    if (!(p->sg[p->cur].egocentrists & (1u << id))) continue;
     if (!p->permit_frame_valid[id] || p->permit_frame[id] != p->frame) return 0;
     if (!(p->permit_mask[id] & (1u << motion_index(dr, dc)))) return 0;
   }
@@ -197,11 +203,11 @@ static int scroll_is_possible(const ox_plot* p, int dr, int dc) {
 
 /* scrolling.py:488-531 order (check_possible handled by callers) */
 static int scroll_order(ox_plot* p, int dr, int dc) {
-  if (p->order_frame_valid && p->order_frame == p->frame) return OX_ERR_SCROLL;
-  p->order_frame_valid = 1;
-  p->order_frame = p->frame;
-  p->order[0] = dr;
-  p->order[1] = dc;
+  if (p->sg[p->cur].order_frame_valid && p->sg[p->cur].order_frame == p->frame) return OX_ERR_SCROLL;
+  p->sg[p->cur].order_frame_valid = 1;
+  p->sg[p->cur].order_frame = p->frame;
+  p->sg[p->cur].order[0] = dr;
+  p->sg[p->cur].order[1] = dc;
   return 0;
 }
 
@@ -363,7 +369,7 @@ static void sc_maybe_move(const pcxo_engine* e, ox_env* env, int di, int dr, int
   /* case 2 :592-659 */
   int vert = 0, horiz = 0;
   for (int id = 0; id < PCX_MAX_SPRITES; ++id) { /* only Sprites count :611 */
-    if (!(p->egocentrists & (1u << id))) continue;
+    if (!(p->sg[p->cur].egocentrists & (1u << id))) continue;
     int v, h;
     sc_burrows(e, d, &env->sprites[id], dr, dc, &v, &h);
     vert |= v;
@@ -790,6 +796,8 @@ static int run_program(ox_ctx* x, int id) {
   int prog = id < PCX_MAX_SPRITES ? e->t.sprites[id].program
                                   : e->t.drapes[id - PCX_MAX_SPRITES].program;
   int di = id - PCX_MAX_SPRITES;
+  x->env->plot.cur = id < PCX_MAX_SPRITES ? e->t.sprites[id].scrolling_group : e->t.drapes[di].scrolling_group;
+  if (x->env->plot.cur >= PCX_MAX_SCROLL_GROUPS) return -1;
   if (prog == PCX_PROG_WALKER || prog == PCX_PROG_SCROLLY || prog == PCX_PROG_STATIC) {
     if (id < PCX_MAX_SPRITES) issue_directives(x, id, e->t.sprites[id].ch, e->t.sprites[id].param);
     else issue_directives(x, id, e->t.drapes[di].ch, e->t.drapes[di].param);

@@ -31,6 +31,19 @@ WORLD = ['#############################',
          '#                 #         #',
          '#############################']
 
+WORLD2 = ['%%%%%%%%%%%%%%%%%%%%%%%%%',
+          '%        %        %     %',
+          '%  %%%   %   %%   %  %  %',
+          '%    %       %       %  %',
+          '%    %   %%%%%   %%%%%  %',
+          '%        +   %          %',
+          '%%%  %%      %    %%    %',
+          '%      Q  %     b %     %',
+          '%   %     %  %%%%%%  %  %',
+          '%   %%%      %       %  %',
+          '%        %   %   %      %',
+          '%%%%%%%%%%%%%%%%%%%%%%%%%']
+
 SCENARIOS = {
     # three independently steered walkers: action = aP | aQ << 4 | ax << 8
     'walkers_room': dict(
@@ -55,6 +68,19 @@ SCENARIOS = {
         # at the pattern's corner a diagonal motion meets an order of (0, 0) and the
         # reference raises (sprites.py:449-454); keep this tape to cardinal moves
         cardinal_only=True),
+    # two independent scrolling groups over one board (protocols/scrolling.py:287-312,
+    # sprites.py:153-156 `scrolling_group=`): world '#' scrolls for P (group 'left',
+    # action field 0), world '%' for Q (group 'right', field 1); 'a' and 'b' are carried
+    # along by their own group's orders only
+    'walkers_scroll_groups': dict(
+        kind='scroll2', board=(7, 11), beneath=' ',
+        worlds=[dict(world=WORLD, mark='+', group='left', field=(0, 15),
+                     scrollies={'#': dict(margins=(2, 3))},
+                     walkers={'P': dict(impassable='#', egocentric=True), 'a': dict(impassable='#')}),
+                dict(world=WORLD2, mark='+', group='right', field=(4, 15),
+                     scrollies={'%': dict(margins=None)},
+                     walkers={'Q': dict(impassable='%', egocentric=True), 'b': dict(impassable='')})],
+        schedule=[['#', '%'], ['a', 'P', 'b', 'Q']], z_order='a#b%QP', n_fields=2, cardinal_only=True),
 }
 
 
@@ -70,6 +96,19 @@ def build(spec, ascii_art, walker_cls, scrolly_cls, use_fields):
         kw['action_field'] = w['field']
       sprites[ch] = P(walker_cls, **kw)
     return ascii_art.ascii_art_to_game(spec['art'], spec['beneath'], sprites=sprites,
+                                       update_schedule=spec['schedule'], z_order=spec['z_order'])
+  if spec['kind'] == 'scroll2':
+    rows, cols = spec['board']
+    drapes, sprites = {}, {}
+    for w in spec['worlds']:
+      info = scrolly_cls.PatternInfo(w['world'], spec['board'], w['mark'], spec['beneath'])
+      extra = dict(action_field=w['field']) if use_fields else {}
+      for ch, d in w['scrollies'].items():
+        drapes[ch] = P(scrolly_cls, scroll_margins=d['margins'], scrolling_group=w['group'], **dict(info.kwargs(ch), **extra))
+      for ch, wk in w['walkers'].items():
+        sprites[ch] = P(_positioned(walker_cls), info.virtual_position(ch), impassable=wk['impassable'],
+                        egocentric_scroller=wk.get('egocentric', False), scrolling_group=w['group'], **extra)
+    return ascii_art.ascii_art_to_game([' ' * cols] * rows, ' ', sprites=sprites, drapes=drapes,
                                        update_schedule=spec['schedule'], z_order=spec['z_order'])
   info = scrolly_cls.PatternInfo(spec['world'], spec['board'], spec['mark'], spec['beneath'])
   rows, cols = spec['board']

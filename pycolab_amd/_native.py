@@ -17,6 +17,7 @@ MAX_CHARS = 32
 MAX_SPRITES = 16
 MAX_DRAPES = 8
 MAX_THINGS = MAX_SPRITES + MAX_DRAPES
+MAX_SCROLL_GROUPS = 4
 ACTION_NONE = -1
 
 OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_STATE = 0, -1, -2, -3, -4
@@ -38,14 +39,14 @@ CROP_FIXED, CROP_SCROLLING = 1, 2
 class SpriteDesc(ctypes.Structure):
   _fields_ = [('ch', c_u8), ('is_walker', c_u8), ('visible', c_u8),
               ('prior_visible', c_u8), ('confined', c_u8), ('egocentric', c_u8),
-              ('pad0', c_u8 * 2), ('program', c_i32),
+              ('scrolling_group', c_u8), ('pad0', c_u8), ('program', c_i32),
               ('row', c_i32), ('col', c_i32), ('vrow', c_i32), ('vcol', c_i32),
               ('impassable', c_u8 * 16), ('param', c_i32 * 4)]
 
 
 class DrapeDesc(ctypes.Structure):
   _fields_ = [('ch', c_u8), ('is_scrolly', c_u8), ('have_margins', c_u8),
-              ('pad0', c_u8), ('program', c_i32),
+              ('scrolling_group', c_u8), ('program', c_i32),
               ('curtain', c_u8_p), ('pattern', c_u8_p),
               ('pattern_rows', c_i32), ('pattern_cols', c_i32),
               ('corner_row', c_i32), ('corner_col', c_i32),

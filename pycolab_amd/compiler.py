@@ -95,6 +95,11 @@ class GameTemplate(object):
     progs = [programs.resolve(eng.backdrop)]
     if progs[0] != N.PROG_STATIC:
       raise programs.UnsupportedEntityError('only static Backdrops are supported')
+    # scrolling groups (protocols/scrolling.py): indices into the sorted distinct names
+    group_names = sorted({getattr(ent, '_scrolling_group', '') for ent in eng._sprites_and_drapes.values()})
+    if len(group_names) > N.MAX_SCROLL_GROUPS:
+      raise programs.UnsupportedEntityError('at most {} scrolling groups per game'.format(N.MAX_SCROLL_GROUPS))
+    group_index = {name: i for i, name in enumerate(group_names)} if group_names != [''] else {'': 0}
     for ch, ent in eng._sprites_and_drapes.items():
       prog = programs.resolve(ent)
       progs.append(prog)
@@ -107,15 +112,15 @@ class GameTemplate(object):
             prior_visible=int(bool(getattr(ent, '_prior_visible', None))),
             confined=int(bool(getattr(ent, '_confined_to_board', False))),
             egocentric=int(bool(getattr(ent, '_egocentric_scroller', False))),
+            scrolling_group=group_index[getattr(ent, '_scrolling_group', '')],
             program=prog, row=int(pos[0]), col=int(pos[1]),
             vrow=int(vpos[0]), vcol=int(vpos[1]),
             impassable=_impassable_bits(getattr(ent, '_impassable', ())),
             param=programs.extract_params(ent, prog)))
-        if getattr(ent, '_scrolling_group', '') != '':
-          raise programs.UnsupportedEntityError('only the default scrolling group is supported')
       else:
         scrolly = isinstance(ent, prefab_drapes.Scrolly)
         d = dict(ch=ord(ch), is_scrolly=int(scrolly), have_margins=0, program=prog,
+                 scrolling_group=group_index[getattr(ent, '_scrolling_group', '')],
                  curtain=np.ascontiguousarray(ent.curtain, dtype=np.uint8),
                  pattern=None, corner=(0, 0), margins=(0, 0),
                  param=programs.extract_params(ent, prog))
@@ -125,8 +130,6 @@ class GameTemplate(object):
           d['have_margins'] = int(ent._have_margins)
           if ent._have_margins:
             d['margins'] = (int(ent._scroll_margins[0]), int(ent._scroll_margins[1]))
-          if ent._scrolling_group != '':
-            raise programs.UnsupportedEntityError('only the default scrolling group is supported')
         t.drapes.append(d)
     # plot directives of tabled entities (prefab_parts/tabled.py), in z-order of the entities
     for ch, ent in eng._sprites_and_drapes.items():
@@ -259,6 +262,7 @@ class GameTemplate(object):
       for k in ('ch', 'is_walker', 'visible', 'prior_visible', 'confined',
                 'egocentric', 'program', 'row', 'col', 'vrow', 'vcol'):
         setattr(cs, k, s[k])
+      cs.scrolling_group = s.get('scrolling_group', 0)
       for j, b in enumerate(s['impassable']):
         cs.impassable[j] = b
       for j, v in enumerate(s['param']):
@@ -268,6 +272,7 @@ class GameTemplate(object):
       cd = ct.drapes[i]
       cd.ch, cd.is_scrolly, cd.have_margins = d['ch'], d['is_scrolly'], d['have_margins']
       cd.program = d['program']
+      cd.scrolling_group = d.get('scrolling_group', 0)
       cd.curtain = ptr(d['curtain'])
       if d['pattern'] is not None:
         cd.pattern = ptr(d['pattern'])

@@ -32,6 +32,7 @@ constexpr int MAX_L = 20;
 enum : int { T_CH = 0, T_KIND, T_IDX, T_PROG, T_LAYER, T_ABOVE, T_FLAGS, T_P0, T_P1, T_IMP0, T_IMP1, T_IMP2, T_IMP3,
              T_ABOVE_S, T_ABOVE_D,  // the things in front, as a sprite-index mask and a drape-index mask
              T_P2, T_P3,            // tabled entities: directive field of the action (shift, mask)
+             T_GROUP,               // scrolling group (protocols/scrolling.py), 0..PCX_MAX_SCROLL_GROUPS-1
              T_WORDS };
 // plot directives (include/pcx.h pcx_directive), four words each, staged into LDS
 enum : int { D_WHO = 0 /* thing | kind << 8 | move_this thing << 16 | in_front_of thing << 24 (0xFF = None) */, D_SEL, D_REWARD,
@@ -53,6 +54,8 @@ struct Consts {
   int32_t n_dir, zdyn, w_z;  // plot directives; any change_z_order among them; state offset of the z-order words
   int32_t l_dir, l_zord, l_zabove, l_zabove_s, l_zabove_d, l_zq, l_ztmp;
   int32_t has_scroll, w_scroll;  // any Scrolly drape / egocentric walker; state offset of the protocol words
+  int32_t n_sgroups;             // distinct scrolling groups among the things
+  uint32_t group_sprites[PCX_MAX_SCROLL_GROUPS];  // sprite-index mask of each group's members
   uint32_t magic_q, magic_c;  // 32-bit reciprocals of QW and C (exhaustively checked on the host)
   uint32_t seed_lo, seed_hi, envoff_lo, envoff_hi;
   int32_t w_sflags, w_drapes;           // state word offsets
@@ -105,8 +108,12 @@ struct Ctx {
   float discount;
   int32_t v[4];  // program variables (state words W_V0..3)
   // protocols/scrolling.py, scrolling group '': the order lives one frame only
+  // protocols/scrolling.py: the order of the running entity's scrolling group
+  // (it lives one frame only); with several groups the others' orders wait in
+  // `orders`, eight bits each (valid, o0 + 1, o1 + 1)
   int order_valid, o0, o1;
-  uint32_t registered;  // bit per sprite index: 'scrolling__egocentrists'
+  uint32_t orders, gsprites;  // gsprites: sprite-index mask of that group's members
+  uint32_t registered;  // bit per sprite index: 'scrolling_X_egocentrists' of every group X
   int nzq;              // queued change_z_order directives (plot.py:173-174)
 };
 
@@ -289,7 +296,7 @@ __device__ __forceinline__ bool mw_move(Ctx& x, int thing, int dr, int dc) {
 // scrolling.py:437-485 is_possible
 __device__ __forceinline__ bool is_possible(const Ctx& x, int dr, int dc) {
   for (int s = 0; s < x.k.NS; ++s) {
-    if (!((x.registered >> s) & 1)) continue;
+    if (!(((x.registered & x.gsprites) >> s) & 1)) continue;
     const uint32_t mask = x.l.pmask[s * WAVE + x.lane];
     if (!(mask & 0x80000000u) || x.l.pframe[s * WAVE + x.lane] != (uint32_t)x.frame) return false;
     if (!((mask >> motion_bit(dr, dc)) & 1)) return false;
@@ -341,7 +348,7 @@ __device__ __forceinline__ void maybe_move(Ctx& x, int thing, int dr, int dc) {
     const int margin_n = mrows - 1, margin_s = x.k.R - mrows, margin_w = mcols - 1, margin_e = x.k.C - mcols;
     bool vert = false, horiz = false;
     for (int s = 0; s < x.k.NS; ++s) {  // registered egocentric *sprites* (:611)
-      if (!((x.registered >> s) & 1)) continue;
+      if (!(((x.registered & x.gsprites) >> s) & 1)) continue;
       int old_r, old_c;
       sprite_true(x, s, old_r, old_c);
       const int new_r = old_r + dr, new_c = old_c + dc;
@@ -798,7 +805,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
   }
   const int ndw = k.ND * k.R * k.RW;
   if (!skip) {
-    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}, 0, 0, 0, 0, 0};
+    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0};
     // bits 8..15 of the flags word: MarauderDrape._dx + 1; W_RNG: RNG draws so far (survive resets)
     uint32_t draws = st[W_RNG * bp];
     int dxv;
@@ -869,6 +876,12 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
       for (; i < k.NT && (int)(l.sched[i] >> 8) == g; ++i) {
         const int thing = l.sched[i] & 0xFF;
         const unsigned long long tp0 = timing ? __builtin_readcyclecounter() : 0ull;
+        const int sgroup = k.n_sgroups > 1 ? (int)tfield(x, thing, T_GROUP) : 0;
+        if (k.n_sgroups > 1) {  // this entity's scrolling group comes into view
+          const uint32_t ov = (x.orders >> (8 * sgroup)) & 0xFFu;
+          x.order_valid = ov & 1; x.o0 = (int)((ov >> 1) & 3u) - 1; x.o1 = (int)((ov >> 3) & 3u) - 1;
+          x.gsprites = sgroup == 0 ? k.group_sprites[0] : sgroup == 1 ? k.group_sprites[1] : sgroup == 2 ? k.group_sprites[2] : k.group_sprites[3];
+        }
         if (k.n_dir) {
           const uint32_t prog = tfield(x, thing, T_PROG);
           if (prog == PCX_PROG_WALKER || prog == PCX_PROG_SCROLLY || prog == PCX_PROG_STATIC) issue_directives(x, thing);
@@ -890,6 +903,10 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
           case PCX_PROG_WALKER: prog_walker(x, thing); break;
           case PCX_PROG_SCROLLY: prog_scrolly(x, thing); break;
           default: break;  // PCX_PROG_STATIC
+        }
+        if (k.n_sgroups > 1) {
+          const uint32_t ov = (uint32_t)(x.order_valid & 1) | ((uint32_t)(x.o0 + 1) & 3u) << 1 | ((uint32_t)(x.o1 + 1) & 3u) << 3;
+          x.orders = (x.orders & ~(0xFFu << (8 * sgroup))) | (ov << (8 * sgroup));
         }
         if (timing) {
           const unsigned long long dt = __builtin_readcyclecounter() - tp0;
@@ -1104,6 +1121,8 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   auto layer_of = [&](int ch) { for (int i = 0; i < k.L; ++i) if (t.chars[i] == ch) return i; return -1; };
   std::vector<uint32_t> things((size_t)k.NT * T_WORDS, 0), zt(k.NT), sched(k.NT), patterns;
   k.has_scroll = 0;
+  k.n_sgroups = 1;
+  for (int g = 0; g < PCX_MAX_SCROLL_GROUPS; ++g) k.group_sprites[g] = 0;
   k.ip = k.ix = k.ib = k.tx = -1;
   k.bolt_mask_all = k.bolt_mask_up = k.box_mask = 0;
   for (int z = 0; z < k.NT; ++z) {
@@ -1122,6 +1141,10 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
       e[T_P0] = sd.param[0]; e[T_P1] = sd.param[1]; e[T_P2] = sd.param[2]; e[T_P3] = sd.param[3];
       memcpy(&e[T_IMP0], sd.impassable, 16);
       if (sd.egocentric) { e[T_FLAGS] |= TF_EGO; k.has_scroll = 1; }
+      if (sd.scrolling_group >= PCX_MAX_SCROLL_GROUPS) return set_error(PCX_E_UNSUPPORTED, "generic backend: more than %d scrolling groups", PCX_MAX_SCROLL_GROUPS);
+      e[T_GROUP] = sd.scrolling_group;
+      k.group_sprites[sd.scrolling_group] |= 1u << s;
+      if ((int)sd.scrolling_group + 1 > k.n_sgroups) k.n_sgroups = sd.scrolling_group + 1;
       if (ch == 'P') k.ip = z;
       if (sd.program == PCX_PROG_EM_UPBOLT) { k.bolt_mask_all |= 1 << s; k.bolt_mask_up |= 1 << s; }
       if (sd.program == PCX_PROG_EM_DOWNBOLT) k.bolt_mask_all |= 1 << s;
@@ -1130,6 +1153,9 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
       const pcx_drape_desc& dd = t.drapes[d];
       e[T_KIND] = 1; e[T_IDX] = d; e[T_PROG] = dd.program; e[T_P0] = dd.param[0]; e[T_P1] = dd.param[1];
       e[T_P2] = dd.param[2]; e[T_P3] = dd.param[3];
+      if (dd.scrolling_group >= PCX_MAX_SCROLL_GROUPS) return set_error(PCX_E_UNSUPPORTED, "generic backend: more than %d scrolling groups", PCX_MAX_SCROLL_GROUPS);
+      e[T_GROUP] = dd.scrolling_group;
+      if ((int)dd.scrolling_group + 1 > k.n_sgroups) k.n_sgroups = dd.scrolling_group + 1;
       if (dd.is_scrolly) {
         if (dd.pattern_rows > 4096 || dd.pattern_cols > 4096 || dd.margin_rows > 255 || dd.margin_cols > 255)
           return set_error(PCX_E_UNSUPPORTED, "generic backend: Scrolly pattern too large");

@@ -993,6 +993,8 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   // 1); the template lists them in engine insertion order, which is the z-order
   // for ascii_art games (ascii_art.py:278-283).  sp[s] = the template's
   // description of sprite s, tmpl_index[s] = its place in the template.
+  for (int s = 0; s < t.n_sprites; ++s) if (t.sprites[s].scrolling_group) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: one scrolling group only");
+  for (int d = 0; d < t.n_drapes; ++d) if (t.drapes[d].scrolling_group) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: one scrolling group only");
   const pcx_sprite_desc* sp[MAX_NS] = {};
   for (int s = 0; s < t.n_sprites; ++s) {
     k.tmpl_index[s] = -1;
