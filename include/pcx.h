@@ -386,6 +386,25 @@ typedef struct pcx_post pcx_post;
 int pcx_post_create(const pcx_planes_view* src, const pcx_post_desc* d, int device_id, pcx_post** out);
 void pcx_post_destroy(pcx_post* p);
 int pcx_post_run(pcx_post* p, void* stream);
+/* Fused epilogue: rendering.ObservationToFeatureArray in its
+ * default axis order written by the step kernel's own render loop -- the layer
+ * masks are in registers there -- into a caller-owned float32 array
+ * [batch][depth][rows*cols] (16-byte aligned), every step from the next one on.
+ * chars: the stacked layers' characters (distinct; a character the game does
+ * not have leaves its plane as the caller initialised it: zeros).
+ * skip_layers != 0: the uint8 layer planes of `planes` are no longer written
+ * (the board plane is) -- for consumers that only ingest the feature array.
+ * Answers PCX_E_UNSUPPORTED where the backend's render loop cannot do it (the
+ * table-driven kernel, boards with rows*cols % 4 != 0): run pcx_post_* then.
+ * A NULL desc clears the epilogue. */
+typedef struct pcx_epilogue_desc {
+  int32_t depth;
+  uint8_t chars[PCX_POST_MAX_DEPTH];
+  float* out_dev;
+  int32_t skip_layers;
+} pcx_epilogue_desc;
+int pcx_engine_set_epilogue(pcx_engine* e, const pcx_epilogue_desc* d);
+
 /* out_dev: TO_ARRAY/FEATURE_ARRAY [batch][depth*rows*cols] elements; REPAINT a
  * planes array [batch][1 + depth][pitch], pitch = pcx_post_plane_pitch() =
  * rows*cols rounded up to a multiple of 4 (pad bytes are 0). */

@@ -118,6 +118,10 @@ class PostDesc(ctypes.Structure):
               ('chars', c_u8 * POST_MAX_DEPTH), ('stride', c_i64 * 3)]
 
 
+class EpilogueDesc(ctypes.Structure):
+  _fields_ = [('depth', c_i32), ('chars', c_u8 * POST_MAX_DEPTH), ('out_dev', ctypes.c_void_p), ('skip_layers', c_i32)]
+
+
 # Every symbol include/pcx.h declares: (name, restype, argtypes).
 _VP = ctypes.c_void_p
 SYMBOLS = [
@@ -131,6 +135,7 @@ SYMBOLS = [
     ('pcx_engine_bind_buffers', c_i32, [_VP, ctypes.POINTER(Buffers)]),
     ('pcx_engine_read_things', c_i32, [_VP, c_i64, c_i64, _VP, _VP]),
     ('pcx_engine_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
+    ('pcx_engine_set_epilogue', c_i32, [_VP, ctypes.POINTER(EpilogueDesc)]),
     ('pcx_memcpy_d2h', c_i32, [_VP, _VP, c_u64]),
     ('pcx_memcpy_h2d', c_i32, [_VP, _VP, c_u64]),
     ('pcx_device_malloc', c_i32, [ctypes.POINTER(_VP), c_u64]),

@@ -77,6 +77,11 @@ __global__ void pcx_any_nonzero(const uint8_t* v, int64_t n, uint32_t* flag) {
   if (any) atomicOr(flag, 1u);
 }
 
+int Backend::set_epilogue(const pcx_epilogue_desc* d) {
+  if (!d) return 0;
+  return set_error(PCX_E_UNSUPPORTED, "%s has no fused feature-array epilogue", kernel_name());
+}
+
 ErrorPoll::~ErrorPoll() {
   if (dev) (void)hipFree(dev);
   if (host) (void)hipHostFree(host);
@@ -258,6 +263,19 @@ int pcx_engine_error_poll(pcx_engine* e, void* stream, int32_t* seen) {
   if (!e || !e->out.error) return set_error(PCX_E_INVALID, "pcx_engine_error_poll: bad arguments");
   PCX_HIP(hipSetDevice(e->device));
   return e->error_poll.poll(e->out.error, e->batch, (hipStream_t)stream, seen);
+}
+
+int pcx_engine_set_epilogue(pcx_engine* e, const pcx_epilogue_desc* d) {
+  if (!e) return set_error(PCX_E_INVALID, "pcx_engine_set_epilogue: null engine");
+  if (d) {
+    if (d->depth < 1 || d->depth > PCX_POST_MAX_DEPTH || !d->out_dev || (reinterpret_cast<uintptr_t>(d->out_dev) & 15u))
+      return set_error(PCX_E_INVALID, "pcx_engine_set_epilogue: bad descriptor");
+    for (int i = 0; i < d->depth; ++i)
+      for (int j = 0; j < i; ++j)
+        if (d->chars[i] == d->chars[j]) return set_error(PCX_E_UNSUPPORTED, "pcx_engine_set_epilogue: a layer is stacked twice");
+  }
+  PCX_HIP(hipSetDevice(e->device));
+  return e->backend->set_epilogue(d);
 }
 
 int pcx_engine_read_things(pcx_engine* e, int64_t env0, int64_t n, pcx_sprite_state* sprites_host,

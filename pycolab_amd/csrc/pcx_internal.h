@@ -100,6 +100,10 @@ class Backend {
   virtual int64_t batch_pad() const = 0;
   // bytes between consecutive planes of one environment (>= rows*cols, multiple of 4)
   virtual int plane_pitch() const = 0;
+  // include/pcx.h pcx_engine_set_epilogue: null clears.  Backends whose render
+  // loop cannot produce it answer PCX_E_UNSUPPORTED (the caller then runs the
+  // post-processor as its own kernel).
+  virtual int set_epilogue(const pcx_epilogue_desc* d);
 };
 
 Backend* make_scrolly_maze_backend();

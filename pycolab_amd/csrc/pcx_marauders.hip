@@ -136,9 +136,9 @@ __device__ __forceinline__ int select_bit(uint32_t w, int n) {
 }
 
 // NWAVES waves per workgroup: wave 0 steps the group, all share the render loop.
-template <int NWAVES>
+template <int NWAVES, bool EPI = false>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                                    const pcx_buffers out) {
+                                                                    const pcx_buffers out, const stream::EpilogueArgs epi) {
   extern __shared__ uint32_t lds[];
   constexpr int O_BD = 0, O_BDM = O_BD + QW, O_TAB_END = O_BDM + NB * QW;
   constexpr int O_FLAT = O_TAB_END, O_XS = O_FLAT + ND * WAVE * FWP, O_SDESC = (O_XS + WAVE * FWP + 1) & ~1,
@@ -439,8 +439,8 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts 
 #pragma unroll
   for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  stream::stream_planes<NS, ND, NB, QW, NWAVES>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                               flat, sdesc, skipv, FWP, lane, wave);
+  stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                               flat, sdesc, skipv, FWP, lane, wave, epi, env0);
 }
 
 // ---------------------------------------------------------------------------
@@ -463,9 +463,16 @@ class MaraudersBackend : public Backend {
   int curtain_words() const override { return FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return pitch; }
+  int set_epilogue(const pcx_epilogue_desc* d) override {
+    if (!stream::fill_epilogue(epi_, d, cells, sprite_ch_, NS, drape_ch_, ND, bchar_ch_, NB))
+      return set_error(PCX_E_UNSUPPORTED, "marauders backend: epilogue needs rows*cols %% 4 == 0");
+    return 0;
+  }
 
  private:
   Consts k_{};
+  stream::EpilogueArgs epi_{};
+  int sprite_ch_[NS] = {}, drape_ch_[ND] = {}, bchar_ch_[NB] = {};
   int64_t batch_ = 0, bpad_ = 0;
   int num_cus_ = 256;
   DevArray<uint32_t> tables_, initc_, state_, curtains_;
@@ -530,12 +537,15 @@ int MaraudersBackend::init(const pcx_template& t, int64_t batch) {
   for (int s = 0; s < NS; ++s) {
     k.sprite_off[s] = (uint32_t)(1 + layer_of(t.sprites[s].ch)) * pitch;
     k.sprite_ch4[s] = t.sprites[s].ch * 0x01010101u;
+    sprite_ch_[s] = t.sprites[s].ch;
   }
   for (int d = 0; d < ND; ++d) {
     const pcx_drape_desc& dd = t.drapes[k.drape_slot_tmpl[d]];
     k.drape_off[d] = (uint32_t)(1 + layer_of(dd.ch)) * pitch;
     k.drape_ch4[d] = dd.ch * 0x01010101u;
+    drape_ch_[d] = dd.ch;
   }
+  stream::fill_epilogue(epi_, nullptr, cells, sprite_ch_, NS, drape_ch_, ND, bchar_ch_, NB);
   std::vector<uint32_t> tab((size_t)QW * (1 + NB), 0);
   memcpy(tab.data(), t.backdrop, cells);
   int nb = 0;
@@ -547,6 +557,7 @@ int MaraudersBackend::init(const pcx_template& t, int64_t batch) {
     if (thing) continue;
     if (nb >= NB) return set_error(PCX_E_INVALID, "marauders backend: inconsistent character set");
     k.bchar_off[nb] = (uint32_t)(1 + i) * pitch;
+    bchar_ch_[nb] = ch;
     uint8_t* m = reinterpret_cast<uint8_t*>(tab.data() + (size_t)QW * (1 + nb));
     for (int c = 0; c < cells; ++c) m[c] = t.backdrop[c] == ch;
     ++nb;
@@ -603,9 +614,13 @@ int MaraudersBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     if (want > 64 * 1024) want = 64 * 1024;
     if (want > lds) lds = want;
   }
-  if (nwaves == 8) hipLaunchKernelGGL((pcx_marauders_step<8>), dim3((unsigned)groups), dim3(8 * WAVE), lds, s, k_, P, a, out);
-  else if (nwaves == 4) hipLaunchKernelGGL((pcx_marauders_step<4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out);
-  else hipLaunchKernelGGL((pcx_marauders_step<1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out);
+#define PCX_EM_LAUNCH(nw, epi)                                                                                 \
+  hipLaunchKernelGGL((pcx_marauders_step<nw, epi>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_)
+  const bool epi = epi_.out != nullptr;  // the feature-array epilogue has its own instances
+  if (nwaves == 8) { if (epi) PCX_EM_LAUNCH(8, true); else PCX_EM_LAUNCH(8, false); }
+  else if (nwaves == 4) { if (epi) PCX_EM_LAUNCH(4, true); else PCX_EM_LAUNCH(4, false); }
+  else { if (epi) PCX_EM_LAUNCH(1, true); else PCX_EM_LAUNCH(1, false); }
+#undef PCX_EM_LAUNCH
   PCX_HIP(hipGetLastError());
   return 0;
 }

@@ -27,6 +27,7 @@
 // 12 bytes for level 0 instead of a 4005-cell pattern.
 
 #include "pcx_internal.h"
+#include "pcx_stream.h"  // EpilogueArgs: the feature-array epilogue shared with the other hand-written kernels
 
 #include <cstdarg>
 #include <cstdlib>
@@ -346,9 +347,10 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 // TFUSE: small batches, several consecutive steps in one launch
 // (StepArgs::n_steps): wave 0 steps the group for step i + 1 while waves 1-3
 // render step i out of the other descriptor buffer; one barrier per step.
-template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false>
+// EPI: the render loop also writes the float32 feature-array epilogue (pcx_stream.h).
+template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false, bool EPI = false>
 __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                                  const pcx_buffers out) {
+                                                                  const pcx_buffers out, const stream::EpilogueArgs epi) {
   // A workgroup is two wavefronts with different jobs, looping over groups of
   // 64 environments: wave 0 (logic) steps group i+1 and leaves its render
   // descriptors in one LDS buffer while wave 1 (render) streams the
@@ -859,10 +861,15 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // environment at most once per iteration, so the update is four selects.
   constexpr bool INCR = !COOP && !TFUSE && SR != 0 && (SR * SC / 4) >= WAVE;
   uint32_t e = 0, q = lane, voff = 4u * lane, eF = 0;
+  // epilogue (EPI): float32 planes of the selected layers, 16 bytes per board dword
+  const bool layers_on = !(EPI && epi.skip_layers);
+  uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(epi.out) + (size_t)env0 * epi.env_stride);
+  const uint32_t f_skew = epi.env_stride - 16u * (uint32_t)QW;  // foff = 16 f + e * f_skew
+  uint32_t foff = 16u * lane;
 #pragma unroll 1
   for (int it = COOP ? wave : TFUSE ? wave - 1 : 0; it < QW;
        it += COOP ? (int)(blockDim.x >> 6) : TFUSE ? (int)(blockDim.x >> 6) - 1 : 1) {
-    uint32_t e_now, q_now, voff_now, eF_now;
+    uint32_t e_now, q_now, voff_now, eF_now, foff_now = 0;
     if constexpr (INCR) {
       e_now = e; q_now = q; voff_now = voff; eF_now = eF;
       q += WAVE; voff += 4u * WAVE;
@@ -871,21 +878,35 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       e = wrap ? e + 1 : e;
       voff = wrap ? voff + e_skew : voff;
       eF = wrap ? eF + FWP : eF;
+      if constexpr (EPI) { foff_now = foff; foff += 16u * WAVE; foff = wrap ? foff + f_skew : foff; }
     } else {
       const uint32_t f = (uint32_t)it * WAVE + lane;
       e_now = (f * magic_q) >> 20;
       q_now = f - e_now * QW;
       voff_now = 4u * f + e_now * e_skew;
       eF_now = e_now * FWP;
+      if constexpr (EPI) foff_now = 16u * f + e_now * f_skew;
     }
     if (any_skip && l.skip[e_now]) continue;
     // scalar base (pinned above) + 32-bit lane offset: one `global_store_dword
     // voffset, data, sbase` per plane, no per-store address arithmetic
     compose(e_now, q_now, eF_now, [&](int plane, uint32_t v) {
-      if constexpr (SL != 0)  // the static-shape instance keeps all nine bases in SGPRs
-        asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(pb[plane]));
-      else
-        *reinterpret_cast<uint32_t*>(pb[plane] + voff_now) = v;
+      if (!EPI || plane == 0 || layers_on) {
+        if constexpr (SL != 0)  // the static-shape instance keeps all nine bases in SGPRs
+          asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(pb[plane]));
+        else
+          *reinterpret_cast<uint32_t*>(pb[plane] + voff_now) = v;
+      }
+      if constexpr (EPI) {  // a selected layer also leaves as four float32 (rendering.py:545-661)
+        const int32_t slot = plane == 0 ? -1 : plane < 3 ? epi.drape_slot[plane - 1]
+                             : plane < 3 + NS ? epi.sprite_slot[plane - 3 < NS ? plane - 3 : 0] : epi.bchar_slot[plane - 3 - NS];
+        if (slot >= 0) {
+          stream::f32x4 f;
+          f.x = (float)(v & 0xFFu); f.y = (float)((v >> 8) & 0xFFu); f.z = (float)((v >> 16) & 0xFFu); f.w = (float)(v >> 24);
+          const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
+          asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(fo), "v"(f), "s"(fbase));
+        }
+      }
     });
   }
   }
@@ -921,16 +942,28 @@ class ScrollyMazeBackend : public Backend {
     return 4 + 4 * (int64_t)k_.NW + 4 * (int64_t)(k_.NW - k_.CW) + (int64_t)(1 + k_.L) * k_.cells + 15;
   }
   const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
-  int max_fused_steps() const override { return fused_ok_ ? 256 : 1; }
+  int max_fused_steps() const override { return fused_ok_ && !epi_.out ? 256 : 1; }  // the epilogue has no multi-step instance
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
   int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)2 * k_.FW * bpad_); }
   int curtain_words() const override { return k_.FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return k_.cells; }
+  int set_epilogue(const pcx_epilogue_desc* d) override {
+    const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
+    if (d && !shipped_shape)
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the feature-array epilogue exists for the shipped 10x30 shape");
+    int sc[MAX_NS], dc[2] = {k_.maze_ch, k_.cash_ch}, bc[MAX_L];
+    for (int s = 0; s < k_.NS; ++s) sc[s] = k_.sprite_ch[s];
+    for (int i = 0; i < k_.n_bchars; ++i) bc[i] = k_.bchar[i];
+    if (!stream::fill_epilogue(epi_, d, k_.cells, sc, k_.NS, dc, 2, bc, k_.n_bchars))
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: epilogue needs rows*cols %% 4 == 0");
+    return 0;
+  }
 
  private:
   Consts k_{};
+  stream::EpilogueArgs epi_{};
   bool fused_ok_ = false;  // shipped shape and a batch small enough for the four-wave shapes
   int64_t batch_ = 0, bpad_ = 0;
   DevArray<uint32_t> walls_, backdrop4_, state_, curtains_;
@@ -1174,6 +1207,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     fused_ok_ = !(f && atoi(f) == 0) && !unoccluded_ && k.NS == 4 && k.R == 10 && k.C == 30 && k.L == 8 && k.ip == 3 &&
                 k.ie == 3 && bpad_ / WAVE < (int64_t)num_cus_ * below;
   }
+  set_epilogue(nullptr);
   int rc;
   if ((rc = walls_.upload(wb))) return rc;
   if ((rc = backdrop4_.upload(bd4))) return rc;
@@ -1221,23 +1255,32 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (a.n_steps > 1) {
     // several steps in this launch: the logic wave runs ahead of the render waves
-    if (!shipped_shape || !fused_ok_ || a.mode != 0)
+    if (!shipped_shape || !fused_ok_ || a.mode != 0 || epi_.out)
       return set_error(PCX_E_INVALID, "scrolly_maze backend: %d steps in one launch are not available here", a.n_steps);
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), dim3((unsigned)groups),
-                       dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out);
+                       dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_);
   } else if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
     int coop_waves = groups <= num_cus_ ? 8 : 4;  // at most one group per CU: split the render loop eight ways
     if (const char* e = getenv("PCX_COOP_WAVES")) coop_waves = atoi(e) == 4 ? 4 : 8;
-    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3((unsigned)groups),
-                       dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out);
+    if (epi_.out)
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, true>), dim3((unsigned)groups),
+                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_);
+    else
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3((unsigned)groups),
+                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_);
   } else if (shipped_shape) {
-    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out);
+    if (epi_.out && waves_per_wg == 1)
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true>), grid, block, lds, s, k_, P, a, out, epi_);
+    else if (epi_.out)
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the epilogue needs the single-wave launch shape");
+    else
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out, epi_);
   } else {
     switch (k_.NS) {
 #define PCX_SM_CASE(n)                                                                                          \
   case n:                                                                                                       \
-    if (unoccluded_) hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, true>), grid, block, lds, s, k_, P, a, out); \
-    else hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, false>), grid, block, lds, s, k_, P, a, out);            \
+    if (unoccluded_) hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, true>), grid, block, lds, s, k_, P, a, out, epi_); \
+    else hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, false>), grid, block, lds, s, k_, P, a, out, epi_);            \
     break;
       PCX_SM_CASE(1) PCX_SM_CASE(2) PCX_SM_CASE(3) PCX_SM_CASE(4) PCX_SM_CASE(5) PCX_SM_CASE(6)
 #undef PCX_SM_CASE

@@ -71,6 +71,23 @@ struct PlaneMap {
   uint32_t sprite_ch4[NS], drape_ch4[ND];                 // character replicated into four bytes
 };
 
+// Optional epilogue of the streaming loop: rendering.ObservationToFeatureArray
+// (rendering.py:545-661, default axis order) written by the step kernel itself.
+// The loop holds every layer's mask dword in registers; a selected layer is
+// also stored as four float32 (one 16-byte store per lane: 1 KiB contiguous per
+// wave) into a caller-owned array [batch][depth][cells] -- the consumer's
+// tensor is ready when the step is, without a second pass over the planes.
+// slot: place of the layer in the feature stack, -1 = not selected.  With
+// skip_layers the uint8 layer planes are not written at all (the board is).
+struct EpilogueArgs {
+  float* out = nullptr;      // [batch][depth][cells] float32; null = no epilogue
+  uint32_t env_stride = 0;   // bytes per environment = depth * cells * 4
+  uint32_t plane_bytes = 0;  // cells * 4
+  int32_t skip_layers = 0;
+  int32_t sprite_slot[PCX_MAX_SPRITES], drape_slot[PCX_MAX_DRAPES], bchar_slot[PCX_MAX_CHARS];
+};
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // The wavefront streams board + layers of the group's 64 environments.
 // One (environment e, board dword q) task per lane and iteration; consecutive
 // lanes take consecutive dwords, so every plane store of a wave covers 256
@@ -80,10 +97,12 @@ struct PlaneMap {
 // or divisions in the loop).  NWAVES waves of a workgroup share the loop,
 // iterations round-robin.
 //   QW: dwords per plane (plane pitch / 4); record = (1 + L) planes.
-template <int NS, int ND, int NB, int QW, int NWAVES>
+//   EPI: also write the float32 feature-array epilogue (EpilogueArgs).
+template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI>
 __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
                                               const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
-                                              const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave) {
+                                              const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
+                                              const EpilogueArgs& epi, int64_t env0) {
   uint8_t* const pb_board = uniform_ptr(group_base);
   uint8_t* pb_s[NS];
   uint8_t* pb_d[ND];
@@ -108,20 +127,40 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   uint32_t voff = e * env_stride + 4u * q, eF = e * (uint32_t)FWP;
   const uint32_t dvoff = (uint32_t)DE * env_stride + 4u * (uint32_t)DQ, dF = (uint32_t)DE * (uint32_t)FWP;
   const uint32_t wrap_voff = env_stride - 4u * (uint32_t)QW;
+  // epilogue addressing: one scalar base for the group, a lane offset that
+  // advances like voff (16 bytes per board dword), the layer's slot added per store
+  // EPI is a compile-time switch: the plain loop carries none of the epilogue's
+  // branches (measured: they cost it 1.5-4 %, profiles/r02_post_kernels.md)
+  constexpr bool epi_on = EPI;
+  const bool layers_on = !(epi_on && epi.skip_layers);
+  uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(epi.out) + (size_t)env0 * epi.env_stride);
+  uint32_t foff = e * epi.env_stride + 16u * q;
+  const uint32_t dfoff = (uint32_t)DE * epi.env_stride + 16u * (uint32_t)DQ, wrap_foff = epi.env_stride - 16u * (uint32_t)QW;
 #pragma unroll 1
   for (int it = wave; it < QW; it += NWAVES) {
-    const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF;
-    q += DQ; e += DE; voff += dvoff; eF += dF;
+    const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF, foff_now = foff;
+    q += DQ; e += DE; voff += dvoff; eF += dF; foff += dfoff;
     {
       const bool wrap = q >= (uint32_t)QW;
       q = wrap ? q - QW : q;
       e = wrap ? e + 1 : e;
       voff = wrap ? voff + wrap_voff : voff;
       eF = wrap ? eF + FWP : eF;
+      foff = wrap ? foff + wrap_foff : foff;
     }
     if (any_skip && skip[e_now]) continue;
     auto put = [&](uint8_t* base, uint32_t v) {
       asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(base));
+    };
+    // a layer: its uint8 plane and, when selected, its float32 feature plane
+    auto put_layer = [&](uint8_t* base, uint32_t m01, int32_t slot) {
+      if (layers_on) put(base, m01);
+      if (epi_on && slot >= 0) {
+        f32x4 f;
+        f.x = (float)(m01 & 0xFFu); f.y = (float)((m01 >> 8) & 0xFFu); f.z = (float)((m01 >> 16) & 0xFFu); f.w = (float)(m01 >> 24);
+        const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
+        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(fo), "v"(f), "s"(fbase));
+      }
     };
     // every LDS read of the iteration is issued up front
     uint32_t d = backdrop4[q_now];
@@ -156,12 +195,35 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
     // rendering.py:177-179 layers[c] = (board == c): by construction the thing's
     // own mask, or the backdrop's precomputed mask where no thing paints
 #pragma unroll
-    for (int dd = 0; dd < ND; ++dd) put(pb_d[dd], md[dd] & 0x01010101u);
+    for (int dd = 0; dd < ND; ++dd) put_layer(pb_d[dd], md[dd] & 0x01010101u, epi.drape_slot[dd]);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) put(pb_s[s], ms[s] & 0x01010101u);
+    for (int s = 0; s < NS; ++s) put_layer(pb_s[s], ms[s] & 0x01010101u, epi.sprite_slot[s]);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) put(pb_b[b], mb[b] & ~uni);
+    for (int b = 0; b < NB; ++b) put_layer(pb_b[b], mb[b] & ~uni, epi.bchar_slot[b]);
   }
+}
+
+// Host side: an epilogue descriptor (include/pcx.h) as EpilogueArgs for a backend
+// whose sprites / drape slots / backdrop-only characters paint the given
+// characters.  Returns false when the board is not a whole number of dwords.
+inline bool fill_epilogue(EpilogueArgs& a, const pcx_epilogue_desc* d, int cells, const int* sprite_ch, int ns,
+                          const int* drape_ch, int nd, const int* bchar_ch, int nb) {
+  a = EpilogueArgs();
+  for (int i = 0; i < PCX_MAX_SPRITES; ++i) a.sprite_slot[i] = -1;
+  for (int i = 0; i < PCX_MAX_DRAPES; ++i) a.drape_slot[i] = -1;
+  for (int i = 0; i < PCX_MAX_CHARS; ++i) a.bchar_slot[i] = -1;
+  if (!d) return true;
+  if (cells % 4 != 0) return false;
+  a.out = d->out_dev;
+  a.env_stride = (uint32_t)d->depth * (uint32_t)cells * 4u;
+  a.plane_bytes = (uint32_t)cells * 4u;
+  a.skip_layers = d->skip_layers != 0;
+  for (int f = 0; f < d->depth; ++f) {
+    for (int i = 0; i < ns; ++i) if (sprite_ch[i] == d->chars[f]) a.sprite_slot[i] = f;
+    for (int i = 0; i < nd; ++i) if (drape_ch[i] == d->chars[f]) a.drape_slot[i] = f;
+    for (int i = 0; i < nb; ++i) if (bchar_ch[i] == d->chars[f]) a.bchar_slot[i] = f;
+  }
+  return true;
 }
 
 // Constants of the streaming phase every backend derives the same way.

@@ -74,9 +74,9 @@ __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16
 // NS sprites: boxes 0..NS-2 in template order, the player is sprite NS-1 and
 // the front-most thing.  R x C board, NB backdrop-only characters, NWAVES waves
 // per workgroup (wave 0 steps the group, all of them share the render loop).
-template <int NS, int R, int C, int NB, int NWAVES>
+template <int NS, int R, int C, int NB, int NWAVES, bool EPI = false>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                                    const pcx_buffers out) {
+                                                                    const pcx_buffers out, const stream::EpilogueArgs epi) {
   extern __shared__ uint32_t lds[];
   constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32, FWP = FW | 1;
   constexpr int L = NS + 1 + NB, IP = NS - 1, NBOX = NS - 1;
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
 #pragma unroll
   for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  stream::stream_planes<NS, 1, NB, QW, NWAVES>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                              flat, sdesc, skipv, FWP, lane, wave);
+  stream::stream_planes<NS, 1, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                              flat, sdesc, skipv, FWP, lane, wave, epi, env0);
 }
 
 // ---------------------------------------------------------------------------
@@ -321,9 +321,16 @@ class WarehouseBackend : public Backend {
   int curtain_words() const override { return lay_.FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return lay_.pitch; }
+  int set_epilogue(const pcx_epilogue_desc* d) override {
+    if (!stream::fill_epilogue(epi_, d, lay_.cells, sprite_ch_, NS_, &drape_ch_, 1, bchar_ch_, NB_))
+      return set_error(PCX_E_UNSUPPORTED, "warehouse backend: epilogue needs rows*cols %% 4 == 0");
+    return 0;
+  }
 
  private:
   Consts k_{};
+  stream::EpilogueArgs epi_{};
+  int sprite_ch_[MAX_NS] = {}, drape_ch_ = 0, bchar_ch_[MAX_NB] = {};
   stream::Layout lay_;
   int NS_ = 0, R_ = 0, C_ = 0, NB_ = 0, L_ = 0, NW_ = 0;
   int64_t batch_ = 0, bpad_ = 0;
@@ -401,9 +408,12 @@ int WarehouseBackend::init(const pcx_template& t, int64_t batch) {
   for (int s = 0; s < NS_; ++s) {
     k.sprite_off[s] = (uint32_t)(1 + layer_of(t.sprites[s].ch)) * lay_.pitch;
     k.sprite_ch4[s] = t.sprites[s].ch * 0x01010101u;
+    sprite_ch_[s] = t.sprites[s].ch;
   }
   k.drape_off = (uint32_t)(1 + layer_of(dd.ch)) * lay_.pitch;
   k.drape_ch4 = dd.ch * 0x01010101u;
+  drape_ch_ = dd.ch;
+  stream::fill_epilogue(epi_, nullptr, lay_.cells, sprite_ch_, NS_, &drape_ch_, 1, bchar_ch_, NB_);
 
   // tables staged into LDS
   std::vector<uint32_t> tab((size_t)lay_.QW * (1 + NB_) + 3 * R_, 0);
@@ -416,6 +426,7 @@ int WarehouseBackend::init(const pcx_template& t, int64_t batch) {
     if (thing) continue;
     if (nb >= NB_) return set_error(PCX_E_INVALID, "warehouse backend: inconsistent character set");
     k.bchar_off[nb] = (uint32_t)(1 + i) * lay_.pitch;
+    bchar_ch_[nb] = ch;
     uint8_t* m = reinterpret_cast<uint8_t*>(tab.data() + (size_t)lay_.QW * (1 + nb));
     for (int c = 0; c < lay_.cells; ++c) m[c] = t.backdrop[c] == ch;
     ++nb;
@@ -482,14 +493,22 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     if (want > lds) lds = want;
   }
   bool launched = false;
+  const bool epi = epi_.out != nullptr;  // the feature-array epilogue has its own instances (whole-dword boards only)
+#define PCX_WM_LAUNCH(ns, r, c, nb, nw, ep)                                                                  \
+  hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, nw, ep>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_)
 #define X(ns, r, c, nb)                                                                                     \
   if (!launched && NS_ == ns && R_ == r && C_ == c && NB_ == nb) {                                          \
-    if (coop) hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out); \
-    else hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out);          \
+    if constexpr ((r * c) % 4 == 0) {                                                                       \
+      if (epi && coop) PCX_WM_LAUNCH(ns, r, c, nb, 4, true);                                                \
+      else if (epi) PCX_WM_LAUNCH(ns, r, c, nb, 1, true);                                                   \
+    }                                                                                                       \
+    if (!epi && coop) PCX_WM_LAUNCH(ns, r, c, nb, 4, false);                                                \
+    else if (!epi) PCX_WM_LAUNCH(ns, r, c, nb, 1, false);                                                   \
     launched = true;                                                                                        \
   }
   PCX_WM_SHAPES(X)
 #undef X
+#undef PCX_WM_LAUNCH
   if (!launched) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: no instance");
   PCX_HIP(hipGetLastError());
   return 0;

@@ -55,6 +55,7 @@ class Engine(object):
     self._bufs = None
     self._packed = None
     self._actions = None
+    self._steps_launched = 0  # reset / step launches so far (fused epilogues know when they are fresh)
     self._croppers = []
 
   def _register_cropper(self, cropper):
@@ -229,6 +230,7 @@ class Engine(object):
     for cropper in self._croppers:  # croppers attached with set_engine() before showtime
       cropper._create_native()
     N.check(lib.pcx_engine_reset(self._native, None, dev.current_stream(self._device_id)))
+    self._steps_launched += 1
     return self._result()
 
   def play(self, actions):
@@ -268,6 +270,7 @@ class Engine(object):
         keep.upload(np.asarray(env_mask, np.uint8))
         ptr = keep.ptr
     N.check(N.lib().pcx_engine_reset(self._native, ptr, dev.current_stream(self._device_id)))
+    self._steps_launched += 1
     dev.synchronize(self._device_id)
     return self._result()
 
@@ -276,6 +279,7 @@ class Engine(object):
     ptr = self._stage_actions(actions)
     N.check(N.lib().pcx_engine_step(self._native, ptr, int(self._auto_reset),
                                     dev.current_stream(self._device_id)))
+    self._steps_launched += 1
 
   def step_n(self, action_tape):
     """`len(action_tape)` consecutive steps from a device int32 tensor (or host
@@ -295,6 +299,7 @@ class Engine(object):
       raise ValueError('action tape must have shape [T, batch]')
     N.check(N.lib().pcx_engine_step_n(self._native, ptr, int(steps), int(self._auto_reset),
                                       dev.current_stream(self._device_id)))
+    self._steps_launched += int(steps)
     dev.synchronize(self._device_id)  # the staging buffer may be freed after this call
 
   def step_hashed(self, seed, t0, steps, env_offset=None):
@@ -305,6 +310,7 @@ class Engine(object):
     N.check(N.lib().pcx_engine_step_hashed(
         self._native, seed, env_offset, t0, steps, int(self._auto_reset),
         dev.current_stream(self._device_id)))
+    self._steps_launched += int(steps)
 
   def _stage_actions(self, actions):
     torch = dev.torch_module()

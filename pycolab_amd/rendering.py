@@ -210,8 +210,47 @@ class ObservationToFeatureArray(object):
     if self._depth > N.POST_MAX_DEPTH:
       raise NotImplementedError('more than {} layers'.format(N.POST_MAX_DEPTH))
     self._post = None
+    self._fused = None  # (engine, device tensor) once fuse_into() succeeded
+
+  def fuse_into(self, engine, skip_layers=False):
+    """Have `engine`'s step kernel write this feature array itself, as an
+    epilogue of its render loop (the layer masks are in registers there):
+    from the next `play()` / `step()` on, calling this object with one of the
+    engine's observations returns the tensor the step already filled -- no
+    second pass over the planes, no extra launch.  `skip_layers=True` also
+    stops the step from writing the uint8 layer planes (`Observation.layers`
+    then goes stale; the board stays valid) for consumers that only ingest
+    the features.  Returns False, and changes nothing, where the engine's
+    kernel cannot do it (default axis order only, batch > 1, boards with
+    rows*cols % 4 == 0, the hand-written step kernels): calls then run the
+    post-processor as its own kernel, as before."""
+    torch = dev.torch_module()
+    if (self._permute not in (None, (0, 1, 2)) or torch is None or engine._native is None or engine.batch == 1 or
+        len(set(self._layers)) != len(self._layers) or any(ord(c) > 255 for c in self._layers)):
+      return False
+    out = torch.zeros((engine.batch, self._depth, engine.rows, engine.cols), dtype=torch.float32,
+                      device='cuda:%d' % engine._device_id)
+    d = N.EpilogueDesc()
+    d.depth = self._depth
+    for i, ch in enumerate(self._layers):
+      d.chars[i] = ord(ch)
+    d.out_dev = out.data_ptr()
+    d.skip_layers = int(bool(skip_layers))
+    try:
+      N.check(N.lib().pcx_engine_set_epilogue(engine._native, ctypes.byref(d)))
+    except NotImplementedError:
+      return False
+    # start from the current observation (environments a later step leaves
+    # untouched keep features that match their planes)
+    out.copy_(ObservationToFeatureArray(self._layers)(engine._result()[0]))
+    self._fused = (engine, out, engine._steps_launched)
+    return True
 
   def __call__(self, observation):
+    if self._fused is not None and getattr(observation, '_source', None) is self._fused[0]:
+      engine, out, attached_at = self._fused
+      if engine._steps_launched > attached_at:  # a step has run since: the kernel wrote `out`
+        return out
     if not any(l in observation.layers for l in self._layers):
       raise RuntimeError(
           'The layers argument to this ObservationToFeatureArray, {}, has no '

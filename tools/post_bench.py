@@ -80,6 +80,29 @@ def main():
   ms = timed(lambda: hwc(obs), args.steps)
   add('ObservationToFeatureArray permute=(1,2,0)', 'pcx_post_features (strided stores), marauders %d envs' % eng.batch, ms,
       eng.batch * len(t.chars) * cells * 5)
+  # the same feature array as an epilogue of the step kernel: step alone, step + separate kernel, fused step
+  tape = torch.randint(0, 4, (64, eng.batch), dtype=torch.int32, device='cuda')
+  counter = [0]
+
+  def one_step():
+    eng.step(tape[counter[0] % 64]); counter[0] += 1
+  ms_step = timed(one_step, args.steps)
+  ms_both = timed(lambda: (one_step(), feats(obs)), args.steps)
+  fused = rendering.ObservationToFeatureArray(''.join(chr(c) for c in t.chars))
+  assert fused.fuse_into(eng)
+  ms_fused = timed(one_step, args.steps)
+  assert fused.fuse_into(eng, skip_layers=True)
+  ms_fused_only = timed(one_step, args.steps)
+  step_bytes = eng.batch * 7283
+  feat_bytes = eng.batch * len(t.chars) * cells * 4
+  add('play() alone', 'pcx_marauders_step, %d envs' % eng.batch, ms_step, step_bytes)
+  add('play() + ObservationToFeatureArray (two kernels)', 'pcx_marauders_step + pcx_post_features', ms_both,
+      step_bytes + feat_bytes + eng.batch * len(t.chars) * cells)
+  add('play() with the feature array fused (epilogue)', 'pcx_marauders_step', ms_fused, step_bytes + feat_bytes)
+  add('... fused, uint8 layer planes skipped', 'pcx_marauders_step', ms_fused_only,
+      step_bytes + feat_bytes - eng.batch * len(t.chars) * cells)
+  N_ = __import__('pycolab_amd._native', fromlist=['x'])
+  N_.check(N_.lib().pcx_engine_set_epilogue(eng._native, None))
   rep = rendering.ObservationCharacterRepainter(dict([(b, '^') for b in 'abcd'] + [(b, '|') for b in 'yz']))
   rep(obs)
   depth = len(rep._out_chars)
@@ -105,6 +128,23 @@ def main():
   ms = timed(lambda: feats(obs), args.steps)
   add('ObservationToFeatureArray, all %d layers' % len(t.chars), 'pcx_post_features, scrolly_maze %d envs' % eng.batch, ms,
       eng.batch * len(t.chars) * cells * 5)
+  tape = torch.randint(0, 5, (16, eng.batch), dtype=torch.int32, device='cuda')
+  counter = [0]
+
+  def one_step():
+    eng.step(tape[counter[0] % 16]); counter[0] += 1
+  ms_step = timed(one_step, 50)
+  ms_both = timed(lambda: (one_step(), feats(obs)), 50)
+  fused = rendering.ObservationToFeatureArray(''.join(chr(c) for c in t.chars))
+  assert fused.fuse_into(eng)
+  ms_fused = timed(one_step, 50)
+  assert fused.fuse_into(eng, skip_layers=True)
+  ms_fused_only = timed(one_step, 50)
+  step_bytes, feat_bytes, lay_bytes = eng.batch * 2819, eng.batch * len(t.chars) * cells * 4, eng.batch * len(t.chars) * cells
+  add('play() alone', 'pcx_scrolly_maze_step, %d envs' % eng.batch, ms_step, step_bytes)
+  add('play() + ObservationToFeatureArray (two kernels)', 'pcx_scrolly_maze_step + pcx_post_features', ms_both, step_bytes + feat_bytes + lay_bytes)
+  add('play() with the feature array fused (epilogue)', 'pcx_scrolly_maze_step', ms_fused, step_bytes + feat_bytes)
+  add('... fused, uint8 layer planes skipped', 'pcx_scrolly_maze_step', ms_fused_only, step_bytes + feat_bytes - lay_bytes)
   eng.close()
 
   print('| post-processor | kernel, workload | ms | algorithmic MB | GB/s | of 8 TB/s |')
