@@ -600,11 +600,13 @@ int MaraudersBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   }
   Ptrs P{tables_.ptr, initc_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
   const int64_t groups = bpad_ / WAVE;
-  // Launch shape: single-wave workgroups with LDS padded so that about eight
-  // share a CU (profiles/r01_tuning.md); when the batch leaves the chip
-  // underfilled (BASELINE config 3: 32,768 environments = two groups per CU)
-  // four or eight waves share a group's render loop.
-  int waves_per_cu = 8, nwaves = groups <= (int64_t)num_cus_ * 2 ? 8 : groups < (int64_t)num_cus_ * 5 ? 4 : 1;
+  // Launch shape: single-wave workgroups with LDS padded so that about four
+  // share a CU; when the batch leaves the chip underfilled (BASELINE config 3:
+  // 32,768 environments = two groups per CU) four waves share a group's render loop.
+  // Measured (tools/knob_sweep_r02.sh, profiles/r02_tuning.md): 32,768 envs 4 waves 0.0413 ms vs 8 waves 0.0435;
+  // 262,144 envs single-wave workgroups at 4 per CU 0.412 ms vs 0.490 at 8 (eleven 624-byte planes per
+  // environment: fewer concurrent write streams per CU are faster, as for scrolly_maze).
+  int waves_per_cu = 4, nwaves = groups < (int64_t)num_cus_ * 5 ? 4 : 1;
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   if (const char* e = getenv("PCX_EM_WAVES")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 8) nwaves = v; }
   const size_t words = (size_t)QW * (1 + NB) + (ND + 1) * WAVE * FWP + 2 + 2 * NS * WAVE + WAVE;

@@ -479,9 +479,9 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   Ptrs P{tables_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
   const int64_t groups = bpad_ / WAVE;
   // Launch shape as for scrolly_maze (profiles/r01_tuning.md): single-wave
-  // workgroups with LDS padded so that about eight of them share a CU; four
+  // workgroups with LDS padded so that about four of them share a CU; four
   // waves per group when the batch leaves most of the chip idle.
-  int coop_below = 5, waves_per_cu = 8;
+  int coop_below = 5, waves_per_cu = 4;  // measured: 1,048,576 envs 0.320 ms at 4 per CU vs 0.345 at 8 (tools/knob_sweep_r02.sh)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
