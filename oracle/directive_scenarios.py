@@ -126,3 +126,46 @@ def tape(spec, rng, T):
         a |= rng.randint(1, e['directive'][1] + 1) << e['directive'][0]
     out[t] = a
   return out
+
+
+# Three compatible chapters (same 3x9 board; every character used one way) for
+# storytelling.Story (oracle/gen_story_golden.py): each ends through a
+# terminate_episode directive, some with a custom discount.
+STORY = [
+    dict(art=['.........', '...Q.R...', '.........'], beneath='.', z_order='QR', schedule=[['Q', 'R']],
+         entities={
+             'Q': dict(kind='sprite', motion=None, directive=(0, 3),
+                       calls={1: [('add_reward', 5)], 2: [('terminate_episode',)], 3: [('terminate_episode', 0.5), ('add_reward', 1)]}),
+             'R': dict(kind='sprite', motion=None, directive=(2, 3),
+                       calls={1: [('add_reward', 7)], 2: [('add_reward', 11)], 3: [('add_reward', -3)]})}),
+    dict(art=['.........', '.a.....b.', '....D....'], beneath='.', z_order='aDb', schedule=[['a', 'b'], ['D']],
+         entities={
+             'a': dict(kind='walker', impassable='', confined=True, motion=(4, 15), directive=(0, 3),
+                       calls={1: [('change_z_order', 'a', 'b')], 3: [('add_reward', 2)]}),
+             'b': dict(kind='walker', impassable='a', confined=True, motion=(8, 15), directive=(2, 3),
+                       calls={2: [('change_z_order', 'b', None)]}),
+             'D': dict(kind='drape', motion=None, directive=(12, 3),
+                       calls={1: [('terminate_episode', 0.25), ('add_reward', 10)], 2: [('add_reward', 1)]})}),
+    dict(art=['....Q....', '.........', '..c......'], beneath='.', z_order='cQ', schedule=[['c', 'Q']],
+         entities={
+             'c': dict(kind='walker', impassable='Q', confined=False, motion=(4, 15), directive=(2, 3),
+                       calls={3: [('add_reward', 100)]}),
+             'Q': dict(kind='sprite', motion=None, directive=(0, 3),
+                       calls={1: [('add_reward', 5)], 2: [('terminate_episode',)], 3: [('terminate_episode', 0.5), ('add_reward', 1)]})}),
+]
+
+
+def story_tape(rng, T):
+  """Packed actions for a story run: every field of every chapter gets random bits."""
+  import numpy as np
+  out = np.zeros(T, np.int32)
+  for t in range(T):
+    a = rng.randint(9) << 4 | rng.randint(9) << 8
+    if rng.rand() < 0.45:
+      a |= rng.randint(1, 4)
+    if rng.rand() < 0.4:
+      a |= rng.randint(1, 4) << 2
+    if rng.rand() < 0.25:
+      a |= rng.randint(1, 3) << 12
+    out[t] = a
+  return out

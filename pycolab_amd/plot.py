@@ -14,6 +14,32 @@ class Plot(dict):
     super(Plot, self).__init__()
     self._engine = engine
     self._update_group = None
+    # global story state (plot.py:282-330): maintained by storytelling.Story
+    self._prior_chapter = None
+    self._this_chapter = None
+    self._next_chapter = None
+
+  @property
+  def prior_chapter(self):
+    """Key/index of the prior game in a `Story`, or None (plot.py:284-287)."""
+    return self._prior_chapter
+
+  @property
+  def this_chapter(self):
+    """Key/index of the current game in a `Story` (plot.py:289-292)."""
+    return self._this_chapter
+
+  @property
+  def next_chapter(self):
+    """Key/index of the next game in a `Story`, or None (plot.py:294-297)."""
+    return self._next_chapter
+
+  @next_chapter.setter
+  def next_chapter(self, next_chapter):
+    """plot.py:299-324.  Entities' `update()` bodies are device programs here, so
+    this is set from the host (between `play()` calls) when a story's order is
+    not the list order."""
+    self._next_chapter = next_chapter
 
   @property
   def frame(self):

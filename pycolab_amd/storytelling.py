@@ -1,0 +1,386 @@
+"""`Story`: a game made of other games (reference: pycolab/storytelling.py:36-475).
+
+Same constructor, `its_showtime()` / `play()` contract and properties as the
+reference: chapters are argumentless builders returning engines ready for
+`its_showtime()`; a list/tuple plays them in order, a dict follows
+`the_plot.next_chapter`; when a chapter terminates the next one is started at
+once, its first observation and discount replace the old game's last ones and
+the rewards add up (storytelling.py:391-470).  Everything here is host-side
+orchestration of device engines; nothing of it is on the step path.
+
+Batch 1 (the builders' engines have `batch == 1`) is the reference's behaviour
+to the letter: one engine at a time, a fresh one from the builder whenever a
+chapter starts.
+
+Batch > 1 adds what the reference cannot express: every environment is in its
+OWN chapter.  The story keeps one engine per chapter key, each over the whole
+batch; an environment that enters a chapter is restarted there with a masked
+reset (`Engine.reset(mask)`), only the environments that currently are in a
+chapter read that chapter's results, and the per-environment observation is
+assembled (on the device) over the union of the chapters' characters.  Engines
+of chapters an environment is not in keep stepping it with nobody looking --
+simple and correct, at the price of one launch per live chapter per step.
+Because entity `update()` bodies are device programs, `next_chapter` cannot be
+written by entities; set it from the host (`story.the_plot.next_chapter = k` at
+batch 1, `story.set_next_chapter(k_or_array)` at batch > 1) when a dict story's
+order is not known up front.
+"""
+
+import collections
+
+import numpy as np
+
+from pycolab_amd import cropping
+from pycolab_amd import device as dev
+from pycolab_amd import engine
+from pycolab_amd import rendering
+from pycolab_amd import things
+
+
+class Story(object):
+  """A programmable sequence of mutually compatible games."""
+
+  def __init__(self, chapters, first_chapter=None, croppers=None, auto_reset=False):
+    """As the reference's constructor (storytelling.py:105-170).  `auto_reset`
+    (batch > 1 only): an environment whose story is over starts it again from
+    the first chapter at the next `play()`, which counts as that step."""
+    self._auto_reset = bool(auto_reset)
+    self._auto_advance = not isinstance(chapters, collections.abc.Mapping)
+    if self._auto_advance and first_chapter is None:
+      first_chapter = 0
+    self._chapters, self._croppers = _normalise(chapters, first_chapter, croppers)
+    facts = _collect_facts(self._chapters, self._croppers)
+    (self._chars_sprites, self._chars_drapes, self._chars_backdrops, (self._rows, self._cols), self._batch) = facts
+    self._first_chapter = first_chapter
+    self._showtime = False
+    self._game_over = False
+    if self._batch == 1:
+      self._current_game = self._chapters[first_chapter]()
+      self._current_cropper = self._croppers[first_chapter]
+      self._current_cropper.set_engine(self._current_game)
+      self._stamp(self._current_game.the_plot, None, first_chapter)
+    else:
+      self._keys = sorted(self._chapters, key=repr)
+      self._engines = {}
+      self._chapter_of = np.full((self._batch,), self._keys.index(first_chapter), np.int32)  # -1: story over
+      self._next_override = None
+      self._union = sorted(self._chars_sprites | self._chars_drapes | self._chars_backdrops)
+      self._current_game = self._engine_for(first_chapter)
+
+  # ------------------------------------------------------------------ batch 1
+  def _stamp(self, plot, prior, this):
+    plot._prior_chapter, plot._this_chapter = prior, this
+    if self._auto_advance:
+      plot._next_chapter = this + 1 if (this + 1) in self._chapters else None
+
+  def its_showtime(self):
+    """storytelling.py:172-214."""
+    if self._showtime:
+      raise RuntimeError('its_showtime should not be called more than once.')
+    self._showtime = True
+    if self._batch > 1:
+      return self._batched_start()
+    observation, reward, discount = self._current_game.its_showtime()
+    observation = self._current_cropper.crop(observation)
+    if self._current_game.game_over:
+      return self._start_next_game(observation, reward, discount)
+    return observation, reward, discount
+
+  def play(self, actions):
+    """storytelling.py:216-283."""
+    if not self._showtime:
+      raise RuntimeError('play() cannot be called until the Story is placed in '
+                         '"play mode" via the its_showtime() method.')
+    if self._batch > 1:
+      return self._batched_play(actions)
+    if self._game_over:
+      raise RuntimeError('play() was called after the last game managed by the '
+                         'Story has terminated.')
+    observation, reward, discount = self._current_game.play(actions)
+    observation = self._current_cropper.crop(observation)
+    if self._current_game.game_over:
+      return self._start_next_game(observation, reward, discount)
+    return observation, reward, discount
+
+  def _start_next_game(self, observation, reward, discount):
+    """storytelling.py:391-470: chain games until one survives its first frame."""
+    while True:
+      old_plot = self._current_game.the_plot
+      nxt = old_plot.next_chapter
+      if nxt is None:
+        self._game_over = True
+        return observation, reward, discount
+      if nxt not in self._chapters:
+        raise KeyError(
+            'The game that just finished in the Story currently underway '
+            '(identified by the key/index "{}") said that the next game in the '
+            'story should be {}, but no game was supplied to the Story '
+            'constructor under that key or index.'.format(old_plot.this_chapter, repr(nxt)))
+      new_game = self._chapters[nxt]()
+      new_game.the_plot.update(old_plot)  # values left in the Plot travel on (storytelling.py:449-450)
+      self._stamp(new_game.the_plot, old_plot.this_chapter, nxt)
+      self._current_game.close()
+      self._current_game, self._current_cropper = new_game, self._croppers[nxt]
+      self._current_cropper.set_engine(new_game)
+      observation, more, discount = new_game.its_showtime()
+      observation = self._current_cropper.crop(observation)
+      if more is not None:
+        reward = more if reward is None else reward + more
+      if not new_game.game_over:
+        return observation, reward, discount
+
+  # ---------------------------------------------------------------- batch > 1
+  def _engine_for(self, key):
+    if key not in self._engines:
+      game = self._chapters[key]()
+      if game.batch != self._batch:
+        raise ValueError('every chapter of a Story must have the same batch size')
+      game._auto_reset = True  # environments that are not in this chapter run unobserved
+      self._croppers[key].set_engine(game)
+      self._engines[key] = game
+    return self._engines[key]
+
+  def set_next_chapter(self, key):
+    """Batch > 1: where environments go when their current chapter ends -- one
+    key for all, or a sequence of keys per environment (None = the story ends
+    for it).  Overrides the list order until changed again; `None` as the
+    whole argument restores the default."""
+    if key is None or not isinstance(key, (list, tuple, np.ndarray)):
+      self._next_override = None if key is None else [key] * self._batch
+    else:
+      if len(key) != self._batch:
+        raise ValueError('one next chapter per environment')
+      self._next_override = list(key)
+
+  def _next_of(self, env, chapter_index):
+    if self._next_override is not None:
+      return self._next_override[env]
+    if not self._auto_advance:
+      return None
+    nxt = self._keys[chapter_index] + 1
+    return nxt if nxt in self._chapters else None
+
+  def _batched_start(self):
+    B = self._batch
+    torch = dev.torch_module()
+    L = len(self._union)
+    self._planes = torch.zeros((B, 1 + L, self._rows, self._cols), dtype=torch.uint8, device='cuda:%d' % self._current_game._device_id)
+    self._reward = np.zeros((B,), np.int64)
+    self._reward_set = np.zeros((B,), bool)
+    self._discount = np.ones((B,), np.float32)
+    first = self._keys.index(self._first_chapter)
+    game = self._engine_for(self._first_chapter)
+    obs, _, _ = game.its_showtime()
+    self._started = {self._first_chapter}
+    self._absorb(self._first_chapter, obs, np.ones((B,), bool))
+    self._chain(self._finished(self._first_chapter, np.ones((B,), bool)))
+    del first
+    return self._batched_result()
+
+  def _scalars(self, key):
+    sc = self._engines[key]._read_scalars()  # one synchronisation: the story decides on the host
+    return sc['reward'].astype(np.int64), sc['reward_set'].astype(bool), sc['discount'], sc['done'].astype(bool)
+
+  def _absorb(self, key, obs, members):
+    """Takes chapter `key`'s results for the environments in `members`."""
+    torch = dev.torch_module()
+    reward, rset, discount, _ = self._scalars(key)
+    self._reward[members] += np.where(rset[members], reward[members], 0)
+    self._reward_set[members] |= rset[members]
+    self._discount[members] = discount[members]
+    cropped = self._croppers[key].crop(obs)
+    idx = torch.from_numpy(np.flatnonzero(members)).to(self._planes.device)
+    if idx.numel() == 0:
+      return
+    self._planes[idx, 0] = _as_tensor(cropped.board, self._planes)[idx]
+    self._planes[idx, 1:] = 0
+    for ch, layer in cropped.layers.items():
+      self._planes[idx, 1 + self._union.index(ch)] = _as_tensor(layer, self._planes)[idx].to(torch.uint8)
+
+  def _finished(self, key, members):
+    _, _, _, done = self._scalars(key)
+    return {key: members & done}
+
+  def _chain(self, finished):
+    """Moves every environment whose chapter ended to its next one, restarting
+    it there; repeats while first frames terminate (storytelling.py:391-470)."""
+    while any(m.any() for m in finished.values()):
+      starts = collections.defaultdict(lambda: np.zeros((self._batch,), bool))
+      for key, mask in finished.items():
+        ci = self._keys.index(key)
+        for env in np.flatnonzero(mask):
+          nxt = self._next_of(env, ci)
+          if nxt is None:
+            self._chapter_of[env] = -1
+          else:
+            if nxt not in self._chapters:
+              raise KeyError('no chapter {!r} was supplied to the Story constructor'.format(nxt))
+            self._chapter_of[env] = self._keys.index(nxt)
+            starts[nxt][env] = True
+      finished = {}
+      for key, mask in starts.items():
+        game = self._engine_for(key)
+        if key in self._started:
+          obs, _, _ = game.reset(mask)
+        else:  # the engine's first reset covers every environment; only `mask` is looked at
+          obs, _, _ = game.its_showtime()
+          self._started.add(key)
+        self._absorb(key, obs, mask)
+        finished.update(self._finished(key, mask))
+
+  def _batched_play(self, actions):
+    live = self._chapter_of >= 0
+    self._reward[:] = 0
+    self._reward_set[:] = False
+    self._discount[~live] = 0.0  # a finished story reports an empty step, like a finished engine (pcx.h)
+    finished = {}
+    restart = ~live if self._auto_reset else np.zeros_like(live)
+    for ci in np.unique(self._chapter_of[live]):
+      key = self._keys[ci]
+      members = (self._chapter_of == ci) & live
+      obs, _, _ = self._engines[key].play(actions)
+      self._absorb(key, obs, members)
+      finished[key] = self._finished(key, members)[key]
+    if restart.any():  # a new story for these environments: frame 0 of the first chapter is their step
+      first = self._first_chapter  # (after the engines have stepped: a restarted environment must not be stepped too)
+      self._chapter_of[restart] = self._keys.index(first)
+      obs, _, _ = self._engines[first].reset(restart)
+      self._absorb(first, obs, restart)
+      finished[first] = finished.get(first, np.zeros_like(live)) | self._finished(first, restart)[first]
+    self._chain(finished)
+    return self._batched_result()
+
+  def _batched_result(self):
+    layers = {ch: self._planes[:, 1 + k] for k, ch in enumerate(self._union)}
+    obs = rendering.Observation(board=self._planes[:, 0], layers=layers)
+    self._game_over = bool((self._chapter_of < 0).all())
+    return obs, np.where(self._reward_set, self._reward, 0).astype(np.int32), self._discount.copy()
+
+  @property
+  def reward_set(self):
+    """Batch > 1: bool [B], False where the reference's reward would be None."""
+    return self._reward_set.copy()
+
+  @property
+  def this_chapter(self):
+    """The chapter key every environment is in (None where the story is over);
+    batch 1: the current game's key."""
+    if self._batch == 1:
+      return self._current_game.the_plot.this_chapter
+    return [None if c < 0 else self._keys[c] for c in self._chapter_of]
+
+  # ---------------------------------------------------------------- properties
+  @property
+  def the_plot(self):
+    return self._current_game.the_plot
+
+  @property
+  def rows(self):
+    return self._rows
+
+  @property
+  def cols(self):
+    return self._cols
+
+  @property
+  def batch(self):
+    return self._batch
+
+  @property
+  def game_over(self):
+    """bool for batch 1; for batch > 1 a bool array [B] (story over per environment)."""
+    if self._batch == 1 or not self._showtime:
+      return self._game_over
+    return self._chapter_of < 0
+
+  @property
+  def z_order(self):
+    """storytelling.py:308-322: unused characters first, then the current game's order."""
+    current = self._current_game.z_order
+    leftover = sorted((self._chars_sprites - set(current)) | (self._chars_drapes - set(current)))
+    return leftover + current
+
+  @property
+  def backdrop(self):
+    """storytelling.py:326-342."""
+    return things.Backdrop(curtain=self._current_game.backdrop.curtain if self._current_game.backdrop else None,
+                           palette=engine.Palette(self._chars_backdrops))
+
+  @property
+  def current_game(self):
+    return self._current_game
+
+  def close(self):
+    for game in ([self._current_game] if self._batch == 1 else list(self._engines.values())):
+      game.close()
+
+
+def _as_tensor(x, like):
+  torch = dev.torch_module()
+  return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x), device=like.device)
+
+
+def _normalise(chapters, first_chapter, croppers):
+  """Argument checks of storytelling.py:493-553."""
+  if not chapters:
+    raise ValueError('The chapters argument to the Story constructor must not be empty.')
+  if isinstance(chapters, (list, tuple)):
+    chapters = dict(enumerate(chapters))
+    if isinstance(croppers, (list, tuple)):
+      croppers = dict(enumerate(croppers))
+  if not isinstance(chapters, collections.abc.Mapping):
+    raise ValueError('The chapters argument to the Story constructor must be either a dict or a list.')
+  if None in chapters:
+    raise ValueError('None may not be a key in a Story chapters dict.')
+  if first_chapter not in chapters:
+    raise ValueError('The key "{}", specified as a Story\'s first_chapter, does not appear in '
+                     'the chapters supplied to the Story constructor.'.format(first_chapter))
+  if croppers is None:
+    croppers = cropping.ObservationCropper()
+  if isinstance(croppers, cropping.ObservationCropper):
+    croppers = {k: croppers for k in chapters}
+  if not isinstance(croppers, collections.abc.Mapping) or set(chapters) != set(croppers):
+    raise ValueError('Since the croppers argument to the Story constructor was not None '
+                     'or a single ObservationCropper, it must be a collection with the '
+                     'same keys or indices as the chapters argument.')
+  croppers = {k: cropping.ObservationCropper() if c is None else c for k, c in croppers.items()}
+  return dict(chapters), croppers
+
+
+def _collect_facts(chapters, croppers):
+  """Compatibility checks of storytelling.py:556-624 (every builder is called
+  once and its game started, then discarded)."""
+  shapes, batches = set(), set()
+  chars_sprites, chars_drapes, chars_backdrops = set(), set(), set()
+  for key in sorted(chapters, key=repr):
+    game = chapters[key]()
+    cropper = croppers[key]
+    cropper.set_engine(game)
+    kinds = {ch: isinstance(thing, things.Sprite) for ch, thing in game.things.items()}
+    chars_backdrops.update(game.backdrop.palette)
+    observation, _, _ = game.its_showtime()
+    board = cropper.crop(observation).board
+    shapes.add(tuple(board.shape[-2:]))
+    batches.add(game.batch)
+    for ch, is_sprite in kinds.items():
+      (chars_sprites if is_sprite else chars_drapes).add(ch)
+    cropper.set_engine(None) if type(cropper) is cropping.ObservationCropper else cropper._release()
+    game.close()
+  if len(shapes) != 1:
+    raise ValueError(
+        'All pycolab games supplied to the Story constructor should have '
+        'observations that are the same shape, either naturally or with the help '
+        'of observation croppers. The games provided to the constructor have '
+        'diverse shapes: {}.'.format(list(shapes)))
+  if len(batches) != 1:
+    raise ValueError('All games of a Story must have the same batch size; got {}.'.format(sorted(batches)))
+  sd, sb, db = chars_sprites & chars_drapes, chars_sprites & chars_backdrops, chars_drapes & chars_backdrops
+  if sd or sb or db:
+    raise ValueError(
+        'No two pycolab games supplied to the Story constructor should use the '
+        'same character in two different ways: if a character is a Sprite in '
+        'one game, it shouldn\'t be a Drape in another. Across the games '
+        'supplied to this Story, these characters are both a Sprite and a '
+        'Drape: [{}]; these are both a Sprite and in a Backdrop: [{}]; and '
+        'these are both a Drape and in a Backdrop: [{}].'.format(*[''.join(sorted(s)) for s in (sd, sb, db)]))
+  return chars_sprites, chars_drapes, chars_backdrops, shapes.pop(), batches.pop()

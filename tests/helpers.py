@@ -26,6 +26,11 @@ def load_trace(name):
   return tr
 
 
+def load_trace_raw(name):
+  z = np.load(os.path.join(GOLDEN, 'traces', name + '.npz'))
+  return {k: z[k] for k in z.files}
+
+
 def expected_planes(boards, chars):
   """[E, R, C] boards -> [E, 1+L, R, C] planes with occluded layers
   (rendering.py:177-179: layer[c] = board == ord(c))."""

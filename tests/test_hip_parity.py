@@ -113,6 +113,28 @@ def test_hip_table_driven_kernel_waves_per_workgroup(name, waves, monkeypatch):
     assert_same(hip, orc, 'after step %d' % (t0 + 16))
 
 
+@pytest.mark.parametrize('name,knob,value', [('marauders', 'PCX_EM_WAVES', '1'), ('marauders', 'PCX_EM_WAVES', '8'),
+                                             ('warehouse_L0', 'PCX_COOP_BELOW', '0'), ('warehouse_L2', 'PCX_COOP_BELOW', '0'),
+                                             ('warehouse_custom_B', 'PCX_COOP_BELOW', '0')])
+def test_hip_hand_written_kernels_other_launch_shapes(name, knob, value, monkeypatch):
+  """pcx_marauders_step / pcx_warehouse_step pick their launch shape from the
+  batch (test-size batches get four waves per group); force the single-wave
+  shape that BASELINE-size batches run, and the eight-wave one, and compare
+  with the oracle after every step."""
+  monkeypatch.setenv(knob, value)
+  t = helpers.load_template(name)
+  t.param[0] = 0xA11CE
+  B = 200
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  assert_same(hip, orc, 'frame 0')
+  for t0 in range(80):
+    hip.step_hashed(0x5EED, t0, 1); orc.step_hashed(0x5EED, t0, 1)
+    assert_same(hip, orc, 'after step %d' % (t0 + 1))
+  from pycolab_amd import _native as N
+  assert N.lib().pcx_engine_kernel_name(hip.eng._native).decode() in ('pcx_marauders_step', 'pcx_warehouse_step')
+
+
 @pytest.mark.parametrize('fuse', ['0', '1'])
 def test_hip_step_n_fused_and_unfused_match_oracle(fuse, monkeypatch):
   """pcx_engine_step_n / _step_hashed take several steps per launch at small

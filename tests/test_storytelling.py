@@ -1,0 +1,99 @@
+"""storytelling.Story over device engines against a trace of the reference's own
+Story (oracle/gen_story_golden.py: three chapters built from the reference's
+test entities, Plot directives ending them with default and custom discounts).
+Batch 1 replays every environment of the trace with the reference's semantics;
+batch 16 runs all of them at once, every environment in its own chapter."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def chapters(batch):
+  from oracle import directive_scenarios as ds
+  from pycolab_amd import ascii_art
+  from pycolab_amd.prefab_parts import tabled
+  return [lambda spec=spec: ds.build_twin(spec, ascii_art, tabled).configure(batch=batch) for spec in ds.STORY]
+
+
+def test_story_batch1_matches_reference_story():
+  from pycolab_amd import storytelling
+  tr = helpers.load_trace_raw('story_three_chapters')
+  T, E = tr['actions'].shape
+  for e in range(0, E, 3):
+    story = storytelling.Story(chapters(1))
+    obs, r, d = story.its_showtime()
+    row = 0
+
+    def check(obs, r, d, row):
+      where = 'env %d row %d' % (e, row)
+      np.testing.assert_array_equal(obs.board, tr['boards'][row, e], err_msg=where)
+      assert (r is None) == (not tr['reward_set'][row, e]) and (r or 0) == tr['reward'][row, e], where
+      assert d == tr['discount'][row, e] and story.game_over == bool(tr['done'][row, e]), where
+      if not story.game_over:
+        assert story.the_plot.this_chapter == tr['chapter'][row, e], where
+    check(obs, r, d, 0)
+    for t in range(T):
+      row = t + 1
+      if story.game_over:
+        with pytest.raises(RuntimeError):
+          story.play(0)
+        story.close()
+        story = storytelling.Story(chapters(1))
+        check(*story.its_showtime(), row)
+        continue
+      check(*story.play(int(tr['actions'][t, e])), row)
+    story.close()
+
+
+def test_story_batched_every_environment_in_its_own_chapter():
+  from pycolab_amd import storytelling
+  tr = helpers.load_trace_raw('story_three_chapters')
+  T, E = tr['actions'].shape
+  story = storytelling.Story(chapters(E), auto_reset=True)
+  chars = [chr(c) for c in tr['chars']]
+
+  def check(result, row):
+    obs, reward, discount = result
+    board = helpers.to_np(obs.board)
+    np.testing.assert_array_equal(board, tr['boards'][row], err_msg='row %d' % row)
+    np.testing.assert_array_equal(story.reward_set, tr['reward_set'][row].astype(bool), err_msg='row %d' % row)
+    np.testing.assert_array_equal(reward, tr['reward'][row], err_msg='row %d' % row)
+    np.testing.assert_array_equal(discount, tr['discount'][row], err_msg='row %d' % row)
+    np.testing.assert_array_equal(np.asarray(story.game_over), tr['done'][row].astype(bool), err_msg='row %d' % row)
+    want_ch = [None if c < 0 else int(c) for c in tr['chapter'][row]]
+    assert story.this_chapter == want_ch, 'row %d' % row
+    assert sorted(obs.layers) == sorted(chars)
+    for ch in chars:   # layers over the union of the chapters' characters
+      np.testing.assert_array_equal(helpers.to_np(obs.layers[ch]), (board == ord(ch)).astype(np.uint8))
+  check(story.its_showtime(), 0)
+  for t in range(T):
+    check(story.play(tr['actions'][t]), t + 1)
+  story.close()
+
+
+def test_story_constructor_checks():
+  """storytelling.py:493-553, 556-624."""
+  from pycolab_amd import ascii_art, storytelling
+  from pycolab_amd.prefab_parts import tabled
+  with pytest.raises(ValueError):
+    storytelling.Story([])
+  with pytest.raises(ValueError):
+    storytelling.Story(chapters(1), first_chapter=7)
+  big = lambda: ascii_art.ascii_art_to_game(['....', '.a..'], '.', sprites=dict(a=tabled.StaticSprite))
+  with pytest.raises(ValueError):   # observations of different shapes
+    storytelling.Story(chapters(1) + [big])
+  clash = lambda: ascii_art.ascii_art_to_game(['.........', '...Q.....', '.........'], '.', drapes=dict(Q=tabled.StaticDrape))
+  with pytest.raises(ValueError):   # 'Q' is a Sprite in one game and a Drape in another
+    storytelling.Story(chapters(1) + [clash])
+  story = storytelling.Story({'x': chapters(1)[0], 'y': chapters(1)[2]}, first_chapter='x')
+  story.its_showtime()
+  story.the_plot.next_chapter = 'y'      # entities are device programs: the host names the next chapter
+  obs, r, d = story.play(2)              # Q terminates chapter 'x'
+  assert story.the_plot.this_chapter == 'y' and story.the_plot.prior_chapter == 'x' and not story.game_over
+  assert bytes(obs.board[0]) == b'....Q....' and d == 1.0
+  story.the_plot.next_chapter = 'nowhere'
+  with pytest.raises(KeyError):
+    story.play(2)
