@@ -24,7 +24,7 @@ int set_error(int code, const char* fmt, ...);
   } while (0)
 
 // Error bits reported per environment (the reference would have raised).
-enum : uint8_t { ERR_INDEX = 1, ERR_SCROLL = 2, ERR_AFTER_OVER = 4 };
+enum : uint8_t { ERR_INDEX = 1, ERR_SCROLL = 2 };  // IndexError (numpy index rules, np.random.choice([])), scrolling.Error
 
 struct StepArgs {
   const int32_t* actions = nullptr;  // device int32[batch] or null when hashed

@@ -466,6 +466,8 @@ class Engine(object):
 
   def close(self):
     if self._native is not None:
+      for cropper in self._croppers:  # their native halves point into this engine: they go first
+        cropper._release()
       N.lib().pcx_engine_destroy(self._native)
       self._native = None
 

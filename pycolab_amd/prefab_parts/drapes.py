@@ -2,7 +2,8 @@
 
 API surface of the reference's `prefab_parts/drapes.py:30-695`.  Constructors
 run on the host while a game is built; `_maybe_move` and the scrolling
-protocol run on the device (`csrc/pcx_device.h: scrolly_maybe_move`).
+protocol run on the device (`maybe_move` in `csrc/pcx_scrolly_maze.hip` and
+`csrc/pcx_generic.hip`).
 """
 
 import numpy as np

@@ -4,7 +4,8 @@ API surface of the reference's `prefab_parts/sprites.py:27-575`.  The
 constructor and `_teleport` run on the host (game files call them while the
 game is being built); the motion helpers `_north` ... `_stay` are what a
 subclass' `update()` would call, and those run on the device
-(`csrc/pcx_device.h: mw_move / mw_check_motion / mw_teleport`).
+(`mw_move` / `check_motion` / `teleport` in `csrc/pcx_scrolly_maze.hip`,
+`csrc/pcx_generic.hip`, `csrc/pcx_warehouse.hip`, `csrc/pcx_marauders.hip`).
 """
 
 from pycolab_amd import things

@@ -2,7 +2,9 @@
 
 On the device the whole protocol collapses to a few per-environment scalars
 (current order + its frame stamp, a registered bit, a 9-bit permit mask + its
-frame stamp per egocentric sprite); see csrc/pcx_device.h.  The host only needs
+frame stamp per egocentric sprite, per scrolling group); see `mw_move` /
+`maybe_move` / `is_possible` in csrc/pcx_scrolly_maze.hip and
+csrc/pcx_generic.hip.  The host only needs
 the motion names and the exception type.
 """
 
