@@ -87,6 +87,12 @@ struct Consts {
   int32_t FW;  // words of one flat curtain bit-vector (cells bits + 1 spill word)
   int32_t lds_walls, lds_backdrop, lds_rowstart, lds_coincol, lds_flat, lds_sdesc, lds_cmask,
       lds_skip, lds_bdmask, lds_buf_words, lds_flatraw, lds_sdescraw, lds_words;
+  // CODES instance (at most eight characters): every cell's painter as the index
+  // of its character among the sorted characters ("owner code", one byte per
+  // cell), from which v_perm_b32 makes the board dword and every layer dword
+  int32_t lds_bdcode, lds_codes, lds_cmask_c, lds_skip_c, lds_words_codes;  // its own, compact LDS layout
+  uint32_t chars_lo, chars_hi;  // characters 0..3 / 4..7 as bytes
+  int32_t sprite_by_z[MAX_NS];  // sprites back to front
 };
 
 struct Ptrs {
@@ -348,7 +354,10 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 // (StepArgs::n_steps): wave 0 steps the group for step i + 1 while waves 1-3
 // render step i out of the other descriptor buffer; one barrier per step.
 // EPI: the render loop also writes the float32 feature-array epilogue (pcx_stream.h).
-template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false, bool EPI = false>
+// CODES: the logic phase paints an owner-code byte per cell (LDS), the render loop
+// is one LDS read and one v_perm_b32 per plane (static shape, <= 8 characters).
+template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false, bool EPI = false,
+          bool CODES = false>
 __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out, const stream::EpilogueArgs epi) {
   // A workgroup is two wavefronts with different jobs, looping over groups of
@@ -379,19 +388,28 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   l.backdrop4 = lb;
   l.rowstart = reinterpret_cast<const uint16_t*>(lr);
   l.coincol = reinterpret_cast<const uint8_t*>(lc);
-  l.cmask = lds_raw + k.lds_cmask;
+  l.cmask = lds_raw + (CODES ? k.lds_cmask_c : k.lds_cmask);
   uint32_t* lm = lds_raw + k.lds_bdmask;
   l.bdmask = lm;
 
   // ---- stage the shared template constants into LDS (from L2) -------------
   for (int i = threadIdx.x; i < k.PR * k.WPR; i += blockDim.x) lw[i] = P.walls_bits[i];
   for (int i = threadIdx.x; i < QW; i += blockDim.x) lb[i] = P.backdrop4[i];
-  for (int i = threadIdx.x; i < k.n_bchars * QW; i += blockDim.x) lm[i] = P.backdrop4[QW + i];
+  if constexpr (!CODES)  // (the CODES instance has no use for the backdrop-character masks)
+    for (int i = threadIdx.x; i < k.n_bchars * QW; i += blockDim.x) lm[i] = P.backdrop4[QW + i];
   {
     const uint32_t* rs = reinterpret_cast<const uint32_t*>(P.coin_rowstart);
     const uint32_t* cc = reinterpret_cast<const uint32_t*>(P.coin_col);
     for (int i = threadIdx.x; i < (k.PR + 2) / 2; i += blockDim.x) lr[i] = rs[i];
     for (int i = threadIdx.x; i < (k.n_coins + 3) / 4; i += blockDim.x) lc[i] = cc[i];
+  }
+  constexpr int CODE_PITCH = SR ? ((SR * SC / 4) | 1) + 2 : 1;  // dwords per environment, odd: logic (same q, 64
+                                                               // environments) and render (same environment,
+                                                               // consecutive q) both spread over the banks
+  uint32_t* const codes = lds_raw + k.lds_codes;
+  if constexpr (CODES) {
+    uint32_t* lbc = lds_raw + k.lds_bdcode;
+    for (int i = threadIdx.x; i < QW; i += blockDim.x) lbc[i] = P.backdrop4[QW * (1 + k.n_bchars) + i];
   }
   __syncthreads();  // LDS constants visible
 
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     const int buf = single ? 0 : (wave == 0) ? ((round + 1) & 1) : (round & 1);
     l.flat = lds_raw + k.lds_flat + buf * k.lds_buf_words;
     l.sdesc = reinterpret_cast<uint2*>(lds_raw + k.lds_sdesc + buf * k.lds_buf_words);
-    l.skip = lds_raw + k.lds_skip + buf * k.lds_buf_words;
+    l.skip = CODES ? lds_raw + k.lds_skip_c : lds_raw + k.lds_skip + buf * k.lds_buf_words;
   }
   if (wave == 0) {
   if (have_logic) {
@@ -650,7 +668,26 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
           }
         }
       }
-      if constexpr (SR != 0) {
+      if constexpr (CODES) {
+        // owner codes of the backdrop, then the two curtains painted over them
+        // (one in front of the other where both are set): four cells per dword
+        const uint32_t* const bdcode = lds_raw + k.lds_bdcode;
+        const uint32_t wcode4 = (uint32_t)k.lay_drape[0] * 0x01010101u, ccode4 = (uint32_t)k.lay_drape[1] * 0x01010101u;
+#pragma unroll
+        for (int q = 0; q < SR * SC / 4; ++q) {
+          const int i = (4 * q) >> 5, sh = (4 * q) & 31;
+          const uint32_t ww = cash_in_front ? accw[i] & ~accc[i] : accw[i];
+          const uint32_t cc = cash_in_front ? accc[i] : accc[i] & ~accw[i];
+          uint32_t mw = (((ww >> sh) & 0xFu) * 0x00204081u) & 0x01010101u, mc = (((cc >> sh) & 0xFu) * 0x00204081u) & 0x01010101u;
+          uint32_t hw = mw << 8, hc = mc << 8;
+          asm("" : "+v"(hw), "+v"(hc));  // keep (x << 8) - x from becoming a quarter-rate multiply
+          mw = hw - mw; mc = hc - mc;
+          uint32_t code = bdcode[q];
+          code = (code & ~mw) | (wcode4 & mw);
+          code = (code & ~mc) | (ccode4 & mc);
+          codes[lane * CODE_PITCH + q] = code;
+        }
+      } else if constexpr (SR != 0) {
 #pragma unroll
         for (int i = 0; i < ACC; ++i) {
           const uint32_t ww = cash_in_front ? accw[i] & ~accc[i] : accw[i];
@@ -674,7 +711,24 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     // that is painted takes its cell away from both curtains.  After this,
     // every board cell belongs to exactly one of {a sprite, a curtain, the
     // backdrop} and phase B needs no z-order.
-    {
+    if constexpr (CODES) {
+      // the sprites, back to front (engine.py:751-757): a sprite takes its cell
+      // unless a curtain in front of it holds it; one byte each
+      uint8_t* const mine = reinterpret_cast<uint8_t*>(codes + lane * CODE_PITCH);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          if (k.sprite_by_z[i] != s) continue;
+          const int cell = paint_cell(k, w[s]);
+          if (cell < 0) continue;
+          const uint32_t top = mine[cell], ab = k.above[s];
+          const bool covered = (((ab >> NS) & 1) && top == (uint32_t)k.lay_drape[0]) ||
+                               (((ab >> (NS + 1)) & 1) && top == (uint32_t)k.lay_drape[1]);
+          if (!covered) mine[cell] = (uint8_t)k.lay_sprite[s];
+        }
+      }
+    } else {
       int cellv[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) cellv[s] = paint_cell(k, w[s]);
@@ -866,6 +920,25 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(epi.out) + (size_t)env0 * epi.env_stride);
   const uint32_t f_skew = epi.env_stride - 16u * (uint32_t)QW;  // foff = 16 f + e * f_skew
   uint32_t foff = 16u * lane;
+  // CODES: planes in their natural order (plane 1 + k = layer of character k)
+  constexpr int NPK = CODES ? 1 + SL : 1;
+  uint8_t* pbk[NPK];
+  int32_t lslot[NPK];  // epilogue slot of layer k
+  if constexpr (CODES) {
+#pragma unroll
+    for (int kk = 0; kk < NPK; ++kk) pbk[kk] = uniform_ptr(pb_board + (uint32_t)kk * (uint32_t)cells);
+#pragma unroll
+    for (int kk = 0; kk < SL; ++kk) {
+      int32_t slot = -1;
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) if (k.lay_sprite[s2] == kk) slot = epi.sprite_slot[s2];
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) if (k.lay_drape[dd] == kk) slot = epi.drape_slot[dd];
+#pragma unroll
+      for (int b2 = 0; b2 < NBS; ++b2) if (k.lay_bchar[b2] == kk) slot = epi.bchar_slot[b2];
+      lslot[kk] = EPI ? slot : -1;
+    }
+  }
 #pragma unroll 1
   for (int it = COOP ? wave : TFUSE ? wave - 1 : 0; it < QW;
        it += COOP ? (int)(blockDim.x >> 6) : TFUSE ? (int)(blockDim.x >> 6) - 1 : 1) {
@@ -877,17 +950,42 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       q = wrap ? q - QW : q;
       e = wrap ? e + 1 : e;
       voff = wrap ? voff + e_skew : voff;
-      eF = wrap ? eF + FWP : eF;
+      eF = wrap ? eF + (CODES ? CODE_PITCH : FWP) : eF;
       if constexpr (EPI) { foff_now = foff; foff += 16u * WAVE; foff = wrap ? foff + f_skew : foff; }
     } else {
       const uint32_t f = (uint32_t)it * WAVE + lane;
       e_now = (f * magic_q) >> 20;
       q_now = f - e_now * QW;
       voff_now = 4u * f + e_now * e_skew;
-      eF_now = e_now * FWP;
+      eF_now = e_now * (CODES ? CODE_PITCH : FWP);
       if constexpr (EPI) foff_now = 16u * f + e_now * f_skew;
     }
     if (any_skip && l.skip[e_now]) continue;
+    if constexpr (CODES) {
+      // one LDS read, then one v_perm_b32 per plane: the board dword picks each
+      // cell's character out of the eight, layer k picks byte k of a one-hot table
+      const uint32_t code = codes[eF_now + q_now];
+      auto put_plane = [&](uint8_t* base, uint32_t v, int32_t slot) {
+        if (!EPI || slot == -2 || layers_on)
+          asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(base));
+        if constexpr (EPI) {
+          if (slot >= 0) {
+            stream::f32x4 f;
+            f.x = (float)(v & 0xFFu); f.y = (float)((v >> 8) & 0xFFu); f.z = (float)((v >> 16) & 0xFFu); f.w = (float)(v >> 24);
+            const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
+            // s_nop: a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data
+        // registers (ISA data hazard; the compiler cannot see into inline asm to insert the wait state itself)
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(fo), "v"(f), "s"(fbase));
+          }
+        }
+      };
+      put_plane(pbk[0], __builtin_amdgcn_perm(k.chars_hi, k.chars_lo, code), -2);
+#pragma unroll
+      for (int kk = 0; kk < SL; ++kk)
+        put_plane(pbk[1 + kk], __builtin_amdgcn_perm(kk >= 4 ? 1u << (8 * (kk & 3)) : 0u, kk < 4 ? 1u << (8 * (kk & 3)) : 0u, code),
+                  lslot[kk]);
+      continue;
+    }
     // scalar base (pinned above) + 32-bit lane offset: one `global_store_dword
     // voffset, data, sbase` per plane, no per-store address arithmetic
     compose(e_now, q_now, eF_now, [&](int plane, uint32_t v) {
@@ -904,7 +1002,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
           stream::f32x4 f;
           f.x = (float)(v & 0xFFu); f.y = (float)((v >> 8) & 0xFFu); f.z = (float)((v >> 16) & 0xFFu); f.w = (float)(v >> 24);
           const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
-          asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(fo), "v"(f), "s"(fbase));
+          // s_nop: a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data
+        // registers (ISA data hazard; the compiler cannot see into inline asm to insert the wait state itself)
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(fo), "v"(f), "s"(fbase));
         }
       }
     });
@@ -1136,11 +1236,22 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   cc.resize((cc.size() + 7) / 4 * 4, 0);
   std::vector<uint16_t> rs = h_rowstart_;
   rs.resize((rs.size() + 3) / 2 * 2, 0);
-  std::vector<uint32_t> bd4((size_t)k.QW * (1 + k.n_bchars));
+  std::vector<uint32_t> bd4((size_t)k.QW * (2 + k.n_bchars));
   memcpy(bd4.data(), t.backdrop, k.cells);
   for (int b = 0; b < k.n_bchars; ++b) {
     uint8_t* dst = reinterpret_cast<uint8_t*>(bd4.data() + (size_t)k.QW * (1 + b));
     for (int i = 0; i < k.cells; ++i) dst[i] = t.backdrop[i] == k.bchar[b];
+  }
+  {  // owner codes of the backdrop (CODES instance): index of each cell's character among the sorted characters
+    uint8_t* dst = reinterpret_cast<uint8_t*>(bd4.data() + (size_t)k.QW * (1 + k.n_bchars));
+    for (int i = 0; i < k.cells; ++i)
+      for (int c = 0; c < k.L; ++c)
+        if ((int)k.chars[c] == t.backdrop[i]) dst[i] = (uint8_t)c;
+    k.chars_lo = k.chars_hi = 0;
+    for (int c = 0; c < k.L && c < 8; ++c) (c < 4 ? k.chars_lo : k.chars_hi) |= (k.chars[c] & 0xFFu) << (8 * (c & 3));
+    int n = 0;
+    for (int z = 0; z < t.n_things; ++z)
+      if (k.z_kind[z] == 0) k.sprite_by_z[n++] = k.z_idx[z];
   }
 
   // initial state words (what the constructors left: ascii_art.py:247-277)
@@ -1191,6 +1302,14 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   k.lds_sdescraw = off; if (unoccluded_) off += 2 * k.NS * WAVE;
   k.lds_words = off;
   if (off * 4 > 160 * 1024) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: template needs %d bytes of LDS", off * 4);
+  {  // CODES instance: constants, coin masks, the backdrop's owner codes, one code table, the skip flags
+    int o = k.lds_coincol + (int)cc.size() / 4;
+    k.lds_bdcode = o; o += k.QW;
+    k.lds_codes = o; o += WAVE * ((k.QW | 1) + 2);
+    k.lds_cmask_c = o; o += (k.CW ? k.CW : 1) * WAVE;
+    k.lds_skip_c = o; o += WAVE;
+    k.lds_words_codes = o;
+  }
 
   {
     int dev = 0;
@@ -1251,6 +1370,8 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
   // Small batches leave most CUs with one wave or none: let four waves share
   // each group's render loop (COOP instance), one group per workgroup.
+  bool use_codes = true;  // PCX_SM_CODES=0: the mask-composing render loop of round 1 (A/B)
+  if (const char* e = getenv("PCX_SM_CODES")) use_codes = atoi(e) != 0;
   int coop_below = 5;  // groups per CU (measured crossover: profiles/r01_tuning.md)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (a.n_steps > 1) {
@@ -1268,6 +1389,17 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3((unsigned)groups),
                          dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_);
+  } else if (shipped_shape && waves_per_wg == 1 && use_codes) {
+    // owner-code render path: its own, smaller LDS layout, padded to the same workgroups-per-CU target
+    size_t lds_c = (size_t)k_.lds_words_codes * 4;
+    if (waves_per_cu > 0) {
+      size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
+      if (want > lds_c) lds_c = want;
+    }
+    if (epi_.out)
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, true>), grid, block, lds_c, s, k_, P, a, out, epi_);
+    else
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true>), grid, block, lds_c, s, k_, P, a, out, epi_);
   } else if (shipped_shape) {
     if (epi_.out && waves_per_wg == 1)
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true>), grid, block, lds, s, k_, P, a, out, epi_);

@@ -159,7 +159,9 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
         f32x4 f;
         f.x = (float)(m01 & 0xFFu); f.y = (float)((m01 >> 8) & 0xFFu); f.z = (float)((m01 >> 16) & 0xFFu); f.w = (float)(m01 >> 24);
         const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
-        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(fo), "v"(f), "s"(fbase));
+        // s_nop: a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data
+        // registers (ISA data hazard; the compiler cannot see into inline asm to insert the wait state itself)
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(fo), "v"(f), "s"(fbase));
       }
     };
     // every LDS read of the iteration is issued up front
