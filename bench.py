@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 FIXTURES = {'scrolly_maze': 'scrolly_maze_L%d', 'warehouse': 'warehouse_L%d', 'marauders': 'marauders',
-            'hello_world': 'hello_world'}
+            'hello_world': 'hello_world', 'better_scrolly_maze': 'better_scrolly_maze_L%d'}
 
 
 def cpu_worker(args):

@@ -1,0 +1,461 @@
+// pcx_better_scrolly.hip -- hand-written fused step kernel for
+// better_scrolly_maze (reference: pycolab/examples/better_scrolly_maze.py:250-320
+// driven by engine.py:583-847 and prefab_parts/sprites.py MazeWalker): the game
+// that pairs MazeWalkers with real ObservationCroppers on boards of up to 45x89
+// cells.  gfx950 only.
+//
+// One launch = one Engine.play() of every environment of the batch; same shape as
+// the other hand-written kernels: 64 consecutive environments per
+// workgroup, logic phase lane == environment, render phase = pcx_stream.h.
+//
+// ONE update group (`a b c P @`), so every entity sees the repaint the step
+// started with.  The maze walls are the (static) backdrop; the only bulky state
+// is CashDrape's whole-board curtain, kept as a flat cell-bit vector: the same
+// words in HBM (SoA over the batch), loaded straight into the LDS rows the
+// streaming phase reads, tested and cleared in place (a pickup rewrites one
+// word in HBM; the number of coins left rides in the flags word, so "no coins
+// left" needs no reduction).  A MazeWalker probe with impassable == '#' is
+// "wall cell with nothing painted over it" from the register snapshot of the
+// sprites' cells, the coin bit and a static wall bit vector.
+// Other casts, z-orders, impassable sets or shapes: the table-driven kernel.
+
+#include "pcx_internal.h"
+#include "pcx_stream.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace pcx {
+namespace bs {
+
+using stream::WAVE;
+constexpr int NS = 4;  // patrollers a, b, c and the player P (template order)
+constexpr int IP = 3;
+constexpr int ND = 1;  // the coins '@'
+constexpr int NB = 2;  // ' ' and '#'
+
+// State words (uint32 [NW][batch_padded]): frame, flags, positions, coin curtain.
+enum : int { W_FRAME = 0, W_FLAGS, W_POS, W_COINS = W_POS + NS };
+constexpr uint32_t F_OVER = 1u, F_ERR_SHIFT = 1;
+constexpr int F_SF_SHIFT = 4;     // per sprite: visible, prior_visible, moving_east (3 bits)
+constexpr int F_LEFT_SHIFT = 16;  // coins left (CashDrape.curtain.any() without a reduction)
+
+struct Consts {
+  int32_t n_actions;
+  uint32_t confined;
+  uint32_t above[NS];
+  uint32_t init[W_COINS];
+  uint32_t sprite_off[NS], sprite_ch4[NS], drape_off, drape_ch4, bchar_off[NB];
+};
+
+struct Ptrs {
+  const uint32_t* tables;        // staged into LDS: backdrop4 [QW], bdmask [NB][QW], wall bits [FW]
+  const uint32_t* init_curtain;  // [FW]
+  uint32_t* state;               // [NW][bpad]
+  int32_t* track;                // [NS][bpad]
+  uint32_t* curtains;            // [1][FW][bpad] (export_curtains)
+  int64_t batch, bpad;
+};
+
+__device__ __forceinline__ uint32_t action_hash(uint64_t seed, uint64_t env, uint64_t t) {
+  uint64_t x = seed ^ (env * 0x9E3779B97F4A7C15ull) ^ (t * 0xBF58476D1CE4E5B9ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+__device__ __forceinline__ uint32_t pack_pos(int r, int c) { return ((uint32_t)r & 0xFFFFu) | ((uint32_t)c << 16); }
+__device__ __forceinline__ int pos_r(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
+__device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16); }
+
+template <int R, int C, int NWAVES>
+__global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Consts k, const Ptrs P, const StepArgs a,
+                                                                         const pcx_buffers out, const stream::EpilogueArgs epi) {
+  extern __shared__ uint32_t lds[];
+  constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32, FWP = FW | 1;
+  constexpr int L = NS + ND + NB, NW = W_COINS + FW;
+  constexpr int O_BD = 0, O_BDM = O_BD + QW, O_WALL = O_BDM + NB * QW, O_TAB_END = O_WALL + FW;
+  constexpr int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
+  const uint32_t* const wall = lds + O_WALL;
+  uint32_t* const flat = lds + O_FLAT;      // [64][FWP]: the coin curtain of every environment of the group
+  uint32_t* const mine = flat + lane * FWP;
+  uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC);
+  uint32_t* const skipv = lds + O_SKIP;
+  __syncthreads();
+
+  const int64_t env0 = (int64_t)blockIdx.x * WAVE;
+  if (wave == 0) {
+    // ---- logic phase: lane == environment -------------------------------------
+    const int64_t env = env0 + lane, bp = P.bpad;
+    const bool live = env < P.batch;
+    uint32_t* const st = P.state + env;
+    uint32_t flags = 0, ld_frame = 0, ld_pos[NS] = {};
+    int ld_action = PCX_ACTION_NONE;
+    bool skip = !live, do_reset = false;
+    int action = PCX_ACTION_NONE;
+    if (live) {
+      flags = st[W_FLAGS * bp];
+      if (a.mode != 1) {
+        ld_frame = st[W_FRAME * bp];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ld_pos[s] = st[(W_POS + s) * bp];
+        if (!a.hashed) ld_action = a.actions[env];
+      }
+      if (a.mode == 1) {
+        do_reset = a.reset_mask ? a.reset_mask[env] != 0 : true;
+        skip = !do_reset;
+      } else if (flags & F_OVER) {
+        do_reset = a.auto_reset != 0;
+        skip = !do_reset;
+        if (skip) {  // a finished environment left alone reports an empty step (pcx.h)
+          out.reward[env] = 0; out.reward_set[env] = 0; out.discount[env] = 0.0f;
+        }
+      } else {
+        action = a.hashed ? (int)(action_hash(a.seed, (uint64_t)(a.env_offset + env), (uint64_t)a.t) % (uint32_t)k.n_actions)
+                          : ld_action;
+        if (action < 0) action = PCX_ACTION_NONE;
+      }
+    }
+    if (!skip) {
+      // the coin curtain goes from HBM (or the template) straight into this lane's LDS row,
+      // sixteen words in flight at a time
+      if (do_reset) {
+        for (int i = 0; i < FW; ++i) mine[i] = P.init_curtain[i];
+      } else {
+        for (int i0 = 0; i0 < FW; i0 += 16) {
+          uint32_t v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = i0 + j < FW ? st[(W_COINS + i0 + j) * bp] : 0u;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) if (i0 + j < FW) mine[i0 + j] = v[j];
+        }
+      }
+      int frame, left;
+      uint32_t sflags, err;
+      int vr[NS], vc[NS], vis[NS], prior[NS], east[NS];
+      if (do_reset) {  // engine.py:520-581 its_showtime: fresh template state, frame 0 = play(None)
+        frame = (int)k.init[W_FRAME];
+        sflags = k.init[W_FLAGS] >> F_SF_SHIFT;
+        left = (int)(k.init[W_FLAGS] >> F_LEFT_SHIFT);
+        err = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { vr[s] = pos_r(k.init[W_POS + s]); vc[s] = pos_c(k.init[W_POS + s]); }
+        action = PCX_ACTION_NONE;
+      } else {
+        frame = (int)ld_frame;
+        sflags = flags >> F_SF_SHIFT;
+        left = (int)(flags >> F_LEFT_SHIFT);
+        err = (flags >> F_ERR_SHIFT) & 7u;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { vr[s] = pos_r(ld_pos[s]); vc[s] = pos_c(ld_pos[s]); }
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        vis[s] = (sflags >> (3 * s)) & 1; prior[s] = (sflags >> (3 * s + 1)) & 1; east[s] = (sflags >> (3 * s + 2)) & 1;
+      }
+      int reward = 0, reward_set = 0, over = 0;
+      float discount = 1.0f;
+      frame += 1;  // engine.py:698-735
+
+      auto on_board = [](int r, int c) { return (unsigned)r < (unsigned)R && (unsigned)c < (unsigned)C; };
+      auto true_cell = [&](int r, int c) { return on_board(r, c) ? r * C + c : 0; };  // Sprite.position
+      auto teleport = [&](int s, int nr, int nc) {  // sprites.py:315-352
+        const bool old_on = on_board(vr[s], vc[s]), new_on = on_board(nr, nc);
+        if (old_on && !new_on) { prior[s] = vis[s]; vis[s] = 0; }
+        if (!old_on && new_on) vis[s] = prior[s];
+        vr[s] = nr; vc[s] = nc;
+      };
+      // what the last repaint showed at a cell: layers['#'] (rendering.py:177-179) is a wall
+      // cell of the backdrop with no sprite and no coin painted over it
+      int cell0[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) cell0[s] = vis[s] ? true_cell(vr[s], vc[s]) : -1;
+      auto shows_wall = [&](int cell) {
+        bool painted = (mine[cell >> 5] >> (cell & 31)) & 1;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) painted |= cell0[j] == cell;
+        return !painted && ((wall[cell >> 5] >> (cell & 31)) & 1);
+      };
+      // sprites.py:356-389 _move one column / row with impassable == '#'
+      auto move = [&](int s, int dr, int dc) {
+        const int nr = vr[s] + dr, nc = vc[s] + dc;
+        if (!on_board(nr, nc)) { if (!((k.confined >> s) & 1)) teleport(s, nr, nc); return; }
+        if (!shows_wall(nr * C + nc)) teleport(s, nr, nc);
+      };
+
+      // ---- PatrollerSprite.update (better_scrolly_maze.py:284-301), a, b, c in turn
+      const int p_cell_start = true_cell(vr[IP], vc[IP]);  // things['P'].position: the player moves after them
+#pragma unroll
+      for (int s = 0; s < IP; ++s) {
+        if (frame & 1) continue;  // _stay on odd frames
+        const bool on = on_board(vr[s], vc[s]);
+        const int row = on ? vr[s] : 0, col = on ? vc[s] : 0;
+        // layers['#'][row, col - 1] / [row, col + 1] with numpy's index rules
+        const int cw = col - 1 < 0 ? col - 1 + C : col - 1;
+        if (shows_wall(row * C + cw)) east[s] = 1;
+        if (col + 1 >= C) err |= ERR_INDEX;
+        else if (shows_wall(row * C + col + 1)) east[s] = 0;
+        move(s, 0, east[s] ? 1 : -1);
+        if (true_cell(vr[s], vc[s]) == p_cell_start) { over = 1; discount = 0.0f; }
+      }
+      // ---- PlayerSprite.update (:258-272) --------------------------------------------
+      if ((unsigned)action <= 3u) move(IP, action == 0 ? -1 : action == 1 ? 1 : 0, action == 2 ? -1 : action == 3 ? 1 : 0);
+      if (action == 5) { over = 1; discount = 0.0f; }
+      // ---- CashDrape.update (:311-320) -------------------------------------------------
+      int changed_word = -1;
+      {
+        const int pc = true_cell(vr[IP], vc[IP]);
+        const uint32_t w = mine[pc >> 5], bit = 1u << (pc & 31);
+        if (w & bit) {
+          reward += 100; reward_set = 1;
+          mine[pc >> 5] = w & ~bit;
+          changed_word = pc >> 5;
+          if (--left == 0) { over = 1; discount = 0.0f; }
+        }
+      }
+
+      // ---- _apply_and_clear_plot (engine.py:761-847) + state write-back -----------------
+      st[W_FRAME * bp] = (uint32_t)frame;
+      uint32_t sf = 0;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        st[(W_POS + s) * bp] = pack_pos(vr[s], vc[s]);
+        sf |= ((uint32_t)vis[s] | ((uint32_t)prior[s] << 1) | ((uint32_t)east[s] << 2)) << (3 * s);
+        const bool on = on_board(vr[s], vc[s]);
+        P.track[(size_t)s * bp + env] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
+      }
+      st[W_FLAGS * bp] = (over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT) | (sf << F_SF_SHIFT) | ((uint32_t)left << F_LEFT_SHIFT);
+      if (do_reset) {
+        for (int i = 0; i < FW; ++i) st[(W_COINS + i) * bp] = mine[i];
+      } else if (changed_word >= 0) {
+        st[(W_COINS + changed_word) * bp] = mine[changed_word];  // a pickup rewrites one word
+      }
+      if (a.export_curtains)
+        for (int i = 0; i < FW; ++i) P.curtains[(size_t)i * bp + env] = mine[i];
+      out.reward[env] = reward;
+      out.reward_set[env] = (uint8_t)reward_set;
+      out.discount[env] = discount;
+      out.done[env] = (uint8_t)over;
+      out.frame[env] = frame;
+      out.error[env] = (uint8_t)err;
+
+      // ---- render descriptors ---------------------------------------------------------------
+      int cellv[NS];
+      uint32_t above[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { cellv[s] = vis[s] ? true_cell(vr[s], vc[s]) : -1; above[s] = k.above[s]; }
+      stream::resolve_sprites<NS, ND>(cellv, above, flat, FWP, lane, sdesc);
+      (void)NW;
+    }
+    skipv[lane] = skip;
+  }
+  __syncthreads();
+  if (a.debug & 2) return;
+
+  stream::PlaneMap<NS, ND, NB> pm;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { pm.sprite_off[s] = k.sprite_off[s]; pm.sprite_ch4[s] = k.sprite_ch4[s]; }
+  pm.drape_off[0] = k.drape_off; pm.drape_ch4[0] = k.drape_ch4;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
+  constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
+  stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                      flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+}
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+
+#define PCX_BS_SHAPES(X) X(45, 89) X(29, 30) X(29, 89)
+
+class BetterScrollyBackend : public Backend {
+ public:
+  int init(const pcx_template& t, int64_t batch) override;
+  int launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) override;
+  int read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) override;
+  int64_t bytes_per_step() const override {
+    // read: action 4 + state 4 NW (the coin curtain is read every step); write: the scalar state words
+    // (a pickup adds one curtain word) + planes (1 + L) cells + results 15
+    return 4 + 4 * (int64_t)NW_ + 4 * (int64_t)W_COINS + (int64_t)(1 + L_) * lay_.cells + 15;
+  }
+  const char* kernel_name() const override { return "pcx_better_scrolly_step"; }
+  const int32_t* sprite_track() const override { return track_.ptr; }
+  const uint32_t* curtain_bits() const override { return curtains_.ptr; }
+  int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)lay_.FW * bpad_); }
+  int curtain_words() const override { return lay_.FW; }
+  int64_t batch_pad() const override { return bpad_; }
+  int plane_pitch() const override { return lay_.pitch; }
+
+ private:
+  Consts k_{};
+  stream::EpilogueArgs epi_{};
+  stream::Layout lay_;
+  int R_ = 0, C_ = 0, L_ = 0, NW_ = 0;
+  int64_t batch_ = 0, bpad_ = 0;
+  int num_cus_ = 256;
+  DevArray<uint32_t> tables_, initc_, state_, curtains_;
+  DevArray<int32_t> track_;
+};
+
+int BetterScrollyBackend::init(const pcx_template& t, int64_t batch) {
+  Consts& k = k_;
+  batch_ = batch;
+  bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
+  if (const char* e = getenv("PCX_FORCE_GENERIC")) if (atoi(e)) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: PCX_FORCE_GENERIC");
+  if (!t.occlusion_in_layers || t.n_directives) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: occluded layers, no directives");
+  R_ = t.rows; C_ = t.cols; L_ = t.n_chars;
+  bool shape_ok = false;
+#define X(r, c) shape_ok |= R_ == r && C_ == c;
+  PCX_BS_SHAPES(X)
+#undef X
+  if (!shape_ok || t.n_sprites != NS || t.n_drapes != ND || L_ != NS + ND + NB || t.n_groups != 1 || t.n_things != NS + ND)
+    return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the shipped boards and cast only");
+  lay_.set(R_, C_);
+  NW_ = W_COINS + lay_.FW;
+  // sprites: three patrollers then the player; impassable == {'#'}; schedule a b c P @; z-order: patrollers, coins, player
+  for (int s = 0; s < NS; ++s) {
+    const pcx_sprite_desc& sd = t.sprites[s];
+    if (sd.program != (s == IP ? PCX_PROG_BS_PLAYER : PCX_PROG_BS_PATROLLER) || !sd.is_walker || sd.egocentric)
+      return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: unexpected cast");
+    for (int i = 0; i < 16; ++i)
+      if (sd.impassable[i] != (i == ('#' >> 3) ? (1u << ('#' & 7)) : 0u))
+        return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: impassable must be '#'");
+    if (t.schedule[s] != sd.ch || t.group_of[s] != 0) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: unexpected update schedule");
+  }
+  const pcx_drape_desc& dd = t.drapes[0];
+  if (dd.program != PCX_PROG_BS_CASH || dd.is_scrolly || t.schedule[NS] != dd.ch)
+    return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the drape must be the CashDrape, updated last");
+  int zpos[NS + ND];
+  for (int z = 0; z < t.n_things; ++z) {
+    int idx = -1;
+    for (int s = 0; s < NS; ++s) if (t.sprites[s].ch == t.z_order[z]) idx = s;
+    if (t.z_order[z] == dd.ch) idx = NS;
+    if (idx < 0) return set_error(PCX_E_INVALID, "better_scrolly backend: z_order names an unknown character");
+    zpos[idx] = z;
+  }
+  for (int s = 0; s < NS; ++s) {
+    k.above[s] = 0;
+    for (int j = 0; j < NS + ND; ++j) if (zpos[j] > zpos[s]) k.above[s] |= 1u << j;
+  }
+  k.n_actions = t.n_actions;
+  k.confined = 0;
+  for (int s = 0; s < NS; ++s) if (t.sprites[s].confined) k.confined |= 1u << s;
+  auto layer_of = [&](int ch) { for (int i = 0; i < L_; ++i) if (t.chars[i] == ch) return i; return -1; };
+  for (int s = 0; s < NS; ++s) {
+    k.sprite_off[s] = (uint32_t)(1 + layer_of(t.sprites[s].ch)) * lay_.pitch;
+    k.sprite_ch4[s] = t.sprites[s].ch * 0x01010101u;
+  }
+  k.drape_off = (uint32_t)(1 + layer_of(dd.ch)) * lay_.pitch;
+  k.drape_ch4 = dd.ch * 0x01010101u;
+  if (layer_of('#') < 0) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: no '#' in the backdrop");
+
+  std::vector<uint32_t> tab((size_t)lay_.QW * (1 + NB) + lay_.FW, 0);
+  memcpy(tab.data(), t.backdrop, lay_.cells);
+  int nb = 0;
+  for (int i = 0; i < L_; ++i) {
+    const int ch = t.chars[i];
+    bool thing = ch == dd.ch;
+    for (int s = 0; s < NS; ++s) thing |= t.sprites[s].ch == ch;
+    if (thing) continue;
+    if (nb >= NB) return set_error(PCX_E_INVALID, "better_scrolly backend: inconsistent character set");
+    k.bchar_off[nb] = (uint32_t)(1 + i) * lay_.pitch;
+    uint8_t* m = reinterpret_cast<uint8_t*>(tab.data() + (size_t)lay_.QW * (1 + nb));
+    for (int c = 0; c < lay_.cells; ++c) m[c] = t.backdrop[c] == ch;
+    ++nb;
+  }
+  if (nb != NB) return set_error(PCX_E_INVALID, "better_scrolly backend: inconsistent character set");
+  uint32_t* wall = tab.data() + (size_t)lay_.QW * (1 + NB);
+  for (int c = 0; c < lay_.cells; ++c) if (t.backdrop[c] == '#') wall[c >> 5] |= 1u << (c & 31);
+  std::vector<uint32_t> initc(lay_.FW, 0);
+  int coins = 0;
+  for (int c = 0; c < lay_.cells; ++c) if (dd.curtain[c]) { initc[c >> 5] |= 1u << (c & 31); ++coins; }
+  if (coins > 0xFFFF) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: too many coins");
+
+  memset(k.init, 0, sizeof k.init);
+  k.init[W_FRAME] = (uint32_t)-1;
+  uint32_t sf = 0;
+  for (int s = 0; s < NS; ++s) {
+    const pcx_sprite_desc& sd = t.sprites[s];
+    sf |= ((uint32_t)(sd.visible != 0) | ((uint32_t)(sd.prior_visible != 0) << 1) |
+           ((uint32_t)(s != IP && sd.param[0] != 0) << 2)) << (3 * s);  // _moving_east, better_scrolly_maze.py:282
+    k.init[W_POS + s] = ((uint32_t)sd.vrow & 0xFFFFu) | ((uint32_t)sd.vcol << 16);
+  }
+  k.init[W_FLAGS] = (sf << F_SF_SHIFT) | ((uint32_t)coins << F_LEFT_SHIFT);
+  {
+    int sc[NS], dc = dd.ch, bc[NB] = {0, 0};
+    for (int s = 0; s < NS; ++s) sc[s] = t.sprites[s].ch;
+    stream::fill_epilogue(epi_, nullptr, lay_.cells, sc, NS, &dc, 1, bc, NB);
+  }
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      num_cus_ = prop.multiProcessorCount;
+  }
+  int rc;
+  if ((rc = tables_.upload(tab))) return rc;
+  if ((rc = initc_.upload(initc))) return rc;
+  if ((rc = state_.alloc((size_t)NW_ * bpad_))) return rc;
+  if ((rc = track_.alloc((size_t)NS * bpad_))) return rc;
+  return 0;
+}
+
+int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) {
+  if (a.n_steps != 1) return set_error(PCX_E_INVALID, "better_scrolly backend: one step per launch");
+  if (a.export_curtains) { int rc = ensure_curtains(); if (rc) return rc; }
+  Ptrs P{tables_.ptr, initc_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
+  const int64_t groups = bpad_ / WAVE;
+  int coop_below = 5;
+  if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
+  const bool coop = groups < (int64_t)num_cus_ * coop_below;
+  const size_t lds = ((size_t)lay_.QW * (1 + NB) + lay_.FW + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE) * 4;
+  bool launched = false;
+#define X(r, c)                                                                                                   \
+  if (!launched && R_ == r && C_ == c) {                                                                          \
+    if (lds > 64 * 1024) {                                                                                        \
+      PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_better_scrolly_step<r, c, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_better_scrolly_step<r, c, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    }                                                                                                             \
+    if (coop) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_); \
+    else hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_);          \
+    launched = true;                                                                                              \
+  }
+  PCX_BS_SHAPES(X)
+#undef X
+  if (!launched) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: no instance");
+  PCX_HIP(hipGetLastError());
+  return 0;
+}
+
+int BetterScrollyBackend::read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) {
+  std::vector<uint32_t> st((size_t)NW_ * n);
+  PCX_HIP(hipDeviceSynchronize());
+  for (int w = 0; w < NW_; ++w)
+    PCX_HIP(hipMemcpy(st.data() + (size_t)w * n, state_.ptr + (size_t)w * bpad_ + env0, n * 4, hipMemcpyDeviceToHost));
+  auto word = [&](int w, int64_t i) { return st[(size_t)w * n + i]; };
+  for (int64_t i = 0; i < n; ++i) {
+    if (sprites)
+      for (int s = 0; s < NS; ++s) {
+        pcx_sprite_state& o = sprites[i * NS + s];
+        memset(&o, 0, sizeof o);
+        const uint32_t pw = word(W_POS + s, i);
+        o.vrow = (int16_t)(pw & 0xFFFF); o.vcol = (int16_t)(pw >> 16);
+        const bool on = o.vrow >= 0 && o.vrow < R_ && o.vcol >= 0 && o.vcol < C_;
+        o.row = on ? o.vrow : 0; o.col = on ? o.vcol : 0;
+        o.visible = (word(W_FLAGS, i) >> (F_SF_SHIFT + 3 * s)) & 1;
+      }
+    if (curtains)
+      for (int c = 0; c < lay_.cells; ++c)
+        curtains[(size_t)i * lay_.cells + c] = (word(W_COINS + (c >> 5), i) >> (c & 31)) & 1;
+  }
+  return 0;
+}
+
+}  // namespace bs
+
+Backend* make_better_scrolly_backend() { return new bs::BetterScrollyBackend(); }
+
+}  // namespace pcx

@@ -135,6 +135,36 @@ def test_hip_hand_written_kernels_other_launch_shapes(name, knob, value, monkeyp
   assert N.lib().pcx_engine_kernel_name(hip.eng._native).decode() in ('pcx_marauders_step', 'pcx_warehouse_step')
 
 
+@pytest.mark.parametrize('name,kernel', [('better_scrolly_maze_L0', 'pcx_better_scrolly_step'), ('better_scrolly_maze_L1', 'pcx_better_scrolly_step'),
+                                         ('better_scrolly_maze_L2', 'pcx_better_scrolly_step'), ('marauders', 'pcx_marauders_step'),
+                                         ('warehouse_L1', 'pcx_warehouse_step'), ('scrolly_maze_L2', 'pcx_scrolly_maze_step'),
+                                         ('marauders_custom_A', 'pcx_generic_step'), ('hello_world', 'pcx_generic_step'),
+                                         ('warehouse_L0_unoccluded', 'pcx_generic_step')])
+@pytest.mark.parametrize('shape', ['coop', 'single'])
+def test_which_kernel_steps_which_game(name, kernel, shape, monkeypatch):
+  """The shipped shapes run the hand-written kernels, everything else the table-driven
+  one; both launch shapes of each (several waves per group at small batches, single-wave
+  workgroups at BASELINE sizes) match the oracle step by step, quirky actions included."""
+  if shape == 'single':
+    monkeypatch.setenv('PCX_COOP_BELOW', '0')
+    monkeypatch.setenv('PCX_EM_WAVES', '1')
+  from pycolab_amd import _native as N
+  t = helpers.load_template(name)
+  t.param[0] = 0xD00D
+  B = 150
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  assert N.lib().pcx_engine_kernel_name(hip.eng._native).decode() == kernel
+  rng = np.random.RandomState(8)
+  for step in range(48):
+    a = rng.randint(0, t.n_actions, size=B).astype(np.int32)
+    r = rng.rand(B)
+    a[r < 0.03] = -1
+    a[(r >= 0.03) & (r < 0.04)] = t.n_actions   # the quit action of every shipped game
+    hip.step(a, auto_reset=step % 5 != 4); orc.step(a, auto_reset=step % 5 != 4)
+    assert_same(hip, orc, '%s step %d' % (name, step))
+
+
 @pytest.mark.parametrize('fuse', ['0', '1'])
 def test_hip_step_n_fused_and_unfused_match_oracle(fuse, monkeypatch):
   """pcx_engine_step_n / _step_hashed take several steps per launch at small
