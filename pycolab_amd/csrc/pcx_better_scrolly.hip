@@ -9,14 +9,18 @@
 // workgroup, logic phase lane == environment, render phase = pcx_stream.h.
 //
 // ONE update group (`a b c P @`), so every entity sees the repaint the step
-// started with.  The maze walls are the (static) backdrop; the only bulky state
-// is CashDrape's whole-board curtain, kept as a flat cell-bit vector: the same
-// words in HBM (SoA over the batch), loaded straight into the LDS rows the
-// streaming phase reads, tested and cleared in place (a pickup rewrites one
-// word in HBM; the number of coins left rides in the flags word, so "no coins
-// left" needs no reduction).  A MazeWalker probe with impassable == '#' is
-// "wall cell with nothing painted over it" from the register snapshot of the
-// sprites' cells, the coin bit and a static wall bit vector.
+// started with.  The maze walls are the (static) backdrop; CashDrape's
+// whole-board curtain only ever loses cells, so per environment it is a bit mask
+// over the template's coin list (92-186 coins: 3-6 words instead of a 4005-bit
+// curtain), in HBM (SoA over the batch) and in LDS, where a static table gives
+// every board dword the list indices of its four cells -- for the logic phase's
+// "is there a coin here" and for the streaming phase alike (pcx_stream.h,
+// cell_ids).  That keeps a group's LDS near 20 KB, i.e. eight workgroups per CU,
+// where a flat curtain per environment allowed three (0.64 -> see
+// profiles/r02_tuning.md).  The number of coins left rides in the flags word,
+// so "no coins left" needs no reduction.  A MazeWalker probe with impassable ==
+// '#' is "wall cell with nothing painted over it" from the register snapshot of
+// the sprites' cells, the coin bit and a static wall bit vector.
 // Other casts, z-orders, impassable sets or shapes: the table-driven kernel.
 
 #include "pcx_internal.h"
@@ -40,8 +44,10 @@ constexpr uint32_t F_OVER = 1u, F_ERR_SHIFT = 1;
 constexpr int F_SF_SHIFT = 4;     // per sprite: visible, prior_visible, moving_east (3 bits)
 constexpr int F_LEFT_SHIFT = 16;  // coins left (CashDrape.curtain.any() without a reduction)
 
+constexpr int MAX_CW = 8;  // coin-mask words (at most 255 coins: a list index is a byte)
+
 struct Consts {
-  int32_t n_actions;
+  int32_t n_actions, n_coins, CW;
   uint32_t confined;
   uint32_t above[NS];
   uint32_t init[W_COINS];
@@ -49,8 +55,8 @@ struct Consts {
 };
 
 struct Ptrs {
-  const uint32_t* tables;        // staged into LDS: backdrop4 [QW], bdmask [NB][QW], wall bits [FW]
-  const uint32_t* init_curtain;  // [FW]
+  const uint32_t* tables;        // staged into LDS: backdrop4 [QW], bdmask [NB][QW], coin ids [QW], wall bits [FW]
+  const uint32_t* coin_cell;     // [n_coins] cell of every coin of the list (export_curtains only)
   uint32_t* state;               // [NW][bpad]
   int32_t* track;                // [NS][bpad]
   uint32_t* curtains;            // [1][FW][bpad] (export_curtains)
@@ -72,17 +78,19 @@ template <int R, int C, int NWAVES>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                          const pcx_buffers out, const stream::EpilogueArgs epi) {
   extern __shared__ uint32_t lds[];
-  constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32, FWP = FW | 1;
-  constexpr int L = NS + ND + NB, NW = W_COINS + FW;
-  constexpr int O_BD = 0, O_BDM = O_BD + QW, O_WALL = O_BDM + NB * QW, O_TAB_END = O_WALL + FW;
-  constexpr int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
+  constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32;
+  constexpr int L = NS + ND + NB, CWP = MAX_CW | 1;
+  constexpr int O_BD = 0, O_BDM = O_BD + QW, O_CID = O_BDM + NB * QW, O_WALL = O_CID + QW, O_TAB_END = O_WALL + FW;
+  constexpr int O_CM = O_TAB_END, O_SDESC = (O_CM + WAVE * CWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
+  const uint32_t* const cid = lds + O_CID;    // list indices of every board dword's four cells (0xFF: no coin there)
   const uint32_t* const wall = lds + O_WALL;
-  uint32_t* const flat = lds + O_FLAT;      // [64][FWP]: the coin curtain of every environment of the group
-  uint32_t* const mine = flat + lane * FWP;
+  uint32_t* const cm = lds + O_CM;            // [64][CWP]: which coins of the list every environment still has
+  uint32_t* const mine = cm + lane * CWP;
   uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC);
   uint32_t* const skipv = lds + O_SKIP;
+  const int CW = k.CW;
   __syncthreads();
 
   const int64_t env0 = (int64_t)blockIdx.x * WAVE;
@@ -119,18 +127,18 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
       }
     }
     if (!skip) {
-      // the coin curtain goes from HBM (or the template) straight into this lane's LDS row,
-      // sixteen words in flight at a time
+      // the coin mask: from HBM (requested with the other words below) or all ones after a reset
       if (do_reset) {
-        for (int i = 0; i < FW; ++i) mine[i] = P.init_curtain[i];
-      } else {
-        for (int i0 = 0; i0 < FW; i0 += 16) {
-          uint32_t v[16];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) v[j] = i0 + j < FW ? st[(W_COINS + i0 + j) * bp] : 0u;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) if (i0 + j < FW) mine[i0 + j] = v[j];
+        for (int i = 0; i < CW; ++i) {
+          const int rest = k.n_coins - 32 * i;
+          mine[i] = rest >= 32 ? 0xFFFFFFFFu : ((1u << rest) - 1u);
         }
+      } else {
+        uint32_t v[MAX_CW];
+#pragma unroll
+        for (int j = 0; j < MAX_CW; ++j) v[j] = j < CW ? st[(W_COINS + j) * bp] : 0u;
+#pragma unroll
+        for (int j = 0; j < MAX_CW; ++j) if (j < CW) mine[j] = v[j];
       }
       int frame, left;
       uint32_t sflags, err;
@@ -172,8 +180,10 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
       int cell0[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) cell0[s] = vis[s] ? true_cell(vr[s], vc[s]) : -1;
+      auto coin_id = [&](int cell) { return (int)((cid[cell >> 2] >> (8 * (cell & 3))) & 0xFFu); };
+      auto coin_alive = [&](int id) { return id != 0xFF && ((mine[id >> 5] >> (id & 31)) & 1); };
       auto shows_wall = [&](int cell) {
-        bool painted = (mine[cell >> 5] >> (cell & 31)) & 1;
+        bool painted = coin_alive(coin_id(cell));
 #pragma unroll
         for (int j = 0; j < NS; ++j) painted |= cell0[j] == cell;
         return !painted && ((wall[cell >> 5] >> (cell & 31)) & 1);
@@ -206,12 +216,11 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
       // ---- CashDrape.update (:311-320) -------------------------------------------------
       int changed_word = -1;
       {
-        const int pc = true_cell(vr[IP], vc[IP]);
-        const uint32_t w = mine[pc >> 5], bit = 1u << (pc & 31);
-        if (w & bit) {
+        const int id = coin_id(true_cell(vr[IP], vc[IP]));
+        if (coin_alive(id)) {
           reward += 100; reward_set = 1;
-          mine[pc >> 5] = w & ~bit;
-          changed_word = pc >> 5;
+          mine[id >> 5] &= ~(1u << (id & 31));
+          changed_word = id >> 5;
           if (--left == 0) { over = 1; discount = 0.0f; }
         }
       }
@@ -228,12 +237,18 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
       }
       st[W_FLAGS * bp] = (over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT) | (sf << F_SF_SHIFT) | ((uint32_t)left << F_LEFT_SHIFT);
       if (do_reset) {
-        for (int i = 0; i < FW; ++i) st[(W_COINS + i) * bp] = mine[i];
+        for (int i = 0; i < CW; ++i) st[(W_COINS + i) * bp] = mine[i];
       } else if (changed_word >= 0) {
         st[(W_COINS + changed_word) * bp] = mine[changed_word];  // a pickup rewrites one word
       }
-      if (a.export_curtains)
-        for (int i = 0; i < FW; ++i) P.curtains[(size_t)i * bp + env] = mine[i];
+      if (a.export_curtains) {  // a cropper tracks the coins: the raw curtain as flat cell bits (rare path)
+        for (int i = 0; i < FW; ++i) P.curtains[(size_t)i * bp + env] = 0;
+        for (int id = 0; id < k.n_coins; ++id)
+          if ((mine[id >> 5] >> (id & 31)) & 1) {
+            const uint32_t cell = P.coin_cell[id];
+            P.curtains[(size_t)(cell >> 5) * bp + env] |= 1u << (cell & 31);
+          }
+      }
       out.reward[env] = reward;
       out.reward_set[env] = (uint8_t)reward_set;
       out.discount[env] = discount;
@@ -242,12 +257,29 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
       out.error[env] = (uint8_t)err;
 
       // ---- render descriptors ---------------------------------------------------------------
+      // engine.py:751-757: a sprite is painted iff it is visible and neither a sprite in front of it
+      // nor (if the coins are in front of it) a coin holds its cell; a painted sprite hides the coin
+      // under it (in this LDS copy of the mask: the state words are already on their way to HBM)
       int cellv[NS];
-      uint32_t above[NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) { cellv[s] = vis[s] ? true_cell(vr[s], vc[s]) : -1; above[s] = k.above[s]; }
-      stream::resolve_sprites<NS, ND>(cellv, above, flat, FWP, lane, sdesc);
-      (void)NW;
+      for (int s = 0; s < NS; ++s) cellv[s] = vis[s] ? true_cell(vr[s], vc[s]) : -1;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int c = cellv[s];
+        bool shown = c >= 0;
+        if (shown) {
+          const uint32_t ab = k.above[s];
+#pragma unroll
+          for (int j = 0; j < NS; ++j)
+            if (j != s && ((ab >> j) & 1) && cellv[j] == c) shown = false;
+          const int id = coin_id(c);
+          if (coin_alive(id)) {
+            if ((ab >> NS) & 1) shown = false;
+            else if (shown) mine[id >> 5] &= ~(1u << (id & 31));
+          }
+        }
+        sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(c >> 2) : 0xFFFFFFFFu, 0xFFu << ((c & 3) * 8));
+      }
     }
     skipv[lane] = skip;
   }
@@ -262,7 +294,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
   for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                      flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+                                                      cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid);
 }
 
 // ---------------------------------------------------------------------------
@@ -277,8 +309,8 @@ class BetterScrollyBackend : public Backend {
   int launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) override;
   int read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) override;
   int64_t bytes_per_step() const override {
-    // read: action 4 + state 4 NW (the coin curtain is read every step); write: the scalar state words
-    // (a pickup adds one curtain word) + planes (1 + L) cells + results 15
+    // read: action 4 + state 4 NW; write: the scalar state words (a pickup adds one coin-mask word)
+    // + planes (1 + L) cells + results 15
     return 4 + 4 * (int64_t)NW_ + 4 * (int64_t)W_COINS + (int64_t)(1 + L_) * lay_.cells + 15;
   }
   const char* kernel_name() const override { return "pcx_better_scrolly_step"; }
@@ -296,8 +328,9 @@ class BetterScrollyBackend : public Backend {
   int R_ = 0, C_ = 0, L_ = 0, NW_ = 0;
   int64_t batch_ = 0, bpad_ = 0;
   int num_cus_ = 256;
-  DevArray<uint32_t> tables_, initc_, state_, curtains_;
+  DevArray<uint32_t> tables_, coin_cell_, state_, curtains_;
   DevArray<int32_t> track_;
+  std::vector<uint32_t> h_coin_cell_;  // host copy for read_things
 };
 
 int BetterScrollyBackend::init(const pcx_template& t, int64_t batch) {
@@ -314,7 +347,6 @@ int BetterScrollyBackend::init(const pcx_template& t, int64_t batch) {
   if (!shape_ok || t.n_sprites != NS || t.n_drapes != ND || L_ != NS + ND + NB || t.n_groups != 1 || t.n_things != NS + ND)
     return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the shipped boards and cast only");
   lay_.set(R_, C_);
-  NW_ = W_COINS + lay_.FW;
   // sprites: three patrollers then the player; impassable == {'#'}; schedule a b c P @; z-order: patrollers, coins, player
   for (int s = 0; s < NS; ++s) {
     const pcx_sprite_desc& sd = t.sprites[s];
@@ -352,7 +384,7 @@ int BetterScrollyBackend::init(const pcx_template& t, int64_t batch) {
   k.drape_ch4 = dd.ch * 0x01010101u;
   if (layer_of('#') < 0) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: no '#' in the backdrop");
 
-  std::vector<uint32_t> tab((size_t)lay_.QW * (1 + NB) + lay_.FW, 0);
+  std::vector<uint32_t> tab((size_t)lay_.QW * (2 + NB) + lay_.FW, 0);
   memcpy(tab.data(), t.backdrop, lay_.cells);
   int nb = 0;
   for (int i = 0; i < L_; ++i) {
@@ -367,12 +399,23 @@ int BetterScrollyBackend::init(const pcx_template& t, int64_t batch) {
     ++nb;
   }
   if (nb != NB) return set_error(PCX_E_INVALID, "better_scrolly backend: inconsistent character set");
-  uint32_t* wall = tab.data() + (size_t)lay_.QW * (1 + NB);
+  // the coin list (row-major) and, per board dword, the list indices of its four cells
+  uint8_t* ids = reinterpret_cast<uint8_t*>(tab.data() + (size_t)lay_.QW * (1 + NB));
+  memset(ids, 0xFF, (size_t)lay_.QW * 4);
+  h_coin_cell_.clear();
+  for (int c = 0; c < lay_.cells; ++c)
+    if (dd.curtain[c]) {
+      if (h_coin_cell_.size() >= 255) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: more than 255 coins");
+      ids[c] = (uint8_t)h_coin_cell_.size();
+      h_coin_cell_.push_back((uint32_t)c);
+    }
+  const int coins = (int)h_coin_cell_.size();
+  k.n_coins = coins;
+  k.CW = (coins + 31) / 32;
+  if (k.CW > MAX_CW) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: too many coins");
+  NW_ = W_COINS + k.CW;
+  uint32_t* wall = tab.data() + (size_t)lay_.QW * (2 + NB);
   for (int c = 0; c < lay_.cells; ++c) if (t.backdrop[c] == '#') wall[c >> 5] |= 1u << (c & 31);
-  std::vector<uint32_t> initc(lay_.FW, 0);
-  int coins = 0;
-  for (int c = 0; c < lay_.cells; ++c) if (dd.curtain[c]) { initc[c >> 5] |= 1u << (c & 31); ++coins; }
-  if (coins > 0xFFFF) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: too many coins");
 
   memset(k.init, 0, sizeof k.init);
   k.init[W_FRAME] = (uint32_t)-1;
@@ -397,7 +440,7 @@ int BetterScrollyBackend::init(const pcx_template& t, int64_t batch) {
   }
   int rc;
   if ((rc = tables_.upload(tab))) return rc;
-  if ((rc = initc_.upload(initc))) return rc;
+  { std::vector<uint32_t> cc = h_coin_cell_; if (cc.empty()) cc.push_back(0); if ((rc = coin_cell_.upload(cc))) return rc; }
   if ((rc = state_.alloc((size_t)NW_ * bpad_))) return rc;
   if ((rc = track_.alloc((size_t)NS * bpad_))) return rc;
   return 0;
@@ -406,12 +449,21 @@ int BetterScrollyBackend::init(const pcx_template& t, int64_t batch) {
 int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) {
   if (a.n_steps != 1) return set_error(PCX_E_INVALID, "better_scrolly backend: one step per launch");
   if (a.export_curtains) { int rc = ensure_curtains(); if (rc) return rc; }
-  Ptrs P{tables_.ptr, initc_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
+  Ptrs P{tables_.ptr, coin_cell_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
   const int64_t groups = bpad_ / WAVE;
-  int coop_below = 5;
+  // four waves share a group's render loop below this many groups per CU (measured crossover: the 45x89
+  // board 2 vs 3 groups per CU, the 29x30 board 4 vs 8; profiles/r02_tuning.md)
+  int coop_below = lay_.QW >= 512 ? 3 : 5;
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
-  const size_t lds = ((size_t)lay_.QW * (1 + NB) + lay_.FW + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE) * 4;
+  size_t lds = ((size_t)lay_.QW * (2 + NB) + lay_.FW + WAVE * (MAX_CW | 1) + 2 + 2 * NS * WAVE + WAVE) * 4;
+  int waves_per_cu = 8;  // single-wave workgroups: pad LDS so that about eight share a CU (as for scrolly_maze)
+  if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
+  if (!coop && waves_per_cu > 0) {
+    size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
+    if (want > 64 * 1024) want = 64 * 1024;
+    if (want > lds) lds = want;
+  }
   bool launched = false;
 #define X(r, c)                                                                                                   \
   if (!launched && R_ == r && C_ == c) {                                                                          \
@@ -447,9 +499,11 @@ int BetterScrollyBackend::read_things(int64_t env0, int64_t n, pcx_sprite_state*
         o.row = on ? o.vrow : 0; o.col = on ? o.vcol : 0;
         o.visible = (word(W_FLAGS, i) >> (F_SF_SHIFT + 3 * s)) & 1;
       }
-    if (curtains)
-      for (int c = 0; c < lay_.cells; ++c)
-        curtains[(size_t)i * lay_.cells + c] = (word(W_COINS + (c >> 5), i) >> (c & 31)) & 1;
+    if (curtains) {
+      memset(curtains + (size_t)i * lay_.cells, 0, lay_.cells);
+      for (size_t id = 0; id < h_coin_cell_.size(); ++id)
+        if ((word(W_COINS + (int)(id >> 5), i) >> (id & 31)) & 1) curtains[(size_t)i * lay_.cells + h_coin_cell_[id]] = 1;
+    }
   }
   return 0;
 }

@@ -98,11 +98,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // iterations round-robin.
 //   QW: dwords per plane (plane pitch / 4); record = (1 + L) planes.
 //   EPI: also write the float32 feature-array epilogue (EpilogueArgs).
+//   cell_ids (optional): a drape whose cells only ever disappear (coins) kept as a
+//     per-environment bit mask over the template's list of its cells instead of a
+//     flat curtain: cell_ids[q] = the list indices of board dword q's four cells
+//     (0xFF = not a cell of the drape), `flat` = [64][FWP] alive masks.  Needs ND == 1.
 template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI>
 __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
                                               const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
                                               const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
-                                              const EpilogueArgs& epi, int64_t env0) {
+                                              const EpilogueArgs& epi, int64_t env0, const uint32_t* cell_ids = nullptr) {
   uint8_t* const pb_board = uniform_ptr(group_base);
   uint8_t* pb_s[NS];
   uint8_t* pb_d[ND];
@@ -169,7 +173,20 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
     uint32_t md[ND > 0 ? ND : 1], ms[NS > 0 ? NS : 1], mb[NB > 0 ? NB : 1];
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) {
-      const uint32_t bits = (flat[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;
+      uint32_t bits;
+      if (cell_ids != nullptr) {  // (uniform; resolved at compile time where the caller passes a constant)
+        const uint32_t ids = cell_ids[q_now];
+        bits = 0;
+        if (ids != 0xFFFFFFFFu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t id = (ids >> (8 * j)) & 0xFFu;
+            if (id != 0xFFu) bits |= ((flat[eF_now + (id >> 5)] >> (id & 31)) & 1u) << j;
+          }
+        }
+      } else {
+        bits = (flat[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;
+      }
       const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;  // bit i -> byte i
       uint32_t hi8 = m01 << 8;
       asm("" : "+v"(hi8));  // keep LLVM from folding (x << 8) - x into a quarter-rate x * 255
