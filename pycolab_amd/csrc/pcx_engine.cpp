@@ -128,13 +128,14 @@ int pcx_engine_create(const pcx_template* t, int64_t batch, int device_id, pcx_e
     case PCX_GAME_WAREHOUSE: b = pcx::make_warehouse_backend(); break;
     case PCX_GAME_MARAUDERS: b = pcx::make_marauders_backend(); break;
     case PCX_GAME_BETTER_SCROLLY: b = pcx::make_better_scrolly_backend(); break;
-    case PCX_GAME_HELLO_WORLD:
+    case PCX_GAME_HELLO_WORLD: b = pcx::make_hello_world_backend(); break;
     case PCX_GAME_WALKERS: b = pcx::make_generic_backend(); break;
     default:
       return set_error(PCX_E_UNSUPPORTED, "pcx_engine_create: no device program for game id %d", t->game);
   }
   int rc = b->init(*t, batch);
-  if (rc == PCX_E_UNSUPPORTED && (t->game == PCX_GAME_WAREHOUSE || t->game == PCX_GAME_MARAUDERS || t->game == PCX_GAME_BETTER_SCROLLY)) {
+  if (rc == PCX_E_UNSUPPORTED && (t->game == PCX_GAME_WAREHOUSE || t->game == PCX_GAME_MARAUDERS || t->game == PCX_GAME_BETTER_SCROLLY ||
+                                 t->game == PCX_GAME_HELLO_WORLD)) {
     delete b;
     b = pcx::make_generic_backend();
     rc = b->init(*t, batch);

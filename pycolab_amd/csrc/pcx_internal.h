@@ -111,6 +111,7 @@ Backend* make_generic_backend();
 Backend* make_warehouse_backend();  // hand-written; init() answers PCX_E_UNSUPPORTED for templates it leaves to the table-driven kernel
 Backend* make_marauders_backend();
 Backend* make_better_scrolly_backend();
+Backend* make_hello_world_backend();
 
 }  // namespace pcx
 

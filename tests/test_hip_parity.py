@@ -138,7 +138,8 @@ def test_hip_hand_written_kernels_other_launch_shapes(name, knob, value, monkeyp
 @pytest.mark.parametrize('name,kernel', [('better_scrolly_maze_L0', 'pcx_better_scrolly_step'), ('better_scrolly_maze_L1', 'pcx_better_scrolly_step'),
                                          ('better_scrolly_maze_L2', 'pcx_better_scrolly_step'), ('marauders', 'pcx_marauders_step'),
                                          ('warehouse_L1', 'pcx_warehouse_step'), ('scrolly_maze_L2', 'pcx_scrolly_maze_step'),
-                                         ('marauders_custom_A', 'pcx_generic_step'), ('hello_world', 'pcx_generic_step'),
+                                         ('marauders_custom_A', 'pcx_generic_step'), ('hello_world', 'pcx_hello_world_step'),
+                                         ('hello_custom_A', 'pcx_hello_world_step'),
                                          ('warehouse_L0_unoccluded', 'pcx_generic_step')])
 @pytest.mark.parametrize('shape', ['coop', 'single'])
 def test_which_kernel_steps_which_game(name, kernel, shape, monkeypatch):
