@@ -329,6 +329,21 @@ int32_t pcx_cropper_plane_pitch(const pcx_cropper* c);
  * the reference's croppers likewise write a pre-allocated output
  * (cropping.py:131-134).  No copy, no synchronisation on the way out. */
 int pcx_cropper_bind_output(pcx_cropper* c, uint8_t* planes_dev);
+/* Fused croppers.  The step kernel holds the frame it paints in LDS, so it can
+ * cut the croppers' windows from it directly: after this call every
+ * pcx_engine_reset / pcx_engine_step of `e` also moves the windows of these
+ * croppers (ScrollingCropper.crop, cropping.py:393-426, once per step -- i.e.
+ * the caller crops every observation, as human_ui.py:269-293 does) and writes
+ * their output planes, in the same launch; pcx_cropper_crop() on a fused
+ * cropper then launches nothing.  `croppers`: n <= 4 croppers of this engine,
+ * fixed or tracking sprites (not drapes).  only_crops != 0: the full-board
+ * planes are no longer written (pcx_buffers.planes goes stale; the consumer
+ * ingests the windows only).  n == 0 releases the croppers again.  When the
+ * engine is already in play the croppers are brought up to date once, on
+ * `stream`.  PCX_E_UNSUPPORTED (nothing changed) where the engine's kernel
+ * cannot do it: the croppers then run as their own kernels. */
+int pcx_engine_fuse_croppers(pcx_engine* e, pcx_cropper* const* croppers,
+                             int32_t n, int32_t only_crops, void* stream);
 /* Device uint8[batch] behind pcx_cropper_errors (read it on the caller's stream). */
 int pcx_cropper_error_buffer(pcx_cropper* c, const uint8_t** errors_dev);
 int pcx_cropper_error_poll(pcx_cropper* c, void* stream, int32_t* seen);

@@ -154,6 +154,7 @@ SYMBOLS = [
     ('pcx_cropper_errors', c_i32, [_VP, _VP]),
     ('pcx_cropper_plane_pitch', c_i32, [_VP]),
     ('pcx_cropper_bind_output', c_i32, [_VP, _VP]),
+    ('pcx_engine_fuse_croppers', c_i32, [_VP, ctypes.POINTER(_VP), c_i32, c_i32, _VP]),
     ('pcx_cropper_error_buffer', c_i32, [_VP, ctypes.POINTER(_VP)]),
     ('pcx_cropper_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
     ('pcx_engine_planes_view', c_i32, [_VP, ctypes.POINTER(PlanesView)]),

@@ -30,6 +30,7 @@ class ObservationCropper(object):
     self._out = None        # output planes [B, 1 + n_chars, pitch] (a device tensor with PyTorch)
     self._pitch = 0
     self._generation = 0    # bumped whenever the native cropper (and its buffers) is rebuilt
+    self._fused = False     # the engine's step kernel moves the window and writes the planes (fuse_croppers)
 
   def set_engine(self, engine):
     if engine is not self._engine:
@@ -56,9 +57,10 @@ class ObservationCropper(object):
 
   def _release(self):
     if self._native is not None:
-      N.lib().pcx_cropper_destroy(self._native)
+      N.lib().pcx_cropper_destroy(self._native)  # (a fused cropper leaves its engine's step kernel first)
       self._native = None
       self._out = None
+      self._fused = False
       self._generation += 1
 
   def __del__(self):
@@ -247,6 +249,48 @@ class ScrollingCropper(ObservationCropper):
   @property
   def cols(self):
     return self._cols
+
+
+def fuse_croppers(engine, croppers, only_crops=False):
+  """Have `engine`'s step kernel run these croppers itself.
+
+  The step kernel holds the frame it paints in LDS, so it can cut the windows
+  from it directly: from now on every `its_showtime()` / `play()` / `step()`
+  also moves the croppers' windows (one `crop()` per observation, as
+  `human_ui.py:269-293` does) and writes their planes in the same launch;
+  `cropper.crop(observation)` then launches nothing and returns the window the
+  step already wrote.  `only_crops=True` also stops the step from writing the
+  full-board planes (the engine's `Observation` goes stale) for consumers that
+  only ingest the windows -- on a 45x89 board with a 10x30 egocentric window
+  that is 13x less to write.
+
+  Returns False, and changes nothing, where the engine's kernel cannot do it
+  (croppers that track drapes, more than four croppers, games stepped by
+  kernels without the fused path): the croppers then run as their own kernels,
+  as before.  `croppers=[]` releases them again."""
+  croppers = list(croppers)
+  for cr in croppers:
+    if type(cr) is ObservationCropper:
+      raise ValueError('the identity cropper has nothing to fuse')
+    cr.set_engine(engine)
+  if engine._native is None:  # not in play yet: its_showtime() fuses before frame 0
+    engine._fuse_request = (croppers, bool(only_crops))
+    return None
+  for cr in croppers:
+    if cr._native is None:
+      cr._create_native()
+  arr = (ctypes.c_void_p * max(1, len(croppers)))(*[cr._native for cr in croppers])
+  try:
+    N.check(N.lib().pcx_engine_fuse_croppers(engine._native, arr, len(croppers), int(bool(only_crops)),
+                                             dev.current_stream(engine._device_id)))
+  except NotImplementedError:
+    return False
+  for cr in getattr(engine, '_croppers', []):
+    cr._fused = False
+  for cr in croppers:
+    cr._fused = True
+  engine._only_crops = bool(only_crops) and bool(croppers)
+  return True
 
 
 def cropper_from_spec(spec):

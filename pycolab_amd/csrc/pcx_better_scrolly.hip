@@ -76,12 +76,14 @@ __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16
 
 template <int R, int C, int NWAVES>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                                         const pcx_buffers out, const stream::EpilogueArgs epi) {
+                                                                         const pcx_buffers out, const stream::EpilogueArgs epi,
+                                                                         const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
   constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32;
   constexpr int L = NS + ND + NB, CWP = MAX_CW | 1;
   constexpr int O_BD = 0, O_BDM = O_BD + QW, O_CID = O_BDM + NB * QW, O_WALL = O_CID + QW, O_TAB_END = O_WALL + FW;
   constexpr int O_CM = O_TAB_END, O_SDESC = (O_CM + WAVE * CWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
+  constexpr int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
   const uint32_t* const cid = lds + O_CID;    // list indices of every board dword's four cells (0xFF: no coin there)
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
   uint32_t* const mine = cm + lane * CWP;
   uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC);
   uint32_t* const skipv = lds + O_SKIP;
+  uint32_t* const wcorner = lds + O_WCORNER;
   const int CW = k.CW;
   __syncthreads();
 
@@ -228,13 +231,22 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
       // ---- _apply_and_clear_plot (engine.py:761-847) + state write-back -----------------
       st[W_FRAME * bp] = (uint32_t)frame;
       uint32_t sf = 0;
+      int32_t tw[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         st[(W_POS + s) * bp] = pack_pos(vr[s], vc[s]);
         sf |= ((uint32_t)vis[s] | ((uint32_t)prior[s] << 1) | ((uint32_t)east[s] << 2)) << (3 * s);
         const bool on = on_board(vr[s], vc[s]);
-        P.track[(size_t)s * bp + env] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
+        tw[s] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
+        P.track[(size_t)s * bp + env] = tw[s];
       }
+      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
+        stream::move_fused_windows(fc, [&](int ti) {
+          int32_t t = 0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) t = ti == s ? tw[s] : t;
+          return t;
+        }, frame == 0, env, lane, wcorner);
       st[W_FLAGS * bp] = (over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT) | (sf << F_SF_SHIFT) | ((uint32_t)left << F_LEFT_SHIFT);
       if (do_reset) {
         for (int i = 0; i < CW; ++i) st[(W_COINS + i) * bp] = mine[i];
@@ -293,8 +305,12 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
 #pragma unroll
   for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                      cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid);
+  if (!(fc && fc->only))
+    stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                        cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid);
+  if (fc)
+    stream::stream_windows<NS, ND, NB, QW, NWAVES>(fc, pm, R, C, env0, lds + O_BD, lds + O_BDM, cm, sdesc, skipv, CWP, lane, wave,
+                                                   wcorner, cid);
 }
 
 // ---------------------------------------------------------------------------
@@ -320,8 +336,10 @@ class BetterScrollyBackend : public Backend {
   int curtain_words() const override { return lay_.FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return lay_.pitch; }
+  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
 
  private:
+  stream::FusedCropsHolder fused_;
   Consts k_{};
   stream::EpilogueArgs epi_{};
   stream::Layout lay_;
@@ -456,7 +474,7 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
   int coop_below = lay_.QW >= 512 ? 3 : 5;
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
-  size_t lds = ((size_t)lay_.QW * (2 + NB) + lay_.FW + WAVE * (MAX_CW | 1) + 2 + 2 * NS * WAVE + WAVE) * 4;
+  size_t lds = ((size_t)lay_.QW * (2 + NB) + lay_.FW + WAVE * (MAX_CW | 1) + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4;
   int waves_per_cu = 8;  // single-wave workgroups: pad LDS so that about eight share a CU (as for scrolly_maze)
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   if (!coop && waves_per_cu > 0) {
@@ -471,8 +489,8 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
       PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_better_scrolly_step<r, c, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_better_scrolly_step<r, c, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     }                                                                                                             \
-    if (coop) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_); \
-    else hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_);          \
+    if (coop) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());          \
     launched = true;                                                                                              \
   }
   PCX_BS_SHAPES(X)

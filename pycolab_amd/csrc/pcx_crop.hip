@@ -9,6 +9,7 @@
 // Sprite positions come from the step kernel's per-step `track` words, drape
 // curtains (only for drape-tracking croppers) from its raw curtain export.
 #include "pcx_internal.h"
+#include "pcx_crop_window.h"
 
 #include <cstring>
 #include <vector>
@@ -28,8 +29,9 @@ struct CropParams {
   int64_t batch, bpad;
 };
 
-__device__ inline int imax(int a, int b) { return a > b ? a : b; }
-__device__ inline int imin(int a, int b) { return a < b ? a : b; }
+__host__ __device__ inline pcx::crop::WindowRule window_rule(const CropParams& p) {
+  return pcx::crop::WindowRule{p.rows, p.cols, p.R, p.C, p.margin_rows, p.margin_cols, p.off_rows, p.off_cols, p.saccade, p.pad_char};
+}
 
 // int(np.median(indices)) over the set cells of one curtain, along one axis
 __device__ int median_axis(const uint32_t* bits, int64_t stride, int R, int C, int n, bool rows_axis) {
@@ -75,43 +77,9 @@ __global__ void pcx_crop_update(CropParams p, const int32_t* track, const uint32
       }
     }
     int wrow = corner[2 * b], wcol = corner[2 * b + 1];
-    const int rows = p.rows, cols = p.cols, mrow = p.margin_rows, mcol = p.margin_cols;
-    auto rectify = [&]() {  // :539-542
-      wrow = imax(0, wrow) - imax(0, wrow + rows - p.R);
-      wcol = imax(0, wcol) - imax(0, wcol + cols - p.C);
-    };
-    auto initialise = [&](int off_r, int off_c) {  // :438-458
-      if (!have) { wrow = 0; wcol = 0; return; }
-      wrow = crow - off_r;
-      wcol = ccol - off_c;
-      if (p.pad_char < 0) rectify();
-    };
-    if (!has_corner[b]) {
-      initialise(rows / 2 + p.off_rows, cols / 2 + p.off_cols);
-      has_corner[b] = 1;
-    } else if (have) {
-      bool can_vert = (mrow - 1) <= (crow - wrow) && (crow - wrow) <= (rows - mrow);
-      bool can_horiz = (mcol - 1) <= (ccol - wcol) && (ccol - wcol) <= (cols - mcol);
-      if (p.pad_char < 0) {  // :491-504, including the `elif not can_horiz`
-        if (!can_vert) {
-          if (wrow <= 0) can_vert = crow <= mrow;
-          else if (wrow >= p.R - rows) can_vert = crow >= wrow + rows - mrow;
-        } else if (!can_horiz) {
-          if (wcol <= 0) can_horiz = ccol <= mcol;
-          else if (wcol >= p.C - cols) can_horiz = ccol >= wcol + cols - mcol;
-        }
-      }
-      if (can_vert && can_horiz) {  // _pan_to
-        int drow = imin(0, crow - wrow - mrow), dcol = imin(0, ccol - wcol - mcol);
-        if (drow == 0) drow += imax(0, crow - wrow - rows + mrow + 1);
-        if (dcol == 0) dcol += imax(0, ccol - wcol - cols + mcol + 1);
-        wrow += drow;
-        wcol += dcol;
-        if (p.pad_char < 0) rectify();
-      } else if (p.saccade) {
-        initialise(rows / 2, cols / 2);
-      }
-    }
+    bool has = has_corner[b] != 0;
+    pcx::crop::move_window(window_rule(p), have, crow, ccol, has, wrow, wcol);
+    has_corner[b] = 1;
     corner[2 * b] = wrow;
     corner[2 * b + 1] = wcol;
     top = wrow;
@@ -120,7 +88,7 @@ __global__ void pcx_crop_update(CropParams p, const int32_t* track, const uint32
     corner[2 * b] = top;
     corner[2 * b + 1] = left;
   }
-  error[b] = p.pad_char < 0 && (top < 0 || left < 0 || top + p.rows > p.R || left + p.cols > p.C);
+  error[b] = pcx::crop::window_leaves_observation(window_rule(p), top, left);
 }
 
 // _do_crop (cropping.py:118-227).  One lane per (environment, output dword);
@@ -219,6 +187,7 @@ struct pcx_cropper {
   pcx::ErrorPoll error_poll;
   uint8_t* bound = nullptr;  // caller-owned output planes (pcx_cropper_bind_output)
   bool tracks_drape = false;
+  bool fused = false;  // the engine's step kernel moves this window and writes its planes (pcx_engine_fuse_croppers)
   uint8_t* out_planes() const { return bound ? bound : planes.ptr; }
   int ensure_planes() {  // own output planes only when the caller bound none
     if (bound || planes.ptr) return 0;
@@ -281,16 +250,87 @@ int pcx_cropper_create(pcx_engine* e, const pcx_cropper_desc* d, pcx_cropper** o
   return 0;
 }
 
+// (Re)describe the engine's fused croppers to its backend.
+static int push_fused(pcx_engine* e) {
+  pcx::crop::FusedCrops fc{};
+  fc.n = (int32_t)e->fused.size();
+  fc.only = e->fused_only && fc.n > 0;
+  for (int i = 0; i < fc.n; ++i) {
+    pcx_cropper* c = e->fused[i];
+    const CropParams& p = c->p;
+    pcx::crop::FusedWindow& w = fc.w[i];
+    w.out = c->out_planes(); w.corner = c->corner.ptr; w.has_corner = c->has_corner.ptr; w.error = c->error.ptr;
+    w.rule = window_rule(p);
+    w.scrolling = p.kind == PCX_CROP_SCROLLING; w.top = p.top; w.left = p.left;
+    w.n_track = p.n_track;
+    for (int j = 0; j < p.n_track; ++j) w.track_sprite[j] = p.track_idx[j];
+    w.out_pitch = p.out_pitch;
+    w.pad_planes = 0;
+    for (int k = 0; k < p.L; ++k) if (p.pad_char >= 0 && (uint32_t)p.pad_char == p.chars[k]) w.pad_planes |= 1u << k;
+  }
+  return e->backend->set_fused_croppers(&fc);
+}
+
 void pcx_cropper_destroy(pcx_cropper* c) {
   if (!c) return;
   (void)hipSetDevice(c->e->device);
+  if (c->fused) {  // the step kernel must stop writing into this cropper's arrays first
+    pcx_engine* e = c->e;
+    for (size_t i = 0; i < e->fused.size(); ++i)
+      if (e->fused[i] == c) { e->fused.erase(e->fused.begin() + i); break; }
+    if (e->fused.empty()) e->fused_only = false;
+    (void)push_fused(e);
+  }
   delete c;
+}
+
+int pcx_engine_fuse_croppers(pcx_engine* e, pcx_cropper* const* croppers, int32_t n, int32_t only_crops, void* stream) {
+  if (!e || n < 0 || (n > 0 && !croppers)) return set_error(PCX_E_INVALID, "pcx_engine_fuse_croppers: bad arguments");
+  if (n > pcx::crop::MAX_FUSED_CROPPERS)
+    return set_error(PCX_E_UNSUPPORTED, "pcx_engine_fuse_croppers: at most %d croppers", pcx::crop::MAX_FUSED_CROPPERS);
+  PCX_HIP(hipSetDevice(e->device));
+  for (int i = 0; i < n; ++i) {
+    pcx_cropper* c = croppers[i];
+    if (!c || c->e != e) return set_error(PCX_E_INVALID, "pcx_engine_fuse_croppers: a cropper of another engine");
+    for (int j = 0; j < i; ++j) if (croppers[j] == c) return set_error(PCX_E_INVALID, "pcx_engine_fuse_croppers: a cropper twice");
+    if (c->tracks_drape || c->p.n_track > pcx::crop::MAX_FUSED_TRACK)
+      return set_error(PCX_E_UNSUPPORTED, "pcx_engine_fuse_croppers: croppers that track drapes (or more than %d sprites) "
+                                          "run as their own kernels", pcx::crop::MAX_FUSED_TRACK);
+    if (c->p.rows > 255 || c->p.cols > 255) return set_error(PCX_E_UNSUPPORTED, "pcx_engine_fuse_croppers: window larger than 255x255");
+    if (int rc = c->ensure_planes()) return rc;
+  }
+  const std::vector<pcx_cropper*> before = e->fused;
+  const bool before_only = e->fused_only;
+  auto was_fused = [&](pcx_cropper* c) { for (pcx_cropper* b : before) if (b == c) return true; return false; };
+  if (e->showtime && before_only)
+    for (int i = 0; i < n; ++i)
+      if (!was_fused(croppers[i]))
+        return set_error(PCX_E_STATE, "pcx_engine_fuse_croppers: the full observation is not being written (only_crops); "
+                                      "a cropper that joins now has nothing to start from");
+  e->fused.assign(croppers, croppers + n);
+  e->fused_only = n > 0 && only_crops != 0;
+  if (int rc = push_fused(e)) {  // the backend cannot: nothing changed
+    e->fused = before;
+    e->fused_only = before_only;
+    return rc;
+  }
+  for (pcx_cropper* c : before) c->fused = false;
+  for (int i = 0; i < n; ++i) {
+    pcx_cropper* c = croppers[i];
+    // in play already: crop the current observation once the stand-alone way, so that the window
+    // and the output planes are those a crop() at this point would have produced
+    if (e->showtime && !was_fused(c))
+      if (int rc = pcx_cropper_crop(c, stream)) return rc;
+    c->fused = true;
+  }
+  return 0;
 }
 
 int pcx_cropper_crop(pcx_cropper* c, void* stream) {
   if (!c) return set_error(PCX_E_INVALID, "pcx_cropper_crop: null cropper");
   pcx_engine* e = c->e;
   if (!e->showtime) return set_error(PCX_E_STATE, "pcx_cropper_crop: the engine is not in play");
+  if (c->fused) return 0;  // the step kernel moved the window and wrote the planes already
   if (c->tracks_drape && !e->curtains_fresh)
     return set_error(PCX_E_STATE, "pcx_cropper_crop: curtains were not exported by the last step");
   PCX_HIP(hipSetDevice(e->device));
@@ -330,6 +370,7 @@ int32_t pcx_cropper_plane_pitch(const pcx_cropper* c) { return c ? c->p.out_pitc
 int pcx_cropper_bind_output(pcx_cropper* c, uint8_t* planes_dev) {
   if (!c || !planes_dev) return set_error(PCX_E_INVALID, "pcx_cropper_bind_output: bad arguments");
   c->bound = planes_dev;
+  if (c->fused) return push_fused(c->e);  // the step kernel writes there from now on
   return 0;
 }
 

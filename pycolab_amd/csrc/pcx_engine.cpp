@@ -82,6 +82,11 @@ int Backend::set_epilogue(const pcx_epilogue_desc* d) {
   return set_error(PCX_E_UNSUPPORTED, "%s has no fused feature-array epilogue", kernel_name());
 }
 
+int Backend::set_fused_croppers(const crop::FusedCrops* fc) {
+  if (!fc || fc->n <= 0) return 0;
+  return set_error(PCX_E_UNSUPPORTED, "%s cannot run croppers itself", kernel_name());
+}
+
 ErrorPoll::~ErrorPoll() {
   if (dev) (void)hipFree(dev);
   if (host) (void)hipHostFree(host);

@@ -88,18 +88,21 @@ struct Bits {
 
 template <int R, int C, int NWAVES>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                                      const pcx_buffers out, const stream::EpilogueArgs epi) {
+                                                                      const pcx_buffers out, const stream::EpilogueArgs epi,
+                                                                      const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
   using B = Bits<R, C>;
   constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = B::FW, FWP = FW | 1;
   constexpr int L = NS + ND + NB;
   constexpr int O_BD = 0, O_BDM = O_BD + QW, O_TAB_END = O_BDM + NB * QW;
   constexpr int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
+  constexpr int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
   uint32_t* const flat = lds + O_FLAT;
   uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC);
   uint32_t* const skipv = lds + O_SKIP;
+  uint32_t* const wcorner = lds + O_WCORNER;
   __syncthreads();
 
   const int64_t env0 = (int64_t)blockIdx.x * WAVE;
@@ -196,11 +199,20 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
       // ---- _apply_and_clear_plot + state write-back -----------------------------------
       st[W_FRAME * bp] = (uint32_t)frame;
       st[W_FLAGS * bp] = (over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT);
+      int32_t tw[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         st[(W_POS + s) * bp] = (uint32_t)row[s] | ((uint32_t)col[s] << 16);
-        P.track[(size_t)s * bp + env] = row[s] | (col[s] << 8) | ((int)((k.visible >> s) & 1) << 16) | ((int)do_reset << 24);
+        tw[s] = row[s] | (col[s] << 8) | ((int)((k.visible >> s) & 1) << 16) | ((int)do_reset << 24);
+        P.track[(size_t)s * bp + env] = tw[s];
       }
+      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
+        stream::move_fused_windows(fc, [&](int ti) {
+          int32_t t = 0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) t = ti == s ? tw[s] : t;
+          return t;
+        }, frame == 0, env, lane, wcorner);
 #pragma unroll
       for (int i = 0; i < FW; ++i) st[(W_D + i) * bp] = x[i];
       if (a.export_curtains)
@@ -234,8 +246,12 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
 #pragma unroll
   for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                      flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+  if (!(fc && fc->only))
+    stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                        flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+  if (fc)
+    stream::stream_windows<NS, ND, NB, QW, NWAVES>(fc, pm, R, C, env0, lds + O_BD, lds + O_BDM, flat, sdesc, skipv, FWP, lane, wave,
+                                                   wcorner);
 }
 
 // ---------------------------------------------------------------------------
@@ -257,8 +273,10 @@ class HelloWorldBackend : public Backend {
   int curtain_words() const override { return lay_.FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return lay_.pitch; }
+  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
 
  private:
+  stream::FusedCropsHolder fused_;
   Consts k_{};
   stream::EpilogueArgs epi_{};
   stream::Layout lay_;
@@ -361,7 +379,7 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
-  size_t lds = ((size_t)lay_.QW * (1 + NB) + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE) * 4;
+  size_t lds = ((size_t)lay_.QW * (1 + NB) + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4;
   if (!coop && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
     if (want > 64 * 1024) want = 64 * 1024;
@@ -370,8 +388,8 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   bool launched = false;
 #define X(r, c)                                                                                                  \
   if (!launched && R_ == r && C_ == c) {                                                                         \
-    if (coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_); \
-    else hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_);          \
+    if (coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());          \
     launched = true;                                                                                             \
   }
   PCX_HW_SHAPES(X)

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/pcx.h"
+#include "pcx_crop_window.h"
 
 namespace pcx {
 
@@ -104,6 +105,11 @@ class Backend {
   // loop cannot produce it answer PCX_E_UNSUPPORTED (the caller then runs the
   // post-processor as its own kernel).
   virtual int set_epilogue(const pcx_epilogue_desc* d);
+  // include/pcx.h pcx_engine_fuse_croppers: the step kernel moves these windows
+  // and writes their planes itself; null (or n == 0) clears.  Backends whose
+  // kernel cannot answer PCX_E_UNSUPPORTED (the croppers then run as their own
+  // kernels, pcx_crop.hip).
+  virtual int set_fused_croppers(const crop::FusedCrops* fc);
 };
 
 Backend* make_scrolly_maze_backend();
@@ -127,4 +133,6 @@ struct pcx_engine {
   pcx::ErrorPoll error_poll;
   bool want_curtains = false;   // a drape-tracking cropper exists
   bool curtains_fresh = false;  // the last launch exported curtains
+  std::vector<struct pcx_cropper*> fused;  // croppers the step kernel runs itself (pcx_engine_fuse_croppers)
+  bool fused_only = false;                 // ... and the full-board planes are no longer written
 };

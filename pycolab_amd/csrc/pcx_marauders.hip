@@ -138,11 +138,13 @@ __device__ __forceinline__ int select_bit(uint32_t w, int n) {
 // NWAVES waves per workgroup: wave 0 steps the group, all share the render loop.
 template <int NWAVES, bool EPI = false>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                                    const pcx_buffers out, const stream::EpilogueArgs epi) {
+                                                                    const pcx_buffers out, const stream::EpilogueArgs epi,
+                                                                    const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
   constexpr int O_BD = 0, O_BDM = O_BD + QW, O_TAB_END = O_BDM + NB * QW;
   constexpr int O_FLAT = O_TAB_END, O_XS = O_FLAT + ND * WAVE * FWP, O_SDESC = (O_XS + WAVE * FWP + 1) & ~1,
                 O_SKIP = O_SDESC + 2 * NS * WAVE;
+  constexpr int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
   uint32_t* const flat = lds + O_FLAT;  // [ND][64][FWP]
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts 
   uint32_t* const xs = lds + O_XS + lane * FWP;         // scratch: the marauders' layer of the last repaint
   uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC);
   uint32_t* const skipv = lds + O_SKIP;
+  uint32_t* const wcorner = lds + O_WCORNER;
   __syncthreads();
 
   const int64_t env0 = (int64_t)blockIdx.x * WAVE;
@@ -391,13 +394,22 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts 
       // ---- _apply_and_clear_plot (engine.py:761-847) + state write-back ---------------
       st[W_FRAME * bp] = (uint32_t)frame;
       uint32_t sf = 0;
+      int32_t tw[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         st[(W_POS + s) * bp] = pack_pos(vr[s], vc[s]);
         sf |= ((uint32_t)vis[s] | ((uint32_t)prior[s] << 1)) << (2 * s);
         const bool on = on_board(vr[s], vc[s]);
-        P.track[(size_t)s * bp + env] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
+        tw[s] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
+        P.track[(size_t)s * bp + env] = tw[s];
       }
+      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
+        stream::move_fused_windows(fc, [&](int ti) {
+          int32_t t = 0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) t = ti == s ? tw[s] : t;
+          return t;
+        }, frame == 0, env, lane, wcorner);
       st[W_FLAGS * bp] = (over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT) | ((uint32_t)(dx + 1) << F_DX_SHIFT) | (sf << F_SF_SHIFT);
       st[W_RNG * bp] = draws;
 #pragma unroll
@@ -439,8 +451,12 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts 
 #pragma unroll
   for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                               flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+  if (!(fc && fc->only))
+    stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                 flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+  if (fc)
+    stream::stream_windows<NS, ND, NB, QW, NWAVES>(fc, pm, R, C, env0, lds + O_BD, lds + O_BDM, flat, sdesc, skipv, FWP, lane, wave,
+                                                   wcorner);
 }
 
 // ---------------------------------------------------------------------------
@@ -463,6 +479,7 @@ class MaraudersBackend : public Backend {
   int curtain_words() const override { return FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return pitch; }
+  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     if (!stream::fill_epilogue(epi_, d, cells, sprite_ch_, NS, drape_ch_, ND, bchar_ch_, NB))
       return set_error(PCX_E_UNSUPPORTED, "marauders backend: epilogue needs rows*cols %% 4 == 0");
@@ -470,6 +487,7 @@ class MaraudersBackend : public Backend {
   }
 
  private:
+  stream::FusedCropsHolder fused_;
   Consts k_{};
   stream::EpilogueArgs epi_{};
   int sprite_ch_[NS] = {}, drape_ch_[ND] = {}, bchar_ch_[NB] = {};
@@ -609,7 +627,7 @@ int MaraudersBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   int waves_per_cu = 4, nwaves = groups < (int64_t)num_cus_ * 5 ? 4 : 1;
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   if (const char* e = getenv("PCX_EM_WAVES")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 8) nwaves = v; }
-  const size_t words = (size_t)QW * (1 + NB) + (ND + 1) * WAVE * FWP + 2 + 2 * NS * WAVE + WAVE;
+  const size_t words = (size_t)QW * (1 + NB) + (ND + 1) * WAVE * FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS;
   size_t lds = words * 4;
   if (nwaves == 1 && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
@@ -617,7 +635,7 @@ int MaraudersBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     if (want > lds) lds = want;
   }
 #define PCX_EM_LAUNCH(nw, epi)                                                                                 \
-  hipLaunchKernelGGL((pcx_marauders_step<nw, epi>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_)
+  hipLaunchKernelGGL((pcx_marauders_step<nw, epi>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr())
   const bool epi = epi_.out != nullptr;  // the feature-array epilogue has its own instances
   if (nwaves == 8) { if (epi) PCX_EM_LAUNCH(8, true); else PCX_EM_LAUNCH(8, false); }
   else if (nwaves == 4) { if (epi) PCX_EM_LAUNCH(4, true); else PCX_EM_LAUNCH(4, false); }

@@ -21,6 +21,7 @@
 #pragma once
 
 #include "pcx_internal.h"
+#include "pcx_crop_window.h"
 
 namespace pcx {
 namespace stream {
@@ -88,6 +89,70 @@ struct EpilogueArgs {
 };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// What one board dword shows, from the LDS descriptors alone (shared by the
+// streaming loop and by the fused croppers' windows): the board dword and, as
+// 0x00 / 0xFF byte masks, which of its four cells every drape and sprite paints;
+// mb[b] = the backdrop-only character b's layer bytes (0 / 1) where nothing paints.
+template <int NS, int ND, int NB, int QW>
+struct Composer {
+  const PlaneMap<NS, ND, NB>& pm;
+  const uint32_t* backdrop4;
+  const uint32_t* bdmask;
+  const uint32_t* flat;
+  const uint2* sdesc;
+  const uint32_t* cell_ids;
+  int FWP;
+  __device__ __forceinline__ void operator()(uint32_t e_now, uint32_t q_now, uint32_t eF_now, uint32_t& d,
+                                             uint32_t (&md)[ND > 0 ? ND : 1], uint32_t (&ms)[NS > 0 ? NS : 1],
+                                             uint32_t (&mb)[NB > 0 ? NB : 1]) const {
+    // every LDS read of the dword is issued up front
+    d = backdrop4[q_now];
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+      uint32_t bits;
+      if (cell_ids != nullptr) {  // (uniform; resolved at compile time where the caller passes a constant)
+        const uint32_t ids = cell_ids[q_now];
+        bits = 0;
+        if (ids != 0xFFFFFFFFu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t id = (ids >> (8 * j)) & 0xFFu;
+            if (id != 0xFFu) bits |= ((flat[eF_now + (id >> 5)] >> (id & 31)) & 1u) << j;
+          }
+        }
+      } else {
+        bits = (flat[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;
+      }
+      const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;  // bit i -> byte i
+      uint32_t hi8 = m01 << 8;
+      asm("" : "+v"(hi8));  // keep LLVM from folding (x << 8) - x into a quarter-rate x * 255
+      md[dd] = hi8 - m01;   // 0x01 -> 0xFF per byte
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const uint2 sd = sdesc[s * WAVE + e_now];
+      ms[s] = sd.x == q_now ? sd.y : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) mb[b] = bdmask[b * QW + q_now];
+    uint32_t uni = 0;
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+      uni |= md[dd];
+      d = (d & ~md[dd]) | (pm.drape_ch4[dd] & md[dd]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      uni |= ms[s];
+      d = (d & ~ms[s]) | (pm.sprite_ch4[s] & ms[s]);
+    }
+    // rendering.py:177-179 layers[c] = (board == c): by construction the thing's
+    // own mask, or the backdrop's precomputed mask where no thing paints
+#pragma unroll
+    for (int b = 0; b < NB; ++b) mb[b] &= ~uni;
+  }
+};
+
 // The wavefront streams board + layers of the group's 64 environments.
 // One (environment e, board dword q) task per lane and iteration; consecutive
 // lanes take consecutive dwords, so every plane store of a wave covers 256
@@ -118,6 +183,7 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
 #pragma unroll
   for (int b = 0; b < NB; ++b) pb_b[b] = uniform_ptr(pb_board + pm.bchar_off[b]);
 
+  const Composer<NS, ND, NB, QW> compose{pm, backdrop4, bdmask, flat, sdesc, cell_ids, FWP};
   const bool any_skip = __ballot(skip[lane] != 0) != 0ull;
   // Drain the logic phase's own loads/stores once, here: the loop's stores are
   // inline asm the compiler cannot count, and without this it would protect a
@@ -168,57 +234,164 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
         asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(fo), "v"(f), "s"(fbase));
       }
     };
-    // every LDS read of the iteration is issued up front
-    uint32_t d = backdrop4[q_now];
-    uint32_t md[ND > 0 ? ND : 1], ms[NS > 0 ? NS : 1], mb[NB > 0 ? NB : 1];
-#pragma unroll
-    for (int dd = 0; dd < ND; ++dd) {
-      uint32_t bits;
-      if (cell_ids != nullptr) {  // (uniform; resolved at compile time where the caller passes a constant)
-        const uint32_t ids = cell_ids[q_now];
-        bits = 0;
-        if (ids != 0xFFFFFFFFu) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t id = (ids >> (8 * j)) & 0xFFu;
-            if (id != 0xFFu) bits |= ((flat[eF_now + (id >> 5)] >> (id & 31)) & 1u) << j;
-          }
-        }
-      } else {
-        bits = (flat[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;
-      }
-      const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;  // bit i -> byte i
-      uint32_t hi8 = m01 << 8;
-      asm("" : "+v"(hi8));  // keep LLVM from folding (x << 8) - x into a quarter-rate x * 255
-      md[dd] = hi8 - m01;   // 0x01 -> 0xFF per byte
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const uint2 sd = sdesc[s * WAVE + e_now];
-      ms[s] = sd.x == q_now ? sd.y : 0u;
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) mb[b] = bdmask[b * QW + q_now];
-    uint32_t uni = 0;
-#pragma unroll
-    for (int dd = 0; dd < ND; ++dd) {
-      uni |= md[dd];
-      d = (d & ~md[dd]) | (pm.drape_ch4[dd] & md[dd]);
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      uni |= ms[s];
-      d = (d & ~ms[s]) | (pm.sprite_ch4[s] & ms[s]);
-    }
+    uint32_t d, md[ND > 0 ? ND : 1], ms[NS > 0 ? NS : 1], mb[NB > 0 ? NB : 1];
+    compose(e_now, q_now, eF_now, d, md, ms, mb);
     put(pb_board, d);
-    // rendering.py:177-179 layers[c] = (board == c): by construction the thing's
-    // own mask, or the backdrop's precomputed mask where no thing paints
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) put_layer(pb_d[dd], md[dd] & 0x01010101u, epi.drape_slot[dd]);
 #pragma unroll
     for (int s = 0; s < NS; ++s) put_layer(pb_s[s], ms[s] & 0x01010101u, epi.sprite_slot[s]);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) put_layer(pb_b[b], mb[b] & ~uni, epi.bchar_slot[b]);
+    for (int b = 0; b < NB; ++b) put_layer(pb_b[b], mb[b], epi.bchar_slot[b]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused croppers (pcx_crop_window.h FusedCrops; include/pcx.h
+// pcx_engine_fuse_croppers).  The frame is in LDS when the step kernel streams
+// it, so the croppers' windows are cut from the same descriptors: the logic
+// wave moves every window (cropping.py:393-598, one lane per environment) and
+// all waves of the workgroup stream the windows' planes (cropping.py:118-227)
+// -- no second pass over the observation in HBM, no extra launches.
+// ---------------------------------------------------------------------------
+
+constexpr int WCORNER_WORDS = crop::MAX_FUSED_CROPPERS * WAVE;  // LDS words a kernel sets aside for the corners
+constexpr uint32_t WCORNER_NONE = 0x00008000u;                  // "this environment's window is not written"
+
+// Logic phase, lane == environment.  track_of(i) = the packed track word
+// (row | col << 8 | visible << 16) of template sprite i after this step.
+template <typename TrackOf>
+__device__ __forceinline__ void move_fused_windows(const crop::FusedCrops* fc, TrackOf track_of, bool new_episode,
+                                                   int64_t env, int lane, uint32_t* wcorner) {
+  const int n = fc->n;
+  for (int w = 0; w < n; ++w) {
+    const crop::FusedWindow& fw = fc->w[w];
+    int top = fw.top, left = fw.left;
+    if (fw.scrolling) {
+      bool has = !new_episode && fw.has_corner[env] != 0;  // a new episode is a new Engine (cropping.py:378-391)
+      int wrow = fw.corner[2 * env], wcol = fw.corner[2 * env + 1];
+      bool have = false;
+      int crow = 0, ccol = 0;
+      for (int i = 0; i < fw.n_track; ++i) {  // :544-549 the first visible sprite of to_track
+        const int32_t t = track_of(fw.track_sprite[i]);
+        if (!have && ((t >> 16) & 1)) { crow = t & 0xFF; ccol = (t >> 8) & 0xFF; have = true; }
+      }
+      crop::move_window(fw.rule, have, crow, ccol, has, wrow, wcol);
+      fw.has_corner[env] = 1;
+      top = wrow;
+      left = wcol;
+    }
+    fw.corner[2 * env] = top;
+    fw.corner[2 * env + 1] = left;
+    const bool err = crop::window_leaves_observation(fw.rule, top, left);
+    fw.error[env] = (uint8_t)err;
+    wcorner[w * WAVE + lane] = err ? WCORNER_NONE : (((uint32_t)top & 0xFFFFu) | ((uint32_t)left << 16));
+  }
+}
+
+// All waves of the workgroup.  One (environment, output dword) task per lane;
+// a dword whose four cells lie in one window row and on the board is two
+// composed board dwords funnelled by the window's byte phase, anything else
+// (row ends, the board's edge, the pad region) goes cell by cell.
+//   plane_of_*: the layer (0-based, plane 1 + k) every thing / backdrop-only character owns.
+template <int NS, int ND, int NB, int QW, int NWAVES>
+__device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const PlaneMap<NS, ND, NB>& pm, int R, int C,
+                                               int64_t env0, const uint32_t* backdrop4, const uint32_t* bdmask,
+                                               const uint32_t* flat, const uint2* sdesc, const uint32_t* skip, int FWP,
+                                               int lane, int wave, const uint32_t* wcorner,
+                                               const uint32_t* cell_ids = nullptr) {
+  constexpr int L = NS + ND + NB;
+  constexpr uint32_t pitch = 4u * QW;
+  const Composer<NS, ND, NB, QW> compose{pm, backdrop4, bdmask, flat, sdesc, cell_ids, FWP};
+  uint32_t lay_s[NS > 0 ? NS : 1], lay_d[ND > 0 ? ND : 1], lay_b[NB > 0 ? NB : 1];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) lay_s[s] = pm.sprite_off[s] / pitch - 1u;
+#pragma unroll
+  for (int d = 0; d < ND; ++d) lay_d[d] = pm.drape_off[d] / pitch - 1u;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) lay_b[b] = pm.bchar_off[b] / pitch - 1u;
+  const int n = fc->n;
+  for (int w = 0; w < n; ++w) {
+    const crop::FusedWindow& fw = fc->w[w];
+    const int rows = fw.rule.rows, cols = fw.rule.cols, wcells = rows * cols;
+    const uint32_t opitch = (uint32_t)fw.out_pitch, qw = opitch >> 2, total = (uint32_t)WAVE * qw;
+    const uint32_t ostride = (uint32_t)(1 + L) * opitch;
+    uint8_t* const obase = uniform_ptr(fw.out + (size_t)env0 * ostride);
+    const uint32_t pad_planes = fw.pad_planes, pad4 = (uint32_t)(fw.rule.pad_char & 0xFF) * 0x01010101u;
+    for (uint32_t f0 = (uint32_t)wave * WAVE; f0 < total; f0 += NWAVES * WAVE) {
+      const uint32_t f = f0 + (uint32_t)lane;
+      if (f >= total) continue;
+      const uint32_t e = f / qw, q = f - e * qw;
+      if (skip[e]) continue;
+      const uint32_t cw = wcorner[w * WAVE + e];
+      if (cw == WCORNER_NONE) continue;
+      const int top = (int)(int16_t)(cw & 0xFFFFu), left = (int)(int16_t)(cw >> 16);
+      const int cell0 = (int)q * 4, orow = cell0 / cols, ocol = cell0 - orow * cols;
+      const int sr = top + orow, sc = left + ocol;
+      const uint32_t eF = e * (uint32_t)FWP;
+      uint32_t od = 0, omd[ND > 0 ? ND : 1] = {}, oms[NS > 0 ? NS : 1] = {}, omb[NB > 0 ? NB : 1] = {};
+      const bool fast = cell0 + 3 < wcells && ocol + 3 < cols && (unsigned)sr < (unsigned)R && sc >= 0 && sc + 3 < C;
+      if (fast) {
+        const uint32_t a = (uint32_t)(sr * C + sc), phase = a & 3u, qa = a >> 2;
+        uint32_t d0, md0[ND > 0 ? ND : 1], ms0[NS > 0 ? NS : 1], mb0[NB > 0 ? NB : 1];
+        compose(e, qa, eF, d0, md0, ms0, mb0);
+        od = d0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) omd[d] = md0[d];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) oms[s] = ms0[s];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) omb[b] = mb0[b];
+        if (phase) {
+          uint32_t d1, md1[ND > 0 ? ND : 1], ms1[NS > 0 ? NS : 1], mb1[NB > 0 ? NB : 1];
+          compose(e, qa + 1, eF, d1, md1, ms1, mb1);
+          od = __builtin_amdgcn_alignbyte(d1, od, phase);
+#pragma unroll
+          for (int d = 0; d < ND; ++d) omd[d] = __builtin_amdgcn_alignbyte(md1[d], omd[d], phase);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) oms[s] = __builtin_amdgcn_alignbyte(ms1[s], oms[s], phase);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) omb[b] = __builtin_amdgcn_alignbyte(mb1[b], omb[b], phase);
+        }
+      } else {
+        int r = orow, c = ocol;
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j, ++c) {
+          if (c >= cols) { c = 0; ++r; }
+          if (cell0 + j >= wcells) break;  // past the window: plane padding, zeros
+          const int rr = top + r, cc = left + c;
+          const uint32_t sh = 8u * (uint32_t)j;
+          if ((unsigned)rr < (unsigned)R && (unsigned)cc < (unsigned)C) {
+            const uint32_t a = (uint32_t)(rr * C + cc), bs = 8u * (a & 3u);
+            uint32_t d1, md1[ND > 0 ? ND : 1], ms1[NS > 0 ? NS : 1], mb1[NB > 0 ? NB : 1];
+            compose(e, a >> 2, eF, d1, md1, ms1, mb1);
+            od |= ((d1 >> bs) & 0xFFu) << sh;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) omd[d] |= ((md1[d] >> bs) & 0xFFu) << sh;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) oms[s] |= ((ms1[s] >> bs) & 0xFFu) << sh;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) omb[b] |= ((mb1[b] >> bs) & 0xFFu) << sh;
+          } else {  // cropping.py:186-191 the pad character and its layer
+            od |= (pad4 & 0xFFu) << sh;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) omd[d] |= ((pad_planes >> lay_d[d]) & 1u) << sh;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) oms[s] |= ((pad_planes >> lay_s[s]) & 1u) << sh;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) omb[b] |= ((pad_planes >> lay_b[b]) & 1u) << sh;
+          }
+        }
+      }
+      uint32_t* const o = reinterpret_cast<uint32_t*>(obase + e * ostride) + q;
+      o[0] = od;
+#pragma unroll
+      for (int d = 0; d < ND; ++d) o[(1u + lay_d[d]) * qw] = omd[d] & 0x01010101u;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) o[(1u + lay_s[s]) * qw] = oms[s] & 0x01010101u;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) o[(1u + lay_b[b]) * qw] = omb[b] & 0x01010101u;
+    }
   }
 }
 
@@ -244,6 +417,23 @@ inline bool fill_epilogue(EpilogueArgs& a, const pcx_epilogue_desc* d, int cells
   }
   return true;
 }
+
+// Host side of the fused croppers: their description lives in device memory (the
+// kernels take a pointer, null = none), rewritten only when croppers are fused
+// or released -- never on the step path.
+struct FusedCropsHolder {
+  DevArray<crop::FusedCrops> dev;
+  bool on = false;
+  int set(const crop::FusedCrops* fc) {
+    PCX_HIP(hipDeviceSynchronize());  // no launch in flight may still read the old description
+    if (!fc || fc->n <= 0) { on = false; return 0; }
+    if (!dev.ptr) { if (int rc = dev.alloc(1)) return rc; }
+    PCX_HIP(hipMemcpy(dev.ptr, fc, sizeof *fc, hipMemcpyHostToDevice));
+    on = true;
+    return 0;
+  }
+  const crop::FusedCrops* ptr() const { return on ? dev.ptr : nullptr; }
+};
 
 // Constants of the streaming phase every backend derives the same way.
 struct Layout {

@@ -76,13 +76,15 @@ __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16
 // per workgroup (wave 0 steps the group, all of them share the render loop).
 template <int NS, int R, int C, int NB, int NWAVES, bool EPI = false>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                                    const pcx_buffers out, const stream::EpilogueArgs epi) {
+                                                                    const pcx_buffers out, const stream::EpilogueArgs epi,
+                                                                    const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
   constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32, FWP = FW | 1;
   constexpr int L = NS + 1 + NB, IP = NS - 1, NBOX = NS - 1;
   constexpr int O_BD = 0, O_BDM = O_BD + QW, O_GOAL = O_BDM + NB * QW, O_BBLK = O_GOAL + R, O_PBLK = O_BBLK + R,
                 O_TAB_END = O_PBLK + R;
   constexpr int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
+  constexpr int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
   const uint32_t* const goal_rows = lds + O_GOAL;
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
   uint32_t* const flat = lds + O_FLAT;
   uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC);
   uint32_t* const skipv = lds + O_SKIP;
+  uint32_t* const wcorner = lds + O_WCORNER;
   __syncthreads();
 
   const int64_t env0 = (int64_t)blockIdx.x * WAVE;
@@ -264,13 +267,22 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
       st[W_FRAME * bp] = (uint32_t)frame;
       st[W_FLAGS * bp] = (over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT) | ((uint32_t)(last & 0xFF) << F_LAST_SHIFT);
       uint32_t sf = 0;
+      int32_t tw[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         st[(W_POS + s) * bp] = pack_pos(vr[s], vc[s]);
         sf |= ((uint32_t)vis[s] | ((uint32_t)prior[s] << 1)) << (2 * s);
         const bool on = on_board(vr[s], vc[s]);
-        P.track[(size_t)k.tmpl_index[s] * bp + env] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
+        tw[s] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
+        P.track[(size_t)k.tmpl_index[s] * bp + env] = tw[s];
       }
+      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
+        stream::move_fused_windows(fc, [&](int ti) {
+          int32_t t = 0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) t = ti == (int)k.tmpl_index[s] ? tw[s] : t;
+          return t;
+        }, frame == 0, env, lane, wcorner);
       st[W_SFLAGS * bp] = sf;
       out.reward[env] = reward;
       out.reward_set[env] = (uint8_t)reward_set;
@@ -292,8 +304,12 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
 #pragma unroll
   for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  stream::stream_planes<NS, 1, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                              flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+  if (!(fc && fc->only))
+    stream::stream_planes<NS, 1, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+  if (fc)
+    stream::stream_windows<NS, 1, NB, QW, NWAVES>(fc, pm, R, C, env0, lds + O_BD, lds + O_BDM, flat, sdesc, skipv, FWP, lane, wave,
+                                                  wcorner);
 }
 
 // ---------------------------------------------------------------------------
@@ -321,6 +337,7 @@ class WarehouseBackend : public Backend {
   int curtain_words() const override { return lay_.FW; }
   int64_t batch_pad() const override { return bpad_; }
   int plane_pitch() const override { return lay_.pitch; }
+  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     if (!stream::fill_epilogue(epi_, d, lay_.cells, sprite_ch_, NS_, &drape_ch_, 1, bchar_ch_, NB_))
       return set_error(PCX_E_UNSUPPORTED, "warehouse backend: epilogue needs rows*cols %% 4 == 0");
@@ -328,6 +345,7 @@ class WarehouseBackend : public Backend {
   }
 
  private:
+  stream::FusedCropsHolder fused_;
   Consts k_{};
   stream::EpilogueArgs epi_{};
   int sprite_ch_[MAX_NS] = {}, drape_ch_ = 0, bchar_ch_[MAX_NB] = {};
@@ -485,7 +503,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
-  const size_t words = (size_t)lay_.QW * (1 + NB_) + 3 * R_ + WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE + WAVE;
+  const size_t words = (size_t)lay_.QW * (1 + NB_) + 3 * R_ + WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE + WAVE + stream::WCORNER_WORDS;
   size_t lds = words * 4;
   if (!coop && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
@@ -495,7 +513,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   bool launched = false;
   const bool epi = epi_.out != nullptr;  // the feature-array epilogue has its own instances (whole-dword boards only)
 #define PCX_WM_LAUNCH(ns, r, c, nb, nw, ep)                                                                  \
-  hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, nw, ep>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_)
+  hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, nw, ep>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr())
 #define X(ns, r, c, nb)                                                                                     \
   if (!launched && NS_ == ns && R_ == r && C_ == c && NB_ == nb) {                                          \
     if constexpr ((r * c) % 4 == 0) {                                                                       \

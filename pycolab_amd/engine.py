@@ -57,6 +57,8 @@ class Engine(object):
     self._actions = None
     self._steps_launched = 0  # reset / step launches so far (fused epilogues know when they are fresh)
     self._croppers = []
+    self._fuse_request = None  # cropping.fuse_croppers() before its_showtime(): (croppers, only_crops)
+    self._only_crops = False   # fused croppers only: the full-board planes are not written
 
   def _register_cropper(self, cropper):
     if cropper not in self._croppers:
@@ -229,6 +231,10 @@ class Engine(object):
     self._current_update_group = None
     for cropper in self._croppers:  # croppers attached with set_engine() before showtime
       cropper._create_native()
+    if self._fuse_request is not None:  # fused croppers see frame 0 like every other frame
+      from pycolab_amd import cropping
+      request, self._fuse_request = self._fuse_request, None
+      cropping.fuse_croppers(self, *request)
     N.check(lib.pcx_engine_reset(self._native, None, dev.current_stream(self._device_id)))
     self._steps_launched += 1
     return self._result()

@@ -145,3 +145,136 @@ def test_device_cropper_outputs_are_zero_copy_device_tensors_and_survive_a_new_e
       np.testing.assert_array_equal(board[0], ref)
       obs = eng.play(np.full((B,), step % 4, np.int32))[0]
     eng.close()
+
+
+# ---- croppers fused into the step kernel (cropping.fuse_croppers, pcx_engine_fuse_croppers) ----
+
+FUSABLE = ['warehouse_L1', 'marauders', 'better_scrolly_maze_L0', 'better_scrolly_maze_L1', 'better_scrolly_maze_L2']
+
+
+def _fusable(specs, drapes):
+  """Up to four croppers the step kernels can run themselves: fixed, or tracking sprites only."""
+  picked = [i for i, sp in enumerate(specs) if sp['kind'] == 'fixed' or not (set(sp['to_track']) & drapes)]
+  return picked[:4]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('only_crops', [False, True])
+@pytest.mark.parametrize('name', FUSABLE)
+def test_fused_croppers_match_reference(name, only_crops):
+  """The reference's own cropped observations, from croppers the step kernel
+  runs itself (requested before its_showtime(): frame 0 included); the croppers
+  the kernel cannot run (drape trackers) stay stand-alone next to them."""
+  from pycolab_amd.engine import Engine
+  tr = helpers.load_trace(name)
+  t = helpers.load_template(tr['template'])
+  T, E = tr['actions'].shape
+  eng = Engine.from_template(t, batch=E, auto_reset=True, seed=helpers.GOLDEN_RNG_SEED)
+  specs = specs_of(tr)
+  crops = [cropping.cropper_from_spec(sp) for sp in specs]
+  drapes = {chr(d['ch']) for d in t.drapes}
+  fused = _fusable(specs, drapes)
+  if only_crops:  # the stand-alone croppers would read a stale observation
+    crops = [crops[i] for i in fused]
+    kept = fused
+    fused = list(range(len(crops)))
+  else:
+    kept = list(range(len(crops)))
+    for cr in crops:
+      cr.set_engine(eng)
+  assert cropping.fuse_croppers(eng, [crops[i] for i in fused], only_crops=only_crops) is None  # deferred to showtime
+  chars = list(tr['chars'])
+  obs = eng.its_showtime()[0]
+  assert all(crops[i]._fused for i in fused), 'the step kernel of %s should run these croppers itself' % name
+  assert eng._only_crops == only_crops
+  for step in range(T + 1):
+    if step:
+      obs = eng.play(tr['actions'][step - 1])[0]
+    if not only_crops:
+      np.testing.assert_array_equal(helpers.to_np(obs.board), tr['boards'][step], err_msg='frame %d board' % step)
+    for i, cr in enumerate(crops):
+      out = cr.crop(obs)
+      want = tr['crop_%d' % kept[i]][step]
+      np.testing.assert_array_equal(helpers.to_np(out.board), want, err_msg='cropper %d frame %d board' % (kept[i], step))
+      for k, ch in enumerate(chars):
+        np.testing.assert_array_equal(helpers.to_np(out.layers[chr(ch)]).astype(np.uint8), (want == ch).astype(np.uint8),
+                                      err_msg='cropper %d frame %d layer %r' % (kept[i], step, chr(ch)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', ['coop', 'single'])
+@pytest.mark.parametrize('name,batch', [('better_scrolly_maze_L0', 3000), ('better_scrolly_maze_L2', 700), ('warehouse_L0', 5000),
+                                        ('marauders', 1500), ('hello_world', 900)])
+def test_fused_croppers_equal_stand_alone_croppers(name, batch, shape, monkeypatch):
+  """Many groups (a ragged last one), both launch shapes, episodes ending and
+  restarting: the windows the step kernel writes are the windows the
+  stand-alone cropper kernels cut from the observation; fusing in mid-episode
+  carries the windows over; releasing the croppers hands them back."""
+  import torch
+  from pycolab_amd.engine import Engine
+  monkeypatch.setenv('PCX_COOP_BELOW', '1000000' if shape == 'coop' else '0')
+  if name == 'marauders':
+    monkeypatch.setenv('PCX_EM_WAVES', '4' if shape == 'coop' else '1')
+  t = helpers.load_template(name)
+  names = [chr(sp['ch']) for sp in t.sprites]
+  track = ['P'] if 'P' in names else names[:1]
+  R, C = t.rows, t.cols
+
+  def make():
+    return [cropping.ScrollingCropper(5, 7, track, pad_char=chr(t.chars[0]), scroll_margins=(1, 2)),
+            cropping.ScrollingCropper(min(R, 7), min(C, 10), track, scroll_margins=(2, 3), initial_offset=(1, -2)),
+            cropping.FixedCropper((R - 3, C - 5), 6, 9, pad_char=chr(t.chars[1])),
+            cropping.ScrollingCropper(3, 3, track, pad_char=chr(t.chars[0]), scroll_margins=(None, None), saccade=False)]
+
+  a = Engine.from_template(t, batch=batch, auto_reset=True, seed=7)
+  b = Engine.from_template(t, batch=batch, auto_reset=True, seed=7)
+  ca, cb = make(), make()
+  for cr in ca:
+    cr.set_engine(a)
+  for cr in cb:
+    cr.set_engine(b)
+  cropping.fuse_croppers(a, ca)
+  oa, ob = a.its_showtime()[0], b.its_showtime()[0]
+  assert all(cr._fused for cr in ca) and not any(cr._fused for cr in cb)
+
+  def same(step):
+    assert torch.equal(oa.board, ob.board), 'step %d: boards differ' % step
+    for i, (x, y) in enumerate(zip(ca, cb)):
+      wx, wy = x.crop(oa), y.crop(ob)
+      assert torch.equal(wx.board, wy.board), 'step %d cropper %d: boards differ' % (step, i)
+      for ch in wy.layers:
+        assert torch.equal(wx.layers[ch], wy.layers[ch]), 'step %d cropper %d layer %r' % (step, i, ch)
+
+  same(0)
+  n_act = int(t.n_actions)
+  rng = np.random.RandomState(3)
+  for step in range(1, 49):
+    acts = rng.randint(0, n_act, size=batch).astype(np.int32)
+    oa, ob = a.play(acts)[0], b.play(acts)[0]
+    if step % 3 == 0 or step > 40:
+      same(step)
+    if step == 20:  # b's croppers join its step kernel in mid-episode ...
+      assert cropping.fuse_croppers(b, cb) is True
+    if step == 30:  # ... and a's leave theirs
+      assert cropping.fuse_croppers(a, []) is True
+      assert not any(cr._fused for cr in ca)
+  a.close()
+  b.close()
+
+
+@pytest.mark.gpu
+def test_fuse_croppers_answers_false_where_the_kernel_cannot():
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('scrolly_maze_L0')   # pcx_scrolly_maze_step has no fused cropper path
+  eng = Engine.from_template(t, batch=8, auto_reset=True)
+  cr = cropping.ScrollingCropper(5, 11, ['P'], pad_char=' ', scroll_margins=(1, 2))
+  cr.set_engine(eng)
+  obs = eng.its_showtime()[0]
+  assert cropping.fuse_croppers(eng, [cr]) is False and not cr._fused
+  assert helpers.to_np(cr.crop(obs).board).shape == (8, 5, 11)   # still crops, as its own kernels
+  t2 = helpers.load_template('warehouse_L0')
+  eng2 = Engine.from_template(t2, batch=8, auto_reset=True)
+  drape = cropping.ScrollingCropper(3, 3, ['X'], pad_char=' ', scroll_margins=(None, None))
+  drape.set_engine(eng2)
+  eng2.its_showtime()
+  assert cropping.fuse_croppers(eng2, [drape]) is False          # drape trackers stay stand-alone
