@@ -65,6 +65,35 @@ def main():
     ms = timed(lambda: cr.crop(obs), args.steps)
     add(name, 'pcx_crop_update + pcx_crop_copy, %d envs, %d planes' % (eng.batch, P), ms,
         eng.batch * (P * cells + P * ((cells + 3) & ~3) + 24))
+  # the example's own cropper set (better_scrolly_maze.py:237-247) on every observation: as their own kernels
+  # after the step, fused into the step kernel, and fused with the full-board planes no longer written
+  def example_croppers():
+    return [cropping.ScrollingCropper(10, 30, ['P'], initial_offset=(-2, -12)),
+            cropping.ScrollingCropper(7, 10, ['c'], pad_char=' ', scroll_margins=(None, 3)),
+            cropping.FixedCropper((3, 9), 12, 20, pad_char=' ')]
+  tape = torch.randint(0, 5, (16, eng.batch), dtype=torch.int32, device='cuda')
+  counter = [0]
+
+  def one_step():
+    eng.step(tape[counter[0] % 16]); counter[0] += 1
+  crs = example_croppers()
+  for cr in crs:
+    cr.set_engine(eng)
+    cr.crop(obs)
+  win_bytes = eng.batch * sum(P * ((cr.rows * cr.cols + 3) & ~3) + 24 for cr in crs)
+  step_bytes = eng.batch * 32131
+  ms_step = timed(one_step, args.steps)
+  ms_sep = timed(lambda: (one_step(), [cr.crop(obs) for cr in crs]), args.steps)
+  assert cropping.fuse_croppers(eng, crs) is True
+  ms_fused = timed(one_step, args.steps)
+  assert cropping.fuse_croppers(eng, crs, only_crops=True) is True
+  ms_only = timed(one_step, args.steps)
+  add('play() alone, better_scrolly_maze 45x89', 'pcx_better_scrolly_step, %d envs' % eng.batch, ms_step, step_bytes)
+  add('play() + the example\'s three croppers (seven kernels)', 'pcx_better_scrolly_step + 3 x (pcx_crop_update + pcx_crop_copy)',
+      ms_sep, step_bytes + win_bytes + eng.batch * sum(P * cr.rows * cr.cols for cr in crs))
+  add('play() with the three croppers fused', 'pcx_better_scrolly_step', ms_fused, step_bytes + win_bytes)
+  add('... fused, windows only (full-board planes not written)', 'pcx_better_scrolly_step', ms_only,
+      step_bytes - eng.batch * P * 4008 + win_bytes)
   eng.close()
 
   # post-processors on the BASELINE config games
