@@ -182,6 +182,8 @@ def bind(lib, symbols, rename=None):
   """Attach restype/argtypes for every (name, restype, argtypes) entry."""
   for name, restype, argtypes in symbols:
     real = rename(name) if rename else name
+    if os.environ.get('PCX_LIB') and not hasattr(lib, real):
+      continue  # an older build selected for an A/B run: calling what it lacks raises AttributeError then
     fn = getattr(lib, real)  # AttributeError if the symbol is missing
     fn.restype = restype
     fn.argtypes = argtypes

@@ -32,7 +32,7 @@ struct Consts {
   uint32_t dx[NS], dy[NS];  // per action a: ((d >> 2a) & 3) - 1   (hello_world.py:98-99)
   uint32_t above[NS];
   uint32_t init[W_D];
-  uint32_t sprite_off[NS], sprite_ch4[NS], drape_off, drape_ch4, bchar_off[NB];
+  uint32_t sprite_off[NS], sprite_ch4[NS], drape_off, drape_ch4, bchar_off[NB], bchar_ch4[NB];
 };
 
 struct Ptrs {
@@ -243,15 +243,15 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
 #pragma unroll
   for (int s = 0; s < NS; ++s) { pm.sprite_off[s] = k.sprite_off[s]; pm.sprite_ch4[s] = k.sprite_ch4[s]; }
   pm.drape_off[0] = k.drape_off; pm.drape_ch4[0] = k.drape_ch4;
+  uint32_t bch4[NB > 0 ? NB : 1] = {};
 #pragma unroll
-  for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
+  for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
     stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                         flat, sdesc, skipv, FWP, lane, wave, epi, env0);
   if (fc)
-    stream::stream_windows<NS, ND, NB, QW, NWAVES>(fc, pm, R, C, env0, lds + O_BD, lds + O_BDM, flat, sdesc, skipv, FWP, lane, wave,
-                                                   wcorner);
+    stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
 }
 
 // ---------------------------------------------------------------------------
@@ -341,6 +341,7 @@ int HelloWorldBackend::init(const pcx_template& t, int64_t batch) {
     if (thing) continue;
     if (nb >= NB) return set_error(PCX_E_INVALID, "hello_world backend: inconsistent character set");
     k.bchar_off[nb] = (uint32_t)(1 + i) * lay_.pitch;
+    k.bchar_ch4[nb] = (uint32_t)ch * 0x01010101u;
     uint8_t* m = reinterpret_cast<uint8_t*>(tab.data() + (size_t)lay_.QW * (1 + nb));
     for (int c = 0; c < lay_.cells; ++c) m[c] = t.backdrop[c] == ch;
     ++nb;

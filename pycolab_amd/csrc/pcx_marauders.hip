@@ -56,7 +56,7 @@ struct Consts {
   uint32_t confined;        // bit s
   uint32_t above[NS];       // bit j: sprite j in front of sprite s; bit NS + d: drape slot d in front
   uint32_t init[W_B];       // initial scalar words
-  uint32_t sprite_off[NS], sprite_ch4[NS], drape_off[ND], drape_ch4[ND], bchar_off[NB];
+  uint32_t sprite_off[NS], sprite_ch4[NS], drape_off[ND], drape_ch4[ND], bchar_off[NB], bchar_ch4[NB];
   uint32_t seed_lo, seed_hi, envoff_lo, envoff_hi;  // np.random.choice stand-in (shared with the oracle)
   int32_t drape_slot_tmpl[ND];  // template drape index of slot d
 };
@@ -448,15 +448,15 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts 
   for (int s = 0; s < NS; ++s) { pm.sprite_off[s] = k.sprite_off[s]; pm.sprite_ch4[s] = k.sprite_ch4[s]; }
 #pragma unroll
   for (int d = 0; d < ND; ++d) { pm.drape_off[d] = k.drape_off[d]; pm.drape_ch4[d] = k.drape_ch4[d]; }
+  uint32_t bch4[NB > 0 ? NB : 1] = {};
 #pragma unroll
-  for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
+  for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
     stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                  flat, sdesc, skipv, FWP, lane, wave, epi, env0);
   if (fc)
-    stream::stream_windows<NS, ND, NB, QW, NWAVES>(fc, pm, R, C, env0, lds + O_BD, lds + O_BDM, flat, sdesc, skipv, FWP, lane, wave,
-                                                   wcorner);
+    stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
 }
 
 // ---------------------------------------------------------------------------
@@ -575,6 +575,7 @@ int MaraudersBackend::init(const pcx_template& t, int64_t batch) {
     if (thing) continue;
     if (nb >= NB) return set_error(PCX_E_INVALID, "marauders backend: inconsistent character set");
     k.bchar_off[nb] = (uint32_t)(1 + i) * pitch;
+    k.bchar_ch4[nb] = (uint32_t)ch * 0x01010101u;
     bchar_ch_[nb] = ch;
     uint8_t* m = reinterpret_cast<uint8_t*>(tab.data() + (size_t)QW * (1 + nb));
     for (int c = 0; c < cells; ++c) m[c] = t.backdrop[c] == ch;

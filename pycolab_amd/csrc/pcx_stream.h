@@ -289,27 +289,37 @@ __device__ __forceinline__ void move_fused_windows(const crop::FusedCrops* fc, T
   }
 }
 
-// All waves of the workgroup.  One (environment, output dword) task per lane;
-// a dword whose four cells lie in one window row and on the board is two
-// composed board dwords funnelled by the window's byte phase, anything else
-// (row ends, the board's edge, the pad region) goes cell by cell.
-//   plane_of_*: the layer (0-based, plane 1 + k) every thing / backdrop-only character owns.
-template <int NS, int ND, int NB, int QW, int NWAVES>
-__device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const PlaneMap<NS, ND, NB>& pm, int R, int C,
-                                               int64_t env0, const uint32_t* backdrop4, const uint32_t* bdmask,
-                                               const uint32_t* flat, const uint2* sdesc, const uint32_t* skip, int FWP,
-                                               int lane, int wave, const uint32_t* wcorner,
+// All waves of the workgroup.  One (environment, output dword) task per lane:
+// every output cell has exactly one source cell, so a lane asks the LDS
+// descriptors who paints its four cells (backdrop character, a curtain's bit,
+// the pad character outside the board: cropping.py:186-191), lays the painted
+// sprites that fall into the window over the dword, and derives every layer from
+// the finished board dword by a byte-wise compare -- rendering.py:177-179
+// layers[c] = (board == c), which is how the reference builds the layers it
+// crops.  Consecutive lanes write consecutive dwords of one output plane.
+//   bchar_ch4: the backdrop-only characters, replicated into four bytes (plane order of pm.bchar_off).
+template <int NS, int ND, int NB, int QW, int NWAVES, int R, int C>
+__device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const PlaneMap<NS, ND, NB>& pm,
+                                               const uint32_t (&bchar_ch4)[NB > 0 ? NB : 1], int64_t env0,
+                                               const uint32_t* backdrop4, const uint32_t* flat, const uint2* sdesc,
+                                               const uint32_t* skip, int FWP, int lane, int wave, const uint32_t* wcorner,
                                                const uint32_t* cell_ids = nullptr) {
   constexpr int L = NS + ND + NB;
   constexpr uint32_t pitch = 4u * QW;
-  const Composer<NS, ND, NB, QW> compose{pm, backdrop4, bdmask, flat, sdesc, cell_ids, FWP};
+  const uint8_t* const backdrop1 = reinterpret_cast<const uint8_t*>(backdrop4);
+  const uint8_t* const cell_id1 = reinterpret_cast<const uint8_t*>(cell_ids);
   uint32_t lay_s[NS > 0 ? NS : 1], lay_d[ND > 0 ? ND : 1], lay_b[NB > 0 ? NB : 1];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) lay_s[s] = pm.sprite_off[s] / pitch - 1u;
+  for (int s = 0; s < NS; ++s) lay_s[s] = pm.sprite_off[s] / pitch;
 #pragma unroll
-  for (int d = 0; d < ND; ++d) lay_d[d] = pm.drape_off[d] / pitch - 1u;
+  for (int d = 0; d < ND; ++d) lay_d[d] = pm.drape_off[d] / pitch;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) lay_b[b] = pm.bchar_off[b] / pitch - 1u;
+  for (int b = 0; b < NB; ++b) lay_b[b] = pm.bchar_off[b] / pitch;
+  // bytes of x equal to the bytes of c4, as 0x01 per byte (exact: no borrow between bytes)
+  auto eq01 = [](uint32_t x, uint32_t c4) {
+    const uint32_t y = x ^ c4;
+    return (~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) >> 7) & 0x01010101u;
+  };
   const int n = fc->n;
   for (int w = 0; w < n; ++w) {
     const crop::FusedWindow& fw = fc->w[w];
@@ -317,80 +327,63 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
     const uint32_t opitch = (uint32_t)fw.out_pitch, qw = opitch >> 2, total = (uint32_t)WAVE * qw;
     const uint32_t ostride = (uint32_t)(1 + L) * opitch;
     uint8_t* const obase = uniform_ptr(fw.out + (size_t)env0 * ostride);
-    const uint32_t pad_planes = fw.pad_planes, pad4 = (uint32_t)(fw.rule.pad_char & 0xFF) * 0x01010101u;
+    const uint32_t pad = (uint32_t)(fw.rule.pad_char & 0xFF);
+    const uint32_t magic_qw = 0xFFFFFFFFu / qw, magic_cols = 0xFFFFFFFFu / (uint32_t)cols;  // floor(2^32 / d) or one less
     for (uint32_t f0 = (uint32_t)wave * WAVE; f0 < total; f0 += NWAVES * WAVE) {
       const uint32_t f = f0 + (uint32_t)lane;
       if (f >= total) continue;
-      const uint32_t e = f / qw, q = f - e * qw;
+      uint32_t e = __umulhi(f, magic_qw), q = f - e * qw;  // f / qw: the estimate is at most one short
+      if (q >= qw) { q -= qw; ++e; }
       if (skip[e]) continue;
       const uint32_t cw = wcorner[w * WAVE + e];
       if (cw == WCORNER_NONE) continue;
       const int top = (int)(int16_t)(cw & 0xFFFFu), left = (int)(int16_t)(cw >> 16);
-      const int cell0 = (int)q * 4, orow = cell0 / cols, ocol = cell0 - orow * cols;
-      const int sr = top + orow, sc = left + ocol;
+      const uint32_t cell0 = q * 4u;
+      uint32_t orow = __umulhi(cell0, magic_cols), ocol = cell0 - orow * (uint32_t)cols;
+      if (ocol >= (uint32_t)cols) { ocol -= (uint32_t)cols; ++orow; }
       const uint32_t eF = e * (uint32_t)FWP;
-      uint32_t od = 0, omd[ND > 0 ? ND : 1] = {}, oms[NS > 0 ? NS : 1] = {}, omb[NB > 0 ? NB : 1] = {};
-      const bool fast = cell0 + 3 < wcells && ocol + 3 < cols && (unsigned)sr < (unsigned)R && sc >= 0 && sc + 3 < C;
-      if (fast) {
-        const uint32_t a = (uint32_t)(sr * C + sc), phase = a & 3u, qa = a >> 2;
-        uint32_t d0, md0[ND > 0 ? ND : 1], ms0[NS > 0 ? NS : 1], mb0[NB > 0 ? NB : 1];
-        compose(e, qa, eF, d0, md0, ms0, mb0);
-        od = d0;
+      uint32_t od = 0;
+      int r = (int)orow, c = (int)ocol;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) omd[d] = md0[d];
+      for (int j = 0; j < 4; ++j) {
+        const bool real = (int)cell0 + j < wcells;  // cells past the window are plane padding: zeros
+        const int sr = top + r, sc = left + c;
+        const bool inside = real && (unsigned)sr < (unsigned)R && (unsigned)sc < (unsigned)C;
+        const uint32_t a = inside ? (uint32_t)(sr * C + sc) : 0u;
+        uint32_t ch = backdrop1[a];
+        if (cell_ids != nullptr) {  // (compile-time at every call site)
+          const uint32_t id = cell_id1[a];
+          const uint32_t word = flat[eF + (id >> 5)];  // (id 0xFF reads word 7 of the mask: in range, ignored)
+          if (id != 0xFFu && ((word >> (id & 31u)) & 1u)) ch = pm.drape_ch4[0] & 0xFFu;
+        } else {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) oms[s] = ms0[s];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) omb[b] = mb0[b];
-        if (phase) {
-          uint32_t d1, md1[ND > 0 ? ND : 1], ms1[NS > 0 ? NS : 1], mb1[NB > 0 ? NB : 1];
-          compose(e, qa + 1, eF, d1, md1, ms1, mb1);
-          od = __builtin_amdgcn_alignbyte(d1, od, phase);
-#pragma unroll
-          for (int d = 0; d < ND; ++d) omd[d] = __builtin_amdgcn_alignbyte(md1[d], omd[d], phase);
-#pragma unroll
-          for (int s = 0; s < NS; ++s) oms[s] = __builtin_amdgcn_alignbyte(ms1[s], oms[s], phase);
-#pragma unroll
-          for (int b = 0; b < NB; ++b) omb[b] = __builtin_amdgcn_alignbyte(mb1[b], omb[b], phase);
+          for (int d = 0; d < ND; ++d)
+            if ((flat[d * WAVE * FWP + eF + (a >> 5)] >> (a & 31u)) & 1u) ch = pm.drape_ch4[d] & 0xFFu;
         }
-      } else {
-        int r = orow, c = ocol;
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j, ++c) {
-          if (c >= cols) { c = 0; ++r; }
-          if (cell0 + j >= wcells) break;  // past the window: plane padding, zeros
-          const int rr = top + r, cc = left + c;
-          const uint32_t sh = 8u * (uint32_t)j;
-          if ((unsigned)rr < (unsigned)R && (unsigned)cc < (unsigned)C) {
-            const uint32_t a = (uint32_t)(rr * C + cc), bs = 8u * (a & 3u);
-            uint32_t d1, md1[ND > 0 ? ND : 1], ms1[NS > 0 ? NS : 1], mb1[NB > 0 ? NB : 1];
-            compose(e, a >> 2, eF, d1, md1, ms1, mb1);
-            od |= ((d1 >> bs) & 0xFFu) << sh;
+        ch = inside ? ch : real ? pad : 0u;
+        od |= ch << (8 * j);
+        if (++c >= cols) { c = 0; ++r; }
+      }
+      // the painted sprites (resolve_sprites: at most one per cell) that fall into this dword
 #pragma unroll
-            for (int d = 0; d < ND; ++d) omd[d] |= ((md1[d] >> bs) & 0xFFu) << sh;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) oms[s] |= ((ms1[s] >> bs) & 0xFFu) << sh;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) omb[b] |= ((mb1[b] >> bs) & 0xFFu) << sh;
-          } else {  // cropping.py:186-191 the pad character and its layer
-            od |= (pad4 & 0xFFu) << sh;
-#pragma unroll
-            for (int d = 0; d < ND; ++d) omd[d] |= ((pad_planes >> lay_d[d]) & 1u) << sh;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) oms[s] |= ((pad_planes >> lay_s[s]) & 1u) << sh;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) omb[b] |= ((pad_planes >> lay_b[b]) & 1u) << sh;
-          }
-        }
+      for (int s = 0; s < NS; ++s) {
+        const uint2 sd = sdesc[s * WAVE + e];
+        const uint32_t scell = sd.x * 4u + ((uint32_t)__builtin_ctz(sd.y | 0x80000000u) >> 3);
+        const int srow = (int)(scell / (uint32_t)C), scol = (int)(scell - (uint32_t)srow * (uint32_t)C);
+        const int wr = srow - top, wc = scol - left;
+        const uint32_t wi = (uint32_t)(wr * cols + wc);
+        const bool hit = sd.x != 0xFFFFFFFFu && (unsigned)wr < (unsigned)rows && (unsigned)wc < (unsigned)cols && (wi >> 2) == q;
+        const uint32_t m = hit ? 0xFFu << (8u * (wi & 3u)) : 0u;
+        od = (od & ~m) | (pm.sprite_ch4[s] & m);
       }
       uint32_t* const o = reinterpret_cast<uint32_t*>(obase + e * ostride) + q;
       o[0] = od;
 #pragma unroll
-      for (int d = 0; d < ND; ++d) o[(1u + lay_d[d]) * qw] = omd[d] & 0x01010101u;
+      for (int d = 0; d < ND; ++d) o[lay_d[d] * qw] = eq01(od, pm.drape_ch4[d]);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) o[(1u + lay_s[s]) * qw] = oms[s] & 0x01010101u;
+      for (int s = 0; s < NS; ++s) o[lay_s[s] * qw] = eq01(od, pm.sprite_ch4[s]);
 #pragma unroll
-      for (int b = 0; b < NB; ++b) o[(1u + lay_b[b]) * qw] = omb[b] & 0x01010101u;
+      for (int b = 0; b < NB; ++b) o[lay_b[b] * qw] = eq01(od, bchar_ch4[b]);
     }
   }
 }

@@ -48,7 +48,7 @@ struct Consts {
   uint32_t confined;         // bit s: sprite s is confined to the board
   uint32_t above[MAX_NS];    // bit j: sprite j is in front of sprite s; bit NS: the judge drape is
   uint32_t init[W_POS + MAX_NS];
-  uint32_t sprite_off[MAX_NS], sprite_ch4[MAX_NS], drape_off, drape_ch4, bchar_off[MAX_NB];
+  uint32_t sprite_off[MAX_NS], sprite_ch4[MAX_NS], drape_off, drape_ch4, bchar_off[MAX_NB], bchar_ch4[MAX_NB];
   int32_t tmpl_index[MAX_NS];  // sprite s here is sprite tmpl_index[s] of the template
 };
 
@@ -301,15 +301,15 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
 #pragma unroll
   for (int s = 0; s < NS; ++s) { pm.sprite_off[s] = k.sprite_off[s]; pm.sprite_ch4[s] = k.sprite_ch4[s]; }
   pm.drape_off[0] = k.drape_off; pm.drape_ch4[0] = k.drape_ch4;
+  uint32_t bch4[NB > 0 ? NB : 1] = {};
 #pragma unroll
-  for (int b = 0; b < NB; ++b) pm.bchar_off[b] = k.bchar_off[b];
+  for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
     stream::stream_planes<NS, 1, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                 flat, sdesc, skipv, FWP, lane, wave, epi, env0);
   if (fc)
-    stream::stream_windows<NS, 1, NB, QW, NWAVES>(fc, pm, R, C, env0, lds + O_BD, lds + O_BDM, flat, sdesc, skipv, FWP, lane, wave,
-                                                  wcorner);
+    stream::stream_windows<NS, 1, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
 }
 
 // ---------------------------------------------------------------------------
@@ -444,6 +444,7 @@ int WarehouseBackend::init(const pcx_template& t, int64_t batch) {
     if (thing) continue;
     if (nb >= NB_) return set_error(PCX_E_INVALID, "warehouse backend: inconsistent character set");
     k.bchar_off[nb] = (uint32_t)(1 + i) * lay_.pitch;
+    k.bchar_ch4[nb] = (uint32_t)ch * 0x01010101u;
     bchar_ch_[nb] = ch;
     uint8_t* m = reinterpret_cast<uint8_t*>(tab.data() + (size_t)lay_.QW * (1 + nb));
     for (int c = 0; c < lay_.cells; ++c) m[c] = t.backdrop[c] == ch;
