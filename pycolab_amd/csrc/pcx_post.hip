@@ -3,7 +3,9 @@
 // or a cropper just wrote (L2 / Infinity-Cache hot); one lane per board dword
 // (four cells), so plane reads are coalesced dwords and -- in the reference's
 // default axis order -- every store is a 4-, 16- or 32-byte vector per lane
-// (256 B to 2 KiB contiguous per wave).  Permuted outputs (`permute=`) fall
+// (256 B to 2 KiB contiguous per wave).  The channels-last feature array
+// (`permute=(1, 2, 0)`) divides its OUTPUT among the lanes instead (1 KiB
+// contiguous per wave store, layer bytes gathered); other permuted outputs fall
 // back to strided element stores.  The output array belongs to the caller
 // when one was bound (pcx_post_bind_output): the host hands it on as a device
 // tensor, no copy and no synchronisation.
@@ -88,25 +90,6 @@ __global__ void pcx_post_features(PostParams p, const uint8_t* planes, float* ou
   const uint32_t* src = reinterpret_cast<const uint32_t*>(planes + (size_t)b * p.n_planes * p.pitch) + q;
   const int cell0 = (int)q * 4, n = p.cells - cell0 < 4 ? p.cells - cell0 : 4;
   float* const o = out + (size_t)b * p.depth * p.cells;
-  if (p.linear == 2 && n == 4) {
-    // permute=(1, 2, 0), "channels last": a cell's depth values are adjacent, so
-    // the lane's four cells are one run of 4 * depth floats = depth 16-byte
-    // stores; element e of the run is layer e % depth of cell e / depth (the
-    // layer dwords are re-read from L1/L2 rather than kept in registers)
-    float4* const run = reinterpret_cast<float4*>(o + (size_t)cell0 * p.depth);
-    for (int i = 0; i < p.depth; ++i) {
-      float v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = 4 * i + k, j = e / p.depth, d = e - j * p.depth;
-        const int plane = p.layer_plane[d];
-        const uint32_t m = plane < 0 ? 0u : src[(size_t)plane * qw];
-        v[k] = (float)((m >> (8 * j)) & 0xFFu);
-      }
-      run[i] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    return;
-  }
   for (int d = 0; d < p.depth; ++d) {
     const int plane = p.layer_plane[d];
     const uint32_t m = plane < 0 ? 0u : src[(size_t)plane * qw];
@@ -120,6 +103,48 @@ __global__ void pcx_post_features(PostParams p, const uint8_t* planes, float* ou
         o[d * p.stride[0] + r * p.stride[1] + c * p.stride[2]] = v[j];
       }
     }
+  }
+}
+
+// ObservationToFeatureArray with permute=(1, 2, 0) ("channels last", [R][C][depth] per environment) on
+// boards of whole dwords, where the output of the whole batch is one contiguous run of
+// batch * cells * depth floats in cell order.  The OUTPUT is what the lanes divide: a wave owns 64 * depth
+// consecutive float4s (the features of 256 consecutive cells), lane l writes float4 number i * 64 + l in
+// trip i -- every store instruction is 1 KiB contiguous -- and gathers the four layer bytes behind it from
+// the planes (a few hundred bytes per wave, L1-resident).  Lanes dividing the INPUT instead (a cell dword
+// each, 16-byte stores 16 * depth bytes apart) measured 0.74 ms on marauders at 32,768 environments
+// against 0.20 ms for the default axis order; profiles/r02_post_kernels.md.
+__global__ void pcx_post_features_hwc(PostParams p, const uint8_t* planes, float* out, uint32_t depth_magic) {
+  __shared__ int32_t lplane[PCX_POST_MAX_DEPTH];
+  if (threadIdx.x < PCX_POST_MAX_DEPTH) lplane[threadIdx.x] = p.layer_plane[threadIdx.x];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t cell_first = wave_id * 256u, total_cells = (uint64_t)p.batch * (uint64_t)p.cells;
+  if (cell_first >= total_cells) return;
+  const uint32_t depth = (uint32_t)p.depth, cells = (uint32_t)p.cells;
+  const uint64_t b_first = cell_first / cells;         // (wave-uniform)
+  const uint32_t c_first = (uint32_t)(cell_first - b_first * cells);
+  const size_t env_bytes = (size_t)p.n_planes * p.pitch;
+  float4* const o = reinterpret_cast<float4*>(out + cell_first * depth);
+  const uint32_t cells_here = total_cells - cell_first < 256u ? (uint32_t)(total_cells - cell_first) : 256u;
+  for (uint32_t i = 0; i < depth; ++i) {
+    const uint32_t g = i * 64u + lane;                 // float4 of the wave's run
+    float v[4];
+    bool live = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t e = 4u * g + (uint32_t)k;         // element of the run: cell e / depth, layer e % depth
+      uint32_t j = __umulhi(e, depth_magic), d = e - j * depth;
+      if (d >= depth) { d -= depth; ++j; }             // (the estimate is at most one short)
+      live |= j < cells_here;
+      uint32_t c = c_first + (j < cells_here ? j : 0u);
+      uint64_t b = b_first;
+      while (c >= cells) { c -= cells; ++b; }
+      const int plane = lplane[d];
+      v[k] = plane < 0 ? 0.0f : (float)planes[b * env_bytes + (size_t)plane * p.pitch + c];
+    }
+    if (live) o[g] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -277,7 +302,14 @@ int pcx_post_run(pcx_post* q, void* stream) {
       hipLaunchKernelGGL(pcx_post_to_array<uint64_t>, grid, block, lds, s, p, q->planes, q->lut.ptr, q->mapped.ptr,
                          reinterpret_cast<uint64_t*>(q->out_ptr()), q->error.ptr);
   } else if (p.kind == PCX_POST_FEATURE_ARRAY) {
-    hipLaunchKernelGGL(pcx_post_features, grid, block, 0, s, p, q->planes, reinterpret_cast<float*>(q->out_ptr()));
+    if (p.linear == 2) {  // channels last on a whole-dword board: the lanes divide the output
+      const int64_t waves = (p.batch * p.cells + 255) / 256;
+      const uint32_t magic = 0xFFFFFFFFu / (uint32_t)p.depth;
+      hipLaunchKernelGGL(pcx_post_features_hwc, dim3((unsigned)((waves + 3) / 4)), block, 0, s, p, q->planes,
+                         reinterpret_cast<float*>(q->out_ptr()), magic);
+    } else {
+      hipLaunchKernelGGL(pcx_post_features, grid, block, 0, s, p, q->planes, reinterpret_cast<float*>(q->out_ptr()));
+    }
   } else {
     hipLaunchKernelGGL(pcx_post_repaint, grid, block, 0, s, p, q->planes, q->lut.ptr, reinterpret_cast<uint8_t*>(q->out_ptr()),
                        q->error.ptr);

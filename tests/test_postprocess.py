@@ -130,7 +130,7 @@ def test_device_to_array_unmapped_character_raises_and_croppers_chain():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['marauders', 'warehouse_L0'])
+@pytest.mark.parametrize('name', ['marauders', 'warehouse_L0', 'hello_world', 'scrolly_maze_L0'])
 def test_device_feature_and_value_arrays_in_every_axis_order(name):
   """Every `permute` of ObservationToFeatureArray / ObservationToArray equals
   np.transpose of the default order (rendering.py:520-542, 640-661); the
