@@ -110,41 +110,47 @@ __global__ void pcx_post_features(PostParams p, const uint8_t* planes, float* ou
 // boards of whole dwords, where the output of the whole batch is one contiguous run of
 // batch * cells * depth floats in cell order.  The OUTPUT is what the lanes divide: a wave owns 64 * depth
 // consecutive float4s (the features of 256 consecutive cells), lane l writes float4 number i * 64 + l in
-// trip i -- every store instruction is 1 KiB contiguous -- and gathers the four layer bytes behind it from
-// the planes (a few hundred bytes per wave, L1-resident).  Lanes dividing the INPUT instead (a cell dword
+// trip i -- every store instruction is 1 KiB contiguous -- and takes the four layer bytes behind it from
+// the wave's LDS copy of its cells' layer dwords (fetched with coalesced dword loads).  Lanes dividing the INPUT instead (a cell dword
 // each, 16-byte stores 16 * depth bytes apart) measured 0.74 ms on marauders at 32,768 environments
 // against 0.20 ms for the default axis order; profiles/r02_post_kernels.md.
 __global__ void pcx_post_features_hwc(PostParams p, const uint8_t* planes, float* out, uint32_t depth_magic) {
-  __shared__ int32_t lplane[PCX_POST_MAX_DEPTH];
-  if (threadIdx.x < PCX_POST_MAX_DEPTH) lplane[threadIdx.x] = p.layer_plane[threadIdx.x];
-  __syncthreads();
-  const uint32_t lane = threadIdx.x & 63u;
+  extern __shared__ uint32_t stage_all[];  // [waves per block][depth][64] layer dwords of the wave's 256 cells
+  const uint32_t lane = threadIdx.x & 63u, depth = (uint32_t)p.depth, cells = (uint32_t)p.cells;
+  uint32_t* const stage = stage_all + (threadIdx.x >> 6) * depth * 64u;
   const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t cell_first = wave_id * 256u, total_cells = (uint64_t)p.batch * (uint64_t)p.cells;
   if (cell_first >= total_cells) return;
-  const uint32_t depth = (uint32_t)p.depth, cells = (uint32_t)p.cells;
-  const uint64_t b_first = cell_first / cells;         // (wave-uniform)
-  const uint32_t c_first = (uint32_t)(cell_first - b_first * cells);
-  const size_t env_bytes = (size_t)p.n_planes * p.pitch;
+  // stage: lane l fetches, per layer, the dword of cells 4l .. 4l+3 of the wave's run (coalesced; a dword never
+  // straddles two environments because cells % 4 == 0)
+  {
+    const uint64_t cell = cell_first + 4u * lane;
+    const bool live = cell < total_cells;
+    const uint64_t b = live ? cell / cells : 0;
+    const uint32_t c = live ? (uint32_t)(cell - b * cells) : 0u;
+    const uint8_t* const src = planes + b * ((size_t)p.n_planes * p.pitch) + c;
+    for (uint32_t d = 0; d < depth; ++d) {
+      const int plane = p.layer_plane[d];  // (uniform)
+      stage[d * 64u + lane] = (live && plane >= 0) ? *reinterpret_cast<const uint32_t*>(src + (size_t)plane * p.pitch) : 0u;
+    }
+  }
+  // (a wave reads back only what it wrote itself: no barrier, the LDS accesses of one wave complete in order)
+  const uint8_t* const bytes = reinterpret_cast<const uint8_t*>(stage);
   float4* const o = reinterpret_cast<float4*>(out + cell_first * depth);
   const uint32_t cells_here = total_cells - cell_first < 256u ? (uint32_t)(total_cells - cell_first) : 256u;
   for (uint32_t i = 0; i < depth; ++i) {
     const uint32_t g = i * 64u + lane;                 // float4 of the wave's run
     float v[4];
-    bool live = false;
+    uint32_t j0 = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint32_t e = 4u * g + (uint32_t)k;         // element of the run: cell e / depth, layer e % depth
       uint32_t j = __umulhi(e, depth_magic), d = e - j * depth;
       if (d >= depth) { d -= depth; ++j; }             // (the estimate is at most one short)
-      live |= j < cells_here;
-      uint32_t c = c_first + (j < cells_here ? j : 0u);
-      uint64_t b = b_first;
-      while (c >= cells) { c -= cells; ++b; }
-      const int plane = lplane[d];
-      v[k] = plane < 0 ? 0.0f : (float)planes[b * env_bytes + (size_t)plane * p.pitch + c];
+      if (k == 0) j0 = j;
+      v[k] = (float)bytes[d * 256u + j];
     }
-    if (live) o[g] = make_float4(v[0], v[1], v[2], v[3]);
+    if (j0 < cells_here) o[g] = make_float4(v[0], v[1], v[2], v[3]);  // (cells_here is a multiple of 4, depth elements per cell)
   }
 }
 
@@ -305,7 +311,7 @@ int pcx_post_run(pcx_post* q, void* stream) {
     if (p.linear == 2) {  // channels last on a whole-dword board: the lanes divide the output
       const int64_t waves = (p.batch * p.cells + 255) / 256;
       const uint32_t magic = 0xFFFFFFFFu / (uint32_t)p.depth;
-      hipLaunchKernelGGL(pcx_post_features_hwc, dim3((unsigned)((waves + 3) / 4)), block, 0, s, p, q->planes,
+      hipLaunchKernelGGL(pcx_post_features_hwc, dim3((unsigned)((waves + 3) / 4)), block, (size_t)p.depth * 256 * 4, s, p, q->planes,
                          reinterpret_cast<float*>(q->out_ptr()), magic);
     } else {
       hipLaunchKernelGGL(pcx_post_features, grid, block, 0, s, p, q->planes, reinterpret_cast<float*>(q->out_ptr()));

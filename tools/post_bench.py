@@ -107,7 +107,7 @@ def main():
   hwc = rendering.ObservationToFeatureArray(''.join(chr(c) for c in t.chars), permute=(1, 2, 0))
   hwc(obs)
   ms = timed(lambda: hwc(obs), args.steps)
-  add('ObservationToFeatureArray permute=(1,2,0)', 'pcx_post_features (strided stores), marauders %d envs' % eng.batch, ms,
+  add('ObservationToFeatureArray permute=(1,2,0)', 'pcx_post_features_hwc, marauders %d envs' % eng.batch, ms,
       eng.batch * len(t.chars) * cells * 5)
   # the same feature array as an epilogue of the step kernel: step alone, step + separate kernel, fused step
   tape = torch.randint(0, 4, (64, eng.batch), dtype=torch.int32, device='cuda')
