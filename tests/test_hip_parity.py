@@ -286,6 +286,44 @@ def test_full_batch_properties_configs_3_and_4(name, B, T):
   assert done_seen > 0 or name != 'marauders'  # marauders episodes end (and restart) inside the run; random play never solves a warehouse
 
 
+@pytest.mark.parametrize('name,B,T', [('better_scrolly_maze_L0', 139264, 24), ('scrolly_maze_L0', 1703936, 24),
+                                      ('marauders', 720896, 24), ('hello_world', 1245184, 12)])
+def test_observation_planes_beyond_4_gib(name, B, T):
+  """Maximum sizes: batches whose observation planes exceed 4 GiB (byte offsets
+  no longer fit 32 bits; the GPU holds 288 GB).  The last K environments live
+  beyond the 4 GiB mark: they and the first K against the oracle, layer ==
+  (board == c) over a slice that straddles the mark, no error bits."""
+  import torch
+  t = helpers.load_template(name)
+  t.param[0] = 0xBEEF
+  K = 512
+  hip = HipAdapter(t, B)
+  head = OracleAdapter(t, K)
+  tt = helpers.load_template(name)
+  tt.param[0] = 0xBEEF
+  tt.param[2], tt.param[3] = (B - K) & 0xFFFFFFFF, (B - K) >> 32
+  tail = OracleAdapter(tt, K)
+  hip.reset(); head.reset(); tail.reset()
+  hip.step_hashed(0xC0FFEE, 0, T); head.step_hashed(0xC0FFEE, 0, T); tail.step_hashed(0xC0FFEE, 0, T, env_offset=B - K)
+  planes = hip.eng.planes_view()
+  assert planes.numel() > (1 << 32), 'the case must exceed 4 GiB of planes'
+  np.testing.assert_array_equal(planes[:K].cpu().numpy(), head.read('planes'), err_msg=name + ' (head)')
+  np.testing.assert_array_equal(planes[B - K:].cpu().numpy(), tail.read('planes'), err_msg=name + ' (tail)')
+  for key in ('reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+    got = hip.eng.buffers[key].tensor
+    np.testing.assert_array_equal(got[:K].cpu().numpy(), head.read(key), err_msg=name + ' head ' + key)
+    np.testing.assert_array_equal(got[B - K:].cpu().numpy(), tail.read(key), err_msg=name + ' tail ' + key)
+  per_env = planes[0].numel()
+  mark = (1 << 32) // per_env  # the environment the 4 GiB mark falls into
+  chars = torch.tensor(list(t.chars), dtype=torch.uint8, device='cuda')
+  for lo in (0, mark - 2048, B - 4096):
+    chunk = planes[lo:lo + 4096]
+    want = (chunk[:, :1] == chars.view(1, -1, 1, 1)).to(torch.uint8)
+    assert torch.equal(chunk[:, 1:], want), '%s environments %d..' % (name, lo)
+  assert not hip.eng.buffers['error'].tensor.any()
+  hip.eng.close()
+
+
 def test_engine_facade_batch1_matches_trace():
   """`Engine.play()` with batch 1 returns the reference's types and values."""
   tr = helpers.load_trace('scrolly_maze_L0')
