@@ -252,10 +252,13 @@ def main():
     del tape
     eng.close()
     if world == 1 and args.game == 'scrolly_maze' and not args.no_other_configs:
-      # BASELINE configs 2-4 on the same GPU, same run (their own kernels and rooflines)
+      # BASELINE configs 2-4 on the same GPU, same run (their own kernels and rooflines), then the other two
+      # hand-written kernels: SURVEY 8 f-1 (better_scrolly_maze, 45x89 board) and config 1's game on the GPU
       line['other_configs'] = [measure_config('scrolly_maze', 0, 4096, 200, 20, local),
                                measure_config('marauders', 0, 32768, 200, 20, local),
-                               measure_config('warehouse', 0, 262144, 100, 10, local)]
+                               measure_config('warehouse', 0, 262144, 100, 10, local),
+                               measure_config('better_scrolly_maze', 0, 65536, 50, 10, local),
+                               measure_config('hello_world', 0, 1048576, 50, 10, local)]
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(template_path)
     print(json.dumps(line))

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
     stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                         cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid);
   if (fc)
-    stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, cm, sdesc, skipv, CWP, lane, wave, wcorner, cid);
+    stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C, true>(fc, pm, bch4, env0, lds + O_BD, cm, sdesc, skipv, CWP, lane, wave, wcorner, cid);
 }
 
 // ---------------------------------------------------------------------------

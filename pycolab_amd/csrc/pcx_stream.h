@@ -298,7 +298,8 @@ __device__ __forceinline__ void move_fused_windows(const crop::FusedCrops* fc, T
 // layers[c] = (board == c), which is how the reference builds the layers it
 // crops.  Consecutive lanes write consecutive dwords of one output plane.
 //   bchar_ch4: the backdrop-only characters, replicated into four bytes (plane order of pm.bchar_off).
-template <int NS, int ND, int NB, int QW, int NWAVES, int R, int C>
+//   IDS: the one drape is a mask over its cell list (cell_ids, as in stream_planes).
+template <int NS, int ND, int NB, int QW, int NWAVES, int R, int C, bool IDS = false>
 __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const PlaneMap<NS, ND, NB>& pm,
                                                const uint32_t (&bchar_ch4)[NB > 0 ? NB : 1], int64_t env0,
                                                const uint32_t* backdrop4, const uint32_t* flat, const uint2* sdesc,
@@ -329,19 +330,42 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
     uint8_t* const obase = uniform_ptr(fw.out + (size_t)env0 * ostride);
     const uint32_t pad = (uint32_t)(fw.rule.pad_char & 0xFF);
     const uint32_t magic_qw = 0xFFFFFFFFu / qw, magic_cols = 0xFFFFFFFFu / (uint32_t)cols;  // floor(2^32 / d) or one less
+    // plane bases in SGPRs, one shared 32-bit lane offset (as in the board loop)
+    uint8_t* pb_s[NS > 0 ? NS : 1];
+    uint8_t* pb_d[ND > 0 ? ND : 1];
+    uint8_t* pb_b[NB > 0 ? NB : 1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) pb_s[s] = uniform_ptr(obase + lay_s[s] * opitch);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) pb_d[d] = uniform_ptr(obase + lay_d[d] * opitch);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) pb_b[b] = uniform_ptr(obase + lay_b[b] * opitch);
     for (uint32_t f0 = (uint32_t)wave * WAVE; f0 < total; f0 += NWAVES * WAVE) {
+      // straight-line code (selects, clamped indices); one predicated region for the stores at the end
       const uint32_t f = f0 + (uint32_t)lane;
-      if (f >= total) continue;
+      const bool in_range = f < total;
       uint32_t e = __umulhi(f, magic_qw), q = f - e * qw;  // f / qw: the estimate is at most one short
-      if (q >= qw) { q -= qw; ++e; }
-      if (skip[e]) continue;
-      const uint32_t cw = wcorner[w * WAVE + e];
-      if (cw == WCORNER_NONE) continue;
+      const bool carry = q >= qw;
+      q = carry ? q - qw : q;
+      e = carry ? e + 1 : e;
+      e = in_range ? e : 0u;
+      const uint32_t cw = wcorner[w * WAVE + e], sk = skip[e];
+      const bool active = (uint32_t)in_range & (uint32_t)(sk == 0u) & (uint32_t)(cw != WCORNER_NONE);
       const int top = (int)(int16_t)(cw & 0xFFFFu), left = (int)(int16_t)(cw >> 16);
       const uint32_t cell0 = q * 4u;
       uint32_t orow = __umulhi(cell0, magic_cols), ocol = cell0 - orow * (uint32_t)cols;
-      if (ocol >= (uint32_t)cols) { ocol -= (uint32_t)cols; ++orow; }
+      const bool carry2 = ocol >= (uint32_t)cols;
+      ocol = carry2 ? ocol - (uint32_t)cols : ocol;
+      orow = carry2 ? orow + 1 : orow;
       const uint32_t eF = e * (uint32_t)FWP;
+      // the cell every painted sprite shows at (resolve_sprites: at most one sprite per cell), none: no cell
+      uint32_t scell[NS > 0 ? NS : 1];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        // one 8-byte read; dword 0xFFFFFFFF (not painted) gives a cell no window cell has
+        const uint64_t sd = reinterpret_cast<const uint64_t*>(sdesc)[s * WAVE + e];
+        scell[s] = ((uint32_t)sd << 2) | ((uint32_t)__builtin_ctz((uint32_t)(sd >> 32)) >> 3);
+      }
       uint32_t od = 0;
       int r = (int)orow, c = (int)ocol;
 #pragma unroll
@@ -351,39 +375,39 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
         const bool inside = real && (unsigned)sr < (unsigned)R && (unsigned)sc < (unsigned)C;
         const uint32_t a = inside ? (uint32_t)(sr * C + sc) : 0u;
         uint32_t ch = backdrop1[a];
-        if (cell_ids != nullptr) {  // (compile-time at every call site)
+        if constexpr (IDS) {
           const uint32_t id = cell_id1[a];
           const uint32_t word = flat[eF + (id >> 5)];  // (id 0xFF reads word 7 of the mask: in range, ignored)
-          if (id != 0xFFu && ((word >> (id & 31u)) & 1u)) ch = pm.drape_ch4[0] & 0xFFu;
+          const uint32_t coin = (word >> (id & 31u)) & (uint32_t)(id != 0xFFu);  // (arithmetic: no branch around the read)
+          ch = (coin & 1u) ? pm.drape_ch4[0] & 0xFFu : ch;
         } else {
 #pragma unroll
-          for (int d = 0; d < ND; ++d)
-            if ((flat[d * WAVE * FWP + eF + (a >> 5)] >> (a & 31u)) & 1u) ch = pm.drape_ch4[d] & 0xFFu;
+          for (int d = 0; d < ND; ++d) {
+            const bool bit = ((flat[d * WAVE * FWP + eF + (a >> 5)] >> (a & 31u)) & 1u) != 0u;
+            ch = bit ? pm.drape_ch4[d] & 0xFFu : ch;
+          }
         }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ch = a == scell[s] ? pm.sprite_ch4[s] & 0xFFu : ch;
         ch = inside ? ch : real ? pad : 0u;
         od |= ch << (8 * j);
-        if (++c >= cols) { c = 0; ++r; }
+        const bool wrap = c + 1 >= cols;
+        c = wrap ? 0 : c + 1;
+        r = wrap ? r + 1 : r;
       }
-      // the painted sprites (resolve_sprites: at most one per cell) that fall into this dword
+      if (active) {
+        const uint32_t voff = e * ostride + 4u * q;
+        auto put = [&](uint8_t* base, uint32_t v) {
+          asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(base));
+        };
+        put(obase, od);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const uint2 sd = sdesc[s * WAVE + e];
-        const uint32_t scell = sd.x * 4u + ((uint32_t)__builtin_ctz(sd.y | 0x80000000u) >> 3);
-        const int srow = (int)(scell / (uint32_t)C), scol = (int)(scell - (uint32_t)srow * (uint32_t)C);
-        const int wr = srow - top, wc = scol - left;
-        const uint32_t wi = (uint32_t)(wr * cols + wc);
-        const bool hit = sd.x != 0xFFFFFFFFu && (unsigned)wr < (unsigned)rows && (unsigned)wc < (unsigned)cols && (wi >> 2) == q;
-        const uint32_t m = hit ? 0xFFu << (8u * (wi & 3u)) : 0u;
-        od = (od & ~m) | (pm.sprite_ch4[s] & m);
+        for (int d = 0; d < ND; ++d) put(pb_d[d], eq01(od, pm.drape_ch4[d]));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) put(pb_s[s], eq01(od, pm.sprite_ch4[s]));
+#pragma unroll
+        for (int b = 0; b < NB; ++b) put(pb_b[b], eq01(od, bchar_ch4[b]));
       }
-      uint32_t* const o = reinterpret_cast<uint32_t*>(obase + e * ostride) + q;
-      o[0] = od;
-#pragma unroll
-      for (int d = 0; d < ND; ++d) o[lay_d[d] * qw] = eq01(od, pm.drape_ch4[d]);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) o[lay_s[s] * qw] = eq01(od, pm.sprite_ch4[s]);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) o[lay_b[b] * qw] = eq01(od, bchar_ch4[b]);
     }
   }
 }
