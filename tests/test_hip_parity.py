@@ -66,6 +66,26 @@ def test_hip_matches_oracle_hashed_actions(name):
   assert resets > 0 or not name.startswith(('scrolly_maze_L0', 'scrolly_maze_L1', 'marauders'))  # reset path exercised (L2 patrollers are boxed in)
 
 
+@pytest.mark.parametrize('name,T', [('scrolly_maze_L0', 4000), ('scrolly_maze_L2', 2000), ('warehouse_L0', 3000),
+                                    ('marauders', 2500), ('hello_world', 1500), ('better_scrolly_maze_L1', 1200)])
+def test_long_run_matches_oracle(name, T):
+  """Thousands of consecutive steps per environment (many episodes end and
+  restart, frame counters and RNG draw counters run far beyond what the
+  traces reach): everything compared at checkpoints, state included."""
+  t = helpers.load_template(name)
+  t.param[0] = 0xFACE
+  B = 192
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  episodes = 0
+  for t0 in range(0, T, 250):
+    n = min(250, T - t0)
+    hip.step_hashed(0xABCDE, t0, n); orc.step_hashed(0xABCDE, t0, n)
+    assert_same(hip, orc, '%s after step %d' % (name, t0 + n))
+    episodes += int(orc.read('done').sum())
+  assert int(orc.read('frame').max()) > 0
+
+
 @pytest.mark.parametrize('name', LEVELS)
 def test_hip_matches_oracle_single_wave_launch_shape(name, monkeypatch):
   """Small batches take the cooperative launch shape (four waves share a
