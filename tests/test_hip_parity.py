@@ -306,14 +306,17 @@ def test_full_batch_properties_configs_3_and_4(name, B, T):
   assert done_seen > 0 or name != 'marauders'  # marauders episodes end (and restart) inside the run; random play never solves a warehouse
 
 
-@pytest.mark.parametrize('name,B,T', [('better_scrolly_maze_L0', 139264, 24), ('scrolly_maze_L0', 1703936, 24),
-                                      ('marauders', 720896, 24), ('hello_world', 1245184, 12)])
-def test_observation_planes_beyond_4_gib(name, B, T):
+@pytest.mark.parametrize('name,B,T,generic', [('better_scrolly_maze_L0', 139264, 24, False), ('scrolly_maze_L0', 1703936, 24, False),
+                                              ('marauders', 720896, 24, False), ('hello_world', 1245184, 12, False),
+                                              ('warehouse_L0', 3407872, 12, False), ('hello_world', 1245184, 6, True)])
+def test_observation_planes_beyond_4_gib(name, B, T, generic, monkeypatch):
   """Maximum sizes: batches whose observation planes exceed 4 GiB (byte offsets
   no longer fit 32 bits; the GPU holds 288 GB).  The last K environments live
   beyond the 4 GiB mark: they and the first K against the oracle, layer ==
   (board == c) over a slice that straddles the mark, no error bits."""
   import torch
+  if generic:  # the table-driven kernel
+    monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
   t = helpers.load_template(name)
   t.param[0] = 0xBEEF
   K = 512
@@ -327,6 +330,8 @@ def test_observation_planes_beyond_4_gib(name, B, T):
   hip.step_hashed(0xC0FFEE, 0, T); head.step_hashed(0xC0FFEE, 0, T); tail.step_hashed(0xC0FFEE, 0, T, env_offset=B - K)
   planes = hip.eng.planes_view()
   assert planes.numel() > (1 << 32), 'the case must exceed 4 GiB of planes'
+  from pycolab_amd import _native as N
+  assert (N.lib().pcx_engine_kernel_name(hip.eng._native).decode() == 'pcx_generic_step') == generic
   np.testing.assert_array_equal(planes[:K].cpu().numpy(), head.read('planes'), err_msg=name + ' (head)')
   np.testing.assert_array_equal(planes[B - K:].cpu().numpy(), tail.read('planes'), err_msg=name + ' (tail)')
   for key in ('reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
