@@ -111,6 +111,22 @@ WAREHOUSE_ART = {
                            '.#  9  _  0  _  #.',
                            '.################.',
                            '..................'],
+    # shapes without a compiled instance of pcx_warehouse_step: its run-time-shape instances
+    'warehouse_custom_C': ['...............',
+                           '.#############.',
+                           '.#  _   #  _ #.',
+                           '.# 1  2    # #.',
+                           '.#   ##  3   #.',
+                           '.# _    P  4 #.',
+                           '.#    #   _  #.',
+                           '.#############.',
+                           '...............'],
+    'warehouse_custom_D': ['........',
+                           '.######.',
+                           '.# 1 _#.',
+                           '.#  P #.',
+                           '.######.',
+                           '........'],
 }
 WAREHOUSE_NAMES = sorted(WAREHOUSE_ART)
 for _name, _art in WAREHOUSE_ART.items():
@@ -192,3 +208,45 @@ def make_hello(name, example, ascii_art):
                '4': ascii_art.Partial(example.SlidingSprite, 1)},
       drapes={'@': example.RollingDrape},
       z_order='4@321')
+
+
+# ---- better_scrolly_maze boards that the reference does not ship ---------------------
+# The example's own classes (PlayerSprite, PatrollerSprite, CashDrape;
+# better_scrolly_maze.py:250-320) on boards without a compiled instance of
+# pcx_better_scrolly_step (its run-time-shape instance): 17x38 (646 cells: the
+# planes are padded to whole dwords) and 12x20.
+# name -> (seed, rows, cols)
+BETTER_SPECS = {
+    'better_scrolly_custom_A': (201, 17, 38),
+    'better_scrolly_custom_B': (202, 12, 20),
+}
+BETTER_NAMES = sorted(BETTER_SPECS)
+
+
+def better_art(name):
+  seed, rows, cols = BETTER_SPECS[name]
+  rng = np.random.RandomState(seed)
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  art[0, :] = art[-1, :] = art[:, 0] = art[:, -1] = '#'
+  inner = rng.rand(rows - 2, cols - 2)
+  art[1:-1, 1:-1][inner < 0.18] = '#'
+  art[1:-1, 1:-1][(inner >= 0.18) & (inner < 0.26)] = '@'
+  for ch in 'abcP':
+    for _ in range(10000):
+      r = int(rng.randint(1, rows - 1)); c = int(rng.randint(1, cols - 1))
+      if art[r, c] == ' ':
+        art[r, c] = ch
+        break
+    else:
+      raise RuntimeError('no room for sprite ' + ch)
+  return [''.join(row) for row in art]
+
+
+def make_better_scrolly(name, example, ascii_art):
+  """better_scrolly_maze.make_game (better_scrolly_maze.py:209-222) for BETTER_SPECS[name]."""
+  return ascii_art.ascii_art_to_game(
+      better_art(name), what_lies_beneath=' ',
+      sprites={'P': example.PlayerSprite, 'a': example.PatrollerSprite, 'b': example.PatrollerSprite,
+               'c': example.PatrollerSprite},
+      drapes={'@': example.CashDrape},
+      update_schedule=['a', 'b', 'c', 'P', '@'], z_order='abc@P')

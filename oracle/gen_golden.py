@@ -200,6 +200,7 @@ CROPPERS = {  # keyed by trace name
                         S(5, 5, 'cb', '.', (None, None), (1, -1), False), S(3, 9, '@P', ' ', (1, 3))],
     'warehouse_L1': [S(5, 5, 'P', None, (1, 1)), S(7, 7, '3P', '.', (2, 2), (0, 1)), F((2, 3), 5, 6),
                      S(3, 9, 'XP', ' ', (1, 2)), F((8, 9), 6, 7, '#')],
+    'warehouse_custom_C': [S(5, 7, 'P', None, (1, 2)), F((4, 8), 6, 9, '#'), S(3, 5, '2P', '.', (None, None))],
     'marauders': [S(7, 15, 'P', None, (2, 4)), S(9, 11, 'ayP', ' ', (None, None)), F((10, -5), 8, 20, 'B'),
                   S(5, 9, 'X', ' ', (1, 3), None, False)],
 }
@@ -342,6 +343,12 @@ def main():
                       F(bsm.TEASER_CORNER[level], 12, 20, ' ')]
     run(name, lambda: bsm.make_game(level), E=12, T=160, n_ordinary=5, quit_action=5, seed=61 + level,
         template_name=name)
+  for i, name in enumerate(custom_levels.BETTER_NAMES):  # boards without a compiled kernel instance, with croppers
+    rows, cols = custom_levels.BETTER_SPECS[name][1:]
+    CROPPERS[name] = [S(7, 11, 'P', None, (2, 3)), S(5, 9, 'bP', ' ', (None, None), (1, -2)),
+                      F((rows - 4, cols - 6), 6, 10, '#')]
+    run(name, lambda: custom_levels.make_better_scrolly(name, bsm, ref_ascii_art), E=12, T=160, n_ordinary=5,
+        quit_action=5, seed=161 + i, template_name=name)
   run('hello_world', hello_world.make_game, E=16, T=96, n_ordinary=4, quit_action=4, seed=27,
       template_name='hello_world')
   for i, name in enumerate(custom_levels.HELLO_NAMES):

@@ -11,7 +11,7 @@ from pycolab_amd import cropping
 from tests import helpers
 
 CROPPED = ['scrolly_maze_L0', 'warehouse_L1', 'marauders', 'better_scrolly_maze_L0', 'better_scrolly_maze_L1',
-           'better_scrolly_maze_L2']
+           'better_scrolly_maze_L2', 'warehouse_custom_C', 'better_scrolly_custom_A', 'better_scrolly_custom_B']
 
 
 def specs_of(trace):
@@ -149,7 +149,8 @@ def test_device_cropper_outputs_are_zero_copy_device_tensors_and_survive_a_new_e
 
 # ---- croppers fused into the step kernel (cropping.fuse_croppers, pcx_engine_fuse_croppers) ----
 
-FUSABLE = ['warehouse_L1', 'marauders', 'better_scrolly_maze_L0', 'better_scrolly_maze_L1', 'better_scrolly_maze_L2']
+FUSABLE = ['warehouse_L1', 'marauders', 'better_scrolly_maze_L0', 'better_scrolly_maze_L1', 'better_scrolly_maze_L2',
+           'warehouse_custom_C', 'better_scrolly_custom_A', 'better_scrolly_custom_B']
 
 
 def _fusable(specs, drapes):
