@@ -102,6 +102,7 @@ struct Composer {
   const uint2* sdesc;
   const uint32_t* cell_ids;
   int FWP;
+  int qw;  // dwords per plane when QW == 0 (run-time board shape)
   __device__ __forceinline__ void operator()(uint32_t e_now, uint32_t q_now, uint32_t eF_now, uint32_t& d,
                                              uint32_t (&md)[ND > 0 ? ND : 1], uint32_t (&ms)[NS > 0 ? NS : 1],
                                              uint32_t (&mb)[NB > 0 ? NB : 1]) const {
@@ -134,7 +135,7 @@ struct Composer {
       ms[s] = sd.x == q_now ? sd.y : 0u;
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) mb[b] = bdmask[b * QW + q_now];
+    for (int b = 0; b < NB; ++b) mb[b] = bdmask[b * (QW ? QW : qw) + q_now];
     uint32_t uni = 0;
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) {
@@ -161,7 +162,9 @@ struct Composer {
 // one shared 32-bit lane offset`; indices advance incrementally (no multiplies
 // or divisions in the loop).  NWAVES waves of a workgroup share the loop,
 // iterations round-robin.
-//   QW: dwords per plane (plane pitch / 4); record = (1 + L) planes.
+//   QW: dwords per plane (plane pitch / 4); record = (1 + L) planes.  QW == 0: the board's shape is
+//     not known at compile time, qw_rt is the number of dwords (the run-time-shape instances that
+//     step unshipped levels; the per-iteration work is the same, the strides live in registers).
 //   EPI: also write the float32 feature-array epilogue (EpilogueArgs).
 //   cell_ids (optional): a drape whose cells only ever disappear (coins) kept as a
 //     per-environment bit mask over the template's list of its cells instead of a
@@ -171,7 +174,9 @@ template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI>
 __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
                                               const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
                                               const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
-                                              const EpilogueArgs& epi, int64_t env0, const uint32_t* cell_ids = nullptr) {
+                                              const EpilogueArgs& epi, int64_t env0, const uint32_t* cell_ids = nullptr,
+                                              int qw_rt = 0) {
+  const uint32_t QWv = QW ? (uint32_t)QW : (uint32_t)qw_rt;
   uint8_t* const pb_board = uniform_ptr(group_base);
   uint8_t* pb_s[NS];
   uint8_t* pb_d[ND];
@@ -183,20 +188,20 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
 #pragma unroll
   for (int b = 0; b < NB; ++b) pb_b[b] = uniform_ptr(pb_board + pm.bchar_off[b]);
 
-  const Composer<NS, ND, NB, QW> compose{pm, backdrop4, bdmask, flat, sdesc, cell_ids, FWP};
+  const Composer<NS, ND, NB, QW> compose{pm, backdrop4, bdmask, flat, sdesc, cell_ids, FWP, (int)QWv};
   const bool any_skip = __ballot(skip[lane] != 0) != 0ull;
   // Drain the logic phase's own loads/stores once, here: the loop's stores are
   // inline asm the compiler cannot count, and without this it would protect a
   // register of an older store with a vmcnt(0) inside the loop.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt/lgkmcnt untouched
 
-  constexpr int ADV = NWAVES * WAVE;          // tasks between a wave's consecutive iterations
-  constexpr int DE = ADV / QW, DQ = ADV % QW;  // ... as whole environments + dwords
+  constexpr uint32_t ADV = NWAVES * WAVE;             // tasks between a wave's consecutive iterations
+  const uint32_t DE = ADV / QWv, DQ = ADV - DE * QWv;  // ... as whole environments + dwords (constants when QW != 0)
   const uint32_t f0 = (uint32_t)(wave * WAVE + lane);
-  uint32_t e = f0 / (uint32_t)QW, q = f0 % (uint32_t)QW;  // compile-time divisor, once
+  uint32_t e = f0 / QWv, q = f0 - e * QWv;  // once
   uint32_t voff = e * env_stride + 4u * q, eF = e * (uint32_t)FWP;
-  const uint32_t dvoff = (uint32_t)DE * env_stride + 4u * (uint32_t)DQ, dF = (uint32_t)DE * (uint32_t)FWP;
-  const uint32_t wrap_voff = env_stride - 4u * (uint32_t)QW;
+  const uint32_t dvoff = DE * env_stride + 4u * DQ, dF = DE * (uint32_t)FWP;
+  const uint32_t wrap_voff = env_stride - 4u * QWv;
   // epilogue addressing: one scalar base for the group, a lane offset that
   // advances like voff (16 bytes per board dword), the layer's slot added per store
   // EPI is a compile-time switch: the plain loop carries none of the epilogue's
@@ -205,14 +210,14 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   const bool layers_on = !(epi_on && epi.skip_layers);
   uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(epi.out) + (size_t)env0 * epi.env_stride);
   uint32_t foff = e * epi.env_stride + 16u * q;
-  const uint32_t dfoff = (uint32_t)DE * epi.env_stride + 16u * (uint32_t)DQ, wrap_foff = epi.env_stride - 16u * (uint32_t)QW;
+  const uint32_t dfoff = DE * epi.env_stride + 16u * DQ, wrap_foff = epi.env_stride - 16u * QWv;
 #pragma unroll 1
-  for (int it = wave; it < QW; it += NWAVES) {
+  for (int it = wave; it < (int)QWv; it += NWAVES) {
     const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF, foff_now = foff;
     q += DQ; e += DE; voff += dvoff; eF += dF; foff += dfoff;
     {
-      const bool wrap = q >= (uint32_t)QW;
-      q = wrap ? q - QW : q;
+      const bool wrap = q >= QWv;
+      q = wrap ? q - QWv : q;
       e = wrap ? e + 1 : e;
       voff = wrap ? voff + wrap_voff : voff;
       eF = wrap ? eF + FWP : eF;
@@ -299,14 +304,17 @@ __device__ __forceinline__ void move_fused_windows(const crop::FusedCrops* fc, T
 // crops.  Consecutive lanes write consecutive dwords of one output plane.
 //   bchar_ch4: the backdrop-only characters, replicated into four bytes (plane order of pm.bchar_off).
 //   IDS: the one drape is a mask over its cell list (cell_ids, as in stream_planes).
+//   R == 0: run-time board shape `rt` (rows, cols, dwords per plane), as QW == 0 in stream_planes.
+struct BoardShape { int rows, cols, qw; };
 template <int NS, int ND, int NB, int QW, int NWAVES, int R, int C, bool IDS = false>
 __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const PlaneMap<NS, ND, NB>& pm,
                                                const uint32_t (&bchar_ch4)[NB > 0 ? NB : 1], int64_t env0,
                                                const uint32_t* backdrop4, const uint32_t* flat, const uint2* sdesc,
                                                const uint32_t* skip, int FWP, int lane, int wave, const uint32_t* wcorner,
-                                               const uint32_t* cell_ids = nullptr) {
+                                               const uint32_t* cell_ids = nullptr, BoardShape rt = BoardShape{0, 0, 0}) {
   constexpr int L = NS + ND + NB;
-  constexpr uint32_t pitch = 4u * QW;
+  const int Rv = R ? R : rt.rows, Cv = C ? C : rt.cols;
+  const uint32_t pitch = 4u * (QW ? (uint32_t)QW : (uint32_t)rt.qw);
   const uint8_t* const backdrop1 = reinterpret_cast<const uint8_t*>(backdrop4);
   const uint8_t* const cell_id1 = reinterpret_cast<const uint8_t*>(cell_ids);
   uint32_t lay_s[NS > 0 ? NS : 1], lay_d[ND > 0 ? ND : 1], lay_b[NB > 0 ? NB : 1];
@@ -372,8 +380,8 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
       for (int j = 0; j < 4; ++j) {
         const bool real = (int)cell0 + j < wcells;  // cells past the window are plane padding: zeros
         const int sr = top + r, sc = left + c;
-        const bool inside = real && (unsigned)sr < (unsigned)R && (unsigned)sc < (unsigned)C;
-        const uint32_t a = inside ? (uint32_t)(sr * C + sc) : 0u;
+        const bool inside = real && (unsigned)sr < (unsigned)Rv && (unsigned)sc < (unsigned)Cv;
+        const uint32_t a = inside ? (uint32_t)(sr * Cv + sc) : 0u;
         uint32_t ch = backdrop1[a];
         if constexpr (IDS) {
           const uint32_t id = cell_id1[a];

@@ -45,6 +45,7 @@ constexpr int F_LAST_SHIFT = 8;  // JudgeDrape._last_num_boxes_on_goals, 8 bits
 
 struct Consts {
   int32_t n_actions;
+  int32_t rows, cols;        // the board (read by the run-time-shape instances)
   uint32_t confined;         // bit s: sprite s is confined to the board
   uint32_t above[MAX_NS];    // bit j: sprite j is in front of sprite s; bit NS: the judge drape is
   uint32_t init[W_POS + MAX_NS];
@@ -74,17 +75,21 @@ __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16
 // NS sprites: boxes 0..NS-2 in template order, the player is sprite NS-1 and
 // the front-most thing.  R x C board, NB backdrop-only characters, NWAVES waves
 // per workgroup (wave 0 steps the group, all of them share the render loop).
-template <int NS, int R, int C, int NB, int NWAVES, bool EPI = false>
+// SR x SC: the board's shape when the instance is compiled for it; 0 x 0: read from k.rows / k.cols
+// (levels that are neither shipped nor among the fixtures' compiled shapes).
+template <int NS, int SR, int SC, int NB, int NWAVES, bool EPI = false>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                     const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                     const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
-  constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32, FWP = FW | 1;
+  const int R = SR ? SR : k.rows, C = SC ? SC : k.cols;  // (constants in the compiled-shape instances)
+  constexpr int SQW = ((SR * SC + 3) & ~3) / 4;           // dwords per plane, 0: run-time shape
+  const int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32, FWP = FW | 1;
   constexpr int L = NS + 1 + NB, IP = NS - 1, NBOX = NS - 1;
-  constexpr int O_BD = 0, O_BDM = O_BD + QW, O_GOAL = O_BDM + NB * QW, O_BBLK = O_GOAL + R, O_PBLK = O_BBLK + R,
-                O_TAB_END = O_PBLK + R;
-  constexpr int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
-  constexpr int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
+  const int O_BD = 0, O_BDM = O_BD + QW, O_GOAL = O_BDM + NB * QW, O_BBLK = O_GOAL + R, O_PBLK = O_BBLK + R,
+            O_TAB_END = O_PBLK + R;
+  const int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
+  const int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
   const uint32_t* const goal_rows = lds + O_GOAL;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
       float discount = 1.0f;
       frame += 1;  // engine.py:698-735
 
-      auto on_board = [](int r, int c) { return (unsigned)r < (unsigned)R && (unsigned)c < (unsigned)C; };
+      auto on_board = [&](int r, int c) { return (unsigned)r < (unsigned)R && (unsigned)c < (unsigned)C; };
       // Sprite.position: the virtual position while on the board, else (0, 0) (sprites.py:223-275)
       auto true_cell = [&](int r, int c) { return on_board(r, c) ? r * C + c : 0; };
       // sprites.py:315-352 _teleport with the exit/enter visibility bookkeeping
@@ -304,12 +309,13 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
   uint32_t bch4[NB > 0 ? NB : 1] = {};
 #pragma unroll
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
-  constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
+  const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
-    stream::stream_planes<NS, 1, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+    stream::stream_planes<NS, 1, NB, SQW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                 flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, QW);
   if (fc)
-    stream::stream_windows<NS, 1, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
+    stream::stream_windows<NS, 1, NB, SQW, NWAVES, SR, SC>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner,
+                                                         nullptr, stream::BoardShape{R, C, QW});
 }
 
 // ---------------------------------------------------------------------------
@@ -339,6 +345,7 @@ class WarehouseBackend : public Backend {
   int plane_pitch() const override { return lay_.pitch; }
   int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
   int set_epilogue(const pcx_epilogue_desc* d) override {
+    if (d && !static_shape_) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: the feature-array epilogue exists for the compiled shapes");
     if (!stream::fill_epilogue(epi_, d, lay_.cells, sprite_ch_, NS_, &drape_ch_, 1, bchar_ch_, NB_))
       return set_error(PCX_E_UNSUPPORTED, "warehouse backend: epilogue needs rows*cols %% 4 == 0");
     return 0;
@@ -353,6 +360,7 @@ class WarehouseBackend : public Backend {
   int NS_ = 0, R_ = 0, C_ = 0, NB_ = 0, L_ = 0, NW_ = 0;
   int64_t batch_ = 0, bpad_ = 0;
   int num_cus_ = 256;
+  bool static_shape_ = false;  // a compiled instance for exactly this shape exists
   std::vector<uint8_t> goal_;  // host copy for read_things
   DevArray<uint32_t> tables_, state_, curtains_;
   DevArray<int32_t> track_;
@@ -367,13 +375,17 @@ int WarehouseBackend::init(const pcx_template& t, int64_t batch) {
   if (t.n_directives) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: plot directives");
   NS_ = t.n_sprites; R_ = t.rows; C_ = t.cols; L_ = t.n_chars;
   NB_ = L_ - NS_ - 1;
-  bool shape_ok = false;
-#define X(ns, r, c, nb) shape_ok |= NS_ == ns && R_ == r && C_ == c && NB_ == nb;
+  static_shape_ = false;
+#define X(ns, r, c, nb) static_shape_ |= NS_ == ns && R_ == r && C_ == c && NB_ == nb;
   PCX_WM_SHAPES(X)
 #undef X
-  if (t.n_drapes != 1 || !shape_ok || NS_ > MAX_NS || NB_ > MAX_NB)
+  // any other level takes a run-time-shape instance (one per number of sprites): rows of at most 32 cells
+  // (goal / blocked tables are a word per row), the usual four backdrop-only characters
+  const bool dynamic_ok = NS_ >= 2 && NS_ <= MAX_NS && NB_ == 4 && C_ <= 32 && R_ <= 255;
+  if (t.n_drapes != 1 || !(static_shape_ || dynamic_ok) || NS_ > MAX_NS || NB_ > MAX_NB)
     return set_error(PCX_E_UNSUPPORTED, "warehouse backend: no instance for this shape");
   lay_.set(R_, C_);
+  k.rows = R_; k.cols = C_;
   // sprites: boxes first, the player last (template order is kept: ascii_art.py:278-283)
   const int ip = NS_ - 1;
   for (int s = 0; s < NS_; ++s) {
@@ -527,6 +539,20 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   }
   PCX_WM_SHAPES(X)
 #undef X
+  if (!launched && !static_shape_ && !epi) {  // run-time-shape instances, one per number of sprites
+    if (lds > 64 * 1024) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: board too large for the step kernel's LDS tables");
+    switch (NS_) {
+#define PCX_WM_DYN(ns)                                                                                      \
+  case ns:                                                                                                  \
+    if (coop) PCX_WM_LAUNCH(ns, 0, 0, 4, 4, false); else PCX_WM_LAUNCH(ns, 0, 0, 4, 1, false);              \
+    launched = true;                                                                                        \
+    break;
+      PCX_WM_DYN(2) PCX_WM_DYN(3) PCX_WM_DYN(4) PCX_WM_DYN(5) PCX_WM_DYN(6) PCX_WM_DYN(7) PCX_WM_DYN(8) PCX_WM_DYN(9)
+      PCX_WM_DYN(10) PCX_WM_DYN(11)
+#undef PCX_WM_DYN
+      default: break;
+    }
+  }
 #undef PCX_WM_LAUNCH
   if (!launched) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: no instance");
   PCX_HIP(hipGetLastError());

@@ -162,6 +162,7 @@ def test_hip_hand_written_kernels_other_launch_shapes(name, knob, value, monkeyp
                                          ('warehouse_L1', 'pcx_warehouse_step'), ('scrolly_maze_L2', 'pcx_scrolly_maze_step'),
                                          ('marauders_custom_A', 'pcx_generic_step'), ('hello_world', 'pcx_hello_world_step'),
                                          ('hello_custom_A', 'pcx_hello_world_step'),
+                                         ('warehouse_custom_C', 'pcx_warehouse_step'), ('warehouse_custom_D', 'pcx_warehouse_step'),
                                          ('warehouse_L0_unoccluded', 'pcx_generic_step')])
 @pytest.mark.parametrize('shape', ['coop', 'single'])
 def test_which_kernel_steps_which_game(name, kernel, shape, monkeypatch):
