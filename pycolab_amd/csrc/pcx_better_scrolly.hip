@@ -47,6 +47,7 @@ constexpr int F_LEFT_SHIFT = 16;  // coins left (CashDrape.curtain.any() without
 constexpr int MAX_CW = 8;  // coin-mask words (at most 255 coins: a list index is a byte)
 
 struct Consts {
+  int32_t rows, cols;  // the board (read by the run-time-shape instance)
   int32_t n_actions, n_coins, CW;
   uint32_t confined;
   uint32_t above[NS];
@@ -74,16 +75,20 @@ __device__ __forceinline__ uint32_t pack_pos(int r, int c) { return ((uint32_t)r
 __device__ __forceinline__ int pos_r(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
 __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16); }
 
-template <int R, int C, int NWAVES>
+// SR x SC: the board's shape when the instance is compiled for it (the three shipped boards); 0 x 0: read
+// from k.rows / k.cols (boards the example does not ship).
+template <int SR, int SC, int NWAVES>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                          const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                          const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
-  constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32;
+  const int R = SR ? SR : k.rows, C = SC ? SC : k.cols;  // (constants in the compiled-shape instances)
+  constexpr int SQW = ((SR * SC + 3) & ~3) / 4;           // dwords per plane, 0: run-time shape
+  const int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32;
   constexpr int L = NS + ND + NB, CWP = MAX_CW | 1;
-  constexpr int O_BD = 0, O_BDM = O_BD + QW, O_CID = O_BDM + NB * QW, O_WALL = O_CID + QW, O_TAB_END = O_WALL + FW;
-  constexpr int O_CM = O_TAB_END, O_SDESC = (O_CM + WAVE * CWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
-  constexpr int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
+  const int O_BD = 0, O_BDM = O_BD + QW, O_CID = O_BDM + NB * QW, O_WALL = O_CID + QW, O_TAB_END = O_WALL + FW;
+  const int O_CM = O_TAB_END, O_SDESC = (O_CM + WAVE * CWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
+  const int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
   const uint32_t* const cid = lds + O_CID;    // list indices of every board dword's four cells (0xFF: no coin there)
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
       float discount = 1.0f;
       frame += 1;  // engine.py:698-735
 
-      auto on_board = [](int r, int c) { return (unsigned)r < (unsigned)R && (unsigned)c < (unsigned)C; };
+      auto on_board = [&](int r, int c) { return (unsigned)r < (unsigned)R && (unsigned)c < (unsigned)C; };
       auto true_cell = [&](int r, int c) { return on_board(r, c) ? r * C + c : 0; };  // Sprite.position
       auto teleport = [&](int s, int nr, int nc) {  // sprites.py:315-352
         const bool old_on = on_board(vr[s], vc[s]), new_on = on_board(nr, nc);
@@ -305,12 +310,13 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
   uint32_t bch4[NB > 0 ? NB : 1] = {};
 #pragma unroll
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
-  constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
+  const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
-    stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                        cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid);
+    stream::stream_planes<NS, ND, NB, SQW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                         cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid, QW);
   if (fc)
-    stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C, true>(fc, pm, bch4, env0, lds + O_BD, cm, sdesc, skipv, CWP, lane, wave, wcorner, cid);
+    stream::stream_windows<NS, ND, NB, SQW, NWAVES, SR, SC, true>(fc, pm, bch4, env0, lds + O_BD, cm, sdesc, skipv, CWP, lane, wave, wcorner,
+                                                                 cid, stream::BoardShape{R, C, QW});
 }
 
 // ---------------------------------------------------------------------------
@@ -346,6 +352,7 @@ class BetterScrollyBackend : public Backend {
   int R_ = 0, C_ = 0, L_ = 0, NW_ = 0;
   int64_t batch_ = 0, bpad_ = 0;
   int num_cus_ = 256;
+  bool static_shape_ = false;  // a compiled instance for exactly this board exists
   DevArray<uint32_t> tables_, coin_cell_, state_, curtains_;
   DevArray<int32_t> track_;
   std::vector<uint32_t> h_coin_cell_;  // host copy for read_things
@@ -358,13 +365,17 @@ int BetterScrollyBackend::init(const pcx_template& t, int64_t batch) {
   if (const char* e = getenv("PCX_FORCE_GENERIC")) if (atoi(e)) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: PCX_FORCE_GENERIC");
   if (!t.occlusion_in_layers || t.n_directives) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: occluded layers, no directives");
   R_ = t.rows; C_ = t.cols; L_ = t.n_chars;
-  bool shape_ok = false;
-#define X(r, c) shape_ok |= R_ == r && C_ == c;
+  static_shape_ = false;
+#define X(r, c) static_shape_ |= R_ == r && C_ == c;
   PCX_BS_SHAPES(X)
 #undef X
+  // any other board takes the run-time-shape instance, as long as its tables fit the 64 KB of LDS a workgroup may have
+  const bool shape_ok = static_shape_ || (R_ <= 255 && C_ <= 255 &&
+      ((size_t)((R_ * C_ + 3) / 4) * (2 + NB) + (R_ * C_ + 31) / 32 + WAVE * (MAX_CW | 1) + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4 <= 64 * 1024);
   if (!shape_ok || t.n_sprites != NS || t.n_drapes != ND || L_ != NS + ND + NB || t.n_groups != 1 || t.n_things != NS + ND)
     return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the shipped boards and cast only");
   lay_.set(R_, C_);
+  k.rows = R_; k.cols = C_;
   // sprites: three patrollers then the player; impassable == {'#'}; schedule a b c P @; z-order: patrollers, coins, player
   for (int s = 0; s < NS; ++s) {
     const pcx_sprite_desc& sd = t.sprites[s];
@@ -496,6 +507,12 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
   }
   PCX_BS_SHAPES(X)
 #undef X
+  if (!launched && !static_shape_) {  // the run-time-shape instance
+    if (lds > 64 * 1024) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: board too large for the step kernel's LDS tables");
+    if (coop) hipLaunchKernelGGL((pcx_better_scrolly_step<0, 0, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());
+    else hipLaunchKernelGGL((pcx_better_scrolly_step<0, 0, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());
+    launched = true;
+  }
   if (!launched) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: no instance");
   PCX_HIP(hipGetLastError());
   return 0;

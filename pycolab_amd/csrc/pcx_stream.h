@@ -89,71 +89,6 @@ struct EpilogueArgs {
 };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// What one board dword shows, from the LDS descriptors alone (shared by the
-// streaming loop and by the fused croppers' windows): the board dword and, as
-// 0x00 / 0xFF byte masks, which of its four cells every drape and sprite paints;
-// mb[b] = the backdrop-only character b's layer bytes (0 / 1) where nothing paints.
-template <int NS, int ND, int NB, int QW>
-struct Composer {
-  const PlaneMap<NS, ND, NB>& pm;
-  const uint32_t* backdrop4;
-  const uint32_t* bdmask;
-  const uint32_t* flat;
-  const uint2* sdesc;
-  const uint32_t* cell_ids;
-  int FWP;
-  int qw;  // dwords per plane when QW == 0 (run-time board shape)
-  __device__ __forceinline__ void operator()(uint32_t e_now, uint32_t q_now, uint32_t eF_now, uint32_t& d,
-                                             uint32_t (&md)[ND > 0 ? ND : 1], uint32_t (&ms)[NS > 0 ? NS : 1],
-                                             uint32_t (&mb)[NB > 0 ? NB : 1]) const {
-    // every LDS read of the dword is issued up front
-    d = backdrop4[q_now];
-#pragma unroll
-    for (int dd = 0; dd < ND; ++dd) {
-      uint32_t bits;
-      if (cell_ids != nullptr) {  // (uniform; resolved at compile time where the caller passes a constant)
-        const uint32_t ids = cell_ids[q_now];
-        bits = 0;
-        if (ids != 0xFFFFFFFFu) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t id = (ids >> (8 * j)) & 0xFFu;
-            if (id != 0xFFu) bits |= ((flat[eF_now + (id >> 5)] >> (id & 31)) & 1u) << j;
-          }
-        }
-      } else {
-        bits = (flat[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;
-      }
-      const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;  // bit i -> byte i
-      uint32_t hi8 = m01 << 8;
-      asm("" : "+v"(hi8));  // keep LLVM from folding (x << 8) - x into a quarter-rate x * 255
-      md[dd] = hi8 - m01;   // 0x01 -> 0xFF per byte
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const uint2 sd = sdesc[s * WAVE + e_now];
-      ms[s] = sd.x == q_now ? sd.y : 0u;
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) mb[b] = bdmask[b * (QW ? QW : qw) + q_now];
-    uint32_t uni = 0;
-#pragma unroll
-    for (int dd = 0; dd < ND; ++dd) {
-      uni |= md[dd];
-      d = (d & ~md[dd]) | (pm.drape_ch4[dd] & md[dd]);
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      uni |= ms[s];
-      d = (d & ~ms[s]) | (pm.sprite_ch4[s] & ms[s]);
-    }
-    // rendering.py:177-179 layers[c] = (board == c): by construction the thing's
-    // own mask, or the backdrop's precomputed mask where no thing paints
-#pragma unroll
-    for (int b = 0; b < NB; ++b) mb[b] &= ~uni;
-  }
-};
-
 // The wavefront streams board + layers of the group's 64 environments.
 // One (environment e, board dword q) task per lane and iteration; consecutive
 // lanes take consecutive dwords, so every plane store of a wave covers 256
@@ -188,7 +123,6 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
 #pragma unroll
   for (int b = 0; b < NB; ++b) pb_b[b] = uniform_ptr(pb_board + pm.bchar_off[b]);
 
-  const Composer<NS, ND, NB, QW> compose{pm, backdrop4, bdmask, flat, sdesc, cell_ids, FWP, (int)QWv};
   const bool any_skip = __ballot(skip[lane] != 0) != 0ull;
   // Drain the logic phase's own loads/stores once, here: the loop's stores are
   // inline asm the compiler cannot count, and without this it would protect a
@@ -239,15 +173,57 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
         asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(fo), "v"(f), "s"(fbase));
       }
     };
-    uint32_t d, md[ND > 0 ? ND : 1], ms[NS > 0 ? NS : 1], mb[NB > 0 ? NB : 1];
-    compose(e_now, q_now, eF_now, d, md, ms, mb);
+    // every LDS read of the iteration is issued up front
+    uint32_t d = backdrop4[q_now];
+    uint32_t md[ND > 0 ? ND : 1], ms[NS > 0 ? NS : 1], mb[NB > 0 ? NB : 1];
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+      uint32_t bits;
+      if (cell_ids != nullptr) {  // (uniform; resolved at compile time where the caller passes a constant)
+        const uint32_t ids = cell_ids[q_now];
+        bits = 0;
+        if (ids != 0xFFFFFFFFu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t id = (ids >> (8 * j)) & 0xFFu;
+            if (id != 0xFFu) bits |= ((flat[eF_now + (id >> 5)] >> (id & 31)) & 1u) << j;
+          }
+        }
+      } else {
+        bits = (flat[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;
+      }
+      const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;  // bit i -> byte i
+      uint32_t hi8 = m01 << 8;
+      asm("" : "+v"(hi8));  // keep LLVM from folding (x << 8) - x into a quarter-rate x * 255
+      md[dd] = hi8 - m01;   // 0x01 -> 0xFF per byte
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const uint2 sd = sdesc[s * WAVE + e_now];
+      ms[s] = sd.x == q_now ? sd.y : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) mb[b] = bdmask[b * QWv + q_now];
+    uint32_t uni = 0;
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+      uni |= md[dd];
+      d = (d & ~md[dd]) | (pm.drape_ch4[dd] & md[dd]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      uni |= ms[s];
+      d = (d & ~ms[s]) | (pm.sprite_ch4[s] & ms[s]);
+    }
     put(pb_board, d);
+    // rendering.py:177-179 layers[c] = (board == c): by construction the thing's
+    // own mask, or the backdrop's precomputed mask where no thing paints
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) put_layer(pb_d[dd], md[dd] & 0x01010101u, epi.drape_slot[dd]);
 #pragma unroll
     for (int s = 0; s < NS; ++s) put_layer(pb_s[s], ms[s] & 0x01010101u, epi.sprite_slot[s]);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) put_layer(pb_b[b], mb[b], epi.bchar_slot[b]);
+    for (int b = 0; b < NB; ++b) put_layer(pb_b[b], mb[b] & ~uni, epi.bchar_slot[b]);
   }
 }
 

@@ -163,6 +163,7 @@ def test_hip_hand_written_kernels_other_launch_shapes(name, knob, value, monkeyp
                                          ('marauders_custom_A', 'pcx_generic_step'), ('hello_world', 'pcx_hello_world_step'),
                                          ('hello_custom_A', 'pcx_hello_world_step'),
                                          ('warehouse_custom_C', 'pcx_warehouse_step'), ('warehouse_custom_D', 'pcx_warehouse_step'),
+                                         ('better_scrolly_custom_A', 'pcx_better_scrolly_step'), ('better_scrolly_custom_B', 'pcx_better_scrolly_step'),
                                          ('warehouse_L0_unoccluded', 'pcx_generic_step')])
 @pytest.mark.parametrize('shape', ['coop', 'single'])
 def test_which_kernel_steps_which_game(name, kernel, shape, monkeypatch):
