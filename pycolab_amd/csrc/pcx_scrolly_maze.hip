@@ -939,10 +939,16 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       lslot[kk] = EPI ? slot : -1;
     }
   }
+  // CODES + INCR: the code dword of the NEXT iteration is requested before this iteration's stores are
+  // issued, so its LDS latency runs under them (software pipelining by hand: the loop is not unrolled)
+  constexpr bool PREFETCH = CODES && INCR;
+  uint32_t code_pf = 0;
+  if constexpr (PREFETCH) code_pf = codes[eF + q];
 #pragma unroll 1
   for (int it = COOP ? wave : TFUSE ? wave - 1 : 0; it < QW;
        it += COOP ? (int)(blockDim.x >> 6) : TFUSE ? (int)(blockDim.x >> 6) - 1 : 1) {
     uint32_t e_now, q_now, voff_now, eF_now, foff_now = 0;
+    uint32_t code_cur = 0;
     if constexpr (INCR) {
       e_now = e; q_now = q; voff_now = voff; eF_now = eF;
       q += WAVE; voff += 4u * WAVE;
@@ -952,6 +958,10 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       voff = wrap ? voff + e_skew : voff;
       eF = wrap ? eF + (CODES ? CODE_PITCH : FWP) : eF;
       if constexpr (EPI) { foff_now = foff; foff += 16u * WAVE; foff = wrap ? foff + f_skew : foff; }
+      if constexpr (PREFETCH) {
+        code_cur = code_pf;
+        code_pf = codes[it + 1 < QW ? eF + q : 0u];
+      }
     } else {
       const uint32_t f = (uint32_t)it * WAVE + lane;
       e_now = (f * magic_q) >> 20;
@@ -964,7 +974,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     if constexpr (CODES) {
       // one LDS read, then one v_perm_b32 per plane: the board dword picks each
       // cell's character out of the eight, layer k picks byte k of a one-hot table
-      const uint32_t code = codes[eF_now + q_now];
+      const uint32_t code = PREFETCH ? code_cur : codes[eF_now + q_now];
       auto put_plane = [&](uint8_t* base, uint32_t v, int32_t slot) {
         if (!EPI || slot == -2 || layers_on)
           asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(base));
