@@ -265,6 +265,7 @@ class Engine(object):
     """Restart environments in place (a new episode = a new Engine in the
     reference): all of them, or those where `env_mask` (uint8/bool [batch],
     host array or device tensor) is nonzero."""
+    self._b  # (raises after close())
     ptr, keep = None, None
     if env_mask is not None:
       torch = dev.torch_module()
@@ -282,6 +283,7 @@ class Engine(object):
 
   def step(self, actions):
     """`play()` without materialising return values (no host sync)."""
+    self._b  # (raises after close())
     ptr = self._stage_actions(actions)
     N.check(N.lib().pcx_engine_step(self._native, ptr, int(self._auto_reset),
                                     dev.current_stream(self._device_id)))
@@ -290,6 +292,7 @@ class Engine(object):
   def step_n(self, action_tape):
     """`len(action_tape)` consecutive steps from a device int32 tensor (or host
     array) of shape [T, batch]; only the last step's observation survives."""
+    self._b  # (raises after close())
     torch = dev.torch_module()
     if torch is not None and isinstance(action_tape, torch.Tensor):
       if action_tape.dtype != torch.int32 or not action_tape.is_cuda or not action_tape.is_contiguous():
@@ -311,6 +314,7 @@ class Engine(object):
   def step_hashed(self, seed, t0, steps, env_offset=None):
     """`steps` steps with on-device actions `hash(seed, env, t) % n_actions`,
     env = `env_offset` (default: the engine's configured offset) + local index."""
+    self._b  # (raises after close())
     if env_offset is None:
       env_offset = self._env_offset
     N.check(N.lib().pcx_engine_step_hashed(
@@ -338,7 +342,7 @@ class Engine(object):
 
   def _read_scalars(self):
     dev.synchronize(self._device_id)
-    return {k: self._bufs[k].numpy() for k in
+    return {k: self._b[k].numpy() for k in
             ('reward', 'reward_set', 'discount', 'done', 'frame', 'error')}
 
   def check_errors(self):
@@ -346,7 +350,7 @@ class Engine(object):
     reference raises for (the bits are sticky within an episode).  `play()`
     with batch 1 checks every step; with batch > 1 it polls asynchronously and
     raises one or two steps late; `step()` never checks."""
-    err = self._bufs['error'].numpy()
+    err = self._b['error'].numpy()
     if err.any():
       bad = int(np.flatnonzero(err)[0])
       code = int(err[bad])
@@ -358,7 +362,7 @@ class Engine(object):
     """Observation planes as [B, 1+n_chars, rows, cols]: a zero-copy strided
     view of the device tensor (plane pitch may exceed rows*cols), or a NumPy
     copy with `host=True` / without PyTorch."""
-    planes = self._bufs['planes']
+    planes = self._b['planes']
     B, P, R, C = self._batch, 1 + len(self._template.chars), self._rows, self._cols
     if planes.tensor is not None and not host:
       return planes.tensor.as_strided((B, P, R, C), (P * self._pitch, self._pitch, C, 1))
@@ -375,8 +379,8 @@ class Engine(object):
       return self._tag(rendering.Observation(board=p[0], layers=layers)), reward, float(sc['discount'][0])
     arr = self.planes_view()
     layers = {chr(c): arr[:, 1 + k] for k, c in enumerate(L)}
-    pick = lambda k: (self._bufs[k].tensor if self._bufs[k].tensor is not None
-                      else self._bufs[k].numpy())
+    pick = lambda k: (self._b[k].tensor if self._b[k].tensor is not None
+                      else self._b[k].numpy())
     return (self._tag(rendering.Observation(board=arr[:, 0], layers=layers)),
             pick('reward'), pick('discount'))
 
@@ -393,11 +397,11 @@ class Engine(object):
   @property
   def planes(self):
     """The raw observation planes buffer [B, 1+n_chars, pitch] (see planes_view)."""
-    return self._bufs['planes']
+    return self._b['planes']
 
   @property
   def buffers(self):
-    return self._bufs
+    return self._b
 
   @property
   def scalars_packed(self):
@@ -408,7 +412,7 @@ class Engine(object):
   @property
   def reward_set(self):
     """uint8 [B]: 0 where the reference's reward would be `None`."""
-    b = self._bufs['reward_set']
+    b = self._b['reward_set']
     return b.tensor if b.tensor is not None else b.numpy()
 
   @property
@@ -429,7 +433,7 @@ class Engine(object):
     if self._native is None:
       return False
     dev.synchronize(self._device_id)
-    done = self._bufs['done'].numpy()  # this one array only
+    done = self._b['done'].numpy()  # this one array only
     return bool(done[0]) if self._batch == 1 else done
 
   @property
@@ -470,12 +474,24 @@ class Engine(object):
         cu.ctypes.data if (curtains and nd) else None))
     return sp, cu
 
+  @property
+  def _b(self):
+    """The engine's device buffers; raises once the engine was closed."""
+    if not self._bufs:
+      raise RuntimeError('this Engine is not in play (its_showtime() has not run, or close() has)')
+    return self._bufs
+
   def close(self):
+    """Destroys the device engine and lets go of its device memory (tensors the
+    caller still holds -- observations, cropped windows -- stay valid)."""
     if self._native is not None:
       for cropper in self._croppers:  # their native halves point into this engine: they go first
         cropper._release()
       N.lib().pcx_engine_destroy(self._native)
       self._native = None
+      # engine <-> cropper references form a cycle: without this the buffers would wait for the garbage collector
+      self._croppers = []
+      self._bufs, self._packed, self._actions, self._keepalive = {}, None, None, None
 
   def __del__(self):
     try:
