@@ -44,39 +44,47 @@ __device__ __forceinline__ void store4<uint64_t>(uint64_t* dst, uint64_t a, uint
 template <typename T>
 __global__ void pcx_post_to_array(PostParams p, const uint8_t* planes, const uint64_t* lut, const uint8_t* mapped,
                                   T* out, uint8_t* error) {
-  extern __shared__ uint64_t lds_lut[];  // [depth][128] values, then 128 mapped bytes
-  uint8_t* lds_mapped = reinterpret_cast<uint8_t*>(lds_lut + p.depth * 128);
-  for (int i = threadIdx.x; i < p.depth * 128; i += blockDim.x) lds_lut[i] = lut[i];
+  extern __shared__ uint64_t lds_raw64[];  // [depth][128] values of type T, then 128 mapped bytes
+  T* const lds_lut = reinterpret_cast<T*>(lds_raw64);
+  uint8_t* const lds_mapped = reinterpret_cast<uint8_t*>(lds_lut + p.depth * 128);
+  for (int i = threadIdx.x; i < p.depth * 128; i += blockDim.x) lds_lut[i] = (T)lut[i];
   for (int i = threadIdx.x; i < 128; i += blockDim.x) lds_mapped[i] = mapped[i];
   __syncthreads();
-  // the table is staged once per workgroup, so a workgroup takes many dwords
-  // (grid-stride): one lane per board dword and trip
-  const int qw = p.pitch / 4;
-  const uint32_t total = (uint32_t)p.batch * (uint32_t)qw;
-  for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < total; f += gridDim.x * blockDim.x) {
-    const uint32_t b = f / (uint32_t)qw, q = f - b * (uint32_t)qw;
-    const uint32_t d4 = reinterpret_cast<const uint32_t*>(planes + (size_t)b * p.n_planes * p.pitch)[q];
-    const int cell0 = (int)q * 4, n = p.cells - cell0 < 4 ? p.cells - cell0 : 4;
-    uint32_t ch[4];
-    bool bad = false;
+  // the table is staged once per workgroup, so a workgroup takes many dwords: a contiguous chunk of the
+  // batch's dwords, walked front to back (sequential read and write streams per workgroup), one lane per
+  // board dword and trip; (environment, dword) advance incrementally -- one division per lane, not per trip
+  const uint32_t qw = (uint32_t)p.pitch / 4u, total = (uint32_t)p.batch * qw;
+  const uint32_t chunk = (total + gridDim.x - 1) / gridDim.x, stride = blockDim.x;
+  const uint32_t db = stride / qw, dq = stride - db * qw;
+  uint32_t f = blockIdx.x * chunk + threadIdx.x;
+  const uint32_t end = (blockIdx.x + 1) * chunk < total ? (blockIdx.x + 1) * chunk : total;
+  uint32_t b = f / qw, q = f - b * qw;
+  for (; f < end; f += stride) {
+    const uint32_t b_now = b, q_now = q;
+    q += dq; b += db;
+    if (q >= qw) { q -= qw; ++b; }
+    const uint32_t d4 = reinterpret_cast<const uint32_t*>(planes + (size_t)b_now * p.n_planes * p.pitch)[q_now];
+    const int cell0 = (int)q_now * 4, n = p.cells - cell0 < 4 ? p.cells - cell0 : 4;
+    uint32_t ch[4], bad = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      ch[j] = (d4 >> (8 * j)) & 0xFFu;
-      if (j < n && (ch[j] >= 128u || !lds_mapped[ch[j]])) bad = true;  // rendering.py:503-507
-      ch[j] &= 127u;
+      const uint32_t c8 = (d4 >> (8 * j)) & 0xFFu;
+      ch[j] = c8 & 127u;
+      // rendering.py:503-507 a character the mapping lacks (arithmetic: no branch around the table read)
+      bad |= (uint32_t)(j < n) & ((uint32_t)(c8 >= 128u) | (uint32_t)(lds_mapped[ch[j]] == 0));
     }
-    if (bad) { error[b] = 1; continue; }
-    T* const o = out + (size_t)b * p.depth * p.cells;
+    if (bad) { error[b_now] = 1; continue; }
+    T* const o = out + (size_t)b_now * p.depth * p.cells;
     if (p.linear && n == 4) {  // default axis order: (d, r, c) row-major, four consecutive elements per layer
       for (int d = 0; d < p.depth; ++d)
-        store4<T>(o + (size_t)d * p.cells + cell0, (T)lds_lut[d * 128 + ch[0]], (T)lds_lut[d * 128 + ch[1]],
-                  (T)lds_lut[d * 128 + ch[2]], (T)lds_lut[d * 128 + ch[3]]);
+        store4<T>(o + (size_t)d * p.cells + cell0, lds_lut[d * 128 + ch[0]], lds_lut[d * 128 + ch[1]],
+                  lds_lut[d * 128 + ch[2]], lds_lut[d * 128 + ch[3]]);
       continue;
     }
     for (int j = 0; j < n; ++j) {
       const int cell = cell0 + j, r = cell / p.C, c = cell - r * p.C;
       for (int d = 0; d < p.depth; ++d)
-        o[d * p.stride[0] + r * p.stride[1] + c * p.stride[2]] = (T)lds_lut[d * 128 + ch[j]];
+        o[d * p.stride[0] + r * p.stride[1] + c * p.stride[2]] = lds_lut[d * 128 + ch[j]];
     }
   }
 }
@@ -296,7 +304,7 @@ int pcx_post_run(pcx_post* q, void* stream) {
   const int64_t n = p.batch * (p.pitch / 4);
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (p.kind == PCX_POST_TO_ARRAY) {
-    const size_t lds = (size_t)p.depth * 128 * 8 + 128;
+    const size_t lds = (((size_t)p.depth * 128 * p.esize + 7) & ~(size_t)7) + 128;
     const dim3 grid((unsigned)((n + 255) / 256 < 256 * 16 ? (n + 255) / 256 : 256 * 16));  // 16 workgroups per CU stage the table once each
     if (p.esize == 1)
       hipLaunchKernelGGL(pcx_post_to_array<uint8_t>, grid, block, lds, s, p, q->planes, q->lut.ptr, q->mapped.ptr,
