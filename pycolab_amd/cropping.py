@@ -273,6 +273,11 @@ def fuse_croppers(engine, croppers, only_crops=False):
     if type(cr) is ObservationCropper:
       raise ValueError('the identity cropper has nothing to fuse')
     cr.set_engine(engine)
+  if only_crops:
+    others = [cr for cr in getattr(engine, '_croppers', []) if cr not in croppers and type(cr) is not ObservationCropper]
+    if others:
+      raise ValueError('only_crops=True stops the engine from writing the observation that its %d other cropper(s) '
+                       'read: fuse them too, or detach them' % len(others))
   if engine._native is None:  # not in play yet: its_showtime() fuses before frame 0
     engine._fuse_request = (croppers, bool(only_crops))
     return None

@@ -278,3 +278,6 @@ def test_fuse_croppers_answers_false_where_the_kernel_cannot():
   drape.set_engine(eng2)
   eng2.its_showtime()
   assert cropping.fuse_croppers(eng2, [drape]) is False          # drape trackers stay stand-alone
+  sprite = cropping.ScrollingCropper(3, 3, ['P'], pad_char=' ', scroll_margins=(None, None))
+  with pytest.raises(ValueError):                                  # the stand-alone cropper would read stale planes
+    cropping.fuse_croppers(eng2, [sprite], only_crops=True)
