@@ -1,0 +1,219 @@
+"""Randomised levels of the shipped games, built where the reference's example
+files are absent: the entity classes below opt in to the device programs with
+`pcx_program` (what a user's own variant of a shipped class does), the art is
+drawn at random, and the HIP path must agree with the oracle on every step.
+Exercises the shape-generic / run-time-shape instances of the hand-written
+kernels on shapes no fixture has (boards that are not whole dwords, one to ten
+boxes, one to six walkers, windows of 12 to 900 cells)."""
+import numpy as np
+import pytest
+
+from oracle import binding
+from pycolab_amd import _native as N
+from pycolab_amd import ascii_art
+from pycolab_amd import things
+from pycolab_amd.compiler import GameTemplate
+from pycolab_amd.prefab_parts import drapes as prefab_drapes
+from pycolab_amd.prefab_parts import sprites as prefab_sprites
+from tests.hip_adapter import HipAdapter
+
+
+class OracleAdapter(binding.OracleEngine):
+
+  def read(self, name):
+    return np.array(getattr(self, name))
+
+
+# ---- warehouse_manager (constructors as warehouse_manager.py:209-212, 241-243, 280-283) ----
+class Box(prefab_sprites.MazeWalker):
+  pcx_program = 'warehouse.box'
+
+  def __init__(self, corner, position, character):
+    super(Box, self).__init__(corner, position, character, set('#.0123456789PX') - set(character))
+
+
+class Judge(things.Drape):
+  pcx_program = 'warehouse.judge'
+
+  def __init__(self, curtain, character):
+    super(Judge, self).__init__(curtain, character)
+    self._last_num_boxes_on_goals = 0
+
+
+class Pusher(prefab_sprites.MazeWalker):
+  pcx_program = 'warehouse.player'
+
+  def __init__(self, corner, position, character):
+    super(Pusher, self).__init__(corner, position, character, impassable='#.0123456789X')
+
+
+def random_warehouse(rng):
+  rows, cols = int(rng.randint(5, 14)), int(rng.randint(6, 31))
+  art = np.full((rows, cols), '.', dtype='<U1')
+  art[1:-1, 1:-1] = '#'
+  art[2:-2, 2:-2] = ' '
+  inner = [(r, c) for r in range(2, rows - 2) for c in range(2, cols - 2)]
+  if len(inner) < 4:
+    return random_warehouse(rng)
+  rng.shuffle(inner)
+  n_boxes = int(rng.randint(1, min(10, len(inner) // 3) + 1))
+  cells = iter(inner)
+  boxes = list('1234567890'[:n_boxes])
+  for ch in boxes:
+    art[next(cells)] = ch
+  art[next(cells)] = 'P'
+  for _ in range(n_boxes):
+    art[next(cells)] = '_'
+  for cell in cells:
+    if rng.rand() < 0.12:
+      art[cell] = '#'
+  sprites = {ch: Box for ch in boxes}
+  sprites['P'] = Pusher
+  return ascii_art.ascii_art_to_game([''.join(r) for r in art], ' ', sprites, {'X': Judge},
+                                     update_schedule=[boxes, ['X'], ['P']])
+
+
+# ---- better_scrolly_maze (better_scrolly_maze.py:250-320) ----
+class Walker(prefab_sprites.MazeWalker):
+  pcx_program = 'better_scrolly_maze.player'
+
+  def __init__(self, corner, position, character):
+    super(Walker, self).__init__(corner, position, character, impassable='#')
+
+
+class Patroller(prefab_sprites.MazeWalker):
+  pcx_program = 'better_scrolly_maze.patroller'
+
+  def __init__(self, corner, position, character):
+    super(Patroller, self).__init__(corner, position, character, impassable='#')
+    self._moving_east = bool(ord(character) % 2)
+
+
+class Cash(things.Drape):
+  pcx_program = 'better_scrolly_maze.cash'
+
+
+def random_better_scrolly(rng):
+  rows, cols = int(rng.randint(6, 40)), int(rng.randint(8, 70))
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  art[0, :] = art[-1, :] = art[:, 0] = art[:, -1] = '#'
+  inner = rng.rand(rows - 2, cols - 2)
+  art[1:-1, 1:-1][inner < 0.2] = '#'
+  coins = (inner >= 0.2) & (inner < 0.2 + min(0.1, 200.0 / (rows * cols)))
+  art[1:-1, 1:-1][coins] = '@'
+  free = [(r, c) for r in range(1, rows - 1) for c in range(1, cols - 1) if art[r, c] == ' ']
+  if len(free) < 4 or not coins.any():
+    return random_better_scrolly(rng)
+  rng.shuffle(free)
+  for ch, cell in zip('abcP', free):
+    art[cell] = ch
+  return ascii_art.ascii_art_to_game(
+      [''.join(r) for r in art], ' ',
+      sprites={'P': Walker, 'a': Patroller, 'b': Patroller, 'c': Patroller}, drapes={'@': Cash},
+      update_schedule=['a', 'b', 'c', 'P', '@'], z_order='abc@P')
+
+
+# ---- scrolly_maze (scrolly_maze.py:245-357; built as scrolly_maze.make_game does, :213-235) ----
+class Explorer(prefab_sprites.MazeWalker):
+  pcx_program = 'scrolly_maze.player'
+
+  def __init__(self, corner, position, character, virtual_position):
+    super(Explorer, self).__init__(corner, position, character, egocentric_scroller=True, impassable='#')
+    self._teleport(virtual_position)
+
+
+class Guard(prefab_sprites.MazeWalker):
+  pcx_program = 'scrolly_maze.patroller'
+
+  def __init__(self, corner, position, character, virtual_position):
+    super(Guard, self).__init__(corner, position, character, '#')
+    self._teleport(virtual_position)
+    self._moving_east = bool(ord(character) % 2)
+
+
+class Maze(prefab_drapes.Scrolly):
+  pcx_program = 'scrolly_maze.maze'
+
+
+class Coins(prefab_drapes.Scrolly):
+  pcx_program = 'scrolly_maze.cash'
+
+
+def random_scrolly(rng):
+  br, bc = int(rng.randint(4, 13)), int(rng.randint(6, 33))  # (the default scroll margins (2, 3) need at least 4 x 6)
+  rows, cols = br + int(rng.randint(0, 25)), bc + int(rng.randint(0, 50))
+  rows, cols = max(rows, 5), max(cols, 6)
+  br, bc = min(br, rows), min(bc, cols)
+  patrollers = 'abcde'[:int(rng.randint(0, 6))]
+  sprites = patrollers + 'P'
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  art[0, :] = art[-1, :] = art[:, 0] = art[:, -1] = '#'
+  inner = rng.rand(rows - 2, cols - 2)
+  art[1:-1, 1:-1][inner < 0.2] = '#'
+  art[1:-1, 1:-1][(inner >= 0.2) & (inner < 0.27)] = '@'
+  cr, cc = int(rng.randint(0, rows - br + 1)), int(rng.randint(0, cols - bc + 1))
+  placed = set()
+  for ch in sprites:
+    for _ in range(2000):
+      if ch == 'P':  # the egocentric player starts inside the window
+        r, c = int(rng.randint(cr, cr + br)), int(rng.randint(cc, cc + bc))
+      else:
+        r, c = int(rng.randint(1, rows - 1)), int(rng.randint(1, cols - 1))
+      if 0 < r < rows - 1 and 0 < c < cols - 1 and art[r, c] == ' ' and (r, c) != (cr, cc):
+        art[r, c] = ch
+        placed.add(ch)
+        break
+  if 'P' not in placed:
+    return random_scrolly(rng)
+  sprites = ''.join(ch for ch in sprites if ch in placed)
+  beneath = art[cr, cc] if art[cr, cc] in '# ' else ' '
+  art[cr, cc] = '+'
+  stars = np.full((br, bc), ' ', dtype='<U1')
+  stars[rng.rand(br, bc) < 0.1] = '.'
+  maze, stars = [''.join(r) for r in art], [''.join(r) for r in stars]
+  info = prefab_drapes.Scrolly.PatternInfo(maze, stars, board_northwest_corner_mark='+', what_lies_beneath=str(beneath))
+  parts = {ch: ascii_art.Partial(Explorer if ch == 'P' else Guard, info.virtual_position(ch)) for ch in sprites}
+  z = list(sprites.replace('P', '')) + ['@', '#', 'P']
+  rng.shuffle(z)
+  return ascii_art.ascii_art_to_game(
+      stars, what_lies_beneath=' ', sprites=parts,
+      drapes={'#': ascii_art.Partial(Maze, **info.kwargs('#')), '@': ascii_art.Partial(Coins, **info.kwargs('@'))},
+      update_schedule=[['#'], list(sprites), ['@']], z_order=''.join(z))
+
+
+def _compare(t, kernel, batch, steps, seed):
+  hip, orc = HipAdapter(t, batch), OracleAdapter(t, batch)
+  hip.reset(); orc.reset()
+  assert N.lib().pcx_engine_kernel_name(hip.eng._native).decode() == kernel
+  t0 = 0
+  while t0 < steps:
+    n = 1 if t0 < 12 else 6
+    hip.step_hashed(seed, t0, n); orc.step_hashed(seed, t0, n)
+    t0 += n
+    for name in ('planes', 'reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+      np.testing.assert_array_equal(hip.read(name), orc.read(name), err_msg='%s after step %d (%dx%d)' % (name, t0, t.rows, t.cols))
+  np.testing.assert_array_equal(hip.sprites(), orc.sprites())
+  hip.eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('maker,kernel', [(random_warehouse, 'pcx_warehouse_step'), (random_better_scrolly, 'pcx_better_scrolly_step'),
+                                          (random_scrolly, 'pcx_scrolly_maze_step')])
+@pytest.mark.parametrize('seed', range(8))
+def test_random_levels_match_oracle(maker, kernel, seed):
+  rng = np.random.RandomState(1000 + seed)
+  t = GameTemplate.from_engine(maker(rng))
+  _compare(t, kernel, batch=int(rng.choice([70, 200, 1500])), steps=60, seed=0xF00D + seed)
+
+
+def test_random_levels_build_and_step_on_the_oracle():
+  """CPU: the makers produce valid games (host mirror + template compiler) and the oracle steps them."""
+  rng = np.random.RandomState(3)
+  for maker in (random_warehouse, random_better_scrolly, random_scrolly):
+    for _ in range(4):
+      t = GameTemplate.from_engine(maker(rng))
+      orc = OracleAdapter(t, 8)
+      orc.reset()
+      orc.step_hashed(1, 0, 40)
+      assert orc.read('planes').shape[1] == 1 + len(t.chars)
+      assert not orc.read('error').any()
