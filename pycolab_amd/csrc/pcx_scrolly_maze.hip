@@ -371,7 +371,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   const int wave = threadIdx.x >> 6;
   const int ngroups = (int)(P.bpad / WAVE);
   const int R = SR ? SR : k.R, C = SC ? SC : k.C, L = SL ? SL : k.L;
-  const int cells = R * C, QW = cells >> 2;
+  const int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch >> 2;  // planes start dword-aligned (pad bytes are 0)
   const int FW = SR ? (SR * SC + 31) / 32 + 1 : k.FW;
   // curtain word w of drape d of environment e.  Environment-major with an odd
   // pitch: the logic phase (lane == e, same w) and the render phase (same e,
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   constexpr int NBS = SL ? SL - NS - 2 : MAX_L;  // backdrop-only characters
   const int NB = SL ? NBS : k.n_bchars;
   uint32_t sch4[NS], dch4[2];
-  const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)cells;
+  const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   const int64_t env0 = g_render * WAVE;
   // Uniform per-plane base pointers: every store below is `scalar base +
   // 32-bit lane offset`, and the lane offset is the same for all nine planes.
@@ -815,14 +815,14 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     sch4[s] = (uint32_t)k.sprite_ch[s] * 0x01010101u;
-    pb_s[s] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_sprite[s]) * (uint32_t)cells);
+    pb_s[s] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_sprite[s]) * (uint32_t)pitch);
   }
   dch4[0] = (uint32_t)k.maze_ch * 0x01010101u;
   dch4[1] = (uint32_t)k.cash_ch * 0x01010101u;
-  pb_d[0] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_drape[0]) * (uint32_t)cells);
-  pb_d[1] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_drape[1]) * (uint32_t)cells);
+  pb_d[0] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_drape[0]) * (uint32_t)pitch);
+  pb_d[1] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_drape[1]) * (uint32_t)pitch);
 #pragma unroll
-  for (int i = 0; i < NBS; ++i) pb_b[i] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_bchar[i]) * (uint32_t)cells);
+  for (int i = 0; i < NBS; ++i) pb_b[i] = uniform_ptr(pb_board + (uint32_t)(1 + k.lay_bchar[i]) * (uint32_t)pitch);
   const uint32_t magic_q = k.magic_q;
   const uint32_t e_skew = env_stride - 4u * (uint32_t)QW;  // voff = 4 f + e * e_skew
   const uint32_t* const flat_raw = lds_raw + k.lds_flatraw;
@@ -836,11 +836,11 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   uint32_t po[NPL];
   pb[0] = pb_board; po[0] = 0;
 #pragma unroll
-  for (int dd = 0; dd < 2; ++dd) { pb[1 + dd] = pb_d[dd]; po[1 + dd] = (uint32_t)(1 + k.lay_drape[dd]) * (uint32_t)cells; }
+  for (int dd = 0; dd < 2; ++dd) { pb[1 + dd] = pb_d[dd]; po[1 + dd] = (uint32_t)(1 + k.lay_drape[dd]) * (uint32_t)pitch; }
 #pragma unroll
-  for (int s = 0; s < NS; ++s) { pb[3 + s] = pb_s[s]; po[3 + s] = (uint32_t)(1 + k.lay_sprite[s]) * (uint32_t)cells; }
+  for (int s = 0; s < NS; ++s) { pb[3 + s] = pb_s[s]; po[3 + s] = (uint32_t)(1 + k.lay_sprite[s]) * (uint32_t)pitch; }
 #pragma unroll
-  for (int i = 0; i < NBS; ++i) { pb[3 + NS + i] = pb_b[i]; po[3 + NS + i] = (uint32_t)(1 + k.lay_bchar[i]) * (uint32_t)cells; }
+  for (int i = 0; i < NBS; ++i) { pb[3 + NS + i] = pb_b[i]; po[3 + NS + i] = (uint32_t)(1 + k.lay_bchar[i]) * (uint32_t)pitch; }
 
   // One (environment e, board dword q) task: compose the board dword and hand
   // it and the layer dwords to put(plane tag, value).
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   int32_t lslot[NPK];  // epilogue slot of layer k
   if constexpr (CODES) {
 #pragma unroll
-    for (int kk = 0; kk < NPK; ++kk) pbk[kk] = uniform_ptr(pb_board + (uint32_t)kk * (uint32_t)cells);
+    for (int kk = 0; kk < NPK; ++kk) pbk[kk] = uniform_ptr(pb_board + (uint32_t)kk * (uint32_t)pitch);
 #pragma unroll
     for (int kk = 0; kk < SL; ++kk) {
       int32_t slot = -1;
@@ -1058,7 +1058,7 @@ class ScrollyMazeBackend : public Backend {
   int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)2 * k_.FW * bpad_); }
   int curtain_words() const override { return k_.FW; }
   int64_t batch_pad() const override { return bpad_; }
-  int plane_pitch() const override { return k_.cells; }
+  int plane_pitch() const override { return (k_.cells + 3) & ~3; }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
     if (d && !shipped_shape)
@@ -1098,10 +1098,10 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: expects 2 Scrolly drapes and 1..%d sprites", MAX_NS);
   k.R = t.rows; k.C = t.cols; k.cells = t.rows * t.cols; k.L = t.n_chars; k.NS = t.n_sprites;
   k.n_things = t.n_things; k.n_actions = t.n_actions;
-  if (k.C > 32 || k.cells % 4 != 0 || k.L > MAX_L || k.n_things > MAX_Z || k.cells > 4096)
+  if (k.C > 32 || k.L > MAX_L || k.n_things > MAX_Z || k.cells > 4096)
     return set_error(PCX_E_UNSUPPORTED,
-                     "scrolly_maze backend: needs cols <= 32, rows*cols %% 4 == 0, <= %d characters", MAX_L);
-  k.QW = k.cells / 4;
+                     "scrolly_maze backend: needs cols <= 32 and <= %d characters", MAX_L);
+  k.QW = (k.cells + 3) / 4;
   bool ok1, ok2;
   k.magic_q = magic20(k.QW, WAVE * k.QW, &ok1);
   k.magic_c = magic20(k.C, k.cells, &ok2);
