@@ -217,3 +217,89 @@ def test_random_levels_build_and_step_on_the_oracle():
       orc.step_hashed(1, 0, 40)
       assert orc.read('planes').shape[1] == 1 + len(t.chars)
       assert not orc.read('error').any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('maker', [random_warehouse, random_better_scrolly])
+@pytest.mark.parametrize('seed', range(4))
+def test_random_levels_match_oracle_through_the_table_driven_kernel(maker, seed, monkeypatch):
+  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+  rng = np.random.RandomState(2000 + seed)
+  t = GameTemplate.from_engine(maker(rng))
+  _compare(t, 'pcx_generic_step', batch=int(rng.choice([70, 200])), steps=48, seed=0xBEAD + seed)
+
+
+def _random_croppers(rng, t, track):
+  from pycolab_amd import cropping
+  R, C = t.rows, t.cols
+  pad = chr(t.chars[int(rng.randint(len(t.chars)))])
+  out = []
+  for _ in range(int(rng.randint(1, 5))):
+    kind = rng.randint(3)
+    if kind == 0:
+      out.append(('F', (int(rng.randint(-3, R)), int(rng.randint(-3, C))), int(rng.randint(1, 9)), int(rng.randint(1, 12)), pad))
+    else:
+      rows, cols = int(rng.randint(3, 8)), int(rng.randint(3, 12))
+      padded = kind == 1 or rows > R or cols > C
+      margins = (int(rng.randint(1, (rows + 1) // 2)) if rows > 2 else 1, int(rng.randint(1, (cols + 1) // 2)) if cols > 2 else 1)
+      if 2 * margins[0] >= rows or 2 * margins[1] >= cols:
+        margins = (1, 1)
+      out.append(('S', rows, cols, track, pad if padded else None, margins,
+                  (int(rng.randint(-2, 3)), int(rng.randint(-2, 3))), bool(rng.randint(2))))
+  def build():
+    made = []
+    for spec in out:
+      if spec[0] == 'F':
+        made.append(cropping.FixedCropper(spec[1], spec[2], spec[3], pad_char=spec[4]))
+      else:
+        made.append(cropping.ScrollingCropper(spec[1], spec[2], list(spec[3]), pad_char=spec[4], scroll_margins=spec[5],
+                                              initial_offset=spec[6], saccade=spec[7]))
+    return made
+  return build
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('maker,track', [(random_warehouse, 'P'), (random_better_scrolly, 'bP')])
+@pytest.mark.parametrize('seed', range(6))
+def test_random_levels_fused_croppers_equal_stand_alone(maker, track, seed):
+  """Random windows (padded and not, larger than the board, off the board, every
+  margin / offset / saccade setting) on random levels: the step kernel's own
+  croppers against the stand-alone cropper kernels, every step."""
+  import torch
+  from pycolab_amd import cropping
+  from pycolab_amd.engine import Engine
+  rng = np.random.RandomState(3000 + seed)
+  t = GameTemplate.from_engine(maker(rng))
+  build = _random_croppers(rng, t, track)
+  B = int(rng.choice([70, 333]))
+  a = Engine.from_template(t, batch=B, auto_reset=True, seed=9)
+  b = Engine.from_template(t, batch=B, auto_reset=True, seed=9)
+  ca, cb = build(), build()
+  for cr in ca:
+    cr.set_engine(a)
+  for cr in cb:
+    cr.set_engine(b)
+  cropping.fuse_croppers(a, ca)
+  oa, ob = a.its_showtime()[0], b.its_showtime()[0]
+  assert all(cr._fused for cr in ca)
+  n_act = int(t.n_actions)
+  for step in range(40):
+    for i, (x, y) in enumerate(zip(ca, cb)):
+      wx, wy = x.crop(oa), y.crop(ob)
+      assert torch.equal(wx.board, wy.board), 'step %d cropper %d (%s)' % (step, i, type(x).__name__)
+      for ch in wy.layers:
+        assert torch.equal(wx.layers[ch], wy.layers[ch]), 'step %d cropper %d layer %r' % (step, i, ch)
+    acts = rng.randint(0, n_act, size=B).astype(np.int32)
+    oa, ob = a.play(acts)[0], b.play(acts)[0]
+  for x, y in zip(ca, cb):  # the windows never left the observation without a pad character ... or both noticed
+    ex = ey = None
+    try:
+      x.check_errors()
+    except RuntimeError as e:
+      ex = e
+    try:
+      y.check_errors()
+    except RuntimeError as e:
+      ey = e
+    assert (ex is None) == (ey is None)
+  a.close(); b.close()
