@@ -193,6 +193,19 @@ def _compare(t, kernel, batch, steps, seed):
     for name in ('planes', 'reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
       np.testing.assert_array_equal(hip.read(name), orc.read(name), err_msg='%s after step %d (%dx%d)' % (name, t0, t.rows, t.cols))
   np.testing.assert_array_equal(hip.sprites(), orc.sprites())
+  # quirky actions: None, the quit action, out-of-range values; episodes left finished every third step
+  rng = np.random.RandomState(seed)
+  n_act = int(t.n_actions)
+  for step in range(24):
+    a = rng.randint(0, n_act, size=batch).astype(np.int32)
+    r = rng.rand(batch)
+    a[r < 0.05] = -1
+    a[(r >= 0.05) & (r < 0.08)] = n_act
+    a[(r >= 0.08) & (r < 0.11)] = rng.randint(n_act + 1, 40)
+    auto = step % 3 != 0
+    hip.step(a, auto_reset=auto); orc.step(a, auto_reset=auto)
+    for name in ('planes', 'reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+      np.testing.assert_array_equal(hip.read(name), orc.read(name), err_msg='%s, quirky step %d (%dx%d)' % (name, step, t.rows, t.cols))
   hip.eng.close()
 
 
