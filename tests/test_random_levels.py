@@ -316,3 +316,48 @@ def test_random_levels_fused_croppers_equal_stand_alone(maker, track, seed):
       ey = e
     assert (ex is None) == (ey is None)
   a.close(); b.close()
+
+
+# ---- hello_world (hello_world.py:72-123): boards other than the two compiled ones go to the table-driven kernel ----
+class Rolling(things.Drape):
+  pcx_program = 'hello_world.rolling'
+
+
+class Sliding(things.Sprite):
+  pcx_program = 'hello_world.sliding'
+  _DX = ([-1, 1, -1, 1], [-1, 1, -1, 1], [1, -1, 1, -1], [1, -1, 1, -1])
+  _DY = ([-1, 1, 1, -1], [1, -1, -1, 1], [1, -1, -1, 1], [-1, 1, 1, -1])
+
+  def __init__(self, corner, position, character, direction_set):
+    super(Sliding, self).__init__(corner, position, character)
+    self._dx = self._DX[direction_set]
+    self._dy = self._DY[direction_set]
+
+
+def random_hello(rng):
+  rows, cols = int(rng.randint(2, 24)), int(rng.randint(2, 60))
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  art[rng.rand(rows, cols) < 0.2] = '@'
+  art[rng.rand(rows, cols) < 0.05] = '#'
+  cells = [(r, c) for r in range(rows) for c in range(cols)]
+  rng.shuffle(cells)
+  n = int(rng.randint(1, min(4, len(cells) - 1) + 1))
+  names = '1234'[:n]
+  for ch, cell in zip(names, cells):
+    art[cell] = ch
+  if not (art == '@').any():
+    art[cells[-1]] = '@'
+  z = list(names) + ['@']
+  rng.shuffle(z)
+  return ascii_art.ascii_art_to_game(
+      [''.join(r) for r in art], ' ',
+      sprites={ch: ascii_art.Partial(Sliding, int(rng.randint(4))) for ch in names},
+      drapes={'@': Rolling}, z_order=''.join(z))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(6))
+def test_random_hello_world_boards_match_oracle(seed):
+  rng = np.random.RandomState(4000 + seed)
+  t = GameTemplate.from_engine(random_hello(rng))
+  _compare(t, 'pcx_generic_step', batch=int(rng.choice([70, 200])), steps=48, seed=0xCAFE + seed)
