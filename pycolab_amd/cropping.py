@@ -35,6 +35,9 @@ class ObservationCropper(object):
   def set_engine(self, engine):
     if engine is not self._engine:
       self._release()
+      forget = getattr(self._engine, '_unregister_cropper', None)
+      if forget is not None:  # (set_engine(None) detaches the cropper)
+        forget(self)
     self._engine = engine
     register = getattr(engine, '_register_cropper', None)
     if register is not None:  # lets its_showtime() attach device croppers before frame 0

@@ -67,6 +67,10 @@ class Engine(object):
       cropper._create_native()
 
   # ---------------------------------------------------------------- builder API
+  def _unregister_cropper(self, cropper):
+    if cropper in self._croppers:
+      self._croppers.remove(cropper)
+
   def set_backdrop(self, characters, backdrop_class, *args, **kwargs):
     """engine.py:248-279."""
     return self.set_prefilled_backdrop(

@@ -67,6 +67,8 @@ def main():
         eng.batch * (P * cells + P * ((cells + 3) & ~3) + 24))
   # the example's own cropper set (better_scrolly_maze.py:237-247) on every observation: as their own kernels
   # after the step, fused into the step kernel, and fused with the full-board planes no longer written
+  for cr in list(eng._croppers):
+    cr.set_engine(None)  # detach the stand-alone croppers timed above
   def example_croppers():
     return [cropping.ScrollingCropper(10, 30, ['P'], initial_offset=(-2, -12)),
             cropping.ScrollingCropper(7, 10, ['c'], pad_char=' ', scroll_margins=(None, 3)),
