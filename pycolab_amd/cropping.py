@@ -215,7 +215,7 @@ class ScrollingCropper(ObservationCropper):
   def set_engine(self, engine):
     prior = self._engine
     super(ScrollingCropper, self).set_engine(engine)
-    if engine is not prior:
+    if engine is not prior and engine is not None:
       if ((engine.rows < self._rows or engine.cols < self._cols)
           and self._pad_char is None):
         raise ValueError(
