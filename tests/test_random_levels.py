@@ -361,3 +361,70 @@ def test_random_hello_world_boards_match_oracle(seed):
   rng = np.random.RandomState(4000 + seed)
   t = GameTemplate.from_engine(random_hello(rng))
   _compare(t, 'pcx_generic_step', batch=int(rng.choice([70, 200])), steps=48, seed=0xCAFE + seed)
+
+
+# ---- extraterrestrial_marauders (extraterrestrial_marauders.py:104-256): the shipped 16x39 cast, other layouts ----
+class EMPlayer(prefab_sprites.MazeWalker):
+  pcx_program = 'marauders.player'
+
+  def __init__(self, corner, position, character):
+    super(EMPlayer, self).__init__(corner, position, character, impassable='', confined_to_board=True)
+
+
+class EMUpBolt(prefab_sprites.MazeWalker):
+  pcx_program = 'marauders.upward_bolt'
+
+  def __init__(self, corner, position, character):
+    super(EMUpBolt, self).__init__(corner, position, character, impassable='')
+    self._teleport((-1, -1))
+
+
+class EMDownBolt(prefab_sprites.MazeWalker):
+  pcx_program = 'marauders.downward_bolt'
+
+  def __init__(self, corner, position, character):
+    super(EMDownBolt, self).__init__(corner, position, character, impassable='')
+    self._teleport((-1, -1))
+
+
+class EMMarauders(things.Drape):
+  pcx_program = 'marauders.marauder'
+
+  def __init__(self, curtain, character):
+    super(EMMarauders, self).__init__(curtain, character)
+    self._dx = -1
+
+
+class EMBunkers(things.Drape):
+  pcx_program = 'marauders.bunker'
+
+
+def random_marauders(rng):
+  rows, cols = 16, 39  # (the hand-written kernel's cast and board; the layout is free)
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  top = int(rng.randint(0, 4))
+  for r in range(top, top + int(rng.randint(1, 6))):
+    for c in range(int(rng.randint(1, 6)), cols - int(rng.randint(1, 6))):
+      if rng.rand() < 0.45:
+        art[r, c] = 'X'
+  for c0 in range(int(rng.randint(1, 5)), cols - 4, int(rng.randint(5, 11))):
+    h, w = int(rng.randint(1, 4)), int(rng.randint(2, 5))
+    art[10:10 + h, c0:c0 + w] = 'B'
+  art[int(rng.choice([13, 14, 15])), int(rng.randint(0, cols))] = 'P'
+  if not (art == 'X').any():
+    art[1, 5] = 'X'
+  sprites = dict([('P', EMPlayer)] + [(c, EMUpBolt) for c in 'abcd'] + [(c, EMDownBolt) for c in 'yz'])
+  return ascii_art.ascii_art_to_game([''.join(r) for r in art], ' ', sprites, dict(X=EMMarauders, B=EMBunkers),
+                                     update_schedule=['P', 'B', 'X'] + list('abcdyz'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('generic', [False, True])
+@pytest.mark.parametrize('seed', range(5))
+def test_random_marauders_layouts_match_oracle(seed, generic, monkeypatch):
+  if generic:
+    monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+  rng = np.random.RandomState(5000 + seed)
+  t = GameTemplate.from_engine(random_marauders(rng))
+  t.param[0] = 0xA11CE + seed  # seeds the marauders' return fire (np.random.choice, :253)
+  _compare(t, 'pcx_generic_step' if generic else 'pcx_marauders_step', batch=int(rng.choice([70, 300])), steps=90, seed=0xD1CE + seed)
