@@ -188,6 +188,10 @@ struct pcx_cropper {
   uint8_t* bound = nullptr;  // caller-owned output planes (pcx_cropper_bind_output)
   bool tracks_drape = false;
   bool fused = false;  // the engine's step kernel moves this window and writes its planes (pcx_engine_fuse_croppers)
+  // released from a windows-only fusion: the engine's planes are stale until its next launch, the cropper's own
+  // output (written by that fusion) is what crop() must keep handing out until then
+  bool hold = false;
+  uint64_t hold_epoch = 0;
   uint8_t* out_planes() const { return bound ? bound : planes.ptr; }
   int ensure_planes() {  // own output planes only when the caller bound none
     if (bound || planes.ptr) return 0;
@@ -314,7 +318,11 @@ int pcx_engine_fuse_croppers(pcx_engine* e, pcx_cropper* const* croppers, int32_
     e->fused_only = before_only;
     return rc;
   }
-  for (pcx_cropper* c : before) c->fused = false;
+  for (pcx_cropper* c : before) {
+    c->fused = false;
+    c->hold = before_only;
+    c->hold_epoch = e->epoch;
+  }
   for (int i = 0; i < n; ++i) {
     pcx_cropper* c = croppers[i];
     // in play already: crop the current observation once the stand-alone way, so that the window
@@ -331,6 +339,10 @@ int pcx_cropper_crop(pcx_cropper* c, void* stream) {
   pcx_engine* e = c->e;
   if (!e->showtime) return set_error(PCX_E_STATE, "pcx_cropper_crop: the engine is not in play");
   if (c->fused) return 0;  // the step kernel moved the window and wrote the planes already
+  if (c->hold) {
+    if (c->hold_epoch == e->epoch) return 0;  // no launch since the windows-only fusion ended: its output stands
+    c->hold = false;
+  }
   if (c->tracks_drape && !e->curtains_fresh)
     return set_error(PCX_E_STATE, "pcx_cropper_crop: curtains were not exported by the last step");
   PCX_HIP(hipSetDevice(e->device));

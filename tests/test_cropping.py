@@ -263,6 +263,37 @@ def test_fused_croppers_equal_stand_alone_croppers(name, batch, shape, monkeypat
 
 
 @pytest.mark.gpu
+def test_croppers_released_from_a_windows_only_fusion_keep_their_output_until_the_next_step():
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('better_scrolly_maze_L1')
+  eng = Engine.from_template(t, batch=200, auto_reset=True)
+  cr = cropping.ScrollingCropper(7, 9, ['P'], pad_char='#', scroll_margins=(2, 3))
+  cropping.fuse_croppers(eng, [cr], only_crops=True)
+  obs = eng.its_showtime()[0]
+  for step in range(5):
+    obs = eng.play(np.full((200,), step % 4, np.int32))[0]
+  want = cr.crop(obs).board.clone()
+  assert cropping.fuse_croppers(eng, []) is True        # released: the full-board planes are stale until the next step
+  assert torch.equal(cr.crop(obs).board, want)           # ... so the window the fusion wrote stands
+  obs = eng.play(np.zeros((200,), np.int32))[0]          # planes written again: the stand-alone kernels take over
+  ref = cropping.ScrollingCropper(7, 9, ['P'], pad_char='#', scroll_margins=(2, 3))
+  got = cr.crop(obs).board
+  full = helpers.to_np(obs.board)
+  win = helpers.to_np(got)
+  for b in (0, 57, 199):                                 # the window shows the player where the board has it
+    (pr, pc), = np.argwhere(full[b] == ord('P'))
+    (wr, wc), = np.argwhere(win[b] == ord('P'))
+    top, left = pr - wr, pc - wc
+    for r in range(7):
+      for c in range(9):
+        inside = 0 <= top + r < full.shape[1] and 0 <= left + c < full.shape[2]
+        assert win[b, r, c] == (full[b, top + r, left + c] if inside else ord('#'))
+  del ref
+  eng.close()
+
+
+@pytest.mark.gpu
 def test_fuse_croppers_answers_false_where_the_kernel_cannot():
   from pycolab_amd.engine import Engine
   t = helpers.load_template('scrolly_maze_L0')   # pcx_scrolly_maze_step has no fused cropper path
