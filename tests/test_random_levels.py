@@ -219,18 +219,6 @@ def test_random_levels_match_oracle(maker, kernel, seed):
   _compare(t, kernel, batch=int(rng.choice([70, 200, 1500])), steps=60, seed=0xF00D + seed)
 
 
-def test_random_levels_build_and_step_on_the_oracle():
-  """CPU: the makers produce valid games (host mirror + template compiler) and the oracle steps them."""
-  rng = np.random.RandomState(3)
-  for maker in (random_warehouse, random_better_scrolly, random_scrolly):
-    for _ in range(4):
-      t = GameTemplate.from_engine(maker(rng))
-      orc = OracleAdapter(t, 8)
-      orc.reset()
-      orc.step_hashed(1, 0, 40)
-      assert orc.read('planes').shape[1] == 1 + len(t.chars)
-      assert not orc.read('error').any()
-
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('maker', [random_warehouse, random_better_scrolly])
@@ -428,3 +416,16 @@ def test_random_marauders_layouts_match_oracle(seed, generic, monkeypatch):
   t = GameTemplate.from_engine(random_marauders(rng))
   t.param[0] = 0xA11CE + seed  # seeds the marauders' return fire (np.random.choice, :253)
   _compare(t, 'pcx_generic_step' if generic else 'pcx_marauders_step', batch=int(rng.choice([70, 300])), steps=90, seed=0xD1CE + seed)
+
+
+def test_random_levels_build_and_step_on_the_oracle():
+  """CPU: the makers produce valid games (host mirror + template compiler) and the oracle steps them."""
+  rng = np.random.RandomState(3)
+  for maker in (random_warehouse, random_better_scrolly, random_scrolly, random_hello, random_marauders):
+    for _ in range(4):
+      t = GameTemplate.from_engine(maker(rng))
+      orc = OracleAdapter(t, 8)
+      orc.reset()
+      orc.step_hashed(1, 0, 40)
+      assert orc.read('planes').shape[1] == 1 + len(t.chars)
+      assert not orc.read('error').any()
