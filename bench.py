@@ -11,8 +11,18 @@ that are already resident in HBM.  Prints ONE JSON line on rank 0.
   python bench.py --gpus 8 --scaling strong   fixed global batch 1,048,576 = 131,072 envs per GPU
   python bench.py --gpus 8 --gather     also times the steps followed by the RCCL all-gather of the packed
                                         reward/discount/reward_set/done record (10 B/env), reported separately
+  python bench.py --gpus 2 --oversubscribe    the same N-rank path on a node with FEWER GPUs than ranks: ranks
+                                        share devices round-robin and the process group is gloo (RCCL refuses two
+                                        ranks on one device); launcher, sharding, accounting and JSON are the
+                                        real path's.  The line says "oversubscribed": true; its value is not a
+                                        scaling measurement
   python bench.py --game marauders --batch 32768    the other BASELINE configs (3: marauders 32,768;
   python bench.py --game warehouse --batch 262144    4: warehouse 262,144; 2: scrolly_maze --batch 4096)
+
+Timing: after W warm-up steps the run times EXACTLY K steps between barrier +
+torch.cuda.synchronize() on both sides, max over ranks -- `--repeats R` (default
+5) times in a row; `value` / `ms_per_step` are the MEDIAN repeat, and every
+repeat is in the line ("repeats").
 """
 import argparse
 import json
@@ -25,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+REFERENCE = os.environ.get('PCX_REFERENCE', '/root/reference')
 
 FIXTURES = {'scrolly_maze': 'scrolly_maze_L%d', 'warehouse': 'warehouse_L%d', 'marauders': 'marauders',
             'hello_world': 'hello_world', 'better_scrolly_maze': 'better_scrolly_maze_L%d'}
@@ -59,6 +70,16 @@ def cpu_baseline(template_path, budget_envs=1024, steps=512, max_procs=64):
                     % (cores, budget_envs, steps, wall)}
 
 
+def cpu_reference_python(game, level, seconds=10.0, max_procs=64):
+  """The REAL reference (`/root/reference`, imported) on this box's host cores:
+  present in the build container only, so a run there carries the reference's own
+  env-steps/s next to the C port's.  TEST INFRASTRUCTURE leg (oracle/ref_timing.py)."""
+  if not os.path.isdir(os.path.join(REFERENCE, 'pycolab')):
+    return None
+  from oracle import ref_timing
+  return ref_timing.measure(REFERENCE, game, level, seconds=seconds, max_procs=max_procs)
+
+
 def pmc_traffic(game, level, batch):
   """HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json:
   WRITE_SIZE + corrected FETCH_SIZE, collected as MI355X_MICROARCH.md prescribes),
@@ -73,11 +94,15 @@ def pmc_traffic(game, level, batch):
   return None
 
 
-def spawn_ranks(n, argv):
+TRAFFIC_SOURCE = ('profiles/hbm_traffic.json (committed rocprofv3 --pmc passes of this kernel at this batch; '
+                  'a constant looked up by workload, NOT measured in this run)')
+
+
+def spawn_ranks(n, argv, oversubscribe):
   """`--gpus N` without a launcher: become `torch.distributed.run` with N ranks."""
   import torch
   have = torch.cuda.device_count()
-  if have < n:
+  if have < 1 or (have < n and not oversubscribe):
     raise SystemExit('bench.py: --gpus %d but this node exposes %d GPU(s)' % (n, have))
   s = socket.socket()
   s.bind(('127.0.0.1', 0))
@@ -88,15 +113,15 @@ def spawn_ranks(n, argv):
   os.execv(sys.executable, cmd)
 
 
-def time_steps(eng, tape, lo, hi, barrier, after_step=None):
-  """Times steps [lo, hi) of the tape: (wall seconds, avg ms per step on the launch stream)."""
+def time_steps(eng, row, lo, hi, barrier, after_step=None):
+  """Times steps [lo, hi) -- actions row(t) -- once: (wall seconds, avg ms per step on the launch stream)."""
   import torch
   barrier()
   ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   t0 = time.perf_counter()
   ev0.record()
   for t in range(lo, hi):
-    eng.step(tape[t])
+    eng.step(row(t))
     if after_step is not None:
       after_step()
   ev1.record()
@@ -105,7 +130,34 @@ def time_steps(eng, tape, lo, hi, barrier, after_step=None):
   return wall, ev0.elapsed_time(ev1) / (hi - lo)
 
 
-def measure_config(game, level, batch, steps, warmup, device):
+def median(xs):
+  s = sorted(xs)
+  return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
+def fill_probe_gbs(nbytes, device):
+  """This box's store-only bandwidth, same run: best of 8 launches of pcx_device_fill_probe
+  over as many bytes as the step kernel writes per launch."""
+  import ctypes
+  import torch
+  from pycolab_amd import _native as N
+  nbytes = max(1 << 24, nbytes // 4 * 4)
+  buf = torch.empty(nbytes, dtype=torch.uint8, device='cuda:%d' % device)
+  stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+  best = float('inf')
+  for i in range(10):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    N.check(N.lib().pcx_device_fill_probe(buf.data_ptr(), nbytes, stream))
+    ev1.record()
+    torch.cuda.synchronize(device)
+    if i >= 2:
+      best = min(best, ev0.elapsed_time(ev1))
+  del buf
+  return nbytes / (best * 1e-3) / 1e9
+
+
+def measure_config(game, level, batch, steps, warmup, device, repeats=3):
   """One of the other BASELINE configs on this GPU (reported inside the headline line)."""
   import torch
   from pycolab_amd import _native as N
@@ -120,10 +172,13 @@ def measure_config(game, level, batch, steps, warmup, device):
   tape = torch.randint(0, template.n_actions, (warmup + steps, batch), dtype=torch.int32, device='cuda', generator=g)
   for t in range(warmup):
     eng.step(tape[t])
-  _, kernel_ms = time_steps(eng, tape, warmup, warmup + steps, torch.cuda.synchronize)
+  sync = lambda: torch.cuda.synchronize(device)
+  runs = [time_steps(eng, lambda t: tape[t], warmup, warmup + steps, sync)[1] for _ in range(repeats)]
+  kernel_ms = median(runs)
   eng.check_errors()
   bps = int(N.lib().pcx_engine_bytes_per_step(eng._native))
   out = {'workload': 'examples/%s, %d envs' % (fixture, batch), 'ms_per_step': kernel_ms,
+         'ms_per_step_min_max': [min(runs), max(runs)],
          'env_steps_per_s': batch / (kernel_ms * 1e-3),
          'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(), 'algorithmic_bytes_per_env_step': bps,
          'hbm_frac': bps * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -137,11 +192,22 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=200)
   ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--repeats', type=int, default=5,
+                  help='how many times the K timed steps are repeated; value = the median repeat')
   ap.add_argument('--batch', type=int, default=1 << 20,
                   help='environments per GPU (--scaling weak) or in total (--scaling strong)')
   ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
   ap.add_argument('--gather', action='store_true',
                   help='also time steps followed by the all-gather of the packed 10 B/env step results')
+  ap.add_argument('--oversubscribe', action='store_true',
+                  help='allow more ranks than GPUs (ranks share devices; process group over gloo)')
+  ap.add_argument('--actions', default='random', choices=['random', 'hashed'],
+                  help='random: a device-generated uniform tape per rank (default).  hashed: pcx_action_hash(0x5EED, '
+                       'GLOBAL env, step) %% n_actions, staged from the host -- what an unsharded '
+                       'Engine.step_hashed(0x5EED, 0, T) draws, so shards can be checked against one engine')
+  ap.add_argument('--dump-scalars', default=None, metavar='NPZ',
+                  help='after the last step: all-gather reward/reward_set/discount/done (ScalarGather) and per-rank '
+                       'observation checksums, and have rank 0 save them with the number of steps taken')
   ap.add_argument('--level', type=int, default=0)
   ap.add_argument('--game', default='scrolly_maze', choices=sorted(FIXTURES),
                   help='scrolly_maze is the headline metric; the others are the parity configs of BASELINE.json')
@@ -149,10 +215,12 @@ def main():
   ap.add_argument('--no-other-configs', action='store_true',
                   help='skip the short measurements of BASELINE configs 2-4 added to the N=1 headline line')
   args = ap.parse_args()
+  if args.repeats < 1 or args.steps < 1:
+    raise SystemExit('bench.py: --steps and --repeats must be >= 1')
 
   launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ  # by torch.distributed.run
   if args.gpus > 1 and not launched:
-    spawn_ranks(args.gpus, sys.argv[1:])  # does not return
+    spawn_ranks(args.gpus, sys.argv[1:], args.oversubscribe)  # does not return
   rank = int(os.environ.get('RANK', '0')) if launched else 0
   world = int(os.environ.get('WORLD_SIZE', '1')) if launched else 1
   local = int(os.environ.get('LOCAL_RANK', '0')) if launched else 0
@@ -160,16 +228,26 @@ def main():
     raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
   import torch
-  if torch.cuda.device_count() <= local:
-    raise SystemExit('bench.py: rank %d has no GPU (device_count=%d)' % (rank, torch.cuda.device_count()))
-  torch.cuda.set_device(local)
+  n_dev = torch.cuda.device_count()
+  if n_dev <= local and not (args.oversubscribe and n_dev >= 1):
+    raise SystemExit('bench.py: rank %d has no GPU (device_count=%d)' % (rank, n_dev))
+  device = local % n_dev
+  oversubscribed = world > n_dev
+  torch.cuda.set_device(device)
   distributed = world > 1 or launched
+  backend = None
   if distributed:
     import torch.distributed as dist
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if oversubscribed:
+      backend = 'gloo'
+      dist.init_process_group('gloo')
+    else:
+      backend = 'nccl'  # = RCCL on ROCm
+      dist.init_process_group('nccl', device_id=torch.device('cuda', device))
     assert dist.get_world_size() == world
 
   from pycolab_amd import _native as N
+  from pycolab_amd import actions as pactions
   from pycolab_amd import distributed as pdist
   from pycolab_amd.compiler import GameTemplate
   from pycolab_amd.engine import Engine
@@ -182,15 +260,21 @@ def main():
     B, global_batch = hi - lo, args.batch
   else:
     B, global_batch, lo = args.batch, args.batch * world, rank * args.batch
-  eng = Engine.from_template(template, batch=B, device=local, auto_reset=True, seed=0x5EED, env_offset=lo)
+  eng = Engine.from_template(template, batch=B, device=device, auto_reset=True, seed=0x5EED, env_offset=lo)
   eng.its_showtime()
 
   # Synthetic action tape, resident in HBM before timing: uniform ordinary
   # actions {0..n_actions-1}, one int32 row per step.
-  g = torch.Generator(device='cuda')
-  g.manual_seed(0x5EED + rank)
-  total = args.warmup + args.steps
-  tape = torch.randint(0, template.n_actions, (total, B), dtype=torch.int32, device='cuda', generator=g)
+  K, W, R = args.steps, args.warmup, args.repeats
+  total = W + K * (R + (1 if args.gather and distributed else 0))
+  if args.actions == 'hashed':  # every step has its own row: step t of global env e plays hash(seed, e, t)
+    tape = torch.from_numpy(pactions.hashed_tape(0x5EED, lo, B, 0, total, template.n_actions)).to('cuda:%d' % device)
+    row = lambda t: tape[t]
+  else:  # W + K rows; every repeat replays rows [W, W + K)
+    g = torch.Generator(device='cuda')
+    g.manual_seed(0x5EED + rank)
+    tape = torch.randint(0, template.n_actions, (W + K, B), dtype=torch.int32, device='cuda', generator=g)
+    row = lambda t: tape[t if t < W else W + (t - W) % K]
 
   def barrier():
     if distributed:
@@ -200,39 +284,77 @@ def main():
   def max_over_ranks(x):
     if not distributed:
       return x
-    w = torch.tensor([x], dtype=torch.float64, device='cuda')
+    w = torch.tensor([x], dtype=torch.float64, device='cpu' if backend == 'gloo' else 'cuda')
     dist.all_reduce(w, op=dist.ReduceOp.MAX)
     return float(w.item())
 
-  for t in range(args.warmup):
-    eng.step(tape[t])
-  wall, kernel_ms = time_steps(eng, tape, args.warmup, total, barrier)
-  wall = max_over_ranks(wall)
+  def every_rank(x):
+    if not distributed:
+      return [x]
+    out = [None] * world
+    dist.all_gather_object(out, x)
+    return out
+
+  for t in range(W):
+    eng.step(row(t))
+  walls, kernels = [], []
+  for r in range(R):
+    wall, kernel_ms = time_steps(eng, row, W + r * K, W + (r + 1) * K, barrier)
+    walls.append(max_over_ranks(wall))
+    kernels.append(kernel_ms)
+  steps_taken = W + R * K
   eng.check_errors()
+  wall = median(walls)
+  kernel_ms = median(kernels)
+  per_rank_kernel_ms = every_rank(kernel_ms)
 
   gather = None
   if args.gather and distributed:
     sg = pdist.ScalarGather(eng.scalars_packed, global_batch=global_batch)
     sg.gather()  # communicator warm-up
-    gwall, _ = time_steps(eng, tape, args.warmup, total, barrier, after_step=sg.gather)
+    gwall, _ = time_steps(eng, row, steps_taken, steps_taken + K, barrier, after_step=sg.gather)
+    steps_taken += K
     gwall = max_over_ranks(gwall)
-    gather = {'collective': 'all_gather_into_tensor over RCCL, one per step, 10 B/env packed record, no host sync',
-              'bytes_per_rank_per_step': 10 * B, 'ms_per_step_with_gather': gwall / args.steps * 1e3,
-              'value_with_gather': global_batch * args.steps / gwall}
+    gather = {'collective': 'all_gather_into_tensor over %s, one per step, 10 B/env packed record%s'
+                            % ('RCCL' if backend == 'nccl' else 'gloo (staged through pinned host memory)',
+                               ', no host sync' if backend == 'nccl' else ''),
+              'bytes_per_rank_per_step': 10 * B, 'ms_per_step_with_gather': gwall / K * 1e3,
+              'value_with_gather': global_batch * K / gwall}
+
+  if args.dump_scalars:
+    # the union of the shards, as a consumer would gather it, + a checksum of every rank's observation
+    torch.cuda.synchronize()
+    planes = eng.buffers['planes'].tensor.view(B, -1)
+    per_env = planes.sum(dim=1, dtype=torch.int64)
+    weights = torch.arange(lo + 1, lo + B + 1, dtype=torch.int64, device=planes.device)
+    checks = every_rank({'rank': rank, 'lo': lo, 'n': B, 'device': device,
+                         'planes_sum': int(per_env.sum().item()), 'planes_weighted': int((per_env * weights).sum().item()),
+                         'frame_sum': int(eng.buffers['frame'].tensor.sum(dtype=torch.int64).item())})
+    if distributed:
+      sg = pdist.ScalarGather(eng.scalars_packed, global_batch=global_batch)
+      sg.gather()
+      got = [x.cpu().numpy() for x in sg.unpack()]
+    else:
+      got = [eng.buffers[k].numpy() for k in ('reward', 'reward_set', 'discount', 'done')]
+    if rank == 0:
+      import numpy as np
+      np.savez(args.dump_scalars, reward=got[0], reward_set=got[1], discount=got[2], done=got[3],
+               steps_taken=np.array([steps_taken]), checks=np.frombuffer(json.dumps(checks).encode(), np.uint8))
 
   if rank == 0:
     bytes_per_step = int(N.lib().pcx_engine_bytes_per_step(eng._native))
     achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
     traffic = pmc_traffic(args.game, args.level, B)
+    L = len(template.chars)
     line = {
         'metric': 'env-steps/sec (whole node), scrolly_maze batch=1M; bit-exact vs CPU' if args.game == 'scrolly_maze'
                   else 'env-steps/sec (whole node), %s' % fixture,
-        'value': global_batch * args.steps / wall,
+        'value': global_batch * K / wall,
         'unit': 'env-steps/s',
         'n_gpus': world,
-        'steps': args.steps,
-        'warmup': args.warmup,
-        'ms_per_step': wall / args.steps * 1e3,
+        'steps': K,
+        'warmup': W,
+        'ms_per_step': wall / K * 1e3,
         'higher_is_better': True,
         'scaling': args.scaling,
         'vs_baseline': None,
@@ -240,31 +362,57 @@ def main():
         'data': 'synthetic',
         'config': {'workload': 'examples/%s level %d, %d envs per GPU, uniform actions 0-%d, '
                                'auto-reset episodes, full observation (board + %d layers) every step'
-                               % (fixture, args.level, B, template.n_actions - 1, len(template.chars)),
+                               % (fixture, args.level, B, template.n_actions - 1, L),
                    'batch_per_gpu': B, 'global_batch': global_batch, 'parallelism': 'env-shard x%d' % world},
+        'repeats': {'k': R, 'statistic': 'median', 'steps_each': K,
+                    'ms_per_step_all': [w / K * 1e3 for w in walls],
+                    'ms_per_step_min': min(walls) / K * 1e3, 'ms_per_step_max': max(walls) / K * 1e3,
+                    'kernel_ms_all': kernels},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'traffic_source': TRAFFIC_SOURCE if traffic is not None else None,
                      'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(),
                      'kernel_ms': kernel_ms, 'algorithmic_bytes_per_env_step': bytes_per_step},
     }
+    if distributed:
+      line['dist'] = {'backend': backend, 'world_size': dist.get_world_size(), 'oversubscribed': oversubscribed,
+                      'devices_on_node': n_dev, 'rank_device': every_rank_devices(world, n_dev),
+                      'per_rank_kernel_ms': per_rank_kernel_ms,
+                      'per_rank_envs': [pdist.shard_range(global_batch, r, world)[1] - pdist.shard_range(global_batch, r, world)[0]
+                                        if args.scaling == 'strong' else args.batch for r in range(world)]}
     if gather is not None:
       line['gather'] = gather
     del tape
     eng.close()
+    if not oversubscribed:
+      # what this box's HBM takes from a kernel that only stores, same run: the
+      # step kernel's bytes are 96 % writes, so this is its practical ceiling
+      plane_bytes = B * (1 + L) * template.rows * template.cols
+      fill = fill_probe_gbs(min(plane_bytes, 8 << 30), device)
+      line['roofline']['achievable'] = {'GBps': fill, 'what': 'pcx_device_fill_probe: store-only kernel over the '
+                                        'step kernel\'s output size, best of 8 launches, same run'}
+      line['roofline']['frac_of_achievable'] = achieved / fill
     if world == 1 and args.game == 'scrolly_maze' and not args.no_other_configs:
       # BASELINE configs 2-4 on the same GPU, same run (their own kernels and rooflines), then the other two
       # hand-written kernels: SURVEY 8 f-1 (better_scrolly_maze, 45x89 board) and config 1's game on the GPU
-      line['other_configs'] = [measure_config('scrolly_maze', 0, 4096, 200, 20, local),
-                               measure_config('marauders', 0, 32768, 200, 20, local),
-                               measure_config('warehouse', 0, 262144, 100, 10, local),
-                               measure_config('better_scrolly_maze', 0, 65536, 50, 10, local),
-                               measure_config('hello_world', 0, 1048576, 50, 10, local)]
+      line['other_configs'] = [measure_config('scrolly_maze', 0, 4096, 200, 20, device),
+                               measure_config('marauders', 0, 32768, 200, 20, device),
+                               measure_config('warehouse', 0, 262144, 100, 10, device),
+                               measure_config('better_scrolly_maze', 0, 65536, 50, 10, device),
+                               measure_config('hello_world', 0, 1048576, 50, 10, device)]
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(template_path)
+      ref = cpu_reference_python(args.game, args.level)
+      if ref is not None:
+        line['cpu_reference_python'] = ref
     print(json.dumps(line))
   if distributed:
     dist.barrier()
     dist.destroy_process_group()
+
+
+def every_rank_devices(world, n_dev):
+  return [r % n_dev for r in range(world)]
 
 
 if __name__ == '__main__':

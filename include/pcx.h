@@ -21,6 +21,11 @@
  *                          Engine.game_over / the_plot.frame  engine.py:660, plot.py:274
  *   pcx_cropper_*       <- cropping.ObservationCropper._do_crop  pycolab/cropping.py:118-227,
  *                          FixedCropper.crop :255-268, ScrollingCropper.crop :393-426
+ *   pcx_post_*          <- rendering.ObservationToArray / ObservationToFeatureArray /
+ *                          ObservationCharacterRepainter  pycolab/rendering.py:304-661
+ *   pcx_gather_*        <- (nothing in the reference: one Engine = one environment,
+ *                          engine.py:102-104) the reward/discount/done gather of a
+ *                          batch sharded over the GPUs of a node
  *
  * Conventions: every function returns 0 on success or a negative PCX_E_*
  * code and leaves a thread-local message for pcx_last_error().  Pointers in
@@ -264,6 +269,12 @@ int pcx_engine_read_things(pcx_engine* e, int64_t env0, int64_t n,
  * completed; nonzero = take the synchronous path and look at `error`).  The
  * cropper and post-processor polls below work the same way. */
 int pcx_engine_error_poll(pcx_engine* e, void* stream, int32_t* seen);
+/* Host copy of uint8[batch]: the `error` array ORed with every error bit an
+ * earlier pcx_engine_error_poll saw.  An environment's error bits last until
+ * its next reset -- with auto_reset that is a step or two -- so a host that
+ * polls asynchronously reads the errors HERE: they stay until read with
+ * clear != 0.  Synchronous. */
+int pcx_engine_errors_seen(pcx_engine* e, uint8_t* errors_host, int32_t clear);
 
 /* Convenience synchronous copies (host <-> device) for thin FFI hosts. */
 int pcx_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes);
@@ -271,6 +282,12 @@ int pcx_memcpy_h2d(void* dst_dev, const void* src_host, uint64_t bytes);
 int pcx_device_malloc(void** out_dev, uint64_t bytes);
 int pcx_device_free(void* dev);
 int pcx_stream_synchronize(void* stream);
+/* Measurement aid ("confirm the peak with a device microbench on the
+ * box and report that measured peak too"): one launch that does nothing but
+ * store `bytes` (a multiple of 4, dword-aligned) to dst_dev, a wave writing 256
+ * contiguous bytes per instruction.  The caller times it on `stream`; bench.py
+ * reports the step kernel against it as roofline.frac_of_achievable. */
+int pcx_device_fill_probe(void* dst_dev, uint64_t bytes, void* stream);
 
 /* The counter-based action generator shared by host, oracle and device. */
 uint32_t pcx_action_hash(uint64_t seed, uint64_t env, uint64_t t);
@@ -435,6 +452,32 @@ int pcx_post_error_poll(pcx_post* p, void* stream, int32_t* seen);
 /* Host copy of uint8[batch]: 1 where a board character had no mapping
  * (rendering.py:503-507 RuntimeError) or was not ASCII.  Synchronous. */
 int pcx_post_errors(pcx_post* p, uint8_t* errors_host);
+
+/* ------------------------------------------------------------------------ */
+/* Node-level gather of the step results: environments never
+ * interact (one Engine per environment, pycolab/engine.py:102-104), so a batch
+ * sharded over the GPUs of a node needs no data-path collective; the one
+ * optional exchange is this gather of what play() returns besides the
+ * observation -- reward i32, discount f32, reward_set u8, done u8 = 10 bytes
+ * per environment (engine.py:639; plot.py:69-104).  For a host that drives
+ * every GPU from ONE process: `engines` = n engines on n distinct devices;
+ * create() builds one RCCL communicator per device (ncclCommInitAll; RCCL is
+ * bound with dlopen at this call, so a process that never gathers never loads
+ * it).  (One-process-per-GPU hosts gather the same packed record with their
+ * framework's collective: pycolab_amd.distributed.ScalarGather.)              */
+typedef struct pcx_gather pcx_gather;
+int pcx_gather_create(pcx_engine* const* engines, int32_t n, pcx_gather** out);
+void pcx_gather_destroy(pcx_gather* g);
+/* One ncclAllGather per device, grouped, enqueued on streams[i] (hipStream_t of
+ * engine i's device; NULL array = default streams) after whatever the engine
+ * last launched there; asynchronous.  Engine i contributes the record
+ * [reward i32[B_i] | discount f32[B_i] | reward_set u8[B_i] | done u8[B_i]]
+ * zero-padded to `slot` = 10 * max_i(B_i) rounded up to 16 bytes (sent in place
+ * when the engine's outputs were bound as exactly that one allocation).       */
+int pcx_gather_scalars(pcx_gather* g, void* const* streams);
+/* Where engine i's device received everybody's records: uint8 [n][slot]; the
+ * record of engine r starts at r * slot and is laid out with ITS B_r.          */
+int pcx_gather_buffers(pcx_gather* g, int32_t i, uint8_t** recv_dev, int64_t* slot_bytes);
 
 #ifdef __cplusplus
 }

@@ -290,7 +290,9 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
     if unoccluded:
       layers.append([x[6] for x in rec])
   sw = lambda x, dt: np.ascontiguousarray(np.swapaxes(np.array(x, dtype=dt), 0, 1))
-  path = os.path.join(ROOT, 'tests', 'golden', 'traces', name + '.npz')
+  out_root = os.environ.get('PCX_GOLDEN_OUT') or os.path.join(ROOT, 'tests', 'golden')  # PCX_GOLDEN_OUT: regenerate elsewhere (tests/test_fixture_reproducibility.py)
+  os.makedirs(os.path.join(out_root, 'traces'), exist_ok=True)
+  path = os.path.join(out_root, 'traces', name + '.npz')
   import json
   extra = {'crop_%d' % i: sw(crops[i], np.uint8) for i in range(len(specs))}
   extra['crop_specs'] = np.frombuffer(json.dumps(specs).encode(), np.uint8)

@@ -73,7 +73,9 @@ def main():
     discounts.append([x[3] for x in rec]); dones.append([x[4] for x in rec]); chapters.append([x[5] for x in rec])
     restarted.append([x[6] for x in rec])
   sw = lambda x, dt: np.ascontiguousarray(np.swapaxes(np.array(x, dtype=dt), 0, 1))
-  path = os.path.join(ROOT, 'tests', 'golden', 'traces', 'story_three_chapters.npz')
+  out_root = os.environ.get('PCX_GOLDEN_OUT') or os.path.join(ROOT, 'tests', 'golden')
+  os.makedirs(os.path.join(out_root, 'traces'), exist_ok=True)
+  path = os.path.join(out_root, 'traces', 'story_three_chapters.npz')
   np.savez_compressed(path, actions=actions, boards=sw(boards, np.uint8), reward=sw(rewards, np.int32),
                       reward_set=sw(rsets, np.uint8), discount=sw(discounts, np.float32), done=sw(dones, np.uint8),
                       chapter=sw(chapters, np.int8), fresh=sw(restarted, np.uint8),

@@ -31,6 +31,12 @@ Run here (CPU container):  python oracle/harvest_reference_tests.py
 import json
 import os
 import sys
+
+if os.environ.get('PYTHONHASHSEED') != '0':
+  # games built from sets of characters iterate them in string-hash order: pin it so
+  # that the fixtures come out byte-identical on every run (tests/test_fixture_reproducibility.py)
+  os.environ['PYTHONHASHSEED'] = '0'
+  os.execv(sys.executable, [sys.executable] + sys.argv)
 import unittest
 import warnings
 
@@ -52,7 +58,7 @@ from pycolab_amd.compiler import GameTemplate  # noqa: E402
 from pycolab_amd.prefab_parts import tabled  # noqa: E402
 
 MOTIONS = ['n', 'ne', 'e', 'se', 's', 'sw', 'w', 'nw']
-OUT = os.path.join(ROOT, 'tests', 'golden', 'reftests')
+OUT = os.path.join(os.environ.get('PCX_GOLDEN_OUT') or os.path.join(ROOT, 'tests', 'golden'), 'reftests')
 FIXTURES = []
 
 

@@ -135,12 +135,14 @@ SYMBOLS = [
     ('pcx_engine_bind_buffers', c_i32, [_VP, ctypes.POINTER(Buffers)]),
     ('pcx_engine_read_things', c_i32, [_VP, c_i64, c_i64, _VP, _VP]),
     ('pcx_engine_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
+    ('pcx_engine_errors_seen', c_i32, [_VP, _VP, c_i32]),
     ('pcx_engine_set_epilogue', c_i32, [_VP, ctypes.POINTER(EpilogueDesc)]),
     ('pcx_memcpy_d2h', c_i32, [_VP, _VP, c_u64]),
     ('pcx_memcpy_h2d', c_i32, [_VP, _VP, c_u64]),
     ('pcx_device_malloc', c_i32, [ctypes.POINTER(_VP), c_u64]),
     ('pcx_device_free', c_i32, [_VP]),
     ('pcx_stream_synchronize', c_i32, [_VP]),
+    ('pcx_device_fill_probe', c_i32, [_VP, c_u64, _VP]),
     ('pcx_action_hash', c_u32, [c_u64, c_u64, c_u64]),
     ('pcx_engine_plane_pitch', c_i32, [_VP]),
     ('pcx_engine_bytes_per_step', c_i64, [_VP]),
@@ -168,6 +170,10 @@ SYMBOLS = [
     ('pcx_post_bind_output', c_i32, [_VP, _VP, c_u64]),
     ('pcx_post_error_buffer', c_i32, [_VP, ctypes.POINTER(_VP)]),
     ('pcx_post_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
+    ('pcx_gather_create', c_i32, [ctypes.POINTER(_VP), c_i32, ctypes.POINTER(_VP)]),
+    ('pcx_gather_destroy', None, [_VP]),
+    ('pcx_gather_scalars', c_i32, [_VP, ctypes.POINTER(_VP)]),
+    ('pcx_gather_buffers', c_i32, [_VP, c_i32, ctypes.POINTER(_VP), ctypes.POINTER(c_i64)]),
 ]
 
 # PCX_LIB selects another build of the same library (A/B kernel experiments).

@@ -46,6 +46,15 @@ class ObservationCropper(object):
   def crop(self, observation):
     return observation
 
+  def _clone(self):
+    """A cropper with the same constructor arguments and no engine: what a
+    batched Story gives every chapter when one cropper object was supplied for
+    all of them (a device cropper holds ONE engine's window state)."""
+    other = copy.copy(self)
+    other._engine, other._native, other._out, other._fused = None, None, None, False
+    other._generation = 0
+    return other
+
   @property
   def rows(self):
     return self._engine.rows

@@ -64,7 +64,7 @@ static int ensure_outputs(pcx_engine* e) {
   return 0;
 }
 
-__global__ void pcx_any_nonzero(const uint8_t* v, int64_t n, uint32_t* flag) {
+__global__ void pcx_any_nonzero(const uint8_t* v, int64_t n, uint32_t* flag, uint8_t* sticky) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
   if (i >= n) return;
   uint32_t any = 0;
@@ -74,7 +74,20 @@ __global__ void pcx_any_nonzero(const uint8_t* v, int64_t n, uint32_t* flag) {
   } else {
     for (int64_t j = i; j < n && j < i + 16; ++j) any |= v[j];
   }
-  if (any) atomicOr(flag, 1u);
+  if (any) {
+    atomicOr(flag, 1u);
+    for (int64_t j = i; j < n && j < i + 16; ++j)  // rare: keep which environments, past their auto-reset
+      if (v[j]) sticky[j] |= v[j];
+  }
+}
+
+// include/pcx.h pcx_device_fill_probe: the plainest full-chip store stream (a wave
+// writes 256 contiguous bytes per instruction, grid-stride), i.e. what this box's
+// HBM takes from a kernel that does nothing but store
+__global__ __launch_bounds__(256) void pcx_fill_probe(uint32_t* p, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = (uint32_t)i;
 }
 
 int Backend::set_epilogue(const pcx_epilogue_desc* d) {
@@ -90,6 +103,19 @@ int Backend::set_fused_croppers(const crop::FusedCrops* fc) {
 ErrorPoll::~ErrorPoll() {
   if (dev) (void)hipFree(dev);
   if (host) (void)hipHostFree(host);
+  if (sticky) (void)hipFree(sticky);
+}
+
+int ErrorPoll::errors_seen(const uint8_t* errors_dev, int64_t n, uint8_t* out_host, int clear) {
+  PCX_HIP(hipDeviceSynchronize());
+  PCX_HIP(hipMemcpy(out_host, errors_dev, (size_t)n, hipMemcpyDeviceToHost));
+  if (sticky && sticky_n == n) {
+    std::vector<uint8_t> st((size_t)n);
+    PCX_HIP(hipMemcpy(st.data(), sticky, (size_t)n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) out_host[i] |= st[i];
+    if (clear) PCX_HIP(hipMemset(sticky, 0, (size_t)n));
+  }
+  return 0;
 }
 
 int ErrorPoll::poll(const uint8_t* errors_dev, int64_t n, hipStream_t s, int32_t* seen) {
@@ -98,10 +124,17 @@ int ErrorPoll::poll(const uint8_t* errors_dev, int64_t n, hipStream_t s, int32_t
     PCX_HIP(hipHostMalloc(reinterpret_cast<void**>(&host), 4, hipHostMallocDefault));
     *host = 0;
   }
+  if (!sticky || sticky_n != n) {
+    if (sticky) (void)hipFree(sticky);
+    sticky = nullptr;
+    PCX_HIP(hipMalloc(reinterpret_cast<void**>(&sticky), (size_t)(n ? n : 1)));
+    PCX_HIP(hipMemset(sticky, 0, (size_t)(n ? n : 1)));
+    sticky_n = n;
+  }
   if (seen) *seen = (int32_t)*reinterpret_cast<volatile uint32_t*>(host);
   PCX_HIP(hipMemsetAsync(dev, 0, 4, s));
   const int64_t threads = (n + 15) / 16;
-  hipLaunchKernelGGL(pcx_any_nonzero, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, errors_dev, n, dev);
+  hipLaunchKernelGGL(pcx_any_nonzero, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, errors_dev, n, dev, sticky);
   PCX_HIP(hipGetLastError());
   PCX_HIP(hipMemcpyAsync(host, dev, 4, hipMemcpyDeviceToHost, s));
   return 0;
@@ -271,6 +304,12 @@ int pcx_engine_error_poll(pcx_engine* e, void* stream, int32_t* seen) {
   return e->error_poll.poll(e->out.error, e->batch, (hipStream_t)stream, seen);
 }
 
+int pcx_engine_errors_seen(pcx_engine* e, uint8_t* errors_host, int32_t clear) {
+  if (!e || !e->out.error || !errors_host) return set_error(PCX_E_INVALID, "pcx_engine_errors_seen: bad arguments");
+  PCX_HIP(hipSetDevice(e->device));
+  return e->error_poll.errors_seen(e->out.error, e->batch, errors_host, clear);
+}
+
 int pcx_engine_set_epilogue(pcx_engine* e, const pcx_epilogue_desc* d) {
   if (!e) return set_error(PCX_E_INVALID, "pcx_engine_set_epilogue: null engine");
   if (d) {
@@ -309,6 +348,14 @@ int pcx_device_malloc(void** out_dev, uint64_t bytes) {
 }
 int pcx_device_free(void* dev) {
   PCX_HIP(hipFree(dev));
+  return 0;
+}
+int pcx_device_fill_probe(void* dst_dev, uint64_t bytes, void* stream) {
+  if (!dst_dev || bytes < 4 || (reinterpret_cast<uintptr_t>(dst_dev) & 3u))
+    return set_error(PCX_E_INVALID, "pcx_device_fill_probe: bad arguments");
+  hipLaunchKernelGGL(pcx::pcx_fill_probe, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<uint32_t*>(dst_dev), bytes / 4);
+  PCX_HIP(hipGetLastError());
   return 0;
 }
 int pcx_stream_synchronize(void* stream) {

@@ -72,8 +72,15 @@ struct DevArray {
 struct ErrorPoll {
   uint32_t* dev = nullptr;
   uint32_t* host = nullptr;
+  // every poll also ORs the error array into this one: an error bit lives only
+  // until its environment's next reset (auto-reset clears it within a step or
+  // two), the copy here stays until the host has read it (errors_seen)
+  uint8_t* sticky = nullptr;
+  int64_t sticky_n = 0;
   ~ErrorPoll();
   int poll(const uint8_t* errors_dev, int64_t n, hipStream_t s, int32_t* seen);
+  // host copy of (sticky | live); clear != 0 forgets the sticky part.  Synchronous.
+  int errors_seen(const uint8_t* errors_dev, int64_t n, uint8_t* out_host, int clear);
 };
 
 class Backend {

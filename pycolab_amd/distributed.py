@@ -50,8 +50,16 @@ class ScalarGather(object):
 
   `packed`: this rank's uint8 tensor [10 * n_local] (`Engine.scalars_packed`);
   it is read in place at every `gather()`.  `global_batch` fixes every rank's
-  shard length through `shard_range` (no size exchange); when omitted all
-  shards have this rank's length.  The receive buffer is allocated once.
+  shard length through `shard_range` (no size exchange per step); when omitted
+  all shards must have this rank's length -- checked ONCE here with a size
+  exchange, so that ragged shards raise instead of hanging the collective.
+  The receive buffer is allocated once.
+
+  Device tensors travel over the group's own backend ("nccl" = RCCL over
+  xGMI).  A group whose backend cannot take device tensors (gloo: the
+  `bench.py --oversubscribe` mode, where several ranks share one GPU and RCCL
+  refuses duplicate devices) stages the 10 B/env block through pinned host
+  memory -- the same collective, shapes and unpacking.
   """
 
   def __init__(self, packed, global_batch=None, group=None):
@@ -62,6 +70,11 @@ class ScalarGather(object):
     rank = dist.get_rank(group)
     n_local = packed.numel() // 10
     if global_batch is None:
+      sizes = [None] * self.world
+      dist.all_gather_object(sizes, int(n_local), group=group)
+      if len(set(sizes)) != 1:
+        raise ValueError('shards differ in length ({}): pass global_batch so that every rank derives the same '
+                         'layout from shard_range'.format(sizes))
       self.sizes = [n_local] * self.world
     else:
       self.sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, self.world) for r in range(self.world))]
@@ -73,13 +86,22 @@ class ScalarGather(object):
     if packed.numel() != self._slot:   # a shorter (or oddly sized) shard sends a padded copy of its block
       self._send = torch.zeros(self._slot, dtype=torch.uint8, device=packed.device)
     self.out = torch.empty(self.world * self._slot, dtype=torch.uint8, device=packed.device)
+    self.staged = bool(packed.is_cuda and dist.get_backend(group) == 'gloo')
+    if self.staged:
+      self._host_send = torch.zeros(self._slot, dtype=torch.uint8).pin_memory()
+      self._host_out = torch.empty(self.world * self._slot, dtype=torch.uint8).pin_memory()
 
   def gather(self):
     """Issues the collective on the current stream; returns the raw receive
-    buffer [world, slot] (asynchronous on GPUs: no host sync here)."""
+    buffer [world, slot] (asynchronous on GPUs over RCCL: no host sync here)."""
     if self._send is not self._local:
       self._send[:self._local.numel()].copy_(self._local)
-    self._dist.all_gather_into_tensor(self.out, self._send, group=self._group)
+    if self.staged:
+      self._host_send.copy_(self._send)  # device -> pinned host, synchronous
+      self._dist.all_gather_into_tensor(self._host_out, self._host_send, group=self._group)
+      self.out.copy_(self._host_out, non_blocking=True)
+    else:
+      self._dist.all_gather_into_tensor(self.out, self._send, group=self._group)
     return self.out.view(self.world, self._slot)
 
   def unpack(self):

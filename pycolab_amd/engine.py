@@ -59,6 +59,23 @@ class Engine(object):
     self._croppers = []
     self._fuse_request = None  # cropping.fuse_croppers() before its_showtime(): (croppers, only_crops)
     self._only_crops = False   # fused croppers only: the full-board planes are not written
+    self._epilogue = None      # (converter, float tensor the step kernel writes): rendering.fuse_into
+
+  def _install_epilogue(self, converter, out):
+    """rendering.ObservationToFeatureArray.fuse_into(): the step kernel writes
+    `out` from now on, so the engine holds it (and its converter) until the
+    epilogue is cleared or the engine closed."""
+    if self._epilogue is not None and self._epilogue[0] is not converter:
+      self._epilogue[0]._epilogue_gone()  # the kernel feeds one array: the earlier converter is on its own again
+    self._epilogue = (converter, out)
+
+  def _clear_epilogue(self, converter=None):
+    if self._epilogue is None or (converter is not None and self._epilogue[0] is not converter):
+      return
+    if self._native is not None:
+      N.check(N.lib().pcx_engine_set_epilogue(self._native, None))
+    self._epilogue[0]._epilogue_gone()
+    self._epilogue = None
 
   def _register_cropper(self, cropper):
     if cropper not in self._croppers:
@@ -354,7 +371,11 @@ class Engine(object):
     reference raises for (the bits are sticky within an episode).  `play()`
     with batch 1 checks every step; with batch > 1 it polls asynchronously and
     raises one or two steps late; `step()` never checks."""
-    err = self._b['error'].numpy()
+    self._b  # (raises after close())
+    err = np.zeros((self._batch,), np.uint8)
+    # the live error array ORed with what the asynchronous polls saw: an
+    # environment that raised and was auto-reset since is still reported
+    N.check(N.lib().pcx_engine_errors_seen(self._native, err.ctypes.data, 1))
     if err.any():
       bad = int(np.flatnonzero(err)[0])
       code = int(err[bad])
@@ -374,6 +395,17 @@ class Engine(object):
 
   def _result(self):
     L = self._template.chars
+    if self._only_crops:
+      # cropping.fuse_croppers(..., only_crops=True): the step kernel no longer
+      # writes the full-board planes, so there is no observation to hand out --
+      # the fused croppers' crop() returns what the step wrote
+      sc = None if self._batch > 1 else self._read_scalars()
+      stale = self._tag(rendering.Observation(board=None, layers={}))
+      if self._batch == 1:
+        self.check_errors()
+        return stale, (int(sc['reward'][0]) if sc['reward_set'][0] else None), float(sc['discount'][0])
+      pick = lambda k: (self._b[k].tensor if self._b[k].tensor is not None else self._b[k].numpy())
+      return stale, pick('reward'), pick('discount')
     if self._batch == 1:
       sc = self._read_scalars()
       self.check_errors()
@@ -491,6 +523,8 @@ class Engine(object):
     if self._native is not None:
       for cropper in self._croppers:  # their native halves point into this engine: they go first
         cropper._release()
+      if self._epilogue is not None:  # the kernel stops writing the converter's tensor before anybody frees it
+        self._clear_epilogue()
       N.lib().pcx_engine_destroy(self._native)
       self._native = None
       # engine <-> cropper references form a cycle: without this the buffers would wait for the garbage collector

@@ -243,8 +243,22 @@ class ObservationToFeatureArray(object):
     # start from the current observation (environments a later step leaves
     # untouched keep features that match their planes)
     out.copy_(ObservationToFeatureArray(self._layers)(engine._result()[0]))
+    # The ENGINE owns the epilogue: it keeps this converter and the tensor the
+    # kernel writes alive for as long as it may launch (a converter that was
+    # garbage-collected would leave the kernel writing freed memory), tells the
+    # converter it replaces that it is no longer fed, and lets go in close().
+    engine._install_epilogue(self, out)
     self._fused = (engine, out, engine._steps_launched)
     return True
+
+  def unfuse(self):
+    """Takes the epilogue out of the engine's step kernel again (calls then run
+    the post-processor as its own kernel)."""
+    if self._fused is not None:
+      self._fused[0]._clear_epilogue(self)
+
+  def _epilogue_gone(self):
+    self._fused = None
 
   def __call__(self, observation):
     if self._fused is not None and getattr(observation, '_source', None) is self._fused[0]:

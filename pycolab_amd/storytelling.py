@@ -54,6 +54,19 @@ class Story(object):
     self._first_chapter = first_chapter
     self._showtime = False
     self._game_over = False
+    self._dummies = {}
+    if self._batch > 1:
+      # every chapter keeps its own engine alive, so every chapter needs its own
+      # cropper: one cropper object handed in for all chapters (which the
+      # reference allows, storytelling.py:129-137) becomes one clone per chapter
+      # -- a device cropper is bound to ONE engine and holds that engine's
+      # per-environment window state
+      seen = {}
+      for key in sorted(self._croppers, key=repr):
+        cr = self._croppers[key]
+        if type(cr) is not cropping.ObservationCropper and id(cr) in seen:
+          self._croppers[key] = cr._clone()
+        seen[id(cr)] = key
     if self._batch == 1:
       self._current_game = self._chapters[first_chapter]()
       self._current_cropper = self._croppers[first_chapter]
@@ -307,12 +320,65 @@ class Story(object):
                            palette=engine.Palette(self._chars_backdrops))
 
   @property
+  def things(self):
+    """storytelling.py:344-377: the current game's entities, plus stand-ins for
+    the characters only other chapters use (`is_fictional` tells them apart).
+    Batch > 1: the entities are the FIRST chapter engine's batched views (every
+    environment has its own chapter: `this_chapter`, `engine_of(key).things`)."""
+    out = dict(self._current_game.things)
+    shape = (self._current_game.rows, self._current_game.cols)
+    for c in self._chars_sprites:
+      if c not in out:
+        out[c] = self._dummies.setdefault(('s', c, shape), _DummySprite(things.Sprite.Position(*shape), c))
+    for c in self._chars_drapes:
+      if c not in out:
+        out[c] = self._dummies.setdefault(('d', c, shape), _DummyDrape(np.zeros(shape, dtype=bool), c))
+    return out
+
+  @property
   def current_game(self):
+    """storytelling.py:379-388.  Batch > 1: the first chapter's engine -- `the_plot`,
+    `z_order` and `backdrop` describe that engine whichever chapters the
+    environments are in; use `engine_of(key)` for another chapter's."""
     return self._current_game
+
+  def engine_of(self, key):
+    """Batch > 1: the engine that steps chapter `key` (created on first use)."""
+    if self._batch == 1:
+      raise RuntimeError('engine_of() is for batched stories; use current_game')
+    if key not in self._chapters:
+      raise KeyError(key)
+    return self._engine_for(key)
 
   def close(self):
     for game in ([self._current_game] if self._batch == 1 else list(self._engines.values())):
       game.close()
+
+
+def is_fictional(thing):
+  """True iff `thing` is one of the stand-ins `Story.things` returns
+  (storytelling.py:473-483)."""
+  return isinstance(thing, (_DummySprite, _DummyDrape))
+
+
+class _DummySprite(things.Sprite):
+  """An invisible Sprite standing for a character the current game does not use
+  (storytelling.py:627-641)."""
+
+  def __init__(self, corner, character):
+    super(_DummySprite, self).__init__(corner=corner, position=self.Position(0, 0), character=character)
+    self._visible = False
+
+  def update(self, *args, **kwargs):
+    raise RuntimeError('_DummySprite.update should never be called.')
+
+
+class _DummyDrape(things.Drape):
+  """An empty Drape standing for a character the current game does not use
+  (storytelling.py:644-656)."""
+
+  def update(self, *args, **kwargs):
+    raise RuntimeError('_DummyDrape.update should never be called.')
 
 
 def _as_tensor(x, like):

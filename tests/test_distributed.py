@@ -110,22 +110,89 @@ def test_bench_refuses_more_gpus_than_the_node_has():
   assert 'GPU(s)' in r.stderr and '"n_gpus"' not in r.stdout
 
 
+def _ragged_worker(rank, world, port, out_dir):
+  sys.path.insert(0, helpers.ROOT)
+  import torch
+  import torch.distributed as dist
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  n = 5 + rank  # shards of different length and no global_batch: must raise on every rank, not hang
+  try:
+    pdist.ScalarGather(torch.zeros(10 * n, dtype=torch.uint8))
+    verdict = 'no error'
+  except ValueError as e:
+    verdict = 'ValueError: %s' % e
+  open(os.path.join(out_dir, 'rank%d.txt' % rank), 'w').write(verdict)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_ragged_shards_without_global_batch_raise(tmp_path):
+  import torch.multiprocessing as mp
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  mp.spawn(_ragged_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  for rank in range(2):
+    verdict = open(str(tmp_path / ('rank%d.txt' % rank))).read()
+    assert verdict.startswith('ValueError') and 'global_batch' in verdict, verdict
+
+
+def test_hashed_tape_is_the_device_generator():
+  """pycolab_amd.actions.hashed_tape (what a sharded bench stages) == pcx_action_hash of the C ABI."""
+  from pycolab_amd import _native as N
+  from pycolab_amd import actions
+  tape = actions.hashed_tape(0x5EED, 1000, 7, 3, 5, 5)
+  want = [[N.lib().pcx_action_hash(0x5EED, 1000 + e, 3 + t) % 5 for e in range(7)] for t in range(5)]
+  np.testing.assert_array_equal(tape, np.array(want, np.int32))
+
+
 @pytest.mark.gpu
-def test_bench_two_ranks_over_rccl():
-  """Two ranks spawned by bench.py itself, weak and strong scaling, with the
-  packed scalar all-gather timed (needs a node with at least two GPUs)."""
+@pytest.mark.parametrize('scaling,batch', [('strong', 1001), ('weak', 512)])
+def test_bench_two_ranks_equal_one_unsharded_engine(tmp_path, scaling, batch):
+  """The N>1 path of bench.py, executed: two ranks spawned by bench.py itself through
+  torch.distributed.run -- over RCCL where the node has two GPUs; on a one-GPU box with
+  `--oversubscribe` (both ranks share the GPU, so the group is gloo; launcher, shard_range /
+  env_offset, weak and strong accounting, ScalarGather with padded sends and the rank-0 JSON
+  are the real path's).  The union of the two shards -- gathered scalars and per-rank
+  observation checksums -- must equal ONE unsharded engine."""
   import json
   import torch
-  if torch.cuda.device_count() < 2:
-    pytest.skip('needs two GPUs')
-  for scaling, per_gpu in (('weak', 8192), ('strong', 4096)):
-    r = _run_bench('--gpus', '2', '--steps', '6', '--warmup', '2', '--batch', '8192', '--scaling', scaling,
-                   '--gather', '--no-cpu-baseline')
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line['n_gpus'] == 2 and line['scaling'] == scaling
-    assert line['config']['batch_per_gpu'] == per_gpu and line['config']['global_batch'] == 2 * per_gpu
-    assert line['gather']['bytes_per_rank_per_step'] == 10 * per_gpu
+  from tests.hip_adapter import HipAdapter
+  dump = str(tmp_path / 'gathered.npz')
+  real = torch.cuda.device_count() >= 2
+  r = _run_bench('--gpus', '2', *([] if real else ['--oversubscribe']), '--steps', '5', '--warmup', '2', '--repeats', '2',
+                 '--batch', str(batch), '--scaling', scaling, '--gather', '--actions', 'hashed',
+                 '--dump-scalars', dump, '--no-cpu-baseline')
+  assert r.returncode == 0, r.stderr[-3000:]
+  line = json.loads(r.stdout.strip().splitlines()[-1])
+  global_batch = batch if scaling == 'strong' else 2 * batch
+  sizes = [hi - lo for lo, hi in (pdist.shard_range(global_batch, k, 2) for k in range(2))]
+  assert line['n_gpus'] == 2 and line['scaling'] == scaling
+  assert line['config']['global_batch'] == global_batch and line['config']['batch_per_gpu'] == sizes[0]
+  assert line['dist']['world_size'] == 2 and line['dist']['backend'] == ('nccl' if real else 'gloo')
+  assert line['dist']['oversubscribed'] == (not real)
+  assert line['dist']['per_rank_envs'] == sizes and len(line['dist']['per_rank_kernel_ms']) == 2
+  assert all(ms > 0 for ms in line['dist']['per_rank_kernel_ms'])
+  assert line['repeats']['k'] == 2 and len(line['repeats']['ms_per_step_all']) == 2
+  assert line['gather']['bytes_per_rank_per_step'] == 10 * sizes[0]
+  assert abs(line['value'] - global_batch * 5 / (line['ms_per_step'] * 5e-3)) < 1e-6 * line['value']
+  got = np.load(dump)
+  steps = int(got['steps_taken'][0])
+  assert steps == 2 + 2 * 5 + 5
+  whole = HipAdapter(helpers.load_template('scrolly_maze_L0'), global_batch)
+  whole.reset()
+  whole.step_hashed(0x5EED, 0, steps)
+  for name in ('reward', 'reward_set', 'discount', 'done'):
+    np.testing.assert_array_equal(got[name], whole.read(name), err_msg=name)
+  planes = whole.read('planes').reshape(global_batch, -1).astype(np.int64).sum(axis=1)
+  frames = whole.read('frame').astype(np.int64)
+  checks = json.loads(bytes(got['checks']).decode())
+  assert [c['rank'] for c in checks] == [0, 1] and [c['n'] for c in checks] == sizes
+  for c in checks:
+    lo, hi = c['lo'], c['lo'] + c['n']
+    assert c['planes_sum'] == int(planes[lo:hi].sum())
+    assert c['planes_weighted'] == int((planes[lo:hi] * np.arange(lo + 1, hi + 1)).sum())
+    assert c['frame_sum'] == int(frames[lo:hi].sum())
+  assert (frames < steps).any()  # episodes ended and restarted inside the run
 
 
 @pytest.mark.gpu
@@ -150,3 +217,65 @@ def test_packed_scalars_gather_matches_buffers():
     assert hip.read('reward_set').any()
   finally:
     dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_c_abi_gather_scalars_over_rccl():
+  """include/pcx.h pcx_gather_*: the gather a torch-less FFI host uses -- one process, one RCCL
+  communicator per engine's device (one device on this box), bound with dlopen.  Both send
+  paths: the engine's own four output arrays (packed by a kernel) and the one packed
+  allocation pycolab_amd.Engine binds (sent in place)."""
+  import ctypes
+  from pycolab_amd import _native as N
+  from pycolab_amd.engine import Engine
+  lib = N.lib()
+  t = helpers.load_template('scrolly_maze_L0')
+  steps = 40
+
+  def gathered(native, batch):
+    g = ctypes.c_void_p()
+    arr = (ctypes.c_void_p * 1)(native)
+    N.check(lib.pcx_gather_create(arr, 1, ctypes.byref(g)))
+    try:
+      N.check(lib.pcx_gather_scalars(g, None))
+      recv, slot = ctypes.c_void_p(), N.c_i64()
+      N.check(lib.pcx_gather_buffers(g, 0, ctypes.byref(recv), ctypes.byref(slot)))
+      assert slot.value == (10 * batch + 15) // 16 * 16
+      N.check(lib.pcx_stream_synchronize(None))
+      host = np.empty((slot.value,), np.uint8)
+      N.check(lib.pcx_memcpy_d2h(host.ctypes.data, recv, host.nbytes))
+      return (host[:4 * batch].view(np.int32), host[8 * batch:9 * batch], host[4 * batch:8 * batch].view(np.float32),
+              host[9 * batch:10 * batch])
+    finally:
+      lib.pcx_gather_destroy(g)
+
+  # (a) a bare C-ABI engine: no bound buffers, its own separate output arrays
+  batch = 1003
+  ct, keep = t.to_ctypes()
+  h = ctypes.c_void_p()
+  N.check(lib.pcx_engine_create(ctypes.byref(ct), batch, 0, ctypes.byref(h)))
+  try:
+    N.check(lib.pcx_engine_reset(h, None, None))
+    N.check(lib.pcx_engine_step_hashed(h, 0xABCD, 0, 0, steps, 1, None))
+    got = gathered(h, batch)
+    bufs = N.Buffers()
+    N.check(lib.pcx_engine_buffers(h, ctypes.byref(bufs)))
+    for i, (name, dt) in enumerate((('reward', np.int32), ('reward_set', np.uint8), ('discount', np.float32), ('done', np.uint8))):
+      want = np.empty((batch,), dt)
+      N.check(lib.pcx_memcpy_d2h(want.ctypes.data, getattr(bufs, name), want.nbytes))
+      np.testing.assert_array_equal(got[i], want, err_msg=name)
+    assert got[3].any() or got[1].any()
+  finally:
+    lib.pcx_engine_destroy(h)
+  del keep
+  # (b) the Python facade's engine: outputs bound as ONE packed allocation, 10 * batch a multiple of 16
+  batch = 1024
+  eng = Engine.from_template(t, batch=batch, auto_reset=True)
+  eng.its_showtime()
+  eng.step_hashed(0xABCD, 0, steps)
+  import torch
+  torch.cuda.synchronize()
+  got = gathered(eng._native, batch)
+  for i, name in enumerate(('reward', 'reward_set', 'discount', 'done')):
+    np.testing.assert_array_equal(got[i], eng.buffers[name].numpy(), err_msg=name)
+  eng.close()
