@@ -229,3 +229,45 @@ def test_feature_array_fused_into_the_step_kernel(skip_layers):
   wm = Engine.from_template(helpers.load_template('warehouse_L0'), batch=8)   # 110 cells: not whole dwords
   wm.its_showtime()
   assert not rendering.ObservationToFeatureArray('#P').fuse_into(wm)
+
+
+@pytest.mark.gpu
+def test_fused_epilogue_belongs_to_the_engine():
+  """The step kernel writes a fused converter's tensor at every step, so the ENGINE keeps
+  converter and tensor alive (a converter dropped by the caller must not leave the kernel
+  writing freed memory); a second converter takes the first one's place and the first runs
+  as its own kernel again; unfuse() and close() stop the writes."""
+  import gc
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('marauders')
+  B = 200
+  eng = Engine.from_template(t, batch=B, auto_reset=True, seed=5)
+  eng.its_showtime()
+  first = rendering.ObservationToFeatureArray('PX')
+  assert first.fuse_into(eng)
+  kept = eng._epilogue[1]
+  del first
+  gc.collect()
+  assert eng._epilogue is not None and eng._epilogue[1] is kept      # still owned: the kernel may write it
+  junk = [torch.full((B, 2, t.rows, t.cols), 7.0, device='cuda') for _ in range(4)]  # would reuse freed blocks
+  obs = eng.play(np.zeros(B, np.int32))[0]
+  assert all(bool((x == 7.0).all()) for x in junk)
+  assert torch.equal(kept[:, 0], (obs.board == ord('P')).to(torch.float32))
+  a, b = rendering.ObservationToFeatureArray('PX'), rendering.ObservationToFeatureArray('B a')
+  assert a.fuse_into(eng) and b.fuse_into(eng)                        # b replaces a in the kernel
+  assert a._fused is None and b._fused is not None
+  obs = eng.play(np.ones(B, np.int32))[0]
+  board = obs.board
+  for conv, chars in ((a, 'PX'), (b, 'B a')):                         # a: its own kernel again; b: fused
+    got = conv(obs)
+    for k, ch in enumerate(chars):
+      assert torch.equal(got[:, k], (board == ord(ch)).to(torch.float32)), ch
+  b.unfuse()
+  assert eng._epilogue is None and b._fused is None
+  stale = b(eng.play(np.ones(B, np.int32))[0])                        # separate kernel now
+  assert torch.equal(stale[:, 0], (eng._result()[0].board == ord('B')).to(torch.float32))
+  c = rendering.ObservationToFeatureArray('P')
+  assert c.fuse_into(eng)
+  eng.close()
+  assert c._fused is None

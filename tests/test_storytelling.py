@@ -74,6 +74,35 @@ def test_story_batched_every_environment_in_its_own_chapter():
   story.close()
 
 
+def test_story_batched_with_one_cropper_shared_by_all_chapters():
+  """The reference lets ONE cropper serve every game of a Story (storytelling.py:129-137).
+  At batch > 1 every chapter has its own live engine, so the story clones the cropper per
+  chapter: each environment's window must come from the chapter IT is in."""
+  from pycolab_amd import cropping, storytelling
+  tr = helpers.load_trace_raw('story_three_chapters')
+  T, E = tr['actions'].shape
+  shared = cropping.FixedCropper((-1, 3), 4, 5, pad_char='.')
+  story = storytelling.Story(chapters(E), croppers=shared, auto_reset=True)
+  assert len({id(c) for c in story._croppers.values()}) == 3
+  assert story.rows == 4 and story.cols == 5
+
+  def want(row):
+    full = tr['boards'][row]
+    out = np.full((E, 4, 5), ord('.'), np.uint8)
+    out[:, 1:, :] = full[:, 0:3, 3:8]
+    return out
+
+  obs = story.its_showtime()[0]
+  np.testing.assert_array_equal(helpers.to_np(obs.board), want(0))
+  for t in range(T):
+    obs = story.play(tr['actions'][t])[0]
+    np.testing.assert_array_equal(helpers.to_np(obs.board), want(t + 1), err_msg='row %d' % (t + 1))
+  things = story.things  # storytelling.py:344-377: stand-ins for the other chapters' characters
+  assert set(things) == set('QRabDc')
+  assert sum(storytelling.is_fictional(x) for x in things.values()) == 4
+  story.close()
+
+
 def test_story_constructor_checks():
   """storytelling.py:493-553, 556-624."""
   from pycolab_amd import ascii_art, storytelling
