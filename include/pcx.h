@@ -276,6 +276,21 @@ int pcx_engine_error_poll(pcx_engine* e, void* stream, int32_t* seen);
  * clear != 0.  Synchronous. */
 int pcx_engine_errors_seen(pcx_engine* e, uint8_t* errors_host, int32_t clear);
 
+/* Checkpoint / resume.  The reference keeps an episode alive as a Python object
+ * graph (an Engine is picklable: engine.py:98-246 holds plain attributes); here an
+ * episode is the engine's device arrays.  export writes them into caller-owned
+ * host memory of pcx_engine_state_size() bytes: the per-environment state words
+ * (entity state, Plot scalars, RNG draw counters), the sprite track the
+ * croppers read, and what the last play() returned besides the observation;
+ * with_observation != 0 adds the observation planes (environments whose episode
+ * is over and are left alone keep showing their last frame).  import restores a
+ * checkpoint into an engine created from the same template with the same batch
+ * (pcx_engine_reset need not have run): the steps that follow are exactly the
+ * steps the exporting engine would have taken.  Synchronous. */
+int pcx_engine_state_size(pcx_engine* e, int32_t with_observation, uint64_t* bytes);
+int pcx_engine_export_state(pcx_engine* e, void* state_host, uint64_t bytes, int32_t with_observation);
+int pcx_engine_import_state(pcx_engine* e, const void* state_host, uint64_t bytes);
+
 /* Convenience synchronous copies (host <-> device) for thin FFI hosts. */
 int pcx_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes);
 int pcx_memcpy_h2d(void* dst_dev, const void* src_host, uint64_t bytes);

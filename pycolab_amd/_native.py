@@ -136,6 +136,9 @@ SYMBOLS = [
     ('pcx_engine_read_things', c_i32, [_VP, c_i64, c_i64, _VP, _VP]),
     ('pcx_engine_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
     ('pcx_engine_errors_seen', c_i32, [_VP, _VP, c_i32]),
+    ('pcx_engine_state_size', c_i32, [_VP, c_i32, ctypes.POINTER(c_u64)]),
+    ('pcx_engine_export_state', c_i32, [_VP, _VP, c_u64, c_i32]),
+    ('pcx_engine_import_state', c_i32, [_VP, _VP, c_u64]),
     ('pcx_engine_set_epilogue', c_i32, [_VP, ctypes.POINTER(EpilogueDesc)]),
     ('pcx_memcpy_d2h', c_i32, [_VP, _VP, c_u64]),
     ('pcx_memcpy_h2d', c_i32, [_VP, _VP, c_u64]),

@@ -310,6 +310,97 @@ int pcx_engine_errors_seen(pcx_engine* e, uint8_t* errors_host, int32_t clear) {
   return e->error_poll.errors_seen(e->out.error, e->batch, errors_host, clear);
 }
 
+// ---- checkpoint / resume -------------------------------------------------------------
+namespace {
+struct StateHeader {
+  uint32_t magic, abi;
+  int32_t game, rows, cols, n_chars, n_sprites, n_drapes;
+  int64_t batch;
+  uint64_t epoch;
+  int32_t with_observation, n_arrays;
+};
+constexpr uint32_t STATE_MAGIC = 0x53584350u;  // "PCXS"
+
+// the arrays of a checkpoint, in order: backend arrays, then what play() last returned
+int state_arrays(pcx_engine* e, int with_obs, std::vector<std::pair<void*, size_t>>& arr) {
+  int rc = pcx::ensure_outputs(e);
+  if (rc) return rc;
+  e->backend->persistent_arrays(arr);
+  const size_t B = (size_t)e->batch;
+  arr.push_back({e->out.reward, B * 4}); arr.push_back({e->out.reward_set, B}); arr.push_back({e->out.discount, B * 4});
+  arr.push_back({e->out.done, B}); arr.push_back({e->out.frame, B * 4}); arr.push_back({e->out.error, B});
+  if (with_obs) arr.push_back({e->out.planes, B * (size_t)(1 + e->t.n_chars) * (size_t)e->backend->plane_pitch()});
+  return 0;
+}
+}  // namespace
+
+int pcx_engine_state_size(pcx_engine* e, int32_t with_observation, uint64_t* bytes) {
+  if (!e || !bytes) return set_error(PCX_E_INVALID, "pcx_engine_state_size: bad arguments");
+  PCX_HIP(hipSetDevice(e->device));
+  std::vector<std::pair<void*, size_t>> arr;
+  int rc = state_arrays(e, with_observation, arr);
+  if (rc) return rc;
+  uint64_t n = sizeof(StateHeader);
+  for (auto& a : arr) n += 8 + ((a.second + 7) & ~(size_t)7);
+  *bytes = n;
+  return 0;
+}
+
+int pcx_engine_export_state(pcx_engine* e, void* host, uint64_t bytes, int32_t with_observation) {
+  if (!e || !host) return set_error(PCX_E_INVALID, "pcx_engine_export_state: bad arguments");
+  if (!e->showtime) return set_error(PCX_E_STATE, "pcx_engine_export_state: the engine is not in play (its_showtime)");
+  uint64_t need = 0;
+  int rc = pcx_engine_state_size(e, with_observation, &need);
+  if (rc) return rc;
+  if (bytes < need) return set_error(PCX_E_INVALID, "pcx_engine_export_state: %llu bytes given, %llu needed",
+                                     (unsigned long long)bytes, (unsigned long long)need);
+  std::vector<std::pair<void*, size_t>> arr;
+  if ((rc = state_arrays(e, with_observation, arr))) return rc;
+  PCX_HIP(hipDeviceSynchronize());
+  StateHeader h{STATE_MAGIC, PCX_ABI_VERSION, e->t.game, e->t.rows, e->t.cols, e->t.n_chars, e->t.n_sprites, e->t.n_drapes,
+                e->batch, e->epoch, with_observation != 0, (int32_t)arr.size()};
+  uint8_t* p = static_cast<uint8_t*>(host);
+  memcpy(p, &h, sizeof h); p += sizeof h;
+  for (auto& a : arr) {
+    const uint64_t n = a.second;
+    memcpy(p, &n, 8); p += 8;
+    PCX_HIP(hipMemcpy(p, a.first, a.second, hipMemcpyDeviceToHost));
+    p += (a.second + 7) & ~(size_t)7;
+  }
+  return 0;
+}
+
+int pcx_engine_import_state(pcx_engine* e, const void* host, uint64_t bytes) {
+  if (!e || !host || bytes < sizeof(StateHeader)) return set_error(PCX_E_INVALID, "pcx_engine_import_state: bad arguments");
+  PCX_HIP(hipSetDevice(e->device));
+  StateHeader h;
+  memcpy(&h, host, sizeof h);
+  if (h.magic != STATE_MAGIC || h.abi != PCX_ABI_VERSION) return set_error(PCX_E_INVALID, "pcx_engine_import_state: not a checkpoint of this ABI");
+  if (h.game != e->t.game || h.rows != e->t.rows || h.cols != e->t.cols || h.n_chars != e->t.n_chars ||
+      h.n_sprites != e->t.n_sprites || h.n_drapes != e->t.n_drapes || h.batch != e->batch)
+    return set_error(PCX_E_INVALID, "pcx_engine_import_state: the checkpoint is of another game, board or batch");
+  std::vector<std::pair<void*, size_t>> arr;
+  int rc = state_arrays(e, h.with_observation, arr);
+  if (rc) return rc;
+  if ((int32_t)arr.size() != h.n_arrays) return set_error(PCX_E_INVALID, "pcx_engine_import_state: array count mismatch");
+  const uint8_t* p = static_cast<const uint8_t*>(host) + sizeof h;
+  const uint8_t* const end = static_cast<const uint8_t*>(host) + bytes;
+  PCX_HIP(hipDeviceSynchronize());
+  for (auto& a : arr) {
+    uint64_t n = 0;
+    if (p + 8 > end) return set_error(PCX_E_INVALID, "pcx_engine_import_state: truncated checkpoint");
+    memcpy(&n, p, 8); p += 8;
+    if (n != a.second || p + n > end)
+      return set_error(PCX_E_INVALID, "pcx_engine_import_state: array size mismatch (another launch shape or kernel?)");
+    PCX_HIP(hipMemcpy(a.first, p, a.second, hipMemcpyHostToDevice));
+    p += (a.second + 7) & ~(size_t)7;
+  }
+  e->showtime = true;
+  e->epoch = h.epoch + 1;  // croppers: the observation changed under them
+  e->curtains_fresh = false;
+  return 0;
+}
+
 int pcx_engine_set_epilogue(pcx_engine* e, const pcx_epilogue_desc* d) {
   if (!e) return set_error(PCX_E_INVALID, "pcx_engine_set_epilogue: null engine");
   if (d) {

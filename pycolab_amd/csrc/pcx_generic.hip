@@ -33,6 +33,7 @@ enum : int { T_CH = 0, T_KIND, T_IDX, T_PROG, T_LAYER, T_ABOVE, T_FLAGS, T_P0, T
              T_ABOVE_S, T_ABOVE_D,  // the things in front, as a sprite-index mask and a drape-index mask
              T_P2, T_P3,            // tabled entities: directive field of the action (shift, mask)
              T_GROUP,               // scrolling group (protocols/scrolling.py), 0..PCX_MAX_SCROLL_GROUPS-1
+             T_IMPT,                // walkers: mask of the things whose character is in the impassable set
              T_WORDS };
 // plot directives (include/pcx.h pcx_directive), four words each, staged into LDS
 enum : int { D_WHO = 0 /* thing | kind << 8 | move_this thing << 16 | in_front_of thing << 24 (0xFF = None) */, D_SEL, D_REWARD,
@@ -64,7 +65,7 @@ struct Consts {
   int32_t bolt_mask_all, bolt_mask_up;  // marauders: sprite-index masks of 'abcdyz' / 'abcd'
   int32_t box_mask;                     // warehouse: sprite-index mask of the box sprites
   // LDS layout (word offsets); per-lane arrays are [i][lane]
-  int32_t l_things, l_z, l_sched, l_backdrop, l_bdmask, l_aux, l_init, l_initd, l_laybc, l_s2t;
+  int32_t l_things, l_z, l_sched, l_backdrop, l_bdmask, l_aux, l_init, l_initd, l_laybc, l_s2t, l_d2t;
   int32_t l_pos, l_flg, l_snap, l_cur, l_snapd, l_flat, l_sdesc, l_skip, l_flatraw, l_sdescraw, l_corner, l_pmask, l_pframe, l_words;
 };
 
@@ -79,7 +80,7 @@ struct Ptrs {
 };
 
 struct L {
-  const uint32_t *things, *z, *sched, *backdrop4, *bdmask, *aux, *init, *initd, *laybc, *s2t;
+  const uint32_t *things, *z, *sched, *backdrop4, *bdmask, *aux, *init, *initd, *laybc, *s2t, *d2t;
   uint32_t *pos, *flg, *cur, *snapd, *flat, *skip, *flatraw, *corner, *pmask, *pframe;
   const uint32_t* dir;
   uint32_t *zord, *zabove, *zabove_s, *zabove_d, *zq, *ztmp;  // per-lane z-order (only when a game changes it)
@@ -115,12 +116,23 @@ struct Ctx {
   uint32_t orders, gsprites;  // gsprites: sprite-index mask of that group's members
   uint32_t registered;  // bit per sprite index: 'scrolling_X_egocentrists' of every group X
   int nzq;              // queued change_z_order directives (plot.py:173-174)
+  // A program's MazeWalker._move is not called where the program stands: it is left here and made
+  // by the ONE mw_move the kernel contains, right after the program switch (the probes behind a move
+  // are the bulk of the code; a copy per program tripled the kernel and its register pressure).
+  int mv_dr, mv_dc, mv_post;  // mv_post: 0 no move, 1 move, 2 move + BS patroller's catch check
 };
 
 __device__ __forceinline__ bool on_board(const Consts& k, int r, int c) {
   return (unsigned)r < (unsigned)k.R && (unsigned)c < (unsigned)k.C;
 }
-__device__ __forceinline__ uint32_t tfield(const Ctx& x, int thing, int f) { return x.l.things[thing * T_WORDS + f]; }
+// (every lane reads the same word: pinning the value to an SGPR keeps the interpreter's control flow
+// scalar and its table values out of the vector registers)
+__device__ __forceinline__ uint32_t tfield(const Ctx& x, int thing, int f) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)x.l.things[thing * T_WORDS + f]);
+}
+// ... and where the thing (or the field) is the lane's own -- the thing on top of a cell, a place in an
+// environment's own z-order, the impassable word of the lane's backdrop character
+__device__ __forceinline__ uint32_t tfield_v(const Ctx& x, int thing, int f) { return x.l.things[thing * T_WORDS + f]; }
 // The z-order (engine.py:751-757 paints `_sprites_and_drapes` in order).  Things
 // are numbered by their place in the template's order; a game whose entities
 // issue change_z_order keeps every environment's current order, and the
@@ -137,7 +149,7 @@ __device__ __forceinline__ void derive_above(const Ctx& x) {  // masks from the 
     x.l.zabove_s[t * WAVE + x.lane] = sp;
     x.l.zabove_d[t * WAVE + x.lane] = dr;
     all |= 1u << t;
-    if (tfield(x, t, T_KIND) == 0) sp |= 1u << tfield(x, t, T_IDX); else dr |= 1u << tfield(x, t, T_IDX);
+    if (tfield_v(x, t, T_KIND) == 0) sp |= 1u << tfield_v(x, t, T_IDX); else dr |= 1u << tfield_v(x, t, T_IDX);
   }
 }
 
@@ -195,28 +207,63 @@ __device__ __forceinline__ void row_put(const Ctx& x, uint32_t* base, int d, int
 __device__ __forceinline__ void snapshot(const Ctx& x) {
   for (int s = 0; s < x.k.NS; ++s) x.l.snap[s * WAVE + x.lane] = sprite_cell(x, s);
   const int n = x.k.ND * x.k.R * x.k.RW;
-  for (int i = 0; i < n; ++i) x.l.snapd[i * WAVE + x.lane] = x.l.cur[i * WAVE + x.lane];
+  for (int i0 = 0; i0 < n; i0 += 4) {  // four LDS reads in flight
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = x.l.cur[(i0 + j < n ? i0 + j : i0) * WAVE + x.lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (i0 + j < n) x.l.snapd[(i0 + j) * WAVE + x.lane] = v[j];
+  }
+}
+// Which things the last repaint painted at board cell (r, c), as a mask over
+// thing ids (= places in the template's z-order): every sprite's snapshot cell
+// and every curtain's snapshot bit -- one per-lane LDS read per thing and no
+// read that depends on another, instead of a walk over the z-order with three
+// table look-ups and a dependent read per thing.
+__device__ __forceinline__ uint32_t present_at(const Ctx& x, int r, int c) {
+  const int cell = r * x.k.C + c, NS = x.k.NS, ND = x.k.ND;
+  uint32_t m = 0;
+#pragma unroll 2
+  for (int s = 0; s < NS; ++s) {
+    const int at = x.l.snap[s * WAVE + x.lane];
+    const uint32_t bit = 1u << __builtin_amdgcn_readfirstlane((int)x.l.s2t[s]);
+    m |= at == cell ? bit : 0u;
+  }
+  const int wo = r * x.k.RW + (c >> 5), sh = c & 31, dstride = x.k.R * x.k.RW;
+  for (int d = 0; d < ND; ++d) {
+    const uint32_t w = x.l.snapd[(d * dstride + wo) * WAVE + x.lane];
+    const uint32_t bit = 1u << __builtin_amdgcn_readfirstlane((int)x.l.d2t[d]);
+    m |= ((w >> sh) & 1u) ? bit : 0u;
+  }
+  return m;
+}
+// The thing in front among those of a non-empty mask (engine.py:751-757 paints
+// back to front): the highest id in the template's order, or -- where entities
+// change the z-order -- the one none of the others is in front of.
+__device__ __forceinline__ int top_thing(const Ctx& x, uint32_t m) {
+  if (!x.k.zdyn) return 31 - __clz((int)m);
+  int top = 31 - __clz((int)m);
+  for (uint32_t rest = m; rest; rest &= rest - 1u) {
+    const int t = __ffs((int)rest) - 1;
+    if (!(m & x.l.zabove[t * WAVE + x.lane])) top = t;
+  }
+  return top;
 }
 // character on top of board cell (r, c) in the last repaint (rendering.py:85-184)
 __device__ __forceinline__ int top_char(const Ctx& x, int r, int c) {
   const int cell = r * x.k.C + c;
-  int ch = (x.l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
-  for (int z = 0; z < x.k.NT; ++z) {  // back to front
-    const int t = thing_at_z(x, z);
-    const uint32_t kind = tfield(x, t, T_KIND), idx = tfield(x, t, T_IDX);
-    const bool here = kind == 0 ? x.l.snap[idx * WAVE + x.lane] == cell : bit_at(x, x.l.snapd, idx, r, c);
-    if (here) ch = tfield(x, t, T_CH);
-  }
-  return ch;
+  const int back = (x.l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
+  const uint32_t m = present_at(x, r, c);
+  return m ? (int)tfield_v(x, top_thing(x, m), T_CH) : back;
 }
 // layers[thing's char][r, c] in the last repaint: with occlusion the thing must
 // be the one on top (rendering.py:177-179); without, its own mask counts
 // (rendering.py:236-278).
 __device__ __forceinline__ bool thing_layer(const Ctx& x, int thing, int r, int c) {
-  const uint32_t kind = tfield(x, thing, T_KIND), idx = tfield(x, thing, T_IDX);
-  const bool raw = kind == 0 ? x.l.snap[idx * WAVE + x.lane] == r * x.k.C + c : bit_at(x, x.l.snapd, idx, r, c);
+  const uint32_t m = present_at(x, r, c);
+  const bool raw = (m >> thing) & 1u;
   if (!x.k.occl || !raw) return raw;
-  return top_char(x, r, c) == (int)tfield(x, thing, T_CH);
+  return top_thing(x, m) == thing;
 }
 // Row r of a drape's layer in the last repaint, 64 columns at once: its
 // snapshot row, and with occlusion minus every cell a thing in front of it
@@ -251,18 +298,29 @@ __device__ __forceinline__ bool layer_at(Ctx& x, int thing, int r, int c) {
 __device__ __forceinline__ bool blocked_at(Ctx& x, int thing, int vr, int vc, int dr, int dc) {
   const int r = vr + dr, c = vc + dc;
   if (!on_board(x.k, r, c)) return (tfield(x, thing, T_FLAGS) & TF_CONFINED) != 0;  // EDGE
-  const int ch = top_char(x, r, c);
-  if (ch >= 128) return false;  // impassable sets are ASCII (compiler.py); anything else is passable
-  return (tfield(x, thing, T_IMP0 + (ch >> 5)) >> (ch & 31)) & 1;
+  const int cell = r * x.k.C + c;
+  const int back = (x.l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
+  const uint32_t impt = tfield(x, thing, T_IMPT), imp_back = tfield_v(x, thing, T_IMP0 + ((back >> 5) & 3));
+  const uint32_t m = present_at(x, r, c);
+  if (m) return (impt >> top_thing(x, m)) & 1u;  // the thing in front decides
+  if (back >= 128) return false;  // impassable sets are ASCII (compiler.py); anything else is passable
+  return (imp_back >> (back & 31)) & 1u;
 }
+// One copy of the probe in the code, walked by a loop: the target cell, then (diagonals only) the
+// two flanks (sprites.py:539-543: blocked by its own cell, or by both flanks).
 __device__ __forceinline__ bool check_motion(Ctx& x, int thing, int vr, int vc, int dr, int dc) {
-  if (dr != 0 && dc != 0)
-    return blocked_at(x, thing, vr, vc, dr, dc) ||
-           (blocked_at(x, thing, vr, vc, dr, 0) && blocked_at(x, thing, vr, vc, 0, dc));
-  if (dr != 0 || dc != 0) return blocked_at(x, thing, vr, vc, dr, dc);
-  return false;
+  if (dr == 0 && dc == 0) return false;
+  const int n = (dr != 0 && dc != 0) ? 3 : 1;
+  bool hit[3] = {false, false, false};
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) {
+    const bool b = blocked_at(x, thing, vr, vc, i == 2 ? 0 : dr, i == 1 ? 0 : dc);
+    hit[0] = i == 0 ? b : hit[0]; hit[1] = i == 1 ? b : hit[1]; hit[2] = i == 2 ? b : hit[2];
+  }
+  return hit[0] || (hit[1] && hit[2]);
 }
 __device__ __forceinline__ int motion_bit(int dr, int dc) { return (dr + 1) * 3 + (dc + 1); }
+__device__ __forceinline__ void request_move(Ctx& x, int dr, int dc, int post = 1) { x.mv_dr = dr; x.mv_dc = dc; x.mv_post = post; }
 __device__ __forceinline__ bool mw_move(Ctx& x, int thing, int dr, int dc) {
   const int s = tfield(x, thing, T_IDX);
   const bool ego = x.k.has_scroll && (tfield(x, thing, T_FLAGS) & TF_EGO);
@@ -279,10 +337,23 @@ __device__ __forceinline__ bool mw_move(Ctx& x, int thing, int dr, int dc) {
   const bool blocked = check_motion(x, thing, vr, vc, dr, dc);
   if (!blocked) { teleport(x, s, vr + dr, vc + dc); vr += dr; vc += dc; }
   if (ego) {  // sprites.py:456-477 + scrolling.py:372-434 permit()
+    // the eight neighbours, each probed once (sprites.py:539-543: a diagonal is blocked by its
+    // own cell or by both of its flanks)
+    uint32_t nb = 0;  // bit motion_bit(a, b): the neighbour at (a, b) is impassable
+#pragma unroll 1
+    for (int i = 0; i < 9; ++i) {
+      const int a = i / 3 - 1, b = i - 3 * (i / 3) - 1;
+      if (i != 4 && blocked_at(x, thing, vr, vc, a, b)) nb |= 1u << i;
+    }
+    const bool n = (nb >> motion_bit(-1, 0)) & 1, so = (nb >> motion_bit(1, 0)) & 1;
+    const bool we = (nb >> motion_bit(0, -1)) & 1, ea = (nb >> motion_bit(0, 1)) & 1;
+    const bool nw = (nb >> motion_bit(-1, -1)) & 1, ne = (nb >> motion_bit(-1, 1)) & 1;
+    const bool sw = (nb >> motion_bit(1, -1)) & 1, se = (nb >> motion_bit(1, 1)) & 1;
     uint32_t legal = 1u << motion_bit(0, 0);
-    for (int a = -1; a <= 1; ++a)
-      for (int b = -1; b <= 1; ++b)
-        if ((a || b) && !check_motion(x, thing, vr, vc, a, b)) legal |= 1u << motion_bit(a, b);
+    legal |= (uint32_t)!n << motion_bit(-1, 0) | (uint32_t)!so << motion_bit(1, 0);
+    legal |= (uint32_t)!we << motion_bit(0, -1) | (uint32_t)!ea << motion_bit(0, 1);
+    legal |= (uint32_t)!(nw || (n && we)) << motion_bit(-1, -1) | (uint32_t)!(ne || (n && ea)) << motion_bit(-1, 1);
+    legal |= (uint32_t)!(sw || (so && we)) << motion_bit(1, -1) | (uint32_t)!(se || (so && ea)) << motion_bit(1, 1);
     const uint32_t my_frame = (uint32_t)(x.frame + 1);
     uint32_t mask = x.l.pmask[s * WAVE + x.lane];
     if (!(mask & 0x80000000u) || x.l.pframe[s * WAVE + x.lane] != my_frame) mask = 0;
@@ -385,7 +456,7 @@ __device__ __forceinline__ void motion9(int a, int& dr, int& dc) {
 __device__ __forceinline__ void prog_walker(Ctx& x, int thing) {
   int dr, dc;
   motion9(entity_action(x, thing), dr, dc);
-  mw_move(x, thing, dr, dc);
+  request_move(x, dr, dc);
 }
 __device__ __forceinline__ void prog_scrolly(Ctx& x, int thing) {
   int dr, dc;
@@ -452,23 +523,28 @@ __device__ __forceinline__ bool char_layer_at(Ctx& x, int ch, int r, int c) {
 // ---- examples/better_scrolly_maze.py -------------------------------------------
 __device__ __forceinline__ void prog_bs_player(Ctx& x, int thing) {  // :258-272
   const int a = x.action;
-  if ((unsigned)a <= 4u) mw_move(x, thing, a == 0 ? -1 : a == 1 ? 1 : 0, a == 2 ? -1 : a == 3 ? 1 : 0);
+  if ((unsigned)a <= 4u) request_move(x, a == 0 ? -1 : a == 1 ? 1 : 0, a == 2 ? -1 : a == 3 ? 1 : 0);
   if (a == 5) terminate(x);
 }
 __device__ __forceinline__ void prog_bs_patroller(Ctx& x, int thing) {  // :284-301
   const int s = tfield(x, thing, T_IDX);
-  if (x.frame & 1) { mw_move(x, thing, 0, 0); return; }
+  if (x.frame & 1) { request_move(x, 0, 0); return; }
   int r, c;
   sprite_true(x, s, r, c);
   uint32_t f = x.l.flg[s * WAVE + x.lane];  // bit 2: _moving_east
   if (char_layer_at(x, '#', r, c - 1)) f |= 4u;
   if (char_layer_at(x, '#', r, c + 1)) f &= ~4u;
   x.l.flg[s * WAVE + x.lane] = f;
-  mw_move(x, thing, 0, (f & 4u) ? 1 : -1);
-  int pr, pc;
-  sprite_true(x, s, r, c);
-  sprite_true(x, tfield(x, x.k.ip, T_IDX), pr, pc);
-  if (r == pr && c == pc) terminate(x);
+  request_move(x, 0, (f & 4u) ? 1 : -1, 2);  // ... then :298-301, in after_move()
+}
+// what follows the move in a program's update()
+__device__ __forceinline__ void after_move(Ctx& x, int thing) {
+  if (x.mv_post == 2) {  // better_scrolly_maze.py:298-301: the patroller catches the player
+    int r, c, pr, pc;
+    sprite_true(x, tfield(x, thing, T_IDX), r, c);
+    sprite_true(x, tfield(x, x.k.ip, T_IDX), pr, pc);
+    if (r == pr && c == pc) terminate(x);
+  }
 }
 __device__ __forceinline__ void prog_bs_cash(Ctx& x, int thing) {  // :311-320
   const int d = tfield(x, thing, T_IDX);
@@ -495,7 +571,7 @@ __device__ __forceinline__ void prog_wm_box(Ctx& x, int thing) {  // :214-226
   const int a = x.action;
   if ((unsigned)a > 3u) return;
   const int dr = a == 0 ? -1 : a == 1 ? 1 : 0, dc = a == 2 ? -1 : a == 3 ? 1 : 0;
-  if (layer_at(x, x.k.ip, r - dr, c - dc)) mw_move(x, thing, dr, dc);
+  if (layer_at(x, x.k.ip, r - dr, c - dc)) request_move(x, dr, dc);
 }
 __device__ __forceinline__ void prog_wm_judge(Ctx& x, int thing) {  // :245-266
   const int d = tfield(x, thing, T_IDX);
@@ -521,7 +597,7 @@ __device__ __forceinline__ void prog_wm_judge(Ctx& x, int thing) {  // :245-266
 }
 __device__ __forceinline__ void prog_wm_player(Ctx& x, int thing) {  // :285-295
   const int a = x.action;
-  if ((unsigned)a <= 3u) mw_move(x, thing, a == 0 ? -1 : a == 1 ? 1 : 0, a == 2 ? -1 : a == 3 ? 1 : 0);
+  if ((unsigned)a <= 3u) request_move(x, a == 0 ? -1 : a == 1 ? 1 : 0, a == 2 ? -1 : a == 3 ? 1 : 0);
 }
 
 // ---- examples/hello_world.py ---------------------------------------------------
@@ -574,14 +650,16 @@ __device__ __forceinline__ int em_erode(Ctx& x, int d, int bolt_mask, int& hitte
     if (cell < 0) continue;
     const int r = cell / x.k.C, c = cell - r * x.k.C;
     if (!bit_at(x, x.l.cur, d, r, c)) continue;
-    if (!thing_layer(x, x.l.s2t[s], r, c)) continue;
+    // layers[bolt][r, c]: the bolt is at this cell of the last repaint; with occlusion it must
+    // also be the thing in front there
+    const uint32_t m = present_at(x, r, c);
+    const int top = top_thing(x, m);  // (m holds the bolt itself: never empty)
+    if (x.k.occl && top != (int)x.l.s2t[s]) continue;
     row_put(x, x.l.cur, d, r, row_get(x, x.l.cur, d, r) & ~(1ull << c));
     ++hits;
     // board[hits]: the character drawn on top of the hit cell (with occlusion
     // that is this bolt; without, a bolt in front of it may be the one named)
-    const int top = top_char(x, r, c);
-    for (int j = 0; j < x.k.NS; ++j)
-      if ((int)tfield(x, x.l.s2t[j], T_CH) == top) hitters |= 1 << j;
+    if (tfield_v(x, top, T_KIND) == 0) hitters |= 1 << tfield_v(x, top, T_IDX);
   }
   return hits;
 }
@@ -613,7 +691,7 @@ __device__ __forceinline__ void prog_em_marauder(Ctx& x, int thing, int& dxv) { 
   for (int r = 0; r < R; ++r) row_put(x, x.l.cur, d, r, rot_cols(row_get(x, x.l.cur, d, r), dxv, C));
 }
 __device__ __forceinline__ void prog_em_player(Ctx& x, int thing) {  // :178-186
-  if (x.action == 0 || x.action == 1) mw_move(x, thing, 0, x.action == 0 ? -1 : 1);
+  if (x.action == 0 || x.action == 1) request_move(x, 0, x.action == 0 ? -1 : 1);
   else if (x.action == 4) terminate(x);
 }
 __device__ __forceinline__ void prog_em_upbolt(Ctx& x, int thing) {  // :198-220
@@ -622,7 +700,7 @@ __device__ __forceinline__ void prog_em_upbolt(Ctx& x, int thing) {  // :198-220
   sprite_get(x, s, vr, vc, vis, prior);
   if (vis) {
     if (((x.v[0] | x.v[1]) >> s) & 1) { teleport(x, s, -1, -1); return; }
-    mw_move(x, thing, -1, 0);
+    request_move(x, -1, 0);
   } else if (x.action == 2) {
     if (x.v[2] == x.frame) return;
     x.v[2] = x.frame;
@@ -642,7 +720,7 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
     sprite_true(x, s, r, c);
     sprite_true(x, tfield(x, x.k.ip, T_IDX), pr, pc);
     if (r == pr && c == pc) terminate(x);
-    mw_move(x, thing, 1, 0);
+    request_move(x, 1, 0);
   } else {
     if (x.v[3] == x.frame) return;
     x.v[3] = x.frame;
@@ -773,7 +851,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
   L l;
   l.things = lds + k.l_things; l.z = lds + k.l_z; l.sched = lds + k.l_sched;
   l.backdrop4 = lds + k.l_backdrop; l.bdmask = lds + k.l_bdmask; l.aux = lds + k.l_aux;
-  l.init = lds + k.l_init; l.initd = lds + k.l_initd; l.laybc = lds + k.l_laybc; l.s2t = lds + k.l_s2t;
+  l.init = lds + k.l_init; l.initd = lds + k.l_initd; l.laybc = lds + k.l_laybc; l.s2t = lds + k.l_s2t; l.d2t = lds + k.l_d2t;
   l.pos = lds + k.l_pos; l.flg = lds + k.l_flg; l.snap = reinterpret_cast<int32_t*>(lds + k.l_snap);
   l.cur = lds + k.l_cur; l.snapd = lds + k.l_snapd; l.flat = lds + k.l_flat;
   l.sdesc = reinterpret_cast<uint2*>(lds + k.l_sdesc); l.skip = lds + k.l_skip;
@@ -805,7 +883,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
   }
   const int ndw = k.ND * k.R * k.RW;
   if (!skip) {
-    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0};
+    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
     // bits 8..15 of the flags word: MarauderDrape._dx + 1; W_RNG: RNG draws so far (survive resets)
     uint32_t draws = st[W_RNG * bp];
     int dxv;
@@ -873,8 +951,8 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     const int64_t genv = ((int64_t)k.envoff_lo | ((int64_t)k.envoff_hi << 32)) + env;
     int i = 0;
     for (int g = 0; g < k.n_groups; ++g) {
-      for (; i < k.NT && (int)(l.sched[i] >> 8) == g; ++i) {
-        const int thing = l.sched[i] & 0xFF;
+      for (; i < k.NT && __builtin_amdgcn_readfirstlane((int)(l.sched[i] >> 8)) == g; ++i) {
+        const int thing = __builtin_amdgcn_readfirstlane((int)(l.sched[i] & 0xFF));
         const unsigned long long tp0 = timing ? __builtin_readcyclecounter() : 0ull;
         const int sgroup = k.n_sgroups > 1 ? (int)tfield(x, thing, T_GROUP) : 0;
         if (k.n_sgroups > 1) {  // this entity's scrolling group comes into view
@@ -903,6 +981,11 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
           case PCX_PROG_WALKER: prog_walker(x, thing); break;
           case PCX_PROG_SCROLLY: prog_scrolly(x, thing); break;
           default: break;  // PCX_PROG_STATIC
+        }
+        if (x.mv_post) {  // the program's MazeWalker._move (sprites.py:356-389), the kernel's one copy
+          mw_move(x, thing, x.mv_dr, x.mv_dc);
+          after_move(x, thing);
+          x.mv_post = 0;
         }
         if (k.n_sgroups > 1) {
           const uint32_t ov = (uint32_t)(x.order_valid & 1) | ((uint32_t)(x.o0 + 1) & 3u) << 1 | ((uint32_t)(x.o1 + 1) & 3u) << 3;
@@ -1003,20 +1086,22 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     if (timing) c_sec[5] = __builtin_readcyclecounter() - t_occ;  // + curtains over curtains
     // every sprite's cell once (sdesc doubles as the scratch: x = cell, y = shown)
     for (int s = 0; s < k.NS; ++s) l.sdesc[s * WAVE + lane] = make_uint2((uint32_t)sprite_cell(x, s), 0u);
-    for (int t = 0; t < k.NT; ++t) {  // back to front
-      if (tfield(x, t, T_KIND) != 0) continue;
-      const int s = tfield(x, t, T_IDX);
+    // In any order (a shown sprite only takes its cell from curtains that are behind it or do not
+    // hold it): who else is at the sprite's cell, as masks over sprite and drape indices -- four
+    // independent LDS reads at a time -- against the masks of what is in front of it.
+    for (int s = 0; s < k.NS; ++s) {
+      const int t = (int)l.s2t[s];
       const int cell = (int)l.sdesc[s * WAVE + lane].x;
-      bool shown = cell >= 0;
-      if (shown) {
-        const int wi = cell >> 5, sh = cell & 31;
-        for (uint32_t m = above_sprites(x, t); m; m &= m - 1)
-          if ((int)l.sdesc[(__ffs((int)m) - 1) * WAVE + lane].x == cell) shown = false;
-        for (uint32_t m = above_drapes(x, t); m; m &= m - 1)
-          if ((l.flat[GFLAT(__ffs((int)m) - 1, wi, lane)] >> sh) & 1) shown = false;
-        if (shown)
-          for (int d = 0; d < k.ND; ++d) l.flat[GFLAT(d, wi, lane)] &= ~(1u << sh);
-      }
+      const uint32_t ab_s = above_sprites(x, t), ab_d = above_drapes(x, t);
+      const bool vis = cell >= 0;
+      const int cc = vis ? cell : 0, wi = cc >> 5, sh = cc & 31;
+      uint32_t here_s = 0, here_d = 0;
+#pragma unroll 2
+      for (int j = 0; j < k.NS; ++j) here_s |= (int)l.sdesc[j * WAVE + lane].x == cell ? 1u << j : 0u;
+      for (int d = 0; d < k.ND; ++d) here_d |= ((l.flat[GFLAT(d, wi, lane)] >> sh) & 1u) ? 1u << d : 0u;
+      const bool shown = vis && !(here_s & ab_s) && !(here_d & ab_d);
+      if (shown && here_d)
+        for (int d = 0; d < k.ND; ++d) l.flat[GFLAT(d, wi, lane)] &= ~(1u << sh);
       l.sdesc[s * WAVE + lane].y = shown ? 1u : 0u;
     }
     for (int s = 0; s < k.NS; ++s) {
@@ -1071,6 +1156,10 @@ class GenericBackend : public Backend {
   int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)(k_.ND ? k_.ND : 1) * k_.FW * bpad_); }
   int curtain_words() const override { return k_.FW; }
   int64_t batch_pad() const override { return bpad_; }
+  void persistent_arrays(std::vector<std::pair<void*, size_t>>& out) override {  // pcx_engine_export_state
+    out.push_back({state_.ptr, state_.count * sizeof(uint32_t)});
+    out.push_back({track_.ptr, track_.count * sizeof(int32_t)});
+  }
   int plane_pitch() const override { return k_.pitch; }
 
  private:
@@ -1220,8 +1309,19 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   std::vector<uint32_t> bd4(k.QW, 0);
   memcpy(bd4.data(), t.backdrop, k.cells);
   k.n_bchars = 0;
-  std::vector<uint32_t> bdmask, laybc, s2t(k.NS ? k.NS : 1, 0);
-  for (int z = 0; z < k.NT; ++z) if (things[(size_t)z * T_WORDS + T_KIND] == 0) s2t[things[(size_t)z * T_WORDS + T_IDX]] = z;
+  std::vector<uint32_t> bdmask, laybc, s2t(k.NS ? k.NS : 1, 0), d2t(k.ND ? k.ND : 1, 0);
+  for (int z = 0; z < k.NT; ++z)
+    (things[(size_t)z * T_WORDS + T_KIND] == 0 ? s2t : d2t)[things[(size_t)z * T_WORDS + T_IDX]] = z;
+  for (int z = 0; z < k.NT; ++z) {  // walkers: which things' characters are impassable to them (sprites.py:496-511)
+    if (things[(size_t)z * T_WORDS + T_KIND] != 0) continue;
+    const pcx_sprite_desc& sd = t.sprites[things[(size_t)z * T_WORDS + T_IDX]];
+    uint32_t impt = 0;
+    for (int u = 0; u < k.NT; ++u) {
+      const int ch = t.z_order[u];
+      if (ch < 128 && ((sd.impassable[ch >> 3] >> (ch & 7)) & 1)) impt |= 1u << u;
+    }
+    things[(size_t)z * T_WORDS + T_IMPT] = impt;
+  }
   for (int z = 0; z < k.NT; ++z)
     for (int u = z + 1; u < k.NT; ++u) {
       const uint32_t* f = &things[(size_t)u * T_WORDS];
@@ -1312,7 +1412,7 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.l_things = place(things); k.l_z = place(zt); k.l_sched = place(sched); k.l_backdrop = place(bd4);
   k.l_bdmask = place(bdmask); k.l_aux = place(aux); k.l_init = place(init); k.l_initd = place(initd);
   if (laybc.empty()) laybc.push_back(0);
-  k.l_laybc = place(laybc); k.l_s2t = place(s2t);
+  k.l_laybc = place(laybc); k.l_s2t = place(s2t); k.l_d2t = place(d2t);
   k.l_dir = place(dirs);
   {
     const int pat0 = place(patterns);

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pcx.h"
@@ -43,6 +44,40 @@ struct StepArgs {
   int export_curtains = 0;  // write every drape's raw curtain bits to curtain_bits() (drape-tracking croppers)
   int debug = 0;  // ablation bits for profiling (PCX_DEBUG env): 1 skip entity updates, 2 skip phase B, 4 skip render descriptors
 };
+
+// Plane stores of the render loops: `global_store_dword voffset, data, sbase` -- a wave-uniform
+// 64-bit base in an SGPR pair plus one 32-bit lane offset shared by every plane -- written as
+// inline asm because the compiler does not pick this form by itself.  The price: the statement is
+// opaque to the compiler's hazard recogniser.  The ISA wants 5 wait states between a VALU write
+// of an SGPR (v_readlane_b32 / v_readfirstlane_b32: how the register allocator fetches an SGPR
+// it had parked in a VGPR lane) and a VMEM instruction that reads that SGPR as its base; the
+// compiler pads its own VMEM instructions, not these.  Two defences:
+//  * GUARD: the statement copies the base with s_mov_b64 first -- an SALU read of a VALU-written
+//    SGPR is interlocked, and an SALU write needs no wait before a VMEM read -- for the instances
+//    that are not store-issue-bound;
+//  * the build scans every kernel's assembly for the pattern (tools/sgpr_hazard_scan.py, run by
+//    csrc/Makefile) and fails if an unguarded store sits within 5 wait states of such a write.
+typedef float pcx_f32x4 __attribute__((ext_vector_type(4)));
+template <bool GUARD>
+__device__ __forceinline__ void saddr_store_dword(uint32_t voff, uint32_t v, uint8_t* base) {
+  if constexpr (GUARD) {
+    uint64_t own;
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0" : "=&s"(own) : "v"(voff), "v"(v), "s"(base));
+  } else {
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(base));
+  }
+}
+// (s_nop 1: a VMEM store of more than 64 bits must not be followed at once by a VALU write of its
+// data registers -- again a wait state the compiler cannot insert into inline asm)
+template <bool GUARD>
+__device__ __forceinline__ void saddr_store_dwordx4(uint32_t voff, pcx_f32x4 v, uint8_t* base) {
+  if constexpr (GUARD) {
+    uint64_t own;
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, %0\n\ts_nop 1" : "=&s"(own) : "v"(voff), "v"(v), "s"(base));
+  } else {
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base));
+  }
+}
 
 // Device-resident copy of a byte array.
 template <typename T>
@@ -106,6 +141,9 @@ class Backend {
   virtual int ensure_curtains() { return 0; }
   virtual int curtain_words() const { return 0; }
   virtual int64_t batch_pad() const = 0;
+  // include/pcx.h pcx_engine_export_state: every device array of the backend that carries an
+  // episode from one launch to the next (state words incl. RNG counters, the croppers' sprite track)
+  virtual void persistent_arrays(std::vector<std::pair<void*, size_t>>& out) = 0;
   // bytes between consecutive planes of one environment (>= rows*cols, multiple of 4)
   virtual int plane_pitch() const = 0;
   // include/pcx.h pcx_engine_set_epilogue: null clears.  Backends whose render

@@ -478,6 +478,10 @@ class MaraudersBackend : public Backend {
   int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)ND * FW * bpad_); }
   int curtain_words() const override { return FW; }
   int64_t batch_pad() const override { return bpad_; }
+  void persistent_arrays(std::vector<std::pair<void*, size_t>>& out) override {  // pcx_engine_export_state
+    out.push_back({state_.ptr, state_.count * sizeof(uint32_t)});
+    out.push_back({track_.ptr, track_.count * sizeof(int32_t)});
+  }
   int plane_pitch() const override { return pitch; }
   int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
   int set_epilogue(const pcx_epilogue_desc* d) override {

@@ -21,10 +21,12 @@
 //     SWAR compares, and stores 1+L dwords; a wave store covers 256
 //     contiguous bytes of one plane.  Nothing is read back from HBM.
 //
-// Shared, immutable template data (wall pattern as bit-rows, backdrop, the
-// coin list) is staged into LDS once per workgroup from L2.  Per-environment
-// coins are a bitmask over the template's coin list (coins only disappear),
-// 12 bytes for level 0 instead of a 4005-cell pattern.
+// Shared, immutable template data (wall pattern and coin pattern as bit-rows,
+// backdrop) is staged into LDS once per workgroup from L2.  Per-environment
+// coins are a bitmask over the template's coins in row-major order (coins only
+// disappear), 12 bytes for level 0 instead of a 4005-cell pattern; the id of the
+// coin at a pattern cell is a popcount over the coin pattern's bit-rows, so a
+// board probe is a handful of independent LDS reads -- no list to walk.
 
 #include "pcx_internal.h"
 #include "pcx_stream.h"  // EpilogueArgs: the feature-array epilogue shared with the other hand-written kernels
@@ -98,8 +100,8 @@ struct Consts {
 struct Ptrs {
   const uint32_t* walls_bits;   // [PR][WPR]
   const uint32_t* backdrop4;    // [QW] backdrop as dwords, then [n_bchars][QW] (backdrop == bchar) 0/1 bytes
-  const uint16_t* coin_rowstart;  // [PR+1]
-  const uint8_t* coin_col;        // [n_coins]
+  const uint32_t* coin_bits;      // [PR][CWPR] the CashDrape's whole pattern as bit-rows (no spare word)
+  const uint16_t* coin_rowbase;   // [PR+1] coins in the rows before row r (row-major coin ids)
   uint32_t* state;                // [NW][bpad]
   int32_t* track;                 // [NS][bpad] packed true row | col<<8 | visible<<16
   uint32_t* curtains;             // [2][FW][bpad] raw curtain bits, template drape order (export_curtains)
@@ -144,8 +146,8 @@ __device__ __forceinline__ int paint_cell(const Consts& k, const Walker& w) {
 struct Lds {
   const uint32_t* walls;
   const uint32_t* backdrop4;
-  const uint16_t* rowstart;
-  const uint8_t* coincol;
+  const uint32_t* coinbits;   // [PR][CWPR]
+  const uint16_t* rowbase;    // [PR+1]
   uint32_t* flat;   // [2][FW][64] curtains as flat cell-bit vectors
   uint2* sdesc;     // [NS][64] sprite paint descriptors {dword index q, byte mask}
   uint32_t* cmask;  // [CW][64]
@@ -157,13 +159,27 @@ __device__ __forceinline__ int wall_at(const Consts& k, const Lds& l, int pr, in
   if ((unsigned)pr >= (unsigned)k.PR || (unsigned)pc >= (unsigned)k.PC) { err |= ERR_INDEX; return 0; }
   return (l.walls[pr * k.WPR + (pc >> 5)] >> (pc & 31)) & 1;
 }
-// id of the template coin at pattern cell (pr, pc), or -1
+// Coins are numbered in row-major order of the pattern.  Number of template
+// coins in row pr before column pc (pr in range, 0 <= pc <= PC): every read is
+// independent of the others (one LDS round trip).
+__device__ __forceinline__ int coins_before(const Consts& k, const Lds& l, int pr, int pc) {
+  const int CWPR = k.WPR - 1, wi = pc >> 5;
+  const uint32_t* row = l.coinbits + pr * CWPR;
+  int n = l.rowbase[pr];
+  for (int j = 0; j < CWPR; ++j) {  // uniform trip count, predicated by j <= wi
+    const uint32_t w = row[j];
+    n += j < wi ? __popc(w) : j == wi ? __popc(w & ((1u << (pc & 31)) - 1u)) : 0;
+  }
+  return n;
+}
+// id of the template coin at pattern cell (pr, pc), or -1.  Branch-free: cells
+// outside the pattern read row 0 and answer -1.
 __device__ __forceinline__ int coin_id_at(const Consts& k, const Lds& l, int pr, int pc) {
-  if ((unsigned)pr >= (unsigned)k.PR) return -1;
-  int k0 = l.rowstart[pr], k1 = l.rowstart[pr + 1];
-  for (int i = k0; i < k1; ++i)
-    if (l.coincol[i] == pc) return i;
-  return -1;
+  const bool in = (unsigned)pr < (unsigned)k.PR && (unsigned)pc < (unsigned)k.PC;
+  const int prc = in ? pr : 0, pcc = in ? pc : 0;
+  const uint32_t w = l.coinbits[prc * (k.WPR - 1) + (pcc >> 5)];
+  const int id = coins_before(k, l, prc, pcc);
+  return (in && ((w >> (pcc & 31)) & 1u)) ? id : -1;
 }
 __device__ __forceinline__ bool coin_alive(const Lds& l, int lane, int id) {
   return (l.cmask[(id >> 5) * WAVE + lane] >> (id & 31)) & 1;
@@ -182,28 +198,43 @@ struct Snap {
 template <int NS>
 __device__ __forceinline__ bool blocked_at(const Consts& k, const Lds& l, const Snap<NS>& sn, int s,
                                            const Walker& w, int dr, int dc, int lane, uint32_t& err) {
-  int r = w.vr + dr, c = w.vc + dc;
-  if (!on_board(k, r, c)) return k.confined[s] != 0;  // EDGE
+  // Straight-line code: the only branches are on kernel arguments (uniform), so
+  // the probes of one _move -- up to three for the motion, eight for the scroll
+  // permits -- have all their LDS reads in flight together.  A cell off the
+  // board is probed at (0, 0) and the verdict replaced by EDGE's.
+  const int r0 = w.vr + dr, c0 = w.vc + dc;
+  const bool onb = on_board(k, r0, c0);
+  const int r = onb ? r0 : 0, c = onb ? c0 : 0;
   const uint32_t rel = k.relevant[s];
   uint32_t present = 0;
   const int cell = r * k.C + c;
 #pragma unroll
   for (int j = 0; j < NS; ++j)
     if ((rel >> k.zpos_sprite[j]) & 1) present |= (uint32_t)(sn.cell[j] == cell) << k.zpos_sprite[j];
-  if ((rel >> k.zpos_maze) & 1) present |= (uint32_t)wall_at(k, l, sn.maze_r + r, sn.maze_c + c, err) << k.zpos_maze;
+  if ((rel >> k.zpos_maze) & 1) {
+    const int pr = sn.maze_r + r, pc = sn.maze_c + c;
+    const bool in = (unsigned)pr < (unsigned)k.PR && (unsigned)pc < (unsigned)k.PC;
+    const uint32_t wbits = l.walls[in ? pr * k.WPR + (pc >> 5) : 0];
+    if (onb && !in) err |= ERR_INDEX;
+    present |= (uint32_t)(in && ((wbits >> (pc & 31)) & 1u)) << k.zpos_maze;
+  }
   if ((rel >> k.zpos_cash) & 1) {
     const int id = coin_id_at(k, l, sn.cash_r + r, sn.cash_c + c);
-    const bool there = id >= 0 && (coin_alive(l, lane, id) || (uint32_t)id == sn.stale);
+    const bool there = id >= 0 && (coin_alive(l, lane, id < 0 ? 0 : id) || (uint32_t)id == sn.stale);
     present |= (uint32_t)there << k.zpos_cash;
   }
-  if (present) return (k.imp_z[s] >> (31 - __clz((int)present))) & 1;  // the thing in front decides
-  if (!k.relevant_backdrop[s]) return false;
-  const int top = (l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
-  // static word selects: a runtime index into the kernarg struct would force
-  // the compiler to spill the whole struct to scratch
-  const uint32_t hi = (uint32_t)top >> 5;
-  const uint32_t word = hi == 0 ? k.imp[s][0] : hi == 1 ? k.imp[s][1] : hi == 2 ? k.imp[s][2] : k.imp[s][3];
-  return (word >> (top & 31)) & 1;
+  bool blocked = (k.imp_z[s] >> (present ? 31 - __clz((int)present) : 0)) & 1;  // the thing in front decides
+  if (k.relevant_backdrop[s]) {
+    const int top = (l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
+    // the 128-bit impassable set as two 64-bit halves and one select: anything that looks like a
+    // runtime index into the kernarg struct makes the compiler copy the table to scratch
+    const uint64_t lo64 = (uint64_t)k.imp[s][0] | ((uint64_t)k.imp[s][1] << 32), hi64 = (uint64_t)k.imp[s][2] | ((uint64_t)k.imp[s][3] << 32);
+    const uint64_t half = top < 64 ? lo64 : hi64;
+    blocked = present ? blocked : (top < 128 && ((half >> (top & 63)) & 1ull) != 0);
+  } else {
+    blocked = present ? blocked : false;
+  }
+  return onb ? blocked : k.confined[s] != 0;  // EDGE
 }
 
 // sprites.py:479-546 _check_motion
@@ -219,10 +250,11 @@ __device__ __forceinline__ bool check_motion(const Consts& k, const Lds& l, cons
 }
 
 // sprites.py:356-389 _move (with :413-477 scrolling hooks)
-template <int NS>
+// EGO: whether the walker is the egocentric one, when the instance knows (1 / 0), else -1 (ask Consts)
+template <int NS, int EGO = -1>
 __device__ __forceinline__ bool mw_move(const Consts& k, const Lds& l, const Snap<NS>& sn, int s, Walker& w,
                                         Plot& p, int dr, int dc, int lane, uint32_t& err) {
-  bool ego = k.egocentric[s] != 0;
+  const bool ego = EGO >= 0 ? EGO != 0 : k.egocentric[s] != 0;
   if (ego) p.flags |= F_REGISTERED;  // scrolling.py:287-312
   if (p.order_valid) {               // sprites.py:446-454
     teleport(k, w, w.vr - p.o0, w.vc - p.o1);
@@ -338,9 +370,18 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
   if constexpr (FIXED >= 0) {
     return w[FIXED];
   } else {
+    // field-by-field value selects (a conditional struct copy can end up as a select between
+    // two addresses of w[], which would pin the whole array in scratch)
     Walker r = w[0];
 #pragma unroll
-    for (int j = 1; j < NS; ++j) if (j == dyn) r = w[j];
+    for (int j = 1; j < NS; ++j) {
+      const bool hit = j == dyn;
+      r.vr = hit ? w[j].vr : r.vr;
+      r.vc = hit ? w[j].vc : r.vc;
+      r.vis = hit ? w[j].vis : r.vis;
+      r.prior = hit ? w[j].prior : r.prior;
+      r.var = hit ? w[j].var : r.var;
+    }
     return r;
   }
 }
@@ -386,8 +427,8 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   uint32_t* lc = lds_raw + k.lds_coincol;
   l.walls = lw;
   l.backdrop4 = lb;
-  l.rowstart = reinterpret_cast<const uint16_t*>(lr);
-  l.coincol = reinterpret_cast<const uint8_t*>(lc);
+  l.coinbits = lr;
+  l.rowbase = reinterpret_cast<const uint16_t*>(lc);
   l.cmask = lds_raw + (CODES ? k.lds_cmask_c : k.lds_cmask);
   uint32_t* lm = lds_raw + k.lds_bdmask;
   l.bdmask = lm;
@@ -398,10 +439,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   if constexpr (!CODES)  // (the CODES instance has no use for the backdrop-character masks)
     for (int i = threadIdx.x; i < k.n_bchars * QW; i += blockDim.x) lm[i] = P.backdrop4[QW + i];
   {
-    const uint32_t* rs = reinterpret_cast<const uint32_t*>(P.coin_rowstart);
-    const uint32_t* cc = reinterpret_cast<const uint32_t*>(P.coin_col);
-    for (int i = threadIdx.x; i < (k.PR + 2) / 2; i += blockDim.x) lr[i] = rs[i];
-    for (int i = threadIdx.x; i < (k.n_coins + 3) / 4; i += blockDim.x) lc[i] = cc[i];
+    const uint32_t* rb = reinterpret_cast<const uint32_t*>(P.coin_rowbase);
+    for (int i = threadIdx.x; i < k.PR * (k.WPR - 1); i += blockDim.x) lr[i] = P.coin_bits[i];
+    for (int i = threadIdx.x; i < (k.PR + 2) / 2; i += blockDim.x) lc[i] = rb[i];
   }
   constexpr int CODE_PITCH = SR ? ((SR * SC / 4) | 1) + 2 : 1;  // dwords per environment, odd: logic (same q, 64
                                                                // environments) and render (same environment,
@@ -538,9 +578,12 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     // group 1: sprites in insertion order, all reading repaint #1
     // One copy of the body per sprite index (a macro, not a loop or a lambda:
     // the compiler must see compile-time indices into w[] to keep it in VGPRs).
+    // (instances that know which sprite is the player and which the egocentric one compile only
+    // the one body each sprite runs, and the scroll-permit probes for the egocentric sprite alone)
 #define PCX_SM_SPRITE(s)                                                                         \
   if constexpr ((s) < NS) {                                                                      \
-    if (k.prog[s] == PCX_PROG_SM_PATROLLER) { /* scrolly_maze.py:284-305 */                      \
+    constexpr int ego_s = IE >= 0 ? (int)((s) == IE) : -1;                                       \
+    if (IP >= 0 ? (s) != IP : k.prog[s] == PCX_PROG_SM_PATROLLER) { /* scrolly_maze.py:284-305 */ \
       const bool walks = !(p.frame & 1); /* odd frames: _stay */                                 \
       int mdc = 0;                                                                               \
       if (walks) {                                                                               \
@@ -552,13 +595,13 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
         if (wall_at(k, l, pr, pc, err)) w[s].var ^= 1;                                           \
         mdc = w[s].var ? 1 : -1;                                                                 \
       }                                                                                          \
-      mw_move<NS>(k, l, sn, s, w[s], p, 0, mdc, lane, err); /* one call site for both */         \
+      mw_move<NS, ego_s>(k, l, sn, s, w[s], p, 0, mdc, lane, err); /* one call site for both */  \
       if (walks) {                                                                               \
         const Walker pl = pick<NS, IP>(w, k.ip);                                                 \
         if (w[s].vr == pl.vr && w[s].vc == pl.vc) { p.game_over = 1; p.discount = 0.0f; }        \
       }                                                                                          \
     } else { /* PlayerSprite.update (scrolly_maze.py:259-271) */                                 \
-      if (moves) mw_move<NS>(k, l, sn, s, w[s], p, dr, dc, lane, err);                           \
+      if (moves) mw_move<NS, ego_s>(k, l, sn, s, w[s], p, dr, dc, lane, err);                    \
     }                                                                                            \
   }
     PCX_SM_SPRITE(0) PCX_SM_SPRITE(1) PCX_SM_SPRITE(2) PCX_SM_SPRITE(3) PCX_SM_SPRITE(4) PCX_SM_SPRITE(5)
@@ -623,15 +666,38 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
         } else {
           err |= ERR_INDEX;
         }
-        // coins curtain row
+        // coins curtain row: the pattern's coin bits in the window, each kept iff
+        // its coin is alive (or is the stale one).  The window's coins have
+        // consecutive ids, so their alive bits are one bit range of the mask.
         int cr = cash.r + r;
         uint32_t cbits = 0;
         if ((unsigned)cr < (unsigned)k.PR) {
-          int k0 = l.rowstart[cr], k1 = l.rowstart[cr + 1];
-          for (int i = k0; i < k1; ++i) {
-            int col = (int)l.coincol[i] - cash.c;
-            if ((unsigned)col < (unsigned)C && (coin_alive(l, lane, i) || (uint32_t)i == stale)) cbits |= 1u << col;
+          const int CWPR = k.WPR - 1;
+          uint32_t sbits;
+          int id0;
+          if (cash.c >= 0 && cash.c + C <= k.PC) {
+            const uint32_t* row = l.coinbits + cr * CWPR;
+            const int wi = cash.c >> 5, sh = cash.c & 31;
+            const uint64_t pair = (uint64_t)row[wi] | ((uint64_t)row[wi + 1 < CWPR ? wi + 1 : wi] << 32);
+            sbits = (uint32_t)(pair >> sh) & cmaskC;
+            id0 = coins_before(k, l, cr, cash.c);
+          } else {  // a window that leaves the pattern sideways (never, while the drape obeys its limits): cell by cell
+            sbits = 0;
+            id0 = -1;
+            for (int col = 0; col < C; ++col) {
+              const int id = coin_id_at(k, l, cr, cash.c + col);
+              if (id >= 0) { sbits |= 1u << col; if (id0 < 0) id0 = id; }
+            }
+            if (id0 < 0) id0 = 0;
           }
+          const int w0 = id0 >> 5;
+          const uint32_t lo = l.cmask[w0 * WAVE + lane];
+          const uint32_t hi = l.cmask[(w0 + 1 < k.CW ? w0 + 1 : w0) * WAVE + lane];
+          uint32_t alive = (uint32_t)((((uint64_t)hi << 32) | lo) >> (id0 & 31));
+          const uint32_t st_rel = stale - (uint32_t)id0;  // the coin picked up last frame is still drawn
+          alive |= st_rel < 32u ? 1u << st_rel : 0u;
+          for (uint32_t sb = sbits; sb; sb &= sb - 1u, alive >>= 1)  // deposit alive bit j at the j-th coin of the row window
+            cbits |= (alive & 1u) ? sb & (0u - sb) : 0u;
         }
         const int off = r * C, wi = off >> 5, sh = off & 31;
         if constexpr (SR != 0) {
@@ -899,6 +965,10 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   };
 
   const bool any_skip = __ballot(l.skip[lane] != 0) != 0ull;  // same in both waves of a workgroup
+  // The multi-wave instances are under SGPR pressure (the register allocator parks plane bases in
+  // VGPR lanes and fetches them with v_readlane right in front of a store) and are latency-bound,
+  // not store-issue-bound: their stores take the hazard-proof form (pcx_internal.h).
+  constexpr bool GUARD_SADDR = COOP || TFUSE;
   {
   // Direct path.  Each wave store covers 256 contiguous bytes of one plane of
   // one or two environment records; all nine planes of a 64-dword span leave
@@ -1001,7 +1071,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     compose(e_now, q_now, eF_now, [&](int plane, uint32_t v) {
       if (!EPI || plane == 0 || layers_on) {
         if constexpr (SL != 0)  // the static-shape instance keeps all nine bases in SGPRs
-          asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(pb[plane]));
+          saddr_store_dword<GUARD_SADDR>(voff_now, v, pb[plane]);
         else
           *reinterpret_cast<uint32_t*>(pb[plane] + voff_now) = v;
       }
@@ -1012,9 +1082,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
           stream::f32x4 f;
           f.x = (float)(v & 0xFFu); f.y = (float)((v >> 8) & 0xFFu); f.z = (float)((v >> 16) & 0xFFu); f.w = (float)(v >> 24);
           const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
-          // s_nop: a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data
-        // registers (ISA data hazard; the compiler cannot see into inline asm to insert the wait state itself)
-        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(fo), "v"(f), "s"(fbase));
+          saddr_store_dwordx4<GUARD_SADDR>(fo, f, fbase);
         }
       }
     });
@@ -1058,6 +1126,10 @@ class ScrollyMazeBackend : public Backend {
   int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)2 * k_.FW * bpad_); }
   int curtain_words() const override { return k_.FW; }
   int64_t batch_pad() const override { return bpad_; }
+  void persistent_arrays(std::vector<std::pair<void*, size_t>>& out) override {  // pcx_engine_export_state
+    out.push_back({state_.ptr, state_.count * sizeof(uint32_t)});
+    out.push_back({track_.ptr, track_.count * sizeof(int32_t)});
+  }
   int plane_pitch() const override { return (k_.cells + 3) & ~3; }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
@@ -1077,8 +1149,8 @@ class ScrollyMazeBackend : public Backend {
   bool fused_ok_ = false;  // shipped shape and a batch small enough for the four-wave shapes
   int64_t batch_ = 0, bpad_ = 0;
   DevArray<uint32_t> walls_, backdrop4_, state_, curtains_;
-  DevArray<uint16_t> rowstart_;
-  DevArray<uint8_t> coincol_;
+  DevArray<uint32_t> coinbits_;
+  DevArray<uint16_t> rowbase_;
   DevArray<int32_t> track_;
   std::vector<uint8_t> walls_pattern_, coin_pattern_;  // host copies for read_things
   std::vector<uint16_t> h_rowstart_;
@@ -1242,8 +1314,13 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   if (k.n_coins > 65000) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: too many coins");
   k.CW = (k.n_coins + 31) / 32;
   k.NW = W_SPOS + k.NS + k.CW;
-  std::vector<uint8_t> cc = h_coincol_;
-  cc.resize((cc.size() + 7) / 4 * 4, 0);
+  // device image: the coin pattern as bit-rows (WPR - 1 words per row: no spare word) and the
+  // number of coins before every row; h_rowstart_ / h_coincol_ stay on the host (read_things)
+  const int CWPR = k.WPR - 1;
+  std::vector<uint32_t> cbits((size_t)k.PR * CWPR, 0);
+  for (int r = 0; r < k.PR; ++r)
+    for (int c = 0; c < k.PC; ++c)
+      if (cd.pattern[(size_t)r * k.PC + c]) cbits[(size_t)r * CWPR + (c >> 5)] |= 1u << (c & 31);
   std::vector<uint16_t> rs = h_rowstart_;
   rs.resize((rs.size() + 3) / 2 * 2, 0);
   std::vector<uint32_t> bd4((size_t)k.QW * (2 + k.n_bchars));
@@ -1293,8 +1370,8 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   int off = 0;
   k.lds_walls = off; off += k.PR * k.WPR;
   k.lds_backdrop = off; off += k.QW;
-  k.lds_rowstart = off; off += (int)rs.size() / 2;
-  k.lds_coincol = off; off += (int)cc.size() / 4;
+  k.lds_rowstart = off; off += k.PR * CWPR;      // the coin pattern's bit-rows
+  k.lds_coincol = off; off += (int)rs.size() / 2;  // coins before every row
   k.FW = (k.cells + 31) / 32 + 1;
   // per-group render descriptors, double-buffered between the two waves
   const int buf0 = off;
@@ -1313,7 +1390,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   k.lds_words = off;
   if (off * 4 > 160 * 1024) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: template needs %d bytes of LDS", off * 4);
   {  // CODES instance: constants, coin masks, the backdrop's owner codes, one code table, the skip flags
-    int o = k.lds_coincol + (int)cc.size() / 4;
+    int o = k.lds_coincol + (int)rs.size() / 2;
     k.lds_bdcode = o; o += k.QW;
     k.lds_codes = o; o += WAVE * ((k.QW | 1) + 2);
     k.lds_cmask_c = o; o += (k.CW ? k.CW : 1) * WAVE;
@@ -1340,8 +1417,8 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   int rc;
   if ((rc = walls_.upload(wb))) return rc;
   if ((rc = backdrop4_.upload(bd4))) return rc;
-  if ((rc = rowstart_.upload(rs))) return rc;
-  if ((rc = coincol_.upload(cc))) return rc;
+  if ((rc = coinbits_.upload(cbits))) return rc;
+  if ((rc = rowbase_.upload(rs))) return rc;
   if ((rc = state_.alloc((size_t)k.NW * bpad_))) return rc;
   if ((rc = track_.alloc((size_t)k.NS * bpad_))) return rc;
   return 0;
@@ -1374,7 +1451,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   }
   if (const char* pad = getenv("PCX_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   if (lds > 64 * 1024) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds);
-  Ptrs P{walls_.ptr, backdrop4_.ptr, rowstart_.ptr, coincol_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_};
+  Ptrs P{walls_.ptr, backdrop4_.ptr, coinbits_.ptr, rowbase_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_};
   // Specialised instance for the shipped scrolly_maze shape (10x30 board,
   // 8 characters, 'abcP' sprites); anything else takes the generic instance.
   const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;

@@ -158,9 +158,10 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
       foff = wrap ? foff + wrap_foff : foff;
     }
     if (any_skip && skip[e_now]) continue;
-    auto put = [&](uint8_t* base, uint32_t v) {
-      asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(base));
-    };
+    // (only the single-wave shape without epilogue -- the store-issue-bound one, few enough plane
+    // bases to stay in SGPRs -- takes the bare store; see pcx_internal.h saddr_store_dword)
+    constexpr bool GUARD = NWAVES > 1 || EPI;
+    auto put = [&](uint8_t* base, uint32_t v) { saddr_store_dword<GUARD>(voff_now, v, base); };
     // a layer: its uint8 plane and, when selected, its float32 feature plane
     auto put_layer = [&](uint8_t* base, uint32_t m01, int32_t slot) {
       if (layers_on) put(base, m01);
@@ -168,9 +169,7 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
         f32x4 f;
         f.x = (float)(m01 & 0xFFu); f.y = (float)((m01 >> 8) & 0xFFu); f.z = (float)((m01 >> 16) & 0xFFu); f.w = (float)(m01 >> 24);
         const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
-        // s_nop: a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data
-        // registers (ISA data hazard; the compiler cannot see into inline asm to insert the wait state itself)
-        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(fo), "v"(f), "s"(fbase));
+        saddr_store_dwordx4<GUARD>(fo, f, fbase);
       }
     };
     // every LDS read of the iteration is issued up front
@@ -381,9 +380,7 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
       }
       if (active) {
         const uint32_t voff = e * ostride + 4u * q;
-        auto put = [&](uint8_t* base, uint32_t v) {
-          asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(base));
-        };
+        auto put = [&](uint8_t* base, uint32_t v) { saddr_store_dword<true>(voff, v, base); };  // (compute-bound loop)
         put(obase, od);
 #pragma unroll
         for (int d = 0; d < ND; ++d) put(pb_d[d], eq01(od, pm.drape_ch4[d]));

@@ -366,6 +366,28 @@ class Engine(object):
     return {k: self._b[k].numpy() for k in
             ('reward', 'reward_set', 'discount', 'done', 'frame', 'error')}
 
+  def export_state(self, with_observation=False):
+    """A checkpoint of every environment's episode as a NumPy uint8 array
+    (`pcx_engine_export_state`): state words (entity state, Plot scalars, RNG
+    draw counters) and what the last `play()` returned; `with_observation=True`
+    adds the observation planes.  Synchronises."""
+    self._b  # (raises after close())
+    n = N.c_u64(0)
+    N.check(N.lib().pcx_engine_state_size(self._native, int(bool(with_observation)), ctypes.byref(n)))
+    blob = np.empty((n.value,), np.uint8)
+    N.check(N.lib().pcx_engine_export_state(self._native, blob.ctypes.data, n.value, int(bool(with_observation))))
+    return blob
+
+  def import_state(self, blob):
+    """Restores a checkpoint made by an engine of the same template and batch
+    (this one must be in play: `its_showtime()` has run).  The steps that follow
+    are exactly the steps the exporting engine would have taken."""
+    self._b  # (raises after close())
+    blob = np.ascontiguousarray(blob, np.uint8)
+    N.check(N.lib().pcx_engine_import_state(self._native, blob.ctypes.data, blob.nbytes))
+    self._steps_launched += 1
+    dev.synchronize(self._device_id)
+
   def check_errors(self):
     """Synchronises and raises if a device program hit a condition the
     reference raises for (the bits are sticky within an episode).  `play()`
