@@ -863,7 +863,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
 
   const bool timing = (a.debug & 8) != 0 && P.stats != nullptr;
   const unsigned long long t_start = timing ? __builtin_readcyclecounter() : 0ull;
-  unsigned long long c_sec[7] = {0, 0, 0, 0, 0, 0, 0}, c_prog[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long c_sec[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c_prog[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool live = wave == 0 && env < P.batch;  // the logic phase is wave 0's
   const int64_t bp = P.bpad;
   uint32_t* st = P.state + env;
@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     if (timing) c_sec[5] = __builtin_readcyclecounter() - t_occ;  // + curtains over curtains
     // every sprite's cell once (sdesc doubles as the scratch: x = cell, y = shown)
     for (int s = 0; s < k.NS; ++s) l.sdesc[s * WAVE + lane] = make_uint2((uint32_t)sprite_cell(x, s), 0u);
+    if (timing) c_sec[7] = __builtin_readcyclecounter() - t_occ;  // + sprite cells
     // In any order (a shown sprite only takes its cell from curtains that are behind it or do not
     // hold it): who else is at the sprite's cell, as masks over sprite and drape indices -- four
     // independent LDS reads at a time -- against the masks of what is in front of it.
@@ -1104,6 +1105,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
         for (int d = 0; d < k.ND; ++d) l.flat[GFLAT(d, wi, lane)] &= ~(1u << sh);
       l.sdesc[s * WAVE + lane].y = shown ? 1u : 0u;
     }
+    if (timing) c_sec[8] = __builtin_readcyclecounter() - t_occ;  // + sprites resolved
     for (int s = 0; s < k.NS; ++s) {
       const uint2 cs = l.sdesc[s * WAVE + lane];
       const int cell = (int)cs.x;
@@ -1121,6 +1123,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     atomicAdd(P.stats + 64, c_sec[0]); atomicAdd(P.stats + 65, c_sec[1]);
     atomicAdd(P.stats + 66, c_sec[2]); atomicAdd(P.stats + 68, c_sec[3]);
     atomicAdd(P.stats + 70, c_sec[4]); atomicAdd(P.stats + 71, c_sec[5]);
+    atomicAdd(P.stats + 72, c_sec[7]); atomicAdd(P.stats + 73, c_sec[8]);
     for (int b2 = 0; b2 < 8; ++b2) atomicAdd(P.stats + b2, c_prog[b2]);
   }
   if (wave == 0) l.skip[lane] = skip;
@@ -1491,8 +1494,9 @@ int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_
     static int printed = 0;
     if (printed++ % 32 == 8) {
       const double n = (double)(h[69] ? h[69] : 1);
-      fprintf(stderr, "[pcx generic] cycles per group: load %.0f, update groups %.0f, write-back %.0f, occlusion %.0f (flat vectors %.0f, curtain pairs %.0f, sprites %.0f), logic total %.0f; by program id mod 8:",
-              h[64] / n, h[65] / n, h[66] / n, h[68] / n, h[70] / n, (h[71] - h[70]) / n, (h[68] - h[71]) / n, h[67] / n);
+      fprintf(stderr, "[pcx generic] cycles per group: load %.0f, update groups %.0f, write-back %.0f, occlusion %.0f (flat vectors %.0f, curtain pairs %.0f, sprite cells %.0f, resolve %.0f, descriptors + track %.0f), logic total %.0f; by program id mod 8:",
+              h[64] / n, h[65] / n, h[66] / n, h[68] / n, h[70] / n, (h[71] - h[70]) / n, (h[72] - h[71]) / n, (h[73] - h[72]) / n,
+              (h[68] - h[73]) / n, h[67] / n);
       for (int p = 0; p < 8; ++p) if (h[p]) fprintf(stderr, " %d:%.0f", p, h[p] / n);
       fprintf(stderr, "\n");
     }

@@ -28,7 +28,7 @@ def timed(fn, steps=100):
 
 
 for name, batch in CASES:
-  t = GameTemplate.load('tests/golden/templates/%s.npz' % name)
+  t = GameTemplate.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'templates', name + '.npz'))
   eng = Engine.from_template(t, batch=batch, auto_reset=True, seed=1)
   eng.its_showtime()
   tape = torch.randint(0, max(1, t.n_actions), (16, batch), dtype=torch.int32, device='cuda')

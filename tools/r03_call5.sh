@@ -1,9 +1,9 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r03_call5
+OUT=$ROOT/gpurun_out/r03_call6
 mkdir -p $OUT
 cd $ROOT
-timeout 1500 python -m pytest tests -m gpu -q > $OUT/suite.log 2>&1; echo "suite rc=$?"; grep -E "passed|failed|FAILED" $OUT/suite.log | tail -8
+echo skip suite
 cd /tmp && export TMPDIR=/tmp
 for pass in "a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "b SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY" "c SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VALU"; do
   set -- $pass; name=$1; shift
