@@ -111,39 +111,61 @@ __global__ void pcx_crop_copy(CropParams p, const uint8_t* in, const int32_t* co
   const bool fast = ocol + 3 < p.cols && (unsigned)sr < (unsigned)p.R && sc >= 0 && sc + 3 < p.C;
   const uint8_t* src = in + (size_t)b * planes * p.in_pitch;
   uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)b * planes * p.out_pitch) + q;
+  // Planes four at a time: every load of a batch is issued before its first store, so a lane waits
+  // for ONE memory round trip per four planes (the plain plane-after-plane loop made this kernel
+  // latency-bound: 1 + L dependent round trips per lane; profiles/r03_post_kernels.md).
+  constexpr int PB = 4;
+  const int ipq = p.in_pitch / 4;
   if (fast) {
     const uint32_t a = (uint32_t)(sr * p.C + sc), phase = a & 3u;
     const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src) + (a >> 2);
-    for (int pl = 0; pl < planes; ++pl) {
-      const uint32_t lo = s32[0], hi = phase ? s32[1] : 0u;
-      *dst = __builtin_amdgcn_alignbyte(hi, lo, phase);
-      s32 += p.in_pitch / 4;
-      dst += qw;
+    for (int pl0 = 0; pl0 < planes; pl0 += PB) {
+      uint32_t lo[PB], hi[PB];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const uint32_t* s = s32 + (size_t)(pl0 + j < planes ? pl0 + j : pl0) * ipq;
+        lo[j] = s[0];
+        hi[j] = s[phase ? 1 : 0];
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        if (pl0 + j < planes) dst[(size_t)(pl0 + j) * qw] = __builtin_amdgcn_alignbyte(hi[j], lo[j], phase);
     }
     return;
   }
-  int rr[4], cc[4];
-  bool inside[4], real[4];
+  int off[4];         // the four cells' byte offsets inside a source plane (0 where the cell is not read)
+  uint32_t take = 0;  // bit j: cell j comes from the observation; bit 4 + j: cell j is a real window cell
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int cell = cell0 + j;
-    real[j] = cell < p.rows * p.cols;  // cells past the window are plane padding (zeros)
+    const bool real = cell < p.rows * p.cols;  // cells past the window are plane padding (zeros)
     const int r = cell / p.cols;
-    rr[j] = r + top;
-    cc[j] = cell - r * p.cols + left;
-    inside[j] = (unsigned)rr[j] < (unsigned)p.R && (unsigned)cc[j] < (unsigned)p.C;
+    const int rr = r + top, cc = cell - r * p.cols + left;
+    const bool inside = real && (unsigned)rr < (unsigned)p.R && (unsigned)cc < (unsigned)p.C;
+    off[j] = inside ? rr * p.C + cc : 0;
+    take |= (uint32_t)inside << j | (uint32_t)real << (4 + j);
   }
-  for (int pl = 0; pl < planes; ++pl) {
-    const uint32_t pad = pl == 0 ? (uint32_t)p.pad_char : (uint32_t)((uint32_t)p.pad_char == p.chars[pl - 1]);
-    uint32_t v = 0;
+  for (int pl0 = 0; pl0 < planes; pl0 += PB) {
+    uint32_t byte[PB][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t byte = !real[j] ? 0u : inside[j] ? src[rr[j] * p.C + cc[j]] : pad;
-      v |= (byte & 0xFFu) << (8 * j);
+    for (int i = 0; i < PB; ++i) {
+      const uint8_t* s = src + (size_t)(pl0 + i < planes ? pl0 + i : pl0) * p.in_pitch;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) byte[i][j] = s[off[j]];
     }
-    *dst = v;
-    src += p.in_pitch;
-    dst += qw;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int pl = pl0 + i;
+      if (pl >= planes) break;
+      const uint32_t pad = pl == 0 ? (uint32_t)p.pad_char : (uint32_t)((uint32_t)p.pad_char == p.chars[pl - 1]);
+      uint32_t v = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t b8 = ((take >> j) & 1u) ? byte[i][j] : ((take >> (4 + j)) & 1u) ? pad : 0u;
+        v |= (b8 & 0xFFu) << (8 * j);
+      }
+      dst[(size_t)pl * qw] = v;
+    }
   }
 }
 

@@ -349,34 +349,72 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
         const uint64_t sd = reinterpret_cast<const uint64_t*>(sdesc)[s * WAVE + e];
         scell[s] = ((uint32_t)sd << 2) | ((uint32_t)__builtin_ctz((uint32_t)(sd >> 32)) >> 3);
       }
+      // The output dword four cells at a time, the way the board loop composes a board dword: a run of
+      // window cells that lies in one window row is a run of consecutive board cells, so its backdrop
+      // bytes are two aligned LDS dwords funnelled by the byte phase, a curtain's four bits one shifted
+      // pair of flat words, a painted sprite a byte mask by its distance from the run's first cell.  A
+      // dword that straddles window rows (cols % 4 != 0) is two or more such runs.
+      const int QWsrc = (int)(pitch >> 2);
       uint32_t od = 0;
-      int r = (int)orow, c = (int)ocol;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool real = (int)cell0 + j < wcells;  // cells past the window are plane padding: zeros
-        const int sr = top + r, sc = left + c;
-        const bool inside = real && (unsigned)sr < (unsigned)Rv && (unsigned)sc < (unsigned)Cv;
-        const uint32_t a = inside ? (uint32_t)(sr * Cv + sc) : 0u;
-        uint32_t ch = backdrop1[a];
+      int done = 0, wr = (int)orow, wc = (int)ocol;
+      while (done < 4) {
+        const int n = cols - wc < 4 - done ? cols - wc : 4 - done;  // cells of this run
+        const bool real_row = wr < rows;                              // rows past the window are plane padding: zeros
+        const int sr = top + wr, sc = left + wc;
+        const bool row_in = real_row && (unsigned)sr < (unsigned)Rv;
+        // the run's cells that lie inside the board: columns [lo, hi) of the run
+        const int lo = sc < 0 ? -sc : 0, hi = Cv - sc < n ? Cv - sc : n;
+        const bool any_in = row_in && lo < hi;
+        const uint32_t a = any_in ? (uint32_t)(sr * Cv + sc + lo) : 0u;  // first board cell read
+        const uint32_t qa = a >> 2, qb = (int)qa + 1 < QWsrc ? qa + 1 : qa, ph = a & 3u;
+        uint32_t d = __builtin_amdgcn_alignbyte(backdrop4[qb], backdrop4[qa], ph);
         if constexpr (IDS) {
-          const uint32_t id = cell_id1[a];
-          const uint32_t word = flat[eF + (id >> 5)];  // (id 0xFF reads word 7 of the mask: in range, ignored)
-          const uint32_t coin = (word >> (id & 31u)) & (uint32_t)(id != 0xFFu);  // (arithmetic: no branch around the read)
-          ch = (coin & 1u) ? pm.drape_ch4[0] & 0xFFu : ch;
+          const uint32_t ids = __builtin_amdgcn_alignbyte(cell_ids[qb], cell_ids[qa], ph);
+          if (ids != 0xFFFFFFFFu) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t id = (ids >> (8 * j)) & 0xFFu;
+              const uint32_t word = flat[eF + ((id >> 5) & 7u)];  // (id 0xFF reads word 7 of the mask: in range, ignored)
+              bits |= ((word >> (id & 31u)) & (uint32_t)(id != 0xFFu)) << j;
+            }
+            const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+            uint32_t hi8 = m01 << 8;
+            asm("" : "+v"(hi8));
+            const uint32_t m = hi8 - m01;
+            d = (d & ~m) | (pm.drape_ch4[0] & m);
+          }
         } else {
 #pragma unroll
-          for (int d = 0; d < ND; ++d) {
-            const bool bit = ((flat[d * WAVE * FWP + eF + (a >> 5)] >> (a & 31u)) & 1u) != 0u;
-            ch = bit ? pm.drape_ch4[d] & 0xFFu : ch;
+          for (int dd = 0; dd < ND; ++dd) {
+            const uint32_t w0 = a >> 5, w1 = (int)w0 + 1 < FWP ? w0 + 1 : w0;
+            const uint64_t pair = (uint64_t)flat[dd * WAVE * FWP + eF + w0] | ((uint64_t)flat[dd * WAVE * FWP + eF + w1] << 32);
+            const uint32_t bits = (uint32_t)(pair >> (a & 31u)) & 0xFu;
+            const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+            uint32_t hi8 = m01 << 8;
+            asm("" : "+v"(hi8));
+            const uint32_t m = hi8 - m01;
+            d = (d & ~m) | (pm.drape_ch4[dd] & m);
           }
         }
 #pragma unroll
-        for (int s = 0; s < NS; ++s) ch = a == scell[s] ? pm.sprite_ch4[s] & 0xFFu : ch;
-        ch = inside ? ch : real ? pad : 0u;
-        od |= ch << (8 * j);
-        const bool wrap = c + 1 >= cols;
-        c = wrap ? 0 : c + 1;
-        r = wrap ? r + 1 : r;
+        for (int s = 0; s < NS; ++s) {
+          const uint32_t delta = scell[s] - a;
+          const uint32_t m = delta < 4u ? 0xFFu << (8u * delta) : 0u;
+          d = (d & ~m) | (pm.sprite_ch4[s] & m);
+        }
+        // bytes [0, hi - lo) of d are the board cells of the run's columns [lo, hi); the rest of the
+        // run is the pad character, what is not a window cell at all stays zero
+        const int nin = any_in ? hi - lo : 0;
+        const uint32_t keep = nin >= 4 ? 0xFFFFFFFFu : (1u << (8 * nin)) - 1u;
+        uint32_t run = any_in ? (d & keep) << (8 * lo) : 0u;
+        const uint32_t in_mask = any_in ? keep << (8 * lo) : 0u;
+        const uint32_t run_mask = n >= 4 ? 0xFFFFFFFFu : (1u << (8 * n)) - 1u;
+        run |= real_row ? (pad * 0x01010101u) & run_mask & ~in_mask : 0u;
+        od |= run << (8 * done);
+        done += n;
+        wc += n;
+        if (wc >= cols) { wc = 0; ++wr; }
       }
       if (active) {
         const uint32_t voff = e * ostride + 4u * q;
