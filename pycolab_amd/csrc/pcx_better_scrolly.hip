@@ -77,7 +77,7 @@ __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16
 
 // SR x SC: the board's shape when the instance is compiled for it (the three shipped boards); 0 x 0: read
 // from k.rows / k.cols (boards the example does not ship).
-template <int SR, int SC, int NWAVES>
+template <int SR, int SC, int NWAVES, bool EPI = false>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                          const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                          const crop::FusedCrops* fc) {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
-    stream::stream_planes<NS, ND, NB, SQW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+    stream::stream_planes<NS, ND, NB, SQW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                          cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid, QW);
   if (fc)
     stream::stream_windows<NS, ND, NB, SQW, NWAVES, SR, SC, true>(fc, pm, bch4, env0, lds + O_BD, cm, sdesc, skipv, CWP, lane, wave, wcorner,
@@ -347,6 +347,14 @@ class BetterScrollyBackend : public Backend {
   }
   int plane_pitch() const override { return lay_.pitch; }
   int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
+  int set_epilogue(const pcx_epilogue_desc* d) override {  // include/pcx.h pcx_engine_set_epilogue
+    if (d && !static_shape_) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the feature-array epilogue exists for the compiled boards");
+    int sc[NS], dc = k_.drape_ch4 & 0xFF, bc[NB > 0 ? NB : 1] = {};
+    for (int s = 0; s < NS; ++s) sc[s] = k_.sprite_ch4[s] & 0xFF;
+    for (int b = 0; b < NB; ++b) bc[b] = k_.bchar_ch4[b] & 0xFF;
+    stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB);
+    return 0;
+  }
 
  private:
   stream::FusedCropsHolder fused_;
@@ -505,7 +513,13 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
       PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_better_scrolly_step<r, c, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_better_scrolly_step<r, c, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     }                                                                                                             \
-    if (coop) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    if (lds > 64 * 1024 && epi_.out) {                                                                            \
+      PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_better_scrolly_step<r, c, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_better_scrolly_step<r, c, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    }                                                                                                             \
+    if (epi_.out && coop) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 4, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else if (epi_.out) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 1, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());       \
+    else if (coop) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
     else hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());          \
     launched = true;                                                                                              \
   }

@@ -86,7 +86,7 @@ struct Bits {
   }
 };
 
-template <int R, int C, int NWAVES>
+template <int R, int C, int NWAVES, bool EPI = false>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                       const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                       const crop::FusedCrops* fc) {
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
-    stream::stream_planes<NS, ND, NB, QW, NWAVES, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+    stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                         flat, sdesc, skipv, FWP, lane, wave, epi, env0);
   if (fc)
     stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
@@ -278,6 +278,13 @@ class HelloWorldBackend : public Backend {
   }
   int plane_pitch() const override { return lay_.pitch; }
   int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
+  int set_epilogue(const pcx_epilogue_desc* d) override {  // include/pcx.h pcx_engine_set_epilogue
+    int sc[NS], dc = k_.drape_ch4 & 0xFF, bc[NB > 0 ? NB : 1] = {};
+    for (int s = 0; s < NS; ++s) sc[s] = k_.sprite_ch4[s] & 0xFF;
+    for (int b = 0; b < NB; ++b) bc[b] = k_.bchar_ch4[b] & 0xFF;
+    stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB);
+    return 0;
+  }
 
  private:
   stream::FusedCropsHolder fused_;
@@ -393,7 +400,9 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   bool launched = false;
 #define X(r, c)                                                                                                  \
   if (!launched && R_ == r && C_ == c) {                                                                         \
-    if (coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    if (epi_.out && coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else if (epi_.out) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());       \
+    else if (coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
     else hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());          \
     launched = true;                                                                                             \
   }

@@ -142,6 +142,7 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   // branches (measured: they cost it 1.5-4 %, profiles/r02_post_kernels.md)
   constexpr bool epi_on = EPI;
   const bool layers_on = !(epi_on && epi.skip_layers);
+  const uint32_t epi_rem = epi_on ? (epi.plane_bytes >> 2) & 3u : 0u;  // cells in the last dword of a plane, 0 = four
   uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(epi.out) + (size_t)env0 * epi.env_stride);
   uint32_t foff = e * epi.env_stride + 16u * q;
   const uint32_t dfoff = DE * epi.env_stride + 16u * DQ, wrap_foff = epi.env_stride - 16u * QWv;
@@ -169,7 +170,15 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
         f32x4 f;
         f.x = (float)(m01 & 0xFFu); f.y = (float)((m01 >> 8) & 0xFFu); f.z = (float)((m01 >> 16) & 0xFFu); f.w = (float)(m01 >> 24);
         const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
-        saddr_store_dwordx4<GUARD>(fo, f, fbase);
+        // a board that is not a whole number of dwords: the plane's last dword holds 1-3 cells, and the
+        // floats behind them belong to the next layer's plane
+        if (epi_rem && q_now + 1u == QWv) {
+          saddr_store_dword<GUARD>(fo, __float_as_uint(f.x), fbase);
+          if (epi_rem > 1) saddr_store_dword<GUARD>(fo + 4u, __float_as_uint(f.y), fbase);
+          if (epi_rem > 2) saddr_store_dword<GUARD>(fo + 8u, __float_as_uint(f.z), fbase);
+        } else {
+          saddr_store_dwordx4<GUARD>(fo, f, fbase);
+        }
       }
     };
     // every LDS read of the iteration is issued up front
@@ -433,7 +442,8 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
 
 // Host side: an epilogue descriptor (include/pcx.h) as EpilogueArgs for a backend
 // whose sprites / drape slots / backdrop-only characters paint the given
-// characters.  Returns false when the board is not a whole number of dwords.
+// characters.  (Boards that are not a whole number of dwords are fine: stream_planes writes the
+// last dword of a feature plane cell by cell.)
 inline bool fill_epilogue(EpilogueArgs& a, const pcx_epilogue_desc* d, int cells, const int* sprite_ch, int ns,
                           const int* drape_ch, int nd, const int* bchar_ch, int nb) {
   a = EpilogueArgs();
@@ -441,7 +451,6 @@ inline bool fill_epilogue(EpilogueArgs& a, const pcx_epilogue_desc* d, int cells
   for (int i = 0; i < PCX_MAX_DRAPES; ++i) a.drape_slot[i] = -1;
   for (int i = 0; i < PCX_MAX_CHARS; ++i) a.bchar_slot[i] = -1;
   if (!d) return true;
-  if (cells % 4 != 0) return false;
   a.out = d->out_dev;
   a.env_stride = (uint32_t)d->depth * (uint32_t)cells * 4u;
   a.plane_bytes = (uint32_t)cells * 4u;

@@ -533,10 +533,8 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, nw, ep>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr())
 #define X(ns, r, c, nb)                                                                                     \
   if (!launched && NS_ == ns && R_ == r && C_ == c && NB_ == nb) {                                          \
-    if constexpr ((r * c) % 4 == 0) {                                                                       \
-      if (epi && coop) PCX_WM_LAUNCH(ns, r, c, nb, 4, true);                                                \
-      else if (epi) PCX_WM_LAUNCH(ns, r, c, nb, 1, true);                                                   \
-    }                                                                                                       \
+    if (epi && coop) PCX_WM_LAUNCH(ns, r, c, nb, 4, true);                                                  \
+    else if (epi) PCX_WM_LAUNCH(ns, r, c, nb, 1, true);                                                     \
     if (!epi && coop) PCX_WM_LAUNCH(ns, r, c, nb, 4, false);                                                \
     else if (!epi) PCX_WM_LAUNCH(ns, r, c, nb, 1, false);                                                   \
     launched = true;                                                                                        \

@@ -223,12 +223,38 @@ def test_feature_array_fused_into_the_step_kernel(skip_layers):
       np.testing.assert_array_equal(helpers.to_np(got), helpers.to_np(plain(obs)))
   assert helpers.to_np(eng.game_over).any() or True
   # engines whose kernel has no epilogue say so and change nothing
-  hw = Engine.from_template(helpers.load_template('hello_world'), batch=8)
-  hw.its_showtime()
-  assert not rendering.ObservationToFeatureArray('#@').fuse_into(hw)
-  wm = Engine.from_template(helpers.load_template('warehouse_L0'), batch=8)   # 110 cells: not whole dwords
-  wm.its_showtime()
-  assert not rendering.ObservationToFeatureArray('#P').fuse_into(wm)
+  tb = Engine.from_template(helpers.load_template('walkers_room'), batch=8)     # the table-driven kernel
+  tb.its_showtime()
+  assert not rendering.ObservationToFeatureArray('w').fuse_into(tb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('batch', [300, 40000])
+@pytest.mark.parametrize('name,chars,n_actions', [('hello_world', '@1 #3', 4), ('hello_custom_A', '@2#', 4),
+                                                   ('warehouse_L0', '#P_1X ', 5), ('warehouse_L2', 'P23X', 5),
+                                                   ('better_scrolly_maze_L0', 'P@#a ', 5), ('better_scrolly_maze_L1', '@cP#', 5)])
+def test_feature_array_fused_on_boards_of_any_size(name, chars, n_actions, batch):
+  """The epilogue in pcx_hello_world_step, pcx_warehouse_step and pcx_better_scrolly_step, in both launch
+  shapes, including boards that are not a whole number of dwords (110, 143, 4005 and 870 cells: the last
+  dword of every float plane is written cell by cell)."""
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template(name)
+  eng = Engine.from_template(t, batch=batch, auto_reset=True, seed=2)
+  eng.its_showtime()
+  eng.step_hashed(5, 0, 10)
+  fused = rendering.ObservationToFeatureArray(chars)
+  assert fused.fuse_into(eng), name
+  guard = fused._fused[1]
+  for step in range(6):
+    obs = eng.play(torch.randint(0, n_actions, (batch,), dtype=torch.int32, device='cuda'))[0]
+    got = fused(obs)
+    assert got is guard and got.shape == (batch, len(chars), t.rows, t.cols)
+    for k, ch in enumerate(chars):
+      assert torch.equal(got[:, k], (obs.board == ord(ch)).to(torch.float32)), (name, step, ch)
+    for ch, layer in obs.layers.items():
+      assert torch.equal(layer, (obs.board == ord(ch)).to(torch.uint8)), (name, step, ch)
+  eng.close()
 
 
 @pytest.mark.gpu
