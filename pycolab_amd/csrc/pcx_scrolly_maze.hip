@@ -88,7 +88,7 @@ struct Consts {
   int32_t n_bchars, bchar[MAX_L], lay_bchar[MAX_L];  // characters only the backdrop paints
   int32_t FW;  // words of one flat curtain bit-vector (cells bits + 1 spill word)
   int32_t lds_walls, lds_backdrop, lds_rowstart, lds_coincol, lds_flat, lds_sdesc, lds_cmask,
-      lds_skip, lds_bdmask, lds_buf_words, lds_flatraw, lds_sdescraw, lds_words;
+      lds_skip, lds_bdmask, lds_buf_words, lds_flatraw, lds_sdescraw, lds_wcorner, lds_words;
   // CODES instance (at most eight characters): every cell's painter as the index
   // of its character among the sorted characters ("owner code", one byte per
   // cell), from which v_perm_b32 makes the board dword and every layer dword
@@ -400,7 +400,12 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false, bool EPI = false,
           bool CODES = false>
 __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                                  const pcx_buffers out, const stream::EpilogueArgs epi) {
+                                                                  const pcx_buffers out, const stream::EpilogueArgs epi,
+                                                                  const crop::FusedCrops* fc_arg) {
+  // Fused croppers (include/pcx.h pcx_engine_fuse_croppers): the instances that keep the frame as curtain
+  // bit vectors + sprite descriptors (pcx_stream.h's contract) and render a group in the round they step it
+  constexpr bool FUSABLE = !TFUSE && !CODES && !UNOCC && !EPI;
+  const crop::FusedCrops* const fc = FUSABLE ? fc_arg : nullptr;
   // A workgroup is two wavefronts with different jobs, looping over groups of
   // 64 environments: wave 0 (logic) steps group i+1 and leaves its render
   // descriptors in one LDS buffer while wave 1 (render) streams the
@@ -842,6 +847,19 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
                               ((int)do_reset << 24);
     }
     st[W_SFLAGS * bp] = sf;
+    if constexpr (FUSABLE) {
+      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
+        stream::move_fused_windows(fc, [&](int ti) {  // ti: the TEMPLATE's sprite index
+          int32_t t = 0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            const bool on = on_board(k, w[s].vr, w[s].vc);
+            const int32_t tw = (on ? w[s].vr : 0) | ((on ? w[s].vc : 0) << 8) | (w[s].vis << 16);
+            t = k.tmpl_index[s] == ti ? tw : t;
+          }
+          return t;
+        }, p.frame == 0, env, lane, lds_raw + k.lds_wcorner);
+    }
     if (coins_dirty)
       for (int i = 0; i < k.CW; ++i) st[(W_SPOS + NS + i) * bp] = l.cmask[i * WAVE + lane];
     out.reward[env] = p.reward;
@@ -1014,8 +1032,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   constexpr bool PREFETCH = CODES && INCR;
   uint32_t code_pf = 0;
   if constexpr (PREFETCH) code_pf = codes[eF + q];
+  const bool planes_on = !(fc && fc->only);  // fused croppers, windows only: the full-board planes are not written
 #pragma unroll 1
-  for (int it = COOP ? wave : TFUSE ? wave - 1 : 0; it < QW;
+  for (int it = !planes_on ? QW : COOP ? wave : TFUSE ? wave - 1 : 0; it < QW;
        it += COOP ? (int)(blockDim.x >> 6) : TFUSE ? (int)(blockDim.x >> 6) - 1 : 1) {
     uint32_t e_now, q_now, voff_now, eF_now, foff_now = 0;
     uint32_t code_cur = 0;
@@ -1087,6 +1106,21 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       }
     });
   }
+  if constexpr (FUSABLE) {
+    if (fc) {  // the croppers' windows, cut from the same descriptors (pcx_stream.h stream_windows)
+      stream::PlaneMap<NS, 2, NBS> pm;
+      uint32_t bch4[NBS > 0 ? NBS : 1] = {};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { pm.sprite_off[s] = (uint32_t)(1 + k.lay_sprite[s]) * (uint32_t)pitch; pm.sprite_ch4[s] = sch4[s]; }
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) { pm.drape_off[dd] = (uint32_t)(1 + k.lay_drape[dd]) * (uint32_t)pitch; pm.drape_ch4[dd] = dch4[dd]; }
+#pragma unroll
+      for (int i = 0; i < NBS; ++i) { pm.bchar_off[i] = (uint32_t)(1 + k.lay_bchar[i]) * (uint32_t)pitch; bch4[i] = (uint32_t)k.bchar[i] * 0x01010101u; }
+      stream::stream_windows<NS, 2, NBS, SR ? (SR * SC + 3) / 4 : 0, 0, SR, SC>(
+          fc, pm, bch4, env0, l.backdrop4, l.flat, l.sdesc, l.skip, FWP, lane, COOP ? wave : 0, lds_raw + k.lds_wcorner, nullptr,
+          stream::BoardShape{R, C, QW}, COOP ? (int)(blockDim.x >> 6) : 1, NB);
+    }
+  }
   }
   }  // render wave
   __syncthreads();  // swap buffers
@@ -1120,7 +1154,14 @@ class ScrollyMazeBackend : public Backend {
     return 4 + 4 * (int64_t)k_.NW + 4 * (int64_t)(k_.NW - k_.CW) + (int64_t)(1 + k_.L) * k_.cells + 15;
   }
   const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
-  int max_fused_steps() const override { return fused_ok_ && !epi_.out ? 256 : 1; }  // the epilogue has no multi-step instance
+  int max_fused_steps() const override { return fused_ok_ && !epi_.out && !fused_.on ? 256 : 1; }  // the epilogue / fused croppers have no multi-step instance
+  // include/pcx.h pcx_engine_fuse_croppers: the instances that render from curtain bit vectors + sprite
+  // descriptors cut the windows too (pcx_stream.h stream_windows); the owner-code and multi-step instances step aside
+  int set_fused_croppers(const crop::FusedCrops* fc) override {
+    if (fc && fc->n > 0 && (unoccluded_ || epi_.out))
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: fused croppers need occluded layers and no feature-array epilogue");
+    return fused_.set(fc);
+  }
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
   int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)2 * k_.FW * bpad_); }
@@ -1133,6 +1174,7 @@ class ScrollyMazeBackend : public Backend {
   int plane_pitch() const override { return (k_.cells + 3) & ~3; }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
+    if (d && fused_.on) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: release the fused croppers first");
     if (d && !shipped_shape)
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the feature-array epilogue exists for the shipped 10x30 shape");
     int sc[MAX_NS], dc[2] = {k_.maze_ch, k_.cash_ch}, bc[MAX_L];
@@ -1146,6 +1188,7 @@ class ScrollyMazeBackend : public Backend {
  private:
   Consts k_{};
   stream::EpilogueArgs epi_{};
+  stream::FusedCropsHolder fused_;
   bool fused_ok_ = false;  // shipped shape and a batch small enough for the four-wave shapes
   int64_t batch_ = 0, bpad_ = 0;
   DevArray<uint32_t> walls_, backdrop4_, state_, curtains_;
@@ -1387,6 +1430,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   k.lds_flatraw = off; if (unoccluded_) off += 2 * (k.FW | 1) * WAVE;
   off = (off + 1) & ~1;
   k.lds_sdescraw = off; if (unoccluded_) off += 2 * k.NS * WAVE;
+  k.lds_wcorner = off; off += stream::WCORNER_WORDS;  // fused croppers: the windows' corners
   k.lds_words = off;
   if (off * 4 > 160 * 1024) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: template needs %d bytes of LDS", off * 4);
   {  // CODES instance: constants, coin masks, the backdrop's owner codes, one code table, the skip flags
@@ -1440,6 +1484,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   if (const char* e = getenv("PCX_WGS_PER_CU")) wgs_per_cu = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_WG")) waves_per_wg = atoi(e) == 2 ? 2 : 1;
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
+  if (fused_.on) waves_per_wg = 1;  // fused croppers: a group is rendered in the round that steps it
   if (waves_per_wg == 2 && wgs_per_cu == 0) wgs_per_cu = 4;
   int64_t max_wgs = wgs_per_cu > 0 ? (int64_t)num_cus_ * wgs_per_cu : groups;
   dim3 grid((unsigned)(groups < max_wgs ? groups : max_wgs)), block(waves_per_wg * WAVE);
@@ -1459,6 +1504,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   // each group's render loop (COOP instance), one group per workgroup.
   bool use_codes = true;  // PCX_SM_CODES=0: the mask-composing render loop of round 1 (A/B)
   if (const char* e = getenv("PCX_SM_CODES")) use_codes = atoi(e) != 0;
+  if (fused_.on) use_codes = false;  // the windows are cut from the curtain bit vectors
   int coop_below = 5;  // groups per CU (measured crossover: profiles/r01_tuning.md)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (a.n_steps > 1) {
@@ -1466,16 +1512,16 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     if (!shipped_shape || !fused_ok_ || a.mode != 0 || epi_.out)
       return set_error(PCX_E_INVALID, "scrolly_maze backend: %d steps in one launch are not available here", a.n_steps);
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), dim3((unsigned)groups),
-                       dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_);
+                       dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_, fused_.ptr());
   } else if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
     int coop_waves = groups <= num_cus_ ? 8 : 4;  // at most one group per CU: split the render loop eight ways
     if (const char* e = getenv("PCX_COOP_WAVES")) coop_waves = atoi(e) == 4 ? 4 : 8;
     if (epi_.out)
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, true>), dim3((unsigned)groups),
-                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_);
+                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_, fused_.ptr());
     else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3((unsigned)groups),
-                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_);
+                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_, fused_.ptr());
   } else if (shipped_shape && waves_per_wg == 1 && use_codes) {
     // owner-code render path: its own, smaller LDS layout, padded to the same workgroups-per-CU target
     size_t lds_c = (size_t)k_.lds_words_codes * 4;
@@ -1484,22 +1530,22 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
       if (want > lds_c) lds_c = want;
     }
     if (epi_.out)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, true>), grid, block, lds_c, s, k_, P, a, out, epi_);
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, true>), grid, block, lds_c, s, k_, P, a, out, epi_, fused_.ptr());
     else
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true>), grid, block, lds_c, s, k_, P, a, out, epi_);
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true>), grid, block, lds_c, s, k_, P, a, out, epi_, fused_.ptr());
   } else if (shipped_shape) {
     if (epi_.out && waves_per_wg == 1)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true>), grid, block, lds, s, k_, P, a, out, epi_);
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true>), grid, block, lds, s, k_, P, a, out, epi_, fused_.ptr());
     else if (epi_.out)
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the epilogue needs the single-wave launch shape");
     else
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out, epi_);
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out, epi_, fused_.ptr());
   } else {
     switch (k_.NS) {
 #define PCX_SM_CASE(n)                                                                                          \
   case n:                                                                                                       \
-    if (unoccluded_) hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, true>), grid, block, lds, s, k_, P, a, out, epi_); \
-    else hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, false>), grid, block, lds, s, k_, P, a, out, epi_);            \
+    if (unoccluded_) hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, true>), grid, block, lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else hipLaunchKernelGGL((pcx_scrolly_maze_step<n, 0, 0, 0, -1, -1, false>), grid, block, lds, s, k_, P, a, out, epi_, fused_.ptr());            \
     break;
       PCX_SM_CASE(1) PCX_SM_CASE(2) PCX_SM_CASE(3) PCX_SM_CASE(4) PCX_SM_CASE(5) PCX_SM_CASE(6)
 #undef PCX_SM_CASE

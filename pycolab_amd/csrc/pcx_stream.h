@@ -295,8 +295,13 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
                                                const uint32_t (&bchar_ch4)[NB > 0 ? NB : 1], int64_t env0,
                                                const uint32_t* backdrop4, const uint32_t* flat, const uint2* sdesc,
                                                const uint32_t* skip, int FWP, int lane, int wave, const uint32_t* wcorner,
-                                               const uint32_t* cell_ids = nullptr, BoardShape rt = BoardShape{0, 0, 0}) {
-  constexpr int L = NS + ND + NB;
+                                               const uint32_t* cell_ids = nullptr, BoardShape rt = BoardShape{0, 0, 0},
+                                               int nwaves_rt = 0, int nb_rt = -1) {
+  // NWAVES == 0: the number of waves sharing the loop is nwaves_rt; nb_rt >= 0: only the first nb_rt of
+  // the NB backdrop-only characters exist (kernels whose character set is a run-time value)
+  const int nbv = nb_rt >= 0 ? nb_rt : NB;
+  const int L = NS + ND + nbv;
+  const uint32_t wave_step = (uint32_t)(NWAVES ? NWAVES : nwaves_rt) * WAVE;
   const int Rv = R ? R : rt.rows, Cv = C ? C : rt.cols;
   const uint32_t pitch = 4u * (QW ? (uint32_t)QW : (uint32_t)rt.qw);
   const uint8_t* const backdrop1 = reinterpret_cast<const uint8_t*>(backdrop4);
@@ -332,7 +337,7 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
     for (int d = 0; d < ND; ++d) pb_d[d] = uniform_ptr(obase + lay_d[d] * opitch);
 #pragma unroll
     for (int b = 0; b < NB; ++b) pb_b[b] = uniform_ptr(obase + lay_b[b] * opitch);
-    for (uint32_t f0 = (uint32_t)wave * WAVE; f0 < total; f0 += NWAVES * WAVE) {
+    for (uint32_t f0 = (uint32_t)wave * WAVE; f0 < total; f0 += wave_step) {
       // straight-line code (selects, clamped indices); one predicated region for the stores at the end
       const uint32_t f = f0 + (uint32_t)lane;
       const bool in_range = f < total;
@@ -434,7 +439,8 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
 #pragma unroll
         for (int s = 0; s < NS; ++s) put(pb_s[s], eq01(od, pm.sprite_ch4[s]));
 #pragma unroll
-        for (int b = 0; b < NB; ++b) put(pb_b[b], eq01(od, bchar_ch4[b]));
+        for (int b = 0; b < NB; ++b)
+          if (b < nbv) put(pb_b[b], eq01(od, bchar_ch4[b]));
       }
     }
   }

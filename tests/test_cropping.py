@@ -149,7 +149,7 @@ def test_device_cropper_outputs_are_zero_copy_device_tensors_and_survive_a_new_e
 
 # ---- croppers fused into the step kernel (cropping.fuse_croppers, pcx_engine_fuse_croppers) ----
 
-FUSABLE = ['warehouse_L1', 'marauders', 'better_scrolly_maze_L0', 'better_scrolly_maze_L1', 'better_scrolly_maze_L2',
+FUSABLE = ['scrolly_maze_L0', 'warehouse_L1', 'marauders', 'better_scrolly_maze_L0', 'better_scrolly_maze_L1', 'better_scrolly_maze_L2',
            'warehouse_custom_C', 'better_scrolly_custom_A', 'better_scrolly_custom_B']
 
 
@@ -205,7 +205,8 @@ def test_fused_croppers_match_reference(name, only_crops):
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', ['coop', 'single'])
 @pytest.mark.parametrize('name,batch', [('better_scrolly_maze_L0', 3000), ('better_scrolly_maze_L2', 700), ('warehouse_L0', 5000),
-                                        ('marauders', 1500), ('hello_world', 900)])
+                                        ('marauders', 1500), ('hello_world', 900), ('scrolly_maze_L0', 2500), ('scrolly_maze_L2', 800),
+                                        ('scrolly_custom_B', 1100), ('scrolly_custom_D', 700)])
 def test_fused_croppers_equal_stand_alone_croppers(name, batch, shape, monkeypatch):
   """Many groups (a ragged last one), both launch shapes, episodes ending and
   restarting: the windows the step kernel writes are the windows the
@@ -296,13 +297,18 @@ def test_croppers_released_from_a_windows_only_fusion_keep_their_output_until_th
 @pytest.mark.gpu
 def test_fuse_croppers_answers_false_where_the_kernel_cannot():
   from pycolab_amd.engine import Engine
-  t = helpers.load_template('scrolly_maze_L0')   # pcx_scrolly_maze_step has no fused cropper path
+  t = helpers.load_template('walkers_room')   # the table-driven kernel has no fused cropper path
   eng = Engine.from_template(t, batch=8, auto_reset=True)
-  cr = cropping.ScrollingCropper(5, 11, ['P'], pad_char=' ', scroll_margins=(1, 2))
+  cr = cropping.ScrollingCropper(5, 7, [chr(t.sprites[0]['ch'])], pad_char=chr(t.chars[0]), scroll_margins=(1, 2))
   cr.set_engine(eng)
   obs = eng.its_showtime()[0]
   assert cropping.fuse_croppers(eng, [cr]) is False and not cr._fused
-  assert helpers.to_np(cr.crop(obs).board).shape == (8, 5, 11)   # still crops, as its own kernels
+  assert helpers.to_np(cr.crop(obs).board).shape == (8, 5, 7)   # still crops, as its own kernels
+  um = Engine.from_template(helpers.load_template('scrolly_maze_L1_unoccluded'), batch=8, auto_reset=True)
+  cu = cropping.ScrollingCropper(5, 11, ['P'], pad_char=' ', scroll_margins=(1, 2))
+  cu.set_engine(um)
+  um.its_showtime()
+  assert cropping.fuse_croppers(um, [cu]) is False                  # unoccluded layers: the windows derive layers from the board
   t2 = helpers.load_template('warehouse_L0')
   eng2 = Engine.from_template(t2, batch=8, auto_reset=True)
   drape = cropping.ScrollingCropper(3, 3, ['X'], pad_char=' ', scroll_margins=(None, None))

@@ -12,6 +12,7 @@ VALU_SGPR = re.compile(r'^\s*(v_readlane_b32|v_readfirstlane_b32)\s+(s\d+)')
 VMEM = re.compile(r'^\s*(global_store|global_load|buffer_|scratch_)\S*\s+(.*)')
 SREG = re.compile(r's\[(\d+):(\d+)\]|\bs(\d+)\b')
 NOP = re.compile(r'^\s*s_nop\s+(\d+)')
+SALU_DST = re.compile(r"^\s*(s_(?!nop|waitcnt|cbranch|branch|barrier|endpgm|sleep|setprio|sethalt|cmp|bitcmp)\w+)\s+(?:s\[(\d+):(\d+)\]|s(\d+)\b)")
 
 bad = 0
 for path in sys.argv[1:]:
@@ -38,6 +39,11 @@ for path in sys.argv[1:]:
         if reg in used and age < 5:
           bad += 1
           print('%s:%d: %s uses s%d written by a VALU %d wait state(s) earlier  [%s]' % (path, n, t.split()[0], reg, age, kernel[:90]))
+    sal = SALU_DST.match(line)
+    if sal:  # an SALU write replaces the VALU-written value: what follows reads the SALU's result (no hazard)
+      a, b, c = sal.group(2), sal.group(3), sal.group(4)
+      gone = set(range(int(a), int(b) + 1)) if a else {int(c)}
+      recent = [(r, age) for r, age in recent if r not in gone]
     nop = NOP.match(line)
     step = 1 + int(nop.group(1)) if nop else 1
     recent = [(r, a + step) for r, a in recent if a + step < 6]
