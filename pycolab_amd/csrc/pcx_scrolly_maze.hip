@@ -88,7 +88,7 @@ struct Consts {
   int32_t n_bchars, bchar[MAX_L], lay_bchar[MAX_L];  // characters only the backdrop paints
   int32_t FW;  // words of one flat curtain bit-vector (cells bits + 1 spill word)
   int32_t lds_walls, lds_backdrop, lds_rowstart, lds_coincol, lds_flat, lds_sdesc, lds_cmask,
-      lds_skip, lds_bdmask, lds_buf_words, lds_flatraw, lds_sdescraw, lds_wcorner, lds_words;
+      lds_skip, lds_bdmask, lds_buf_words, lds_flatraw, lds_sdescraw, lds_wcorner, lds_fparams, lds_words;
   // CODES instance (at most eight characters): every cell's painter as the index
   // of its character among the sorted characters ("owner code", one byte per
   // cell), from which v_perm_b32 makes the board dword and every layer dword
@@ -183,6 +183,57 @@ __device__ __forceinline__ int coin_id_at(const Consts& k, const Lds& l, int pr,
 }
 __device__ __forceinline__ bool coin_alive(const Lds& l, int lane, int id) {
   return (l.cmask[(id >> 5) * WAVE + lane] >> (id & 31)) & 1;
+}
+
+// Row r of both curtains of the environment in LDS column `e`: the walls' pattern window, and the
+// pattern's coin bits in the window, each kept iff its coin is alive (or is the stale one).  The
+// window's coins have consecutive ids, so their alive bits are one bit range of the coin mask.
+// Returns false where the walls' window leaves the pattern (the reference raises IndexError).
+__device__ __forceinline__ bool curtain_row_bits(const Consts& k, const Lds& l, int e, int maze_r, int maze_c, int cash_r,
+                                                 int cash_c, uint32_t stale, int r, int C, uint32_t cmaskC, uint32_t& wbits,
+                                                 uint32_t& cbits) {
+  bool ok = true;
+  const int pr = maze_r + r;
+  wbits = 0;
+  if ((unsigned)pr < (unsigned)k.PR && maze_c >= 0 && maze_c + C <= k.PC) {
+    const uint32_t* row = l.walls + pr * k.WPR;
+    const int wi = maze_c >> 5, sh = maze_c & 31;
+    const uint64_t pair = (uint64_t)row[wi] | ((uint64_t)row[wi + 1] << 32);  // WPR has a spare word
+    wbits = (uint32_t)(pair >> sh) & cmaskC;
+  } else {
+    ok = false;
+  }
+  const int cr = cash_r + r;
+  cbits = 0;
+  if ((unsigned)cr < (unsigned)k.PR) {
+    const int CWPR = k.WPR - 1;
+    uint32_t sbits;
+    int id0;
+    if (cash_c >= 0 && cash_c + C <= k.PC) {
+      const uint32_t* row = l.coinbits + cr * CWPR;
+      const int wi = cash_c >> 5, sh = cash_c & 31;
+      const uint64_t pair = (uint64_t)row[wi] | ((uint64_t)row[wi + 1 < CWPR ? wi + 1 : wi] << 32);
+      sbits = (uint32_t)(pair >> sh) & cmaskC;
+      id0 = coins_before(k, l, cr, cash_c);
+    } else {  // a window that leaves the pattern sideways (never, while the drape obeys its limits): cell by cell
+      sbits = 0;
+      id0 = -1;
+      for (int col = 0; col < C; ++col) {
+        const int id = coin_id_at(k, l, cr, cash_c + col);
+        if (id >= 0) { sbits |= 1u << col; if (id0 < 0) id0 = id; }
+      }
+      if (id0 < 0) id0 = 0;
+    }
+    const int w0 = id0 >> 5;
+    const uint32_t lo = l.cmask[w0 * WAVE + e];
+    const uint32_t hi = l.cmask[(w0 + 1 < k.CW ? w0 + 1 : w0) * WAVE + e];
+    uint32_t alive = (uint32_t)((((uint64_t)hi << 32) | lo) >> (id0 & 31));
+    const uint32_t st_rel = stale - (uint32_t)id0;  // the coin picked up last frame is still drawn
+    alive |= st_rel < 32u ? 1u << st_rel : 0u;
+    for (uint32_t sb = sbits; sb; sb &= sb - 1u, alive >>= 1)  // deposit alive bit j at the j-th coin of the row window
+      cbits |= (alive & 1u) ? sb & (0u - sb) : 0u;
+  }
+  return ok;
 }
 
 // What the last repaint showed, for lazy board probes.
@@ -644,7 +695,20 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     }
 
     }  // debug & 1
-    if (!(a.debug & 4)) {
+    if constexpr (COOP) {
+      // Cooperative shape: the render descriptors are built by ALL waves of the workgroup after
+      // this phase (one (environment, row) task per lane -- the step is latency-bound at these batch
+      // sizes and this wave has done its share); they need the two corners, the stale coin and the
+      // sprites' cells.  What the row loop would have found wrong is known from the corner alone.
+      uint32_t* const fp = lds_raw + k.lds_fparams;
+      fp[0 * WAVE + lane] = pack_pos(maze.r, maze.c);
+      fp[1 * WAVE + lane] = pack_pos(cash.r, cash.c);
+      fp[2 * WAVE + lane] = stale;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) fp[(3 + s) * WAVE + lane] = (uint32_t)paint_cell(k, w[s]);
+      if (!(maze.r >= 0 && maze.r + R <= k.PR && maze.c >= 0 && maze.c + C <= k.PC)) err |= ERR_INDEX;
+    }
+    if (!COOP && !(a.debug & 4)) {
     // ---- render descriptors for phase B ------------------------------------
     // Both curtains as flat cell-bit vectors (bit i = cell i), so that phase B
     // finds the 4 bits of a board dword with one aligned LDS read.
@@ -660,50 +724,8 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       const uint32_t cmaskC = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
 #pragma unroll
       for (int r = 0; r < (SR ? SR : R); ++r) {
-        // walls curtain row: bits [maze.c, maze.c + C) of pattern row maze.r + r
-        int pr = maze.r + r;
-        uint32_t wbits = 0;
-        if ((unsigned)pr < (unsigned)k.PR && maze.c >= 0 && maze.c + C <= k.PC) {
-          const uint32_t* row = l.walls + pr * k.WPR;
-          int wi = maze.c >> 5, sh = maze.c & 31;
-          uint64_t pair = (uint64_t)row[wi] | ((uint64_t)row[wi + 1] << 32);  // WPR has a spare word
-          wbits = (uint32_t)(pair >> sh) & cmaskC;
-        } else {
-          err |= ERR_INDEX;
-        }
-        // coins curtain row: the pattern's coin bits in the window, each kept iff
-        // its coin is alive (or is the stale one).  The window's coins have
-        // consecutive ids, so their alive bits are one bit range of the mask.
-        int cr = cash.r + r;
-        uint32_t cbits = 0;
-        if ((unsigned)cr < (unsigned)k.PR) {
-          const int CWPR = k.WPR - 1;
-          uint32_t sbits;
-          int id0;
-          if (cash.c >= 0 && cash.c + C <= k.PC) {
-            const uint32_t* row = l.coinbits + cr * CWPR;
-            const int wi = cash.c >> 5, sh = cash.c & 31;
-            const uint64_t pair = (uint64_t)row[wi] | ((uint64_t)row[wi + 1 < CWPR ? wi + 1 : wi] << 32);
-            sbits = (uint32_t)(pair >> sh) & cmaskC;
-            id0 = coins_before(k, l, cr, cash.c);
-          } else {  // a window that leaves the pattern sideways (never, while the drape obeys its limits): cell by cell
-            sbits = 0;
-            id0 = -1;
-            for (int col = 0; col < C; ++col) {
-              const int id = coin_id_at(k, l, cr, cash.c + col);
-              if (id >= 0) { sbits |= 1u << col; if (id0 < 0) id0 = id; }
-            }
-            if (id0 < 0) id0 = 0;
-          }
-          const int w0 = id0 >> 5;
-          const uint32_t lo = l.cmask[w0 * WAVE + lane];
-          const uint32_t hi = l.cmask[(w0 + 1 < k.CW ? w0 + 1 : w0) * WAVE + lane];
-          uint32_t alive = (uint32_t)((((uint64_t)hi << 32) | lo) >> (id0 & 31));
-          const uint32_t st_rel = stale - (uint32_t)id0;  // the coin picked up last frame is still drawn
-          alive |= st_rel < 32u ? 1u << st_rel : 0u;
-          for (uint32_t sb = sbits; sb; sb &= sb - 1u, alive >>= 1)  // deposit alive bit j at the j-th coin of the row window
-            cbits |= (alive & 1u) ? sb & (0u - sb) : 0u;
-        }
+        uint32_t wbits, cbits;
+        if (!curtain_row_bits(k, l, lane, maze.r, maze.c, cash.r, cash.c, stale, r, C, cmaskC, wbits, cbits)) err |= ERR_INDEX;
         const int off = r * C, wi = off >> 5, sh = off & 31;
         if constexpr (SR != 0) {
           accw[wi] |= wbits << sh;
@@ -871,8 +893,81 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   }
   l.skip[lane] = skip;
   }  // have_logic
+  } else if constexpr (COOP) {
+    // (the other waves, while wave 0 steps the group: an empty slate for the curtains)
+    for (int i = (int)threadIdx.x - WAVE; i < 2 * WAVE * FWP; i += (int)blockDim.x - WAVE) l.flat[i] = 0;
   }
   if (single) __syncthreads();
+  if constexpr (COOP) {
+    if (have_render && !(a.debug & 4)) {
+      const uint32_t* const fp = lds_raw + k.lds_fparams;
+      const uint32_t cmaskC = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
+      // the curtains' rows: one (environment, row) task per lane, OR-ed into the flat bit vectors
+      for (int task = (int)threadIdx.x; task < WAVE * R; task += (int)blockDim.x) {
+        const int e = task / R, r = task - e * R;
+        if (l.skip[e]) continue;
+        const uint32_t mz = fp[0 * WAVE + e], cs = fp[1 * WAVE + e];
+        uint32_t wbits, cbits;
+        curtain_row_bits(k, l, e, pos_r(mz), pos_c(mz), pos_r(cs), pos_c(cs), fp[2 * WAVE + e], r, C, cmaskC, wbits, cbits);
+        const int off = r * C, wi = off >> 5, sh = off & 31;
+        if (wbits) atomicOr(&l.flat[FLAT(0, wi, e)], wbits << sh);
+        if (cbits) atomicOr(&l.flat[FLAT(1, wi, e)], cbits << sh);
+        if (sh + C > 32) {
+          if (wbits >> (32 - sh)) atomicOr(&l.flat[FLAT(0, wi + 1, e)], wbits >> (32 - sh));
+          if (cbits >> (32 - sh)) atomicOr(&l.flat[FLAT(1, wi + 1, e)], cbits >> (32 - sh));
+        }
+      }
+      __syncthreads();
+      const bool cash_front = (k.above[NS] >> (NS + 1)) & 1;
+      if (a.export_curtains) {  // raw curtains for drape-tracking croppers
+        const int ms = P.maze_slot, cs2 = 1 - P.maze_slot;
+        const int64_t env_base = g_render * WAVE;
+        for (int task = (int)threadIdx.x; task < WAVE * FW; task += (int)blockDim.x) {
+          const int i = task / WAVE, e = task - i * WAVE;  // consecutive lanes = consecutive environments: coalesced
+          if (env_base + e >= P.batch || l.skip[e]) continue;
+          P.curtains[((size_t)ms * FW + i) * P.bpad + env_base + e] = l.flat[FLAT(0, i, e)];
+          P.curtains[((size_t)cs2 * FW + i) * P.bpad + env_base + e] = l.flat[FLAT(1, i, e)];
+        }
+        __syncthreads();
+      }
+      if (fc) {  // the fused croppers' windows paint the curtains in index order: resolve them first
+        for (int task = (int)threadIdx.x; task < WAVE * FW; task += (int)blockDim.x) {
+          const int e = task / FW, i = task - e * FW;
+          const uint32_t ww = l.flat[FLAT(0, i, e)], cc = l.flat[FLAT(1, i, e)];
+          l.flat[FLAT(0, i, e)] = cash_front ? ww & ~cc : ww;
+          l.flat[FLAT(1, i, e)] = cash_front ? cc : cc & ~ww;
+        }
+        __syncthreads();
+      }
+      // the sprites, one (environment, sprite) task per lane: painted iff nothing in front covers the
+      // cell (a curtain occluded by the other curtain still stands for "something covers it"); a
+      // painted sprite takes its cell from both curtains.  Order-free, as in pcx_stream.h.
+      for (int task = (int)threadIdx.x; task < WAVE * NS; task += (int)blockDim.x) {
+        const int e = task / NS, s = task - e * NS;
+        if (l.skip[e]) continue;
+        int cellv[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) cellv[j] = (int)fp[(3 + j) * WAVE + e];
+        int cell = cellv[0];
+        uint32_t ab = k.above[0];
+#pragma unroll
+        for (int j = 1; j < NS; ++j) { cell = s == j ? cellv[j] : cell; ab = s == j ? k.above[j] : ab; }
+        bool shown = cell >= 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) shown = shown && !(j != s && ((ab >> j) & 1) && cellv[j] == cell);
+        const int cc = cell >= 0 ? cell : 0, wi = cc >> 5, sh = cc & 31;
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+          shown = shown && !(((ab >> (NS + dd)) & 1) && ((l.flat[FLAT(dd, wi, e)] >> sh) & 1));
+        if (shown) {
+          atomicAnd(&l.flat[FLAT(0, wi, e)], ~(1u << sh));
+          atomicAnd(&l.flat[FLAT(1, wi, e)], ~(1u << sh));
+        }
+        l.sdesc[s * WAVE + e] = make_uint2(shown ? (uint32_t)(cc >> 2) : 0xFFFFFFFFu, 0xFFu << ((cc & 3) * 8));
+      }
+      __syncthreads();
+    }
+  }
   if ((single || (TFUSE ? wave >= 1 : wave == 1)) && have_render && !(a.debug & 2)) {
 
 
@@ -946,6 +1041,12 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     }
 #pragma unroll
     for (int i = 0; i < NBS; ++i) mb[i] = (SL || i < NB) ? l.bdmask[i * QW + q] : 0u;
+    if constexpr (COOP) {  // (the cooperative shape leaves the two curtains unresolved against each other)
+      const bool cash_front = (k.above[NS] >> (NS + 1)) & 1;
+      const uint32_t m0 = md[0], m1 = md[1];
+      md[0] = cash_front ? m0 & ~m1 : m0;
+      md[1] = cash_front ? m1 : m1 & ~m0;
+    }
     uint32_t uni = md[0] | md[1];
     d = (d & ~md[0]) | (dch4[0] & md[0]);
     d = (d & ~md[1]) | (dch4[1] & md[1]);
@@ -1431,6 +1532,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   off = (off + 1) & ~1;
   k.lds_sdescraw = off; if (unoccluded_) off += 2 * k.NS * WAVE;
   k.lds_wcorner = off; off += stream::WCORNER_WORDS;  // fused croppers: the windows' corners
+  k.lds_fparams = off; off += (3 + MAX_NS) * WAVE;    // cooperative shape: corners, stale coin, sprite cells
   k.lds_words = off;
   if (off * 4 > 160 * 1024) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: template needs %d bytes of LDS", off * 4);
   {  // CODES instance: constants, coin masks, the backdrop's owner codes, one code table, the skip flags
