@@ -41,6 +41,7 @@ struct StepArgs {
   // step i takes actions + i * action_stride, or hash step t + i
   int n_steps = 1;
   int64_t action_stride = 0;
+  int envs_per_group = 64;  // cooperative launch shapes that split a wave's worth of environments further (pcx_scrolly_maze_step)
   int export_curtains = 0;  // write every drape's raw curtain bits to curtain_bits() (drape-tracking croppers)
   int debug = 0;  // ablation bits for profiling (PCX_DEBUG env): 1 skip entity updates, 2 skip phase B, 4 skip render descriptors
 };

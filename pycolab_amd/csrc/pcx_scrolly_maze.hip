@@ -466,7 +466,12 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   extern __shared__ uint32_t lds_raw[];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x >> 6;
-  const int ngroups = (int)(P.bpad / WAVE);
+  // Environments per workgroup: a whole wave's worth, except that the cooperative shape may take 32 or
+  // 16 (lanes beyond stay idle in the logic phase) so that a batch of a few thousand environments
+  // still puts a workgroup on every CU -- its steps are latency-bound, and what is left to shorten is
+  // each workgroup's share of the descriptor tasks and of the streaming (StepArgs::envs_per_group).
+  const int EPW = COOP ? a.envs_per_group : WAVE;
+  const int ngroups = (int)(P.bpad / EPW);
   const int R = SR ? SR : k.R, C = SC ? SC : k.C, L = SL ? SL : k.L;
   const int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch >> 2;  // planes start dword-aligned (pad bytes are 0)
   const int FW = SR ? (SR * SC + 31) / 32 + 1 : k.FW;
@@ -529,9 +534,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   if (wave == 0) {
   if (have_logic) {
   // ---- phase A (logic wave): lane == environment ---------------------------
-  const int64_t env0 = g_logic * WAVE;
+  const int64_t env0 = g_logic * EPW;
   const int64_t env = env0 + lane;
-  const bool live = env < P.batch;
+  const bool live = lane < EPW && env < P.batch;
   uint32_t* st = P.state + env;  // word w at st[w * bpad]
   const int64_t bp = P.bpad;
   uint32_t flags = 0;
@@ -903,7 +908,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       const uint32_t* const fp = lds_raw + k.lds_fparams;
       const uint32_t cmaskC = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
       // the curtains' rows: one (environment, row) task per lane, OR-ed into the flat bit vectors
-      for (int task = (int)threadIdx.x; task < WAVE * R; task += (int)blockDim.x) {
+      for (int task = (int)threadIdx.x; task < EPW * R; task += (int)blockDim.x) {
         const int e = task / R, r = task - e * R;
         if (l.skip[e]) continue;
         const uint32_t mz = fp[0 * WAVE + e], cs = fp[1 * WAVE + e];
@@ -921,17 +926,17 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       const bool cash_front = (k.above[NS] >> (NS + 1)) & 1;
       if (a.export_curtains) {  // raw curtains for drape-tracking croppers
         const int ms = P.maze_slot, cs2 = 1 - P.maze_slot;
-        const int64_t env_base = g_render * WAVE;
+        const int64_t env_base = g_render * EPW;
         for (int task = (int)threadIdx.x; task < WAVE * FW; task += (int)blockDim.x) {
           const int i = task / WAVE, e = task - i * WAVE;  // consecutive lanes = consecutive environments: coalesced
-          if (env_base + e >= P.batch || l.skip[e]) continue;
+          if (e >= EPW || env_base + e >= P.batch || l.skip[e]) continue;
           P.curtains[((size_t)ms * FW + i) * P.bpad + env_base + e] = l.flat[FLAT(0, i, e)];
           P.curtains[((size_t)cs2 * FW + i) * P.bpad + env_base + e] = l.flat[FLAT(1, i, e)];
         }
         __syncthreads();
       }
       if (fc) {  // the fused croppers' windows paint the curtains in index order: resolve them first
-        for (int task = (int)threadIdx.x; task < WAVE * FW; task += (int)blockDim.x) {
+        for (int task = (int)threadIdx.x; task < EPW * FW; task += (int)blockDim.x) {
           const int e = task / FW, i = task - e * FW;
           const uint32_t ww = l.flat[FLAT(0, i, e)], cc = l.flat[FLAT(1, i, e)];
           l.flat[FLAT(0, i, e)] = cash_front ? ww & ~cc : ww;
@@ -942,7 +947,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       // the sprites, one (environment, sprite) task per lane: painted iff nothing in front covers the
       // cell (a curtain occluded by the other curtain still stands for "something covers it"); a
       // painted sprite takes its cell from both curtains.  Order-free, as in pcx_stream.h.
-      for (int task = (int)threadIdx.x; task < WAVE * NS; task += (int)blockDim.x) {
+      for (int task = (int)threadIdx.x; task < EPW * NS; task += (int)blockDim.x) {
         const int e = task / NS, s = task - e * NS;
         if (l.skip[e]) continue;
         int cellv[NS];
@@ -979,7 +984,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   const int NB = SL ? NBS : k.n_bchars;
   uint32_t sch4[NS], dch4[2];
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  const int64_t env0 = g_render * WAVE;
+  const int64_t env0 = g_render * EPW;
   // Uniform per-plane base pointers: every store below is `scalar base +
   // 32-bit lane offset`, and the lane offset is the same for all nine planes.
   auto uniform_ptr = [](uint8_t* p) {  // pin a wave-uniform pointer to an SGPR pair
@@ -1134,8 +1139,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   uint32_t code_pf = 0;
   if constexpr (PREFETCH) code_pf = codes[eF + q];
   const bool planes_on = !(fc && fc->only);  // fused croppers, windows only: the full-board planes are not written
+  const int n_iter = COOP ? (EPW * QW + WAVE - 1) / WAVE : QW;  // 64 tasks per iteration
 #pragma unroll 1
-  for (int it = !planes_on ? QW : COOP ? wave : TFUSE ? wave - 1 : 0; it < QW;
+  for (int it = !planes_on ? n_iter : COOP ? wave : TFUSE ? wave - 1 : 0; it < n_iter;
        it += COOP ? (int)(blockDim.x >> 6) : TFUSE ? (int)(blockDim.x >> 6) - 1 : 1) {
     uint32_t e_now, q_now, voff_now, eF_now, foff_now = 0;
     uint32_t code_cur = 0;
@@ -1160,6 +1166,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       eF_now = e_now * (CODES ? CODE_PITCH : FWP);
       if constexpr (EPI) foff_now = 16u * f + e_now * f_skew;
     }
+    if constexpr (COOP) { if ((int)e_now >= EPW) continue; }  // (past the group's last environment)
     if (any_skip && l.skip[e_now]) continue;
     if constexpr (CODES) {
       // one LDS read, then one v_perm_b32 per plane: the board dword picks each
@@ -1618,12 +1625,21 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   } else if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
     int coop_waves = groups <= num_cus_ ? 8 : 4;  // at most one group per CU: split the render loop eight ways
     if (const char* e = getenv("PCX_COOP_WAVES")) coop_waves = atoi(e) == 4 ? 4 : 8;
+    // ... and while CUs would still stand empty, halve the environments per workgroup (32, 16): the
+    // descriptor tasks and the streaming of a step spread over more CUs (config 2: 4,096 environments
+    // = 256 workgroups of 16)
+    StepArgs ac = a;
+    int epw = WAVE;
+    while (epw > 16 && bpad_ / epw < (int64_t)num_cus_) epw >>= 1;
+    if (const char* e = getenv("PCX_COOP_EPW")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) epw = v; }
+    ac.envs_per_group = epw;
+    const unsigned coop_groups = (unsigned)(bpad_ / epw);
     if (epi_.out)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, true>), dim3((unsigned)groups),
-                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_, fused_.ptr());
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, true>), dim3(coop_groups),
+                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
     else
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3((unsigned)groups),
-                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_, fused_.ptr());
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3(coop_groups),
+                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
   } else if (shipped_shape && waves_per_wg == 1 && use_codes) {
     // owner-code render path: its own, smaller LDS layout, padded to the same workgroups-per-CU target
     size_t lds_c = (size_t)k_.lds_words_codes * 4;
