@@ -304,7 +304,7 @@ __device__ __forceinline__ bool check_motion(const Consts& k, const Lds& l, cons
 // EGO: whether the walker is the egocentric one, when the instance knows (1 / 0), else -1 (ask Consts)
 template <int NS, int EGO = -1>
 __device__ __forceinline__ bool mw_move(const Consts& k, const Lds& l, const Snap<NS>& sn, int s, Walker& w,
-                                        Plot& p, int dr, int dc, int lane, uint32_t& err) {
+                                        Plot& p, int dr, int dc, int lane, uint32_t& err, int quad_j = -1) {
   const bool ego = EGO >= 0 ? EGO != 0 : k.egocentric[s] != 0;
   if (ego) p.flags |= F_REGISTERED;  // scrolling.py:287-312
   if (p.order_valid) {               // sprites.py:446-454
@@ -315,10 +315,26 @@ __device__ __forceinline__ bool mw_move(const Consts& k, const Lds& l, const Sna
   if (!blocked) teleport(k, w, w.vr + dr, w.vc + dc);
   if (ego) {  // sprites.py:456-477 + scrolling.py:372-434 permit()
     // the eight neighbours, each probed once
-    bool n = blocked_at<NS>(k, l, sn, s, w, -1, 0, lane, err), so = blocked_at<NS>(k, l, sn, s, w, 1, 0, lane, err);
-    bool we = blocked_at<NS>(k, l, sn, s, w, 0, -1, lane, err), ea = blocked_at<NS>(k, l, sn, s, w, 0, 1, lane, err);
-    bool nw = blocked_at<NS>(k, l, sn, s, w, -1, -1, lane, err), ne = blocked_at<NS>(k, l, sn, s, w, -1, 1, lane, err);
-    bool sw = blocked_at<NS>(k, l, sn, s, w, 1, -1, lane, err), se = blocked_at<NS>(k, l, sn, s, w, 1, 1, lane, err);
+    bool n, so, we, ea, nw, ne, sw, se;
+    if (quad_j >= 0) {
+      // four lanes step this environment in lock step: lane j probes neighbours 2j and 2j + 1 (in the order N, S,
+      // W, E, NW, NE, SW, SE), then the quad ORs its verdicts (and whatever the probes found wrong) together
+      const int a0 = quad_j == 0 ? -1 : quad_j == 1 ? 0 : quad_j == 2 ? -1 : 1, b0 = quad_j == 0 ? 0 : -1;
+      const int a1 = quad_j == 0 ? 1 : quad_j == 1 ? 0 : quad_j == 2 ? -1 : 1, b1 = quad_j == 0 ? 0 : 1;
+      uint32_t nb = (uint32_t)blocked_at<NS>(k, l, sn, s, w, a0, b0, lane, err) << (2 * quad_j);
+      nb |= (uint32_t)blocked_at<NS>(k, l, sn, s, w, a1, b1, lane, err) << (2 * quad_j + 1);
+      nb |= err << 8;
+      nb |= (uint32_t)__shfl_xor((int)nb, 1);
+      nb |= (uint32_t)__shfl_xor((int)nb, 2);
+      err |= (nb >> 8) & 7u;
+      n = nb & 1u; so = (nb >> 1) & 1u; we = (nb >> 2) & 1u; ea = (nb >> 3) & 1u;
+      nw = (nb >> 4) & 1u; ne = (nb >> 5) & 1u; sw = (nb >> 6) & 1u; se = (nb >> 7) & 1u;
+    } else {
+      n = blocked_at<NS>(k, l, sn, s, w, -1, 0, lane, err); so = blocked_at<NS>(k, l, sn, s, w, 1, 0, lane, err);
+      we = blocked_at<NS>(k, l, sn, s, w, 0, -1, lane, err); ea = blocked_at<NS>(k, l, sn, s, w, 0, 1, lane, err);
+      nw = blocked_at<NS>(k, l, sn, s, w, -1, -1, lane, err); ne = blocked_at<NS>(k, l, sn, s, w, -1, 1, lane, err);
+      sw = blocked_at<NS>(k, l, sn, s, w, 1, -1, lane, err); se = blocked_at<NS>(k, l, sn, s, w, 1, 1, lane, err);
+    }
     uint32_t legal = 1u << motion_bit(0, 0);
     legal |= (uint32_t)!n << motion_bit(-1, 0);
     legal |= (uint32_t)!so << motion_bit(1, 0);
@@ -534,9 +550,15 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   if (wave == 0) {
   if (have_logic) {
   // ---- phase A (logic wave): lane == environment ---------------------------
+  // (cooperative shape with 16 environments per workgroup: FOUR lanes per environment.  All four step it
+  // identically -- same loads, same stores -- except that the egocentric sprite's eight scroll-permit probes,
+  // half of a step's probes, are shared out two per lane and their verdicts exchanged with two quad shuffles.)
+  const bool quad = COOP && EPW == 16;
+  const int col = quad ? lane >> 2 : lane;   // the environment's column in the per-environment LDS arrays
+  const int quad_j = quad ? lane & 3 : -1;
   const int64_t env0 = g_logic * EPW;
-  const int64_t env = env0 + lane;
-  const bool live = lane < EPW && env < P.batch;
+  const int64_t env = env0 + col;
+  const bool live = col < EPW && env < P.batch;
   uint32_t* st = P.state + env;  // word w at st[w * bpad]
   const int64_t bp = P.bpad;
   uint32_t flags = 0;
@@ -592,7 +614,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       for (int s = 0; s < NS; ++s) spos[s] = k.init[W_SPOS + s];
       for (int i = 0; i < k.CW; ++i) {
         int left = k.n_coins - 32 * i;
-        l.cmask[i * WAVE + lane] = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u);
+        l.cmask[i * WAVE + col] = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u);
       }
       coins_dirty = true;
       action = PCX_ACTION_NONE;
@@ -605,7 +627,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       sflags = ld_sflags;
 #pragma unroll
       for (int s = 0; s < NS; ++s) spos[s] = ld_spos[s];
-      for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + lane] = st[(W_SPOS + NS + i) * bp];
+      for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + col] = st[(W_SPOS + NS + i) * bp];
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -656,13 +678,13 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
         if (wall_at(k, l, pr, pc, err)) w[s].var ^= 1;                                           \
         mdc = w[s].var ? 1 : -1;                                                                 \
       }                                                                                          \
-      mw_move<NS, ego_s>(k, l, sn, s, w[s], p, 0, mdc, lane, err); /* one call site for both */  \
+      mw_move<NS, ego_s>(k, l, sn, s, w[s], p, 0, mdc, col, err, quad_j); /* one call site for both */  \
       if (walks) {                                                                               \
         const Walker pl = pick<NS, IP>(w, k.ip);                                                 \
         if (w[s].vr == pl.vr && w[s].vc == pl.vc) { p.game_over = 1; p.discount = 0.0f; }        \
       }                                                                                          \
     } else { /* PlayerSprite.update (scrolly_maze.py:259-271) */                                 \
-      if (moves) mw_move<NS, ego_s>(k, l, sn, s, w[s], p, dr, dc, lane, err);                    \
+      if (moves) mw_move<NS, ego_s>(k, l, sn, s, w[s], p, dr, dc, col, err, quad_j);                    \
     }                                                                                            \
   }
     PCX_SM_SPRITE(0) PCX_SM_SPRITE(1) PCX_SM_SPRITE(2) PCX_SM_SPRITE(3) PCX_SM_SPRITE(4) PCX_SM_SPRITE(5)
@@ -680,14 +702,14 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
         err |= ERR_INDEX;
       } else {
         int id = coin_id_at(k, l, pr, pc);
-        if (id >= 0 && coin_alive(l, lane, id)) {
+        if (id >= 0 && coin_alive(l, col, id)) {
           p.reward_set = 1;
           p.reward += 100;
-          l.cmask[(id >> 5) * WAVE + lane] &= ~(1u << (id & 31));
+          l.cmask[(id >> 5) * WAVE + col] &= ~(1u << (id & 31));
           coins_dirty = true;
           stale = (uint32_t)id;  // still drawn until the curtain is refreshed
           uint32_t any = 0;
-          for (int i = 0; i < k.CW; ++i) any |= l.cmask[i * WAVE + lane];
+          for (int i = 0; i < k.CW; ++i) any |= l.cmask[i * WAVE + col];
           if (!any) { p.game_over = 1; p.discount = 0.0f; }
         }
       }
@@ -702,15 +724,15 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     }  // debug & 1
     if constexpr (COOP) {
       // Cooperative shape: the render descriptors are built by ALL waves of the workgroup after
-      // this phase (one (environment, row) task per lane -- the step is latency-bound at these batch
+      // this phase (one (environment, row) task per col -- the step is latency-bound at these batch
       // sizes and this wave has done its share); they need the two corners, the stale coin and the
       // sprites' cells.  What the row loop would have found wrong is known from the corner alone.
       uint32_t* const fp = lds_raw + k.lds_fparams;
-      fp[0 * WAVE + lane] = pack_pos(maze.r, maze.c);
-      fp[1 * WAVE + lane] = pack_pos(cash.r, cash.c);
-      fp[2 * WAVE + lane] = stale;
+      fp[0 * WAVE + col] = pack_pos(maze.r, maze.c);
+      fp[1 * WAVE + col] = pack_pos(cash.r, cash.c);
+      fp[2 * WAVE + col] = stale;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) fp[(3 + s) * WAVE + lane] = (uint32_t)paint_cell(k, w[s]);
+      for (int s = 0; s < NS; ++s) fp[(3 + s) * WAVE + col] = (uint32_t)paint_cell(k, w[s]);
       if (!(maze.r >= 0 && maze.r + R <= k.PR && maze.c >= 0 && maze.c + C <= k.PC)) err |= ERR_INDEX;
     }
     if (!COOP && !(a.debug & 4)) {
@@ -724,13 +746,13 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
 #pragma unroll
         for (int i = 0; i < ACC; ++i) accw[i] = accc[i] = 0;
       } else {
-        for (int i = 0; i < FW; ++i) l.flat[FLAT(0, i, lane)] = l.flat[FLAT(1, i, lane)] = 0;
+        for (int i = 0; i < FW; ++i) l.flat[FLAT(0, i, col)] = l.flat[FLAT(1, i, col)] = 0;
       }
       const uint32_t cmaskC = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
 #pragma unroll
       for (int r = 0; r < (SR ? SR : R); ++r) {
         uint32_t wbits, cbits;
-        if (!curtain_row_bits(k, l, lane, maze.r, maze.c, cash.r, cash.c, stale, r, C, cmaskC, wbits, cbits)) err |= ERR_INDEX;
+        if (!curtain_row_bits(k, l, col, maze.r, maze.c, cash.r, cash.c, stale, r, C, cmaskC, wbits, cbits)) err |= ERR_INDEX;
         const int off = r * C, wi = off >> 5, sh = off & 31;
         if constexpr (SR != 0) {
           accw[wi] |= wbits << sh;
@@ -740,11 +762,11 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
             accc[wi + 1] |= cbits >> (32 - sh);
           }
         } else {
-          l.flat[FLAT(0, wi, lane)] |= wbits << sh;
-          l.flat[FLAT(1, wi, lane)] |= cbits << sh;
+          l.flat[FLAT(0, wi, col)] |= wbits << sh;
+          l.flat[FLAT(1, wi, col)] |= cbits << sh;
           if (sh + C > 32) {
-            l.flat[FLAT(0, wi + 1, lane)] |= wbits >> (32 - sh);
-            l.flat[FLAT(1, wi + 1, lane)] |= cbits >> (32 - sh);
+            l.flat[FLAT(0, wi + 1, col)] |= wbits >> (32 - sh);
+            l.flat[FLAT(1, wi + 1, col)] |= cbits >> (32 - sh);
           }
         }
       }
@@ -761,8 +783,8 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
           }
         } else {
           for (int i = 0; i < FW; ++i) {
-            P.curtains[((size_t)ms * FW + i) * bp + env] = l.flat[FLAT(0, i, lane)];
-            P.curtains[((size_t)cs2 * FW + i) * bp + env] = l.flat[FLAT(1, i, lane)];
+            P.curtains[((size_t)ms * FW + i) * bp + env] = l.flat[FLAT(0, i, col)];
+            P.curtains[((size_t)cs2 * FW + i) * bp + env] = l.flat[FLAT(1, i, col)];
           }
         }
       }
@@ -783,25 +805,25 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
           uint32_t code = bdcode[q];
           code = (code & ~mw) | (wcode4 & mw);
           code = (code & ~mc) | (ccode4 & mc);
-          codes[lane * CODE_PITCH + q] = code;
+          codes[col * CODE_PITCH + q] = code;
         }
       } else if constexpr (SR != 0) {
 #pragma unroll
         for (int i = 0; i < ACC; ++i) {
           const uint32_t ww = cash_in_front ? accw[i] & ~accc[i] : accw[i];
           const uint32_t cc = cash_in_front ? accc[i] : accc[i] & ~accw[i];
-          l.flat[FLAT(0, i, lane)] = ww;
-          l.flat[FLAT(1, i, lane)] = cc;
+          l.flat[FLAT(0, i, col)] = ww;
+          l.flat[FLAT(1, i, col)] = cc;
         }
       } else {
         for (int i = 0; i < FW; ++i) {
-          const uint32_t ww = l.flat[FLAT(0, i, lane)], cc = l.flat[FLAT(1, i, lane)];
+          const uint32_t ww = l.flat[FLAT(0, i, col)], cc = l.flat[FLAT(1, i, col)];
           if constexpr (UNOCC) {  // unoccluded layers are the raw curtains (rendering.py:236-278)
-            (lds_raw + k.lds_flatraw)[FLAT(0, i, lane)] = ww;
-            (lds_raw + k.lds_flatraw)[FLAT(1, i, lane)] = cc;
+            (lds_raw + k.lds_flatraw)[FLAT(0, i, col)] = ww;
+            (lds_raw + k.lds_flatraw)[FLAT(1, i, col)] = cc;
           }
-          l.flat[FLAT(0, i, lane)] = cash_in_front ? ww & ~cc : ww;
-          l.flat[FLAT(1, i, lane)] = cash_in_front ? cc : cc & ~ww;
+          l.flat[FLAT(0, i, col)] = cash_in_front ? ww & ~cc : ww;
+          l.flat[FLAT(1, i, col)] = cash_in_front ? cc : cc & ~ww;
         }
       }
     }
@@ -812,7 +834,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     if constexpr (CODES) {
       // the sprites, back to front (engine.py:751-757): a sprite takes its cell
       // unless a curtain in front of it holds it; one byte each
-      uint8_t* const mine = reinterpret_cast<uint8_t*>(codes + lane * CODE_PITCH);
+      uint8_t* const mine = reinterpret_cast<uint8_t*>(codes + col * CODE_PITCH);
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
 #pragma unroll
@@ -842,15 +864,15 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
           const int wi = cell >> 5, sh = cell & 31;
 #pragma unroll
           for (int dd = 0; dd < 2; ++dd)
-            if (((ab >> (NS + dd)) & 1) && ((l.flat[FLAT(dd, wi, lane)] >> sh) & 1)) shown = false;
+            if (((ab >> (NS + dd)) & 1) && ((l.flat[FLAT(dd, wi, col)] >> sh) & 1)) shown = false;
           if (shown) {
-            l.flat[FLAT(0, wi, lane)] &= ~(1u << sh);
-            l.flat[FLAT(1, wi, lane)] &= ~(1u << sh);
+            l.flat[FLAT(0, wi, col)] &= ~(1u << sh);
+            l.flat[FLAT(1, wi, col)] &= ~(1u << sh);
           }
         }
-        l.sdesc[s * WAVE + lane] = make_uint2(shown ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
+        l.sdesc[s * WAVE + col] = make_uint2(shown ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
         if constexpr (UNOCC)
-          reinterpret_cast<uint2*>(lds_raw + k.lds_sdescraw)[s * WAVE + lane] =
+          reinterpret_cast<uint2*>(lds_raw + k.lds_sdescraw)[s * WAVE + col] =
               make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
       }
     }
@@ -885,10 +907,10 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
             t = k.tmpl_index[s] == ti ? tw : t;
           }
           return t;
-        }, p.frame == 0, env, lane, lds_raw + k.lds_wcorner);
+        }, p.frame == 0, env, col, lds_raw + k.lds_wcorner);
     }
     if (coins_dirty)
-      for (int i = 0; i < k.CW; ++i) st[(W_SPOS + NS + i) * bp] = l.cmask[i * WAVE + lane];
+      for (int i = 0; i < k.CW; ++i) st[(W_SPOS + NS + i) * bp] = l.cmask[i * WAVE + col];
     out.reward[env] = p.reward;
     out.reward_set[env] = (uint8_t)p.reward_set;
     out.discount[env] = p.discount;
@@ -896,7 +918,8 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     out.frame[env] = p.frame;
     out.error[env] = (uint8_t)err;
   }
-  l.skip[lane] = skip;
+  if (quad) l.skip[lane] = 1;  // (columns past the group's environments: nobody's)
+  l.skip[col] = skip;
   }  // have_logic
   } else if constexpr (COOP) {
     // (the other waves, while wave 0 steps the group: an empty slate for the curtains)
