@@ -488,6 +488,33 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // each workgroup's share of the descriptor tasks and of the streaming (StepArgs::envs_per_group).
   const int EPW = COOP ? a.envs_per_group : WAVE;
   const int ngroups = (int)(P.bpad / EPW);
+  // Cooperative shape (one group per workgroup, latency-bound): the logic wave asks for its
+  // environments' state words before anybody stages the template constants into LDS, so that the two
+  // memory round trips run side by side instead of one after the other.
+  uint32_t pre_flags = 0, pre_frame = 0, pre_permit = 0, pre_mz = 0, pre_cs = 0, pre_stale = 0, pre_sflags = 0, pre_spos[NS] = {},
+           pre_cm[4] = {0, 0, 0, 0};
+  int pre_action = PCX_ACTION_NONE;
+  if constexpr (COOP) {
+    if (threadIdx.x < WAVE) {
+      const int col0 = EPW == 16 ? (int)threadIdx.x >> 2 : (int)threadIdx.x;
+      const int64_t env_p = (int64_t)blockIdx.x * EPW + col0;
+      if (col0 < EPW && env_p < P.batch) {
+        const uint32_t* stp = P.state + env_p;
+        const int64_t bpp = P.bpad;
+        pre_flags = stp[W_FLAGS * bpp];
+        if (a.mode != 1) {
+          pre_frame = stp[W_FRAME * bpp]; pre_permit = stp[W_PERMIT_FRAME * bpp];
+          pre_mz = stp[W_MAZE * bpp]; pre_cs = stp[W_CASH * bpp];
+          pre_stale = stp[W_STALE * bpp]; pre_sflags = stp[W_SFLAGS * bpp];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) pre_spos[s] = stp[(W_SPOS + s) * bpp];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (i < k.CW) pre_cm[i] = stp[(W_SPOS + NS + i) * bpp];
+          if (!a.hashed) pre_action = a.actions[env_p];
+        }
+      }
+    }
+  }
   const int R = SR ? SR : k.R, C = SC ? SC : k.C, L = SL ? SL : k.L;
   const int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch >> 2;  // planes start dword-aligned (pad bytes are 0)
   const int FW = SR ? (SR * SC + 31) / 32 + 1 : k.FW;
@@ -570,9 +597,15 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // trip for the whole logic phase instead of two or three in a row
   uint32_t ld_frame = 0, ld_permit = 0, ld_mz = 0, ld_cs = 0, ld_stale = 0, ld_sflags = 0, ld_spos[NS] = {};
   int ld_action = PCX_ACTION_NONE;
+  if constexpr (COOP) {  // (asked for at the top of the kernel)
+    flags = pre_flags; ld_frame = pre_frame; ld_permit = pre_permit; ld_mz = pre_mz; ld_cs = pre_cs;
+    ld_stale = pre_stale; ld_sflags = pre_sflags; ld_action = pre_action;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ld_spos[s] = pre_spos[s];
+  }
   if (live) {
-    flags = st[W_FLAGS * bp];
-    if (a.mode != 1) {
+    if constexpr (!COOP) flags = st[W_FLAGS * bp];
+    if (!COOP && a.mode != 1) {
       ld_frame = st[W_FRAME * bp]; ld_permit = st[W_PERMIT_FRAME * bp];
       ld_mz = st[W_MAZE * bp]; ld_cs = st[W_CASH * bp];
       ld_stale = st[W_STALE * bp]; ld_sflags = st[W_SFLAGS * bp];
@@ -627,7 +660,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       sflags = ld_sflags;
 #pragma unroll
       for (int s = 0; s < NS; ++s) spos[s] = ld_spos[s];
-      for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + col] = st[(W_SPOS + NS + i) * bp];
+      for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + col] = (COOP && i < 4) ? (i == 0 ? pre_cm[0] : i == 1 ? pre_cm[1] : i == 2 ? pre_cm[2] : pre_cm[3]) : st[(W_SPOS + NS + i) * bp];
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
