@@ -149,9 +149,14 @@ typedef struct pcx_drape_desc {
 enum pcx_directive_kind {
   PCX_DIR_ADD_REWARD = 1, /* the_plot.add_reward(reward)              plot.py:200-226 */
   PCX_DIR_TERMINATE = 2,  /* the_plot.terminate_episode(discount)     plot.py:176-198 */
-  PCX_DIR_Z_ORDER = 3     /* the_plot.change_z_order(move_this, in_front_of)  plot.py:136-174,
+  PCX_DIR_Z_ORDER = 3,    /* the_plot.change_z_order(move_this, in_front_of)  plot.py:136-174,
                              applied by engine.py:796-835 after the last update group */
+  PCX_DIR_NEXT_CHAPTER = 4 /* the_plot.next_chapter = reward  (plot.py:299-324; examples/ordeal.py:177-235:
+                             a game entity names the Story's next game): `reward` is the chapter's index
+                             or integer key, PCX_CHAPTER_NONE for None ("the story ends here") */
 };
+#define PCX_CHAPTER_NONE (-1)              /* the_plot.next_chapter = None                         */
+#define PCX_CHAPTER_UNSET (-2147483647 - 1) /* no entity has set it in this episode: the Story's own */
 typedef struct pcx_directive {
   uint8_t ch;          /* the entity that issues it                          */
   uint8_t kind;        /* enum pcx_directive_kind                            */
@@ -290,6 +295,12 @@ int pcx_engine_errors_seen(pcx_engine* e, uint8_t* errors_host, int32_t clear);
 int pcx_engine_state_size(pcx_engine* e, int32_t with_observation, uint64_t* bytes);
 int pcx_engine_export_state(pcx_engine* e, void* state_host, uint64_t bytes, int32_t with_observation);
 int pcx_engine_import_state(pcx_engine* e, const void* state_host, uint64_t bytes);
+
+/* Host copy of int32[batch]: what the environments' entities last assigned to
+ * the_plot.next_chapter in their current episode (PCX_DIR_NEXT_CHAPTER; plot.py:299-324),
+ * PCX_CHAPTER_NONE for None, PCX_CHAPTER_UNSET where no entity has -- a host-side Story
+ * (storytelling.py:425-470) reads it when an environment's game ends.  Synchronous. */
+int pcx_engine_next_chapter(pcx_engine* e, int32_t* next_host);
 
 /* Convenience synchronous copies (host <-> device) for thin FFI hosts. */
 int pcx_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes);

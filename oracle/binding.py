@@ -23,6 +23,7 @@ _SYMS = [
     ('pcxo_engine_step_hashed', N.c_i32, [ctypes.c_void_p, N.c_u64, N.c_i64, N.c_i64, N.c_i32, N.c_i32]),
     ('pcxo_engine_buffers', N.c_i32, [ctypes.c_void_p, ctypes.POINTER(N.Buffers)]),
     ('pcxo_engine_read_things', N.c_i32, [ctypes.c_void_p, N.c_i64, N.c_i64, ctypes.c_void_p, ctypes.c_void_p]),
+    ('pcxo_engine_next_chapter', N.c_i32, [ctypes.c_void_p, ctypes.c_void_p]),
     ('pcxo_action_hash', N.c_u32, [N.c_u64, N.c_u64, N.c_u64]),
     ('pcxo_last_error', ctypes.c_char_p, []),
     ('pcxo_cropper_create', N.c_i32, [ctypes.c_void_p, ctypes.POINTER(N.CropperDesc), ctypes.POINTER(ctypes.c_void_p)]),
@@ -108,6 +109,12 @@ class OracleEngine(object):
 
   def step_hashed(self, seed, t0, steps, env_offset=0, auto_reset=True):
     _check(lib().pcxo_engine_step_hashed(self._h, seed, env_offset, t0, steps, int(auto_reset)))
+
+  def next_chapter(self):
+    """int32 [batch]: what the entities assigned to the_plot.next_chapter (N.CHAPTER_NONE / N.CHAPTER_UNSET)."""
+    out = np.zeros((self.batch,), np.int32)
+    _check(lib().pcxo_engine_next_chapter(self._h, out.ctypes.data))
+    return out
 
   def sprites(self):
     ns = len(self.template.sprites)

@@ -105,7 +105,10 @@ def inject(spec, game, a, tt):
 
     def thing_to_do(actions, board, layers, backdrop, things, the_plot, calls=calls):
       for call in calls:
-        getattr(the_plot, call[0])(*call[1:])
+        if call[0] == 'next_chapter':
+          the_plot.next_chapter = call[1]  # plot.py:299-324 is a property setter
+        else:
+          getattr(the_plot, call[0])(*call[1:])
     tt.pre_update(game, ch, thing_to_do)
 
 
@@ -153,6 +156,20 @@ STORY = [
              'Q': dict(kind='sprite', motion=None, directive=(0, 3),
                        calls={1: [('add_reward', 5)], 2: [('terminate_episode',)], 3: [('terminate_episode', 0.5), ('add_reward', 1)]})}),
 ]
+
+
+# The same three chapters with entities that decide the story's order themselves
+# (`the_plot.next_chapter = ...` from inside update(), as examples/ordeal.py:177-235 does;
+# plot.py:299-324): jumps ahead, jumps back, "the story ends after this game".
+import copy as _copy
+STORY_JUMPS = _copy.deepcopy(STORY)
+STORY_JUMPS[0]['entities']['Q']['calls'] = {1: [('add_reward', 5)], 2: [('next_chapter', 2), ('terminate_episode',)],
+                                            3: [('terminate_episode', 0.5), ('add_reward', 1)]}
+STORY_JUMPS[0]['entities']['R']['calls'] = {1: [('next_chapter', None)], 2: [('add_reward', 11)], 3: [('next_chapter', 1), ('add_reward', -3)]}
+STORY_JUMPS[1]['entities']['D']['calls'] = {1: [('next_chapter', 0), ('terminate_episode', 0.25), ('add_reward', 10)], 2: [('add_reward', 1)]}
+STORY_JUMPS[1]['entities']['b']['calls'] = {2: [('change_z_order', 'b', None)], 1: [('next_chapter', 2)]}
+STORY_JUMPS[2]['entities']['Q']['calls'] = {1: [('next_chapter', 1), ('add_reward', 5)], 2: [('terminate_episode',)],
+                                            3: [('next_chapter', 0), ('terminate_episode', 0.5), ('add_reward', 1)]}
 
 
 def story_tape(rng, T):

@@ -38,17 +38,20 @@ from pycolab.tests import test_things as tt  # noqa: E402
 from oracle import directive_scenarios as ds  # noqa: E402
 
 
-def make_story():
-  return ref_story.Story([lambda spec=spec: ds.build_reference(spec, ref_art, tt) for spec in ds.STORY])
-
-
 def main():
+  generate('story_three_chapters', ds.STORY, 9000)
+  generate('story_entity_chapters', ds.STORY_JUMPS, 9100)  # the entities name the next chapter (plot.py:299-324)
+
+
+def generate(name, specs, seed0):
+  def make_story():
+    return ref_story.Story([lambda spec=spec: ds.build_reference(spec, ref_art, tt) for spec in specs])
   E, T = 16, 96
-  chars = sorted(set('.').union(*[set(spec['entities']) for spec in ds.STORY]))
+  chars = sorted(set('.').union(*[set(spec['entities']) for spec in specs]))
   actions = np.zeros((T, E), np.int32)
   boards, rewards, rsets, discounts, dones, chapters, restarted = [], [], [], [], [], [], []
   for e in range(E):
-    rng = np.random.RandomState(9000 + e)
+    rng = np.random.RandomState(seed0 + e)
     actions[:, e] = ds.story_tape(rng, T)
     story = make_story()
     rec = []
@@ -65,7 +68,7 @@ def main():
         note(obs, r, d, 1)
         continue
       a = int(actions[t, e])
-      spec = ds.STORY[story.the_plot.this_chapter]
+      spec = specs[story.the_plot.this_chapter]
       ds.inject(spec, story.current_game, a, tt)
       obs, r, d = story.play(ds.reference_action(spec, a))
       note(obs, r, d, 0)
@@ -75,7 +78,7 @@ def main():
   sw = lambda x, dt: np.ascontiguousarray(np.swapaxes(np.array(x, dtype=dt), 0, 1))
   out_root = os.environ.get('PCX_GOLDEN_OUT') or os.path.join(ROOT, 'tests', 'golden')
   os.makedirs(os.path.join(out_root, 'traces'), exist_ok=True)
-  path = os.path.join(out_root, 'traces', 'story_three_chapters.npz')
+  path = os.path.join(out_root, 'traces', name + '.npz')
   np.savez_compressed(path, actions=actions, boards=sw(boards, np.uint8), reward=sw(rewards, np.int32),
                       reward_set=sw(rsets, np.uint8), discount=sw(discounts, np.float32), done=sw(dones, np.uint8),
                       chapter=sw(chapters, np.int8), fresh=sw(restarted, np.uint8),

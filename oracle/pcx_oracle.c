@@ -85,6 +85,9 @@ typedef struct {
   /* Plot._EngineDirectives.z_updates (plot.py:136-174): entity ids, -1 = None */
   int n_z_updates;
   int z_move[PCX_MAX_DIRECTIVES], z_front[PCX_MAX_DIRECTIVES];
+  /* Plot._next_chapter as the game's entities left it (plot.py:299-324): a chapter index,
+   * PCX_CHAPTER_NONE for None, PCX_CHAPTER_UNSET while only the Story has written it */
+  int32_t next_chapter;
 } ox_plot;
 
 typedef struct {
@@ -781,6 +784,7 @@ static void issue_directives(ox_ctx* x, int id, int ch, const int32_t* param) {
     switch (d->kind) {
       case PCX_DIR_ADD_REWARD: plot_add_reward(p, d->reward); break;
       case PCX_DIR_TERMINATE: plot_terminate(p, d->discount); break;
+      case PCX_DIR_NEXT_CHAPTER: p->next_chapter = d->reward; break; /* plot.py:299-324: the last call stands */
       case PCX_DIR_Z_ORDER: /* plot.py:173-174: appended, applied after the last group */
         p->z_move[p->n_z_updates] = thing_id(e, d->move_this);
         p->z_front[p->n_z_updates] = d->in_front_of ? thing_id(e, d->in_front_of) : -1;
@@ -898,6 +902,7 @@ static void env_init(pcxo_engine* e, int64_t b) {
   memset(&env->plot, 0, sizeof env->plot);
   env->plot.kv[EM_LAST_PLAYER_SHOT] = env->plot.kv[EM_LAST_MARAUDER_SHOT] = EM_NEVER;
   env->plot.frame = -1;
+  env->plot.next_chapter = PCX_CHAPTER_UNSET; /* a new Engine has a new Plot */
   plot_clear_directives(&env->plot);
   memcpy(env->z_id, e->z_id, sizeof env->z_id);
   env->game_over = 0;
@@ -1069,6 +1074,11 @@ int pcxo_engine_buffers(pcxo_engine* e, pcx_buffers* out) {
   out->rows = e->t.rows; out->cols = e->t.cols; out->n_chars = e->t.n_chars;
   out->planes = e->planes; out->reward = e->reward; out->reward_set = e->reward_set;
   out->discount = e->discount; out->done = e->done; out->frame = e->frame; out->error = e->error;
+  return 0;
+}
+
+int pcxo_engine_next_chapter(pcxo_engine* e, int32_t* out) {
+  for (int64_t b = 0; b < e->batch; ++b) out[b] = e->envs[b].plot.next_chapter;
   return 0;
 }
 

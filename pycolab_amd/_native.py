@@ -55,7 +55,8 @@ class DrapeDesc(ctypes.Structure):
 
 
 MAX_DIRECTIVES = 32
-DIR_ADD_REWARD, DIR_TERMINATE, DIR_Z_ORDER = 1, 2, 3
+DIR_ADD_REWARD, DIR_TERMINATE, DIR_Z_ORDER, DIR_NEXT_CHAPTER = 1, 2, 3, 4
+CHAPTER_NONE, CHAPTER_UNSET = -1, -2147483648
 
 
 class Directive(ctypes.Structure):
@@ -136,6 +137,7 @@ SYMBOLS = [
     ('pcx_engine_read_things', c_i32, [_VP, c_i64, c_i64, _VP, _VP]),
     ('pcx_engine_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
     ('pcx_engine_errors_seen', c_i32, [_VP, _VP, c_i32]),
+    ('pcx_engine_next_chapter', c_i32, [_VP, _VP]),
     ('pcx_engine_state_size', c_i32, [_VP, c_i32, ctypes.POINTER(c_u64)]),
     ('pcx_engine_export_state', c_i32, [_VP, _VP, c_u64, c_i32]),
     ('pcx_engine_import_state', c_i32, [_VP, _VP, c_u64]),

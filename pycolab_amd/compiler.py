@@ -29,8 +29,8 @@ def _impassable_bits(chars):
 
 
 def _directive(ch, selector, call, things_by_char):
-  """One ('add_reward', r) / ('terminate_episode'[, d]) / ('change_z_order', a, b)
-  entry as a pcx_directive tuple, checked the way plot.py and engine.py check it."""
+  """One ('add_reward', r) / ('terminate_episode'[, d]) / ('change_z_order', a, b) /
+  ('next_chapter', key) entry as a pcx_directive tuple, checked the way plot.py and engine.py check it."""
   name, args = call[0], tuple(call[1:])
   if name == 'add_reward':
     (reward,) = args
@@ -57,6 +57,11 @@ def _directive(ch, selector, call, things_by_char):
     if move_this == in_front_of:
       raise ValueError('a z-order change directive cannot move {} in front of itself'.format(repr(move_this)))
     return (ch, N.DIR_Z_ORDER, ord(move_this), 0 if in_front_of is None else ord(in_front_of), selector, 0, 0.0)
+  if name == 'next_chapter':  # the_plot.next_chapter = key (plot.py:299-324; examples/ordeal.py:177-235)
+    (key,) = args
+    if key is not None and (isinstance(key, bool) or int(key) != key or int(key) < 0):
+      raise ValueError('on the device a next_chapter is a chapter index (a non-negative integer key) or None')
+    return (ch, N.DIR_NEXT_CHAPTER, 0, 0, selector, N.CHAPTER_NONE if key is None else int(key), 0.0)
   raise ValueError('unknown plot directive {!r}'.format(name))
 
 

@@ -304,6 +304,19 @@ int pcx_engine_error_poll(pcx_engine* e, void* stream, int32_t* seen) {
   return e->error_poll.poll(e->out.error, e->batch, (hipStream_t)stream, seen);
 }
 
+int pcx_engine_next_chapter(pcx_engine* e, int32_t* next_host) {
+  if (!e || !next_host) return set_error(PCX_E_INVALID, "pcx_engine_next_chapter: bad arguments");
+  PCX_HIP(hipSetDevice(e->device));
+  const int32_t* words = e->backend->next_chapter_words();
+  if (!words) {
+    for (int64_t i = 0; i < e->batch; ++i) next_host[i] = PCX_CHAPTER_UNSET;
+    return 0;
+  }
+  PCX_HIP(hipDeviceSynchronize());
+  PCX_HIP(hipMemcpy(next_host, words, (size_t)e->batch * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int pcx_engine_errors_seen(pcx_engine* e, uint8_t* errors_host, int32_t clear) {
   if (!e || !e->out.error || !errors_host) return set_error(PCX_E_INVALID, "pcx_engine_errors_seen: bad arguments");
   PCX_HIP(hipSetDevice(e->device));

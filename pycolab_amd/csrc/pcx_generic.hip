@@ -53,6 +53,7 @@ struct Consts {
   int32_t game, R, C, cells, pitch, QW, L, NS, ND, NT, n_groups, RW, FW, NW, n_actions, n_bchars;
   int32_t occl;  // Engine(..., occlusion_in_layers)
   int32_t n_dir, zdyn, w_z;  // plot directives; any change_z_order among them; state offset of the z-order words
+  int32_t w_next;            // state offset of the_plot.next_chapter (-1: no entity assigns it)
   int32_t l_dir, l_zord, l_zabove, l_zabove_s, l_zabove_d, l_zq, l_ztmp;
   int32_t has_scroll, w_scroll;  // any Scrolly drape / egocentric walker; state offset of the protocol words
   int32_t n_sgroups;             // distinct scrolling groups among the things
@@ -120,6 +121,7 @@ struct Ctx {
   // by the ONE mw_move the kernel contains, right after the program switch (the probes behind a move
   // are the bulk of the code; a copy per program tripled the kernel and its register pressure).
   int mv_dr, mv_dc, mv_post;  // mv_post: 0 no move, 1 move, 2 move + BS patroller's catch check
+  int next;                   // the_plot.next_chapter as the episode's entities left it (PCX_CHAPTER_UNSET: untouched)
 };
 
 __device__ __forceinline__ bool on_board(const Consts& k, int r, int c) {
@@ -481,6 +483,7 @@ __device__ __forceinline__ void issue_directives(Ctx& x, int thing) {
     switch ((d[D_WHO] >> 8) & 0xFF) {
       case PCX_DIR_ADD_REWARD: add_reward(x, (int)d[D_REWARD]); break;
       case PCX_DIR_TERMINATE: terminate(x, __uint_as_float(d[D_DISCOUNT])); break;
+      case PCX_DIR_NEXT_CHAPTER: x.next = (int)d[D_REWARD]; break;  // plot.py:299-324: the last assignment stands
       case PCX_DIR_Z_ORDER:
         if (x.nzq < MAX_ZQ) x.l.zq[x.nzq++ * WAVE + x.lane] = d[D_WHO] >> 16;  // move_this | in_front_of << 8
         else x.err |= ERR_INDEX;
@@ -883,7 +886,8 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
   }
   const int ndw = k.ND * k.R * k.RW;
   if (!skip) {
-    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
+    Ctx x{k, l, lane, 0, action, 0, 0, 0, 0, 1.0f, {0, 0, 0, 0}, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0, PCX_CHAPTER_UNSET};
+    if (k.w_next >= 0 && !do_reset) x.next = (int)st[k.w_next * bp];  // (a new episode starts with the Story's own)
     // bits 8..15 of the flags word: MarauderDrape._dx + 1; W_RNG: RNG draws so far (survive resets)
     uint32_t draws = st[W_RNG * bp];
     int dxv;
@@ -1015,6 +1019,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
     flags = (x.game_over ? F_OVER : 0u) | ((x.err & 7u) << F_ERR_SHIFT) | ((uint32_t)((dxv + 1) & 0xFF) << 8);
     st[W_RNG * bp] = draws;
+    if (k.w_next >= 0) st[k.w_next * bp] = (uint32_t)x.next;
     st[W_FRAME * bp] = (uint32_t)x.frame;
     st[W_FLAGS * bp] = flags;
     for (int j = 0; j < 4; ++j) st[(W_V0 + j) * bp] = (uint32_t)x.v[j];
@@ -1155,6 +1160,9 @@ class GenericBackend : public Backend {
   }
   const char* kernel_name() const override { return "pcx_generic_step"; }
   const int32_t* sprite_track() const override { return track_.ptr; }
+  const int32_t* next_chapter_words() const override {
+    return k_.w_next >= 0 ? reinterpret_cast<const int32_t*>(state_.ptr + (size_t)k_.w_next * bpad_) : nullptr;
+  }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
   int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)(k_.ND ? k_.ND : 1) * k_.FW * bpad_); }
   int curtain_words() const override { return k_.FW; }
@@ -1353,6 +1361,7 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   // the z-order keeps it per environment (two state words)
   std::vector<uint32_t> dirs;
   k.n_dir = t.n_directives; k.zdyn = 0;
+  bool next_dir = false;
   if (k.n_dir < 0 || k.n_dir > PCX_MAX_DIRECTIVES) return set_error(PCX_E_INVALID, "generic backend: bad directive count");
   auto thing_of = [&](int ch) { for (int z = 0; z < k.NT; ++z) if (t.z_order[z] == ch) return z; return -1; };
   for (int i = 0; i < k.n_dir; ++i) {
@@ -1371,6 +1380,9 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
       k.zdyn = 1;
     } else if (dv.kind == PCX_DIR_TERMINATE) {
       if (!(dv.discount >= 0.0f && dv.discount <= 1.0f)) return set_error(PCX_E_INVALID, "Discount must be in range [0,1].");
+    } else if (dv.kind == PCX_DIR_NEXT_CHAPTER) {
+      if (dv.reward < PCX_CHAPTER_NONE) return set_error(PCX_E_INVALID, "generic backend: a next_chapter directive names chapter %d", dv.reward);
+      next_dir = true;
     } else if (dv.kind != PCX_DIR_ADD_REWARD) {
       return set_error(PCX_E_INVALID, "generic backend: unknown directive kind %d", dv.kind);
     }
@@ -1382,8 +1394,10 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
     dirs.push_back(dbits);
   }
   k.w_z = k.w_scroll + (k.has_scroll ? 1 + k.ND + 2 * k.NS : 0);
-  k.NW = k.w_z + (k.zdyn ? 2 : 0);
+  k.w_next = next_dir ? k.w_z + (k.zdyn ? 2 : 0) : -1;
+  k.NW = k.w_z + (k.zdyn ? 2 : 0) + (next_dir ? 1 : 0);
   std::vector<uint32_t> init(k.NW, 0), initd(ndw ? ndw : 1, 0);
+  if (next_dir) init[k.w_next] = (uint32_t)PCX_CHAPTER_UNSET;
   init[W_FRAME] = (uint32_t)-1;
   uint32_t dx_plus1 = 1;
   int32_t v[4] = {0, 0, (int32_t)NEVER, (int32_t)NEVER};

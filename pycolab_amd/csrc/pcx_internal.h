@@ -142,6 +142,9 @@ class Backend {
   virtual int ensure_curtains() { return 0; }
   virtual int curtain_words() const { return 0; }
   virtual int64_t batch_pad() const = 0;
+  // include/pcx.h pcx_engine_next_chapter: device int32[bpad] the entities' the_plot.next_chapter
+  // assignments live in, or null where the backend's entities never assign it
+  virtual const int32_t* next_chapter_words() const { return nullptr; }
   // include/pcx.h pcx_engine_export_state: every device array of the backend that carries an
   // episode from one launch to the next (state words incl. RNG counters, the croppers' sprite track)
   virtual void persistent_arrays(std::vector<std::pair<void*, size_t>>& out) = 0;

@@ -366,6 +366,19 @@ class Engine(object):
     return {k: self._b[k].numpy() for k in
             ('reward', 'reward_set', 'discount', 'done', 'frame', 'error')}
 
+  def entities_next_chapter(self):
+    """int32 [batch]: what every environment's entities last assigned to
+    `the_plot.next_chapter` in its current episode (a `('next_chapter', key)`
+    directive: plot.py:299-324) -- the chapter's index, `_native.CHAPTER_NONE` for
+    None, `_native.CHAPTER_UNSET` where no entity has.  Synchronises."""
+    self._b  # (raises after close())
+    out = np.empty((self._batch,), np.int32)
+    N.check(N.lib().pcx_engine_next_chapter(self._native, out.ctypes.data))
+    return out
+
+  def _assigns_next_chapter(self):
+    return any(d[1] == N.DIR_NEXT_CHAPTER for d in self.template.directives)
+
   def export_state(self, with_observation=False):
     """A checkpoint of every environment's episode as a NumPy uint8 array
     (`pcx_engine_export_state`): state words (entity state, Plot scalars, RNG

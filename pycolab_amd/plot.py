@@ -31,14 +31,23 @@ class Plot(dict):
 
   @property
   def next_chapter(self):
-    """Key/index of the next game in a `Story`, or None (plot.py:294-297)."""
+    """Key/index of the next game in a `Story`, or None (plot.py:294-297).  What a
+    game entity assigned on the device during this episode (a `('next_chapter',
+    key)` directive of a tabled entity) takes precedence over the host's value --
+    "the last call before termination determines what happens" (plot.py:310-311),
+    and entities run after the host has had its say."""
+    eng = self._engine
+    if eng is not None and eng._native is not None and eng.batch == 1 and eng._assigns_next_chapter():
+      from pycolab_amd import _native as N
+      v = int(eng.entities_next_chapter()[0])
+      if v != N.CHAPTER_UNSET:
+        return None if v == N.CHAPTER_NONE else v
     return self._next_chapter
 
   @next_chapter.setter
   def next_chapter(self, next_chapter):
-    """plot.py:299-324.  Entities' `update()` bodies are device programs here, so
-    this is set from the host (between `play()` calls) when a story's order is
-    not the list order."""
+    """plot.py:299-324.  From the host (between `play()` calls); entities assign it on
+    the device with a `('next_chapter', key)` directive (prefab_parts/tabled.py)."""
     self._next_chapter = next_chapter
 
   @property

@@ -24,6 +24,8 @@ under the value its directive field of the action holds (0 = none):
     ('terminate_episode', 0.5)           ... with a custom discount
     ('change_z_order', 'b', 'c')         the_plot.change_z_order('b', 'c') plot.py:136-174
     ('change_z_order', 'c', None)        ... all the way to the back
+    ('next_chapter', 2)                  the_plot.next_chapter = 2         plot.py:299-324
+    ('next_chapter', None)               ... = None: the Story ends after this game
 """
 
 from pycolab_amd.prefab_parts import drapes

@@ -20,16 +20,18 @@ chapter read that chapter's results, and the per-environment observation is
 assembled (on the device) over the union of the chapters' characters.  Engines
 of chapters an environment is not in keep stepping it with nobody looking --
 simple and correct, at the price of one launch per live chapter per step.
-Because entity `update()` bodies are device programs, `next_chapter` cannot be
-written by entities; set it from the host (`story.the_plot.next_chapter = k` at
-batch 1, `story.set_next_chapter(k_or_array)` at batch > 1) when a dict story's
-order is not known up front.
+`the_plot.next_chapter` (plot.py:299-324) is written either by entities on the
+device -- a `('next_chapter', key)` directive of a tabled entity, per environment,
+as examples/ordeal.py:177-235 does from inside `update()` -- or from the host
+(`story.the_plot.next_chapter = k` at batch 1, `story.set_next_chapter(k_or_array)`
+at batch > 1).
 """
 
 import collections
 
 import numpy as np
 
+from pycolab_amd import _native as _N
 from pycolab_amd import cropping
 from pycolab_amd import device as dev
 from pycolab_amd import engine
@@ -165,9 +167,15 @@ class Story(object):
         raise ValueError('one next chapter per environment')
       self._next_override = list(key)
 
-  def _next_of(self, env, chapter_index):
+  def _next_of(self, env, chapter_index, assigned=None):
+    """Where environment `env` goes after chapter `chapter_index`: what the host said
+    (`set_next_chapter`), else what the chapter's entities assigned to
+    `the_plot.next_chapter` (plot.py:299-324; `assigned`: the engine's per-environment
+    values), else the next chapter of a list."""
     if self._next_override is not None:
       return self._next_override[env]
+    if assigned is not None and assigned[env] != _N.CHAPTER_UNSET:
+      return None if assigned[env] == _N.CHAPTER_NONE else int(assigned[env])
     if not self._auto_advance:
       return None
     nxt = self._keys[chapter_index] + 1
@@ -221,8 +229,10 @@ class Story(object):
       starts = collections.defaultdict(lambda: np.zeros((self._batch,), bool))
       for key, mask in finished.items():
         ci = self._keys.index(key)
+        eng = self._engines[key]
+        assigned = eng.entities_next_chapter() if mask.any() and eng._assigns_next_chapter() else None
         for env in np.flatnonzero(mask):
-          nxt = self._next_of(env, ci)
+          nxt = self._next_of(env, ci, assigned)
           if nxt is None:
             self._chapter_of[env] = -1
           else:

@@ -11,19 +11,26 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 
-def chapters(batch):
+def chapters(batch, which='story_three_chapters'):
   from oracle import directive_scenarios as ds
   from pycolab_amd import ascii_art
   from pycolab_amd.prefab_parts import tabled
-  return [lambda spec=spec: ds.build_twin(spec, ascii_art, tabled).configure(batch=batch) for spec in ds.STORY]
+  specs = ds.STORY if which == 'story_three_chapters' else ds.STORY_JUMPS
+  return [lambda spec=spec: ds.build_twin(spec, ascii_art, tabled).configure(batch=batch) for spec in specs]
 
 
-def test_story_batch1_matches_reference_story():
+# story_entity_chapters: the games' entities assign the_plot.next_chapter themselves (plot.py:299-324,
+# as examples/ordeal.py:177-235 does) -- recorded from the reference's own Story
+STORIES = ['story_three_chapters', 'story_entity_chapters']
+
+
+@pytest.mark.parametrize('which', STORIES)
+def test_story_batch1_matches_reference_story(which):
   from pycolab_amd import storytelling
-  tr = helpers.load_trace_raw('story_three_chapters')
+  tr = helpers.load_trace_raw(which)
   T, E = tr['actions'].shape
   for e in range(0, E, 3):
-    story = storytelling.Story(chapters(1))
+    story = storytelling.Story(chapters(1, which))
     obs, r, d = story.its_showtime()
     row = 0
 
@@ -41,18 +48,19 @@ def test_story_batch1_matches_reference_story():
         with pytest.raises(RuntimeError):
           story.play(0)
         story.close()
-        story = storytelling.Story(chapters(1))
+        story = storytelling.Story(chapters(1, which))
         check(*story.its_showtime(), row)
         continue
       check(*story.play(int(tr['actions'][t, e])), row)
     story.close()
 
 
-def test_story_batched_every_environment_in_its_own_chapter():
+@pytest.mark.parametrize('which', STORIES)
+def test_story_batched_every_environment_in_its_own_chapter(which):
   from pycolab_amd import storytelling
-  tr = helpers.load_trace_raw('story_three_chapters')
+  tr = helpers.load_trace_raw(which)
   T, E = tr['actions'].shape
-  story = storytelling.Story(chapters(E), auto_reset=True)
+  story = storytelling.Story(chapters(E, which), auto_reset=True)
   chars = [chr(c) for c in tr['chars']]
 
   def check(result, row):
@@ -101,6 +109,33 @@ def test_story_batched_with_one_cropper_shared_by_all_chapters():
   assert set(things) == set('QRabDc')
   assert sum(storytelling.is_fictional(x) for x in things.values()) == 4
   story.close()
+
+
+@pytest.mark.parametrize('chapter', [0, 1, 2])
+def test_entities_next_chapter_matches_oracle(chapter):
+  """The PCX_DIR_NEXT_CHAPTER directive on its own: what the entities of each chapter game leave in
+  the_plot.next_chapter, HIP engine against the CPU oracle on the same random directive tapes."""
+  from oracle import binding, directive_scenarios as ds
+  from pycolab_amd import _native as N, ascii_art
+  from pycolab_amd.compiler import GameTemplate
+  from pycolab_amd.prefab_parts import tabled
+  from tests.hip_adapter import HipAdapter
+  t = GameTemplate.from_engine(ds.build_twin(ds.STORY_JUMPS[chapter], ascii_art, tabled))
+  B, T = 200, 60
+  rng = np.random.RandomState(50 + chapter)
+  tape = np.stack([ds.story_tape(rng, T) for _ in range(B)], axis=1)
+  hip, orc = HipAdapter(t, B), binding.OracleEngine(t, B)
+  hip.reset(); orc.reset()
+  seen = set()
+  for step in range(T):
+    auto = step % 7 != 3
+    hip.step(tape[step], auto_reset=auto); orc.step(tape[step], auto_reset=auto)
+    got, want = hip.eng.entities_next_chapter(), orc.next_chapter()
+    np.testing.assert_array_equal(got, want, err_msg='step %d' % step)
+    np.testing.assert_array_equal(hip.read('planes'), np.array(orc.planes), err_msg='step %d' % step)
+    np.testing.assert_array_equal(hip.read('done'), np.array(orc.done), err_msg='step %d' % step)
+    seen.update(int(v) for v in np.unique(got))
+  assert N.CHAPTER_UNSET in seen and len(seen) >= 3, seen
 
 
 def test_story_constructor_checks():
