@@ -86,7 +86,7 @@ struct Bits {
   }
 };
 
-template <int R, int C, int NWAVES, bool EPI = false>
+template <int R, int C, int NWAVES, bool EPI = false, bool UNOCC = false>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                       const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                       const crop::FusedCrops* fc) {
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
   constexpr int O_BD = 0, O_BDM = O_BD + QW, O_TAB_END = O_BDM + NB * QW;
   constexpr int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
   constexpr int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
+  constexpr int O_FLATRAW = O_WCORNER + stream::WCORNER_WORDS, O_SDESCRAW = (O_FLATRAW + WAVE * FWP + 1) & ~1;  // UNOCC only
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
   uint32_t* const flat = lds + O_FLAT;
@@ -232,6 +233,8 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
       uint32_t above[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) { cellv[s] = ((k.visible >> s) & 1) ? row[s] * C + col[s] : -1; above[s] = k.above[s]; }
+      if constexpr (UNOCC)  // occlusion_in_layers=False: the layers are the raw masks (rendering.py:236-278)
+        stream::snapshot_raw<NS, ND>(cellv, flat, FW, FWP, lane, lds + O_FLATRAW, reinterpret_cast<uint2*>(lds + O_SDESCRAW));
       stream::resolve_sprites<NS, ND>(cellv, above, flat, FWP, lane, sdesc);
     }
     skipv[lane] = skip;
@@ -248,8 +251,9 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
-    stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                        flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+    stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                               flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, 0, lds + O_FLATRAW,
+                                                               reinterpret_cast<const uint2*>(lds + O_SDESCRAW));
   if (fc)
     stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
 }
@@ -277,8 +281,13 @@ class HelloWorldBackend : public Backend {
     out.push_back({track_.ptr, track_.count * sizeof(int32_t)});
   }
   int plane_pitch() const override { return lay_.pitch; }
-  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
+  int set_fused_croppers(const crop::FusedCrops* fc) override {
+    if (fc && fc->n > 0 && unoccluded_)  // (the windows derive their layers from the board they cut)
+      return set_error(PCX_E_UNSUPPORTED, "hello_world backend: fused croppers need occluded layers");
+    return fused_.set(fc);
+  }
   int set_epilogue(const pcx_epilogue_desc* d) override {  // include/pcx.h pcx_engine_set_epilogue
+    if (d && unoccluded_) return set_error(PCX_E_UNSUPPORTED, "hello_world backend: the feature-array epilogue needs occluded layers");
     int sc[NS], dc = k_.drape_ch4 & 0xFF, bc[NB > 0 ? NB : 1] = {};
     for (int s = 0; s < NS; ++s) sc[s] = k_.sprite_ch4[s] & 0xFF;
     for (int b = 0; b < NB; ++b) bc[b] = k_.bchar_ch4[b] & 0xFF;
@@ -292,6 +301,7 @@ class HelloWorldBackend : public Backend {
   stream::EpilogueArgs epi_{};
   stream::Layout lay_;
   int R_ = 0, C_ = 0, L_ = 0, NW_ = 0;
+  bool unoccluded_ = false;  // Engine(..., occlusion_in_layers=False)
   int64_t batch_ = 0, bpad_ = 0;
   int num_cus_ = 256;
   DevArray<uint32_t> tables_, initc_, state_, curtains_;
@@ -303,7 +313,8 @@ int HelloWorldBackend::init(const pcx_template& t, int64_t batch) {
   batch_ = batch;
   bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
   if (const char* e = getenv("PCX_FORCE_GENERIC")) if (atoi(e)) return set_error(PCX_E_UNSUPPORTED, "hello_world backend: PCX_FORCE_GENERIC");
-  if (!t.occlusion_in_layers || t.n_directives) return set_error(PCX_E_UNSUPPORTED, "hello_world backend: occluded layers, no directives");
+  if (t.n_directives) return set_error(PCX_E_UNSUPPORTED, "hello_world backend: no directives");
+  unoccluded_ = !t.occlusion_in_layers;  // (no entity of this game reads a layer: only the layer planes differ)
   R_ = t.rows; C_ = t.cols; L_ = t.n_chars;
   bool shape_ok = false;
 #define X(r, c) shape_ok |= R_ == r && C_ == c;
@@ -391,7 +402,8 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
-  size_t lds = ((size_t)lay_.QW * (1 + NB) + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4;
+  size_t lds = ((size_t)lay_.QW * (1 + NB) + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS +
+                (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS * WAVE : 0)) * 4;
   if (!coop && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
     if (want > 64 * 1024) want = 64 * 1024;
@@ -400,7 +412,9 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   bool launched = false;
 #define X(r, c)                                                                                                  \
   if (!launched && R_ == r && C_ == c) {                                                                         \
-    if (epi_.out && coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    if (unoccluded_ && coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4, false, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else if (unoccluded_) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, false, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());       \
+    else if (epi_.out && coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
     else if (epi_.out) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());       \
     else if (coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
     else hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());          \

@@ -65,6 +65,22 @@ __device__ __forceinline__ void resolve_sprites(const int (&cell)[NS], const uin
   }
 }
 
+// Engine(..., occlusion_in_layers=False) (rendering.py:187-301 BaseUnoccludedObservationRenderer):
+// the board is painted as ever, the layers are the things' RAW masks -- a drape's whole curtain, a
+// visible sprite's own cell, the backdrop character wherever the backdrop has it.  Call before
+// resolve_sprites(): it keeps a copy of the curtains (FW words each) and of the sprites' cells
+// that the occlusion pass will not touch; stream_planes<..., UNOCC = true> takes the layers from it.
+template <int NS, int ND>
+__device__ __forceinline__ void snapshot_raw(const int (&cell)[NS], const uint32_t* flat, int FW, int FWP, int lane,
+                                             uint32_t* flatraw, uint2* sdescraw) {
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+    for (int w = 0; w < FW; ++w) flatraw[(d * WAVE + lane) * FWP + w] = flat[(d * WAVE + lane) * FWP + w];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    sdescraw[s * WAVE + lane] = make_uint2(cell[s] >= 0 ? (uint32_t)(cell[s] >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell[s] & 3) * 8));
+}
+
 // What the streaming loop needs besides LDS: all wave-uniform.
 template <int NS, int ND, int NB>
 struct PlaneMap {
@@ -105,12 +121,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //     per-environment bit mask over the template's list of its cells instead of a
 //     flat curtain: cell_ids[q] = the list indices of board dword q's four cells
 //     (0xFF = not a cell of the drape), `flat` = [64][FWP] alive masks.  Needs ND == 1.
-template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI>
+//   UNOCC: occlusion_in_layers=False -- the layers come from the raw copies snapshot_raw() kept.
+template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI, bool UNOCC = false>
 __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
                                               const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
                                               const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
                                               const EpilogueArgs& epi, int64_t env0, const uint32_t* cell_ids = nullptr,
-                                              int qw_rt = 0) {
+                                              int qw_rt = 0, const uint32_t* flatraw = nullptr, const uint2* sdescraw = nullptr) {
   const uint32_t QWv = QW ? (uint32_t)QW : (uint32_t)qw_rt;
   uint8_t* const pb_board = uniform_ptr(group_base);
   uint8_t* pb_s[NS];
@@ -226,6 +243,19 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
     put(pb_board, d);
     // rendering.py:177-179 layers[c] = (board == c): by construction the thing's
     // own mask, or the backdrop's precomputed mask where no thing paints
+    if constexpr (UNOCC) {  // rendering.py:236-278: raw masks, the backdrop's included
+#pragma unroll
+      for (int dd = 0; dd < ND; ++dd) {
+        const uint32_t bits = (flatraw[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;
+        md[dd] = (bits * 0x00204081u) & 0x01010101u;
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const uint2 sr = sdescraw[s * WAVE + e_now];
+        ms[s] = sr.x == q_now ? sr.y : 0u;
+      }
+      uni = 0;
+    }
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) put_layer(pb_d[dd], md[dd] & 0x01010101u, epi.drape_slot[dd]);
 #pragma unroll

@@ -77,7 +77,7 @@ __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16
 // per workgroup (wave 0 steps the group, all of them share the render loop).
 // SR x SC: the board's shape when the instance is compiled for it; 0 x 0: read from k.rows / k.cols
 // (levels that are neither shipped nor among the fixtures' compiled shapes).
-template <int NS, int SR, int SC, int NB, int NWAVES, bool EPI = false>
+template <int NS, int SR, int SC, int NB, int NWAVES, bool EPI = false, bool UNOCC = false>
 __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                     const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                     const crop::FusedCrops* fc) {
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
             O_TAB_END = O_PBLK + R;
   const int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
   const int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
+  const int O_FLATRAW = O_WCORNER + stream::WCORNER_WORDS, O_SDESCRAW = (O_FLATRAW + WAVE * FWP + 1) & ~1;  // UNOCC only
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
   const uint32_t* const goal_rows = lds + O_GOAL;
@@ -266,6 +267,8 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
       uint32_t above[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) { cellv[s] = vis[s] ? true_cell(vr[s], vc[s]) : -1; above[s] = k.above[s]; }
+      if constexpr (UNOCC)  // occlusion_in_layers=False: the layers are the raw masks (rendering.py:236-278)
+        stream::snapshot_raw<NS, 1>(cellv, flat, FW, FWP, lane, lds + O_FLATRAW, reinterpret_cast<uint2*>(lds + O_SDESCRAW));
       stream::resolve_sprites<NS, 1>(cellv, above, flat, FWP, lane, sdesc);
 
       // ---- _apply_and_clear_plot (engine.py:761-847) + state write-back ---------
@@ -311,8 +314,9 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
-    stream::stream_planes<NS, 1, NB, SQW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                 flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, QW);
+    stream::stream_planes<NS, 1, NB, SQW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                        flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, QW, lds + O_FLATRAW,
+                                                        reinterpret_cast<const uint2*>(lds + O_SDESCRAW));
   if (fc)
     stream::stream_windows<NS, 1, NB, SQW, NWAVES, SR, SC>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner,
                                                          nullptr, stream::BoardShape{R, C, QW});
@@ -347,9 +351,13 @@ class WarehouseBackend : public Backend {
     out.push_back({track_.ptr, track_.count * sizeof(int32_t)});
   }
   int plane_pitch() const override { return lay_.pitch; }
-  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
+  int set_fused_croppers(const crop::FusedCrops* fc) override {
+    if (fc && fc->n > 0 && unoccluded_)  // (the windows derive their layers from the board they cut)
+      return set_error(PCX_E_UNSUPPORTED, "warehouse backend: fused croppers need occluded layers");
+    return fused_.set(fc);
+  }
   int set_epilogue(const pcx_epilogue_desc* d) override {
-    if (d && !static_shape_) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: the feature-array epilogue exists for the compiled shapes");
+    if (d && (!static_shape_ || unoccluded_)) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: the feature-array epilogue exists for the compiled shapes, occluded layers");
     if (!stream::fill_epilogue(epi_, d, lay_.cells, sprite_ch_, NS_, &drape_ch_, 1, bchar_ch_, NB_))
       return set_error(PCX_E_UNSUPPORTED, "warehouse backend: epilogue needs rows*cols %% 4 == 0");
     return 0;
@@ -359,6 +367,7 @@ class WarehouseBackend : public Backend {
   stream::FusedCropsHolder fused_;
   Consts k_{};
   stream::EpilogueArgs epi_{};
+  bool unoccluded_ = false;  // Engine(..., occlusion_in_layers=False): the run-time-shape instances' UNOCC variant
   int sprite_ch_[MAX_NS] = {}, drape_ch_ = 0, bchar_ch_[MAX_NB] = {};
   stream::Layout lay_;
   int NS_ = 0, R_ = 0, C_ = 0, NB_ = 0, L_ = 0, NW_ = 0;
@@ -375,7 +384,9 @@ int WarehouseBackend::init(const pcx_template& t, int64_t batch) {
   batch_ = batch;
   bpad_ = (batch + WAVE - 1) / WAVE * WAVE;
   if (const char* e = getenv("PCX_FORCE_GENERIC")) if (atoi(e)) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: PCX_FORCE_GENERIC");
-  if (!t.occlusion_in_layers) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: occlusion_in_layers=False");
+  // occlusion_in_layers=False: the game's rules read nothing an unoccluded layer changes (the boxes look at
+  // layers['P'], and nothing is ever in front of P: checked below); only the layer planes differ
+  unoccluded_ = !t.occlusion_in_layers;
   if (t.n_directives) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: plot directives");
   NS_ = t.n_sprites; R_ = t.rows; C_ = t.cols; L_ = t.n_chars;
   NB_ = L_ - NS_ - 1;
@@ -386,7 +397,7 @@ int WarehouseBackend::init(const pcx_template& t, int64_t batch) {
   // any other level takes a run-time-shape instance (one per number of sprites): rows of at most 32 cells
   // (goal / blocked tables are a word per row), the usual four backdrop-only characters
   const bool dynamic_ok = NS_ >= 2 && NS_ <= MAX_NS && NB_ == 4 && C_ <= 32 && R_ <= 255;
-  if (t.n_drapes != 1 || !(static_shape_ || dynamic_ok) || NS_ > MAX_NS || NB_ > MAX_NB)
+  if (t.n_drapes != 1 || !(static_shape_ || dynamic_ok) || NS_ > MAX_NS || NB_ > MAX_NB || (unoccluded_ && !dynamic_ok))
     return set_error(PCX_E_UNSUPPORTED, "warehouse backend: no instance for this shape");
   lay_.set(R_, C_);
   k.rows = R_; k.cols = C_;
@@ -520,7 +531,8 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
-  const size_t words = (size_t)lay_.QW * (1 + NB_) + 3 * R_ + WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE + WAVE + stream::WCORNER_WORDS;
+  const size_t words = (size_t)lay_.QW * (1 + NB_) + 3 * R_ + WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE + WAVE + stream::WCORNER_WORDS +
+                       (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE : 0);
   size_t lds = words * 4;
   if (!coop && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
@@ -532,7 +544,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
 #define PCX_WM_LAUNCH(ns, r, c, nb, nw, ep)                                                                  \
   hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, nw, ep>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr())
 #define X(ns, r, c, nb)                                                                                     \
-  if (!launched && NS_ == ns && R_ == r && C_ == c && NB_ == nb) {                                          \
+  if (!launched && !unoccluded_ && NS_ == ns && R_ == r && C_ == c && NB_ == nb) {                          \
     if (epi && coop) PCX_WM_LAUNCH(ns, r, c, nb, 4, true);                                                  \
     else if (epi) PCX_WM_LAUNCH(ns, r, c, nb, 1, true);                                                     \
     if (!epi && coop) PCX_WM_LAUNCH(ns, r, c, nb, 4, false);                                                \
@@ -541,12 +553,15 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   }
   PCX_WM_SHAPES(X)
 #undef X
-  if (!launched && !static_shape_ && !epi) {  // run-time-shape instances, one per number of sprites
+  if (!launched && (!static_shape_ || unoccluded_) && !epi) {  // run-time-shape instances, one per number of sprites
     if (lds > 64 * 1024) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: board too large for the step kernel's LDS tables");
     switch (NS_) {
 #define PCX_WM_DYN(ns)                                                                                      \
   case ns:                                                                                                  \
-    if (coop) PCX_WM_LAUNCH(ns, 0, 0, 4, 4, false); else PCX_WM_LAUNCH(ns, 0, 0, 4, 1, false);              \
+    if (unoccluded_) {                                                                                      \
+      if (coop) hipLaunchKernelGGL((pcx_warehouse_step<ns, 0, 0, 4, 4, false, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+      else hipLaunchKernelGGL((pcx_warehouse_step<ns, 0, 0, 4, 1, false, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());          \
+    } else if (coop) PCX_WM_LAUNCH(ns, 0, 0, 4, 4, false); else PCX_WM_LAUNCH(ns, 0, 0, 4, 1, false);      \
     launched = true;                                                                                        \
     break;
       PCX_WM_DYN(2) PCX_WM_DYN(3) PCX_WM_DYN(4) PCX_WM_DYN(5) PCX_WM_DYN(6) PCX_WM_DYN(7) PCX_WM_DYN(8) PCX_WM_DYN(9)

@@ -164,7 +164,9 @@ def test_hip_hand_written_kernels_other_launch_shapes(name, knob, value, monkeyp
                                          ('hello_custom_A', 'pcx_hello_world_step'),
                                          ('warehouse_custom_C', 'pcx_warehouse_step'), ('warehouse_custom_D', 'pcx_warehouse_step'),
                                          ('better_scrolly_custom_A', 'pcx_better_scrolly_step'), ('better_scrolly_custom_B', 'pcx_better_scrolly_step'),
-                                         ('warehouse_L0_unoccluded', 'pcx_generic_step')])
+                                         # occlusion_in_layers=False: the warehouse kernel's own UNOCC instances (round 3);
+                                         # marauders' rules read layers, so its unoccluded variant stays table-driven
+                                         ('warehouse_L0_unoccluded', 'pcx_warehouse_step'), ('marauders_unoccluded', 'pcx_generic_step')])
 @pytest.mark.parametrize('shape', ['coop', 'single'])
 def test_which_kernel_steps_which_game(name, kernel, shape, monkeypatch):
   """The shipped shapes run the hand-written kernels, everything else the table-driven
@@ -188,6 +190,33 @@ def test_which_kernel_steps_which_game(name, kernel, shape, monkeypatch):
     a[(r >= 0.03) & (r < 0.04)] = t.n_actions   # the quit action of every shipped game
     hip.step(a, auto_reset=step % 5 != 4); orc.step(a, auto_reset=step % 5 != 4)
     assert_same(hip, orc, '%s step %d' % (name, step))
+
+
+@pytest.mark.parametrize('shape', ['coop', 'single'])
+@pytest.mark.parametrize('name,kernel', [('hello_world', 'pcx_hello_world_step'), ('hello_custom_A', 'pcx_hello_world_step'),
+                                         ('warehouse_L2', 'pcx_warehouse_step'), ('warehouse_custom_C', 'pcx_warehouse_step')])
+def test_unoccluded_layers_from_the_hand_written_kernels(name, kernel, shape, monkeypatch):
+  """Engine(..., occlusion_in_layers=False) (rendering.py:187-301) on games whose rules read no layer an
+  unoccluded renderer changes: the hand-written kernels' UNOCC instances, against the oracle's unoccluded
+  renderer -- raw drape curtains, visible sprites' own cells, the backdrop's characters where the backdrop has them."""
+  if shape == 'single':
+    monkeypatch.setenv('PCX_COOP_BELOW', '0')
+  from pycolab_amd import _native as N
+  t = helpers.load_template(name)
+  t.occlusion_in_layers = False
+  B = 200
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  assert N.lib().pcx_engine_kernel_name(hip.eng._native).decode() == kernel
+  rng = np.random.RandomState(18)
+  differs = False
+  for step in range(40):
+    a = rng.randint(0, t.n_actions, size=B).astype(np.int32)
+    hip.step(a, auto_reset=step % 5 != 4); orc.step(a, auto_reset=step % 5 != 4)
+    assert_same(hip, orc, '%s step %d' % (name, step))
+    planes = hip.read('planes')
+    differs |= bool((planes[:, 1:] != (planes[:, :1] == np.array(list(t.chars), np.uint8)[None, :, None, None])).any())
+  assert differs, 'no layer ever differed from board == char: the unoccluded renderer was not exercised'
 
 
 @pytest.mark.parametrize('fuse', ['0', '1'])
