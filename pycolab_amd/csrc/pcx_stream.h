@@ -101,6 +101,9 @@ struct EpilogueArgs {
   uint32_t env_stride = 0;   // bytes per environment = depth * cells * 4
   uint32_t plane_bytes = 0;  // cells * 4
   int32_t skip_layers = 0;
+  // the loop runs twice, first for the uint8 planes, then for the float32 planes: a wave then feeds half
+  // as many write streams at a time (it composes every dword twice; the loop is store-bound)
+  int32_t two_pass = 0;
   int32_t sprite_slot[PCX_MAX_SPRITES], drape_slot[PCX_MAX_DRAPES], bchar_slot[PCX_MAX_CHARS];
 };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -146,9 +149,12 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   // register of an older store with a vmcnt(0) inside the loop.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt/lgkmcnt untouched
 
-  constexpr uint32_t ADV = NWAVES * WAVE;             // tasks between a wave's consecutive iterations
+  const bool two_pass = EPI && epi.two_pass && !epi.skip_layers;
+  constexpr int lwaves = NWAVES;
+  const int lwave = wave;
+  constexpr uint32_t ADV = (uint32_t)lwaves * WAVE;   // tasks between a wave's consecutive iterations
   const uint32_t DE = ADV / QWv, DQ = ADV - DE * QWv;  // ... as whole environments + dwords (constants when QW != 0)
-  const uint32_t f0 = (uint32_t)(wave * WAVE + lane);
+  const uint32_t f0 = (uint32_t)(lwave * WAVE + lane);
   uint32_t e = f0 / QWv, q = f0 - e * QWv;  // once
   uint32_t voff = e * env_stride + 4u * q, eF = e * (uint32_t)FWP;
   const uint32_t dvoff = DE * env_stride + 4u * DQ, dF = DE * (uint32_t)FWP;
@@ -163,8 +169,13 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(epi.out) + (size_t)env0 * epi.env_stride);
   uint32_t foff = e * epi.env_stride + 16u * q;
   const uint32_t dfoff = DE * epi.env_stride + 16u * DQ, wrap_foff = epi.env_stride - 16u * QWv;
+  const uint32_t e_0 = e, q_0 = q, voff_0 = voff, eF_0 = eF, foff_0 = foff;
 #pragma unroll 1
-  for (int it = wave; it < (int)QWv; it += NWAVES) {
+  for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
+  const int role = two_pass ? pass : -1;  // 0: the uint8 planes, 1: the float32 planes, -1: both
+  e = e_0; q = q_0; voff = voff_0; eF = eF_0; foff = foff_0;
+#pragma unroll 1
+  for (int it = lwave; it < (int)QWv; it += lwaves) {
     const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF, foff_now = foff;
     q += DQ; e += DE; voff += dvoff; eF += dF; foff += dfoff;
     {
@@ -179,11 +190,11 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
     // (only the single-wave shape without epilogue -- the store-issue-bound one, few enough plane
     // bases to stay in SGPRs -- takes the bare store; see pcx_internal.h saddr_store_dword)
     constexpr bool GUARD = NWAVES > 1 || EPI;
-    auto put = [&](uint8_t* base, uint32_t v) { saddr_store_dword<GUARD>(voff_now, v, base); };
+    auto put = [&](uint8_t* base, uint32_t v) { if (role != 1) saddr_store_dword<GUARD>(voff_now, v, base); };
     // a layer: its uint8 plane and, when selected, its float32 feature plane
     auto put_layer = [&](uint8_t* base, uint32_t m01, int32_t slot) {
       if (layers_on) put(base, m01);
-      if (epi_on && slot >= 0) {
+      if (epi_on && slot >= 0 && role != 0) {
         f32x4 f;
         f.x = (float)(m01 & 0xFFu); f.y = (float)((m01 >> 8) & 0xFFu); f.z = (float)((m01 >> 16) & 0xFFu); f.w = (float)(m01 >> 24);
         const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
@@ -263,6 +274,7 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
 #pragma unroll
     for (int b = 0; b < NB; ++b) put_layer(pb_b[b], mb[b] & ~uni, epi.bchar_slot[b]);
   }
+  }  // passes
 }
 
 // ---------------------------------------------------------------------------
@@ -491,6 +503,11 @@ inline bool fill_epilogue(EpilogueArgs& a, const pcx_epilogue_desc* d, int cells
   a.env_stride = (uint32_t)d->depth * (uint32_t)cells * 4u;
   a.plane_bytes = (uint32_t)cells * 4u;
   a.skip_layers = d->skip_layers != 0;
+  // more than sixteen write streams per wave (board + layers + float planes) go faster as two passes
+  // (marauders 32,768: 0.275 -> 0.198 ms, step + separate kernel: 0.280; hello_world's fifteen do not:
+  // profiles/r03_post_kernels.md)
+  a.two_pass = 1 + ns + nd + nb + d->depth > 16;
+  if (const char* e = getenv("PCX_EPI_TWO_PASS")) a.two_pass = atoi(e) != 0;
   for (int f = 0; f < d->depth; ++f) {
     for (int i = 0; i < ns; ++i) if (sprite_ch[i] == d->chars[f]) a.sprite_slot[i] = f;
     for (int i = 0; i < nd; ++i) if (drape_ch[i] == d->chars[f]) a.drape_slot[i] = f;
