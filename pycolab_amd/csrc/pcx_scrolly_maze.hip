@@ -288,6 +288,70 @@ __device__ __forceinline__ bool blocked_at(const Consts& k, const Lds& l, const 
   return onb ? blocked : k.confined[s] != 0;  // EDGE
 }
 
+// The same probe for a walker that is the LANE's own (cooperative shape, four lanes per environment:
+// lane j steps sprite j): what blocked_at() reads from Consts by compile-time index arrives as values.
+struct WalkerConsts {
+  uint32_t relevant, imp_z;
+  bool relevant_backdrop, confined;
+  uint64_t imp_lo, imp_hi;
+};
+template <int NS>
+__device__ __forceinline__ WalkerConsts walker_consts(const Consts& k, int j) {
+  WalkerConsts c{k.relevant[0], k.imp_z[0], k.relevant_backdrop[0] != 0, k.confined[0] != 0,
+                 (uint64_t)k.imp[0][0] | ((uint64_t)k.imp[0][1] << 32), (uint64_t)k.imp[0][2] | ((uint64_t)k.imp[0][3] << 32)};
+#pragma unroll
+  for (int s = 1; s < NS; ++s) {
+    const bool hit = j == s;
+    c.relevant = hit ? k.relevant[s] : c.relevant;
+    c.imp_z = hit ? k.imp_z[s] : c.imp_z;
+    c.relevant_backdrop = hit ? k.relevant_backdrop[s] != 0 : c.relevant_backdrop;
+    c.confined = hit ? k.confined[s] != 0 : c.confined;
+    c.imp_lo = hit ? ((uint64_t)k.imp[s][0] | ((uint64_t)k.imp[s][1] << 32)) : c.imp_lo;
+    c.imp_hi = hit ? ((uint64_t)k.imp[s][2] | ((uint64_t)k.imp[s][3] << 32)) : c.imp_hi;
+  }
+  return c;
+}
+template <int NS>
+__device__ __forceinline__ bool blocked_at_lane(const Consts& k, const Lds& l, const Snap<NS>& sn, const WalkerConsts& wc,
+                                                const Walker& w, int dr, int dc, int col, uint32_t& err) {
+  const int r0 = w.vr + dr, c0 = w.vc + dc;
+  const bool onb = on_board(k, r0, c0);
+  const int r = onb ? r0 : 0, c = onb ? c0 : 0;
+  uint32_t present = 0;
+  const int cell = r * k.C + c;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) present |= (uint32_t)(sn.cell[j] == cell) << k.zpos_sprite[j];
+  {
+    const int pr = sn.maze_r + r, pc = sn.maze_c + c;
+    const bool in = (unsigned)pr < (unsigned)k.PR && (unsigned)pc < (unsigned)k.PC;
+    const uint32_t wbits = l.walls[in ? pr * k.WPR + (pc >> 5) : 0];
+    if (onb && !in && ((wc.relevant >> k.zpos_maze) & 1)) err |= ERR_INDEX;
+    present |= (uint32_t)(in && ((wbits >> (pc & 31)) & 1u)) << k.zpos_maze;
+  }
+  {
+    const int id = coin_id_at(k, l, sn.cash_r + r, sn.cash_c + c);
+    const bool there = id >= 0 && (coin_alive(l, col, id < 0 ? 0 : id) || (uint32_t)id == sn.stale);
+    present |= (uint32_t)there << k.zpos_cash;
+  }
+  present &= wc.relevant;  // (things that cannot change this walker's verdict were never looked at in blocked_at())
+  bool blocked = (wc.imp_z >> (present ? 31 - __clz((int)present) : 0)) & 1;
+  const int top = (l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
+  const uint64_t half = top < 64 ? wc.imp_lo : wc.imp_hi;
+  const bool back = wc.relevant_backdrop && top < 128 && ((half >> (top & 63)) & 1ull) != 0;
+  blocked = present ? blocked : back;
+  return onb ? blocked : wc.confined;  // EDGE
+}
+template <int NS>
+__device__ __forceinline__ bool check_motion_lane(const Consts& k, const Lds& l, const Snap<NS>& sn, const WalkerConsts& wc,
+                                                  const Walker& w, int dr, int dc, int col, uint32_t& err) {
+  if (dr == 0 && dc == 0) return false;
+  if (dr != 0 && dc != 0) {
+    if (blocked_at_lane<NS>(k, l, sn, wc, w, dr, dc, col, err)) return true;
+    return blocked_at_lane<NS>(k, l, sn, wc, w, dr, 0, col, err) && blocked_at_lane<NS>(k, l, sn, wc, w, 0, dc, col, err);
+  }
+  return blocked_at_lane<NS>(k, l, sn, wc, w, dr, dc, col, err);
+}
+
 // sprites.py:479-546 _check_motion
 template <int NS>
 __device__ __forceinline__ bool check_motion(const Consts& k, const Lds& l, const Snap<NS>& sn, int s,
@@ -720,7 +784,79 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       if (moves) mw_move<NS, ego_s>(k, l, sn, s, w[s], p, dr, dc, col, err, quad_j);                    \
     }                                                                                            \
   }
+    bool group1_done = false;
+    if constexpr (COOP && IP >= 0 && IE == IP && NS == 4) {
+      if (quad) {
+        // Four lanes per environment: lane j steps sprite j -- the three patrollers and the player move at
+        // once, each against the same repaint (they are one update group) -- then all four probe two of the
+        // player's eight neighbours for its scroll permits, and the quad exchanges what changed.
+        group1_done = true;
+        const int qbase = lane & ~3;
+        const bool is_player = quad_j == IP;
+        const WalkerConsts wc = walker_consts<NS>(k, quad_j);
+        Walker me = pick<NS, -1>(w, quad_j);
+        const Walker pl_before = w[IP];  // (the player updates last: the patrollers' catch test sees it where it was)
+        const bool walks = !(p.frame & 1);
+        int mdr = is_player ? dr : 0, mdc = is_player ? dc : 0;
+        if (!is_player && walks) {  // scrolly_maze.py:284-305
+          if (!maze.moved) { maze.pre_r = maze.r; maze.pre_c = maze.c; }
+          int pr = me.vr + maze.pre_r, pc = me.vc + maze.pre_c + (me.var ? 1 : -1);
+          if (pr < 0) pr += k.PR;
+          if (pc < 0) pc += k.PC;
+          if (wall_at(k, l, pr, pc, err)) me.var ^= 1;
+          mdc = me.var ? 1 : -1;
+        }
+        if (!maze.moved) { maze.pre_r = maze.r; maze.pre_c = maze.c; }  // (what the patroller lanes noted, on every lane)
+        const bool calls_move = !is_player || moves;
+        if (calls_move) {  // sprites.py:356-389 _move
+          if (is_player) p.flags |= F_REGISTERED;
+          if (p.order_valid) {
+            teleport(k, me, me.vr - p.o0, me.vc - p.o1);
+            if (is_player && p.o0 != mdr && p.o1 != mdc) err |= ERR_SCROLL;
+          }
+          if (!check_motion_lane<NS>(k, l, sn, wc, me, mdr, mdc, col, err)) teleport(k, me, me.vr + mdr, me.vc + mdc);
+        }
+        if (!is_player && walks && me.vr == pl_before.vr && me.vc == pl_before.vc) { p.game_over = 1; p.discount = 0.0f; }
+        // everybody learns everybody's new state
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+          w[s2].vr = __shfl(me.vr, qbase | s2); w[s2].vc = __shfl(me.vc, qbase | s2);
+          w[s2].vis = __shfl(me.vis, qbase | s2); w[s2].prior = __shfl(me.prior, qbase | s2); w[s2].var = __shfl(me.var, qbase | s2);
+        }
+        // sprites.py:456-477: the player's permits, two neighbours per lane (N S | W E | NW NE | SW SE)
+        uint32_t nb = 0;
+        if (moves) {
+          const int a0 = quad_j == 0 ? -1 : quad_j == 1 ? 0 : quad_j == 2 ? -1 : 1, b0 = quad_j == 0 ? 0 : -1;
+          const int a1 = quad_j == 0 ? 1 : quad_j == 1 ? 0 : quad_j == 2 ? -1 : 1, b1 = quad_j == 0 ? 0 : 1;
+          nb = (uint32_t)blocked_at<NS>(k, l, sn, IP, w[IP], a0, b0, col, err) << (2 * quad_j);
+          nb |= (uint32_t)blocked_at<NS>(k, l, sn, IP, w[IP], a1, b1, col, err) << (2 * quad_j + 1);
+        }
+        nb |= err << 8 | (uint32_t)p.game_over << 11;
+        nb |= (uint32_t)__shfl_xor((int)nb, 1);
+        nb |= (uint32_t)__shfl_xor((int)nb, 2);
+        err |= (nb >> 8) & 7u;
+        if ((nb >> 11) & 1u) { p.game_over = 1; p.discount = 0.0f; }
+        p.flags = (uint32_t)__shfl((int)p.flags, qbase | IP);  // (only the player's lane registered)
+        if (moves) {
+          const bool n = nb & 1u, so = (nb >> 1) & 1u, we = (nb >> 2) & 1u, ea = (nb >> 3) & 1u;
+          const bool nw = (nb >> 4) & 1u, ne = (nb >> 5) & 1u, sw = (nb >> 6) & 1u, se = (nb >> 7) & 1u;
+          uint32_t legal = 1u << motion_bit(0, 0);
+          legal |= (uint32_t)!n << motion_bit(-1, 0) | (uint32_t)!so << motion_bit(1, 0);
+          legal |= (uint32_t)!we << motion_bit(0, -1) | (uint32_t)!ea << motion_bit(0, 1);
+          legal |= (uint32_t)!(nw || (n && we)) << motion_bit(-1, -1) | (uint32_t)!(ne || (n && ea)) << motion_bit(-1, 1);
+          legal |= (uint32_t)!(sw || (so && we)) << motion_bit(1, -1) | (uint32_t)!(se || (so && ea)) << motion_bit(1, 1);
+          const int my_frame = p.frame + 1;
+          uint32_t mask = (p.flags >> F_PERMIT_SHIFT) & 0x1FF;
+          if (!(p.flags & F_PERMIT_VALID) || p.permit_frame != my_frame) mask = 0;
+          mask |= legal;
+          p.flags = (p.flags & ~(0x1FFu << F_PERMIT_SHIFT)) | (mask << F_PERMIT_SHIFT) | F_PERMIT_VALID;
+          p.permit_frame = my_frame;
+        }
+      }
+    }
+    if (!group1_done) {
     PCX_SM_SPRITE(0) PCX_SM_SPRITE(1) PCX_SM_SPRITE(2) PCX_SM_SPRITE(3) PCX_SM_SPRITE(4) PCX_SM_SPRITE(5)
+    }
 #undef PCX_SM_SPRITE
 
     // group 2: CashDrape.update (scrolly_maze.py:341-364)
