@@ -1752,7 +1752,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   {
     // several steps per launch (pcx_engine_step_n / _step_hashed) pay off where one
     // wave per group cannot fill the chip; PCX_FUSE_STEPS=0 turns them off
-    int below = 5;
+    int below = 4;
     if (const char* e = getenv("PCX_COOP_BELOW")) below = atoi(e);
     const char* f = getenv("PCX_FUSE_STEPS");
     fused_ok_ = !(f && atoi(f) == 0) && !unoccluded_ && k.NS == 4 && k.R == 10 && k.C == 30 && k.L == 8 && k.ip == 3 &&
@@ -1806,7 +1806,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   bool use_codes = true;  // PCX_SM_CODES=0: the mask-composing render loop of round 1 (A/B)
   if (const char* e = getenv("PCX_SM_CODES")) use_codes = atoi(e) != 0;
   if (fused_.on) use_codes = false;  // the windows are cut from the curtain bit vectors
-  int coop_below = 5;  // groups per CU (measured crossover: profiles/r01_tuning.md)
+  int coop_below = 4;  // groups per CU (measured crossover: profiles/r03_tuning.md; round 1: 5)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (a.n_steps > 1) {
     // several steps in this launch: the logic wave runs ahead of the render waves

@@ -13,7 +13,7 @@ import sys
 # (kernel, rocprofv3 Grid_Size) -> (game, level, batch) of bench.py's headline + other_configs launches
 LAUNCHES = {
     ('pcx_scrolly_maze_step', '1048576'): ('scrolly_maze', 0, 1048576),
-    ('pcx_scrolly_maze_step', '32768'): ('scrolly_maze', 0, 4096),         # 64 groups x 8 cooperating waves
+    ('pcx_scrolly_maze_step', '131072'): ('scrolly_maze', 0, 4096),        # round 3: 256 workgroups of 16 environments x 8 cooperating waves
     ('pcx_marauders_step', '131072'): ('marauders', 0, 32768),             # 512 groups x 4 waves
     ('pcx_warehouse_step', '262144'): ('warehouse', 0, 262144),
     ('pcx_better_scrolly_step', '65536'): ('better_scrolly_maze', 0, 65536),
@@ -37,5 +37,5 @@ print(json.dumps({
     'source': '%s: WRITE_SIZE (KiB) + 2 x FETCH_SIZE (KiB; gfx950 reports half of a coalesced read stream, '
               'MI355X_MICROARCH.md HBM section), separate --pmc passes with --kernel-trace only, mean over the step '
               'launches of each kernel' % sys.argv[1],
-    'command': 'tools/profile_r02.sh (rocprofv3 --kernel-trace --pmc WRITE_SIZE | FETCH_SIZE -- python bench.py '
+    'command': 'tools/profile_r02.sh <tag> (rocprofv3 --kernel-trace --pmc WRITE_SIZE | FETCH_SIZE -- python bench.py '
                '--steps 20 --warmup 3 --no-cpu-baseline)'}, indent=1))
