@@ -1329,9 +1329,17 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // issued, so its LDS latency runs under them (software pipelining by hand: the loop is not unrolled)
   constexpr bool PREFETCH = CODES && INCR;
   uint32_t code_pf = 0;
-  if constexpr (PREFETCH) code_pf = codes[eF + q];
   const bool planes_on = !(fc && fc->only);  // fused croppers, windows only: the full-board planes are not written
   const int n_iter = COOP ? (EPW * QW + WAVE - 1) / WAVE : QW;  // 64 tasks per iteration
+  // epilogue with more than 16 write streams per wave (pcx_stream.h fill_epilogue): the uint8 planes of the whole
+  // group first, the float32 planes in a second sweep over the same codes
+  constexpr bool TWO_PASS = EPI && CODES && INCR;
+  const int n_pass = TWO_PASS && epi.two_pass && layers_on ? 2 : 1;
+#pragma unroll 1
+  for (int pass = 0; pass < n_pass; ++pass) {
+  const bool do_u8 = n_pass == 1 || pass == 0, do_f32 = n_pass == 1 || pass == 1;
+  if constexpr (TWO_PASS) { e = 0; q = lane; voff = 4u * lane; eF = 0; foff = 16u * lane; }
+  if constexpr (PREFETCH) code_pf = codes[eF + q];
 #pragma unroll 1
   for (int it = !planes_on ? n_iter : COOP ? wave : TFUSE ? wave - 1 : 0; it < n_iter;
        it += COOP ? (int)(blockDim.x >> 6) : TFUSE ? (int)(blockDim.x >> 6) - 1 : 1) {
@@ -1365,10 +1373,10 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       // cell's character out of the eight, layer k picks byte k of a one-hot table
       const uint32_t code = PREFETCH ? code_cur : codes[eF_now + q_now];
       auto put_plane = [&](uint8_t* base, uint32_t v, int32_t slot) {
-        if (!EPI || slot == -2 || layers_on)
+        if (!EPI || ((slot == -2 || layers_on) && do_u8))
           asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(base));
         if constexpr (EPI) {
-          if (slot >= 0) {
+          if (slot >= 0 && do_f32) {
             stream::f32x4 f;
             f.x = (float)(v & 0xFFu); f.y = (float)((v >> 8) & 0xFFu); f.z = (float)((v >> 16) & 0xFFu); f.w = (float)(v >> 24);
             const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
@@ -1406,6 +1414,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       }
     });
   }
+  }  // passes
   if constexpr (FUSABLE) {
     if (fc) {  // the croppers' windows, cut from the same descriptors (pcx_stream.h stream_windows)
       stream::PlaneMap<NS, 2, NBS> pm;

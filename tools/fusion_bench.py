@@ -33,8 +33,9 @@ def engine(name, batch):
   return t, eng, one
 
 what = sys.argv[1] if len(sys.argv) > 1 else 'all'
-if what in ('all', 'epi'):
-  for name, batch in (('marauders', 32768), ('marauders', 262144), ('hello_world', 65536), ('warehouse_L0', 65536)):
+if what in ('all', 'epi', 'sm'):
+  for name, batch in ((('scrolly_maze_L0', 1048576),) if what == 'sm' else
+                      (('marauders', 32768), ('marauders', 262144), ('hello_world', 65536), ('warehouse_L0', 65536))):
     t, eng, one = engine(name, batch)
     chars = ''.join(chr(c) for c in t.chars)
     obs = eng._result()[0]
@@ -45,7 +46,7 @@ if what in ('all', 'epi'):
     fused = rendering.ObservationToFeatureArray(chars)
     assert fused.fuse_into(eng)
     ms_fused = sorted(timed(one) for _ in range(3))[1]
-    print('%-14s %7d envs  two_pass=%s  step %.4f  step+post %.4f  fused %.4f ms' % (name, batch, os.environ.get('PCX_EPI_TWO_PASS', '0'), ms_step, ms_two, ms_fused), flush=True)
+    print('%-14s %7d envs  two_pass=%s  step %.4f  step+post %.4f  fused %.4f ms' % (name, batch, os.environ.get('PCX_EPI_TWO_PASS', 'auto'), ms_step, ms_two, ms_fused), flush=True)
     eng.close()
 if what in ('all', 'win'):
   for batch in (65536, 262144):

@@ -1,7 +1,5 @@
 #!/bin/bash
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-cd $ROOT
-run() { echo -n "B=$B $* : "; env "$@" python bench.py --game scrolly_maze --batch $B --steps 1000 --warmup 100 --repeats 3 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['roofline']['kernel_ms']*1000,2), 'us kernel')"; }
-for B in 8192 16384 32768 65536; do for e in 16 32 64; do run PCX_COOP_EPW=$e; done; done
-B=65536 run PCX_COOP_BELOW=0
-B=32768 run PCX_COOP_BELOW=0
+OUT=gpurun_out/r03_call18; mkdir -p $OUT
+for tp in 0 1 0 1; do PCX_EPI_TWO_PASS=$tp timeout 300 python tools/fusion_bench.py sm >> $OUT/sm_epi.txt 2>&1; done
+timeout 600 python -m pytest tests/test_postprocess.py -m gpu -x -q > $OUT/post_tests.log 2>&1; echo "rc=$?" >> $OUT/post_tests.log
+tail -3 $OUT/post_tests.log; cat $OUT/sm_epi.txt
