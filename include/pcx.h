@@ -453,7 +453,9 @@ int pcx_post_run(pcx_post* p, void* stream);
  * skip_layers != 0: the uint8 layer planes of `planes` are no longer written
  * (the board plane is) -- for consumers that only ingest the feature array.
  * Answers PCX_E_UNSUPPORTED where the backend's render loop cannot do it (the
- * table-driven kernel, boards with rows*cols % 4 != 0): run pcx_post_* then.
+ * table-driven kernel, occlusion_in_layers=False, fused croppers in the same
+ * kernel): run pcx_post_* then.  Boards of any size (a plane's last dword is
+ * stored cell by cell when rows*cols is no multiple of 4).
  * A NULL desc clears the epilogue. */
 typedef struct pcx_epilogue_desc {
   int32_t depth;

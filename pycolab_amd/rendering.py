@@ -221,9 +221,11 @@ class ObservationToFeatureArray(object):
     stops the step from writing the uint8 layer planes (`Observation.layers`
     then goes stale; the board stays valid) for consumers that only ingest
     the features.  Returns False, and changes nothing, where the engine's
-    kernel cannot do it (default axis order only, batch > 1, boards with
-    rows*cols % 4 == 0, the hand-written step kernels): calls then run the
-    post-processor as its own kernel, as before."""
+    kernel cannot do it (default axis order only, batch > 1, the five
+    hand-written step kernels with occluded layers and no fused croppers):
+    calls then run the post-processor as its own kernel, as before.  The
+    engine owns the installed epilogue: when this object goes away, or another
+    post-processor fuses, the kernel stops writing into this one's tensor."""
     torch = dev.torch_module()
     if (self._permute not in (None, (0, 1, 2)) or torch is None or engine._native is None or engine.batch == 1 or
         len(set(self._layers)) != len(self._layers) or any(ord(c) > 255 for c in self._layers)):
