@@ -277,9 +277,10 @@ def fuse_croppers(engine, croppers, only_crops=False):
   that is 13x less to write.
 
   Returns False, and changes nothing, where the engine's kernel cannot do it
-  (croppers that track drapes, more than four croppers, games stepped by
-  kernels without the fused path): the croppers then run as their own kernels,
-  as before.  `croppers=[]` releases them again."""
+  (more than four croppers, unoccluded layers, a cropper that tracks a drape
+  in a game stepped by one of the hand-written kernels -- the table-driven
+  kernel follows drapes too): the croppers then run as their own kernels, as
+  before.  `croppers=[]` releases them again."""
   croppers = list(croppers)
   for cr in croppers:
     if type(cr) is ObservationCropper:

@@ -289,7 +289,7 @@ static int push_fused(pcx_engine* e) {
     w.rule = window_rule(p);
     w.scrolling = p.kind == PCX_CROP_SCROLLING; w.top = p.top; w.left = p.left;
     w.n_track = p.n_track;
-    for (int j = 0; j < p.n_track; ++j) w.track_sprite[j] = p.track_idx[j];
+    for (int j = 0; j < p.n_track; ++j) { w.track_sprite[j] = p.track_idx[j]; w.track_kind[j] = p.track_kind[j]; }
     w.out_pitch = p.out_pitch;
     w.pad_planes = 0;
     for (int k = 0; k < p.L; ++k) if (p.pad_char >= 0 && (uint32_t)p.pad_char == p.chars[k]) w.pad_planes |= 1u << k;
@@ -319,8 +319,8 @@ int pcx_engine_fuse_croppers(pcx_engine* e, pcx_cropper* const* croppers, int32_
     pcx_cropper* c = croppers[i];
     if (!c || c->e != e) return set_error(PCX_E_INVALID, "pcx_engine_fuse_croppers: a cropper of another engine");
     for (int j = 0; j < i; ++j) if (croppers[j] == c) return set_error(PCX_E_INVALID, "pcx_engine_fuse_croppers: a cropper twice");
-    if (c->tracks_drape || c->p.n_track > pcx::crop::MAX_FUSED_TRACK)
-      return set_error(PCX_E_UNSUPPORTED, "pcx_engine_fuse_croppers: croppers that track drapes (or more than %d sprites) "
+    if (c->p.n_track > pcx::crop::MAX_FUSED_TRACK)
+      return set_error(PCX_E_UNSUPPORTED, "pcx_engine_fuse_croppers: croppers that track more than %d entities "
                                           "run as their own kernels", pcx::crop::MAX_FUSED_TRACK);
     if (c->p.rows > 255 || c->p.cols > 255) return set_error(PCX_E_UNSUPPORTED, "pcx_engine_fuse_croppers: window larger than 255x255");
     if (int rc = c->ensure_planes()) return rc;

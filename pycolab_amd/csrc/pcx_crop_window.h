@@ -86,8 +86,9 @@ struct FusedWindow {
   WindowRule rule;
   int32_t scrolling;    // 0: FixedCropper at (top, left)
   int32_t top, left;
-  int32_t n_track;      // ScrollingCropper.to_track, sprites only, as template sprite indices
-  int32_t track_sprite[MAX_FUSED_TRACK];
+  int32_t n_track;      // ScrollingCropper.to_track, in priority order (cropping.py:544-558)
+  int32_t track_sprite[MAX_FUSED_TRACK];  // template sprite index, or the drape's index where track_kind is 1
+  int32_t track_kind[MAX_FUSED_TRACK];    // 0 sprite (its position while visible), 1 drape (median of its curtain, :590-598)
   int32_t out_pitch;    // bytes per output plane (rows * cols rounded up to 4)
   uint32_t pad_planes;  // bit k: layer k (plane 1 + k) is 1 where the pad character fills (pad_char == chars[k])
 };
@@ -97,6 +98,15 @@ struct FusedCrops {
   int32_t only;  // the full-board planes are not written any more
   FusedWindow w[MAX_FUSED_CROPPERS];
 };
+
+// (host) does any window follow a drape?  Only kernels that keep the raw curtains as bit rows can.
+inline bool tracks_drapes(const FusedCrops* fc) {
+  if (!fc) return false;
+  for (int i = 0; i < fc->n; ++i)
+    for (int j = 0; j < fc->w[i].n_track; ++j)
+      if (fc->w[i].track_kind[j]) return true;
+  return false;
+}
 
 }  // namespace crop
 }  // namespace pcx

@@ -18,6 +18,8 @@
 // vectors for the render phase.
 
 #include "pcx_internal.h"
+#include "pcx_crop_window.h"
+#include "pcx_stream.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -68,6 +70,8 @@ struct Consts {
   // LDS layout (word offsets); per-lane arrays are [i][lane]
   int32_t l_things, l_z, l_sched, l_backdrop, l_bdmask, l_aux, l_init, l_initd, l_laybc, l_s2t, l_d2t;
   int32_t l_pos, l_flg, l_snap, l_cur, l_snapd, l_flat, l_sdesc, l_skip, l_flatraw, l_sdescraw, l_corner, l_pmask, l_pframe, l_words;
+  int32_t l_wcorner;              // fused croppers: [MAX_FUSED_CROPPERS][lane] window corners (pcx_stream.h WCORNER_NONE)
+  uint8_t chars[PCX_MAX_CHARS];   // character of layer plane 1 + i
 };
 
 struct Ptrs {
@@ -87,6 +91,7 @@ struct L {
   uint32_t *zord, *zabove, *zabove_s, *zabove_d, *zq, *ztmp;  // per-lane z-order (only when a game changes it)
   int32_t* snap;
   uint2 *sdesc, *sdescraw;
+  uint32_t* wcorner;  // fused croppers: window corners [MAX_FUSED_CROPPERS][lane]
 };
 
 __device__ __forceinline__ uint32_t action_hash(uint64_t seed, uint64_t env, uint64_t t) {
@@ -843,28 +848,195 @@ __device__ __forceinline__ void render_planes(const Consts& k, const L& l, const
   }
 }
 
+// ---- fused croppers (include/pcx.h pcx_engine_fuse_croppers) -----------------
+// ScrollingCropper._centroid of a drape (cropping.py:590-598): int(np.median(.)) of the set cells' row and
+// column indices, taken from the raw curtain's bit rows (lane == environment).  False: the curtain is empty.
+__device__ __forceinline__ bool drape_centroid(const Ctx& x, int d, int& crow, int& ccol) {
+  const int R = x.k.R, C = x.k.C, RW = x.k.RW;
+  const uint32_t* rows = drape_rows(x, x.l.cur, d);
+  int n = 0;
+  for (int r = 0; r < R; ++r)
+    for (int w = 0; w < RW; ++w) {
+      const int nb = C - 32 * w < 32 ? C - 32 * w : 32;
+      n += __popc(rows[(r * RW + w) * WAVE] & (nb < 32 ? (1u << nb) - 1u : 0xFFFFFFFFu));
+    }
+  // the two middle order statistics (0-based) of the sorted index list; their mean, truncated
+  const int lo_rank = (n - 1) / 2, hi_rank = n / 2;
+  int seen = 0, lo = -1, hi = -1;
+  for (int r = 0; r < R; ++r) {
+    int cnt = 0;
+    for (int w = 0; w < RW; ++w) {
+      const int nb = C - 32 * w < 32 ? C - 32 * w : 32;
+      cnt += __popc(rows[(r * RW + w) * WAVE] & (nb < 32 ? (1u << nb) - 1u : 0xFFFFFFFFu));
+    }
+    lo = lo < 0 && seen + cnt > lo_rank ? r : lo;
+    hi = hi < 0 && seen + cnt > hi_rank ? r : hi;
+    seen += cnt;
+  }
+  crow = (lo + hi) >> 1;
+  seen = 0; lo = -1; hi = -1;
+  for (int c = 0; c < C; ++c) {
+    int cnt = 0;
+    for (int r = 0; r < R; ++r) cnt += (rows[(r * RW + (c >> 5)) * WAVE] >> (c & 31)) & 1u;
+    lo = lo < 0 && seen + cnt > lo_rank ? c : lo;
+    hi = hi < 0 && seen + cnt > hi_rank ? c : hi;
+    seen += cnt;
+  }
+  ccol = (lo + hi) >> 1;
+  return n > 0;
+}
+
+// The logic wave moves every fused window for its environment (ScrollingCropper.crop, cropping.py:393-426)
+// and leaves the corners in LDS for render_windows.
+__device__ __forceinline__ void move_windows(const Ctx& x, const crop::FusedCrops* fc, int64_t env, uint32_t* wcorner) {
+  const int n = fc->n;
+  for (int w = 0; w < n; ++w) {
+    const crop::FusedWindow& fw = fc->w[w];
+    int top = fw.top, left = fw.left;
+    if (fw.scrolling) {
+      bool has = x.frame != 0 && fw.has_corner[env] != 0;  // a new episode is a new Engine (cropping.py:378-391)
+      int wrow = fw.corner[2 * env], wcol = fw.corner[2 * env + 1];
+      bool have = false;
+      int crow = 0, ccol = 0;
+      for (int i = 0; i < fw.n_track; ++i) {  // :544-558 the first entity of to_track that has a centroid
+        int r = 0, c = 0;
+        bool ok;
+        if (fw.track_kind[i] == 0) {
+          sprite_true(x, fw.track_sprite[i], r, c);
+          ok = (x.l.flg[fw.track_sprite[i] * WAVE + x.lane] & 1u) != 0;
+        } else {
+          ok = drape_centroid(x, fw.track_sprite[i], r, c);
+        }
+        if (!have && ok) { crow = r; ccol = c; have = true; }
+      }
+      crop::move_window(fw.rule, have, crow, ccol, has, wrow, wcol);
+      fw.has_corner[env] = 1;
+      top = wrow;
+      left = wcol;
+    }
+    fw.corner[2 * env] = top;
+    fw.corner[2 * env + 1] = left;
+    const bool err = crop::window_leaves_observation(fw.rule, top, left);
+    fw.error[env] = (uint8_t)err;
+    wcorner[w * WAVE + x.lane] = err ? stream::WCORNER_NONE : (((uint32_t)top & 0xFFFFu) | ((uint32_t)left << 16));
+  }
+}
+
+// _do_crop (cropping.py:118-227) out of LDS: one (environment, output dword) task per lane; a run of window
+// cells that lies in one window row is a run of consecutive board cells, composed like a board dword
+// (backdrop bytes, each curtain's bits, the painted sprites' cells -- occlusion is resolved already), the
+// pad character outside the board; every layer is `board == c` of the finished dword (rendering.py:177-179).
+__device__ __forceinline__ void render_windows(const Consts& k, const L& l, const crop::FusedCrops* fc, const uint32_t* wcorner,
+                                               int64_t env0, int lane, int wave, int nwaves) {
+  auto eq01 = [](uint32_t v, uint32_t c4) {
+    const uint32_t y = v ^ c4;
+    return (~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) >> 7) & 0x01010101u;
+  };
+  auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  const int FWP = k.FW | 1, Rv = k.R, Cv = k.C, QWsrc = k.QW, NS = k.NS, ND = k.ND, Lc = k.L;
+  const int n = fc->n;
+  for (int w = 0; w < n; ++w) {
+    const crop::FusedWindow& fw = fc->w[w];
+    const int rows = fw.rule.rows, cols = fw.rule.cols;
+    const uint32_t opitch = (uint32_t)fw.out_pitch, qw = opitch >> 2, total = (uint32_t)WAVE * qw;
+    const uint32_t ostride = (uint32_t)(1 + Lc) * opitch;
+    uint8_t* const obase = fw.out + (size_t)env0 * ostride;
+    const uint32_t pad = (uint32_t)(fw.rule.pad_char & 0xFF);
+    const uint32_t magic_qw = 0xFFFFFFFFu / qw, magic_cols = 0xFFFFFFFFu / (uint32_t)cols;
+    for (uint32_t f = (uint32_t)wave * WAVE + (uint32_t)lane; f < total; f += (uint32_t)nwaves * WAVE) {
+      uint32_t e = __umulhi(f, magic_qw), q = f - e * qw;  // f / qw: the estimate is at most one short
+      if (q >= qw) { q -= qw; ++e; }
+      const uint32_t cw = wcorner[w * WAVE + e];
+      if (l.skip[e] || cw == stream::WCORNER_NONE) continue;
+      const int top = (int)(int16_t)(cw & 0xFFFFu), left = (int)(int16_t)(cw >> 16);
+      const uint32_t cell0 = q * 4u;
+      uint32_t orow = __umulhi(cell0, magic_cols), ocol = cell0 - orow * (uint32_t)cols;
+      if (ocol >= (uint32_t)cols) { ocol -= (uint32_t)cols; ++orow; }
+      const uint32_t eF = e * (uint32_t)FWP;
+      uint32_t od = 0;
+      int done = 0, wr = (int)orow, wc = (int)ocol;
+      while (done < 4) {
+        const int nrun = cols - wc < 4 - done ? cols - wc : 4 - done;
+        const bool real_row = wr < rows;  // rows past the window are plane padding: zeros
+        const int sr = top + wr, sc = left + wc;
+        const bool row_in = real_row && (unsigned)sr < (unsigned)Rv;
+        const int lo = sc < 0 ? -sc : 0, hi = Cv - sc < nrun ? Cv - sc : nrun;  // the run's columns inside the board
+        const bool any_in = row_in && lo < hi;
+        const uint32_t a = any_in ? (uint32_t)(sr * Cv + sc + lo) : 0u;
+        const uint32_t qa = a >> 2, qb = (int)qa + 1 < QWsrc ? qa + 1 : qa, ph = a & 3u;
+        uint32_t d = __builtin_amdgcn_alignbyte(l.backdrop4[qb], l.backdrop4[qa], ph);
+        const uint32_t w0 = a >> 5, w1 = (int)w0 + 1 < FWP ? w0 + 1 : w0;
+        for (int dd = 0; dd < ND; ++dd) {
+          const uint32_t base = (uint32_t)dd * WAVE * (uint32_t)FWP + eF;
+          const uint64_t pair = (uint64_t)l.flat[base + w0] | ((uint64_t)l.flat[base + w1] << 32);
+          const uint32_t bits = (uint32_t)(pair >> (a & 31u)) & 0xFu;
+          const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+          const uint32_t m = (m01 << 8) - m01;
+          const uint32_t ch4 = uni(l.things[l.d2t[dd] * T_WORDS + T_CH]) * 0x01010101u;
+          d = (d & ~m) | (ch4 & m);
+        }
+        for (int s2 = 0; s2 < NS; ++s2) {
+          const uint2 sd = l.sdesc[s2 * WAVE + e];  // {board dword, byte mask}; dword 0xFFFFFFFF: not painted
+          const uint32_t scell = (sd.x << 2) | ((uint32_t)__builtin_ctz(sd.y) >> 3);
+          const uint32_t delta = scell - a;
+          const uint32_t m = sd.x != 0xFFFFFFFFu && delta < 4u ? 0xFFu << (8u * delta) : 0u;
+          const uint32_t ch4 = uni(l.things[l.s2t[s2] * T_WORDS + T_CH]) * 0x01010101u;
+          d = (d & ~m) | (ch4 & m);
+        }
+        const int nin = any_in ? hi - lo : 0;
+        const uint32_t keep = nin >= 4 ? 0xFFFFFFFFu : (1u << (8 * nin)) - 1u;
+        uint32_t run = any_in ? (d & keep) << (8 * lo) : 0u;
+        const uint32_t in_mask = any_in ? keep << (8 * lo) : 0u;
+        const uint32_t run_mask = nrun >= 4 ? 0xFFFFFFFFu : (1u << (8 * nrun)) - 1u;
+        run |= real_row ? (pad * 0x01010101u) & run_mask & ~in_mask : 0u;
+        od |= run << (8 * done);
+        done += nrun;
+        wc += nrun;
+        if (wc >= cols) { wc = 0; ++wr; }
+      }
+      uint8_t* const dst = obase + (size_t)e * ostride + 4u * q;
+      *reinterpret_cast<uint32_t*>(dst) = od;
+      for (int kk = 0; kk < Lc; ++kk)
+        *reinterpret_cast<uint32_t*>(dst + (size_t)(1 + kk) * opitch) = eq01(od, (uint32_t)k.chars[kk] * 0x01010101u);
+    }
+  }
+}
+
 __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))) void pcx_generic_step(const Consts k, const Ptrs P, const StepArgs a,
-                                                         const pcx_buffers out) {
+                                                         const pcx_buffers out, const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
   // A workgroup is 1, 2, 4 or 8 waves around one group of 64 environments: wave 0
   // steps them (lane == environment), then all waves share the render loop.
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int64_t env0 = (int64_t)blockIdx.x * WAVE, env = env0 + lane;
   for (int i = threadIdx.x; i < P.n_table_words; i += blockDim.x) lds[i] = P.tables[i];
+  __syncthreads();
+
+  const bool timing = (a.debug & 8) != 0 && P.stats != nullptr;
+  auto render_all = [&](const L& lr, int64_t env0r, int w, int nw) {
+    const bool any_skip = __ballot(lr.skip[lane] != 0) != 0ull;
+    if (fc) {
+      render_windows(k, lr, fc, lr.wcorner, env0r, lane, w, nw);
+      if (fc->only) return;  // the consumer ingests the windows only: no full-board planes
+    }
+    switch ((k.NT + 3) / 4) {
+      case 0: case 1: render_planes<4>(k, lr, out, env0r, lane, w, nw, any_skip); break;
+      case 2: render_planes<8>(k, lr, out, env0r, lane, w, nw, any_skip); break;
+      case 3: render_planes<12>(k, lr, out, env0r, lane, w, nw, any_skip); break;
+      default: render_planes<16>(k, lr, out, env0r, lane, w, nw, any_skip); break;
+    }
+  };
+  const int64_t env0 = (int64_t)blockIdx.x * WAVE, env = env0 + lane;
   L l;
   l.things = lds + k.l_things; l.z = lds + k.l_z; l.sched = lds + k.l_sched;
   l.backdrop4 = lds + k.l_backdrop; l.bdmask = lds + k.l_bdmask; l.aux = lds + k.l_aux;
   l.init = lds + k.l_init; l.initd = lds + k.l_initd; l.laybc = lds + k.l_laybc; l.s2t = lds + k.l_s2t; l.d2t = lds + k.l_d2t;
   l.pos = lds + k.l_pos; l.flg = lds + k.l_flg; l.snap = reinterpret_cast<int32_t*>(lds + k.l_snap);
-  l.cur = lds + k.l_cur; l.snapd = lds + k.l_snapd; l.flat = lds + k.l_flat;
-  l.sdesc = reinterpret_cast<uint2*>(lds + k.l_sdesc); l.skip = lds + k.l_skip;
+  l.cur = lds + k.l_cur; l.snapd = lds + k.l_snapd;
   l.corner = lds + k.l_corner; l.pmask = lds + k.l_pmask; l.pframe = lds + k.l_pframe;
-  l.flatraw = lds + k.l_flatraw; l.sdescraw = reinterpret_cast<uint2*>(lds + k.l_sdescraw);
   l.dir = lds + k.l_dir; l.zord = lds + k.l_zord; l.zabove = lds + k.l_zabove; l.zabove_s = lds + k.l_zabove_s;
   l.zabove_d = lds + k.l_zabove_d; l.zq = lds + k.l_zq; l.ztmp = lds + k.l_ztmp;
-  __syncthreads();
-
-  const bool timing = (a.debug & 8) != 0 && P.stats != nullptr;
+  l.flat = lds + k.l_flat; l.sdesc = reinterpret_cast<uint2*>(lds + k.l_sdesc); l.skip = lds + k.l_skip;
+  l.flatraw = lds + k.l_flatraw; l.sdescraw = reinterpret_cast<uint2*>(lds + k.l_sdescraw); l.wcorner = lds + k.l_wcorner;
   const unsigned long long t_start = timing ? __builtin_readcyclecounter() : 0ull;
   unsigned long long c_sec[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c_prog[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool live = wave == 0 && env < P.batch;  // the logic phase is wave 0's
@@ -1018,6 +1190,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
       st[(k.w_z + 1) * bp] = z1;
     }
     flags = (x.game_over ? F_OVER : 0u) | ((x.err & 7u) << F_ERR_SHIFT) | ((uint32_t)((dxv + 1) & 0xFF) << 8);
+    if (!(a.debug & 16)) {  // (ablation: the logic wave's own global stores)
     st[W_RNG * bp] = draws;
     if (k.w_next >= 0) st[k.w_next * bp] = (uint32_t)x.next;
     st[W_FRAME * bp] = (uint32_t)x.frame;
@@ -1044,6 +1217,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     out.done[env] = (uint8_t)x.game_over;
     out.frame[env] = x.frame;
     out.error[env] = (uint8_t)x.err;
+    }
 
     if (timing) c_sec[2] = __builtin_readcyclecounter() - t_wb;  // write-back
     const unsigned long long t_occ = timing ? __builtin_readcyclecounter() : 0ull;
@@ -1118,8 +1292,9 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
       if (!k.occl) l.sdescraw[s * WAVE + lane] = make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
       int tr, tc;
       sprite_true(x, s, tr, tc);
-      P.track[s * bp + env] = tr | (tc << 8) | ((int)(l.flg[s * WAVE + lane] & 1) << 16) | ((int)do_reset << 24);
+      if (!(a.debug & 16)) P.track[s * bp + env] = tr | (tc << 8) | ((int)(l.flg[s * WAVE + lane] & 1) << 16) | ((int)do_reset << 24);
     }
+    if (fc) move_windows(x, fc, env, l.wcorner);  // fused croppers follow this step's things
     if (timing) c_sec[3] = __builtin_readcyclecounter() - t_occ;  // occlusion + descriptors
   }
   if (timing && wave == 0 && lane == 0) {
@@ -1133,16 +1308,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
   }
   if (wave == 0) l.skip[lane] = skip;
   __syncthreads();
-  if (a.debug & 2) return;
-
-  // ---- render phase: every wave of the workgroup streams board + layers ---------
-  const bool any_skip = __ballot(l.skip[lane] != 0) != 0ull;
-  switch ((k.NT + 3) / 4) {
-    case 0: case 1: render_planes<4>(k, l, out, env0, lane, wave, nwaves, any_skip); break;
-    case 2: render_planes<8>(k, l, out, env0, lane, wave, nwaves, any_skip); break;
-    case 3: render_planes<12>(k, l, out, env0, lane, wave, nwaves, any_skip); break;
-    default: render_planes<16>(k, l, out, env0, lane, wave, nwaves, any_skip); break;
-  }
+  if (!(a.debug & 2)) render_all(l, env0, wave, nwaves);  // every wave of the workgroup streams board + layers
 #undef GFLAT
 }
 
@@ -1159,6 +1325,11 @@ class GenericBackend : public Backend {
     return 4 + 8 * (int64_t)k_.NW + (int64_t)(1 + k_.L) * k_.cells + 15;
   }
   const char* kernel_name() const override { return "pcx_generic_step"; }
+  int set_fused_croppers(const crop::FusedCrops* fc) override {
+    if (fc && fc->n > 0 && !k_.occl)  // (the windows derive their layers from the board they cut)
+      return set_error(PCX_E_UNSUPPORTED, "generic backend: fused croppers need occlusion_in_layers=True");
+    return fused_.set(fc, /*drapes_ok=*/true);  // the raw curtains are bit rows in LDS: a drape's median is at hand
+  }
   const int32_t* sprite_track() const override { return track_.ptr; }
   const int32_t* next_chapter_words() const override {
     return k_.w_next >= 0 ? reinterpret_cast<const int32_t*>(state_.ptr + (size_t)k_.w_next * bpad_) : nullptr;
@@ -1177,6 +1348,7 @@ class GenericBackend : public Backend {
   Consts k_{};
   int64_t batch_ = 0, bpad_ = 0;
   int num_cus_ = 256;
+  stream::FusedCropsHolder fused_;
   DevArray<uint32_t> tables_, state_, curtains_;
   DevArray<unsigned long long> stats_;  // PCX_DEBUG & 8
   DevArray<int32_t> track_;
@@ -1445,10 +1617,6 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.l_snap = off; off += k.NS * WAVE;
   k.l_cur = off; off += ndw * WAVE;
   k.l_snapd = off; off += ndw * WAVE;
-  k.l_flat = off; off += k.ND * (k.FW | 1) * WAVE;
-  off = (off + 1) & ~1;
-  k.l_sdesc = off; off += 2 * k.NS * WAVE;
-  k.l_skip = off; off += WAVE;
   k.l_corner = off; if (k.has_scroll) off += k.ND * WAVE;
   k.l_pmask = off; if (k.has_scroll) off += k.NS * WAVE;
   k.l_pframe = off; if (k.has_scroll) off += k.NS * WAVE;
@@ -1458,10 +1626,17 @@ int GenericBackend::init(const pcx_template& t, int64_t batch) {
   k.l_zabove_d = off; if (k.zdyn) off += k.NT * WAVE;
   k.l_ztmp = off; if (k.zdyn) off += (k.NT + 1) * WAVE;
   k.l_zq = off; if (k.zdyn) off += MAX_ZQ * WAVE;
+  off = (off + 1) & ~1;
+  k.l_flat = off; off += k.ND * (k.FW | 1) * WAVE;  // ---- from here on: what the render phase reads
+  off = (off + 1) & ~1;
+  k.l_sdesc = off; off += 2 * k.NS * WAVE;
+  k.l_skip = off; off += WAVE;
   k.l_flatraw = off; if (!k.occl) off += k.ND * (k.FW | 1) * WAVE;
   off = (off + 1) & ~1;
   k.l_sdescraw = off; if (!k.occl) off += 2 * k.NS * WAVE;
+  k.l_wcorner = off; off += crop::MAX_FUSED_CROPPERS * WAVE;
   k.l_words = off;
+  for (int i = 0; i < PCX_MAX_CHARS; ++i) k.chars[i] = i < t.n_chars ? t.chars[i] : 0;
   {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1489,17 +1664,21 @@ int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_
   if (stats_.ptr) PCX_HIP(hipMemsetAsync(stats_.ptr, 0, 128 * sizeof(unsigned long long), s));
   Ptrs P{tables_.ptr, n_table_words_, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_, stats_.ptr};
   size_t lds = (size_t)k_.l_words * 4;
-  if (lds > 64 * 1024)
-    PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pcx_generic_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // Waves per workgroup (they share the render loop of the group's 64
-  // environments): more when LDS lets only a few workgroups onto a CU, or when
-  // the batch has fewer groups than the chip has room for.
+  // Waves per workgroup (they share the render loop of the group's 64 environments).  The kernel's 95 VGPRs let
+  // five waves onto a SIMD (20 per CU), so of the `fit` workgroups LDS has room for only 20 / n are resident with n
+  // waves each -- and the logic phase (one wave per workgroup, VALU-bound) is what the kernel mostly waits for.
+  // Measured at 262,144 environments (profiles/r03_tuning.md): warehouse_L0 (fit 10) 1/2/4/8 waves 0.172 / 0.162 /
+  // 0.205 / 0.331 ms; walkers_scroll_groups (fit 8) 0.171 / 0.152 / 0.236 / 0.443; hello_world (fit 6, four times
+  // the bytes to stream) 2 waves 0.42, 4 waves 0.33.  Hence: the most waves that still keep about 80 % of `fit`
+  // workgroups resident.  When the batch has fewer groups than the chip has room for, 8 waves split the render loop.
   const int64_t groups = bpad_ / WAVE;
   const int fit = (int)((160 * 1024) / (lds ? lds : 1)) > 0 ? (int)((160 * 1024) / (lds ? lds : 1)) : 1;
-  int nwaves = fit * 8 <= 16 ? 8 : fit * 4 <= 32 ? 4 : fit * 2 <= 32 ? 2 : 1;  // a CU holds 32 waves (measured best: profiles/r01_tuning.md)
+  int nwaves = fit <= 2 ? 8 : fit <= 6 ? 4 : 2;
   if (groups < (int64_t)num_cus_ * (fit < 4 ? fit : 4)) nwaves = 8;  // the chip is underfilled: split the render loop further
   if (const char* e = getenv("PCX_GENERIC_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nwaves = v; }
-  hipLaunchKernelGGL(pcx_generic_step, dim3((unsigned)groups), dim3(nwaves * WAVE), lds, s, k_, P, a, out);
+  if (lds > 64 * 1024)
+    PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pcx_generic_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(pcx_generic_step, dim3((unsigned)groups), dim3(nwaves * WAVE), lds, s, k_, P, a, out, fused_.ptr());
   PCX_HIP(hipGetLastError());
   if (stats_.ptr) {  // debugging aid: where the logic phase spends its cycles (lane 0 of every group)
     unsigned long long h[128];

@@ -522,7 +522,9 @@ inline bool fill_epilogue(EpilogueArgs& a, const pcx_epilogue_desc* d, int cells
 struct FusedCropsHolder {
   DevArray<crop::FusedCrops> dev;
   bool on = false;
-  int set(const crop::FusedCrops* fc) {
+  int set(const crop::FusedCrops* fc, bool drapes_ok = false) {
+    if (!drapes_ok && crop::tracks_drapes(fc))  // (the hand-written kernels keep no raw curtain a median could be taken of)
+      return set_error(PCX_E_UNSUPPORTED, "fused croppers: this game's kernel follows sprites only; a cropper that tracks a drape runs as its own kernel");
     PCX_HIP(hipDeviceSynchronize());  // no launch in flight may still read the old description
     if (!fc || fc->n <= 0) { on = false; return 0; }
     if (!dev.ptr) { if (int rc = dev.alloc(1)) return rc; }

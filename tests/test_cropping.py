@@ -264,6 +264,95 @@ def test_fused_croppers_equal_stand_alone_croppers(name, batch, shape, monkeypat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('waves', ['1', '4'])
+@pytest.mark.parametrize('name,batch', [('walkers_room', 900), ('walkers_scroll_groups', 700), ('directives_z_order', 500),
+                                        ('marauders', 600), ('warehouse_L0', 1000), ('hello_world', 400),
+                                        ('better_scrolly_custom_B', 300)])
+def test_table_driven_kernel_fuses_croppers_drape_trackers_included(name, batch, waves, monkeypatch):
+  """pcx_generic_step runs croppers itself, also those that follow a drape
+  (the median of its raw curtain, cropping.py:590-598) or a priority list of
+  drapes and sprites: step by step the windows equal those of the stand-alone
+  cropper kernels on a twin engine; joining and leaving mid-episode."""
+  import torch
+  from pycolab_amd.engine import Engine
+  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+  monkeypatch.setenv('PCX_GENERIC_WAVES', waves)
+  t = helpers.load_template(name)
+  sprites = [chr(sp['ch']) for sp in t.sprites]
+  drapes = [chr(d['ch']) for d in t.drapes]
+  R, C = t.rows, t.cols
+  pad = chr(t.chars[0])
+
+  def make():
+    out = [cropping.ScrollingCropper(5, 7, sprites[:1], pad_char=pad, scroll_margins=(1, 2)),
+           cropping.FixedCropper((R - 3, C - 5), 6, 9, pad_char=chr(t.chars[1]))]
+    if drapes:
+      out.append(cropping.ScrollingCropper(3, 5, drapes[:1], pad_char=pad, scroll_margins=(None, 1)))
+      out.append(cropping.ScrollingCropper(min(R, 4), min(C, 6), drapes[-1:] + sprites[-1:], scroll_margins=(1, 2),
+                                           initial_offset=(0, 1), saccade=True))
+    else:
+      out.append(cropping.ScrollingCropper(min(R, 4), min(C, 6), sprites[-1:] + sprites[:1], scroll_margins=(1, 2), saccade=False))
+    return out
+
+  a = Engine.from_template(t, batch=batch, auto_reset=True, seed=7)
+  b = Engine.from_template(t, batch=batch, auto_reset=True, seed=7)
+  ca, cb = make(), make()
+  for cr in ca:
+    cr.set_engine(a)
+  for cr in cb:
+    cr.set_engine(b)
+  cropping.fuse_croppers(a, ca)
+  oa, ob = a.its_showtime()[0], b.its_showtime()[0]
+  from pycolab_amd import _native as N
+  assert N.lib().pcx_engine_kernel_name(a._native).decode() == 'pcx_generic_step'
+  assert all(cr._fused for cr in ca) and not any(cr._fused for cr in cb)
+
+  def same(step):
+    assert torch.equal(oa.board, ob.board), 'step %d: boards differ' % step
+    for i, (x, y) in enumerate(zip(ca, cb)):
+      wx, wy = x.crop(oa), y.crop(ob)
+      assert torch.equal(wx.board, wy.board), 'step %d cropper %d: boards differ' % (step, i)
+      for ch in wy.layers:
+        assert torch.equal(wx.layers[ch], wy.layers[ch]), 'step %d cropper %d layer %r' % (step, i, ch)
+
+  same(0)
+  n_act = max(1, int(t.n_actions))
+  rng = np.random.RandomState(5)
+  for step in range(1, 41):
+    acts = rng.randint(0, n_act, size=batch).astype(np.int32)
+    a.step(acts); b.step(acts)  # (step(): random actions make walkers_scroll_groups raise scrolling.Error in some environments, as the reference would)
+    oa, ob = a._result()[0], b._result()[0]
+    same(step)
+    if step == 15:
+      assert cropping.fuse_croppers(b, cb) is True
+    if step == 28:
+      assert cropping.fuse_croppers(a, []) is True
+  # windows only: the full-board planes are no longer written, the windows still are
+  c = Engine.from_template(t, batch=batch, auto_reset=True, seed=7)
+  cc = make()
+  for cr in cc:
+    cr.set_engine(c)
+  cropping.fuse_croppers(c, cc, only_crops=True)
+  oc = c.its_showtime()[0]
+  d = Engine.from_template(t, batch=batch, auto_reset=True, seed=7)
+  cd = make()
+  for cr in cd:
+    cr.set_engine(d)
+  od = d.its_showtime()[0]
+  for cr in cd:
+    cr.crop(od)  # (the fused croppers cropped frame 0 in the showtime launch)
+  rng = np.random.RandomState(5)
+  for step in range(1, 13):
+    acts = rng.randint(0, n_act, size=batch).astype(np.int32)
+    c.step(acts); d.step(acts)
+    oc, od = c._result()[0], d._result()[0]
+    for i, (x, y) in enumerate(zip(cc, cd)):
+      assert torch.equal(x.crop(oc).board, y.crop(od).board), 'windows only, step %d cropper %d' % (step, i)
+  for e in (a, b, c, d):
+    e.close()
+
+
+@pytest.mark.gpu
 def test_croppers_released_from_a_windows_only_fusion_keep_their_output_until_the_next_step():
   import torch
   from pycolab_amd.engine import Engine
@@ -297,7 +386,7 @@ def test_croppers_released_from_a_windows_only_fusion_keep_their_output_until_th
 @pytest.mark.gpu
 def test_fuse_croppers_answers_false_where_the_kernel_cannot():
   from pycolab_amd.engine import Engine
-  t = helpers.load_template('walkers_room')   # the table-driven kernel has no fused cropper path
+  t = helpers.load_template('marauders_unoccluded')   # (table-driven kernel) unoccluded layers: the windows derive layers from the board
   eng = Engine.from_template(t, batch=8, auto_reset=True)
   cr = cropping.ScrollingCropper(5, 7, [chr(t.sprites[0]['ch'])], pad_char=chr(t.chars[0]), scroll_margins=(1, 2))
   cr.set_engine(eng)
@@ -314,7 +403,7 @@ def test_fuse_croppers_answers_false_where_the_kernel_cannot():
   drape = cropping.ScrollingCropper(3, 3, ['X'], pad_char=' ', scroll_margins=(None, None))
   drape.set_engine(eng2)
   eng2.its_showtime()
-  assert cropping.fuse_croppers(eng2, [drape]) is False          # drape trackers stay stand-alone
+  assert cropping.fuse_croppers(eng2, [drape]) is False          # the hand-written kernels follow sprites only
   sprite = cropping.ScrollingCropper(3, 3, ['P'], pad_char=' ', scroll_margins=(None, None))
   with pytest.raises(ValueError):                                  # the stand-alone cropper would read stale planes
     cropping.fuse_croppers(eng2, [sprite], only_crops=True)

@@ -119,17 +119,21 @@ def test_hip_two_wave_pipeline_shape_matches_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize('waves', ['1', '2', '4'])
-@pytest.mark.parametrize('name', ['marauders', 'warehouse_L2'])
+@pytest.mark.parametrize('name', ['marauders', 'warehouse_L2', 'walkers_scroll_groups', 'directives_z_order', 'hello_world',
+                                  'warehouse_L0_unoccluded'])
 def test_hip_table_driven_kernel_waves_per_workgroup(name, waves, monkeypatch):
-  """The table-driven kernel picks 1, 2, 4 or 8 waves per workgroup from the
+  """The table-driven kernel picks 2, 4 or 8 waves per workgroup from the
   batch and the LDS footprint; test-size batches always get 8.  Force the
   others (what BASELINE-size batches run) and compare with the oracle."""
+  from pycolab_amd import _native as N
+  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
   monkeypatch.setenv('PCX_GENERIC_WAVES', waves)
   t = helpers.load_template(name)
   t.param[0] = 0xD1CE
-  B = 320
+  B = 64 * 10 + 37
   hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
   hip.reset(); orc.reset()
+  assert N.lib().pcx_engine_kernel_name(hip.eng._native).decode() == 'pcx_generic_step'
   for t0 in range(0, 96, 16):
     hip.step_hashed(0x5EED, t0, 16); orc.step_hashed(0x5EED, t0, 16)
     assert_same(hip, orc, 'after step %d' % (t0 + 16))

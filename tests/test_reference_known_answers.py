@@ -118,6 +118,34 @@ def test_hip_reproduces_reference_known_answers(name, batch):
       cr.check_errors()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', [n for n in NAMES if load(n)['meta'].get('croppers')])
+def test_hip_fused_croppers_reproduce_reference_known_answers(name):
+  """cropping_test.py's expected crops from croppers the table-driven step kernel
+  runs itself (four at a time: the fused path's limit), drape trackers and
+  priority lists included (testScrollingSaccade tracks ['P', '%'])."""
+  from pycolab_amd.engine import Engine
+  fx = load(name)
+  specs = fx['meta']['croppers']
+  assert fx['meta']['croppers_primed']
+  real = [j for j, sp in enumerate(specs) if sp is not None]
+  for lo in range(0, len(real), 4):
+    chunk = real[lo:lo + 4]
+    eng = Engine.from_template(fx['template'], batch=3)
+    crops = [cropping.cropper_from_spec(specs[j]) for j in chunk]
+    assert cropping.fuse_croppers(eng, crops) is None  # deferred to its_showtime(), which crops frame 0 (the test's priming crop)
+    obs = eng.its_showtime()[0]
+    assert all(cr._fused for cr in crops), name
+    for i, a in enumerate(fx['actions']):
+      obs = eng.play(None if a < 0 else np.full((3,), a, np.int32))[0]
+      for j, cr in zip(chunk, crops):
+        check_board(helpers.to_np(cr.crop(obs).board)[2], fx['crop_%d' % j][i], '%s frame %d cropper %d' % (name, i, j))
+    eng.check_errors()
+    for cr in crops:
+      cr.check_errors()
+    eng.close()
+
+
 # ---- tests/engine_test.py:169-295, restated -----------------------------------
 # The reference injects Plot calls into its test entities as Python callables
 # (`tt.pre_update(engine, 'b', lambda ...: the_plot.change_z_order('b', 'c'))`);
