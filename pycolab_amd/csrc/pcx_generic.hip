@@ -1675,7 +1675,7 @@ int GenericBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_
   const int fit = (int)((160 * 1024) / (lds ? lds : 1)) > 0 ? (int)((160 * 1024) / (lds ? lds : 1)) : 1;
   int nwaves = fit <= 2 ? 8 : fit <= 6 ? 4 : 2;
   if (groups < (int64_t)num_cus_ * (fit < 4 ? fit : 4)) nwaves = 8;  // the chip is underfilled: split the render loop further
-  if (const char* e = getenv("PCX_GENERIC_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nwaves = v; }
+  if (const char* e = getenv("PCX_GENERIC_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) nwaves = v; }
   if (lds > 64 * 1024)
     PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pcx_generic_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(pcx_generic_step, dim3((unsigned)groups), dim3(nwaves * WAVE), lds, s, k_, P, a, out, fused_.ptr());

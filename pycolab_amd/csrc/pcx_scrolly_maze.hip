@@ -560,7 +560,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   int pre_action = PCX_ACTION_NONE;
   if constexpr (COOP) {
     if (threadIdx.x < WAVE) {
-      const int col0 = EPW == 16 ? (int)threadIdx.x >> 2 : (int)threadIdx.x;
+      const int col0 = EPW <= 16 ? (int)threadIdx.x >> 2 : (int)threadIdx.x;
       const int64_t env_p = (int64_t)blockIdx.x * EPW + col0;
       if (col0 < EPW && env_p < P.batch) {
         const uint32_t* stp = P.state + env_p;
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // (cooperative shape with 16 environments per workgroup: FOUR lanes per environment.  All four step it
   // identically -- same loads, same stores -- except that the egocentric sprite's eight scroll-permit probes,
   // half of a step's probes, are shared out two per lane and their verdicts exchanged with two quad shuffles.)
-  const bool quad = COOP && EPW == 16;
+  const bool quad = COOP && EPW <= 16;
   const int col = quad ? lane >> 2 : lane;   // the environment's column in the per-environment LDS arrays
   const int quad_j = quad ? lane & 3 : -1;
   const int64_t env0 = g_logic * EPW;
@@ -1832,7 +1832,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     StepArgs ac = a;
     int epw = WAVE;
     while (epw > 16 && bpad_ / epw < (int64_t)num_cus_) epw >>= 1;
-    if (const char* e = getenv("PCX_COOP_EPW")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) epw = v; }
+    if (const char* e = getenv("PCX_COOP_EPW")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) epw = v; }
     ac.envs_per_group = epw;
     const unsigned coop_groups = (unsigned)(bpad_ / epw);
     if (epi_.out)
