@@ -719,7 +719,7 @@ __device__ __forceinline__ void prog_em_upbolt(Ctx& x, int thing) {  // :198-220
 }
 constexpr uint64_t EM_RNG_SALT = 0x4D415241554445ull;
 __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& draws, int64_t genv) {  // :232-256
-  const int s = tfield(x, thing, T_IDX), R = x.k.R, C = x.k.C;
+  const int s = tfield(x, thing, T_IDX), R = x.k.R;
   int vr, vc, vis, prior;
   sprite_get(x, s, vr, vc, vis, prior);
   if (vis) {
@@ -733,20 +733,32 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
     if (x.v[3] == x.frame) return;
     x.v[3] = x.frame;
     // columns of the layer of 'X' in the last repaint that hold any X
-    // (np.flatnonzero(layers['X'].any(axis=0)), :246)
-    // Few rows hold a bolt in front of X: note which (one bit per row), and
-    // every other row of the layer is just its snapshot row.
-    uint32_t busy_rows = 0;
-    if (x.k.occl) {
-      if (above_drapes(x, x.k.tx) != 0 || R > 32) busy_rows = 0xFFFFFFFFu;
-      for (uint32_t m = above_sprites(x, x.k.tx); m; m &= m - 1) {
-        const int cell = x.l.snap[(__ffs((int)m) - 1) * WAVE + x.lane];
-        if (cell >= 0) busy_rows |= 1u << (__umulhi((uint32_t)cell, x.k.magic_c) & 31u);
+    // (np.flatnonzero(layers['X'].any(axis=0)), :246).  With occlusion the layer is X's snapshot minus the
+    // cells of what stands in front of it: usually a handful of sprites (the bolts), whose rows and column bits
+    // fit eight register pairs -- a row of the layer is then its snapshot row and eight selects, not a walk
+    // over the things per row.
+    const uint32_t dx = tfield(x, x.k.tx, T_IDX);
+    constexpr int MAXC = 8;
+    const uint32_t ab_s = x.k.occl ? above_sprites(x, x.k.tx) : 0u;
+    const bool slow = x.k.occl && (x.k.zdyn || above_drapes(x, x.k.tx) != 0 || __popc(ab_s) > MAXC);  // (uniform)
+    uint32_t cpos[MAXC];  // row << 8 | column of a covering sprite, 0xFFFFFFFF: none
+    {
+      uint32_t m = slow ? 0u : ab_s;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const bool has = m != 0u;
+        const int cell = has ? x.l.snap[(__ffs((int)m) - 1) * WAVE + x.lane] : -1;
+        const uint32_t r = __umulhi((uint32_t)(cell >= 0 ? cell : 0), x.k.magic_c);
+        cpos[i] = cell >= 0 ? (r << 8) | ((uint32_t)cell - r * (uint32_t)x.k.C) : 0xFFFFFFFFu;
+        m &= m - 1u;
       }
     }
-    const uint32_t dx = tfield(x, x.k.tx, T_IDX);
     auto layer_row = [&](int r) {
-      return ((busy_rows >> (r & 31)) & 1) ? drape_layer_row(x, x.k.tx, r) : row_get(x, x.l.snapd, dx, r);
+      if (slow) return drape_layer_row(x, x.k.tx, r);
+      uint64_t cover = 0;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) cover |= (cpos[i] >> 8) == (uint32_t)r ? 1ull << (cpos[i] & 63u) : 0ull;
+      return row_get(x, x.l.snapd, dx, r) & ~cover;
     };
     uint64_t cols = 0;
     for (int r = 0; r < R; ++r) cols |= layer_row(r);
@@ -755,10 +767,19 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
     const uint64_t seed = ((uint64_t)x.k.seed_lo | ((uint64_t)x.k.seed_hi << 32)) ^ EM_RNG_SALT;
     int pick = (int)(action_hash(seed, (uint64_t)genv, (uint64_t)draws) % (uint32_t)n);
     ++draws;
-    // the pick-th set column: drop the pick lowest set bits
-    uint64_t rest = cols;
-    for (int j = 0; j < pick; ++j) rest &= rest - 1;
-    const int col = __ffsll((unsigned long long)rest) - 1;
+    // the pick-th set column (0-based): bisection on popcounts, six steps
+    int col = 0;
+    {
+      uint64_t v = cols;
+#pragma unroll
+      for (int w = 32; w >= 1; w >>= 1) {
+        const int below = __popcll(v & ((1ull << w) - 1ull));
+        const bool up = pick >= below;
+        pick = up ? pick - below : pick;
+        col = up ? col + w : col;
+        v = up ? v >> w : v;
+      }
+    }
     int row = 0;  // the lowest X of that column (np.max(np.flatnonzero(layers['X'][:, col])), :248)
     for (int r = 0; r < R; ++r)
       if ((layer_row(r) >> col) & 1) row = r;
@@ -1190,7 +1211,6 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
       st[(k.w_z + 1) * bp] = z1;
     }
     flags = (x.game_over ? F_OVER : 0u) | ((x.err & 7u) << F_ERR_SHIFT) | ((uint32_t)((dxv + 1) & 0xFF) << 8);
-    if (!(a.debug & 16)) {  // (ablation: the logic wave's own global stores)
     st[W_RNG * bp] = draws;
     if (k.w_next >= 0) st[k.w_next * bp] = (uint32_t)x.next;
     st[W_FRAME * bp] = (uint32_t)x.frame;
@@ -1217,7 +1237,6 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     out.done[env] = (uint8_t)x.game_over;
     out.frame[env] = x.frame;
     out.error[env] = (uint8_t)x.err;
-    }
 
     if (timing) c_sec[2] = __builtin_readcyclecounter() - t_wb;  // write-back
     const unsigned long long t_occ = timing ? __builtin_readcyclecounter() : 0ull;
@@ -1292,7 +1311,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
       if (!k.occl) l.sdescraw[s * WAVE + lane] = make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
       int tr, tc;
       sprite_true(x, s, tr, tc);
-      if (!(a.debug & 16)) P.track[s * bp + env] = tr | (tc << 8) | ((int)(l.flg[s * WAVE + lane] & 1) << 16) | ((int)do_reset << 24);
+      P.track[s * bp + env] = tr | (tc << 8) | ((int)(l.flg[s * WAVE + lane] & 1) << 16) | ((int)do_reset << 24);
     }
     if (fc) move_windows(x, fc, env, l.wcorner);  // fused croppers follow this step's things
     if (timing) c_sec[3] = __builtin_readcyclecounter() - t_occ;  // occlusion + descriptors

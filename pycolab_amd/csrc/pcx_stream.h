@@ -346,8 +346,6 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
   const uint32_t wave_step = (uint32_t)(NWAVES ? NWAVES : nwaves_rt) * WAVE;
   const int Rv = R ? R : rt.rows, Cv = C ? C : rt.cols;
   const uint32_t pitch = 4u * (QW ? (uint32_t)QW : (uint32_t)rt.qw);
-  const uint8_t* const backdrop1 = reinterpret_cast<const uint8_t*>(backdrop4);
-  const uint8_t* const cell_id1 = reinterpret_cast<const uint8_t*>(cell_ids);
   uint32_t lay_s[NS > 0 ? NS : 1], lay_d[ND > 0 ? ND : 1], lay_b[NB > 0 ? NB : 1];
 #pragma unroll
   for (int s = 0; s < NS; ++s) lay_s[s] = pm.sprite_off[s] / pitch;
@@ -363,7 +361,7 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
   const int n = fc->n;
   for (int w = 0; w < n; ++w) {
     const crop::FusedWindow& fw = fc->w[w];
-    const int rows = fw.rule.rows, cols = fw.rule.cols, wcells = rows * cols;
+    const int rows = fw.rule.rows, cols = fw.rule.cols;
     const uint32_t opitch = (uint32_t)fw.out_pitch, qw = opitch >> 2, total = (uint32_t)WAVE * qw;
     const uint32_t ostride = (uint32_t)(1 + L) * opitch;
     uint8_t* const obase = uniform_ptr(fw.out + (size_t)env0 * ostride);
