@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
     stream::stream_planes<NS, ND, NB, SQW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                         cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid, QW);
+                                                         cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid, QW, nullptr, nullptr, lds);
   if (fc)
     stream::stream_windows<NS, ND, NB, SQW, NWAVES, SR, SC, true>(fc, pm, bch4, env0, lds + O_BD, cm, sdesc, skipv, CWP, lane, wave, wcorner,
                                                                  cid, stream::BoardShape{R, C, QW});
@@ -352,7 +352,8 @@ class BetterScrollyBackend : public Backend {
     int sc[NS], dc = k_.drape_ch4 & 0xFF, bc[NB > 0 ? NB : 1] = {};
     for (int s = 0; s < NS; ++s) sc[s] = k_.sprite_ch4[s] & 0xFF;
     for (int b = 0; b < NB; ++b) bc[b] = k_.bchar_ch4[b] & 0xFF;
-    stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB);
+    if (!stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB))
+      return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the channels-last epilogue needs rows*cols %% 4 == 0");
     return 0;
   }
 
@@ -501,6 +502,7 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
   size_t lds = ((size_t)lay_.QW * (2 + NB) + lay_.FW + WAVE * (MAX_CW | 1) + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4;
   int waves_per_cu = 8;  // single-wave workgroups: pad LDS so that about eight share a CU (as for scrolly_maze)
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
+  const stream::EpilogueArgs epi_ = stream::with_hwc_scratch(this->epi_, lds, coop ? 4 : 1);  // (channels-last epilogue: its exchange area behind the kernel's own LDS)
   if (!coop && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
     if (want > 64 * 1024) want = 64 * 1024;

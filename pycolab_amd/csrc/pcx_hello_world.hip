@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
   if (!(fc && fc->only))
     stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                                flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, 0, lds + O_FLATRAW,
-                                                               reinterpret_cast<const uint2*>(lds + O_SDESCRAW));
+                                                               reinterpret_cast<const uint2*>(lds + O_SDESCRAW), lds);
   if (fc)
     stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
 }
@@ -291,7 +291,8 @@ class HelloWorldBackend : public Backend {
     int sc[NS], dc = k_.drape_ch4 & 0xFF, bc[NB > 0 ? NB : 1] = {};
     for (int s = 0; s < NS; ++s) sc[s] = k_.sprite_ch4[s] & 0xFF;
     for (int b = 0; b < NB; ++b) bc[b] = k_.bchar_ch4[b] & 0xFF;
-    stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB);
+    if (!stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB))
+      return set_error(PCX_E_UNSUPPORTED, "hello_world backend: the channels-last epilogue needs rows*cols %% 4 == 0");
     return 0;
   }
 
@@ -404,6 +405,7 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
   size_t lds = ((size_t)lay_.QW * (1 + NB) + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS +
                 (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS * WAVE : 0)) * 4;
+  const stream::EpilogueArgs epi_ = stream::with_hwc_scratch(this->epi_, lds, coop ? 4 : 1);  // (channels-last epilogue: its exchange area behind the kernel's own LDS)
   if (!coop && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
     if (want > 64 * 1024) want = 64 * 1024;

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts 
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   if (!(fc && fc->only))
     stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                 flat, sdesc, skipv, FWP, lane, wave, epi, env0);
+                                                 flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, 0, nullptr, nullptr, lds);
   if (fc)
     stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
 }
@@ -486,7 +486,7 @@ class MaraudersBackend : public Backend {
   int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     if (!stream::fill_epilogue(epi_, d, cells, sprite_ch_, NS, drape_ch_, ND, bchar_ch_, NB))
-      return set_error(PCX_E_UNSUPPORTED, "marauders backend: epilogue needs rows*cols %% 4 == 0");
+      return set_error(PCX_E_UNSUPPORTED, "marauders backend: the channels-last epilogue needs rows*cols %% 4 == 0");
     return 0;
   }
 
@@ -634,6 +634,7 @@ int MaraudersBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   if (const char* e = getenv("PCX_EM_WAVES")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 8) nwaves = v; }
   const size_t words = (size_t)QW * (1 + NB) + (ND + 1) * WAVE * FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS;
   size_t lds = words * 4;
+  const stream::EpilogueArgs epi_ = stream::with_hwc_scratch(this->epi_, lds, nwaves);  // (channels-last epilogue: its exchange area behind the kernel's own LDS)
   if (nwaves == 1 && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
     if (want > 64 * 1024) want = 64 * 1024;

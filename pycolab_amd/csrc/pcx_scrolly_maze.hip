@@ -1486,11 +1486,14 @@ class ScrollyMazeBackend : public Backend {
     if (d && fused_.on) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: release the fused croppers first");
     if (d && !shipped_shape)
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the feature-array epilogue exists for the shipped 10x30 shape");
+    if (d && d->channels_last)
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the channels-last epilogue lives in the shared streaming loop (pcx_stream.h), "
+                                          "not in this kernel's own: run ObservationToFeatureArray as its own kernel");
     int sc[MAX_NS], dc[2] = {k_.maze_ch, k_.cash_ch}, bc[MAX_L];
     for (int s = 0; s < k_.NS; ++s) sc[s] = k_.sprite_ch[s];
     for (int i = 0; i < k_.n_bchars; ++i) bc[i] = k_.bchar[i];
     if (!stream::fill_epilogue(epi_, d, k_.cells, sc, k_.NS, dc, 2, bc, k_.n_bchars))
-      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: epilogue needs rows*cols %% 4 == 0");
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the channels-last epilogue needs rows*cols %% 4 == 0");
     return 0;
   }
 

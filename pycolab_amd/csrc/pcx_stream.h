@@ -104,6 +104,12 @@ struct EpilogueArgs {
   // the loop runs twice, first for the uint8 planes, then for the float32 planes: a wave then feeds half
   // as many write streams at a time (it composes every dword twice; the loop is store-bound)
   int32_t two_pass = 0;
+  // channels last (ObservationToFeatureArray(permute=(1, 2, 0)), rendering.py:545-661): out is [batch][cells][depth].
+  // A wave's 256 cells x depth floats are one contiguous piece of it; the lanes exchange their layer dwords through
+  // `depth` x 64 words of LDS per wave (hwc_lds_off: word offset in the workgroup's dynamic LDS) so that every
+  // store instruction still covers 1 KiB of consecutive bytes.
+  int32_t hwc = 0, depth = 0;
+  uint32_t hwc_lds_off = 0, magic_depth = 0;  // magic_depth: floor(2^32 / depth) + 1
   int32_t sprite_slot[PCX_MAX_SPRITES], drape_slot[PCX_MAX_DRAPES], bchar_slot[PCX_MAX_CHARS];
 };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -130,7 +136,8 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
                                               const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
                                               const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
                                               const EpilogueArgs& epi, int64_t env0, const uint32_t* cell_ids = nullptr,
-                                              int qw_rt = 0, const uint32_t* flatraw = nullptr, const uint2* sdescraw = nullptr) {
+                                              int qw_rt = 0, const uint32_t* flatraw = nullptr, const uint2* sdescraw = nullptr,
+                                              uint32_t* lds_base = nullptr) {
   const uint32_t QWv = QW ? (uint32_t)QW : (uint32_t)qw_rt;
   uint8_t* const pb_board = uniform_ptr(group_base);
   uint8_t* pb_s[NS];
@@ -170,6 +177,11 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   uint32_t foff = e * epi.env_stride + 16u * q;
   const uint32_t dfoff = DE * epi.env_stride + 16u * DQ, wrap_foff = epi.env_stride - 16u * QWv;
   const uint32_t e_0 = e, q_0 = q, voff_0 = voff, eF_0 = eF, foff_0 = foff;
+  // channels last: this wave's exchange area, rows of the layers nobody paints stay zero
+  const bool hwc = epi_on && epi.hwc != 0;
+  uint32_t* const hw = hwc ? lds_base + epi.hwc_lds_off + (uint32_t)wave * (uint32_t)epi.depth * WAVE : nullptr;
+  if (hwc)
+    for (int sl = 0; sl < epi.depth; ++sl) hw[sl * WAVE + lane] = 0u;
 #pragma unroll 1
   for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
   const int role = two_pass ? pass : -1;  // 0: the uint8 planes, 1: the float32 planes, -1: both
@@ -186,15 +198,19 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
       eF = wrap ? eF + FWP : eF;
       foff = wrap ? foff + wrap_foff : foff;
     }
-    if (any_skip && skip[e_now]) continue;
+    // (channels last: a skipped lane still takes part in the exchange below -- its stores are predicated instead)
+    const bool skipped = any_skip && skip[e_now] != 0;
+    if (skipped && !hwc) continue;
     // (only the single-wave shape without epilogue -- the store-issue-bound one, few enough plane
     // bases to stay in SGPRs -- takes the bare store; see pcx_internal.h saddr_store_dword)
     constexpr bool GUARD = NWAVES > 1 || EPI;
-    auto put = [&](uint8_t* base, uint32_t v) { if (role != 1) saddr_store_dword<GUARD>(voff_now, v, base); };
+    auto put = [&](uint8_t* base, uint32_t v) { if (role != 1 && !skipped) saddr_store_dword<GUARD>(voff_now, v, base); };
     // a layer: its uint8 plane and, when selected, its float32 feature plane
     auto put_layer = [&](uint8_t* base, uint32_t m01, int32_t slot) {
       if (layers_on) put(base, m01);
-      if (epi_on && slot >= 0 && role != 0) {
+      if (epi_on && slot >= 0 && role != 0 && hwc) {
+        hw[slot * WAVE + lane] = m01;
+      } else if (epi_on && slot >= 0 && role != 0) {
         f32x4 f;
         f.x = (float)(m01 & 0xFFu); f.y = (float)((m01 >> 8) & 0xFFu); f.z = (float)((m01 >> 16) & 0xFFu); f.w = (float)(m01 >> 24);
         const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
@@ -273,6 +289,36 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
     for (int s = 0; s < NS; ++s) put_layer(pb_s[s], ms[s] & 0x01010101u, epi.sprite_slot[s]);
 #pragma unroll
     for (int b = 0; b < NB; ++b) put_layer(pb_b[b], mb[b] & ~uni, epi.bchar_slot[b]);
+    if (hwc && role != 0) {
+      // The wave's 64 board dwords = 256 consecutive cells = 256 x depth consecutive floats of the output (boards
+      // of whole dwords: no padding between environments).  Lane l, trip j writes the float4 at index j * 64 + l
+      // of that piece: float n belongs to cell n / depth, layer n % depth, whose byte is in the dword lane
+      // (cell >> 2) left in row (n % depth) of the exchange area.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t depth = (uint32_t)epi.depth;
+      const uint32_t piece = 16u * depth * ((uint32_t)it * WAVE);  // byte offset of the piece from the group's base
+      for (uint32_t j = 0; j < depth; ++j) {
+        const uint32_t g = j * WAVE + (uint32_t)lane, n0 = 4u * g;
+        uint32_t cl = __umulhi(n0, epi.magic_depth), sl = n0 - cl * depth;
+        const uint32_t src0 = cl >> 2;
+        f32x4 f;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          v[t] = (float)((hw[sl * WAVE + (cl >> 2)] >> (8u * (cl & 3u))) & 0xFFu);
+          ++sl;
+          if (sl == depth) { sl = 0; ++cl; }
+        }
+        f.x = v[0]; f.y = v[1]; f.z = v[2]; f.w = v[3];
+        // the four floats lie in one environment (cells * depth is a multiple of four): skipped with it
+        bool dropped = false;
+        if (any_skip) dropped = skip[((uint32_t)it * WAVE + src0) / QWv] != 0;
+        if (!dropped) saddr_store_dwordx4<GUARD>(piece + 16u * g, f, fbase);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // (the next iteration overwrites the exchange area)
+    }
   }
   }  // passes
 }
@@ -490,13 +536,13 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
 // whose sprites / drape slots / backdrop-only characters paint the given
 // characters.  (Boards that are not a whole number of dwords are fine: stream_planes writes the
 // last dword of a feature plane cell by cell.)
-inline bool fill_epilogue(EpilogueArgs& a, const pcx_epilogue_desc* d, int cells, const int* sprite_ch, int ns,
+inline bool fill_epilogue(EpilogueArgs& result, const pcx_epilogue_desc* d, int cells, const int* sprite_ch, int ns,
                           const int* drape_ch, int nd, const int* bchar_ch, int nb) {
-  a = EpilogueArgs();
+  EpilogueArgs a;  // (committed to `result` on success only: a refused descriptor changes nothing)
   for (int i = 0; i < PCX_MAX_SPRITES; ++i) a.sprite_slot[i] = -1;
   for (int i = 0; i < PCX_MAX_DRAPES; ++i) a.drape_slot[i] = -1;
   for (int i = 0; i < PCX_MAX_CHARS; ++i) a.bchar_slot[i] = -1;
-  if (!d) return true;
+  if (!d) { result = a; return true; }
   a.out = d->out_dev;
   a.env_stride = (uint32_t)d->depth * (uint32_t)cells * 4u;
   a.plane_bytes = (uint32_t)cells * 4u;
@@ -505,13 +551,30 @@ inline bool fill_epilogue(EpilogueArgs& a, const pcx_epilogue_desc* d, int cells
   // (marauders 32,768: 0.275 -> 0.198 ms, step + separate kernel: 0.280; hello_world's fifteen do not:
   // profiles/r03_post_kernels.md)
   a.two_pass = 1 + ns + nd + nb + d->depth > 16;
+  a.depth = d->depth;
+  a.magic_depth = 0xFFFFFFFFu / (uint32_t)d->depth + 1u;
+  if (d->channels_last) {  // one float32 stream instead of `depth`; needs boards of whole dwords (no padding between environments)
+    if (cells % 4 != 0) return false;
+    a.hwc = 1;
+    a.two_pass = 1 + ns + nd + nb + 1 > 16;
+  }
   if (const char* e = getenv("PCX_EPI_TWO_PASS")) a.two_pass = atoi(e) != 0;
   for (int f = 0; f < d->depth; ++f) {
     for (int i = 0; i < ns; ++i) if (sprite_ch[i] == d->chars[f]) a.sprite_slot[i] = f;
     for (int i = 0; i < nd; ++i) if (drape_ch[i] == d->chars[f]) a.drape_slot[i] = f;
     for (int i = 0; i < nb; ++i) if (bchar_ch[i] == d->chars[f]) a.bchar_slot[i] = f;
   }
+  result = a;
   return true;
+}
+
+// Host side, at launch: the channels-last epilogue's exchange area goes behind the kernel's own dynamic LDS.
+inline EpilogueArgs with_hwc_scratch(EpilogueArgs a, size_t& lds_bytes, int waves_per_workgroup) {
+  if (a.out && a.hwc) {
+    a.hwc_lds_off = (uint32_t)((lds_bytes + 3) / 4);
+    lds_bytes = 4 * (size_t)a.hwc_lds_off + (size_t)waves_per_workgroup * (size_t)a.depth * WAVE * 4;
+  }
+  return a;
 }
 
 // Host side of the fused croppers: their description lives in device memory (the

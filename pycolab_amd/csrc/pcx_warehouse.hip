@@ -316,7 +316,7 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
   if (!(fc && fc->only))
     stream::stream_planes<NS, 1, NB, SQW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                         flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, QW, lds + O_FLATRAW,
-                                                        reinterpret_cast<const uint2*>(lds + O_SDESCRAW));
+                                                        reinterpret_cast<const uint2*>(lds + O_SDESCRAW), lds);
   if (fc)
     stream::stream_windows<NS, 1, NB, SQW, NWAVES, SR, SC>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner,
                                                          nullptr, stream::BoardShape{R, C, QW});
@@ -359,7 +359,7 @@ class WarehouseBackend : public Backend {
   int set_epilogue(const pcx_epilogue_desc* d) override {
     if (d && (!static_shape_ || unoccluded_)) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: the feature-array epilogue exists for the compiled shapes, occluded layers");
     if (!stream::fill_epilogue(epi_, d, lay_.cells, sprite_ch_, NS_, &drape_ch_, 1, bchar_ch_, NB_))
-      return set_error(PCX_E_UNSUPPORTED, "warehouse backend: epilogue needs rows*cols %% 4 == 0");
+      return set_error(PCX_E_UNSUPPORTED, "warehouse backend: the channels-last epilogue needs rows*cols %% 4 == 0");
     return 0;
   }
 
@@ -534,6 +534,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   const size_t words = (size_t)lay_.QW * (1 + NB_) + 3 * R_ + WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE + WAVE + stream::WCORNER_WORDS +
                        (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE : 0);
   size_t lds = words * 4;
+  const stream::EpilogueArgs epi_ = stream::with_hwc_scratch(this->epi_, lds, coop ? 4 : 1);  // (channels-last epilogue: its exchange area behind the kernel's own LDS)
   if (!coop && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
     if (want > 64 * 1024) want = 64 * 1024;

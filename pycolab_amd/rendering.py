@@ -221,30 +221,34 @@ class ObservationToFeatureArray(object):
     stops the step from writing the uint8 layer planes (`Observation.layers`
     then goes stale; the board stays valid) for consumers that only ingest
     the features.  Returns False, and changes nothing, where the engine's
-    kernel cannot do it (default axis order only, batch > 1, the five
-    hand-written step kernels with occluded layers and no fused croppers):
-    calls then run the post-processor as its own kernel, as before.  The
+    kernel cannot do it (batch > 1; the five hand-written step kernels with
+    occluded layers and no fused croppers; axis order default or channels
+    last, `permute=(1, 2, 0)` -- the latter on boards of whole dwords and not
+    in the scrolly_maze kernel): calls then run the post-processor as its own
+    kernel, as before.  The
     engine owns the installed epilogue: when this object goes away, or another
     post-processor fuses, the kernel stops writing into this one's tensor."""
     torch = dev.torch_module()
-    if (self._permute not in (None, (0, 1, 2)) or torch is None or engine._native is None or engine.batch == 1 or
+    if (self._permute not in (None, (0, 1, 2), (1, 2, 0)) or torch is None or engine._native is None or engine.batch == 1 or
         len(set(self._layers)) != len(self._layers) or any(ord(c) > 255 for c in self._layers)):
       return False
-    out = torch.zeros((engine.batch, self._depth, engine.rows, engine.cols), dtype=torch.float32,
-                      device='cuda:%d' % engine._device_id)
+    channels_last = self._permute == (1, 2, 0)
+    shape = (engine.rows, engine.cols, self._depth) if channels_last else (self._depth, engine.rows, engine.cols)
+    out = torch.zeros((engine.batch,) + shape, dtype=torch.float32, device='cuda:%d' % engine._device_id)
     d = N.EpilogueDesc()
     d.depth = self._depth
     for i, ch in enumerate(self._layers):
       d.chars[i] = ord(ch)
     d.out_dev = out.data_ptr()
     d.skip_layers = int(bool(skip_layers))
+    d.channels_last = int(channels_last)
     try:
       N.check(N.lib().pcx_engine_set_epilogue(engine._native, ctypes.byref(d)))
     except NotImplementedError:
       return False
     # start from the current observation (environments a later step leaves
     # untouched keep features that match their planes)
-    out.copy_(ObservationToFeatureArray(self._layers)(engine._result()[0]))
+    out.copy_(ObservationToFeatureArray(self._layers, self._permute)(engine._result()[0]))
     # The ENGINE owns the epilogue: it keeps this converter and the tensor the
     # kernel writes alive for as long as it may launch (a converter that was
     # garbage-collected would leave the kernel writing freed memory), tells the

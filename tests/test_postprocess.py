@@ -258,6 +258,48 @@ def test_feature_array_fused_on_boards_of_any_size(name, chars, n_actions, batch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('skip_layers', [False, True])
+@pytest.mark.parametrize('name,chars,n_actions,batch', [('marauders', 'PXB aqz', 4, 300), ('marauders', 'BX|^P ', 4, 33000),
+                                                         ('hello_world', '@1 #3', 4, 300), ('hello_world', '1234@', 4, 70000),
+                                                         ('hello_custom_A', '@2#', 4, 500), ('warehouse_custom_B', 'P1X #', 5, 700),
+                                                         ('warehouse_custom_B', 'X_.', 5, 90000)])
+def test_channels_last_feature_array_fused_into_the_step_kernel(name, chars, n_actions, batch, skip_layers):
+  """ObservationToFeatureArray(permute=(1, 2, 0)).fuse_into(engine): the render loop writes [B, rows, cols, depth]
+  itself (the lanes of a wave exchange their layer dwords through LDS so that the stores stay contiguous): equal to
+  the separate kernel every step, through auto-resets and with finished environments left frozen, in both launch
+  shapes; refused where the board is not a whole number of dwords and by the scrolly_maze kernel."""
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template(name)
+  assert (t.rows * t.cols) % 4 == 0
+  eng = Engine.from_template(t, batch=batch, auto_reset=True, seed=5)
+  eng.its_showtime()
+  eng.step_hashed(3, 0, 12)
+  fused = rendering.ObservationToFeatureArray(chars, permute=(1, 2, 0))
+  assert fused.fuse_into(eng, skip_layers=skip_layers), name
+  plain = rendering.ObservationToFeatureArray(chars, permute=(1, 2, 0))
+  guard = fused._fused[1]
+  for step in range(10 if batch > 5000 else 40):
+    eng._auto_reset = step % 4 != 3   # every fourth step leaves finished environments untouched
+    obs = eng.play(torch.randint(0, n_actions, (batch,), dtype=torch.int32, device='cuda'))[0]
+    got = fused(obs)
+    assert got is guard and got.shape == (batch, t.rows, t.cols, len(chars))
+    for k, ch in enumerate(chars):
+      assert torch.equal(got[..., k], (obs.board == ord(ch)).to(torch.float32)), (name, step, ch)
+    if not skip_layers:
+      assert torch.equal(got, plain(obs)), (name, step)
+  eng.close()
+  odd = Engine.from_template(helpers.load_template('better_scrolly_maze_L0'), batch=64)   # 4,005 cells
+  odd.its_showtime()
+  assert not rendering.ObservationToFeatureArray('P@', permute=(1, 2, 0)).fuse_into(odd)
+  assert rendering.ObservationToFeatureArray('P@').fuse_into(odd)
+  sm = Engine.from_template(helpers.load_template('scrolly_maze_L0'), batch=64)
+  sm.its_showtime()
+  assert not rendering.ObservationToFeatureArray('P@', permute=(1, 2, 0)).fuse_into(sm)
+  odd.close(); sm.close()
+
+
+@pytest.mark.gpu
 def test_fused_epilogue_belongs_to_the_engine():
   """The step kernel writes a fused converter's tensor at every step, so the ENGINE keeps
   converter and tensor alive (a converter dropped by the caller must not leave the kernel

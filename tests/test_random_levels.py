@@ -260,17 +260,24 @@ def _random_croppers(rng, t, track):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('maker,track', [(random_warehouse, 'P'), (random_better_scrolly, 'bP')])
+@pytest.mark.parametrize('maker,track,generic', [(random_warehouse, 'P', False), (random_better_scrolly, 'bP', False),
+                                                 (random_warehouse, 'XP', True), (random_better_scrolly, '@b', True)])
 @pytest.mark.parametrize('seed', range(6))
-def test_random_levels_fused_croppers_equal_stand_alone(maker, track, seed):
+def test_random_levels_fused_croppers_equal_stand_alone(maker, track, generic, seed, monkeypatch):
   """Random windows (padded and not, larger than the board, off the board, every
   margin / offset / saccade setting) on random levels: the step kernel's own
-  croppers against the stand-alone cropper kernels, every step."""
+  croppers against the stand-alone cropper kernels, every step.  `generic`:
+  through the table-driven kernel, whose croppers also follow drapes (the
+  track lists there start with one)."""
   import torch
   from pycolab_amd import cropping
   from pycolab_amd.engine import Engine
+  if generic:
+    monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
   rng = np.random.RandomState(3000 + seed)
   t = GameTemplate.from_engine(maker(rng))
+  have = {chr(sp['ch']) for sp in t.sprites} | {chr(d['ch']) for d in t.drapes}
+  track = ''.join(c for c in track if c in have) or chr(t.sprites[0]['ch'])
   build = _random_croppers(rng, t, track)
   B = int(rng.choice([70, 333]))
   a = Engine.from_template(t, batch=B, auto_reset=True, seed=9)

@@ -48,6 +48,19 @@ if what in ('all', 'epi', 'sm'):
     ms_fused = sorted(timed(one) for _ in range(3))[1]
     print('%-14s %7d envs  two_pass=%s  step %.4f  step+post %.4f  fused %.4f ms' % (name, batch, os.environ.get('PCX_EPI_TWO_PASS', 'auto'), ms_step, ms_two, ms_fused), flush=True)
     eng.close()
+if what in ('all', 'hwc'):  # channels last: step + pcx_post_features_hwc vs the epilogue exchanging through LDS
+  for name, batch in (('marauders', 32768), ('marauders', 262144), ('hello_world', 65536)):
+    t, eng, one = engine(name, batch)
+    chars = ''.join(chr(c) for c in t.chars)
+    obs = eng._result()[0]
+    post = rendering.ObservationToFeatureArray(chars, permute=(1, 2, 0))
+    post(obs)
+    ms_two = sorted(timed(lambda: (one(), post(obs))) for _ in range(3))[1]
+    fused = rendering.ObservationToFeatureArray(chars, permute=(1, 2, 0))
+    assert fused.fuse_into(eng)
+    ms_fused = sorted(timed(one) for _ in range(3))[1]
+    print('%-14s %7d envs  channels last: step+post %.4f  fused %.4f ms' % (name, batch, ms_two, ms_fused), flush=True)
+    eng.close()
 if what in ('all', 'win'):
   for batch in (65536, 262144):
     t, eng, one = engine('better_scrolly_maze_L0', batch)
