@@ -470,8 +470,7 @@ typedef struct pcx_epilogue_desc {
   int32_t skip_layers;
   /* != 0: channels last -- out_dev is [batch][rows*cols][depth], what
    * ObservationToFeatureArray(permute=(1, 2, 0)) returns (rendering.py:545-661).
-   * Needs rows*cols % 4 == 0; PCX_E_UNSUPPORTED otherwise and from the metric
-   * game's kernel (pcx_scrolly_maze_step), whose render loop is its own. */
+   * Needs rows*cols % 4 == 0 (PCX_E_UNSUPPORTED otherwise). */
   int32_t channels_last;
 } pcx_epilogue_desc;
 int pcx_engine_set_epilogue(pcx_engine* e, const pcx_epilogue_desc* d);

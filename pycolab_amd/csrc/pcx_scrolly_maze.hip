@@ -1335,11 +1335,28 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // group first, the float32 planes in a second sweep over the same codes
   constexpr bool TWO_PASS = EPI && CODES && INCR;
   const int n_pass = TWO_PASS && epi.two_pass && layers_on ? 2 : 1;
+  // channels-last epilogue (pcx_stream.h hwc_emit): this wave's exchange area, rows of unselected layers stay zero
+  const bool hwc = EPI && epi.hwc != 0;
+  // (two areas per wave, used in turn: an iteration drops its bytes into one and stores the floats of the iteration
+  // before from the other)
+  const uint32_t hw_words = hwc ? (uint32_t)epi.depth * WAVE : 0u;
+  uint32_t* const hw = hwc ? lds_raw + epi.hwc_lds_off + (uint32_t)(COOP ? wave : 0) * 2u * hw_words : nullptr;
+  if (hwc)
+    for (uint32_t sl = 0; sl < 2u * (uint32_t)epi.depth; ++sl) hw[sl * WAVE + lane] = 0u;
+  const uint32_t hw_limit = (uint32_t)((COOP ? EPW : WAVE) * QW);
 #pragma unroll 1
   for (int pass = 0; pass < n_pass; ++pass) {
   const bool do_u8 = n_pass == 1 || pass == 0, do_f32 = n_pass == 1 || pass == 1;
   if constexpr (TWO_PASS) { e = 0; q = lane; voff = 4u * lane; eF = 0; foff = 16u * lane; }
   if constexpr (PREFETCH) code_pf = codes[eF + q];
+  int hw_it = -1;
+  uint32_t hw_sel = 0;
+  auto hw_turn = [&](int it_now) {  // store the previous iteration's floats, then this iteration's area becomes "previous"
+    if (hw_it >= 0)
+      stream::hwc_emit<true>(hw + (hw_sel ^ 1u) * hw_words, epi, (uint32_t)hw_it * WAVE, lane, any_skip, l.skip, (uint32_t)QW, fbase, hw_limit);
+    hw_it = it_now;
+    hw_sel ^= 1u;
+  };
 #pragma unroll 1
   for (int it = !planes_on ? n_iter : COOP ? wave : TFUSE ? wave - 1 : 0; it < n_iter;
        it += COOP ? (int)(blockDim.x >> 6) : TFUSE ? (int)(blockDim.x >> 6) - 1 : 1) {
@@ -1366,17 +1383,23 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       eF_now = e_now * (CODES ? CODE_PITCH : FWP);
       if constexpr (EPI) foff_now = 16u * f + e_now * f_skew;
     }
-    if constexpr (COOP) { if ((int)e_now >= EPW) continue; }  // (past the group's last environment)
-    if (any_skip && l.skip[e_now]) continue;
+    // (past the group's last environment, or an environment this launch leaves alone; with the channels-last
+    // epilogue such a lane still takes part in the wave's exchange and only its stores are predicated)
+    bool dead = false;
+    if constexpr (COOP) dead = (int)e_now >= EPW;
+    if (!dead && any_skip) dead = l.skip[e_now] != 0;
+    if (dead && !hwc) continue;
     if constexpr (CODES) {
       // one LDS read, then one v_perm_b32 per plane: the board dword picks each
       // cell's character out of the eight, layer k picks byte k of a one-hot table
       const uint32_t code = PREFETCH ? code_cur : codes[eF_now + q_now];
       auto put_plane = [&](uint8_t* base, uint32_t v, int32_t slot) {
-        if (!EPI || ((slot == -2 || layers_on) && do_u8))
+        if (!EPI || ((slot == -2 || layers_on) && do_u8 && !dead))
           asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(base));
         if constexpr (EPI) {
-          if (slot >= 0 && do_f32) {
+          if (slot >= 0 && do_f32 && hwc) {
+            stream::hwc_put(hw + hw_sel * hw_words, (uint32_t)epi.depth, lane, slot, v);
+          } else if (slot >= 0 && do_f32) {
             stream::f32x4 f;
             f.x = (float)(v & 0xFFu); f.y = (float)((v >> 8) & 0xFFu); f.z = (float)((v >> 16) & 0xFFu); f.w = (float)(v >> 24);
             const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
@@ -1391,12 +1414,15 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       for (int kk = 0; kk < SL; ++kk)
         put_plane(pbk[1 + kk], __builtin_amdgcn_perm(kk >= 4 ? 1u << (8 * (kk & 3)) : 0u, kk < 4 ? 1u << (8 * (kk & 3)) : 0u, code),
                   lslot[kk]);
+      if constexpr (EPI) {
+        if (hwc && do_f32) hw_turn(it);
+      }
       continue;
     }
     // scalar base (pinned above) + 32-bit lane offset: one `global_store_dword
     // voffset, data, sbase` per plane, no per-store address arithmetic
     compose(e_now, q_now, eF_now, [&](int plane, uint32_t v) {
-      if (!EPI || plane == 0 || layers_on) {
+      if ((!EPI || plane == 0 || layers_on) && !dead) {
         if constexpr (SL != 0)  // the static-shape instance keeps all nine bases in SGPRs
           saddr_store_dword<GUARD_SADDR>(voff_now, v, pb[plane]);
         else
@@ -1405,7 +1431,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       if constexpr (EPI) {  // a selected layer also leaves as four float32 (rendering.py:545-661)
         const int32_t slot = plane == 0 ? -1 : plane < 3 ? epi.drape_slot[plane - 1]
                              : plane < 3 + NS ? epi.sprite_slot[plane - 3 < NS ? plane - 3 : 0] : epi.bchar_slot[plane - 3 - NS];
-        if (slot >= 0) {
+        if (slot >= 0 && hwc) {
+          stream::hwc_put(hw + hw_sel * hw_words, (uint32_t)epi.depth, lane, slot, v & 0x01010101u);
+        } else if (slot >= 0) {
           stream::f32x4 f;
           f.x = (float)(v & 0xFFu); f.y = (float)((v >> 8) & 0xFFu); f.z = (float)((v >> 16) & 0xFFu); f.w = (float)(v >> 24);
           const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
@@ -1413,6 +1441,12 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
         }
       }
     });
+    if constexpr (EPI) {
+      if (hwc) hw_turn(it);
+    }
+  }
+  if constexpr (EPI) {
+    if (hwc && hw_it >= 0) hw_turn(-1);  // the last iteration's floats
   }
   }  // passes
   if constexpr (FUSABLE) {
@@ -1486,9 +1520,6 @@ class ScrollyMazeBackend : public Backend {
     if (d && fused_.on) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: release the fused croppers first");
     if (d && !shipped_shape)
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the feature-array epilogue exists for the shipped 10x30 shape");
-    if (d && d->channels_last)
-      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the channels-last epilogue lives in the shared streaming loop (pcx_stream.h), "
-                                          "not in this kernel's own: run ObservationToFeatureArray as its own kernel");
     int sc[MAX_NS], dc[2] = {k_.maze_ch, k_.cash_ch}, bc[MAX_L];
     for (int s = 0; s < k_.NS; ++s) sc[s] = k_.sprite_ch[s];
     for (int i = 0; i < k_.n_bchars; ++i) bc[i] = k_.bchar[i];
@@ -1838,27 +1869,33 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     if (const char* e = getenv("PCX_COOP_EPW")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) epw = v; }
     ac.envs_per_group = epw;
     const unsigned coop_groups = (unsigned)(bpad_ / epw);
-    if (epi_.out)
+    if (epi_.out) {
+      size_t lds_e = (size_t)k_.lds_words * 4;
+      const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_e, coop_waves);
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, true>), dim3(coop_groups),
-                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
-    else
+                         dim3(coop_waves * WAVE), lds_e, s, k_, P, ac, out, ep, fused_.ptr());
+    } else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3(coop_groups),
                          dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
   } else if (shipped_shape && waves_per_wg == 1 && use_codes) {
     // owner-code render path: its own, smaller LDS layout, padded to the same workgroups-per-CU target
     size_t lds_c = (size_t)k_.lds_words_codes * 4;
+    const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_c, 1);  // (channels-last epilogue: its exchange area)
     if (waves_per_cu > 0) {
       size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
       if (want > lds_c) lds_c = want;
     }
     if (epi_.out)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, true>), grid, block, lds_c, s, k_, P, a, out, epi_, fused_.ptr());
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, true>), grid, block, lds_c, s, k_, P, a, out, ep, fused_.ptr());
     else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true>), grid, block, lds_c, s, k_, P, a, out, epi_, fused_.ptr());
   } else if (shipped_shape) {
-    if (epi_.out && waves_per_wg == 1)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true>), grid, block, lds, s, k_, P, a, out, epi_, fused_.ptr());
-    else if (epi_.out)
+    if (epi_.out && waves_per_wg == 1) {
+      size_t lds_e = (size_t)k_.lds_words * 4;
+      const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_e, 1);
+      if (lds > lds_e) lds_e = lds;  // (the padding towards `waves_per_cu` workgroups per CU)
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true>), grid, block, lds_e, s, k_, P, a, out, ep, fused_.ptr());
+    } else if (epi_.out)
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the epilogue needs the single-wave launch shape");
     else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out, epi_, fused_.ptr());

@@ -106,13 +106,52 @@ struct EpilogueArgs {
   int32_t two_pass = 0;
   // channels last (ObservationToFeatureArray(permute=(1, 2, 0)), rendering.py:545-661): out is [batch][cells][depth].
   // A wave's 256 cells x depth floats are one contiguous piece of it; the lanes exchange their layer dwords through
-  // `depth` x 64 words of LDS per wave (hwc_lds_off: word offset in the workgroup's dynamic LDS) so that every
+  // 256 x depth bytes of LDS per wave (hwc_lds_off: word offset in the workgroup's dynamic LDS) so that every
   // store instruction still covers 1 KiB of consecutive bytes.
   int32_t hwc = 0, depth = 0;
   uint32_t hwc_lds_off = 0, magic_depth = 0;  // magic_depth: floor(2^32 / depth) + 1
   int32_t sprite_slot[PCX_MAX_SPRITES], drape_slot[PCX_MAX_DRAPES], bchar_slot[PCX_MAX_CHARS];
 };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Channels-last epilogue.  A wave's 64 board dwords (first one: f_first, counted from the group's first dword) are
+// 256 consecutive cells = 256 x depth consecutive floats of the output (boards of whole dwords: no padding
+// between environments).  The lanes exchange through the wave's area of LDS, laid out like that piece of the
+// output with a byte per float: hwc_put() drops the four cell bytes of one layer dword at [cell][layer], and
+// hwc_emit() has lane l, trip j convert the dword at index j * 64 + l -- four consecutive output floats -- and store
+// them: 1 KiB of consecutive bytes per store instruction.
+__device__ __forceinline__ void hwc_put(uint32_t* hw, uint32_t depth, int lane, int32_t slot, uint32_t m01) {
+  uint8_t* const b = reinterpret_cast<uint8_t*>(hw) + (uint32_t)(4 * lane) * depth + (uint32_t)slot;
+  b[0] = (uint8_t)m01;
+  b[depth] = (uint8_t)(m01 >> 8);
+  b[2 * depth] = (uint8_t)(m01 >> 16);
+  b[3 * depth] = (uint8_t)(m01 >> 24);
+}
+template <bool GUARD>
+__device__ __forceinline__ void hwc_emit(const uint32_t* hw, const EpilogueArgs& epi, uint32_t f_first, int lane, bool any_skip,
+                                         const uint32_t* skip, uint32_t qw, uint8_t* fbase, uint32_t f_limit) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t depth = (uint32_t)epi.depth;
+  const uint32_t piece = 16u * depth * f_first;  // byte offset of the piece from the group's base
+  const bool check = any_skip || f_first + WAVE > f_limit;  // (uniform)
+  for (uint32_t j = 0; j < depth; ++j) {
+    const uint32_t g = j * WAVE + (uint32_t)lane;
+    const uint32_t w = hw[g];
+    f32x4 f;
+    f.x = (float)(w & 0xFFu); f.y = (float)((w >> 8) & 0xFFu); f.z = (float)((w >> 16) & 0xFFu); f.w = (float)(w >> 24);
+    // the four floats lie in one environment (cells * depth is a multiple of four): dropped with it
+    bool dropped = false;
+    if (check) {
+      const uint32_t fsrc = f_first + (__umulhi(4u * g, epi.magic_depth) >> 2);  // the board dword of the floats' cell
+      dropped = fsrc >= f_limit;
+      if (!dropped && any_skip) dropped = skip[fsrc / qw] != 0;
+    }
+    if (!dropped) saddr_store_dwordx4<GUARD>(piece + 16u * g, f, fbase);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // (the next iteration overwrites the exchange area)
+}
 
 // The wavefront streams board + layers of the group's 64 environments.
 // One (environment e, board dword q) task per lane and iteration; consecutive
@@ -179,13 +218,18 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   const uint32_t e_0 = e, q_0 = q, voff_0 = voff, eF_0 = eF, foff_0 = foff;
   // channels last: this wave's exchange area, rows of the layers nobody paints stay zero
   const bool hwc = epi_on && epi.hwc != 0;
-  uint32_t* const hw = hwc ? lds_base + epi.hwc_lds_off + (uint32_t)wave * (uint32_t)epi.depth * WAVE : nullptr;
+  // (two areas per wave, used in turn: an iteration drops its bytes into one and stores the floats of the
+  // iteration before from the other, so that no wave waits for its own LDS writes)
+  const uint32_t hw_words = hwc ? (uint32_t)epi.depth * WAVE : 0u;
+  uint32_t* const hw = hwc ? lds_base + epi.hwc_lds_off + (uint32_t)wave * 2u * hw_words : nullptr;
   if (hwc)
-    for (int sl = 0; sl < epi.depth; ++sl) hw[sl * WAVE + lane] = 0u;
+    for (uint32_t sl = 0; sl < 2u * (uint32_t)epi.depth; ++sl) hw[sl * WAVE + lane] = 0u;
 #pragma unroll 1
   for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
   const int role = two_pass ? pass : -1;  // 0: the uint8 planes, 1: the float32 planes, -1: both
   e = e_0; q = q_0; voff = voff_0; eF = eF_0; foff = foff_0;
+  int hw_it = -1;  // channels last: the iteration whose floats wait in the other exchange area
+  uint32_t hw_sel = 0;
 #pragma unroll 1
   for (int it = lwave; it < (int)QWv; it += lwaves) {
     const uint32_t e_now = e, q_now = q, voff_now = voff, eF_now = eF, foff_now = foff;
@@ -209,7 +253,7 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
     auto put_layer = [&](uint8_t* base, uint32_t m01, int32_t slot) {
       if (layers_on) put(base, m01);
       if (epi_on && slot >= 0 && role != 0 && hwc) {
-        hw[slot * WAVE + lane] = m01;
+        hwc_put(hw + hw_sel * hw_words, (uint32_t)epi.depth, lane, slot, m01);
       } else if (epi_on && slot >= 0 && role != 0) {
         f32x4 f;
         f.x = (float)(m01 & 0xFFu); f.y = (float)((m01 >> 8) & 0xFFu); f.z = (float)((m01 >> 16) & 0xFFu); f.w = (float)(m01 >> 24);
@@ -290,36 +334,14 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
 #pragma unroll
     for (int b = 0; b < NB; ++b) put_layer(pb_b[b], mb[b] & ~uni, epi.bchar_slot[b]);
     if (hwc && role != 0) {
-      // The wave's 64 board dwords = 256 consecutive cells = 256 x depth consecutive floats of the output (boards
-      // of whole dwords: no padding between environments).  Lane l, trip j writes the float4 at index j * 64 + l
-      // of that piece: float n belongs to cell n / depth, layer n % depth, whose byte is in the dword lane
-      // (cell >> 2) left in row (n % depth) of the exchange area.
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t depth = (uint32_t)epi.depth;
-      const uint32_t piece = 16u * depth * ((uint32_t)it * WAVE);  // byte offset of the piece from the group's base
-      for (uint32_t j = 0; j < depth; ++j) {
-        const uint32_t g = j * WAVE + (uint32_t)lane, n0 = 4u * g;
-        uint32_t cl = __umulhi(n0, epi.magic_depth), sl = n0 - cl * depth;
-        const uint32_t src0 = cl >> 2;
-        f32x4 f;
-        float v[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          v[t] = (float)((hw[sl * WAVE + (cl >> 2)] >> (8u * (cl & 3u))) & 0xFFu);
-          ++sl;
-          if (sl == depth) { sl = 0; ++cl; }
-        }
-        f.x = v[0]; f.y = v[1]; f.z = v[2]; f.w = v[3];
-        // the four floats lie in one environment (cells * depth is a multiple of four): skipped with it
-        bool dropped = false;
-        if (any_skip) dropped = skip[((uint32_t)it * WAVE + src0) / QWv] != 0;
-        if (!dropped) saddr_store_dwordx4<GUARD>(piece + 16u * g, f, fbase);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();  // (the next iteration overwrites the exchange area)
+      if (hw_it >= 0)
+        hwc_emit<GUARD>(hw + (hw_sel ^ 1u) * hw_words, epi, (uint32_t)hw_it * WAVE, lane, any_skip, skip, QWv, fbase, (uint32_t)WAVE * QWv);
+      hw_it = it;
+      hw_sel ^= 1u;
     }
   }
+  if (hwc && hw_it >= 0 && role != 0)  // the last iteration's floats
+    hwc_emit<true>(hw + (hw_sel ^ 1u) * hw_words, epi, (uint32_t)hw_it * WAVE, lane, any_skip, skip, QWv, fbase, (uint32_t)WAVE * QWv);
   }  // passes
 }
 
@@ -556,7 +578,7 @@ inline bool fill_epilogue(EpilogueArgs& result, const pcx_epilogue_desc* d, int 
   if (d->channels_last) {  // one float32 stream instead of `depth`; needs boards of whole dwords (no padding between environments)
     if (cells % 4 != 0) return false;
     a.hwc = 1;
-    a.two_pass = 1 + ns + nd + nb + 1 > 16;
+    a.two_pass = 1;  // measured: two sweeps win on every kernel (scrolly_maze 1M: 2.66 vs 3.42 ms; profiles/r03_post_kernels.md)
   }
   if (const char* e = getenv("PCX_EPI_TWO_PASS")) a.two_pass = atoi(e) != 0;
   for (int f = 0; f < d->depth; ++f) {
@@ -572,7 +594,7 @@ inline bool fill_epilogue(EpilogueArgs& result, const pcx_epilogue_desc* d, int 
 inline EpilogueArgs with_hwc_scratch(EpilogueArgs a, size_t& lds_bytes, int waves_per_workgroup) {
   if (a.out && a.hwc) {
     a.hwc_lds_off = (uint32_t)((lds_bytes + 3) / 4);
-    lds_bytes = 4 * (size_t)a.hwc_lds_off + (size_t)waves_per_workgroup * (size_t)a.depth * WAVE * 4;
+    lds_bytes = 4 * (size_t)a.hwc_lds_off + (size_t)waves_per_workgroup * 2 * (size_t)a.depth * WAVE * 4;  // two areas per wave
   }
   return a;
 }

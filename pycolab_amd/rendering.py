@@ -223,9 +223,8 @@ class ObservationToFeatureArray(object):
     the features.  Returns False, and changes nothing, where the engine's
     kernel cannot do it (batch > 1; the five hand-written step kernels with
     occluded layers and no fused croppers; axis order default or channels
-    last, `permute=(1, 2, 0)` -- the latter on boards of whole dwords and not
-    in the scrolly_maze kernel): calls then run the post-processor as its own
-    kernel, as before.  The
+    last, `permute=(1, 2, 0)` -- the latter on boards of whole dwords): calls
+    then run the post-processor as its own kernel, as before.  The
     engine owns the installed epilogue: when this object goes away, or another
     post-processor fuses, the kernel stops writing into this one's tensor."""
     torch = dev.torch_module()

@@ -259,15 +259,28 @@ def test_feature_array_fused_on_boards_of_any_size(name, chars, n_actions, batch
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('skip_layers', [False, True])
-@pytest.mark.parametrize('name,chars,n_actions,batch', [('marauders', 'PXB aqz', 4, 300), ('marauders', 'BX|^P ', 4, 33000),
+@pytest.mark.parametrize('name,chars,n_actions,batch', [('scrolly_maze_L0', 'P@#a +', 5, 300), ('scrolly_maze_L0', 'abcP@# ', 5, 3000),
+                                                         ('scrolly_maze_L0', '@P#', 5, 70000),
+                                                         ('marauders', 'PXB aqz', 4, 300), ('marauders', 'BX|^P ', 4, 33000),
                                                          ('hello_world', '@1 #3', 4, 300), ('hello_world', '1234@', 4, 70000),
                                                          ('hello_custom_A', '@2#', 4, 500), ('warehouse_custom_B', 'P1X #', 5, 700),
                                                          ('warehouse_custom_B', 'X_.', 5, 90000)])
 def test_channels_last_feature_array_fused_into_the_step_kernel(name, chars, n_actions, batch, skip_layers):
+  _check_channels_last(name, chars, n_actions, batch, skip_layers)
+
+
+@pytest.mark.gpu
+def test_channels_last_feature_array_in_the_scrolly_maze_mask_path(monkeypatch):
+  monkeypatch.setenv('PCX_SM_CODES', '0')  # the single-wave instance that composes from masks instead of owner codes
+  _check_channels_last('scrolly_maze_L0', 'Pab@# ', 5, 70000, False)
+
+
+def _check_channels_last(name, chars, n_actions, batch, skip_layers):
   """ObservationToFeatureArray(permute=(1, 2, 0)).fuse_into(engine): the render loop writes [B, rows, cols, depth]
   itself (the lanes of a wave exchange their layer dwords through LDS so that the stores stay contiguous): equal to
   the separate kernel every step, through auto-resets and with finished environments left frozen, in both launch
-  shapes; refused where the board is not a whole number of dwords and by the scrolly_maze kernel."""
+  shapes (scrolly_maze: cooperative, mask path and owner-code path); refused where the board is not a whole number
+  of dwords."""
   import torch
   from pycolab_amd.engine import Engine
   t = helpers.load_template(name)
@@ -293,10 +306,7 @@ def test_channels_last_feature_array_fused_into_the_step_kernel(name, chars, n_a
   odd.its_showtime()
   assert not rendering.ObservationToFeatureArray('P@', permute=(1, 2, 0)).fuse_into(odd)
   assert rendering.ObservationToFeatureArray('P@').fuse_into(odd)
-  sm = Engine.from_template(helpers.load_template('scrolly_maze_L0'), batch=64)
-  sm.its_showtime()
-  assert not rendering.ObservationToFeatureArray('P@', permute=(1, 2, 0)).fuse_into(sm)
-  odd.close(); sm.close()
+  odd.close()
 
 
 @pytest.mark.gpu

@@ -49,7 +49,7 @@ if what in ('all', 'epi', 'sm'):
     print('%-14s %7d envs  two_pass=%s  step %.4f  step+post %.4f  fused %.4f ms' % (name, batch, os.environ.get('PCX_EPI_TWO_PASS', 'auto'), ms_step, ms_two, ms_fused), flush=True)
     eng.close()
 if what in ('all', 'hwc'):  # channels last: step + pcx_post_features_hwc vs the epilogue exchanging through LDS
-  for name, batch in (('marauders', 32768), ('marauders', 262144), ('hello_world', 65536)):
+  for name, batch in (('marauders', 32768), ('marauders', 262144), ('hello_world', 65536), ('scrolly_maze_L0', 4096), ('scrolly_maze_L0', 1048576)):
     t, eng, one = engine(name, batch)
     chars = ''.join(chr(c) for c in t.chars)
     obs = eng._result()[0]
