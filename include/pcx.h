@@ -379,18 +379,18 @@ int pcx_cropper_bind_output(pcx_cropper* c, uint8_t* planes_dev);
  * the caller crops every observation, as human_ui.py:269-293 does) and writes
  * their output planes, in the same launch; pcx_cropper_crop() on a fused
  * cropper then launches nothing.  `croppers`: n <= 4 croppers of this engine,
- * fixed or scrolling after at most four entities each.  Every step kernel
- * follows sprites; the table-driven kernel (pcx_generic_step) also follows
- * drapes -- the median of the raw curtain, cropping.py:590-598 -- and
- * priority lists that mix the two; the hand-written kernels answer
- * PCX_E_UNSUPPORTED for a drape tracker.  only_crops != 0: the full-board
+ * fixed or scrolling after at most four entities each: sprites, drapes (the
+ * median of the raw curtain, cropping.py:590-598) and priority lists that
+ * mix the two.  Drape trackers: the table-driven kernel on any board, the
+ * hand-written kernels on boards of at most 63 x 64 cells, not
+ * pcx_scrolly_maze_step (PCX_E_UNSUPPORTED).  only_crops != 0: the full-board
  * planes are no longer written (pcx_buffers.planes goes stale; the consumer
  * ingests the windows only).  n == 0 releases the croppers again.  When the
  * engine is already in play the croppers are brought up to date once, on
  * `stream`.  PCX_E_UNSUPPORTED (nothing changed) where the engine's kernel
  * cannot do it (occlusion_in_layers=False, an installed feature-array
- * epilogue, a drape tracker on a hand-written kernel): the croppers then run
- * as their own kernels. */
+ * epilogue, a drape tracker where the line above says so): the croppers then
+ * run as their own kernels. */
 int pcx_engine_fuse_croppers(pcx_engine* e, pcx_cropper* const* croppers,
                              int32_t n, int32_t only_crops, void* stream);
 /* Device uint8[batch] behind pcx_cropper_errors (read it on the caller's stream). */

@@ -245,13 +245,6 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
         tw[s] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
         P.track[(size_t)s * bp + env] = tw[s];
       }
-      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
-        stream::move_fused_windows(fc, [&](int ti) {
-          int32_t t = 0;
-#pragma unroll
-          for (int s = 0; s < NS; ++s) t = ti == s ? tw[s] : t;
-          return t;
-        }, frame == 0, env, lane, wcorner);
       st[W_FLAGS * bp] = (over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT) | (sf << F_SF_SHIFT) | ((uint32_t)left << F_LEFT_SHIFT);
       if (do_reset) {
         for (int i = 0; i < CW; ++i) st[(W_COINS + i) * bp] = mine[i];
@@ -266,6 +259,14 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
             P.curtains[(size_t)(cell >> 5) * bp + env] |= 1u << (cell & 31);
           }
       }
+      const stream::CurtainSrc csrc{P.curtains, bp, FW, R, C};
+      if (fc)  // fused croppers (after the export: a cropper may follow the coins): the windows follow this step's positions (cropping.py:393-426)
+        stream::move_fused_windows(fc, [&](int ti) {
+          int32_t t = 0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) t = ti == s ? tw[s] : t;
+          return t;
+        }, frame == 0, env, lane, wcorner, &csrc);
       out.reward[env] = reward;
       out.reward_set[env] = (uint8_t)reward_set;
       out.discount[env] = discount;
@@ -346,7 +347,7 @@ class BetterScrollyBackend : public Backend {
     out.push_back({track_.ptr, track_.count * sizeof(int32_t)});
   }
   int plane_pitch() const override { return lay_.pitch; }
-  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
+  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc, false, R_, C_); }
   int set_epilogue(const pcx_epilogue_desc* d) override {  // include/pcx.h pcx_engine_set_epilogue
     if (d && !static_shape_) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the feature-array epilogue exists for the compiled boards");
     int sc[NS], dc = k_.drape_ch4 & 0xFF, bc[NB > 0 ? NB : 1] = {};

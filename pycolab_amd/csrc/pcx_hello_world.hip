@@ -207,18 +207,19 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
         tw[s] = row[s] | (col[s] << 8) | ((int)((k.visible >> s) & 1) << 16) | ((int)do_reset << 24);
         P.track[(size_t)s * bp + env] = tw[s];
       }
-      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
-        stream::move_fused_windows(fc, [&](int ti) {
-          int32_t t = 0;
-#pragma unroll
-          for (int s = 0; s < NS; ++s) t = ti == s ? tw[s] : t;
-          return t;
-        }, frame == 0, env, lane, wcorner);
 #pragma unroll
       for (int i = 0; i < FW; ++i) st[(W_D + i) * bp] = x[i];
       if (a.export_curtains)
 #pragma unroll
         for (int i = 0; i < FW; ++i) P.curtains[(size_t)i * bp + env] = x[i];
+      const stream::CurtainSrc csrc{P.curtains, bp, FW, R, C};
+      if (fc)  // fused croppers (after the export: a cropper may follow the '@' drape): the windows follow this step's positions (cropping.py:393-426)
+        stream::move_fused_windows(fc, [&](int ti) {
+          int32_t t = 0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) t = ti == s ? tw[s] : t;
+          return t;
+        }, frame == 0, env, lane, wcorner, &csrc);
       out.reward[env] = reward;
       out.reward_set[env] = (uint8_t)reward_set;
       out.discount[env] = discount;
@@ -284,7 +285,7 @@ class HelloWorldBackend : public Backend {
   int set_fused_croppers(const crop::FusedCrops* fc) override {
     if (fc && fc->n > 0 && unoccluded_)  // (the windows derive their layers from the board they cut)
       return set_error(PCX_E_UNSUPPORTED, "hello_world backend: fused croppers need occluded layers");
-    return fused_.set(fc);
+    return fused_.set(fc, false, R_, C_);
   }
   int set_epilogue(const pcx_epilogue_desc* d) override {  // include/pcx.h pcx_engine_set_epilogue
     if (d && unoccluded_) return set_error(PCX_E_UNSUPPORTED, "hello_world backend: the feature-array epilogue needs occluded layers");

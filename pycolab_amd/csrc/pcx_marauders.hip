@@ -403,13 +403,6 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts 
         tw[s] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
         P.track[(size_t)s * bp + env] = tw[s];
       }
-      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
-        stream::move_fused_windows(fc, [&](int ti) {
-          int32_t t = 0;
-#pragma unroll
-          for (int s = 0; s < NS; ++s) t = ti == s ? tw[s] : t;
-          return t;
-        }, frame == 0, env, lane, wcorner);
       st[W_FLAGS * bp] = (over ? F_OVER : 0u) | ((err & 7u) << F_ERR_SHIFT) | ((uint32_t)(dx + 1) << F_DX_SHIFT) | (sf << F_SF_SHIFT);
       st[W_RNG * bp] = draws;
 #pragma unroll
@@ -421,6 +414,14 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_marauders_step(const Consts 
           P.curtains[((size_t)k.drape_slot_tmpl[1] * FW + i) * bp + env] = xx[i];
         }
       }
+      const stream::CurtainSrc csrc{P.curtains, bp, FW, R, C};
+      if (fc)  // fused croppers (after the export: a cropper may follow the marauders or the bunkers): the windows follow this step's positions (cropping.py:393-426)
+        stream::move_fused_windows(fc, [&](int ti) {
+          int32_t t = 0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) t = ti == s ? tw[s] : t;
+          return t;
+        }, frame == 0, env, lane, wcorner, &csrc);
       out.reward[env] = reward;
       out.reward_set[env] = (uint8_t)reward_set;
       out.discount[env] = discount;
@@ -483,7 +484,7 @@ class MaraudersBackend : public Backend {
     out.push_back({track_.ptr, track_.count * sizeof(int32_t)});
   }
   int plane_pitch() const override { return pitch; }
-  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc); }
+  int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc, false, R, C); }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     if (!stream::fill_epilogue(epi_, d, cells, sprite_ch_, NS, drape_ch_, ND, bchar_ch_, NB))
       return set_error(PCX_E_UNSUPPORTED, "marauders backend: the channels-last epilogue needs rows*cols %% 4 == 0");

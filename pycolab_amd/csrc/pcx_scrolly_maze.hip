@@ -1503,6 +1503,8 @@ class ScrollyMazeBackend : public Backend {
   int set_fused_croppers(const crop::FusedCrops* fc) override {
     if (fc && fc->n > 0 && (unoccluded_ || epi_.out))
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: fused croppers need occluded layers and no feature-array epilogue");
+    if (crop::tracks_drapes(fc))  // (this kernel exports its curtains from the render-descriptor phase, after the windows have moved)
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: a cropper that tracks a drape runs as its own kernel");
     return fused_.set(fc);
   }
   const int32_t* sprite_track() const override { return track_.ptr; }

@@ -359,9 +359,61 @@ constexpr uint32_t WCORNER_NONE = 0x00008000u;                  // "this environ
 
 // Logic phase, lane == environment.  track_of(i) = the packed track word
 // (row | col << 8 | visible << 16) of template sprite i after this step.
+// The raw curtains as the step kernels export them for drape-tracking croppers (StepArgs::export_curtains): word w
+// of the template's drape d of environment e at bits[(d * FW + w) * bpad + e], cell bit r * C + c.
+struct CurtainSrc { const uint32_t* bits; int64_t bpad; int FW, R, C; };
+
+// ScrollingCropper._centroid of a drape (cropping.py:590-598): int(np.median(.)) of the set cells' row and column
+// indices, one environment per lane, from the words this lane exported a moment ago.  Rows are read as C-bit
+// vectors (C <= 64, R <= 63: checked on the host); the per-column counts are kept bit-sliced (six 64-bit
+// planes, a ripple-carry add per row), so the whole thing is a few loads and ~50 operations per row.
+__device__ __forceinline__ bool curtain_centroid(const CurtainSrc& cs, int d, int64_t env, int& crow, int& ccol) {
+  const uint32_t* const base = cs.bits + (size_t)d * cs.FW * cs.bpad + env;
+  const int R = cs.R, C = cs.C, FW = cs.FW;
+  auto word = [&](int w) { return w < FW ? base[(size_t)w * cs.bpad] : 0u; };
+  auto row_bits = [&](int r) {
+    const uint32_t bit0 = (uint32_t)(r * C), w0 = bit0 >> 5, sh = bit0 & 31u;
+    const uint64_t lo = (uint64_t)word((int)w0) | ((uint64_t)word((int)w0 + 1) << 32);
+    const uint64_t hi = word((int)w0 + 2);
+    uint64_t v = lo >> sh;
+    v |= sh ? hi << (64u - sh) : 0ull;
+    return C >= 64 ? v : v & ((1ull << C) - 1ull);
+  };
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // (this lane's own export stores, read back below)
+  int n = 0;
+  uint64_t plane[6] = {0, 0, 0, 0, 0, 0};  // bit c of plane[k]: bit k of the number of set cells in column c
+  for (int r = 0; r < R; ++r) {
+    uint64_t carry = row_bits(r);
+    n += __popcll(carry);
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) { const uint64_t t = plane[kk] & carry; plane[kk] ^= carry; carry = t; }
+  }
+  // the two middle order statistics (0-based) of the sorted index list; their mean, truncated
+  const int lo_rank = (n - 1) / 2, hi_rank = n / 2;
+  int seen = 0, lo = -1, hi = -1;
+  for (int r = 0; r < R; ++r) {
+    const int cnt = __popcll(row_bits(r));
+    lo = lo < 0 && seen + cnt > lo_rank ? r : lo;
+    hi = hi < 0 && seen + cnt > hi_rank ? r : hi;
+    seen += cnt;
+  }
+  crow = (lo + hi) >> 1;
+  seen = 0; lo = -1; hi = -1;
+  for (int c = 0; c < C; ++c) {
+    int cnt = 0;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) cnt |= (int)((plane[kk] >> c) & 1ull) << kk;
+    lo = lo < 0 && seen + cnt > lo_rank ? c : lo;
+    hi = hi < 0 && seen + cnt > hi_rank ? c : hi;
+    seen += cnt;
+  }
+  ccol = (lo + hi) >> 1;
+  return n > 0;
+}
+
 template <typename TrackOf>
 __device__ __forceinline__ void move_fused_windows(const crop::FusedCrops* fc, TrackOf track_of, bool new_episode,
-                                                   int64_t env, int lane, uint32_t* wcorner) {
+                                                   int64_t env, int lane, uint32_t* wcorner, const CurtainSrc* curtains = nullptr) {
   const int n = fc->n;
   for (int w = 0; w < n; ++w) {
     const crop::FusedWindow& fw = fc->w[w];
@@ -371,9 +423,15 @@ __device__ __forceinline__ void move_fused_windows(const crop::FusedCrops* fc, T
       int wrow = fw.corner[2 * env], wcol = fw.corner[2 * env + 1];
       bool have = false;
       int crow = 0, ccol = 0;
-      for (int i = 0; i < fw.n_track; ++i) {  // :544-549 the first visible sprite of to_track
-        const int32_t t = track_of(fw.track_sprite[i]);
-        if (!have && ((t >> 16) & 1)) { crow = t & 0xFF; ccol = (t >> 8) & 0xFF; have = true; }
+      for (int i = 0; i < fw.n_track; ++i) {  // :544-558 the first entity of to_track that has a centroid
+        if (fw.track_kind[i] == 0) {         // a sprite: its position while it is visible
+          const int32_t t = track_of(fw.track_sprite[i]);
+          if (!have && ((t >> 16) & 1)) { crow = t & 0xFF; ccol = (t >> 8) & 0xFF; have = true; }
+        } else if (curtains != nullptr) {    // a drape: the median of its raw curtain
+          int r = 0, c = 0;
+          const bool ok = curtain_centroid(*curtains, fw.track_sprite[i], env, r, c);
+          if (!have && ok) { crow = r; ccol = c; have = true; }
+        }
       }
       crop::move_window(fw.rule, have, crow, ccol, has, wrow, wcol);
       fw.has_corner[env] = 1;
@@ -605,9 +663,11 @@ inline EpilogueArgs with_hwc_scratch(EpilogueArgs a, size_t& lds_bytes, int wave
 struct FusedCropsHolder {
   DevArray<crop::FusedCrops> dev;
   bool on = false;
-  int set(const crop::FusedCrops* fc, bool drapes_ok = false) {
-    if (!drapes_ok && crop::tracks_drapes(fc))  // (the hand-written kernels keep no raw curtain a median could be taken of)
-      return set_error(PCX_E_UNSUPPORTED, "fused croppers: this game's kernel follows sprites only; a cropper that tracks a drape runs as its own kernel");
+  // rows, cols: the board, for kernels that take a drape's median from the curtains they export (curtain_centroid:
+  // rows of at most 64 cells, at most 63 of them); drapes_ok: the kernel has its own way (pcx_generic.hip)
+  int set(const crop::FusedCrops* fc, bool drapes_ok = false, int rows = 0, int cols = 0) {
+    if (!drapes_ok && crop::tracks_drapes(fc) && !(rows > 0 && rows <= 63 && cols > 0 && cols <= 64))
+      return set_error(PCX_E_UNSUPPORTED, "fused croppers: a cropper that tracks a drape is fused on boards of at most 63 x 64 cells (this one: %d x %d)", rows, cols);
     PCX_HIP(hipDeviceSynchronize());  // no launch in flight may still read the old description
     if (!fc || fc->n <= 0) { on = false; return 0; }
     if (!dev.ptr) { if (int rc = dev.alloc(1)) return rc; }

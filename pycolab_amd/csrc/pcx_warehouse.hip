@@ -284,13 +284,14 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
         tw[s] = (on ? vr[s] : 0) | ((on ? vc[s] : 0) << 8) | (vis[s] << 16) | ((int)do_reset << 24);
         P.track[(size_t)k.tmpl_index[s] * bp + env] = tw[s];
       }
-      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
+      const stream::CurtainSrc csrc{P.curtains, bp, FW, R, C};
+      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426); a cropper may follow the judge's drape
         stream::move_fused_windows(fc, [&](int ti) {
           int32_t t = 0;
 #pragma unroll
           for (int s = 0; s < NS; ++s) t = ti == (int)k.tmpl_index[s] ? tw[s] : t;
           return t;
-        }, frame == 0, env, lane, wcorner);
+        }, frame == 0, env, lane, wcorner, &csrc);
       st[W_SFLAGS * bp] = sf;
       out.reward[env] = reward;
       out.reward_set[env] = (uint8_t)reward_set;
@@ -354,7 +355,7 @@ class WarehouseBackend : public Backend {
   int set_fused_croppers(const crop::FusedCrops* fc) override {
     if (fc && fc->n > 0 && unoccluded_)  // (the windows derive their layers from the board they cut)
       return set_error(PCX_E_UNSUPPORTED, "warehouse backend: fused croppers need occluded layers");
-    return fused_.set(fc);
+    return fused_.set(fc, false, R_, C_);
   }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     if (d && (!static_shape_ || unoccluded_)) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: the feature-array epilogue exists for the compiled shapes, occluded layers");

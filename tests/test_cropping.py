@@ -264,6 +264,63 @@ def test_fused_croppers_equal_stand_alone_croppers(name, batch, shape, monkeypat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', ['coop', 'single'])
+@pytest.mark.parametrize('name,batch,kernel', [('warehouse_L0', 1500, 'pcx_warehouse_step'), ('warehouse_custom_B', 700, 'pcx_warehouse_step'),
+                                               ('marauders', 900, 'pcx_marauders_step'), ('hello_world', 600, 'pcx_hello_world_step'),
+                                               ('better_scrolly_maze_L1', 500, 'pcx_better_scrolly_step'),
+                                               ('better_scrolly_custom_B', 800, 'pcx_better_scrolly_step')])
+def test_hand_written_kernels_fuse_drape_tracking_croppers(name, batch, kernel, shape, monkeypatch):
+  """A fused cropper may follow a drape in the hand-written kernels too (boards of at most 63 x 64 cells): the
+  logic wave takes the median of the raw curtain it has just exported (pcx_stream.h curtain_centroid).  Windows
+  equal the stand-alone cropper kernels' on a twin engine, every step, drapes emptying and refilling across
+  episodes, priority lists that fall through to a sprite."""
+  import torch
+  from pycolab_amd import _native as N
+  from pycolab_amd.engine import Engine
+  monkeypatch.setenv('PCX_COOP_BELOW', '1000000' if shape == 'coop' else '0')
+  if name == 'marauders':
+    monkeypatch.setenv('PCX_EM_WAVES', '4' if shape == 'coop' else '1')
+  t = helpers.load_template(name)
+  sprites = [chr(sp['ch']) for sp in t.sprites]
+  drapes = [chr(d['ch']) for d in t.drapes]
+  pad = chr(t.chars[0])
+
+  def make():
+    return [cropping.ScrollingCropper(3, 5, drapes[:1], pad_char=pad, scroll_margins=(None, 1)),
+            cropping.ScrollingCropper(min(t.rows, 5), min(t.cols, 8), drapes[-1:] + sprites[:1], scroll_margins=(1, 2),
+                                      initial_offset=(0, 1), saccade=True),
+            cropping.ScrollingCropper(4, 6, sprites[-1:] + drapes[:1], pad_char=pad, scroll_margins=(1, 1), saccade=False)]
+
+  a = Engine.from_template(t, batch=batch, auto_reset=True, seed=11)
+  b = Engine.from_template(t, batch=batch, auto_reset=True, seed=11)
+  ca, cb = make(), make()
+  for cr in ca:
+    cr.set_engine(a)
+  for cr in cb:
+    cr.set_engine(b)
+  assert cropping.fuse_croppers(a, ca) is None
+  oa, ob = a.its_showtime()[0], b.its_showtime()[0]
+  assert N.lib().pcx_engine_kernel_name(a._native).decode() == kernel
+  assert all(cr._fused for cr in ca) and not any(cr._fused for cr in cb)
+  n_act = max(1, int(t.n_actions))
+  rng = np.random.RandomState(8)
+  for step in range(0, 45):
+    if step:
+      acts = rng.randint(0, n_act, size=batch).astype(np.int32)
+      a.step(acts); b.step(acts)
+      oa, ob = a._result()[0], b._result()[0]
+    assert torch.equal(oa.board, ob.board), 'step %d: boards differ' % step
+    for i, (x, y) in enumerate(zip(ca, cb)):
+      wx, wy = x.crop(oa), y.crop(ob)
+      assert torch.equal(wx.board, wy.board), 'step %d cropper %d: windows differ' % (step, i)
+      for ch in wy.layers:
+        assert torch.equal(wx.layers[ch], wy.layers[ch]), 'step %d cropper %d layer %r' % (step, i, ch)
+    if step == 18:  # b's croppers join its step kernel in mid-episode
+      assert cropping.fuse_croppers(b, cb) is True
+  a.close(); b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('waves', ['1', '4'])
 @pytest.mark.parametrize('name,batch', [('walkers_room', 900), ('walkers_scroll_groups', 700), ('directives_z_order', 500),
                                         ('marauders', 600), ('warehouse_L0', 1000), ('hello_world', 400),
@@ -398,12 +455,18 @@ def test_fuse_croppers_answers_false_where_the_kernel_cannot():
   cu.set_engine(um)
   um.its_showtime()
   assert cropping.fuse_croppers(um, [cu]) is False                  # unoccluded layers: the windows derive layers from the board
+  for wide, ch in (('better_scrolly_maze_L0', '@'), ('scrolly_maze_L0', '@')):   # 89 columns; the metric game's kernel
+    e3 = Engine.from_template(helpers.load_template(wide), batch=8, auto_reset=True)
+    d3 = cropping.ScrollingCropper(3, 3, [ch], pad_char=' ', scroll_margins=(None, None))
+    d3.set_engine(e3)
+    e3.its_showtime()
+    assert cropping.fuse_croppers(e3, [d3]) is False, wide       # these drape trackers stay stand-alone
+    e3.close()
   t2 = helpers.load_template('warehouse_L0')
   eng2 = Engine.from_template(t2, batch=8, auto_reset=True)
   drape = cropping.ScrollingCropper(3, 3, ['X'], pad_char=' ', scroll_margins=(None, None))
   drape.set_engine(eng2)
   eng2.its_showtime()
-  assert cropping.fuse_croppers(eng2, [drape]) is False          # the hand-written kernels follow sprites only
   sprite = cropping.ScrollingCropper(3, 3, ['P'], pad_char=' ', scroll_margins=(None, None))
   with pytest.raises(ValueError):                                  # the stand-alone cropper would read stale planes
     cropping.fuse_croppers(eng2, [sprite], only_crops=True)
