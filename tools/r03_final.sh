@@ -15,3 +15,4 @@ timeout 600 python tools/fusion_bench.py > $OUT/fusion.txt 2>&1; cat $OUT/fusion
 timeout 600 python tools/generic_timing.py > $OUT/generic_timing.txt 2>&1; grep -v amdgpu $OUT/generic_timing.txt
 PCX_FORCE_GENERIC=0 timeout 600 python tools/generic_timing.py warehouse_L0_unoccluded:262144 hello_world:262144 > $OUT/unocc_handwritten.txt 2>&1; grep -v amdgpu $OUT/unocc_handwritten.txt
 bash tools/small_batch_ablation.sh > $OUT/small_ablation.txt 2>&1; cat $OUT/small_ablation.txt
+bash tools/profile_generic_r03.sh > $OUT/profile_generic.log 2>&1; echo "generic profile rc=$?"
