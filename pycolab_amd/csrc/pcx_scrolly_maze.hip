@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // epilogue with more than 16 write streams per wave (pcx_stream.h fill_epilogue): the uint8 planes of the whole
   // group first, the float32 planes in a second sweep over the same codes
   constexpr bool TWO_PASS = EPI && CODES && INCR;
-  const int n_pass = TWO_PASS && epi.two_pass && layers_on ? 2 : 1;
+  const int n_pass = TWO_PASS && epi.two_pass ? 2 : 1;  // (with skip_layers the first sweep writes the board plane only)
   // channels-last epilogue (pcx_stream.h hwc_emit): this wave's exchange area, rows of unselected layers stay zero
   const bool hwc = EPI && epi.hwc != 0;
   // (two areas per wave, used in turn: an iteration drops its bytes into one and stores the floats of the iteration

@@ -195,7 +195,7 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   // register of an older store with a vmcnt(0) inside the loop.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt/lgkmcnt untouched
 
-  const bool two_pass = EPI && epi.two_pass && !epi.skip_layers;
+  const bool two_pass = EPI && epi.two_pass;  // (with skip_layers the first sweep writes the board plane only)
   constexpr int lwaves = NWAVES;
   const int lwave = wave;
   constexpr uint32_t ADV = (uint32_t)lwaves * WAVE;   // tasks between a wave's consecutive iterations
@@ -638,6 +638,7 @@ inline bool fill_epilogue(EpilogueArgs& result, const pcx_epilogue_desc* d, int 
     a.hwc = 1;
     a.two_pass = 1;  // measured: two sweeps win on every kernel (scrolly_maze 1M: 2.66 vs 3.42 ms; profiles/r03_post_kernels.md)
   }
+  if (d->skip_layers) a.two_pass = 0;  // board plane + float planes only: one sweep (measured: tools/skip_layers_bench.py)
   if (const char* e = getenv("PCX_EPI_TWO_PASS")) a.two_pass = atoi(e) != 0;
   for (int f = 0; f < d->depth; ++f) {
     for (int i = 0; i < ns; ++i) if (sprite_ch[i] == d->chars[f]) a.sprite_slot[i] = f;
