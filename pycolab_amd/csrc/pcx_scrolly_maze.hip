@@ -1066,6 +1066,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     }
     st[W_SFLAGS * bp] = sf;
     if constexpr (FUSABLE) {
+      // (a cropper may follow the maze or the cash drape where this lane has exported the raw curtains above: the
+      // single-wave shapes; the cooperative shape exports them later, from all waves -- refused on the host)
+      const stream::CurtainSrc csrc{P.curtains, bp, FW, R, C};
       if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
         stream::move_fused_windows(fc, [&](int ti) {  // ti: the TEMPLATE's sprite index
           int32_t t = 0;
@@ -1076,7 +1079,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
             t = k.tmpl_index[s] == ti ? tw : t;
           }
           return t;
-        }, p.frame == 0, env, col, lds_raw + k.lds_wcorner);
+        }, p.frame == 0, env, col, lds_raw + k.lds_wcorner, COOP ? nullptr : &csrc);
     }
     if (coins_dirty)
       for (int i = 0; i < k.CW; ++i) st[(W_SPOS + NS + i) * bp] = l.cmask[i * WAVE + col];
@@ -1497,15 +1500,22 @@ class ScrollyMazeBackend : public Backend {
     return 4 + 4 * (int64_t)k_.NW + 4 * (int64_t)(k_.NW - k_.CW) + (int64_t)(1 + k_.L) * k_.cells + 15;
   }
   const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
+  // Does a single step of this batch run in the cooperative launch shape (launch(): few groups per CU)?
+  bool coop_shape() const {
+    const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
+    int coop_below = 4;  // (as in launch(); with fused croppers a workgroup is always one group)
+    if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
+    return shipped_shape && bpad_ / WAVE < (int64_t)num_cus_ * coop_below;
+  }
   int max_fused_steps() const override { return fused_ok_ && !epi_.out && !fused_.on ? 256 : 1; }  // the epilogue / fused croppers have no multi-step instance
   // include/pcx.h pcx_engine_fuse_croppers: the instances that render from curtain bit vectors + sprite
   // descriptors cut the windows too (pcx_stream.h stream_windows); the owner-code and multi-step instances step aside
   int set_fused_croppers(const crop::FusedCrops* fc) override {
     if (fc && fc->n > 0 && (unoccluded_ || epi_.out))
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: fused croppers need occluded layers and no feature-array epilogue");
-    if (crop::tracks_drapes(fc))  // (this kernel exports its curtains from the render-descriptor phase, after the windows have moved)
-      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: a cropper that tracks a drape runs as its own kernel");
-    return fused_.set(fc);
+    if (crop::tracks_drapes(fc) && coop_shape())  // (the cooperative shape exports the curtains after the windows have moved)
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: at this batch size a cropper that tracks a drape runs as its own kernel");
+    return fused_.set(fc, false, k_.R, k_.C);
   }
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }

@@ -264,11 +264,14 @@ def test_fused_croppers_equal_stand_alone_croppers(name, batch, shape, monkeypat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('shape', ['coop', 'single'])
-@pytest.mark.parametrize('name,batch,kernel', [('warehouse_L0', 1500, 'pcx_warehouse_step'), ('warehouse_custom_B', 700, 'pcx_warehouse_step'),
-                                               ('marauders', 900, 'pcx_marauders_step'), ('hello_world', 600, 'pcx_hello_world_step'),
-                                               ('better_scrolly_maze_L1', 500, 'pcx_better_scrolly_step'),
-                                               ('better_scrolly_custom_B', 800, 'pcx_better_scrolly_step')])
+@pytest.mark.parametrize('name,batch,kernel,shape', [
+    (n, b, k, sh) for n, b, k in [('warehouse_L0', 1500, 'pcx_warehouse_step'), ('warehouse_custom_B', 700, 'pcx_warehouse_step'),
+                                  ('marauders', 900, 'pcx_marauders_step'), ('hello_world', 600, 'pcx_hello_world_step'),
+                                  ('better_scrolly_maze_L1', 500, 'pcx_better_scrolly_step'),
+                                  ('better_scrolly_custom_B', 800, 'pcx_better_scrolly_step')] for sh in ('coop', 'single')] + [
+    # pcx_scrolly_maze_step: its single-wave shapes (shipped 10x30 instance, run-time-shape instance)
+    ('scrolly_maze_L0', 900, 'pcx_scrolly_maze_step', 'single'), ('scrolly_maze_L2', 400, 'pcx_scrolly_maze_step', 'single'),
+    ('scrolly_custom_B', 700, 'pcx_scrolly_maze_step', 'single'), ('scrolly_custom_D', 500, 'pcx_scrolly_maze_step', 'coop')])
 def test_hand_written_kernels_fuse_drape_tracking_croppers(name, batch, kernel, shape, monkeypatch):
   """A fused cropper may follow a drape in the hand-written kernels too (boards of at most 63 x 64 cells): the
   logic wave takes the median of the raw curtain it has just exported (pcx_stream.h curtain_centroid).  Windows
