@@ -473,6 +473,19 @@ typedef struct pcx_epilogue_desc {
    * ObservationToFeatureArray(permute=(1, 2, 0)) returns (rendering.py:545-661).
    * Needs rows*cols % 4 == 0 (PCX_E_UNSUPPORTED otherwise). */
   int32_t channels_last;
+  /* != 0: rendering.ObservationToArray (rendering.py:409-542, default axis
+   * order) instead of the feature array: out_dev is [batch][depth][rows*cols]
+   * elements of `dtype` (enum pcx_post_dtype), element (d, cell) =
+   * lut[d][board character]; `lut` and `mapped` are laid out like the fields
+   * of the same names in struct pcx_post_desc and live in HOST memory (the
+   * call copies them).  Every character of the game must be mapped
+   * (the reference would raise on the first one that is not,
+   * rendering.py:503-507) and rows*cols % 4 == 0; PCX_E_UNSUPPORTED otherwise.
+   * With skip_layers the step writes the board and this array only.        */
+  int32_t to_array;
+  int32_t dtype;
+  const uint64_t* lut;    /* [depth][128] */
+  const uint8_t* mapped;  /* [128] */
 } pcx_epilogue_desc;
 int pcx_engine_set_epilogue(pcx_engine* e, const pcx_epilogue_desc* d);
 

@@ -121,7 +121,8 @@ class PostDesc(ctypes.Structure):
 
 class EpilogueDesc(ctypes.Structure):
   _fields_ = [('depth', c_i32), ('chars', c_u8 * POST_MAX_DEPTH), ('out_dev', ctypes.c_void_p), ('skip_layers', c_i32),
-              ('channels_last', c_i32)]
+              ('channels_last', c_i32), ('to_array', c_i32), ('dtype', c_i32), ('lut', ctypes.c_void_p),
+              ('mapped', ctypes.c_void_p)]
 
 
 # Every symbol include/pcx.h declares: (name, restype, argtypes).

@@ -348,13 +348,17 @@ class BetterScrollyBackend : public Backend {
   }
   int plane_pitch() const override { return lay_.pitch; }
   int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc, false, R_, C_); }
+  size_t base_lds_bytes() const {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
+    return ((size_t)lay_.QW * (2 + NB) + lay_.FW + WAVE * (MAX_CW | 1) + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4;
+  }
+  stream::EpilogueArgs* epilogue_args() override { return &epi_; }
   int set_epilogue(const pcx_epilogue_desc* d) override {  // include/pcx.h pcx_engine_set_epilogue
     if (d && !static_shape_) return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the feature-array epilogue exists for the compiled boards");
     int sc[NS], dc = k_.drape_ch4 & 0xFF, bc[NB > 0 ? NB : 1] = {};
     for (int s = 0; s < NS; ++s) sc[s] = k_.sprite_ch4[s] & 0xFF;
     for (int b = 0; b < NB; ++b) bc[b] = k_.bchar_ch4[b] & 0xFF;
-    if (!stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB))
-      return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the channels-last epilogue needs rows*cols %% 4 == 0");
+    if (!stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB, base_lds_bytes() < 64 * 1024 ? 64 * 1024 - base_lds_bytes() : 0, 4))
+      return set_error(PCX_E_UNSUPPORTED, "better_scrolly backend: the channels-last epilogue needs rows*cols %% 4 == 0 and a stack whose exchange areas fit the LDS left");
     return 0;
   }
 
@@ -500,7 +504,7 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
   int coop_below = lay_.QW >= 512 ? 3 : 5;
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
-  size_t lds = ((size_t)lay_.QW * (2 + NB) + lay_.FW + WAVE * (MAX_CW | 1) + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4;
+  size_t lds = base_lds_bytes();
   int waves_per_cu = 8;  // single-wave workgroups: pad LDS so that about eight share a CU (as for scrolly_maze)
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const stream::EpilogueArgs epi_ = stream::with_hwc_scratch(this->epi_, lds, coop ? 4 : 1);  // (channels-last epilogue: its exchange area behind the kernel's own LDS)

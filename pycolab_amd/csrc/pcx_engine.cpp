@@ -1,5 +1,6 @@
 // pcx_engine.cpp -- the C ABI of include/pcx.h over the game backends.
 #include "pcx_internal.h"
+#include "pcx_stream.h"
 
 #include <cstdarg>
 #include <cstdlib>
@@ -194,6 +195,7 @@ void pcx_engine_destroy(pcx_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   delete e->backend;
+  if (e->epilogue_lut) (void)hipFree(e->epilogue_lut);
   pcx::free_own_outputs(e);
   delete e;
 }
@@ -419,12 +421,51 @@ int pcx_engine_set_epilogue(pcx_engine* e, const pcx_epilogue_desc* d) {
   if (d) {
     if (d->depth < 1 || d->depth > PCX_POST_MAX_DEPTH || !d->out_dev || (reinterpret_cast<uintptr_t>(d->out_dev) & 15u))
       return set_error(PCX_E_INVALID, "pcx_engine_set_epilogue: bad descriptor");
-    for (int i = 0; i < d->depth; ++i)
+    for (int i = 0; i < d->depth && !d->to_array; ++i)
       for (int j = 0; j < i; ++j)
         if (d->chars[i] == d->chars[j]) return set_error(PCX_E_UNSUPPORTED, "pcx_engine_set_epilogue: a layer is stacked twice");
   }
   PCX_HIP(hipSetDevice(e->device));
-  return e->backend->set_epilogue(d);
+  if (!d || !d->to_array) {
+    const int rc = e->backend->set_epilogue(d);
+    if (rc == 0 && e->epilogue_lut) {  // (no launch may still read the old table)
+      PCX_HIP(hipDeviceSynchronize());
+      (void)hipFree(e->epilogue_lut);
+      e->epilogue_lut = nullptr;
+    }
+    return rc;
+  }
+  // ObservationToArray as the epilogue: the board can only show the game's own characters, so "every character
+  // has a value" is decided here, once, instead of per cell and step (rendering.py:503-507 raises at run time)
+  if (d->channels_last || !d->lut || !d->mapped || d->dtype < PCX_U8 || d->dtype > PCX_F64)
+    return set_error(PCX_E_INVALID, "pcx_engine_set_epilogue: bad ObservationToArray descriptor");
+  for (int i = 0; i < e->t.n_chars; ++i)
+    if (e->t.chars[i] > 127 || !d->mapped[e->t.chars[i]])
+      return set_error(PCX_E_UNSUPPORTED, "pcx_engine_set_epilogue: character %d of the game has no value in the mapping "
+                                          "(the stand-alone post-processor reports it per environment)", (int)e->t.chars[i]);
+  const int esize = d->dtype == PCX_U8 ? 1 : (d->dtype == PCX_I32 || d->dtype == PCX_F32) ? 4 : 8;
+  std::vector<uint8_t> packed((((size_t)d->depth * 128 * esize) + 15) & ~(size_t)15, 0);
+  for (int k = 0; k < d->depth; ++k)
+    for (int c = 0; c < 128; ++c) memcpy(packed.data() + ((size_t)k * 128 + c) * esize, &d->lut[(size_t)k * 128 + c], (size_t)esize);
+  void* dev = nullptr;
+  PCX_HIP(hipMalloc(&dev, packed.size()));
+  if (hipMemcpy(dev, packed.data(), packed.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(dev);
+    return set_error(PCX_E_HIP, "pcx_engine_set_epilogue: table upload failed");
+  }
+  const int rc = e->backend->set_epilogue(d);
+  pcx::stream::EpilogueArgs* args = rc == 0 ? e->backend->epilogue_args() : nullptr;
+  if (!args) {
+    (void)hipFree(dev);
+    return rc ? rc : set_error(PCX_E_UNSUPPORTED, "%s has no fused epilogue", e->backend->kernel_name());
+  }
+  args->lut = dev;
+  if (e->epilogue_lut) {
+    PCX_HIP(hipDeviceSynchronize());
+    (void)hipFree(e->epilogue_lut);
+  }
+  e->epilogue_lut = dev;
+  return 0;
 }
 
 int pcx_engine_read_things(pcx_engine* e, int64_t env0, int64_t n, pcx_sprite_state* sprites_host,

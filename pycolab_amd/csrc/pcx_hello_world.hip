@@ -287,13 +287,18 @@ class HelloWorldBackend : public Backend {
       return set_error(PCX_E_UNSUPPORTED, "hello_world backend: fused croppers need occluded layers");
     return fused_.set(fc, false, R_, C_);
   }
+  size_t base_lds_bytes() const {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
+    return ((size_t)lay_.QW * (1 + NB) + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS +
+            (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS * WAVE : 0)) * 4;
+  }
+  stream::EpilogueArgs* epilogue_args() override { return &epi_; }
   int set_epilogue(const pcx_epilogue_desc* d) override {  // include/pcx.h pcx_engine_set_epilogue
     if (d && unoccluded_) return set_error(PCX_E_UNSUPPORTED, "hello_world backend: the feature-array epilogue needs occluded layers");
     int sc[NS], dc = k_.drape_ch4 & 0xFF, bc[NB > 0 ? NB : 1] = {};
     for (int s = 0; s < NS; ++s) sc[s] = k_.sprite_ch4[s] & 0xFF;
     for (int b = 0; b < NB; ++b) bc[b] = k_.bchar_ch4[b] & 0xFF;
-    if (!stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB))
-      return set_error(PCX_E_UNSUPPORTED, "hello_world backend: the channels-last epilogue needs rows*cols %% 4 == 0");
+    if (!stream::fill_epilogue(epi_, d, lay_.cells, sc, NS, &dc, 1, bc, NB, 64 * 1024 - base_lds_bytes(), 4))
+      return set_error(PCX_E_UNSUPPORTED, "hello_world backend: the channels-last epilogue needs rows*cols %% 4 == 0 and a stack whose exchange areas fit the LDS left");
     return 0;
   }
 
@@ -404,8 +409,7 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
-  size_t lds = ((size_t)lay_.QW * (1 + NB) + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS +
-                (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS * WAVE : 0)) * 4;
+  size_t lds = base_lds_bytes();
   const stream::EpilogueArgs epi_ = stream::with_hwc_scratch(this->epi_, lds, coop ? 4 : 1);  // (channels-last epilogue: its exchange area behind the kernel's own LDS)
   if (!coop && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;

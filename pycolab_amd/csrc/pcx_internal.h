@@ -119,6 +119,7 @@ struct ErrorPoll {
   int errors_seen(const uint8_t* errors_dev, int64_t n, uint8_t* out_host, int clear);
 };
 
+namespace stream { struct EpilogueArgs; }
 class Backend {
  public:
   virtual ~Backend() {}
@@ -159,6 +160,8 @@ class Backend {
   // kernel cannot answer PCX_E_UNSUPPORTED (the croppers then run as their own
   // kernels, pcx_crop.hip).
   virtual int set_fused_croppers(const crop::FusedCrops* fc);
+  // the installed epilogue's kernel arguments (the engine hangs the ObservationToArray value table in), null: none
+  virtual stream::EpilogueArgs* epilogue_args() { return nullptr; }
 };
 
 Backend* make_scrolly_maze_backend();
@@ -184,4 +187,5 @@ struct pcx_engine {
   bool curtains_fresh = false;  // the last launch exported curtains
   std::vector<struct pcx_cropper*> fused;  // croppers the step kernel runs itself (pcx_engine_fuse_croppers)
   bool fused_only = false;                 // ... and the full-board planes are no longer written
+  void* epilogue_lut = nullptr;            // device copy of the ObservationToArray epilogue's value table (pcx_engine_set_epilogue)
 };

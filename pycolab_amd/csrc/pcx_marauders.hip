@@ -485,9 +485,14 @@ class MaraudersBackend : public Backend {
   }
   int plane_pitch() const override { return pitch; }
   int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc, false, R, C); }
+  static size_t base_lds_bytes() {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
+    return ((size_t)QW * (1 + NB) + (ND + 1) * WAVE * FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4;
+  }
+  stream::EpilogueArgs* epilogue_args() override { return &epi_; }
   int set_epilogue(const pcx_epilogue_desc* d) override {
-    if (!stream::fill_epilogue(epi_, d, cells, sprite_ch_, NS, drape_ch_, ND, bchar_ch_, NB))
-      return set_error(PCX_E_UNSUPPORTED, "marauders backend: the channels-last epilogue needs rows*cols %% 4 == 0");
+    if (!stream::fill_epilogue(epi_, d, cells, sprite_ch_, NS, drape_ch_, ND, bchar_ch_, NB, 64 * 1024 - base_lds_bytes(), 8))
+      return set_error(PCX_E_UNSUPPORTED, "marauders backend: the channels-last epilogue needs rows*cols %% 4 == 0 and a stack of at most %d layers",
+                       (int)((64 * 1024 - base_lds_bytes()) / (8 * 2 * WAVE * 4)));
     return 0;
   }
 
@@ -633,8 +638,7 @@ int MaraudersBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   int waves_per_cu = 4, nwaves = groups < (int64_t)num_cus_ * 5 ? 4 : 1;
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   if (const char* e = getenv("PCX_EM_WAVES")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 8) nwaves = v; }
-  const size_t words = (size_t)QW * (1 + NB) + (ND + 1) * WAVE * FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS;
-  size_t lds = words * 4;
+  size_t lds = base_lds_bytes();
   const stream::EpilogueArgs epi_ = stream::with_hwc_scratch(this->epi_, lds, nwaves);  // (channels-last epilogue: its exchange area behind the kernel's own LDS)
   if (nwaves == 1 && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;

@@ -1307,8 +1307,13 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // epilogue (EPI): float32 planes of the selected layers, 16 bytes per board dword
   const bool layers_on = !(EPI && epi.skip_layers);
   uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(epi.out) + (size_t)env0 * epi.env_stride);
-  const uint32_t f_skew = epi.env_stride - 16u * (uint32_t)QW;  // foff = 16 f + e * f_skew
-  uint32_t foff = 16u * lane;
+  const uint32_t bpd = EPI ? epi.dword_bytes : 16u;  // epilogue bytes per board dword and plane (16: float32 feature planes)
+  const uint32_t f_skew = epi.env_stride - bpd * (uint32_t)QW;  // foff = bpd f + e * f_skew
+  uint32_t foff = bpd * lane;
+  // ObservationToArray as the epilogue (pcx_stream.h to_array_emit): the value table, copied to LDS by every wave for itself
+  const bool to_array = EPI && epi.to_array != 0;
+  uint32_t* const lut_lds = to_array ? lds_raw + epi.lut_lds_off : nullptr;
+  if (to_array) stream::to_array_stage(epi, lut_lds, lane);
   // CODES: planes in their natural order (plane 1 + k = layer of character k)
   constexpr int NPK = CODES ? 1 + SL : 1;
   uint8_t* pbk[NPK];
@@ -1350,7 +1355,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
 #pragma unroll 1
   for (int pass = 0; pass < n_pass; ++pass) {
   const bool do_u8 = n_pass == 1 || pass == 0, do_f32 = n_pass == 1 || pass == 1;
-  if constexpr (TWO_PASS) { e = 0; q = lane; voff = 4u * lane; eF = 0; foff = 16u * lane; }
+  if constexpr (TWO_PASS) { e = 0; q = lane; voff = 4u * lane; eF = 0; foff = bpd * lane; }
   if constexpr (PREFETCH) code_pf = codes[eF + q];
   int hw_it = -1;
   uint32_t hw_sel = 0;
@@ -1373,7 +1378,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       e = wrap ? e + 1 : e;
       voff = wrap ? voff + e_skew : voff;
       eF = wrap ? eF + (CODES ? CODE_PITCH : FWP) : eF;
-      if constexpr (EPI) { foff_now = foff; foff += 16u * WAVE; foff = wrap ? foff + f_skew : foff; }
+      if constexpr (EPI) { foff_now = foff; foff += bpd * WAVE; foff = wrap ? foff + f_skew : foff; }
       if constexpr (PREFETCH) {
         code_cur = code_pf;
         code_pf = codes[it + 1 < QW ? eF + q : 0u];
@@ -1384,7 +1389,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       q_now = f - e_now * QW;
       voff_now = 4u * f + e_now * e_skew;
       eF_now = e_now * (CODES ? CODE_PITCH : FWP);
-      if constexpr (EPI) foff_now = 16u * f + e_now * f_skew;
+      if constexpr (EPI) foff_now = bpd * f + e_now * f_skew;
     }
     // (past the group's last environment, or an environment this launch leaves alone; with the channels-last
     // epilogue such a lane still takes part in the wave's exchange and only its stores are predicated)
@@ -1397,18 +1402,20 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       // cell's character out of the eight, layer k picks byte k of a one-hot table
       const uint32_t code = PREFETCH ? code_cur : codes[eF_now + q_now];
       auto put_plane = [&](uint8_t* base, uint32_t v, int32_t slot) {
-        if (!EPI || ((slot == -2 || layers_on) && do_u8 && !dead))
+        if constexpr (!EPI) {  // (the plain instance keeps every plane base in SGPRs: the bare store; pcx_internal.h)
           asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(base));
+        } else if ((slot == -2 || layers_on) && do_u8 && !dead) {
+          saddr_store_dword<true>(voff_now, v, base);  // (the epilogue instances spill SGPRs: the base is copied inside the asm block)
+        }
         if constexpr (EPI) {
+          if (slot == -2 && to_array && do_f32 && !dead) stream::to_array_emit<true>(epi, lut_lds, v, foff_now, fbase);
           if (slot >= 0 && do_f32 && hwc) {
             stream::hwc_put(hw + hw_sel * hw_words, (uint32_t)epi.depth, lane, slot, v);
           } else if (slot >= 0 && do_f32) {
             stream::f32x4 f;
             f.x = (float)(v & 0xFFu); f.y = (float)((v >> 8) & 0xFFu); f.z = (float)((v >> 16) & 0xFFu); f.w = (float)(v >> 24);
             const uint32_t fo = foff_now + (uint32_t)slot * epi.plane_bytes;
-            // s_nop: a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data
-        // registers (ISA data hazard; the compiler cannot see into inline asm to insert the wait state itself)
-        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(fo), "v"(f), "s"(fbase));
+            saddr_store_dwordx4<true>(fo, f, fbase);
           }
         }
       };
@@ -1432,6 +1439,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
           *reinterpret_cast<uint32_t*>(pb[plane] + voff_now) = v;
       }
       if constexpr (EPI) {  // a selected layer also leaves as four float32 (rendering.py:545-661)
+        if (plane == 0 && to_array && !dead) stream::to_array_emit<true>(epi, lut_lds, v, foff_now, fbase);
         const int32_t slot = plane == 0 ? -1 : plane < 3 ? epi.drape_slot[plane - 1]
                              : plane < 3 + NS ? epi.sprite_slot[plane - 3 < NS ? plane - 3 : 0] : epi.bchar_slot[plane - 3 - NS];
         if (slot >= 0 && hwc) {
@@ -1527,6 +1535,7 @@ class ScrollyMazeBackend : public Backend {
     out.push_back({track_.ptr, track_.count * sizeof(int32_t)});
   }
   int plane_pitch() const override { return (k_.cells + 3) & ~3; }
+  stream::EpilogueArgs* epilogue_args() override { return &epi_; }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
     if (d && fused_.on) return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: release the fused croppers first");
@@ -1535,8 +1544,8 @@ class ScrollyMazeBackend : public Backend {
     int sc[MAX_NS], dc[2] = {k_.maze_ch, k_.cash_ch}, bc[MAX_L];
     for (int s = 0; s < k_.NS; ++s) sc[s] = k_.sprite_ch[s];
     for (int i = 0; i < k_.n_bchars; ++i) bc[i] = k_.bchar[i];
-    if (!stream::fill_epilogue(epi_, d, k_.cells, sc, k_.NS, dc, 2, bc, k_.n_bchars))
-      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the channels-last epilogue needs rows*cols %% 4 == 0");
+    if (!stream::fill_epilogue(epi_, d, k_.cells, sc, k_.NS, dc, 2, bc, k_.n_bchars, 64 * 1024 - (size_t)k_.lds_words * 4, 8))
+      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the channels-last epilogue needs rows*cols %% 4 == 0 and a stack whose exchange areas fit the LDS left");
     return 0;
   }
 

@@ -110,6 +110,13 @@ struct EpilogueArgs {
   // store instruction still covers 1 KiB of consecutive bytes.
   int32_t hwc = 0, depth = 0;
   uint32_t hwc_lds_off = 0, magic_depth = 0;  // magic_depth: floor(2^32 / depth) + 1
+  // ObservationToArray as the epilogue (rendering.py:409-542, default axis order): out is [batch][depth][cells]
+  // elements of esize bytes, element (d, cell) = lut[d][board character]; the table ([depth][128] elements, device
+  // memory) is copied to LDS by every wave for itself (lut_lds_off: word offset in the dynamic LDS).
+  int32_t to_array = 0, esize = 4;
+  uint32_t dword_bytes = 16;  // output bytes per board dword and plane: 4 * esize (16 for the float32 feature planes)
+  uint32_t lut_lds_off = 0;
+  const void* lut = nullptr;
   int32_t sprite_slot[PCX_MAX_SPRITES], drape_slot[PCX_MAX_DRAPES], bchar_slot[PCX_MAX_CHARS];
 };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -151,6 +158,48 @@ __device__ __forceinline__ void hwc_emit(const uint32_t* hw, const EpilogueArgs&
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   __builtin_amdgcn_wave_barrier();  // (the next iteration overwrites the exchange area)
+}
+
+// ObservationToArray epilogue.  to_array_stage: every wave copies the value table into LDS for itself (all waves
+// write the same words, so none has to wait for another); to_array_emit: the four characters of a board dword
+// through the table, one store per component plane (4, 16 or 2 x 16 bytes per lane).
+__device__ __forceinline__ void to_array_stage(const EpilogueArgs& epi, uint32_t* lut_lds, int lane) {
+  const uint32_t n = ((uint32_t)epi.depth * 128u * (uint32_t)epi.esize + 3u) >> 2;
+  const uint32_t* const src = static_cast<const uint32_t*>(epi.lut);
+  for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) lut_lds[i] = src[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+template <bool GUARD>
+__device__ __forceinline__ void to_array_emit(const EpilogueArgs& epi, const uint32_t* lut_lds, uint32_t board4, uint32_t aoff,
+                                              uint8_t* fbase) {
+  const uint32_t c0 = board4 & 127u, c1 = (board4 >> 8) & 127u, c2 = (board4 >> 16) & 127u, c3 = (board4 >> 24) & 127u;
+  const uint32_t depth = (uint32_t)epi.depth;
+  if (epi.esize == 1) {
+    const uint8_t* const t = reinterpret_cast<const uint8_t*>(lut_lds);
+    for (uint32_t d = 0; d < depth; ++d) {
+      const uint32_t v = (uint32_t)t[d * 128u + c0] | ((uint32_t)t[d * 128u + c1] << 8) | ((uint32_t)t[d * 128u + c2] << 16) |
+                         ((uint32_t)t[d * 128u + c3] << 24);
+      saddr_store_dword<GUARD>(aoff + d * epi.plane_bytes, v, fbase);
+    }
+  } else if (epi.esize == 4) {
+    for (uint32_t d = 0; d < depth; ++d) {
+      f32x4 f;
+      f.x = __uint_as_float(lut_lds[d * 128u + c0]); f.y = __uint_as_float(lut_lds[d * 128u + c1]);
+      f.z = __uint_as_float(lut_lds[d * 128u + c2]); f.w = __uint_as_float(lut_lds[d * 128u + c3]);
+      saddr_store_dwordx4<GUARD>(aoff + d * epi.plane_bytes, f, fbase);
+    }
+  } else {
+    const uint2* const t = reinterpret_cast<const uint2*>(lut_lds);
+    for (uint32_t d = 0; d < depth; ++d) {
+      const uint2 a = t[d * 128u + c0], b = t[d * 128u + c1], c = t[d * 128u + c2], e = t[d * 128u + c3];
+      f32x4 lo, hi;
+      lo.x = __uint_as_float(a.x); lo.y = __uint_as_float(a.y); lo.z = __uint_as_float(b.x); lo.w = __uint_as_float(b.y);
+      hi.x = __uint_as_float(c.x); hi.y = __uint_as_float(c.y); hi.z = __uint_as_float(e.x); hi.w = __uint_as_float(e.y);
+      saddr_store_dwordx4<GUARD>(aoff + d * epi.plane_bytes, lo, fbase);
+      saddr_store_dwordx4<GUARD>(aoff + d * epi.plane_bytes + 16u, hi, fbase);
+    }
+  }
 }
 
 // The wavefront streams board + layers of the group's 64 environments.
@@ -213,8 +262,12 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   const bool layers_on = !(epi_on && epi.skip_layers);
   const uint32_t epi_rem = epi_on ? (epi.plane_bytes >> 2) & 3u : 0u;  // cells in the last dword of a plane, 0 = four
   uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(epi.out) + (size_t)env0 * epi.env_stride);
-  uint32_t foff = e * epi.env_stride + 16u * q;
-  const uint32_t dfoff = DE * epi.env_stride + 16u * DQ, wrap_foff = epi.env_stride - 16u * QWv;
+  const uint32_t bpd = epi_on ? epi.dword_bytes : 16u;  // epilogue bytes per board dword and plane
+  uint32_t foff = e * epi.env_stride + bpd * q;
+  const uint32_t dfoff = DE * epi.env_stride + bpd * DQ, wrap_foff = epi.env_stride - bpd * QWv;
+  const bool to_array = epi_on && epi.to_array != 0;
+  uint32_t* const lut_lds = to_array ? lds_base + epi.lut_lds_off : nullptr;
+  if (to_array) to_array_stage(epi, lut_lds, lane);
   const uint32_t e_0 = e, q_0 = q, voff_0 = voff, eF_0 = eF, foff_0 = foff;
   // channels last: this wave's exchange area, rows of the layers nobody paints stay zero
   const bool hwc = epi_on && epi.hwc != 0;
@@ -312,6 +365,7 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
       d = (d & ~ms[s]) | (pm.sprite_ch4[s] & ms[s]);
     }
     put(pb_board, d);
+    if (to_array && role != 0 && !skipped) to_array_emit<GUARD>(epi, lut_lds, d, foff_now, fbase);
     // rendering.py:177-179 layers[c] = (board == c): by construction the thing's
     // own mask, or the backdrop's precomputed mask where no thing paints
     if constexpr (UNOCC) {  // rendering.py:236-278: raw masks, the backdrop's included
@@ -616,8 +670,10 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
 // whose sprites / drape slots / backdrop-only characters paint the given
 // characters.  (Boards that are not a whole number of dwords are fine: stream_planes writes the
 // last dword of a feature plane cell by cell.)
+// hwc_lds_room: bytes of LDS the channels-last exchange areas may take (64 KB minus the kernel's own LDS), for
+// hwc_waves waves per workgroup at most -- a deeper stack is refused here, not at launch
 inline bool fill_epilogue(EpilogueArgs& result, const pcx_epilogue_desc* d, int cells, const int* sprite_ch, int ns,
-                          const int* drape_ch, int nd, const int* bchar_ch, int nb) {
+                          const int* drape_ch, int nd, const int* bchar_ch, int nb, size_t hwc_lds_room = 0, int hwc_waves = 1) {
   EpilogueArgs a;  // (committed to `result` on success only: a refused descriptor changes nothing)
   for (int i = 0; i < PCX_MAX_SPRITES; ++i) a.sprite_slot[i] = -1;
   for (int i = 0; i < PCX_MAX_DRAPES; ++i) a.drape_slot[i] = -1;
@@ -632,15 +688,26 @@ inline bool fill_epilogue(EpilogueArgs& result, const pcx_epilogue_desc* d, int 
   // profiles/r03_post_kernels.md)
   a.two_pass = 1 + ns + nd + nb + d->depth > 16;
   a.depth = d->depth;
+  if (d->to_array) {  // the value table (uploaded by the engine: Backend::epilogue_args()->lut) goes to LDS next to the kernel's own
+    const int esize = d->dtype == PCX_U8 ? 1 : (d->dtype == PCX_I32 || d->dtype == PCX_F32) ? 4 : 8;
+    if (cells % 4 != 0 || d->channels_last) return false;  // (whole dwords of cells per plane; default axis order)
+    if ((size_t)d->depth * 128 * esize + 16 > hwc_lds_room) return false;
+    a.to_array = 1;
+    a.esize = esize;
+    a.dword_bytes = 4u * (uint32_t)esize;
+    a.env_stride = (uint32_t)d->depth * (uint32_t)cells * (uint32_t)esize;
+    a.plane_bytes = (uint32_t)cells * (uint32_t)esize;
+  }
   a.magic_depth = 0xFFFFFFFFu / (uint32_t)d->depth + 1u;
   if (d->channels_last) {  // one float32 stream instead of `depth`; needs boards of whole dwords (no padding between environments)
     if (cells % 4 != 0) return false;
+    if ((size_t)hwc_waves * 2 * (size_t)d->depth * WAVE * 4 > hwc_lds_room) return false;
     a.hwc = 1;
     a.two_pass = 1;  // measured: two sweeps win on every kernel (scrolly_maze 1M: 2.66 vs 3.42 ms; profiles/r03_post_kernels.md)
   }
   if (d->skip_layers) a.two_pass = 0;  // board plane + float planes only: one sweep (measured: tools/skip_layers_bench.py)
   if (const char* e = getenv("PCX_EPI_TWO_PASS")) a.two_pass = atoi(e) != 0;
-  for (int f = 0; f < d->depth; ++f) {
+  for (int f = 0; f < d->depth && !d->to_array; ++f) {
     for (int i = 0; i < ns; ++i) if (sprite_ch[i] == d->chars[f]) a.sprite_slot[i] = f;
     for (int i = 0; i < nd; ++i) if (drape_ch[i] == d->chars[f]) a.drape_slot[i] = f;
     for (int i = 0; i < nb; ++i) if (bchar_ch[i] == d->chars[f]) a.bchar_slot[i] = f;
@@ -651,6 +718,10 @@ inline bool fill_epilogue(EpilogueArgs& result, const pcx_epilogue_desc* d, int 
 
 // Host side, at launch: the channels-last epilogue's exchange area goes behind the kernel's own dynamic LDS.
 inline EpilogueArgs with_hwc_scratch(EpilogueArgs a, size_t& lds_bytes, int waves_per_workgroup) {
+  if (a.out && a.to_array) {  // the value table of the ObservationToArray epilogue
+    a.lut_lds_off = (uint32_t)((lds_bytes + 3) / 4);
+    lds_bytes = 4 * (size_t)a.lut_lds_off + (((size_t)a.depth * 128 * (size_t)a.esize + 15) & ~(size_t)15);
+  }
   if (a.out && a.hwc) {
     a.hwc_lds_off = (uint32_t)((lds_bytes + 3) / 4);
     lds_bytes = 4 * (size_t)a.hwc_lds_off + (size_t)waves_per_workgroup * 2 * (size_t)a.depth * WAVE * 4;  // two areas per wave

@@ -357,10 +357,15 @@ class WarehouseBackend : public Backend {
       return set_error(PCX_E_UNSUPPORTED, "warehouse backend: fused croppers need occluded layers");
     return fused_.set(fc, false, R_, C_);
   }
+  size_t base_lds_bytes() const {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
+    return ((size_t)lay_.QW * (1 + NB_) + 3 * R_ + WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE + WAVE + stream::WCORNER_WORDS +
+            (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE : 0)) * 4;
+  }
+  stream::EpilogueArgs* epilogue_args() override { return &epi_; }
   int set_epilogue(const pcx_epilogue_desc* d) override {
     if (d && (!static_shape_ || unoccluded_)) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: the feature-array epilogue exists for the compiled shapes, occluded layers");
-    if (!stream::fill_epilogue(epi_, d, lay_.cells, sprite_ch_, NS_, &drape_ch_, 1, bchar_ch_, NB_))
-      return set_error(PCX_E_UNSUPPORTED, "warehouse backend: the channels-last epilogue needs rows*cols %% 4 == 0");
+    if (!stream::fill_epilogue(epi_, d, lay_.cells, sprite_ch_, NS_, &drape_ch_, 1, bchar_ch_, NB_, 64 * 1024 - base_lds_bytes(), 4))
+      return set_error(PCX_E_UNSUPPORTED, "warehouse backend: the channels-last epilogue needs rows*cols %% 4 == 0 and a stack whose exchange areas fit the LDS left");
     return 0;
   }
 
@@ -532,9 +537,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
-  const size_t words = (size_t)lay_.QW * (1 + NB_) + 3 * R_ + WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE + WAVE + stream::WCORNER_WORDS +
-                       (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE : 0);
-  size_t lds = words * 4;
+  size_t lds = base_lds_bytes();
   const stream::EpilogueArgs epi_ = stream::with_hwc_scratch(this->epi_, lds, coop ? 4 : 1);  // (channels-last epilogue: its exchange area behind the kernel's own LDS)
   if (!coop && waves_per_cu > 0) {
     size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;

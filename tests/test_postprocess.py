@@ -302,11 +302,88 @@ def _check_channels_last(name, chars, n_actions, batch, skip_layers):
     if not skip_layers:
       assert torch.equal(got, plain(obs)), (name, step)
   eng.close()
+  deep = Engine.from_template(helpers.load_template('marauders'), batch=64)   # 32 layers: the exchange areas would not fit LDS
+  deep.its_showtime()
+  many = ''.join(chr(c) for c in range(ord('A'), ord('A') + 32))
+  assert not rendering.ObservationToFeatureArray(many, permute=(1, 2, 0)).fuse_into(deep)
+  assert rendering.ObservationToFeatureArray(many).fuse_into(deep)
+  deep.close()
   odd = Engine.from_template(helpers.load_template('better_scrolly_maze_L0'), batch=64)   # 4,005 cells
   odd.its_showtime()
   assert not rendering.ObservationToFeatureArray('P@', permute=(1, 2, 0)).fuse_into(odd)
   assert rendering.ObservationToFeatureArray('P@').fuse_into(odd)
   odd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('skip_layers', [False, True])
+@pytest.mark.parametrize('name,n_actions,batch,kind', [('scrolly_maze_L0', 5, 300, 'rgb'), ('scrolly_maze_L0', 5, 3000, 'scalar'),
+                                                       ('scrolly_maze_L0', 5, 70000, 'rgb'), ('scrolly_maze_L0', 5, 70000, 'wide'),
+                                                       ('marauders', 4, 300, 'scalar'), ('marauders', 4, 33000, 'rgb'),
+                                                       ('hello_world', 4, 500, 'wide'), ('hello_world', 4, 70000, 'rgb'),
+                                                       ('warehouse_custom_B', 5, 700, 'rgb'), ('warehouse_custom_B', 5, 90000, 'scalar')])
+def test_value_array_fused_into_the_step_kernel(name, n_actions, batch, kind, skip_layers):
+  """ObservationToArray.fuse_into(engine): the render loop sends every board dword through the value table (in LDS)
+  and writes the array itself -- uint8 RGB vectors, float32 scalars, int64 vectors -- equal to the separate kernel
+  every step, through auto-resets and with finished environments left frozen, in every launch shape; with
+  skip_layers the step writes the board and the array only."""
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template(name)
+  chars = [chr(c) for c in t.chars]
+  rng = np.random.RandomState(4)
+  if kind == 'rgb':
+    mapping = {c: tuple(int(x) for x in rng.randint(0, 256, size=3)) for c in chars}
+    args = dict(dtype=np.uint8)
+  elif kind == 'scalar':
+    mapping = {c: float(i) * 0.25 - 1.0 for i, c in enumerate(chars)}
+    args = dict(dtype=np.float32)
+  else:
+    mapping = {c: tuple(int(x) for x in rng.randint(-2 ** 40, 2 ** 40, size=2)) for c in chars}
+    args = dict(dtype=np.int64)
+  mapping['~'] = mapping[chars[0]]  # (a key the game never shows)
+  eng = Engine.from_template(t, batch=batch, auto_reset=True, seed=5)
+  eng.its_showtime()
+  eng.step_hashed(3, 0, 12)
+  fused = rendering.ObservationToArray(mapping, **args)
+  assert fused.fuse_into(eng, skip_layers=skip_layers), name
+  plain = rendering.ObservationToArray(mapping, **args)
+  guard = fused._fused[1]
+  for step in range(8 if batch > 5000 else 30):
+    eng._auto_reset = step % 4 != 3   # every fourth step leaves finished environments untouched
+    obs = eng.play(torch.randint(0, n_actions, (batch,), dtype=torch.int32, device='cuda'))[0]
+    got = fused(obs)
+    assert got is guard
+    assert torch.equal(got, plain(obs)), (name, kind, step)
+    if not skip_layers:
+      for ch, layer in obs.layers.items():
+        assert torch.equal(layer, (obs.board == ord(ch)).to(torch.uint8)), (name, step, ch)
+  eng.check_errors()
+  eng.close()
+
+
+@pytest.mark.gpu
+def test_value_array_epilogue_refusals():
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('scrolly_maze_L0')
+  eng = Engine.from_template(t, batch=64)
+  eng.its_showtime()
+  chars = [chr(c) for c in t.chars]
+  full = {c: i for i, c in enumerate(chars)}
+  assert not rendering.ObservationToArray({c: i for i, c in enumerate(chars[:-1])}, dtype=np.float32).fuse_into(eng)  # a character without a value
+  assert not rendering.ObservationToArray(full, dtype=np.float32, permute=(1, 0)).fuse_into(eng)                    # a permuted axis order
+  a = rendering.ObservationToArray(full, dtype=np.float32)
+  assert a.fuse_into(eng)
+  f = rendering.ObservationToFeatureArray(''.join(chars))
+  assert f.fuse_into(eng) and a._fused is None   # the kernel feeds one array: the feature stack replaced the value array
+  eng.close()
+  odd = Engine.from_template(helpers.load_template('warehouse_L0'), batch=64)   # 110 cells
+  odd.its_showtime()
+  assert not rendering.ObservationToArray({chr(c): 1 for c in odd._template.chars}, dtype=np.uint8).fuse_into(odd)
+  gen = Engine.from_template(helpers.load_template('walkers_room'), batch=64)    # the table-driven kernel
+  gen.its_showtime()
+  assert not rendering.ObservationToArray({chr(c): 1 for c in gen._template.chars}, dtype=np.uint8).fuse_into(gen)
+  odd.close(); gen.close()
 
 
 @pytest.mark.gpu

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""ObservationToArray: step + pcx_post_to_array (two kernels) vs the fused epilogue, with and without skip_layers."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from pycolab_amd import rendering
+from pycolab_amd.compiler import GameTemplate
+from pycolab_amd.engine import Engine
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def timed(fn, steps=100):
+  for _ in range(10): fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(steps): fn()
+  e1.record(); torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / steps
+
+
+for name, batch in (('scrolly_maze_L0', 1048576), ('scrolly_maze_L0', 4096), ('marauders', 32768), ('hello_world', 262144)):
+  for kind in ('uint8 RGB', 'float32 scalar'):
+    t = GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', name + '.npz'))
+    chars = [chr(c) for c in t.chars]
+    if kind == 'uint8 RGB':
+      mapping, dtype = {c: (17 * i % 256, 40 * i % 256, 255 - i) for i, c in enumerate(chars)}, np.uint8
+    else:
+      mapping, dtype = {c: float(i) for i, c in enumerate(chars)}, np.float32
+    res = []
+    for mode in ('two kernels', 'fused', 'fused, skip_layers'):
+      eng = Engine.from_template(t, batch=batch, auto_reset=True, seed=1)
+      eng.its_showtime()
+      tape = torch.randint(0, t.n_actions, (16, batch), dtype=torch.int32, device='cuda')
+      c = [0]
+      def one():
+        eng.step(tape[c[0] % 16]); c[0] += 1
+      conv = rendering.ObservationToArray(mapping, dtype=dtype)
+      obs = eng._result()[0]
+      if mode == 'two kernels':
+        conv(obs)
+        fn = lambda: (one(), conv(obs))
+      else:
+        assert conv.fuse_into(eng, skip_layers=mode != 'fused')
+        fn = one
+      res.append(sorted(timed(fn, 50 if batch > 500000 else 100) for _ in range(3))[1])
+      eng.close()
+    print('%-16s %8d envs  %-14s  step+post %.4f  fused %.4f  fused, layers skipped %.4f ms' % ((name, batch, kind) + tuple(res)), flush=True)
