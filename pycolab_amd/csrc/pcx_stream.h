@@ -89,17 +89,18 @@ struct PlaneMap {
 };
 
 // Optional epilogue of the streaming loop: rendering.ObservationToFeatureArray
-// (rendering.py:545-661, default axis order) written by the step kernel itself.
-// The loop holds every layer's mask dword in registers; a selected layer is
-// also stored as four float32 (one 16-byte store per lane: 1 KiB contiguous per
-// wave) into a caller-owned array [batch][depth][cells] -- the consumer's
-// tensor is ready when the step is, without a second pass over the planes.
-// slot: place of the layer in the feature stack, -1 = not selected.  With
+// (rendering.py:545-661; default axis order, or channels last: `hwc` below) or
+// rendering.ObservationToArray (rendering.py:409-542: `to_array` below) written by
+// the step kernel itself.  Feature array: the loop holds every layer's mask dword in
+// registers; a selected layer is also stored as four float32 (one 16-byte store per
+// lane: 1 KiB contiguous per wave) into a caller-owned array [batch][depth][cells] --
+// the consumer's tensor is ready when the step is, without a second pass over the
+// planes.  slot: place of the layer in the feature stack, -1 = not selected.  With
 // skip_layers the uint8 layer planes are not written at all (the board is).
 struct EpilogueArgs {
-  float* out = nullptr;      // [batch][depth][cells] float32; null = no epilogue
-  uint32_t env_stride = 0;   // bytes per environment = depth * cells * 4
-  uint32_t plane_bytes = 0;  // cells * 4
+  float* out = nullptr;      // the caller's array (float32 features, or elements of esize bytes: to_array); null = no epilogue
+  uint32_t env_stride = 0;   // bytes per environment = depth * cells * 4 (to_array: * esize)
+  uint32_t plane_bytes = 0;  // cells * 4 (to_array: * esize)
   int32_t skip_layers = 0;
   // the loop runs twice, first for the uint8 planes, then for the float32 planes: a wave then feeds half
   // as many write streams at a time (it composes every dword twice; the loop is store-bound)
