@@ -458,7 +458,9 @@ int pcx_post_run(pcx_post* p, void* stream);
  * chars: the stacked layers' characters (distinct; a character the game does
  * not have leaves its plane as the caller initialised it: zeros).
  * skip_layers != 0: the uint8 layer planes of `planes` are no longer written
- * (the board plane is) -- for consumers that only ingest the feature array.
+ * (the board plane is) -- for consumers that only ingest the feature array;
+ * skip_layers == 2: nor is the board plane (pcx_buffers.planes goes stale
+ * altogether: the consumer ingests the epilogue's array and nothing else).
  * Answers PCX_E_UNSUPPORTED where the backend's render loop cannot do it (the
  * table-driven kernel, occlusion_in_layers=False, fused croppers in the same
  * kernel): run pcx_post_* then.  Boards of any size (a plane's last dword is

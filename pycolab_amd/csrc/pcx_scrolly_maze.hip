@@ -1352,8 +1352,10 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   if (hwc)
     for (uint32_t sl = 0; sl < 2u * (uint32_t)epi.depth; ++sl) hw[sl * WAVE + lane] = 0u;
   const uint32_t hw_limit = (uint32_t)((COOP ? EPW : WAVE) * QW);
+  // (a sweep that has nothing to store is left out: array-only consumers, EpilogueArgs::skip_board)
+  const bool u8_needed = !EPI || !epi.skip_board || layers_on;
 #pragma unroll 1
-  for (int pass = 0; pass < n_pass; ++pass) {
+  for (int pass = n_pass == 2 && !u8_needed ? 1 : 0; pass < n_pass; ++pass) {
   const bool do_u8 = n_pass == 1 || pass == 0, do_f32 = n_pass == 1 || pass == 1;
   if constexpr (TWO_PASS) { e = 0; q = lane; voff = 4u * lane; eF = 0; foff = bpd * lane; }
   if constexpr (PREFETCH) code_pf = codes[eF + q];
@@ -1401,10 +1403,19 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       // one LDS read, then one v_perm_b32 per plane: the board dword picks each
       // cell's character out of the eight, layer k picks byte k of a one-hot table
       const uint32_t code = PREFETCH ? code_cur : codes[eF_now + q_now];
+      if constexpr (TWO_PASS) {
+        // ObservationToArray's own sweep: code -> board dword -> value table -> component planes, none of the
+        // per-plane selection below (as part of the general body it cost ~120 scalar and ~50 vector
+        // instructions per iteration: profiles/r03_post_kernels.md)
+        if (to_array && n_pass == 2 && pass == 1) {
+          if (!dead) stream::to_array_emit<true>(epi, lut_lds, __builtin_amdgcn_perm(k.chars_hi, k.chars_lo, code), foff_now, fbase);
+          continue;
+        }
+      }
       auto put_plane = [&](uint8_t* base, uint32_t v, int32_t slot) {
         if constexpr (!EPI) {  // (the plain instance keeps every plane base in SGPRs: the bare store; pcx_internal.h)
           asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_now), "v"(v), "s"(base));
-        } else if ((slot == -2 || layers_on) && do_u8 && !dead) {
+        } else if ((slot == -2 ? !epi.skip_board : layers_on) && do_u8 && !dead) {
           saddr_store_dword<true>(voff_now, v, base);  // (the epilogue instances spill SGPRs: the base is copied inside the asm block)
         }
         if constexpr (EPI) {
@@ -1432,7 +1443,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     // scalar base (pinned above) + 32-bit lane offset: one `global_store_dword
     // voffset, data, sbase` per plane, no per-store address arithmetic
     compose(e_now, q_now, eF_now, [&](int plane, uint32_t v) {
-      if ((!EPI || plane == 0 || layers_on) && !dead) {
+      if ((!EPI || (plane == 0 ? !epi.skip_board : layers_on)) && !dead) {
         if constexpr (SL != 0)  // the static-shape instance keeps all nine bases in SGPRs
           saddr_store_dword<GUARD_SADDR>(voff_now, v, pb[plane]);
         else
@@ -1546,6 +1557,9 @@ class ScrollyMazeBackend : public Backend {
     for (int i = 0; i < k_.n_bchars; ++i) bc[i] = k_.bchar[i];
     if (!stream::fill_epilogue(epi_, d, k_.cells, sc, k_.NS, dc, 2, bc, k_.n_bchars, 64 * 1024 - (size_t)k_.lds_words * 4, 8))
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the channels-last epilogue needs rows*cols %% 4 == 0 and a stack whose exchange areas fit the LDS left");
+    // array-only consumers (skip_board): the value array gets a sweep of its own and the general one is left out
+    // (1,048,576 environments: 0.60-0.69 ms against 1.16-1.26 in the general loop; with planes to write as well, one sweep)
+    if (epi_.to_array) epi_.two_pass = epi_.skip_board;
     return 0;
   }
 

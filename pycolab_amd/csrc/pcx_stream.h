@@ -102,6 +102,7 @@ struct EpilogueArgs {
   uint32_t env_stride = 0;   // bytes per environment = depth * cells * 4 (to_array: * esize)
   uint32_t plane_bytes = 0;  // cells * 4 (to_array: * esize)
   int32_t skip_layers = 0;
+  int32_t skip_board = 0;    // ... nor the board plane: the consumer ingests the epilogue's array only
   // the loop runs twice, first for the uint8 planes, then for the float32 planes: a wave then feeds half
   // as many write streams at a time (it composes every dword twice; the loop is store-bound)
   int32_t two_pass = 0;
@@ -365,7 +366,7 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
       uni |= ms[s];
       d = (d & ~ms[s]) | (pm.sprite_ch4[s] & ms[s]);
     }
-    put(pb_board, d);
+    if (!(epi_on && epi.skip_board)) put(pb_board, d);
     if (to_array && role != 0 && !skipped) to_array_emit<GUARD>(epi, lut_lds, d, foff_now, fbase);
     // rendering.py:177-179 layers[c] = (board == c): by construction the thing's
     // own mask, or the backdrop's precomputed mask where no thing paints
@@ -684,6 +685,7 @@ inline bool fill_epilogue(EpilogueArgs& result, const pcx_epilogue_desc* d, int 
   a.env_stride = (uint32_t)d->depth * (uint32_t)cells * 4u;
   a.plane_bytes = (uint32_t)cells * 4u;
   a.skip_layers = d->skip_layers != 0;
+  a.skip_board = d->skip_layers >= 2;
   // more than sixteen write streams per wave (board + layers + float planes) go faster as two passes
   // (marauders 32,768: 0.275 -> 0.198 ms, step + separate kernel: 0.280; hello_world's fifteen do not:
   // profiles/r03_post_kernels.md)

@@ -59,15 +59,17 @@ class Engine(object):
     self._croppers = []
     self._fuse_request = None  # cropping.fuse_croppers() before its_showtime(): (croppers, only_crops)
     self._only_crops = False   # fused croppers only: the full-board planes are not written
+    self._epilogue_only = False  # a fused post-processor with skip_board: the kernel writes its array only
     self._epilogue = None      # (converter, float tensor the step kernel writes): rendering.fuse_into
 
-  def _install_epilogue(self, converter, out):
+  def _install_epilogue(self, converter, out, only=False):
     """rendering.ObservationToFeatureArray.fuse_into(): the step kernel writes
     `out` from now on, so the engine holds it (and its converter) until the
     epilogue is cleared or the engine closed."""
     if self._epilogue is not None and self._epilogue[0] is not converter:
       self._epilogue[0]._epilogue_gone()  # the kernel feeds one array: the earlier converter is on its own again
     self._epilogue = (converter, out)
+    self._epilogue_only = bool(only)
 
   def _clear_epilogue(self, converter=None):
     if self._epilogue is None or (converter is not None and self._epilogue[0] is not converter):
@@ -76,6 +78,7 @@ class Engine(object):
       N.check(N.lib().pcx_engine_set_epilogue(self._native, None))
     self._epilogue[0]._epilogue_gone()
     self._epilogue = None
+    self._epilogue_only = False
 
   def _register_cropper(self, cropper):
     if cropper not in self._croppers:
@@ -430,10 +433,11 @@ class Engine(object):
 
   def _result(self):
     L = self._template.chars
-    if self._only_crops:
-      # cropping.fuse_croppers(..., only_crops=True): the step kernel no longer
-      # writes the full-board planes, so there is no observation to hand out --
-      # the fused croppers' crop() returns what the step wrote
+    if self._only_crops or self._epilogue_only:
+      # cropping.fuse_croppers(..., only_crops=True) / fuse_into(..., skip_board=True):
+      # the step kernel no longer writes the full-board planes, so there is no
+      # observation to hand out -- the fused croppers' crop() (the fused
+      # converter's call) returns what the step wrote
       sc = None if self._batch > 1 else self._read_scalars()
       stale = self._tag(rendering.Observation(board=None, layers={}))
       if self._batch == 1:

@@ -153,15 +153,17 @@ class ObservationToArray(object):
     self._post = None
     self._fused = None  # (engine, device tensor, step count) once fuse_into() succeeded
 
-  def fuse_into(self, engine, skip_layers=False):
+  def fuse_into(self, engine, skip_layers=False, skip_board=False):
     """Have `engine`'s step kernel write this array itself, as an epilogue of
     its render loop (the board dword is in a register there, the value table in
     LDS): from the next `play()` / `step()` on, calling this object with one of
     the engine's observations returns the tensor the step already filled.
     `skip_layers=True` also stops the step from writing the uint8 layer planes
     -- a consumer that ingests, say, an RGB image gets the board and the image
-    and nothing else (scrolly_maze: 1,200 instead of 2,700 bytes per
-    environment and step).  Returns False, and changes nothing, where the
+    and nothing else; `skip_board=True` leaves out the board plane too (the
+    engine's observations then carry `board=None`): the step writes this one
+    array (scrolly_maze, a million environments, RGB: 0.69 ms against 1.05 ms
+    for step + post-processor).  Returns False, and changes nothing, where the
     engine's kernel cannot do it (batch 1, a permuted axis order, boards that
     are not a whole number of dwords, a character of the game without a value,
     the table-driven kernel, unoccluded layers, fused croppers): calls then run
@@ -186,7 +188,7 @@ class ObservationToArray(object):
     d = N.EpilogueDesc()
     d.depth = self._depth
     d.out_dev = out.data_ptr()
-    d.skip_layers = int(bool(skip_layers))
+    d.skip_layers = 2 if skip_board else int(bool(skip_layers))
     d.to_array = 1
     d.dtype = _DTYPES[self._dtype.name]
     d.lut = lut.ctypes.data
@@ -197,7 +199,7 @@ class ObservationToArray(object):
       return False
     # start from the current observation (environments a later step leaves untouched keep values that match their board)
     out.copy_(ObservationToArray(self._value_mapping, self._dtype, self._permute)(engine._result()[0]))
-    engine._install_epilogue(self, out)  # the ENGINE owns the epilogue (see ObservationToFeatureArray.fuse_into)
+    engine._install_epilogue(self, out, only=skip_board)  # the ENGINE owns the epilogue (see ObservationToFeatureArray.fuse_into)
     self._fused = (engine, out, engine._steps_launched)
     return True
 
@@ -273,7 +275,7 @@ class ObservationToFeatureArray(object):
     self._post = None
     self._fused = None  # (engine, device tensor) once fuse_into() succeeded
 
-  def fuse_into(self, engine, skip_layers=False):
+  def fuse_into(self, engine, skip_layers=False, skip_board=False):
     """Have `engine`'s step kernel write this feature array itself, as an
     epilogue of its render loop (the layer masks are in registers there):
     from the next `play()` / `step()` on, calling this object with one of the
@@ -300,7 +302,7 @@ class ObservationToFeatureArray(object):
     for i, ch in enumerate(self._layers):
       d.chars[i] = ord(ch)
     d.out_dev = out.data_ptr()
-    d.skip_layers = int(bool(skip_layers))
+    d.skip_layers = 2 if skip_board else int(bool(skip_layers))  # skip_board: not even the board plane (observations carry board=None)
     d.channels_last = int(channels_last)
     try:
       N.check(N.lib().pcx_engine_set_epilogue(engine._native, ctypes.byref(d)))
@@ -313,7 +315,7 @@ class ObservationToFeatureArray(object):
     # kernel writes alive for as long as it may launch (a converter that was
     # garbage-collected would leave the kernel writing freed memory), tells the
     # converter it replaces that it is no longer fed, and lets go in close().
-    engine._install_epilogue(self, out)
+    engine._install_epilogue(self, out, only=skip_board)
     self._fused = (engine, out, engine._steps_launched)
     return True
 

@@ -363,6 +363,38 @@ def test_value_array_fused_into_the_step_kernel(name, n_actions, batch, kind, sk
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,n_actions,batch', [('scrolly_maze_L0', 5, 300), ('scrolly_maze_L0', 5, 70000), ('marauders', 4, 2000),
+                                                  ('hello_world', 4, 70000), ('warehouse_custom_B', 5, 900)])
+def test_epilogue_without_any_plane(name, n_actions, batch):
+  """skip_board=True: the step kernel writes the fused converter's array and nothing else of the observation
+  (`board=None`).  Checked against a twin engine that runs the separate kernels on the same actions: a value
+  array, then a feature stack, then channels last."""
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template(name)
+  chars = [chr(c) for c in t.chars]
+  mapping = {c: (3 * i + 1, 200 - i, i) for i, c in enumerate(chars)}
+  makers = [lambda: rendering.ObservationToArray(mapping, dtype=np.uint8),
+            lambda: rendering.ObservationToFeatureArray(''.join(chars[:5])),
+            lambda: rendering.ObservationToFeatureArray(''.join(chars[:4]), permute=(1, 2, 0))]
+  a = Engine.from_template(t, batch=batch, auto_reset=True, seed=6)
+  b = Engine.from_template(t, batch=batch, auto_reset=True, seed=6)
+  a.its_showtime(); b.its_showtime()
+  for make in makers:
+    fused, plain = make(), make()
+    assert fused.fuse_into(a, skip_board=True), name
+    for step in range(6):
+      acts = torch.randint(0, n_actions, (batch,), dtype=torch.int32, device='cuda')
+      oa, ob = a.play(acts)[0], b.play(acts)[0]
+      assert oa.board is None
+      assert torch.equal(fused(oa), plain(ob)), (name, step)
+    fused.unfuse()
+    oa, ob = a.play(acts)[0], b.play(acts)[0]   # the planes are written again
+    assert torch.equal(oa.board, ob.board)
+  a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_value_array_epilogue_refusals():
   from pycolab_amd.engine import Engine
   t = helpers.load_template('scrolly_maze_L0')

@@ -29,7 +29,7 @@ for name, batch in (('scrolly_maze_L0', 1048576), ('scrolly_maze_L0', 4096), ('m
     else:
       mapping, dtype = {c: float(i) for i, c in enumerate(chars)}, np.float32
     res = []
-    for mode in ('two kernels', 'fused', 'fused, skip_layers'):
+    for mode in ('two kernels', 'fused', 'fused, skip_layers', 'fused, skip_board'):
       eng = Engine.from_template(t, batch=batch, auto_reset=True, seed=1)
       eng.its_showtime()
       tape = torch.randint(0, t.n_actions, (16, batch), dtype=torch.int32, device='cuda')
@@ -42,8 +42,8 @@ for name, batch in (('scrolly_maze_L0', 1048576), ('scrolly_maze_L0', 4096), ('m
         conv(obs)
         fn = lambda: (one(), conv(obs))
       else:
-        assert conv.fuse_into(eng, skip_layers=mode != 'fused')
+        assert conv.fuse_into(eng, skip_layers=mode != 'fused', skip_board=mode == 'fused, skip_board')
         fn = one
       res.append(sorted(timed(fn, 50 if batch > 500000 else 100) for _ in range(3))[1])
       eng.close()
-    print('%-16s %8d envs  %-14s  step+post %.4f  fused %.4f  fused, layers skipped %.4f ms' % ((name, batch, kind) + tuple(res)), flush=True)
+    print('%-16s %8d envs  %-14s  step+post %.4f  fused %.4f  fused, layers skipped %.4f  fused, array only %.4f ms' % ((name, batch, kind) + tuple(res)), flush=True)
