@@ -502,6 +502,11 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
   // four waves share a group's render loop below this many groups per CU (measured crossover: the 45x89
   // board 2 vs 3 groups per CU, the 29x30 board 4 vs 8; profiles/r02_tuning.md)
   int coop_below = lay_.QW >= 512 ? 3 : 5;
+  // windows only (fused croppers, only_crops): a launch writes ~5 KB per environment instead of 32 KB, and one wave
+  // per SIMD cannot hide the window loop's latencies (SQ counters at 65,536 environments: 38 k VALU instructions per
+  // wave, 1,024 waves on 1,024 SIMDs): four waves per group up to 16 groups per CU -- 0.134 -> 0.085 ms (49 % of
+  // 8 TB/s; eight waves: the same), 262,144 environments 0.484 -> 0.420 ms; profiles/r03_post_kernels.md
+  if (fused_.only) coop_below = 17;
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
   size_t lds = base_lds_bytes();

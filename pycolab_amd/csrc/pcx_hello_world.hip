@@ -406,6 +406,7 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   Ptrs P{tables_.ptr, initc_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
   const int64_t groups = bpad_ / WAVE;
   int coop_below = 5, waves_per_cu = 6;
+  if (fused_.only) coop_below = 17;  // windows only: little to stream per group, latency-bound (see pcx_better_scrolly.hip)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;

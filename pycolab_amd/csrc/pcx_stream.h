@@ -738,16 +738,19 @@ inline EpilogueArgs with_hwc_scratch(EpilogueArgs a, size_t& lds_bytes, int wave
 struct FusedCropsHolder {
   DevArray<crop::FusedCrops> dev;
   bool on = false;
+  bool only = false;  // windows only: the full-board planes are not written (the launch is a few KB per environment:
+                      // the backends then share a group among four waves up to many more groups per CU)
   // rows, cols: the board, for kernels that take a drape's median from the curtains they export (curtain_centroid:
   // rows of at most 64 cells, at most 63 of them); drapes_ok: the kernel has its own way (pcx_generic.hip)
   int set(const crop::FusedCrops* fc, bool drapes_ok = false, int rows = 0, int cols = 0) {
     if (!drapes_ok && crop::tracks_drapes(fc) && !(rows > 0 && rows <= 63 && cols > 0 && cols <= 64))
       return set_error(PCX_E_UNSUPPORTED, "fused croppers: a cropper that tracks a drape is fused on boards of at most 63 x 64 cells (this one: %d x %d)", rows, cols);
     PCX_HIP(hipDeviceSynchronize());  // no launch in flight may still read the old description
-    if (!fc || fc->n <= 0) { on = false; return 0; }
+    if (!fc || fc->n <= 0) { on = false; only = false; return 0; }
     if (!dev.ptr) { if (int rc = dev.alloc(1)) return rc; }
     PCX_HIP(hipMemcpy(dev.ptr, fc, sizeof *fc, hipMemcpyHostToDevice));
     on = true;
+    only = fc->only != 0;
     return 0;
   }
   const crop::FusedCrops* ptr() const { return on ? dev.ptr : nullptr; }

@@ -534,6 +534,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   // workgroups with LDS padded so that about four of them share a CU; four
   // waves per group when the batch leaves most of the chip idle.
   int coop_below = 5, waves_per_cu = 4;  // measured: 1,048,576 envs 0.320 ms at 4 per CU vs 0.345 at 8 (tools/knob_sweep_r02.sh)
+  if (fused_.only) coop_below = 17;  // windows only: little to stream per group, latency-bound (see pcx_better_scrolly.hip)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
