@@ -1310,10 +1310,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   const uint32_t bpd = EPI ? epi.dword_bytes : 16u;  // epilogue bytes per board dword and plane (16: float32 feature planes)
   const uint32_t f_skew = epi.env_stride - bpd * (uint32_t)QW;  // foff = bpd f + e * f_skew
   uint32_t foff = bpd * lane;
-  // ObservationToArray as the epilogue (pcx_stream.h to_array_emit): the value table, copied to LDS by every wave for itself
-  const bool to_array = EPI && epi.to_array != 0;
-  uint32_t* const lut_lds = to_array ? lds_raw + epi.lut_lds_off : nullptr;
-  if (to_array) stream::to_array_stage(epi, lut_lds, lane);
+
   // CODES: planes in their natural order (plane 1 + k = layer of character k)
   constexpr int NPK = CODES ? 1 + SL : 1;
   uint8_t* pbk[NPK];
@@ -1343,8 +1340,17 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // group first, the float32 planes in a second sweep over the same codes
   constexpr bool TWO_PASS = EPI && CODES && INCR;
   const int n_pass = TWO_PASS && epi.two_pass ? 2 : 1;  // (with skip_layers the first sweep writes the board plane only)
+  // The sweeps, compiled once per kind of epilogue (MODE 0: none / float32 feature planes, 1: channels last, 2:
+  // ObservationToArray) and picked at run time below: as run-time flags inside one loop body the later kinds cost
+  // the first a fifth of its speed (1,048,576 environments, feature planes: 2.88 -> 3.50 ms; profiles/r03_post_kernels.md).
+  auto sweeps = [&](auto mode_c) {
+  constexpr int MODE = decltype(mode_c)::value;
+  // ObservationToArray as the epilogue (pcx_stream.h to_array_emit): the value table, copied to LDS by every wave for itself
+  constexpr bool to_array = EPI && MODE == 2;
+  uint32_t* const lut_lds = to_array ? lds_raw + epi.lut_lds_off : nullptr;
+  if (to_array) stream::to_array_stage(epi, lut_lds, lane);
   // channels-last epilogue (pcx_stream.h hwc_emit): this wave's exchange area, rows of unselected layers stay zero
-  const bool hwc = EPI && epi.hwc != 0;
+  constexpr bool hwc = EPI && MODE == 1;
   // (two areas per wave, used in turn: an iteration drops its bytes into one and stores the floats of the iteration
   // before from the other)
   const uint32_t hw_words = hwc ? (uint32_t)epi.depth * WAVE : 0u;
@@ -1471,6 +1477,14 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     if (hwc && hw_it >= 0) hw_turn(-1);  // the last iteration's floats
   }
   }  // passes
+  };  // sweeps
+  if constexpr (!EPI) {
+    sweeps(std::integral_constant<int, 0>{});
+  } else {  // (uniform: one of the three runs)
+    if (epi.hwc) sweeps(std::integral_constant<int, 1>{});
+    else if (epi.to_array) sweeps(std::integral_constant<int, 2>{});
+    else sweeps(std::integral_constant<int, 0>{});
+  }
   if constexpr (FUSABLE) {
     if (fc) {  // the croppers' windows, cut from the same descriptors (pcx_stream.h stream_windows)
       stream::PlaneMap<NS, 2, NBS> pm;

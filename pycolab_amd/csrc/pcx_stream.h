@@ -221,13 +221,16 @@ __device__ __forceinline__ void to_array_emit(const EpilogueArgs& epi, const uin
 //     flat curtain: cell_ids[q] = the list indices of board dword q's four cells
 //     (0xFF = not a cell of the drape), `flat` = [64][FWP] alive masks.  Needs ND == 1.
 //   UNOCC: occlusion_in_layers=False -- the layers come from the raw copies snapshot_raw() kept.
-template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI, bool UNOCC = false>
-__device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
-                                              const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
-                                              const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
-                                              const EpilogueArgs& epi, int64_t env0, const uint32_t* cell_ids = nullptr,
-                                              int qw_rt = 0, const uint32_t* flatraw = nullptr, const uint2* sdescraw = nullptr,
-                                              uint32_t* lds_base = nullptr) {
+//   MODE (epilogue instances): 0 the float32 feature planes, 1 channels last, 2 ObservationToArray -- a compile-time
+//     choice per loop (stream_planes() below picks one at run time): as run-time flags inside ONE loop body the two
+//     later kinds cost the first a fifth of its speed (marauders 262,144: 1.61 -> 1.95 ms; profiles/r03_post_kernels.md).
+template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI, bool UNOCC, int MODE>
+__device__ __forceinline__ void stream_planes_mode(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
+                                                   const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
+                                                   const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
+                                                   const EpilogueArgs& epi, int64_t env0, const uint32_t* cell_ids,
+                                                   int qw_rt, const uint32_t* flatraw, const uint2* sdescraw,
+                                                   uint32_t* lds_base) {
   const uint32_t QWv = QW ? (uint32_t)QW : (uint32_t)qw_rt;
   uint8_t* const pb_board = uniform_ptr(group_base);
   uint8_t* pb_s[NS];
@@ -267,12 +270,12 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   const uint32_t bpd = epi_on ? epi.dword_bytes : 16u;  // epilogue bytes per board dword and plane
   uint32_t foff = e * epi.env_stride + bpd * q;
   const uint32_t dfoff = DE * epi.env_stride + bpd * DQ, wrap_foff = epi.env_stride - bpd * QWv;
-  const bool to_array = epi_on && epi.to_array != 0;
+  constexpr bool to_array = EPI && MODE == 2;
   uint32_t* const lut_lds = to_array ? lds_base + epi.lut_lds_off : nullptr;
   if (to_array) to_array_stage(epi, lut_lds, lane);
   const uint32_t e_0 = e, q_0 = q, voff_0 = voff, eF_0 = eF, foff_0 = foff;
   // channels last: this wave's exchange area, rows of the layers nobody paints stay zero
-  const bool hwc = epi_on && epi.hwc != 0;
+  constexpr bool hwc = EPI && MODE == 1;
   // (two areas per wave, used in turn: an iteration drops its bytes into one and stores the floats of the
   // iteration before from the other, so that no wave waits for its own LDS writes)
   const uint32_t hw_words = hwc ? (uint32_t)epi.depth * WAVE : 0u;
@@ -399,6 +402,26 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
   if (hwc && hw_it >= 0 && role != 0)  // the last iteration's floats
     hwc_emit<true>(hw + (hw_sel ^ 1u) * hw_words, epi, (uint32_t)hw_it * WAVE, lane, any_skip, skip, QWv, fbase, (uint32_t)WAVE * QWv);
   }  // passes
+}
+
+template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI, bool UNOCC = false>
+__device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
+                                              const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
+                                              const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
+                                              const EpilogueArgs& epi, int64_t env0, const uint32_t* cell_ids = nullptr,
+                                              int qw_rt = 0, const uint32_t* flatraw = nullptr, const uint2* sdescraw = nullptr,
+                                              uint32_t* lds_base = nullptr) {
+#define PCX_STREAM_MODE(m)                                                                                                       \
+  stream_planes_mode<NS, ND, NB, QW, NWAVES, EPI, UNOCC, m>(pm, group_base, env_stride, backdrop4, bdmask, flat, sdesc, skip, FWP, lane, \
+                                                            wave, epi, env0, cell_ids, qw_rt, flatraw, sdescraw, lds_base)
+  if constexpr (!EPI) {
+    PCX_STREAM_MODE(0);
+  } else {  // (uniform: one of the three loops runs)
+    if (epi.hwc) PCX_STREAM_MODE(1);
+    else if (epi.to_array) PCX_STREAM_MODE(2);
+    else PCX_STREAM_MODE(0);
+  }
+#undef PCX_STREAM_MODE
 }
 
 // ---------------------------------------------------------------------------
