@@ -483,7 +483,12 @@ typedef struct pcx_epilogue_desc {
    * call copies them).  Every character of the game must be mapped
    * (the reference would raise on the first one that is not,
    * rendering.py:503-507) and rows*cols % 4 == 0; PCX_E_UNSUPPORTED otherwise.
-   * With skip_layers the step writes the board and this array only.        */
+   * With skip_layers the step writes the board and this array only.
+   * to_array == 2: rendering.ObservationCharacterRepainter (rendering.py:304-406):
+   * out_dev is a planes array uint8 [batch][1 + depth][rows*cols] -- plane 0 the
+   * board repainted through lut[0], plane 1 + k the layer of chars[k] (the
+   * repainted observation's characters) -- i.e. what pcx_post_* writes for
+   * PCX_POST_REPAINT; dtype is PCX_U8.                                         */
   int32_t to_array;
   int32_t dtype;
   const uint64_t* lut;    /* [depth][128] */

@@ -444,8 +444,9 @@ int pcx_engine_set_epilogue(pcx_engine* e, const pcx_epilogue_desc* d) {
       return set_error(PCX_E_UNSUPPORTED, "pcx_engine_set_epilogue: character %d of the game has no value in the mapping "
                                           "(the stand-alone post-processor reports it per environment)", (int)e->t.chars[i]);
   const int esize = d->dtype == PCX_U8 ? 1 : (d->dtype == PCX_I32 || d->dtype == PCX_F32) ? 4 : 8;
-  std::vector<uint8_t> packed((((size_t)d->depth * 128 * esize) + 15) & ~(size_t)15, 0);
-  for (int k = 0; k < d->depth; ++k)
+  const int rows = d->to_array == 2 ? 1 : d->depth;  // (the repainter: one row; depth counts its output layers)
+  std::vector<uint8_t> packed((((size_t)rows * 128 * esize) + 15) & ~(size_t)15, 0);
+  for (int k = 0; k < rows; ++k)
     for (int c = 0; c < 128; ++c) memcpy(packed.data() + ((size_t)k * 128 + c) * esize, &d->lut[(size_t)k * 128 + c], (size_t)esize);
   void* dev = nullptr;
   PCX_HIP(hipMalloc(&dev, packed.size()));

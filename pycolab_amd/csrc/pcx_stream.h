@@ -119,6 +119,10 @@ struct EpilogueArgs {
   uint32_t dword_bytes = 16;  // output bytes per board dword and plane: 4 * esize (16 for the float32 feature planes)
   uint32_t lut_lds_off = 0;
   const void* lut = nullptr;
+  // ... as ObservationCharacterRepainter (rendering.py:304-406): a one-row uint8 table repaints the board (plane 0 of
+  // out, a planes array [batch][1 + repaint][cells]) and plane 1 + k is the layer of repaint_ch[k]: board' == that character
+  int32_t repaint = 0;
+  uint8_t repaint_ch[PCX_POST_MAX_DEPTH] = {};
   int32_t sprite_slot[PCX_MAX_SPRITES], drape_slot[PCX_MAX_DRAPES], bchar_slot[PCX_MAX_CHARS];
 };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -183,6 +187,13 @@ __device__ __forceinline__ void to_array_emit(const EpilogueArgs& epi, const uin
       const uint32_t v = (uint32_t)t[d * 128u + c0] | ((uint32_t)t[d * 128u + c1] << 8) | ((uint32_t)t[d * 128u + c2] << 16) |
                          ((uint32_t)t[d * 128u + c3] << 24);
       saddr_store_dword<GUARD>(aoff + d * epi.plane_bytes, v, fbase);
+      if (epi.repaint) {  // (depth == 1) the repainted observation's layers: bytes of v equal to the character, as 0x01
+        for (int kk = 0; kk < epi.repaint; ++kk) {
+          const uint32_t y = v ^ ((uint32_t)epi.repaint_ch[kk] * 0x01010101u);
+          const uint32_t m = (~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) >> 7) & 0x01010101u;
+          saddr_store_dword<GUARD>(aoff + (uint32_t)(1 + kk) * epi.plane_bytes, m, fbase);
+        }
+      }
     }
   } else if (epi.esize == 4) {
     for (uint32_t d = 0; d < depth; ++d) {
@@ -723,6 +734,15 @@ inline bool fill_epilogue(EpilogueArgs& result, const pcx_epilogue_desc* d, int 
     a.dword_bytes = 4u * (uint32_t)esize;
     a.env_stride = (uint32_t)d->depth * (uint32_t)cells * (uint32_t)esize;
     a.plane_bytes = (uint32_t)cells * (uint32_t)esize;
+    if (d->to_array == 2) {  // the repainter: one table row, 1 + depth output planes
+      if (esize != 1) return false;
+      a.repaint = d->depth;
+      for (int i = 0; i < d->depth; ++i) a.repaint_ch[i] = d->chars[i];
+      a.depth = 1;
+      a.magic_depth = 0;
+      a.env_stride = (uint32_t)(1 + d->depth) * (uint32_t)cells;
+      a.two_pass = 1 + ns + nd + nb + 1 + d->depth > 16;
+    }
   }
   a.magic_depth = 0xFFFFFFFFu / (uint32_t)d->depth + 1u;
   if (d->channels_last) {  // one float32 stream instead of `depth`; needs boards of whole dwords (no padding between environments)

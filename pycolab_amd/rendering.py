@@ -363,8 +363,63 @@ class ObservationCharacterRepainter(object):
     self._post = None
     self._out_chars = None
     self._repainted = None
+    self._fused = None  # (engine, step count) once fuse_into() succeeded
+
+  def fuse_into(self, engine, skip_layers=False, skip_board=False):
+    """Have `engine`'s step kernel write the repainted observation itself (the
+    board dword through the character table, every output layer by a byte-wise
+    compare): from the next `play()` / `step()` on, calling this object with
+    one of the engine's observations returns the planes the step already
+    filled; they are a planes source as before (`ObservationToArray(...)(
+    repainter(observation))` chains).  `skip_layers` / `skip_board`: the step
+    no longer writes the original layer planes / any original plane.  Returns
+    False, and changes nothing, where the engine's kernel cannot do it (batch
+    1, boards that are not a whole number of dwords, the table-driven kernel,
+    unoccluded layers, fused croppers)."""
+    torch = dev.torch_module()
+    if torch is None or engine._native is None or engine.batch == 1:
+      return False
+    obs = engine._result()[0]
+    if obs.board is None:
+      return False
+    self(obs)  # creates the output planes (and brings them up to date with the current observation)
+    if self._post.out is None or self._post.out.tensor is None:
+      return False
+    lut = np.zeros((N.POST_MAX_DEPTH, 128), np.uint64)
+    lut[0, :] = np.arange(128)
+    for k, v in self._character_mapping.items():
+      lut[0, ord(k)] = ord(v)
+    mapped = np.ones((128,), np.uint8)
+    d = N.EpilogueDesc()
+    d.depth = len(self._out_chars)
+    for i, ch in enumerate(self._out_chars):
+      d.chars[i] = ord(ch)
+    d.out_dev = self._post.out.ptr
+    d.skip_layers = 2 if skip_board else int(bool(skip_layers))
+    d.to_array = 2
+    d.dtype = N.U8
+    d.lut = lut.ctypes.data
+    d.mapped = mapped.ctypes.data
+    try:
+      N.check(N.lib().pcx_engine_set_epilogue(engine._native, ctypes.byref(d)))
+    except NotImplementedError:
+      return False
+    engine._install_epilogue(self, self._post.out, only=skip_board)
+    self._fused = (engine, engine._steps_launched)
+    return True
+
+  def unfuse(self):
+    if self._fused is not None:
+      self._fused[0]._clear_epilogue(self)
+
+  def _epilogue_gone(self):
+    self._fused = None
 
   def __call__(self, original_observation):
+    fused_now = (self._fused is not None and getattr(original_observation, '_source', None) is self._fused[0] and
+                 self._fused[0]._steps_launched > self._fused[1])
+    if fused_now:
+      return self._wrap(self._post.out.tensor)  # the step kernel wrote the planes
     source = _source_of(original_observation)
     self._post = _bound(self._post, source)
     if self._post is None:
@@ -391,6 +446,10 @@ class ObservationCharacterRepainter(object):
     planes, bad = self._post.run(host=B == 1)
     if bad and self._post.errors().any():
       raise RuntimeError('ObservationCharacterRepainter met a character outside ASCII')
+    return self._wrap(planes)
+
+  def _wrap(self, planes):
+    B = self._post.out_shape[0]
     R, C, pitch = self._repainted.rows, self._repainted.cols, self._repainted.pitch
     if B == 1:
       planes = np.ascontiguousarray(planes[0, :, :R * C]).reshape(-1, R, C)

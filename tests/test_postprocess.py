@@ -395,6 +395,38 @@ def test_epilogue_without_any_plane(name, n_actions, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['planes kept', 'skip_layers', 'skip_board'])
+@pytest.mark.parametrize('name,n_actions,batch', [('scrolly_maze_L0', 5, 300), ('scrolly_maze_L0', 5, 70000), ('marauders', 4, 2000),
+                                                  ('hello_world', 4, 70000), ('warehouse_custom_B', 5, 900)])
+def test_repainter_fused_into_the_step_kernel(name, n_actions, batch, mode):
+  """ObservationCharacterRepainter.fuse_into(engine): the step kernel writes the repainted board and its layers
+  itself; still a planes source (a feature array chained behind it).  Against a twin engine that runs the separate
+  kernels on the same actions."""
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template(name)
+  chars = [chr(c) for c in t.chars]
+  mapping = {chars[0]: '-', chars[1]: chars[2], chars[-1]: 'Z'}   # two characters merge, two get new ones
+  a = Engine.from_template(t, batch=batch, auto_reset=True, seed=6)
+  b = Engine.from_template(t, batch=batch, auto_reset=True, seed=6)
+  a.its_showtime(); b.its_showtime()
+  fused, plain = rendering.ObservationCharacterRepainter(mapping), rendering.ObservationCharacterRepainter(mapping)
+  assert fused.fuse_into(a, skip_layers=mode == 'skip_layers', skip_board=mode == 'skip_board'), name
+  outs = sorted((set(chars) - set(mapping)) | set(mapping.values()))
+  feats_a, feats_b = rendering.ObservationToFeatureArray(''.join(outs)), rendering.ObservationToFeatureArray(''.join(outs))
+  for step in range(6):
+    acts = torch.randint(0, n_actions, (batch,), dtype=torch.int32, device='cuda')
+    oa, ob = a.play(acts)[0], b.play(acts)[0]
+    ra, rb = fused(oa), plain(ob)
+    assert torch.equal(ra.board, rb.board), (name, step)
+    assert sorted(ra.layers) == sorted(rb.layers) == outs
+    for ch in outs:
+      assert torch.equal(ra.layers[ch], rb.layers[ch]), (name, step, ch)
+    assert torch.equal(feats_a(ra), feats_b(rb)), (name, step)   # the repainted planes chain as before
+  a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_value_array_epilogue_refusals():
   from pycolab_amd.engine import Engine
   t = helpers.load_template('scrolly_maze_L0')
