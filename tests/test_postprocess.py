@@ -51,6 +51,20 @@ def test_oracle_postprocessors_match_reference(name):
         np.testing.assert_array_equal(got, want)
 
 
+def test_fuse_into_answers_false_without_a_device_engine():
+  """fuse_into() never raises for "cannot": an engine that is not in play on a device (no native handle yet), a
+  permuted axis order other than channels last.  (The device-side refusals are in the GPU tests.)"""
+  from pycolab_amd.engine import Engine
+  eng = Engine.from_template(helpers.load_template('scrolly_maze_L0'), batch=4)
+  assert eng._native is None
+  assert rendering.ObservationToArray({'a': 1.0}, dtype=np.float32).fuse_into(eng) is False
+  assert rendering.ObservationToArray({'a': (1, 2, 3)}, dtype=np.uint8, permute=(2, 0, 1)).fuse_into(eng) is False
+  assert rendering.ObservationToFeatureArray('P').fuse_into(eng) is False
+  assert rendering.ObservationToFeatureArray('P', permute=(2, 0, 1)).fuse_into(eng) is False
+  assert rendering.ObservationCharacterRepainter({'a': 'b'}).fuse_into(eng) is False
+  assert eng._epilogue is None and not eng._epilogue_only
+
+
 def test_constructor_guards():
   with pytest.raises(ValueError):
     rendering.ObservationToArray({'a': [1, 2]}, permute=(0, 1))
