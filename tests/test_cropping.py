@@ -473,3 +473,48 @@ def test_fuse_croppers_answers_false_where_the_kernel_cannot():
   sprite = cropping.ScrollingCropper(3, 3, ['P'], pad_char=' ', scroll_margins=(None, None))
   with pytest.raises(ValueError):                                  # the stand-alone cropper would read stale planes
     cropping.fuse_croppers(eng2, [sprite], only_crops=True)
+
+
+def _centroid_like_the_kernels(curtain):
+  """pcx_stream.h curtain_centroid / pcx_generic.hip drape_centroid, restated step by step on a bool curtain: rows
+  as C-bit integers, per-column counts kept bit-sliced in six planes (a ripple-carry add per row), the two middle
+  order statistics by prefix counts, their mean truncated."""
+  R, C = curtain.shape
+  rows = [sum(1 << c for c in range(C) if curtain[r, c]) for r in range(R)]
+  n, planes = 0, [0] * 6
+  for v in rows:
+    carry = v
+    n += bin(v).count('1')
+    for k in range(6):
+      planes[k], carry = planes[k] ^ carry, planes[k] & carry
+  if n == 0:
+    return None
+  lo_rank, hi_rank = (n - 1) // 2, n // 2
+
+  def middle(counts):
+    seen, lo, hi = 0, -1, -1
+    for i, cnt in enumerate(counts):
+      if lo < 0 and seen + cnt > lo_rank:
+        lo = i
+      if hi < 0 and seen + cnt > hi_rank:
+        hi = i
+      seen += cnt
+    return (lo + hi) >> 1
+  col_counts = [sum(((planes[k] >> c) & 1) << k for k in range(6)) for c in range(C)]
+  return middle([bin(v).count('1') for v in rows]), middle(col_counts)
+
+
+def test_the_kernels_drape_median_is_the_references():
+  """cropping.py:590-598: `tuple(int(np.median(dim)) for dim in curtain.nonzero())` -- the arithmetic the fused
+  croppers use for it (no sort, no division) on random curtains up to the 63 x 64 limit, dense, sparse and empty."""
+  rng = np.random.RandomState(12)
+  for trial in range(400):
+    R, C = int(rng.randint(1, 64)), int(rng.randint(1, 65))
+    density = rng.choice([0.0, 0.02, 0.3, 0.9, 1.0])
+    curtain = rng.rand(R, C) < density
+    if trial % 7 == 0 and curtain.size > 1:
+      curtain[:] = False
+      curtain[rng.randint(R), rng.randint(C)] = True   # a single cell
+    got = _centroid_like_the_kernels(curtain)
+    want = tuple(int(np.median(dim)) for dim in curtain.nonzero()) if curtain.any() else None
+    assert got == want, (R, C, density, got, want)
