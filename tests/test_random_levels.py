@@ -436,3 +436,26 @@ def test_random_levels_build_and_step_on_the_oracle():
       orc.step_hashed(1, 0, 40)
       assert orc.read('planes').shape[1] == 1 + len(t.chars)
       assert not orc.read('error').any()
+
+
+def test_nth_set_column_by_popcount_bisection():
+  """pcx_generic.hip prog_em_downbolt picks the n-th set column of a 64-bit column mask (the marauders' return fire,
+  extraterrestrial_marauders.py:246-248) with six popcount bisection steps instead of clearing n bits; the same
+  arithmetic here against the plain definition."""
+  rng = np.random.RandomState(21)
+  for _ in range(2000):
+    cols = int(rng.randint(0, 2 ** 32)) | (int(rng.randint(0, 2 ** 32)) << 32)
+    cols &= (1 << int(rng.randint(1, 65))) - 1
+    if not cols:
+      continue
+    n = bin(cols).count('1')
+    pick = int(rng.randint(n))
+    want = [c for c in range(64) if (cols >> c) & 1][pick]
+    col, v, k = 0, cols, pick
+    for w in (32, 16, 8, 4, 2, 1):
+      below = bin(v & ((1 << w) - 1)).count('1')
+      if k >= below:
+        k -= below
+        col += w
+        v >>= w
+    assert col == want, (hex(cols), pick, col, want)
