@@ -328,6 +328,12 @@ int32_t pcx_engine_plane_pitch(const pcx_engine* e);
 int64_t pcx_engine_bytes_per_step(const pcx_engine* e);
 /* Name of the dominant kernel, as rocprofv3 prints it. */
 const char* pcx_engine_kernel_name(const pcx_engine* e);
+/* Which launch shape the engine's LAST step / reset launch took (tests and benchmarks assert that the shape they
+ * mean to measure is the one that ran; no reference counterpart).  pcx_scrolly_maze_step: 0 one single-wave
+ * workgroup per group of 64 environments, 1 persistent single-wave workgroups with the next unit's state words
+ * prefetched into LDS, 2 persistent logic/render wave pairs, 3 two-wave workgroups (round 1), 10 cooperative
+ * (several waves per group), 11 several steps per launch, 20 shape-generic instance; -1: the backend does not say. */
+int32_t pcx_engine_launch_shape(const pcx_engine* e);
 
 const char* pcx_last_error(void);
 uint32_t pcx_abi_version(void);

@@ -479,6 +479,7 @@ int pcx_engine_read_things(pcx_engine* e, int64_t env0, int64_t n, pcx_sprite_st
 int32_t pcx_engine_plane_pitch(const pcx_engine* e) { return e ? e->backend->plane_pitch() : 0; }
 int64_t pcx_engine_bytes_per_step(const pcx_engine* e) { return e ? e->backend->bytes_per_step() : 0; }
 const char* pcx_engine_kernel_name(const pcx_engine* e) { return e ? e->backend->kernel_name() : ""; }
+int32_t pcx_engine_launch_shape(const pcx_engine* e) { return e ? e->backend->launch_shape() : -1; }
 
 int pcx_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes) {
   PCX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));

@@ -132,6 +132,7 @@ class Backend {
                           uint8_t* curtains) = 0;
   virtual int64_t bytes_per_step() const = 0;
   virtual const char* kernel_name() const = 0;
+  virtual int launch_shape() const { return -1; }  // include/pcx.h pcx_engine_launch_shape
   // Sprite state for croppers: device int32 [n_sprites][batch] packed
   // (row | col << 8 | visible << 16), refreshed by every launch.
   virtual const int32_t* sprite_track() const { return nullptr; }

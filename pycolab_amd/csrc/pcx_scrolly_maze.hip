@@ -93,6 +93,9 @@ struct Consts {
   // of its character among the sorted characters ("owner code", one byte per
   // cell), from which v_perm_b32 makes the board dword and every layer dword
   int32_t lds_bdcode, lds_codes, lds_cmask_c, lds_skip_c, lds_words_codes;  // its own, compact LDS layout
+  // persistent shapes of the CODES instance (PS): the state inbox (LDS-DMA target), the hand-over ring of the
+  // logic/render wave pair, and the owner-code buffers (code table + skip flags each)
+  int32_t lds_ps_inbox, lds_ps_ring, lds_ps_cmask, lds_ps_buf0, lds_ps_buf_words, lds_ps_words1, lds_ps_words2;
   uint32_t chars_lo, chars_hi;  // characters 0..3 / 4..7 as bytes
   int32_t sprite_by_z[MAX_NS];  // sprites back to front
 };
@@ -107,6 +110,12 @@ struct Ptrs {
   uint32_t* curtains;             // [2][FW][bpad] raw curtain bits, template drape order (export_curtains)
   int32_t maze_slot;              // template drape index of the maze drape (0 or 1)
   int64_t batch, bpad;
+  // persistent shapes (PS): environments per work unit (64, 32 or 16), the ticket counter {next ticket, workgroups
+  // done} the units beyond every workgroup's first two are drawn from, or static round-robin when `ps_dynamic` is 0
+  uint32_t* ps_ctr;
+  int32_t ps_unit, ps_dynamic;
+  int32_t ps_nb;    // owner-code buffers of a logic/render pair (the logic wave runs up to ps_nb - 1 units ahead)
+  int32_t ps_prio;  // s_setprio of the pair's render wave (0: leave alone)
 };
 
 struct Walker {
@@ -517,6 +526,50 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
   }
 }
 
+// ---- persistent launch shapes (PS) of the owner-code instance -------------------------------------------
+// A workgroup stays on its CU and draws work units (64, 32 or 16 consecutive environments) until none are
+// left; the state words of its NEXT unit travel from HBM straight into an LDS inbox (LDS-DMA,
+// global_load_lds_dword: no VGPR in between, nothing for the compiler to wait for) while the current
+// unit is stepped / streamed, so that a unit's logic phase starts on words that are already there instead of
+// queueing fourteen loads behind the chip's plane stores.
+//   PS == 1: one wave per workgroup does both phases back to back; the inbox fills under the render loop.
+//            vmcnt counts in order and holds at most 63, so after 64 or more plane stores the DMA issued in
+//            front of them has landed -- no wait at all.
+//   PS == 2: two waves per workgroup: wave 0 only steps (and runs ahead by one owner-code buffer), wave 1
+//            only streams; they hand buffers over through a two-slot ring of LDS counters, no barrier.
+constexpr int PS_IB_ACTION = 15;  // inbox rows: the state words (at most 15), then the tape action
+constexpr int PS_IB_ROWS = 16;
+constexpr int PS_NB_MAX = 6;      // owner-code buffers of a logic/render pair, at most (ring words in LDS)
+constexpr uint32_t PS_SPIN_LIMIT = 1u << 22;  // (x s_sleep 2: seconds) a broken hand-over gives up instead of hanging the GPU
+
+// One row of the inbox: lane i's dword base[i] lands at LDS byte address lds_addr + 4 i.  M0 is written in the
+// statement that uses it and restored (the compiler owns it); the base is copied by an SALU instruction so that an
+// SGPR pair fresh from v_readfirstlane is never read by the VMEM instruction within the hazard window.
+__device__ __forceinline__ void ps_dma_row(const uint32_t* base, uint32_t voff, uint32_t lds_addr) {
+  uint32_t keep;
+  uint64_t own;
+  asm volatile(
+      "s_mov_b64 %1, %3\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(own)
+      : "v"(voff), "s"(base), "s"(lds_addr)
+      : "memory");
+}
+// The next ticket of the work counter, fetched by lane 0 alone, NOT waited for: the value is in lane 0 of the result
+// once 64 more VMEM instructions have been issued (or after s_waitcnt vmcnt(0)).
+__device__ __forceinline__ uint32_t ps_ticket_async(uint32_t* ctr) {
+  uint32_t tk, one = 1u, zero = 0u;
+  uint64_t save, own;
+  asm volatile(
+      "s_mov_b64 %2, %5\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %3, %4, %2 sc0\n\ts_mov_b64 exec, %1"
+      : "=&v"(tk), "=&s"(save), "=&s"(own)
+      : "v"(zero), "v"(one), "s"(ctr)
+      : "memory");
+  return tk;
+}
+__device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)p;
+}
+
 // NS sprites.  SR/SC/SL: board rows, cols and layer count when known at
 // compile time (0 = take them from Consts); IP/IE: index of the player and of
 // the egocentric sprite when known at compile time (-1 = from Consts).
@@ -528,14 +581,16 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 // EPI: the render loop also writes the float32 feature-array epilogue (pcx_stream.h).
 // CODES: the logic phase paints an owner-code byte per cell (LDS), the render loop
 // is one LDS read and one v_perm_b32 per plane (static shape, <= 8 characters).
+// PS: persistent launch shape of the owner-code instance (0: none; 1, 2: above).
 template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false, bool EPI = false,
-          bool CODES = false>
+          bool CODES = false, int PS = 0>
 __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                   const crop::FusedCrops* fc_arg) {
   // Fused croppers (include/pcx.h pcx_engine_fuse_croppers): the instances that keep the frame as curtain
   // bit vectors + sprite descriptors (pcx_stream.h's contract) and render a group in the round they step it
   constexpr bool FUSABLE = !TFUSE && !CODES && !UNOCC && !EPI;
+  static_assert(PS == 0 || (CODES && !COOP && !TFUSE && !EPI && !UNOCC && SR != 0), "persistent shapes: owner-code instance only");
   const crop::FusedCrops* const fc = FUSABLE ? fc_arg : nullptr;
   // A workgroup is two wavefronts with different jobs, looping over groups of
   // 64 environments: wave 0 (logic) steps group i+1 and leaves its render
@@ -614,7 +669,38 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   constexpr int CODE_PITCH = SR ? ((SR * SC / 4) | 1) + 2 : 1;  // dwords per environment, odd: logic (same q, 64
                                                                // environments) and render (same environment,
                                                                // consecutive q) both spread over the banks
-  uint32_t* const codes = lds_raw + k.lds_codes;
+  uint32_t* codes = lds_raw + k.lds_codes;
+  // persistent shapes: this wave's unit, the one after it (whose state words are on their way into the inbox) and,
+  // in the single-wave shape, the ticket in flight for the one after that
+  uint32_t* const ps_inbox = lds_raw + k.lds_ps_inbox;
+  // (an LDS-address-space pointer: as a generic one its volatile accesses become FLAT instructions, which count on vmcnt)
+  typedef __attribute__((address_space(3))) volatile uint32_t lds_volatile_u32;
+  lds_volatile_u32* const ps_ring = (lds_volatile_u32*)(lds_raw + k.lds_ps_ring);  // [0] produced, [1] consumed, [2] no more units, [4 + 2 slot] env0, count
+  const uint32_t ps_n = PS ? (uint32_t)((P.bpad + P.ps_unit - 1) / P.ps_unit) : 0u;
+  uint32_t ps_u = blockIdx.x, ps_un = blockIdx.x + gridDim.x, ps_tk = 0;
+  bool ps_need_wait = true;
+  // the state words of unit `u` (and its tape actions) into the inbox; lanes past the unit's environments stay out
+  auto ps_prefetch = [&](uint32_t u_any) {
+    const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u_any);  // (uniform by construction; now provably)
+    const int64_t e0 = (int64_t)u * P.ps_unit;
+    const int64_t left = P.bpad - e0;
+    const int cnt = left < P.ps_unit ? (int)left : P.ps_unit;
+    const uint32_t ib = lds_byte_address(ps_inbox);
+    if (lane < cnt) {
+#pragma unroll
+      for (int w = 0; w < W_SPOS + NS + 4; ++w)
+        if (w < k.NW) ps_dma_row(P.state + (int64_t)w * P.bpad + e0, 4u * lane, ib + (uint32_t)w * (4u * WAVE));
+    }
+    if (!a.hashed && lane < cnt && e0 + lane < P.batch) ps_dma_row(reinterpret_cast<const uint32_t*>(a.actions) + e0, 4u * lane, ib + (uint32_t)PS_IB_ACTION * (4u * WAVE));
+  };
+  if constexpr (PS != 0) {
+    if (threadIdx.x < WAVE) {
+      if (threadIdx.x == 0) { ps_ring[0] = 0; ps_ring[1] = 0; ps_ring[2] = 0; }
+      if (ps_u < ps_n) ps_prefetch(ps_u);  // (under the staging of the level below)
+    } else if (P.ps_prio) {
+      __builtin_amdgcn_s_setprio(3);  // (constant argument; the knob is on / off)
+    }
+  }
   if constexpr (CODES) {
     uint32_t* lbc = lds_raw + k.lds_bdcode;
     for (int i = threadIdx.x; i < QW; i += blockDim.x) lbc[i] = P.backdrop4[QW * (1 + k.n_bchars) + i];
@@ -623,16 +709,63 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
 
   // blockDim.x == 64: one wave does both jobs back to back (no overlap).
   const bool solo = blockDim.x == WAVE;
-  const bool single = solo || COOP;  // logic and render of the same group in the same round
-  for (int round = single ? 0 : -1;; ++round) {
+  const bool single = PS == 1 || (PS == 0 && (solo || COOP));  // logic and render of the same group in the same round
+  for (int round = (single || PS != 0) ? 0 : -1;; ++round) {
   // TFUSE: the rounds are the launch's steps of one and the same group
   const int64_t g_render = TFUSE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
   const int64_t g_logic = (single || TFUSE) ? g_render : g_render + gridDim.x;
   const int tstep = TFUSE ? round + 1 : 0;  // which of the launch's steps the logic wave is on
-  const bool have_render = round >= 0 && g_render < ngroups && (!TFUSE || round < a.n_steps);
-  const bool have_logic = g_logic < ngroups && (!TFUSE || tstep < a.n_steps);
-  if (!have_render && !have_logic) break;
-  {
+  bool have_render = round >= 0 && g_render < ngroups && (!TFUSE || round < a.n_steps);
+  bool have_logic = g_logic < ngroups && (!TFUSE || tstep < a.n_steps);
+  // the environments this round's logic phase steps / its render phase streams: a group of EPW, or (persistent
+  // shapes) a work unit
+  int64_t env0_logic = g_logic * EPW, env0_render = g_render * EPW;
+  int cnt_logic = EPW, cnt_render = EPW;
+  if constexpr (PS == 1) {
+    if (ps_u >= ps_n) break;
+    env0_logic = env0_render = (int64_t)ps_u * P.ps_unit;
+    const int64_t left = P.bpad - env0_logic;
+    cnt_logic = cnt_render = left < P.ps_unit ? (int)left : P.ps_unit;
+    have_logic = have_render = true;
+  } else if constexpr (PS == 2) {
+    const int slot = round % P.ps_nb;
+    codes = lds_raw + k.lds_ps_buf0 + slot * k.lds_ps_buf_words;
+    if (wave == 0) {
+      if (ps_u >= ps_n) {  // nothing left: tell the render wave, after everything this wave has published
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ps_ring[2] = 1u;
+        break;
+      }
+      env0_logic = (int64_t)ps_u * P.ps_unit;
+      const int64_t left = P.bpad - env0_logic;
+      cnt_logic = left < P.ps_unit ? (int)left : P.ps_unit;
+      have_logic = true;
+      have_render = false;
+      uint32_t spins = 0;  // the slot's previous unit must have been streamed
+      while ((uint32_t)round - ps_ring[1] >= (uint32_t)P.ps_nb && ++spins < PS_SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
+    } else {
+      uint32_t spins = 0;
+      bool more = true;
+      while (ps_ring[0] <= (uint32_t)round) {
+        if (ps_ring[2] != 0u && ps_ring[0] <= (uint32_t)round) { more = false; break; }
+        if (++spins >= PS_SPIN_LIMIT) { more = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!more) break;
+      asm volatile("" ::: "memory");
+      env0_render = (int64_t)ps_ring[4 + 2 * slot];
+      cnt_render = (int)ps_ring[5 + 2 * slot];
+      have_logic = false;
+      have_render = true;
+    }
+  } else {
+    if (!have_render && !have_logic) break;
+  }
+  if constexpr (PS != 0) {
+    if constexpr (PS == 1) codes = lds_raw + k.lds_ps_buf0;
+    l.skip = codes + k.lds_ps_buf_words - WAVE;  // (a buffer: the code table of the unit's environments, then 64 skip flags)
+    l.cmask = lds_raw + k.lds_ps_cmask;
+  } else {
     const int buf = single ? 0 : (wave == 0) ? ((round + 1) & 1) : (round & 1);
     l.flat = lds_raw + k.lds_flat + buf * k.lds_buf_words;
     l.sdesc = reinterpret_cast<uint2*>(lds_raw + k.lds_sdesc + buf * k.lds_buf_words);
@@ -647,9 +780,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   const bool quad = COOP && EPW <= 16;
   const int col = quad ? lane >> 2 : lane;   // the environment's column in the per-environment LDS arrays
   const int quad_j = quad ? lane & 3 : -1;
-  const int64_t env0 = g_logic * EPW;
+  const int64_t env0 = env0_logic;
   const int64_t env = env0 + col;
-  const bool live = col < EPW && env < P.batch;
+  const bool live = col < cnt_logic && env < P.batch;
   uint32_t* st = P.state + env;  // word w at st[w * bpad]
   const int64_t bp = P.bpad;
   uint32_t flags = 0;
@@ -661,15 +794,34 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // trip for the whole logic phase instead of two or three in a row
   uint32_t ld_frame = 0, ld_permit = 0, ld_mz = 0, ld_cs = 0, ld_stale = 0, ld_sflags = 0, ld_spos[NS] = {};
   int ld_action = PCX_ACTION_NONE;
-  if constexpr (COOP) {  // (asked for at the top of the kernel)
+  if constexpr (PS != 0) {
+    // the unit's state words are in the inbox (ps_prefetch): the first unit's, and whatever was asked for with
+    // fewer than 64 plane stores behind it, must be waited for; the pair's logic wave always waits (it has the time)
+    if (PS == 2 || ps_need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t* const ib = ps_inbox + lane;
+    pre_flags = ib[W_FLAGS * WAVE]; pre_frame = ib[W_FRAME * WAVE]; pre_permit = ib[W_PERMIT_FRAME * WAVE];
+    pre_mz = ib[W_MAZE * WAVE]; pre_cs = ib[W_CASH * WAVE]; pre_stale = ib[W_STALE * WAVE]; pre_sflags = ib[W_SFLAGS * WAVE];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) pre_spos[s] = ib[(W_SPOS + s) * WAVE];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre_cm[i] = i < k.CW ? ib[(W_SPOS + NS + i) * WAVE] : 0u;
+    pre_action = a.hashed ? PCX_ACTION_NONE : (int)ib[PS_IB_ACTION * WAVE];
+    if constexpr (PS == 2) {
+      // the inbox is free again: the words of the unit after this one travel while this one is stepped
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (ps_un < ps_n) ps_prefetch(ps_un);
+      if (P.ps_dynamic && ps_un < ps_n) ps_tk = ps_ticket_async(P.ps_ctr);
+    }
+  }
+  if constexpr (COOP || PS != 0) {  // (asked for at the top of the kernel / taken from the inbox)
     flags = pre_flags; ld_frame = pre_frame; ld_permit = pre_permit; ld_mz = pre_mz; ld_cs = pre_cs;
     ld_stale = pre_stale; ld_sflags = pre_sflags; ld_action = pre_action;
 #pragma unroll
     for (int s = 0; s < NS; ++s) ld_spos[s] = pre_spos[s];
   }
   if (live) {
-    if constexpr (!COOP) flags = st[W_FLAGS * bp];
-    if (!COOP && a.mode != 1) {
+    if constexpr (!COOP && PS == 0) flags = st[W_FLAGS * bp];
+    if (!COOP && PS == 0 && a.mode != 1) {
       ld_frame = st[W_FRAME * bp]; ld_permit = st[W_PERMIT_FRAME * bp];
       ld_mz = st[W_MAZE * bp]; ld_cs = st[W_CASH * bp];
       ld_stale = st[W_STALE * bp]; ld_sflags = st[W_SFLAGS * bp];
@@ -724,7 +876,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       sflags = ld_sflags;
 #pragma unroll
       for (int s = 0; s < NS; ++s) spos[s] = ld_spos[s];
-      for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + col] = (COOP && i < 4) ? (i == 0 ? pre_cm[0] : i == 1 ? pre_cm[1] : i == 2 ? pre_cm[2] : pre_cm[3]) : st[(W_SPOS + NS + i) * bp];
+      for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + col] = ((COOP || PS != 0) && i < 4) ? (i == 0 ? pre_cm[0] : i == 1 ? pre_cm[1] : i == 2 ? pre_cm[2] : pre_cm[3]) : st[(W_SPOS + NS + i) * bp];
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -1097,7 +1249,26 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     // (the other waves, while wave 0 steps the group: an empty slate for the curtains)
     for (int i = (int)threadIdx.x - WAVE; i < 2 * WAVE * FWP; i += (int)blockDim.x - WAVE) l.flat[i] = 0;
   }
-  if (single) __syncthreads();
+  if constexpr (PS == 0) {
+    if (single) __syncthreads();
+  } else if constexpr (PS == 1) {
+    asm volatile("" ::: "memory");  // one wave: its LDS instructions execute in order
+  } else {
+    if (wave == 0) {  // hand the buffer over: codes and skip flags first, then the counter the render wave polls
+      const int slot = round % P.ps_nb;
+      ps_ring[4 + 2 * slot] = (uint32_t)env0_logic;
+      ps_ring[5 + 2 * slot] = (uint32_t)cnt_logic;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ps_ring[0] = (uint32_t)round + 1u;
+      ps_u = ps_un;
+      if (P.ps_dynamic) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ps_un = ps_un < ps_n ? 2u * gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)ps_tk) : ps_n;
+      } else {
+        ps_un += gridDim.x;
+      }
+    }
+  }
   if constexpr (COOP) {
     if (have_render && !(a.debug & 4)) {
       const uint32_t* const fp = lds_raw + k.lds_fparams;
@@ -1179,7 +1350,13 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   const int NB = SL ? NBS : k.n_bchars;
   uint32_t sch4[NS], dch4[2];
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  const int64_t env0 = g_render * EPW;
+  const int64_t env0 = env0_render;
+  if constexpr (PS == 1) {
+    // the next unit's state words start travelling now, in front of this unit's plane stores, and the ticket for
+    // the unit after that is drawn: both have landed when the loop below is through (vmcnt is in order, 63 at most)
+    if (ps_un < ps_n) ps_prefetch(ps_un);
+    if (P.ps_dynamic && ps_un < ps_n) ps_tk = ps_ticket_async(P.ps_ctr);
+  }
   // Uniform per-plane base pointers: every store below is `scalar base +
   // 32-bit lane offset`, and the lane offset is the same for all nine planes.
   auto uniform_ptr = [](uint8_t* p) {  // pin a wave-uniform pointer to an SGPR pair
@@ -1283,7 +1460,8 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     }
   };
 
-  const bool any_skip = __ballot(l.skip[lane] != 0) != 0ull;  // same in both waves of a workgroup
+  // (persistent shapes: a unit of fewer than 64 environments ends at cnt_render; its skip flags beyond are unset)
+  const bool any_skip = __ballot(l.skip[lane] != 0 && (PS == 0 || lane < cnt_render)) != 0ull;  // same in both waves of a workgroup
   // The multi-wave instances are under SGPR pressure (the register allocator parks plane bases in
   // VGPR lanes and fetches them with v_readlane right in front of a store) and are latency-bound,
   // not store-issue-bound: their stores take the hazard-proof form (pcx_internal.h).
@@ -1296,7 +1474,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // inline asm the compiler cannot count, and without this it protects a
   // register of an older store with a vmcnt(0) *inside* the loop, which would
   // serialise every iteration behind all outstanding plane stores.
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+  if constexpr (PS == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+  // (persistent shapes: no wait here -- the write-back of the logic phase drains under the plane stores; the
+  // build checks that the compiler has put no vmcnt wait into the loop: tools/sgpr_hazard_scan.py --no-loop-vmcnt)
   // (e, q) = the environment and the board dword this lane composes; both and
   // every address derived from them advance incrementally -- no multiplies or
   // divisions in the loop (v_mul_lo/_hi are quarter rate).
@@ -1335,7 +1515,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   constexpr bool PREFETCH = CODES && INCR;
   uint32_t code_pf = 0;
   const bool planes_on = !(fc && fc->only);  // fused croppers, windows only: the full-board planes are not written
-  const int n_iter = COOP ? (EPW * QW + WAVE - 1) / WAVE : QW;  // 64 tasks per iteration
+  const int n_iter = COOP ? (EPW * QW + WAVE - 1) / WAVE : PS != 0 ? (cnt_render * QW + WAVE - 1) / WAVE : QW;  // 64 tasks per iteration
   // epilogue with more than 16 write streams per wave (pcx_stream.h fill_epilogue): the uint8 planes of the whole
   // group first, the float32 planes in a second sweep over the same codes
   constexpr bool TWO_PASS = EPI && CODES && INCR;
@@ -1389,7 +1569,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       if constexpr (EPI) { foff_now = foff; foff += bpd * WAVE; foff = wrap ? foff + f_skew : foff; }
       if constexpr (PREFETCH) {
         code_cur = code_pf;
-        code_pf = codes[it + 1 < QW ? eF + q : 0u];
+        code_pf = codes[it + 1 < n_iter ? eF + q : 0u];
       }
     } else {
       const uint32_t f = (uint32_t)it * WAVE + lane;
@@ -1403,6 +1583,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     // epilogue such a lane still takes part in the wave's exchange and only its stores are predicated)
     bool dead = false;
     if constexpr (COOP) dead = (int)e_now >= EPW;
+    if constexpr (PS != 0) dead = (int)e_now >= cnt_render;
     if (!dead && any_skip) dead = l.skip[e_now] != 0;
     if (dead && !hwc) continue;
     if constexpr (CODES) {
@@ -1478,7 +1659,20 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   }
   }  // passes
   };  // sweeps
-  if constexpr (!EPI) {
+  if constexpr (PS == 1) {
+    sweeps(std::integral_constant<int, 0>{});
+    // fewer than 64 plane stores behind the DMA and the ticket (units with environments left alone, ablation
+    // runs): wait for them; otherwise the next unit's logic phase starts at once
+    ps_need_wait = any_skip || a.debug != 0 || n_iter * (1 + SL) < 64 || !planes_on;
+    if (ps_need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ps_u = ps_un;
+    if (P.ps_dynamic) ps_un = ps_un < ps_n ? 2u * gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)ps_tk) : ps_n;
+    else ps_un += gridDim.x;
+  } else if constexpr (PS == 2) {
+    sweeps(std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the buffer has been read: the logic wave may fill it again
+    ps_ring[1] = (uint32_t)round + 1u;
+  } else if constexpr (!EPI) {
     sweeps(std::integral_constant<int, 0>{});
   } else {  // (uniform: one of the three runs)
     if (epi.hwc) sweeps(std::integral_constant<int, 1>{});
@@ -1502,8 +1696,19 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   }
   }
   }  // render wave
-  __syncthreads();  // swap buffers
+  if constexpr (PS == 0) __syncthreads();  // swap buffers
   }  // rounds
+  if constexpr (PS != 0) {
+    // the last workgroup out rewinds the work counter for the next launch (every ticket of this launch was drawn
+    // before its workgroup got here)
+    if (P.ps_dynamic && threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (atomicAdd(P.ps_ctr + 1, 1u) == gridDim.x - 1u) {
+        atomicExch(P.ps_ctr, 0u);
+        atomicExch(P.ps_ctr + 1, 0u);
+      }
+    }
+  }
 #undef FLAT
 }
 
@@ -1533,12 +1738,21 @@ class ScrollyMazeBackend : public Backend {
     return 4 + 4 * (int64_t)k_.NW + 4 * (int64_t)(k_.NW - k_.CW) + (int64_t)(1 + k_.L) * k_.cells + 15;
   }
   const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
+  int launch_shape() const override { return last_shape_; }
   // Does a single step of this batch run in the cooperative launch shape (launch(): few groups per CU)?
   bool coop_shape() const {
     const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
     int coop_below = 4;  // (as in launch(); with fused croppers a workgroup is always one group)
     if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
     return shipped_shape && bpad_ / WAVE < (int64_t)num_cus_ * coop_below;
+  }
+  // Which persistent launch shape a plain step of the shipped shape takes (0: one workgroup per group; kernel: PS)
+  int ps_shape(const StepArgs& a) const {
+    int shape = 0;
+    if (const char* e = getenv("PCX_SM_SHAPE")) shape = atoi(e);
+    if (shape < 0 || shape > 2) shape = 0;
+    if (a.mode != 0 || a.n_steps > 1 || a.debug != 0 || epi_.out || fused_.on || k_.CW > 4 || k_.NW > PS_IB_ACTION) shape = 0;
+    return shape;
   }
   int max_fused_steps() const override { return fused_ok_ && !epi_.out && !fused_.on ? 256 : 1; }  // the epilogue / fused croppers have no multi-step instance
   // include/pcx.h pcx_engine_fuse_croppers: the instances that render from curtain bit vectors + sprite
@@ -1587,6 +1801,8 @@ class ScrollyMazeBackend : public Backend {
   DevArray<uint32_t> coinbits_;
   DevArray<uint16_t> rowbase_;
   DevArray<int32_t> track_;
+  DevArray<uint32_t> ps_ctr_;
+  int last_shape_ = -1;
   std::vector<uint8_t> walls_pattern_, coin_pattern_;  // host copies for read_things
   std::vector<uint16_t> h_rowstart_;
   std::vector<uint8_t> h_coincol_;
@@ -1833,6 +2049,15 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     k.lds_cmask_c = o; o += (k.CW ? k.CW : 1) * WAVE;
     k.lds_skip_c = o; o += WAVE;
     k.lds_words_codes = o;
+    // persistent shapes: the same constants, then inbox, ring, coin masks and one / PS_NB owner-code buffers
+    o = k.lds_bdcode + k.QW;
+    k.lds_ps_inbox = o; o += PS_IB_ROWS * WAVE;
+    k.lds_ps_ring = o; o += 4 + 2 * PS_NB_MAX;
+    k.lds_ps_cmask = o; o += (k.CW ? k.CW : 1) * WAVE;
+    k.lds_ps_buf0 = o;
+    k.lds_ps_buf_words = WAVE * ((k.QW | 1) + 2) + WAVE;  // code table (CODE_PITCH dwords per environment) + skip flags
+    k.lds_ps_words1 = o + k.lds_ps_buf_words;
+    k.lds_ps_words2 = o + 2 * k.lds_ps_buf_words;  // (launch() sizes the buffers by the unit and the ring by PCX_SM_NB)
   }
 
   {
@@ -1858,6 +2083,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   if ((rc = rowbase_.upload(rs))) return rc;
   if ((rc = state_.alloc((size_t)k.NW * bpad_))) return rc;
   if ((rc = track_.alloc((size_t)k.NS * bpad_))) return rc;
+  if ((rc = ps_ctr_.alloc(64))) return rc;  // persistent shapes: {next ticket, workgroups done}
   return 0;
 }
 
@@ -1889,7 +2115,8 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   }
   if (const char* pad = getenv("PCX_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   if (lds > 64 * 1024) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds);
-  Ptrs P{walls_.ptr, backdrop4_.ptr, coinbits_.ptr, rowbase_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_};
+  Ptrs P{walls_.ptr, backdrop4_.ptr, coinbits_.ptr, rowbase_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_,
+         ps_ctr_.ptr, WAVE, 1, 2, 0};
   // Specialised instance for the shipped scrolly_maze shape (10x30 board,
   // 8 characters, 'abcP' sprites); anything else takes the generic instance.
   const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
@@ -1906,6 +2133,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
       return set_error(PCX_E_INVALID, "scrolly_maze backend: %d steps in one launch are not available here", a.n_steps);
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), dim3((unsigned)groups),
                        dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_, fused_.ptr());
+    last_shape_ = 11;
   } else if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
     int coop_waves = groups <= num_cus_ ? 8 : 4;  // at most one group per CU: split the render loop eight ways
     if (const char* e = getenv("PCX_COOP_WAVES")) coop_waves = atoi(e) == 4 ? 4 : 8;
@@ -1918,6 +2146,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     if (const char* e = getenv("PCX_COOP_EPW")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) epw = v; }
     ac.envs_per_group = epw;
     const unsigned coop_groups = (unsigned)(bpad_ / epw);
+    last_shape_ = 10;
     if (epi_.out) {
       size_t lds_e = (size_t)k_.lds_words * 4;
       const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_e, coop_waves);
@@ -1926,8 +2155,39 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     } else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3(coop_groups),
                          dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
+  } else if (shipped_shape && waves_per_wg == 1 && use_codes && ps_shape(a) != 0) {
+    // persistent shapes of the owner-code instance (see the kernel): workgroups stay and draw work units
+    const int shape = ps_shape(a);
+    int unit = WAVE, per_cu = shape == 2 ? 3 : 8, dynamic = 1;
+    if (const char* e = getenv("PCX_SM_UNIT")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) unit = v; }
+    if (const char* e = getenv("PCX_SM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
+    if (const char* e = getenv("PCX_SM_DYNAMIC")) dynamic = atoi(e) != 0;
+    int nb = 2;
+    if (const char* e = getenv("PCX_SM_NB")) { const int v = atoi(e); if (v >= 2 && v <= PS_NB_MAX) nb = v; }
+    if (const char* e = getenv("PCX_SM_PRIO")) P.ps_prio = atoi(e) != 0;
+    P.ps_unit = unit;
+    P.ps_dynamic = dynamic;
+    P.ps_nb = nb;
+    Consts kk = k_;  // buffers sized by the unit: units of 32 or 16 environments let more pairs (or deeper rings) share a CU
+    kk.lds_ps_buf_words = unit * ((k_.QW | 1) + 2) + WAVE;
+    kk.lds_ps_words1 = kk.lds_ps_buf0 + kk.lds_ps_buf_words;
+    kk.lds_ps_words2 = kk.lds_ps_buf0 + nb * kk.lds_ps_buf_words;
+    int64_t n_units = (bpad_ + unit - 1) / unit, resident = (int64_t)num_cus_ * per_cu;
+    if (const char* e = getenv("PCX_SM_GRID")) { const int v = atoi(e); if (v >= 1) resident = v; }  // (tests: few workgroups, many units each)
+    const dim3 pgrid((unsigned)(n_units < resident ? n_units : resident));
+    last_shape_ = shape;
+    size_t lds_p = (size_t)(shape == 2 ? kk.lds_ps_words2 : kk.lds_ps_words1) * 4;
+    size_t want = ((size_t)(160 * 1024) / (size_t)per_cu) & ~(size_t)255;  // no more workgroups per CU than asked for
+    if (want > 64 * 1024) want = 64 * 1024;
+    if (want > lds_p) lds_p = want;
+    if (lds_p > 64 * 1024) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds_p);
+    if (shape == 2)
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 2>), pgrid, dim3(2 * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
+    else
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 1>), pgrid, dim3(WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
   } else if (shipped_shape && waves_per_wg == 1 && use_codes) {
     // owner-code render path: its own, smaller LDS layout, padded to the same workgroups-per-CU target
+    last_shape_ = 0;
     size_t lds_c = (size_t)k_.lds_words_codes * 4;
     const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_c, 1);  // (channels-last epilogue: its exchange area)
     if (waves_per_cu > 0) {
@@ -1939,6 +2199,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true>), grid, block, lds_c, s, k_, P, a, out, epi_, fused_.ptr());
   } else if (shipped_shape) {
+    last_shape_ = waves_per_wg == 2 ? 3 : 0;
     if (epi_.out && waves_per_wg == 1) {
       size_t lds_e = (size_t)k_.lds_words * 4;
       const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_e, 1);
@@ -1949,6 +2210,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out, epi_, fused_.ptr());
   } else {
+    last_shape_ = 20;
     switch (k_.NS) {
 #define PCX_SM_CASE(n)                                                                                          \
   case n:                                                                                                       \

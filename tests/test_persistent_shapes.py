@@ -1,0 +1,137 @@
+"""GPU parity of the persistent launch shapes of pcx_scrolly_maze_step (round 4): workgroups that stay on their
+CU and draw work units, the next unit's state words prefetched into LDS by LDS-DMA (shape 1), logic / render wave
+pairs handing owner-code buffers over a ring (shape 2).  Every shape must produce exactly what the oracle does
+(reference: engine.py:583-639 via oracle/pcx_oracle.c), with units of 64 / 32 / 16 environments, dynamic tickets
+or static round-robin, few workgroups walking many units, ragged batches, environments left alone (no auto-reset)
+and externally supplied action tapes."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding
+from tests import helpers
+from tests.hip_adapter import HipAdapter
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = ('PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_GRID', 'PCX_SM_PER_CU', 'PCX_COOP_BELOW')
+
+
+class Knobs(object):
+  """Environment knobs of ScrollyMazeBackend::launch, restored on exit (they are read at every launch)."""
+
+  def __init__(self, **kw):
+    self.kw = kw
+
+  def __enter__(self):
+    self.saved = {k: os.environ.get(k) for k in KNOBS}
+    for k, v in self.kw.items():
+      os.environ[k] = str(v)
+    return self
+
+  def __exit__(self, *exc):
+    for k, v in self.saved.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v
+
+
+class OracleAdapter(binding.OracleEngine):
+
+  def read(self, name):
+    return np.array(getattr(self, name))
+
+
+def assert_same(hip, orc, where):
+  for name in ('planes', 'reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+    np.testing.assert_array_equal(hip.read(name), orc.read(name), err_msg='%s: %s' % (where, name))
+  np.testing.assert_array_equal(hip.sprites(), orc.sprites(), err_msg=where + ': sprites')
+  np.testing.assert_array_equal(hip.curtains(), orc.curtains(), err_msg=where + ': curtains')
+
+
+def shape_of(hip):
+  from pycolab_amd import _native as N
+  return int(N.lib().pcx_engine_launch_shape(hip.eng._native))
+
+
+@pytest.mark.parametrize('shape,unit,dynamic,grid', [
+    (1, 64, 1, 5), (1, 64, 0, 5), (1, 32, 1, 7), (1, 16, 1, 3), (1, 64, 1, 1), (1, 64, 1, 4096),
+    (2, 64, 1, 5), (2, 64, 0, 5), (2, 32, 1, 7), (2, 16, 1, 3), (2, 64, 1, 1), (2, 64, 1, 4096),
+])
+def test_persistent_shapes_match_oracle(shape, unit, dynamic, grid):
+  """A ragged batch (not a multiple of 64, 32 or 16) walked by `grid` workgroups; hashed actions, resets included."""
+  t = helpers.load_template('scrolly_maze_L0')
+  B, T = 2999, 160
+  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=shape, PCX_SM_UNIT=unit, PCX_SM_DYNAMIC=dynamic, PCX_SM_GRID=grid):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    assert_same(hip, orc, 'frame 0')
+    t0 = 0
+    while t0 < T:
+      n = 1 if t0 < 24 else 8
+      hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
+      assert shape_of(hip) == shape, 'the launch took shape %d, not %d' % (shape_of(hip), shape)
+      t0 += n
+      assert_same(hip, orc, 'shape %d unit %d after step %d' % (shape, unit, t0))
+    assert int(orc.read('frame').min()) < T  # episodes ended and restarted inside the run
+
+
+@pytest.mark.parametrize('shape', [1, 2])
+def test_persistent_shapes_tape_actions_and_environments_left_alone(shape):
+  """Action tapes from the host (illegal and quit actions among them), and steps without auto-reset: finished
+  environments are skipped (their units stream fewer planes: the wait-for-the-prefetch path of shape 1)."""
+  t = helpers.load_template('scrolly_maze_L1')
+  B, T = 1500, 120
+  rng = np.random.RandomState(7)
+  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=shape, PCX_SM_GRID=4):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    for step in range(T):
+      a = rng.randint(0, 5, size=B).astype(np.int32)
+      r = rng.rand(B)
+      a[r < 0.04] = -1
+      a[(r >= 0.04) & (r < 0.06)] = 5
+      a[(r >= 0.06) & (r < 0.08)] = rng.randint(6, 40)
+      auto = step % 3 != 0
+      hip.step(a, auto_reset=auto); orc.step(a, auto_reset=auto)
+      assert shape_of(hip) == shape
+      assert_same(hip, orc, 'shape %d step %d' % (shape, step))
+
+
+@pytest.mark.parametrize('shape,unit', [(1, 64), (2, 64), (2, 32)])
+def test_persistent_shapes_at_config_5_shard_size(shape, unit):
+  """131,072 environments (BASELINE config 5's per-GPU shard) at the default residency: the first and the last
+  2,048 environments against the oracle, layer == (board == c) over the whole batch, and everything equal to what
+  the one-workgroup-per-group shape writes for the same tape."""
+  import torch
+  t = helpers.load_template('scrolly_maze_L0')
+  B, T, K = 131072, 40, 2048
+  with Knobs(PCX_SM_SHAPE=shape, PCX_SM_UNIT=unit):
+    hip = HipAdapter(t, B)
+    hip.reset()
+    hip.step_hashed(0xC0FFEE, 0, T)
+    assert shape_of(hip) == shape
+    planes = hip.eng.planes_view()
+  with Knobs(PCX_SM_SHAPE=0):
+    ref = HipAdapter(t, B)
+    ref.reset()
+    ref.step_hashed(0xC0FFEE, 0, T)
+    assert shape_of(ref) == 0
+  assert torch.equal(planes, ref.eng.planes_view())
+  for name in ('reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+    assert torch.equal(hip.eng.buffers[name].tensor, ref.eng.buffers[name].tensor), name
+  head, tail = OracleAdapter(t, K), OracleAdapter(t, K)
+  head.reset(); tail.reset()
+  head.step_hashed(0xC0FFEE, 0, T); tail.step_hashed(0xC0FFEE, 0, T, env_offset=B - K)
+  np.testing.assert_array_equal(planes[:K].cpu().numpy(), head.read('planes'))
+  np.testing.assert_array_equal(planes[B - K:].cpu().numpy(), tail.read('planes'))
+  for name in ('reward', 'reward_set', 'discount', 'done', 'frame'):
+    got = hip.eng.buffers[name].tensor
+    np.testing.assert_array_equal(got[:K].cpu().numpy(), head.read(name))
+    np.testing.assert_array_equal(got[B - K:].cpu().numpy(), tail.read(name))
+  chars = torch.tensor(list(t.chars), dtype=torch.uint8, device=planes.device)
+  want = (planes[:, :1] == chars.view(1, -1, 1, 1)).to(torch.uint8)
+  assert torch.equal(planes[:, 1:], want)
+  assert not hip.eng.buffers['error'].tensor.any()

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Same-box, same-process A/B of the launch shapes of pcx_scrolly_maze_step (round 4).
+
+One engine per batch size; the launch shape is chosen by environment knobs that ScrollyMazeBackend::launch
+reads at every launch, so the variants alternate on the same state, the same tape and the same box:
+  python tools/ps_sweep.py --batches 131072,262144,1048576 --steps 100 --repeats 3 --out gpurun_out/ps_sweep.json
+Prints, per batch and variant, the kernel ms per step (HIP events on the launch stream; min / median over the
+repeats) and the fraction of 8 TB/s its algorithmic bytes come to."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+KNOBS = ('PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_PER_CU', 'PCX_WAVES_PER_CU', 'PCX_WAVES_PER_WG',
+         'PCX_WGS_PER_CU', 'PCX_SM_CODES', 'PCX_SM_PRIO', 'PCX_SM_NB', 'PCX_SM_GRID')
+
+VARIANTS = {
+    'head':        {},
+    'head_w7':     {'PCX_WAVES_PER_CU': 7},
+    'A':           {'PCX_SM_SHAPE': 1},
+    'A_static':    {'PCX_SM_SHAPE': 1, 'PCX_SM_DYNAMIC': 0},
+    'A_cu6':       {'PCX_SM_SHAPE': 1, 'PCX_SM_PER_CU': 6},
+    'A_cu7':       {'PCX_SM_SHAPE': 1, 'PCX_SM_PER_CU': 7},
+    'A_cu10':      {'PCX_SM_SHAPE': 1, 'PCX_SM_PER_CU': 10},
+    'A_u32':       {'PCX_SM_SHAPE': 1, 'PCX_SM_UNIT': 32},
+    'B':           {'PCX_SM_SHAPE': 2},
+    'B_cu2':       {'PCX_SM_SHAPE': 2, 'PCX_SM_PER_CU': 2},
+    'B_static':    {'PCX_SM_SHAPE': 2, 'PCX_SM_DYNAMIC': 0},
+    'B_prio':      {'PCX_SM_SHAPE': 2, 'PCX_SM_PRIO': 1},
+    'B_u32':       {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32},
+    'B_u32_cu4':   {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32, 'PCX_SM_PER_CU': 4},
+    'B_u32_cu5':   {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32, 'PCX_SM_PER_CU': 5},
+    'B_u32_nb4':   {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32, 'PCX_SM_NB': 4},
+    'B_u32_nb3_cu4': {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32, 'PCX_SM_NB': 3, 'PCX_SM_PER_CU': 4},
+    'B_u16_cu6':   {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 16, 'PCX_SM_PER_CU': 6},
+}
+
+
+def set_knobs(kw):
+  for k in KNOBS:
+    os.environ.pop(k, None)
+  for k, v in kw.items():
+    os.environ[k] = str(v)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--batches', default='131072,262144,1048576')
+  ap.add_argument('--variants', default=','.join(VARIANTS))
+  ap.add_argument('--extra', default='', help='more variants: name:K=V+K=V,name2:...')
+  ap.add_argument('--steps', type=int, default=100)
+  ap.add_argument('--warmup', type=int, default=10)
+  ap.add_argument('--repeats', type=int, default=3)
+  ap.add_argument('--level', type=int, default=0)
+  ap.add_argument('--out', default=None)
+  args = ap.parse_args()
+  import torch
+  from pycolab_amd import _native as N
+  from pycolab_amd.compiler import GameTemplate
+  from pycolab_amd.engine import Engine
+  variants = {k: VARIANTS[k] for k in args.variants.split(',') if k}
+  for spec in [x for x in args.extra.split(',') if x]:
+    name, kv = spec.split(':')
+    variants[name] = dict(p.split('=') for p in kv.split('+'))
+  template = GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', 'scrolly_maze_L%d.npz' % args.level))
+  results = []
+  for B in [int(x) for x in args.batches.split(',')]:
+    set_knobs({})
+    eng = Engine.from_template(template, batch=B, device=0, auto_reset=True, seed=0x5EED)
+    eng.its_showtime()
+    g = torch.Generator(device='cuda')
+    g.manual_seed(0x5EED)
+    K, W = args.steps, args.warmup
+    tape = torch.randint(0, template.n_actions, (W + K, B), dtype=torch.int32, device='cuda', generator=g)
+    bps = int(N.lib().pcx_engine_bytes_per_step(eng._native))
+    times = {k: [] for k in variants}
+    shapes = {}
+    for rep in range(args.repeats):
+      for name, kw in variants.items():
+        set_knobs(kw)
+        for t in range(W):
+          eng.step(tape[t])
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for t in range(W, W + K):
+          eng.step(tape[t])
+        ev1.record()
+        torch.cuda.synchronize()
+        times[name].append(ev0.elapsed_time(ev1) / K)
+        shapes[name] = int(N.lib().pcx_engine_launch_shape(eng._native))
+    eng.check_errors()
+    for name in variants:
+      xs = sorted(times[name])
+      med = xs[len(xs) // 2]
+      rec = {'batch': B, 'variant': name, 'knobs': variants[name], 'shape': shapes[name], 'ms_min': xs[0], 'ms_median': med,
+             'ms_all': times[name], 'frac_of_8TBs_at_median': bps * B / (med * 1e-3) / 8e12}
+      results.append(rec)
+      print('%8d  %-12s shape %2d  min %.4f  median %.4f ms   %.3f of 8 TB/s' % (B, name, shapes[name], xs[0], med,
+                                                                                 rec['frac_of_8TBs_at_median']), flush=True)
+    eng.close()
+    del tape
+  set_knobs({})
+  if args.out:
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    json.dump({'steps': args.steps, 'repeats': args.repeats, 'results': results}, open(args.out, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+  main()
