@@ -334,6 +334,11 @@ const char* pcx_engine_kernel_name(const pcx_engine* e);
  * prefetched into LDS, 2 persistent logic/render wave pairs, 3 two-wave workgroups (round 1), 10 cooperative
  * (several waves per group), 11 several steps per launch, 20 shape-generic instance; -1: the backend does not say. */
 int32_t pcx_engine_launch_shape(const pcx_engine* e);
+/* Profiling aid (no reference counterpart): the phase timers the last launch left when the backend was asked to keep
+ * them (pcx_scrolly_maze_step's persistent shapes under PCX_SM_PROF=1: 16 words per workgroup, 10 ns ticks; layout in
+ * pcx_scrolly_maze.hip Ptrs::ps_prof).  out_host == NULL with words == -1 clears them.  Synchronous.  PCX_E_UNSUPPORTED from
+ * backends that keep none. */
+int pcx_engine_debug_counters(pcx_engine* e, uint32_t* out_host, int64_t words);
 
 const char* pcx_last_error(void);
 uint32_t pcx_abi_version(void);

@@ -26,10 +26,9 @@ static uint32_t action_hash_host(uint64_t seed, uint64_t env, uint64_t t) {
   return (uint32_t)(x >> 32);
 }
 
-static int debug_flags() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PCX_DEBUG"); v = e ? atoi(e) : 0; }
-  return v;
+static int debug_flags() {  // (read at every launch: tools/ps_sweep.py alternates ablations on one engine)
+  const char* e = getenv("PCX_DEBUG");
+  return e ? atoi(e) : 0;
 }
 
 static void free_own_outputs(pcx_engine* e) {
@@ -99,6 +98,9 @@ int Backend::set_epilogue(const pcx_epilogue_desc* d) {
 int Backend::set_fused_croppers(const crop::FusedCrops* fc) {
   if (!fc || fc->n <= 0) return 0;
   return set_error(PCX_E_UNSUPPORTED, "%s cannot run croppers itself", kernel_name());
+}
+int Backend::read_debug_counters(uint32_t*, int64_t) {
+  return set_error(PCX_E_UNSUPPORTED, "%s keeps no debug counters", kernel_name());
 }
 
 ErrorPoll::~ErrorPoll() {
@@ -480,6 +482,11 @@ int32_t pcx_engine_plane_pitch(const pcx_engine* e) { return e ? e->backend->pla
 int64_t pcx_engine_bytes_per_step(const pcx_engine* e) { return e ? e->backend->bytes_per_step() : 0; }
 const char* pcx_engine_kernel_name(const pcx_engine* e) { return e ? e->backend->kernel_name() : ""; }
 int32_t pcx_engine_launch_shape(const pcx_engine* e) { return e ? e->backend->launch_shape() : -1; }
+int pcx_engine_debug_counters(pcx_engine* e, uint32_t* out_host, int64_t words) {
+  if (!e || (!out_host && words != -1) || words < -1) return set_error(PCX_E_INVALID, "pcx_engine_debug_counters: bad arguments");
+  PCX_HIP(hipSetDevice(e->device));
+  return e->backend->read_debug_counters(out_host, words);
+}
 
 int pcx_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes) {
   PCX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));

@@ -133,6 +133,7 @@ class Backend {
   virtual int64_t bytes_per_step() const = 0;
   virtual const char* kernel_name() const = 0;
   virtual int launch_shape() const { return -1; }  // include/pcx.h pcx_engine_launch_shape
+  virtual int read_debug_counters(uint32_t* out_host, int64_t words);  // include/pcx.h pcx_engine_debug_counters
   // Sprite state for croppers: device int32 [n_sprites][batch] packed
   // (row | col << 8 | visible << 16), refreshed by every launch.
   virtual const int32_t* sprite_track() const { return nullptr; }

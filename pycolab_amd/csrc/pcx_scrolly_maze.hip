@@ -96,6 +96,7 @@ struct Consts {
   // persistent shapes of the CODES instance (PS): the state inbox (LDS-DMA target), the hand-over ring of the
   // logic/render wave pair, and the owner-code buffers (code table + skip flags each)
   int32_t lds_ps_inbox, lds_ps_ring, lds_ps_cmask, lds_ps_buf0, lds_ps_buf_words, lds_ps_words1, lds_ps_words2;
+  int32_t lds_ps_wave_words;  // PS == 3: from one wave's {inbox, coin masks, buffer} to the next wave's
   uint32_t chars_lo, chars_hi;  // characters 0..3 / 4..7 as bytes
   int32_t sprite_by_z[MAX_NS];  // sprites back to front
 };
@@ -116,6 +117,11 @@ struct Ptrs {
   int32_t ps_unit, ps_dynamic;
   int32_t ps_nb;    // owner-code buffers of a logic/render pair (the logic wave runs up to ps_nb - 1 units ahead)
   int32_t ps_prio;  // s_setprio of the pair's render wave (0: leave alone)
+  int32_t ps_lock;  // PS == 3: at most this many waves of a workgroup in their render loop at a time (0: no limit)
+  // phase timers (tools/ps_sweep.py --prof): 16 words per workgroup, 10 ns ticks of s_memrealtime summed over its units --
+  // logic wave: [0] units, [1] wait for the inbox, [2] wait for a free buffer, [3] stepping, [4] wait for the ticket,
+  // [5] lifetime; render wave: [8] units, [9] wait for a full buffer, [10] streaming, [11] lifetime (shape 1: [3], [10] and [5])
+  uint32_t* ps_prof;
 };
 
 struct Walker {
@@ -537,6 +543,11 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
 //            front of them has landed -- no wait at all.
 //   PS == 2: two waves per workgroup: wave 0 only steps (and runs ahead by one owner-code buffer), wave 1
 //            only streams; they hand buffers over through a two-slot ring of LDS counters, no barrier.
+//   PS == 3: several waves per workgroup, each one a PS == 1 worker with its own inbox, coin masks and owner-code
+//            buffer (they share the staged level), and ONE of them streams at a time (an LDS mutex around the render
+//            loop): a CU's write path is saturated by one or two streaming waves and loses efficiency with every further
+//            concurrent stream (tools/experiments/store_width.hip, profiles/r04_tuning.md), while a unit's logic phase
+//            is latency-bound and wants many waves in flight -- the mutex decouples the two counts.
 constexpr int PS_IB_ACTION = 15;  // inbox rows: the state words (at most 15), then the tape action
 constexpr int PS_IB_ROWS = 16;
 constexpr int PS_NB_MAX = 6;      // owner-code buffers of a logic/render pair, at most (ring words in LDS)
@@ -554,17 +565,20 @@ __device__ __forceinline__ void ps_dma_row(const uint32_t* base, uint32_t voff, 
       : "v"(voff), "s"(base), "s"(lds_addr)
       : "memory");
 }
-// The next ticket of the work counter, fetched by lane 0 alone, NOT waited for: the value is in lane 0 of the result
-// once 64 more VMEM instructions have been issued (or after s_waitcnt vmcnt(0)).
-__device__ __forceinline__ uint32_t ps_ticket_async(uint32_t* ctr) {
-  uint32_t tk, one = 1u, zero = 0u;
-  uint64_t save, own;
-  asm volatile(
-      "s_mov_b64 %2, %5\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %3, %4, %2 sc0\n\ts_mov_b64 exec, %1"
-      : "=&v"(tk), "=&s"(save), "=&s"(own)
-      : "v"(zero), "v"(one), "s"(ctr)
-      : "memory");
-  return tk;
+// The next ticket of the work counter: a SCALAR atomic (s_atomic_add; gfx950 has them, coherent across the XCDs:
+// tools/experiments/satomic_probe.hip).  It travels through the scalar cache path, not behind the CU's queue of plane
+// stores, and is waited for on lgkmcnt -- about a microsecond -- so a worker knows its next unit just before it
+// needs it and reserves nothing further ahead (what a worker holds in reserve when the tickets run out is the tail).
+__device__ __forceinline__ uint32_t ps_ticket(uint32_t* ctr_any) {
+  // (uniform by construction; readfirstlane makes it provably so, and the SALU copy inside the statement keeps the scalar
+  // memory instruction from reading an SGPR pair a VALU instruction has just written)
+  const uint64_t v = reinterpret_cast<uint64_t>(ctr_any);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  uint32_t* const ctr = reinterpret_cast<uint32_t*>(((uint64_t)hi << 32) | lo);
+  uint32_t t = 1u;
+  uint64_t own;
+  asm volatile("s_mov_b64 %1, %2\n\ts_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t), "=&s"(own) : "s"(ctr) : "memory");
+  return t;
 }
 __device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)p;
@@ -584,13 +598,14 @@ __device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) {
 // PS: persistent launch shape of the owner-code instance (0: none; 1, 2: above).
 template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false, bool EPI = false,
           bool CODES = false, int PS = 0>
-__global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
+__global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                   const crop::FusedCrops* fc_arg) {
   // Fused croppers (include/pcx.h pcx_engine_fuse_croppers): the instances that keep the frame as curtain
   // bit vectors + sprite descriptors (pcx_stream.h's contract) and render a group in the round they step it
   constexpr bool FUSABLE = !TFUSE && !CODES && !UNOCC && !EPI;
-  static_assert(PS == 0 || (CODES && !COOP && !TFUSE && !EPI && !UNOCC && SR != 0), "persistent shapes: owner-code instance only");
+  static_assert(PS == 0 || (!COOP && !TFUSE && !EPI && !UNOCC && SR != 0 && (CODES || PS == 1 || PS == 3)),
+                "persistent shapes: the static-shape instances (pairs: owner codes only)");
   const crop::FusedCrops* const fc = FUSABLE ? fc_arg : nullptr;
   // A workgroup is two wavefronts with different jobs, looping over groups of
   // 64 environments: wave 0 (logic) steps group i+1 and leaves its render
@@ -666,26 +681,48 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     for (int i = threadIdx.x; i < k.PR * (k.WPR - 1); i += blockDim.x) lr[i] = P.coin_bits[i];
     for (int i = threadIdx.x; i < (k.PR + 2) / 2; i += blockDim.x) lc[i] = rb[i];
   }
-  constexpr int CODE_PITCH = SR ? ((SR * SC / 4) | 1) + 2 : 1;  // dwords per environment, odd: logic (same q, 64
+  // NIB (the persistent shapes): owner codes as NIBBLES, two board dwords per LDS dword -- byte b of dword m holds the
+  // code of cell 8 m + b in its low and of cell 8 m + 4 + b in its high nibble, so the render loop gets the four byte
+  // codes of board dword q = 2 m (+ 1) with one shift and one mask.  Half the LDS per worker: more workers per CU.
+  constexpr bool NIB = CODES && PS != 0;
+  constexpr int CODE_PITCH = !SR ? 1 : NIB ? (((SR * SC / 4 + 1) / 2) | 1) : ((SR * SC / 4) | 1) + 2;  // dwords per environment, odd: logic (same q, 64
                                                                // environments) and render (same environment,
                                                                // consecutive q) both spread over the banks
   uint32_t* codes = lds_raw + k.lds_codes;
   // persistent shapes: this wave's unit, the one after it (whose state words are on their way into the inbox) and,
   // in the single-wave shape, the ticket in flight for the one after that
-  uint32_t* const ps_inbox = lds_raw + k.lds_ps_inbox;
+  const int ps_mine = PS == 3 ? __builtin_amdgcn_readfirstlane(wave) * k.lds_ps_wave_words : 0;  // this wave's own LDS region
+  uint32_t* const ps_inbox = lds_raw + k.lds_ps_inbox + ps_mine;
+  // workers: the waves that draw units (PS == 3: every wave; else one per workgroup)
+  const uint32_t ps_wid = PS == 3 ? blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave : blockIdx.x;
+  const uint32_t ps_nwk = PS == 3 ? gridDim.x * (blockDim.x >> 6) : gridDim.x;
   // (an LDS-address-space pointer: as a generic one its volatile accesses become FLAT instructions, which count on vmcnt)
   typedef __attribute__((address_space(3))) volatile uint32_t lds_volatile_u32;
   lds_volatile_u32* const ps_ring = (lds_volatile_u32*)(lds_raw + k.lds_ps_ring);  // [0] produced, [1] consumed, [2] no more units, [4 + 2 slot] env0, count
   const uint32_t ps_n = PS ? (uint32_t)((P.bpad + P.ps_unit - 1) / P.ps_unit) : 0u;
-  uint32_t ps_u = blockIdx.x, ps_un = blockIdx.x + gridDim.x, ps_tk = 0;
+  // The work counter is sharded (one word per shard, 64 bytes apart): shard x = blockIdx.x % S owns the units
+  // congruent to x mod S, its workgroups draw from its own word.  With S = 8 a shard is one XCD as the hardware places
+  // workgroups today (block b on XCD b % 8: MI355X_MICROARCH.md) -- an eighth of the contention on each word and the
+  // atomic served by the XCD's own L2 slice; nothing depends on the placement but the speed.
+  const uint32_t ps_shards = gridDim.x < 8u ? gridDim.x : 8u;
+  const uint32_t ps_x = blockIdx.x % ps_shards;
+  const uint32_t ps_wpw = PS == 3 ? (blockDim.x >> 6) : 1u;                                  // workers per workgroup
+  const uint32_t ps_shard_nwk = ((gridDim.x - ps_x + ps_shards - 1u) / ps_shards) * ps_wpw;  // workers of this shard
+  const uint32_t ps_local = (blockIdx.x / ps_shards) * ps_wpw + (PS == 3 ? (uint32_t)wave : 0u);
+  uint32_t* const ps_ctr_mine = P.ps_ctr + 16u * ps_x;
+  uint32_t ps_u = P.ps_dynamic ? ps_x + ps_shards * ps_local : ps_wid, ps_un = 0;
   bool ps_need_wait = true;
+  const bool ps_prof = PS != 0 && P.ps_prof != nullptr;
+  uint32_t pt_units = 0, pt_a = 0, pt_b = 0, pt_c = 0, pt_d = 0, pt_mark = 0;
+  auto ps_now = [&]() { return ps_prof ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u; };
+  const uint32_t pt_start = ps_now();
   // the state words of unit `u` (and its tape actions) into the inbox; lanes past the unit's environments stay out
   auto ps_prefetch = [&](uint32_t u_any) {
     const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u_any);  // (uniform by construction; now provably)
     const int64_t e0 = (int64_t)u * P.ps_unit;
     const int64_t left = P.bpad - e0;
     const int cnt = left < P.ps_unit ? (int)left : P.ps_unit;
-    const uint32_t ib = lds_byte_address(ps_inbox);
+    const uint32_t ib = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_address(ps_inbox));
     if (lane < cnt) {
 #pragma unroll
       for (int w = 0; w < W_SPOS + NS + 4; ++w)
@@ -694,8 +731,8 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     if (!a.hashed && lane < cnt && e0 + lane < P.batch) ps_dma_row(reinterpret_cast<const uint32_t*>(a.actions) + e0, 4u * lane, ib + (uint32_t)PS_IB_ACTION * (4u * WAVE));
   };
   if constexpr (PS != 0) {
-    if (threadIdx.x < WAVE) {
-      if (threadIdx.x == 0) { ps_ring[0] = 0; ps_ring[1] = 0; ps_ring[2] = 0; }
+    if (PS == 3 || threadIdx.x < WAVE) {
+      if (threadIdx.x == 0) { ps_ring[0] = 0; ps_ring[1] = 0; ps_ring[2] = 0; ps_ring[3] = 0; }
       if (ps_u < ps_n) ps_prefetch(ps_u);  // (under the staging of the level below)
     } else if (P.ps_prio) {
       __builtin_amdgcn_s_setprio(3);  // (constant argument; the knob is on / off)
@@ -709,7 +746,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
 
   // blockDim.x == 64: one wave does both jobs back to back (no overlap).
   const bool solo = blockDim.x == WAVE;
-  const bool single = PS == 1 || (PS == 0 && (solo || COOP));  // logic and render of the same group in the same round
+  const bool single = PS == 1 || PS == 3 || (PS == 0 && (solo || COOP));  // logic and render of the same group in the same round
   for (int round = (single || PS != 0) ? 0 : -1;; ++round) {
   // TFUSE: the rounds are the launch's steps of one and the same group
   const int64_t g_render = TFUSE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
@@ -721,12 +758,13 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   // shapes) a work unit
   int64_t env0_logic = g_logic * EPW, env0_render = g_render * EPW;
   int cnt_logic = EPW, cnt_render = EPW;
-  if constexpr (PS == 1) {
+  if constexpr (PS == 1 || PS == 3) {
     if (ps_u >= ps_n) break;
     env0_logic = env0_render = (int64_t)ps_u * P.ps_unit;
     const int64_t left = P.bpad - env0_logic;
     cnt_logic = cnt_render = left < P.ps_unit ? (int)left : P.ps_unit;
     have_logic = have_render = true;
+    pt_mark = ps_now();
   } else if constexpr (PS == 2) {
     const int slot = round % P.ps_nb;
     codes = lds_raw + k.lds_ps_buf0 + slot * k.lds_ps_buf_words;
@@ -742,10 +780,13 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       have_logic = true;
       have_render = false;
       uint32_t spins = 0;  // the slot's previous unit must have been streamed
+      pt_mark = ps_now();
       while ((uint32_t)round - ps_ring[1] >= (uint32_t)P.ps_nb && ++spins < PS_SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
+      if (ps_prof) { const uint32_t t = ps_now(); pt_b += t - pt_mark; pt_mark = t; }
     } else {
       uint32_t spins = 0;
       bool more = true;
+      pt_mark = ps_now();
       while (ps_ring[0] <= (uint32_t)round) {
         if (ps_ring[2] != 0u && ps_ring[0] <= (uint32_t)round) { more = false; break; }
         if (++spins >= PS_SPIN_LIMIT) { more = false; break; }
@@ -753,6 +794,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       }
       if (!more) break;
       asm volatile("" ::: "memory");
+      if (ps_prof) { const uint32_t t = ps_now(); pt_a += t - pt_mark; pt_mark = t; }
       env0_render = (int64_t)ps_ring[4 + 2 * slot];
       cnt_render = (int)ps_ring[5 + 2 * slot];
       have_logic = false;
@@ -762,16 +804,22 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     if (!have_render && !have_logic) break;
   }
   if constexpr (PS != 0) {
-    if constexpr (PS == 1) codes = lds_raw + k.lds_ps_buf0;
-    l.skip = codes + k.lds_ps_buf_words - WAVE;  // (a buffer: the code table of the unit's environments, then 64 skip flags)
-    l.cmask = lds_raw + k.lds_ps_cmask;
+    if constexpr (PS == 1 || PS == 3) codes = lds_raw + k.lds_ps_buf0 + ps_mine;
+    // a buffer: the code table of the unit's environments -- or (mask path) both curtains as flat bit vectors and the
+    // sprite descriptors of 64 environments -- then 64 skip flags
+    if constexpr (!CODES) {
+      l.flat = codes;
+      l.sdesc = reinterpret_cast<uint2*>(codes + 2 * WAVE * FWP);
+    }
+    l.skip = codes + k.lds_ps_buf_words - WAVE;
+    l.cmask = lds_raw + k.lds_ps_cmask + ps_mine;
   } else {
     const int buf = single ? 0 : (wave == 0) ? ((round + 1) & 1) : (round & 1);
     l.flat = lds_raw + k.lds_flat + buf * k.lds_buf_words;
     l.sdesc = reinterpret_cast<uint2*>(lds_raw + k.lds_sdesc + buf * k.lds_buf_words);
     l.skip = CODES ? lds_raw + k.lds_skip_c : lds_raw + k.lds_skip + buf * k.lds_buf_words;
   }
-  if (wave == 0) {
+  if (wave == 0 || PS == 3) {
   if (have_logic) {
   // ---- phase A (logic wave): lane == environment ---------------------------
   // (cooperative shape with 16 environments per workgroup: FOUR lanes per environment.  All four step it
@@ -798,6 +846,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     // the unit's state words are in the inbox (ps_prefetch): the first unit's, and whatever was asked for with
     // fewer than 64 plane stores behind it, must be waited for; the pair's logic wave always waits (it has the time)
     if (PS == 2 || ps_need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ps_prof) { const uint32_t t = ps_now(); pt_a += t - pt_mark; pt_mark = t; }
     const uint32_t* const ib = ps_inbox + lane;
     pre_flags = ib[W_FLAGS * WAVE]; pre_frame = ib[W_FRAME * WAVE]; pre_permit = ib[W_PERMIT_FRAME * WAVE];
     pre_mz = ib[W_MAZE * WAVE]; pre_cs = ib[W_CASH * WAVE]; pre_stale = ib[W_STALE * WAVE]; pre_sflags = ib[W_SFLAGS * WAVE];
@@ -809,8 +858,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     if constexpr (PS == 2) {
       // the inbox is free again: the words of the unit after this one travel while this one is stepped
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // every unit after the worker's first is drawn from the work counter: unit = workers + ticket
+      ps_un = P.ps_dynamic ? ps_x + ps_shards * (ps_shard_nwk + ps_ticket(ps_ctr_mine)) : ps_u + ps_nwk;
       if (ps_un < ps_n) ps_prefetch(ps_un);
-      if (P.ps_dynamic && ps_un < ps_n) ps_tk = ps_ticket_async(P.ps_ctr);
     }
   }
   if constexpr (COOP || PS != 0) {  // (asked for at the top of the kernel / taken from the inbox)
@@ -1114,6 +1164,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
         // (one in front of the other where both are set): four cells per dword
         const uint32_t* const bdcode = lds_raw + k.lds_bdcode;
         const uint32_t wcode4 = (uint32_t)k.lay_drape[0] * 0x01010101u, ccode4 = (uint32_t)k.lay_drape[1] * 0x01010101u;
+        uint32_t code_even = 0;  // (NIB: the codes of board dword 2 m wait for those of 2 m + 1)
 #pragma unroll
         for (int q = 0; q < SR * SC / 4; ++q) {
           const int i = (4 * q) >> 5, sh = (4 * q) & 31;
@@ -1126,7 +1177,13 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
           uint32_t code = bdcode[q];
           code = (code & ~mw) | (wcode4 & mw);
           code = (code & ~mc) | (ccode4 & mc);
-          codes[col * CODE_PITCH + q] = code;
+          if constexpr (NIB) {
+            if (q & 1) codes[col * CODE_PITCH + (q >> 1)] = code_even | (code << 4);
+            else if (q == SR * SC / 4 - 1) codes[col * CODE_PITCH + (q >> 1)] = code;
+            else code_even = code;
+          } else {
+            codes[col * CODE_PITCH + q] = code;
+          }
         }
       } else if constexpr (SR != 0) {
 #pragma unroll
@@ -1163,10 +1220,20 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
           if (k.sprite_by_z[i] != s) continue;
           const int cell = paint_cell(k, w[s]);
           if (cell < 0) continue;
-          const uint32_t top = mine[cell], ab = k.above[s];
-          const bool covered = (((ab >> NS) & 1) && top == (uint32_t)k.lay_drape[0]) ||
-                               (((ab >> (NS + 1)) & 1) && top == (uint32_t)k.lay_drape[1]);
-          if (!covered) mine[cell] = (uint8_t)k.lay_sprite[s];
+          const uint32_t ab = k.above[s];
+          if constexpr (NIB) {  // the cell's nibble: dword cell / 8, byte cell % 4, high half for cells 4..7 of the eight
+            uint32_t* const pw = codes + col * CODE_PITCH + (cell >> 3);
+            const int sh = 8 * (cell & 3) + ((cell & 4) ? 4 : 0);
+            const uint32_t word = *pw, top = (word >> sh) & 0xFu;
+            const bool covered = (((ab >> NS) & 1) && top == (uint32_t)k.lay_drape[0]) ||
+                                 (((ab >> (NS + 1)) & 1) && top == (uint32_t)k.lay_drape[1]);
+            if (!covered) *pw = (word & ~(0xFu << sh)) | ((uint32_t)k.lay_sprite[s] << sh);
+          } else {
+            const uint32_t top = mine[cell];
+            const bool covered = (((ab >> NS) & 1) && top == (uint32_t)k.lay_drape[0]) ||
+                                 (((ab >> (NS + 1)) & 1) && top == (uint32_t)k.lay_drape[1]);
+            if (!covered) mine[cell] = (uint8_t)k.lay_sprite[s];
+          }
         }
       }
     } else {
@@ -1251,7 +1318,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   }
   if constexpr (PS == 0) {
     if (single) __syncthreads();
-  } else if constexpr (PS == 1) {
+  } else if constexpr (PS == 1 || PS == 3) {
     asm volatile("" ::: "memory");  // one wave: its LDS instructions execute in order
   } else {
     if (wave == 0) {  // hand the buffer over: codes and skip flags first, then the counter the render wave polls
@@ -1260,13 +1327,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       ps_ring[5 + 2 * slot] = (uint32_t)cnt_logic;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ps_ring[0] = (uint32_t)round + 1u;
+      if (ps_prof) { const uint32_t t = ps_now(); pt_c += t - pt_mark; pt_mark = t; ++pt_units; }
       ps_u = ps_un;
-      if (P.ps_dynamic) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ps_un = ps_un < ps_n ? 2u * gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)ps_tk) : ps_n;
-      } else {
-        ps_un += gridDim.x;
-      }
+      if (ps_prof) { const uint32_t t = ps_now(); pt_d += t - pt_mark; pt_mark = t; }
     }
   }
   if constexpr (COOP) {
@@ -1351,11 +1414,29 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   uint32_t sch4[NS], dch4[2];
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   const int64_t env0 = env0_render;
-  if constexpr (PS == 1) {
-    // the next unit's state words start travelling now, in front of this unit's plane stores, and the ticket for
-    // the unit after that is drawn: both have landed when the loop below is through (vmcnt is in order, 63 at most)
+  if constexpr (PS == 1 || PS == 3) {
+    // the next unit is drawn (scalar atomic, ~1 us) and its state words start travelling now, in front of this unit's
+    // plane stores: they have landed when the loop below is through (vmcnt is in order, 63 at most)
+    if (ps_prof) { const uint32_t t = ps_now(); pt_c += t - pt_mark; pt_mark = t; ++pt_units; }
+    ps_un = P.ps_dynamic ? ps_x + ps_shards * (ps_shard_nwk + ps_ticket(ps_ctr_mine)) : ps_u + ps_nwk;
     if (ps_un < ps_n) ps_prefetch(ps_un);
-    if (P.ps_dynamic && ps_un < ps_n) ps_tk = ps_ticket_async(P.ps_ctr);
+    if (PS == 3 && P.ps_lock) {
+      // at most ps_lock streaming waves per workgroup: a counting semaphore in LDS (lane 0 alone adds; a wave that
+      // finds the count at the limit takes its increment back and tries again a little later)
+      const uint32_t la = lds_byte_address(lds_raw + k.lds_ps_ring + 3);
+      uint32_t spins = 0;
+      for (;;) {
+        uint32_t old, one = 1u;
+        uint64_t save;
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(old), "=&s"(save) : "v"(la), "v"(one) : "memory");
+        if (__builtin_amdgcn_readfirstlane((int)old) < P.ps_lock || ++spins >= PS_SPIN_LIMIT) break;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_sub_u32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(save) : "v"(la), "v"(one) : "memory");
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (ps_prof) { const uint32_t t = ps_now(); pt_b += t - pt_mark; pt_mark = t; }
+    }
+    if (PS == 3 && P.ps_prio) __builtin_amdgcn_s_setprio(3);  // a streaming wave outranks the stepping waves on its SIMD
   }
   // Uniform per-plane base pointers: every store below is `scalar base +
   // 32-bit lane offset`, and the lane offset is the same for all nine planes.
@@ -1544,7 +1625,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   for (int pass = n_pass == 2 && !u8_needed ? 1 : 0; pass < n_pass; ++pass) {
   const bool do_u8 = n_pass == 1 || pass == 0, do_f32 = n_pass == 1 || pass == 1;
   if constexpr (TWO_PASS) { e = 0; q = lane; voff = 4u * lane; eF = 0; foff = bpd * lane; }
-  if constexpr (PREFETCH) code_pf = codes[eF + q];
+  if constexpr (PREFETCH) code_pf = codes[eF + (NIB ? q >> 1 : q)];
   int hw_it = -1;
   uint32_t hw_sel = 0;
   auto hw_turn = [&](int it_now) {  // store the previous iteration's floats, then this iteration's area becomes "previous"
@@ -1569,7 +1650,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
       if constexpr (EPI) { foff_now = foff; foff += bpd * WAVE; foff = wrap ? foff + f_skew : foff; }
       if constexpr (PREFETCH) {
         code_cur = code_pf;
-        code_pf = codes[it + 1 < n_iter ? eF + q : 0u];
+        code_pf = codes[it + 1 < n_iter ? eF + (NIB ? q >> 1 : q) : 0u];
       }
     } else {
       const uint32_t f = (uint32_t)it * WAVE + lane;
@@ -1589,7 +1670,8 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
     if constexpr (CODES) {
       // one LDS read, then one v_perm_b32 per plane: the board dword picks each
       // cell's character out of the eight, layer k picks byte k of a one-hot table
-      const uint32_t code = PREFETCH ? code_cur : codes[eF_now + q_now];
+      const uint32_t code_raw = PREFETCH ? code_cur : codes[eF_now + (NIB ? q_now >> 1 : q_now)];
+      const uint32_t code = NIB ? (code_raw >> ((q_now & 1u) << 2)) & 0x0F0F0F0Fu : code_raw;
       if constexpr (TWO_PASS) {
         // ObservationToArray's own sweep: code -> board dword -> value table -> component planes, none of the
         // per-plane selection below (as part of the general body it cost ~120 scalar and ~50 vector
@@ -1659,19 +1741,26 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   }
   }  // passes
   };  // sweeps
-  if constexpr (PS == 1) {
+  if constexpr (PS == 1 || PS == 3) {
     sweeps(std::integral_constant<int, 0>{});
+    if (PS == 3 && P.ps_prio) __builtin_amdgcn_s_setprio(0);
+    if (PS == 3 && P.ps_lock) {  // (the last plane store is issued: the next wave may stream)
+      const uint32_t la = lds_byte_address(lds_raw + k.lds_ps_ring + 3);
+      uint32_t one = 1u;
+      uint64_t save;
+      asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_sub_u32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(save) : "v"(la), "v"(one) : "memory");
+    }
     // fewer than 64 plane stores behind the DMA and the ticket (units with environments left alone, ablation
     // runs): wait for them; otherwise the next unit's logic phase starts at once
     ps_need_wait = any_skip || a.debug != 0 || n_iter * (1 + SL) < 64 || !planes_on;
     if (ps_need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ps_u = ps_un;
-    if (P.ps_dynamic) ps_un = ps_un < ps_n ? 2u * gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)ps_tk) : ps_n;
-    else ps_un += gridDim.x;
+    if (ps_prof) pt_d += ps_now() - pt_mark;
   } else if constexpr (PS == 2) {
     sweeps(std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the buffer has been read: the logic wave may fill it again
     ps_ring[1] = (uint32_t)round + 1u;
+    if (ps_prof) { pt_c += ps_now() - pt_mark; ++pt_units; }
   } else if constexpr (!EPI) {
     sweeps(std::integral_constant<int, 0>{});
   } else {  // (uniform: one of the three runs)
@@ -1699,13 +1788,19 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : 2 * WAVE) void
   if constexpr (PS == 0) __syncthreads();  // swap buffers
   }  // rounds
   if constexpr (PS != 0) {
+    if (ps_prof && lane == 0) {
+      uint32_t* const pp = P.ps_prof + (PS == 3 ? (size_t)ps_wid * 16 : (size_t)blockIdx.x * 16 + (wave ? 8 : 0));
+      const uint32_t life = ps_now() - pt_start;
+      if (PS == 1 || PS == 3) { pp[0] = pt_units; pp[1] = pt_a; pp[2] = pt_b; pp[3] = pt_c; pp[10] = pt_d; pp[5] = life; }
+      else if (wave == 0) { pp[0] = pt_units; pp[1] = pt_a; pp[2] = pt_b; pp[3] = pt_c; pp[4] = pt_d; pp[5] = life; }
+      else { pp[0] = pt_units; pp[1] = pt_a; pp[2] = pt_c; pp[3] = life; }
+    }
     // the last workgroup out rewinds the work counter for the next launch (every ticket of this launch was drawn
     // before its workgroup got here)
-    if (P.ps_dynamic && threadIdx.x == 0) {
+    if (P.ps_dynamic && (PS == 3 ? lane == 0 : threadIdx.x == 0)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (atomicAdd(P.ps_ctr + 1, 1u) == gridDim.x - 1u) {
-        atomicExch(P.ps_ctr, 0u);
-        atomicExch(P.ps_ctr + 1, 0u);
+      if (atomicAdd(P.ps_ctr + 8 * 16, 1u) == ps_nwk - 1u) {
+        for (int x = 0; x <= 8; ++x) atomicExch(P.ps_ctr + 16 * x, 0u);
       }
     }
   }
@@ -1747,11 +1842,17 @@ class ScrollyMazeBackend : public Backend {
     return shipped_shape && bpad_ / WAVE < (int64_t)num_cus_ * coop_below;
   }
   // Which persistent launch shape a plain step of the shipped shape takes (0: one workgroup per group; kernel: PS)
+  // Default: 3 -- workers with a streaming semaphore (profiles/r04_tuning.md: 6-23 % faster than shape 0 from 65,536
+  // to 2,097,152 environments on the same box); PCX_SM_SHAPE picks another for A/B runs.
   int ps_shape(const StepArgs& a) const {
-    int shape = 0;
-    if (const char* e = getenv("PCX_SM_SHAPE")) shape = atoi(e);
-    if (shape < 0 || shape > 2) shape = 0;
-    if (a.mode != 0 || a.n_steps > 1 || a.debug != 0 || epi_.out || fused_.on || k_.CW > 4 || k_.NW > PS_IB_ACTION) shape = 0;
+    int shape = 3;
+    bool asked = false;
+    if (const char* e = getenv("PCX_SM_SHAPE")) { shape = atoi(e); asked = true; }
+    if (shape < 0 || shape > 3) shape = 0;
+    if (a.mode != 0 || a.n_steps > 1 || (a.debug & ~5) != 0 || epi_.out || fused_.on || k_.CW > 4 || k_.NW > PS_IB_ACTION) shape = 0;
+    if (!asked && getenv("PCX_SM_CODES") && atoi(getenv("PCX_SM_CODES")) == 0) shape = 0;  // (the mask path's A/B runs mean shape 0)
+    // (up to ~5 units per CU one wave per unit, all resident at once, is faster: 65,536 environments 0.053 vs 0.065 ms)
+    if (!asked && bpad_ / WAVE < (int64_t)num_cus_ * 6) shape = 0;
     return shape;
   }
   int max_fused_steps() const override { return fused_ok_ && !epi_.out && !fused_.on ? 256 : 1; }  // the epilogue / fused croppers have no multi-step instance
@@ -1801,13 +1902,28 @@ class ScrollyMazeBackend : public Backend {
   DevArray<uint32_t> coinbits_;
   DevArray<uint16_t> rowbase_;
   DevArray<int32_t> track_;
-  DevArray<uint32_t> ps_ctr_;
+  DevArray<uint32_t> ps_ctr_, ps_prof_;
   int last_shape_ = -1;
+ public:
+  // the phase timers of the last persistent launch (PCX_SM_PROF=1): 16 words per workgroup, see Ptrs::ps_prof
+  int read_debug_counters(uint32_t* out_host, int64_t words) override {
+    if (!ps_prof_.ptr) return set_error(PCX_E_STATE, "scrolly_maze backend: no phase timers (PCX_SM_PROF)");
+    PCX_HIP(hipDeviceSynchronize());
+    if (!out_host) {  // (words == -1: clear)
+      PCX_HIP(hipMemset(ps_prof_.ptr, 0, ps_prof_.count * sizeof(uint32_t)));
+      return 0;
+    }
+    if ((size_t)words > ps_prof_.count) words = (int64_t)ps_prof_.count;
+    PCX_HIP(hipMemcpy(out_host, ps_prof_.ptr, (size_t)words * 4, hipMemcpyDeviceToHost));
+    return 0;
+  }
+ private:
   std::vector<uint8_t> walls_pattern_, coin_pattern_;  // host copies for read_things
   std::vector<uint16_t> h_rowstart_;
   std::vector<uint8_t> h_coincol_;
   int maze_di_ = 0, cash_di_ = 0;
   int num_cus_ = 256;
+  int max_lds_ = 64 * 1024;  // per workgroup (hipDeviceProp_t::sharedMemPerBlock)
   bool unoccluded_ = false;
 };
 
@@ -2051,8 +2167,8 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     k.lds_words_codes = o;
     // persistent shapes: the same constants, then inbox, ring, coin masks and one / PS_NB owner-code buffers
     o = k.lds_bdcode + k.QW;
+    k.lds_ps_ring = o; o += 4 + 2 * PS_NB_MAX;  // [3]: PS == 3's streaming mutex
     k.lds_ps_inbox = o; o += PS_IB_ROWS * WAVE;
-    k.lds_ps_ring = o; o += 4 + 2 * PS_NB_MAX;
     k.lds_ps_cmask = o; o += (k.CW ? k.CW : 1) * WAVE;
     k.lds_ps_buf0 = o;
     k.lds_ps_buf_words = WAVE * ((k.QW | 1) + 2) + WAVE;  // code table (CODE_PITCH dwords per environment) + skip flags
@@ -2065,6 +2181,10 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       num_cus_ = prop.multiProcessorCount;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.sharedMemPerBlock >= 64 * 1024) {
+      max_lds_ = (int)prop.sharedMemPerBlock;
+      if (const char* e = getenv("PCX_SM_TRACE")) if (atoi(e)) fprintf(stderr, "[pcx] sharedMemPerBlock %zu maxSharedMemoryPerMultiProcessor %zu\n", (size_t)prop.sharedMemPerBlock, (size_t)prop.maxSharedMemoryPerMultiProcessor);
+    }
   }
   {
     // several steps per launch (pcx_engine_step_n / _step_hashed) pay off where one
@@ -2083,7 +2203,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   if ((rc = rowbase_.upload(rs))) return rc;
   if ((rc = state_.alloc((size_t)k.NW * bpad_))) return rc;
   if ((rc = track_.alloc((size_t)k.NS * bpad_))) return rc;
-  if ((rc = ps_ctr_.alloc(64))) return rc;  // persistent shapes: {next ticket, workgroups done}
+  if ((rc = ps_ctr_.alloc(16 * 9))) return rc;  // persistent shapes: eight ticket shards and the workers-done count, 64 bytes apart
   return 0;
 }
 
@@ -2116,7 +2236,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   if (const char* pad = getenv("PCX_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   if (lds > 64 * 1024) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds);
   Ptrs P{walls_.ptr, backdrop4_.ptr, coinbits_.ptr, rowbase_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_,
-         ps_ctr_.ptr, WAVE, 1, 2, 0};
+         ps_ctr_.ptr, WAVE, 1, 2, 0, 1, nullptr};
   // Specialised instance for the shipped scrolly_maze shape (10x30 board,
   // 8 characters, 'abcP' sprites); anything else takes the generic instance.
   const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
@@ -2155,10 +2275,19 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     } else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3(coop_groups),
                          dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
-  } else if (shipped_shape && waves_per_wg == 1 && use_codes && ps_shape(a) != 0) {
+  } else if (shipped_shape && waves_per_wg == 1 && ps_shape(a) != 0 && (use_codes || ps_shape(a) != 2)) {
     // persistent shapes of the owner-code instance (see the kernel): workgroups stay and draw work units
     const int shape = ps_shape(a);
     int unit = WAVE, per_cu = shape == 2 ? 3 : 8, dynamic = 1;
+    if (shape == 3) {
+      // two workers per workgroup, one of them streaming.  Few units per worker (config 5's shard: 2,048 units): four
+      // workgroups per CU, every unit somebody's first, no tickets; up to a few units per worker: three per CU,
+      // static round-robin (a drawn ticket commits a worker to one more unit -- the tail -- which costs more than the
+      // imbalance it removes until a worker walks half a dozen units); beyond: three per CU, tickets
+      const int64_t units64 = bpad_ / WAVE;
+      per_cu = units64 <= (int64_t)num_cus_ * 8 ? 4 : 3;
+      dynamic = units64 >= (int64_t)num_cus_ * 6 * 6;
+    }
     if (const char* e = getenv("PCX_SM_UNIT")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) unit = v; }
     if (const char* e = getenv("PCX_SM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
     if (const char* e = getenv("PCX_SM_DYNAMIC")) dynamic = atoi(e) != 0;
@@ -2169,19 +2298,64 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     P.ps_dynamic = dynamic;
     P.ps_nb = nb;
     Consts kk = k_;  // buffers sized by the unit: units of 32 or 16 environments let more pairs (or deeper rings) share a CU
-    kk.lds_ps_buf_words = unit * ((k_.QW | 1) + 2) + WAVE;
+    kk.lds_ps_buf_words = unit * (((k_.QW + 1) / 2) | 1) + WAVE;  // (owner codes as nibbles: the kernel's CODE_PITCH for NIB)
+    if (!use_codes) {
+      // mask path: the staged level ends with the backdrop-character masks instead of the backdrop's owner codes; a
+      // buffer is both curtains as flat bit vectors + the sprite descriptors of 64 environments + the skip flags
+      int o = k_.lds_bdcode;
+      kk.lds_bdmask = o; o += k_.n_bchars * k_.QW;
+      kk.lds_ps_ring = o; o += 4 + 2 * PS_NB_MAX;
+      kk.lds_ps_inbox = o; o += PS_IB_ROWS * WAVE;
+      kk.lds_ps_cmask = o; o += (k_.CW ? k_.CW : 1) * WAVE;
+      o = (o + 1) & ~1;  // (uint2 descriptors)
+      kk.lds_ps_buf0 = o;
+      kk.lds_ps_buf_words = 2 * WAVE * (k_.FW | 1) + 2 * k_.NS * WAVE + WAVE;
+    }
     kk.lds_ps_words1 = kk.lds_ps_buf0 + kk.lds_ps_buf_words;
     kk.lds_ps_words2 = kk.lds_ps_buf0 + nb * kk.lds_ps_buf_words;
+    // PS == 3: `waves` workers per workgroup, each with its own {inbox, coin masks, buffer}
+    int waves = 2;
+    if (const char* e = getenv("PCX_SM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) waves = v; }
+    if (const char* e = getenv("PCX_SM_LOCK")) P.ps_lock = atoi(e);
+    kk.lds_ps_wave_words = kk.lds_ps_words1 - kk.lds_ps_inbox;
+    const int words3 = kk.lds_ps_inbox + waves * kk.lds_ps_wave_words;
     int64_t n_units = (bpad_ + unit - 1) / unit, resident = (int64_t)num_cus_ * per_cu;
     if (const char* e = getenv("PCX_SM_GRID")) { const int v = atoi(e); if (v >= 1) resident = v; }  // (tests: few workgroups, many units each)
-    const dim3 pgrid((unsigned)(n_units < resident ? n_units : resident));
     last_shape_ = shape;
-    size_t lds_p = (size_t)(shape == 2 ? kk.lds_ps_words2 : kk.lds_ps_words1) * 4;
-    size_t want = ((size_t)(160 * 1024) / (size_t)per_cu) & ~(size_t)255;  // no more workgroups per CU than asked for
-    if (want > 64 * 1024) want = 64 * 1024;
-    if (want > lds_p) lds_p = want;
-    if (lds_p > 64 * 1024) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds_p);
-    if (shape == 2)
+    size_t lds_p = (size_t)(shape == 3 ? words3 : shape == 2 ? kk.lds_ps_words2 : kk.lds_ps_words1) * 4;
+    // (no LDS padding here: the grid is sized to what is resident at once, so the occupancy is the grid's)
+    if (lds_p > (size_t)max_lds_) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds_p);
+    if (lds_p > 64 * 1024 && shape == 3) {
+      static bool raised = false;  // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel)
+      if (!raised) {
+        PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
+        PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
+        raised = true;
+      }
+    }
+    {  // no more workgroups than are resident at once: a workgroup that starts late would step its first unit late
+      const int64_t fit = (int64_t)(160 * 1024) / (int64_t)((lds_p + 511) & ~(size_t)511);
+      const int64_t by_regs = shape == 3 ? (waves <= 12 ? 12 / waves : 1) : shape == 2 ? 6 : 12;  // (130-170 VGPRs: three waves per SIMD)
+      int64_t per = per_cu < fit ? per_cu : fit;
+      if (per > by_regs) per = by_regs;
+      if (!getenv("PCX_SM_GRID")) resident = (int64_t)num_cus_ * (per < 1 ? 1 : per);
+    }
+    const int64_t want_wgs = shape == 3 ? (n_units + waves - 1) / waves : n_units;  // (no workgroup without a unit)
+    const dim3 pgrid((unsigned)(want_wgs < resident ? want_wgs : resident));
+    if ((int64_t)pgrid.x * (shape == 3 ? waves : 1) >= n_units) P.ps_dynamic = 0;  // every unit is some worker's first: nothing to draw
+    if (getenv("PCX_SM_PROF")) {
+      if (!ps_prof_.ptr) { int rc = ps_prof_.alloc((size_t)16 * 65536); if (rc) return rc; }
+      if (pgrid.x <= 65536) P.ps_prof = ps_prof_.ptr;
+    }
+    if (shape == 3 && !use_codes)
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
+    else if (shape == 1 && !use_codes)
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 1>), pgrid, dim3(WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
+    else if (shape == 3)
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
+    else if (shape == 2)
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 2>), pgrid, dim3(2 * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
     else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 1>), pgrid, dim3(WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());

@@ -15,7 +15,8 @@ from tests.hip_adapter import HipAdapter
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ('PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_GRID', 'PCX_SM_PER_CU', 'PCX_COOP_BELOW')
+KNOBS = ('PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_GRID', 'PCX_SM_PER_CU', 'PCX_COOP_BELOW', 'PCX_SM_WAVES',
+         'PCX_SM_LOCK', 'PCX_SM_CODES')
 
 
 class Knobs(object):
@@ -56,15 +57,36 @@ def shape_of(hip):
   return int(N.lib().pcx_engine_launch_shape(hip.eng._native))
 
 
-@pytest.mark.parametrize('shape,unit,dynamic,grid', [
-    (1, 64, 1, 5), (1, 64, 0, 5), (1, 32, 1, 7), (1, 16, 1, 3), (1, 64, 1, 1), (1, 64, 1, 4096),
-    (2, 64, 1, 5), (2, 64, 0, 5), (2, 32, 1, 7), (2, 16, 1, 3), (2, 64, 1, 1), (2, 64, 1, 4096),
+@pytest.mark.parametrize('shape,codes,waves,lock,grid,dynamic', [(3, 0, 4, 1, 2, 1), (3, 0, 3, 2, 3, 0), (3, 0, 12, 3, 1, 1), (1, 0, 1, 0, 5, 1),
+                                                          (3, 1, 6, 2, 1, 1), (3, 1, 2, 0, 3, 0)])
+def test_persistent_workers_with_streaming_semaphore_match_oracle(shape, codes, waves, lock, grid, dynamic):
+  """Shape 3 (and shape 1) on both render paths -- owner codes and curtain masks -- with `waves` workers per workgroup of
+  which at most `lock` stream at a time (0: no limit)."""
+  t = helpers.load_template('scrolly_maze_L0')
+  B, T = 2999, 120
+  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=shape, PCX_SM_CODES=codes, PCX_SM_WAVES=waves, PCX_SM_LOCK=lock, PCX_SM_GRID=grid,
+             PCX_SM_DYNAMIC=dynamic):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    t0 = 0
+    while t0 < T:
+      n = 1 if t0 < 16 else 8
+      hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
+      assert shape_of(hip) == shape
+      t0 += n
+      assert_same(hip, orc, 'shape %d codes %d waves %d lock %d after step %d' % (shape, codes, waves, lock, t0))
+
+
+@pytest.mark.parametrize('shape,unit,dynamic,grid,waves', [
+    (1, 64, 1, 5, 1), (1, 64, 0, 5, 1), (1, 32, 1, 7, 1), (1, 16, 1, 3, 1), (1, 64, 1, 1, 1), (1, 64, 1, 4096, 1),
+    (2, 64, 1, 5, 2), (2, 64, 0, 5, 2), (2, 32, 1, 7, 2), (2, 16, 1, 3, 2), (2, 64, 1, 1, 2), (2, 64, 1, 4096, 2),
+    (3, 64, 1, 5, 2), (3, 64, 0, 5, 2), (3, 32, 1, 3, 4), (3, 16, 1, 2, 6), (3, 64, 1, 1, 2), (3, 64, 1, 4096, 2), (3, 64, 1, 2, 1),
 ])
-def test_persistent_shapes_match_oracle(shape, unit, dynamic, grid):
+def test_persistent_shapes_match_oracle(shape, unit, dynamic, grid, waves):
   """A ragged batch (not a multiple of 64, 32 or 16) walked by `grid` workgroups; hashed actions, resets included."""
   t = helpers.load_template('scrolly_maze_L0')
   B, T = 2999, 160
-  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=shape, PCX_SM_UNIT=unit, PCX_SM_DYNAMIC=dynamic, PCX_SM_GRID=grid):
+  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=shape, PCX_SM_UNIT=unit, PCX_SM_DYNAMIC=dynamic, PCX_SM_GRID=grid, PCX_SM_WAVES=waves):
     hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
     hip.reset(); orc.reset()
     assert_same(hip, orc, 'frame 0')
@@ -78,7 +100,7 @@ def test_persistent_shapes_match_oracle(shape, unit, dynamic, grid):
     assert int(orc.read('frame').min()) < T  # episodes ended and restarted inside the run
 
 
-@pytest.mark.parametrize('shape', [1, 2])
+@pytest.mark.parametrize('shape', [1, 2, 3])
 def test_persistent_shapes_tape_actions_and_environments_left_alone(shape):
   """Action tapes from the host (illegal and quit actions among them), and steps without auto-reset: finished
   environments are skipped (their units stream fewer planes: the wait-for-the-prefetch path of shape 1)."""
@@ -100,7 +122,7 @@ def test_persistent_shapes_tape_actions_and_environments_left_alone(shape):
       assert_same(hip, orc, 'shape %d step %d' % (shape, step))
 
 
-@pytest.mark.parametrize('shape,unit', [(1, 64), (2, 64), (2, 32)])
+@pytest.mark.parametrize('shape,unit', [(1, 64), (2, 64), (2, 32), (3, 64), (3, 32)])
 def test_persistent_shapes_at_config_5_shard_size(shape, unit):
   """131,072 environments (BASELINE config 5's per-GPU shard) at the default residency: the first and the last
   2,048 environments against the oracle, layer == (board == c) over the whole batch, and everything equal to what
