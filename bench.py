@@ -7,10 +7,14 @@ that are already resident in HBM.  Prints ONE JSON line on rank 0.
 
   python bench.py                       1 GPU, scrolly_maze L0, 1,048,576 envs (BASELINE metric config)
   python bench.py --gpus 8              8 ranks, one per GPU (spawned here through torch.distributed.run
-                                        when not already launched by it); weak scaling: 1,048,576 envs per GPU
-  python bench.py --gpus 8 --scaling strong   fixed global batch 1,048,576 = 131,072 envs per GPU
-  python bench.py --gpus 8 --gather     also times the steps followed by the RCCL all-gather of the packed
-                                        reward/discount/reward_set/done record (10 B/env), reported separately
+                                        when not already launched by it).  BASELINE config 5 as stated: the FIXED
+                                        global batch 1,048,576 sharded over the ranks (131,072 envs per GPU at
+                                        N = 8; "scaling": "strong"); the weak-scaling figure (1,048,576 envs per
+                                        GPU) is a second timed block of the same line ("weak_scaling"), and the
+                                        steps followed by the RCCL all-gather of the packed reward / discount /
+                                        reward_set / done record (10 B/env) a third ("gather")
+  python bench.py --gpus 8 --scaling weak     1,048,576 envs per GPU as the headline value instead
+  python bench.py --gpus 8 --no-gather  skip the all-gather block
   python bench.py --gpus 2 --oversubscribe    the same N-rank path on a node with FEWER GPUs than ranks: ranks
                                         share devices round-robin and the process group is gloo (RCCL refuses two
                                         ranks on one device); launcher, sharding, accounting and JSON are the
@@ -180,7 +184,8 @@ def measure_config(game, level, batch, steps, warmup, device, repeats=3):
   out = {'workload': 'examples/%s, %d envs' % (fixture, batch), 'ms_per_step': kernel_ms,
          'ms_per_step_min_max': [min(runs), max(runs)],
          'env_steps_per_s': batch / (kernel_ms * 1e-3),
-         'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(), 'algorithmic_bytes_per_env_step': bps,
+         'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(),
+         'launch_shape': int(N.lib().pcx_engine_launch_shape(eng._native)), 'algorithmic_bytes_per_env_step': bps,
          'hbm_frac': bps * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
          'traffic': pmc_traffic(game, level, batch)}
   eng.close()
@@ -196,9 +201,11 @@ def main():
                   help='how many times the K timed steps are repeated; value = the median repeat')
   ap.add_argument('--batch', type=int, default=1 << 20,
                   help='environments per GPU (--scaling weak) or in total (--scaling strong)')
-  ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-  ap.add_argument('--gather', action='store_true',
-                  help='also time steps followed by the all-gather of the packed 10 B/env step results')
+  ap.add_argument('--scaling', default=None, choices=['weak', 'strong'],
+                  help='default: strong (fixed global batch, BASELINE config 5) for --gpus > 1, weak for one GPU')
+  ap.add_argument('--gather', action='store_true', default=None,
+                  help='also time steps followed by the all-gather of the packed 10 B/env step results (default for --gpus > 1)')
+  ap.add_argument('--no-gather', dest='gather', action='store_false')
   ap.add_argument('--oversubscribe', action='store_true',
                   help='allow more ranks than GPUs (ranks share devices; process group over gloo)')
   ap.add_argument('--actions', default='random', choices=['random', 'hashed'],
@@ -215,6 +222,10 @@ def main():
   ap.add_argument('--no-other-configs', action='store_true',
                   help='skip the short measurements of BASELINE configs 2-4 added to the N=1 headline line')
   args = ap.parse_args()
+  if args.scaling is None:
+    args.scaling = 'strong' if args.gpus > 1 else 'weak'
+  if args.gather is None:
+    args.gather = args.gpus > 1
   if args.repeats < 1 or args.steps < 1:
     raise SystemExit('bench.py: --steps and --repeats must be >= 1')
 
@@ -341,6 +352,35 @@ def main():
       np.savez(args.dump_scalars, reward=got[0], reward_set=got[1], discount=got[2], done=got[3],
                steps_taken=np.array([steps_taken]), checks=np.frombuffer(json.dumps(checks).encode(), np.uint8))
 
+  per_rank_envs = [pdist.shard_range(global_batch, r, world)[1] - pdist.shard_range(global_batch, r, world)[0]
+                   if args.scaling == 'strong' else args.batch for r in range(world)]
+
+  # N > 1 with the fixed global batch as the headline: the weak-scaling figure (args.batch environments on EVERY GPU) is a
+  # second timed block of the same line, on a second engine
+  weak = None
+  if distributed and world > 1 and args.scaling == 'strong':
+    engw = Engine.from_template(template, batch=args.batch, device=device, auto_reset=True, seed=0x5EED, env_offset=rank * args.batch)
+    engw.its_showtime()
+    gw = torch.Generator(device='cuda')
+    gw.manual_seed(0x5EED + 1000 + rank)
+    tapew = torch.randint(0, template.n_actions, (W + K, args.batch), dtype=torch.int32, device='cuda', generator=gw)
+    for t in range(W):
+      engw.step(tapew[t])
+    ww, wk = [], []
+    for r in range(min(R, 3)):
+      wall_w, kms_w = time_steps(engw, lambda t: tapew[t], W, W + K, barrier)
+      ww.append(max_over_ranks(wall_w))
+      wk.append(kms_w)
+    engw.check_errors()
+    bps_w = int(N.lib().pcx_engine_bytes_per_step(engw._native))
+    per_rank_w = every_rank(median(wk))
+    weak = {'scaling': 'weak', 'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'steps': K,
+            'value': args.batch * world * K / median(ww), 'unit': 'env-steps/s', 'ms_per_step': median(ww) / K * 1e3,
+            'per_rank_kernel_ms': per_rank_w,
+            'hbm_frac_per_rank': [bps_w * args.batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS for ms in per_rank_w]}
+    del tapew
+    engw.close()
+
   if rank == 0:
     bytes_per_step = int(N.lib().pcx_engine_bytes_per_step(eng._native))
     achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
@@ -372,14 +412,22 @@ def main():
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                      'traffic_source': TRAFFIC_SOURCE if traffic is not None else None,
                      'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(),
+                     'launch_shape': int(N.lib().pcx_engine_launch_shape(eng._native)),
                      'kernel_ms': kernel_ms, 'algorithmic_bytes_per_env_step': bytes_per_step},
     }
+    if world > 1:
+      # N > 1: `achieved` / `frac` above are RANK 0's GPU (one GPU's HBM against one GPU's peak); every rank's own figure:
+      fr = [bytes_per_step * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS for n, ms in zip(per_rank_envs, per_rank_kernel_ms)]
+      line['roofline']['scope'] = 'per GPU (rank 0); frac_per_rank lists every rank'
+      line['roofline']['frac_per_rank'] = fr
+      line['roofline']['frac_min'] = min(fr)
+      line['roofline']['frac_median'] = median(fr)
     if distributed:
       line['dist'] = {'backend': backend, 'world_size': dist.get_world_size(), 'oversubscribed': oversubscribed,
                       'devices_on_node': n_dev, 'rank_device': every_rank_devices(world, n_dev),
-                      'per_rank_kernel_ms': per_rank_kernel_ms,
-                      'per_rank_envs': [pdist.shard_range(global_batch, r, world)[1] - pdist.shard_range(global_batch, r, world)[0]
-                                        if args.scaling == 'strong' else args.batch for r in range(world)]}
+                      'per_rank_kernel_ms': per_rank_kernel_ms, 'per_rank_envs': per_rank_envs}
+    if weak is not None:
+      line['weak_scaling'] = weak
     if gather is not None:
       line['gather'] = gather
     del tape
@@ -395,12 +443,15 @@ def main():
     if world == 1 and args.game == 'scrolly_maze' and not args.no_other_configs:
       # BASELINE configs 2-4 on the same GPU, same run (their own kernels and rooflines), then the other two
       # hand-written kernels: SURVEY 8 f-1 (better_scrolly_maze, 45x89 board) and config 1's game on the GPU
-      line['other_configs'] = [measure_config('scrolly_maze', 0, 4096, 200, 20, device),
+      # (+ config 5's per-GPU shard sizes: 131,072 environments = 1,048,576 over eight GPUs, and 262,144 = over four)
+      line['other_configs'] = [measure_config('scrolly_maze', 0, 131072, 200, 20, device),
+                               measure_config('scrolly_maze', 0, 262144, 200, 20, device),
+                               measure_config('scrolly_maze', 0, 4096, 200, 20, device),
                                measure_config('marauders', 0, 32768, 200, 20, device),
                                measure_config('warehouse', 0, 262144, 100, 10, device),
                                measure_config('better_scrolly_maze', 0, 65536, 50, 10, device),
                                measure_config('hello_world', 0, 1048576, 50, 10, device)]
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:  # (rank 0's host cores, N > 1 included)
       line['cpu_baseline'] = cpu_baseline(template_path)
       ref = cpu_reference_python(args.game, args.level)
       if ref is not None:

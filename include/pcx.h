@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PCX_ABI_VERSION 2u
+#define PCX_ABI_VERSION 3u  /* 3: pcx_epilogue_desc grew (round 3), PCX_DIR_NEXT_CHAPTER, checkpoints carry a template hash */
 
 #define PCX_MAX_CHARS 32    /* distinct characters (layers) in one game   */
 #define PCX_MAX_SPRITES 16
@@ -378,6 +378,15 @@ int pcx_cropper_crop(pcx_cropper* c, void* stream);
 int pcx_cropper_buffers(pcx_cropper* c, uint8_t** planes_dev,
                         int32_t** corner_dev);
 int32_t pcx_cropper_plane_pitch(const pcx_cropper* c);
+/* Checkpoint / resume of a cropper (companion of pcx_engine_export_state; no reference counterpart: the reference's
+ * croppers are pickled with the game).  The window state -- every environment's corner and whether it has one yet,
+ * cropping.py:393-426 -- and, with_planes != 0, the cropped planes the last crop() (or fused step) produced.  Import
+ * AFTER pcx_engine_import_state, into a cropper of the same window on an engine of the same game and batch; with the
+ * planes the next crop() hands them out as they are, without them it cuts them from the engine's restored
+ * observation (PCX_E_STATE if the engine writes no full-board planes).  Synchronous. */
+int pcx_cropper_state_size(pcx_cropper* c, int32_t with_planes, uint64_t* bytes);
+int pcx_cropper_export_state(pcx_cropper* c, void* host, uint64_t bytes, int32_t with_planes);
+int pcx_cropper_import_state(pcx_cropper* c, const void* host, uint64_t bytes);
 /* Optional: make crop() write into a caller-owned device array (e.g. a tensor
  * of the host framework) of batch * (1+n_chars) * pitch bytes, dword-aligned;
  * the reference's croppers likewise write a pre-allocated output

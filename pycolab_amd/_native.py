@@ -12,7 +12,7 @@ c_u8, c_i32, c_i64, c_u32, c_u64 = (ctypes.c_uint8, ctypes.c_int32,
                                     ctypes.c_uint64)
 c_u8_p = ctypes.POINTER(ctypes.c_uint8)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_CHARS = 32
 MAX_SPRITES = 16
 MAX_DRAPES = 8
@@ -164,6 +164,9 @@ SYMBOLS = [
     ('pcx_cropper_buffers', c_i32, [_VP, ctypes.POINTER(_VP), ctypes.POINTER(_VP)]),
     ('pcx_cropper_errors', c_i32, [_VP, _VP]),
     ('pcx_cropper_plane_pitch', c_i32, [_VP]),
+    ('pcx_cropper_state_size', c_i32, [_VP, c_i32, ctypes.POINTER(c_u64)]),
+    ('pcx_cropper_export_state', c_i32, [_VP, _VP, c_u64, c_i32]),
+    ('pcx_cropper_import_state', c_i32, [_VP, _VP, c_u64]),
     ('pcx_cropper_bind_output', c_i32, [_VP, _VP]),
     ('pcx_engine_fuse_croppers', c_i32, [_VP, ctypes.POINTER(_VP), c_i32, c_i32, _VP]),
     ('pcx_cropper_error_buffer', c_i32, [_VP, ctypes.POINTER(_VP)]),

@@ -214,6 +214,9 @@ struct pcx_cropper {
   // output (written by that fusion) is what crop() must keep handing out until then
   bool hold = false;
   uint64_t hold_epoch = 0;
+  // a checkpoint restored the window but not the output planes (pcx_cropper_import_state): the next crop() cuts them
+  // from the engine's restored observation with the stand-alone kernels, also while the step kernel runs this cropper
+  bool refresh = false;
   uint8_t* out_planes() const { return bound ? bound : planes.ptr; }
   int ensure_planes() {  // own output planes only when the caller bound none
     if (bound || planes.ptr) return 0;
@@ -360,7 +363,11 @@ int pcx_cropper_crop(pcx_cropper* c, void* stream) {
   if (!c) return set_error(PCX_E_INVALID, "pcx_cropper_crop: null cropper");
   pcx_engine* e = c->e;
   if (!e->showtime) return set_error(PCX_E_STATE, "pcx_cropper_crop: the engine is not in play");
-  if (c->fused) return 0;  // the step kernel moved the window and wrote the planes already
+  if (c->fused && c->refresh && e->fused_only)
+    return set_error(PCX_E_STATE, "pcx_cropper_crop: the checkpoint held no cropped planes and the engine writes no full-board "
+                                  "planes to cut them from (export with the observation, or step once)");
+  if (c->fused && !c->refresh) return 0;  // the step kernel moved the window and wrote the planes already
+  c->refresh = false;
   if (c->hold) {
     if (c->hold_epoch == e->epoch) return 0;  // no launch since the windows-only fusion ended: its output stands
     c->hold = false;
@@ -378,6 +385,66 @@ int pcx_cropper_crop(pcx_cropper* c, void* stream) {
   hipLaunchKernelGGL(pcx_crop_copy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, e->out.planes,
                      c->corner.ptr, c->error.ptr, c->out_planes());
   PCX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- checkpoint / resume (pcx_engine_export_state's companion: the window state lives here, not in the engine) ----
+namespace {
+struct CropStateHeader {
+  uint32_t magic, abi;
+  int64_t batch;
+  int32_t rows, cols, n_chars, out_pitch, with_planes, pad;
+};
+constexpr uint32_t CROP_STATE_MAGIC = 0x57584350u;  // "PCXW"
+}  // namespace
+
+int pcx_cropper_state_size(pcx_cropper* c, int32_t with_planes, uint64_t* bytes) {
+  if (!c || !bytes) return set_error(PCX_E_INVALID, "pcx_cropper_state_size: bad arguments");
+  const uint64_t B = (uint64_t)c->e->batch;
+  *bytes = sizeof(CropStateHeader) + B * 8 + ((B + 7) & ~7ull) + (with_planes ? B * (1 + c->p.L) * c->p.out_pitch : 0);
+  return 0;
+}
+
+int pcx_cropper_export_state(pcx_cropper* c, void* host, uint64_t bytes, int32_t with_planes) {
+  uint64_t need = 0;
+  if (!c || !host || pcx_cropper_state_size(c, with_planes, &need)) return set_error(PCX_E_INVALID, "pcx_cropper_export_state: bad arguments");
+  if (bytes < need) return set_error(PCX_E_INVALID, "pcx_cropper_export_state: %llu bytes given, %llu needed",
+                                     (unsigned long long)bytes, (unsigned long long)need);
+  PCX_HIP(hipSetDevice(c->e->device));
+  if (with_planes) { if (int rc = c->ensure_planes()) return rc; }
+  PCX_HIP(hipDeviceSynchronize());
+  const uint64_t B = (uint64_t)c->e->batch;
+  CropStateHeader h{CROP_STATE_MAGIC, PCX_ABI_VERSION, c->e->batch, c->p.rows, c->p.cols, c->p.L, c->p.out_pitch, with_planes != 0, 0};
+  uint8_t* p = static_cast<uint8_t*>(host);
+  memcpy(p, &h, sizeof h); p += sizeof h;
+  PCX_HIP(hipMemcpy(p, c->corner.ptr, B * 8, hipMemcpyDeviceToHost)); p += B * 8;
+  PCX_HIP(hipMemcpy(p, c->has_corner.ptr, B, hipMemcpyDeviceToHost)); p += (B + 7) & ~7ull;
+  if (with_planes) PCX_HIP(hipMemcpy(p, c->out_planes(), B * (1 + c->p.L) * c->p.out_pitch, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pcx_cropper_import_state(pcx_cropper* c, const void* host, uint64_t bytes) {
+  if (!c || !host || bytes < sizeof(CropStateHeader)) return set_error(PCX_E_INVALID, "pcx_cropper_import_state: bad arguments");
+  CropStateHeader h;
+  memcpy(&h, host, sizeof h);
+  if (h.magic != CROP_STATE_MAGIC || h.abi != PCX_ABI_VERSION) return set_error(PCX_E_INVALID, "pcx_cropper_import_state: not a cropper checkpoint of this ABI");
+  if (h.batch != c->e->batch || h.rows != c->p.rows || h.cols != c->p.cols || h.n_chars != c->p.L || h.out_pitch != c->p.out_pitch)
+    return set_error(PCX_E_INVALID, "pcx_cropper_import_state: the checkpoint is of another window, game or batch");
+  uint64_t need = 0;
+  pcx_cropper_state_size(c, h.with_planes, &need);
+  if (bytes < need) return set_error(PCX_E_INVALID, "pcx_cropper_import_state: truncated checkpoint");
+  PCX_HIP(hipSetDevice(c->e->device));
+  if (h.with_planes) { if (int rc = c->ensure_planes()) return rc; }
+  PCX_HIP(hipDeviceSynchronize());
+  const uint64_t B = (uint64_t)c->e->batch;
+  const uint8_t* p = static_cast<const uint8_t*>(host) + sizeof h;
+  PCX_HIP(hipMemcpy(c->corner.ptr, p, B * 8, hipMemcpyHostToDevice)); p += B * 8;
+  PCX_HIP(hipMemcpy(c->has_corner.ptr, p, B, hipMemcpyHostToDevice)); p += (B + 7) & ~7ull;
+  if (h.with_planes) PCX_HIP(hipMemcpy(c->out_planes(), p, B * (1 + c->p.L) * c->p.out_pitch, hipMemcpyHostToDevice));
+  // the restored planes stand until the engine's next launch; without them the next crop() cuts them afresh
+  c->hold = h.with_planes != 0;
+  c->hold_epoch = c->e->epoch;
+  c->refresh = !h.with_planes;
   return 0;
 }
 

@@ -184,6 +184,21 @@ int pcx_engine_create(const pcx_template* t, int64_t batch, int device_id, pcx_e
   if (rc) { delete b; return rc; }
   pcx_engine* e = new pcx_engine();
   e->t = *t;
+  {
+    // what makes two engines interchangeable for a checkpoint: the whole template, pointer targets by content
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    pcx_template flat = *t;
+    flat.backdrop = nullptr;
+    for (int i = 0; i < PCX_MAX_DRAPES; ++i) flat.drapes[i].curtain = flat.drapes[i].pattern = nullptr;
+    mix(&flat, sizeof flat);
+    mix(t->backdrop, (size_t)t->rows * t->cols);
+    for (int i = 0; i < t->n_drapes; ++i) {
+      if (t->drapes[i].curtain) mix(t->drapes[i].curtain, (size_t)t->rows * t->cols);
+      if (t->drapes[i].pattern) mix(t->drapes[i].pattern, (size_t)t->drapes[i].pattern_rows * t->drapes[i].pattern_cols);
+    }
+    e->template_hash = h;
+  }
   e->t.backdrop = nullptr;
   for (int i = 0; i < PCX_MAX_DRAPES; ++i) e->t.drapes[i].curtain = e->t.drapes[i].pattern = nullptr;
   e->batch = batch;
@@ -335,6 +350,7 @@ struct StateHeader {
   int64_t batch;
   uint64_t epoch;
   int32_t with_observation, n_arrays;
+  uint64_t template_hash;  // pcx_engine::template_hash: level, tables, directives and parameters, not only the dimensions
 };
 constexpr uint32_t STATE_MAGIC = 0x53584350u;  // "PCXS"
 
@@ -375,7 +391,7 @@ int pcx_engine_export_state(pcx_engine* e, void* host, uint64_t bytes, int32_t w
   if ((rc = state_arrays(e, with_observation, arr))) return rc;
   PCX_HIP(hipDeviceSynchronize());
   StateHeader h{STATE_MAGIC, PCX_ABI_VERSION, e->t.game, e->t.rows, e->t.cols, e->t.n_chars, e->t.n_sprites, e->t.n_drapes,
-                e->batch, e->epoch, with_observation != 0, (int32_t)arr.size()};
+                e->batch, e->epoch, with_observation != 0, (int32_t)arr.size(), e->template_hash};
   uint8_t* p = static_cast<uint8_t*>(host);
   memcpy(p, &h, sizeof h); p += sizeof h;
   for (auto& a : arr) {
@@ -396,6 +412,8 @@ int pcx_engine_import_state(pcx_engine* e, const void* host, uint64_t bytes) {
   if (h.game != e->t.game || h.rows != e->t.rows || h.cols != e->t.cols || h.n_chars != e->t.n_chars ||
       h.n_sprites != e->t.n_sprites || h.n_drapes != e->t.n_drapes || h.batch != e->batch)
     return set_error(PCX_E_INVALID, "pcx_engine_import_state: the checkpoint is of another game, board or batch");
+  if (h.template_hash != e->template_hash)
+    return set_error(PCX_E_INVALID, "pcx_engine_import_state: the checkpoint is of another level or parameter set of this game (template hash)");
   std::vector<std::pair<void*, size_t>> arr;
   int rc = state_arrays(e, h.with_observation, arr);
   if (rc) return rc;

@@ -177,6 +177,7 @@ Backend* make_hello_world_backend();
 
 struct pcx_engine {
   pcx_template t;  // shallow copy; pointer members are NOT valid after create
+  uint64_t template_hash = 0;  // FNV-1a over everything of the template, the arrays behind its pointers included (checkpoints)
   int64_t batch = 0;
   int device = 0;
   bool showtime = false;

@@ -118,6 +118,10 @@ struct Ptrs {
   int32_t ps_nb;    // owner-code buffers of a logic/render pair (the logic wave runs up to ps_nb - 1 units ahead)
   int32_t ps_prio;  // s_setprio of the pair's render wave (0: leave alone)
   int32_t ps_lock;  // PS == 3: at most this many waves of a workgroup in their render loop at a time (0: no limit)
+  // the batch's last environments go in SMALL units (ps_tail_unit environments each; units ps_n1 and up), so that what the
+  // workers hold when the tickets run out -- the launch's tail -- is short; ps_n1 = all units when there is no such region
+  int32_t ps_tail_unit;
+  uint32_t ps_n1, ps_n;
   // phase timers (tools/ps_sweep.py --prof): 16 words per workgroup, 10 ns ticks of s_memrealtime summed over its units --
   // logic wave: [0] units, [1] wait for the inbox, [2] wait for a free buffer, [3] stepping, [4] wait for the ticket,
   // [5] lifetime; render wave: [8] units, [9] wait for a full buffer, [10] streaming, [11] lifetime (shape 1: [3], [10] and [5])
@@ -699,7 +703,15 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   // (an LDS-address-space pointer: as a generic one its volatile accesses become FLAT instructions, which count on vmcnt)
   typedef __attribute__((address_space(3))) volatile uint32_t lds_volatile_u32;
   lds_volatile_u32* const ps_ring = (lds_volatile_u32*)(lds_raw + k.lds_ps_ring);  // [0] produced, [1] consumed, [2] no more units, [4 + 2 slot] env0, count
-  const uint32_t ps_n = PS ? (uint32_t)((P.bpad + P.ps_unit - 1) / P.ps_unit) : 0u;
+  const uint32_t ps_n = PS ? P.ps_n : 0u;
+  // unit -> its first environment and how many it has
+  auto ps_span = [&](uint32_t u, int64_t& e0, int& cnt) {
+    const bool small = u >= P.ps_n1;
+    const int size = small ? P.ps_tail_unit : P.ps_unit;
+    e0 = small ? (int64_t)P.ps_n1 * P.ps_unit + (int64_t)(u - P.ps_n1) * P.ps_tail_unit : (int64_t)u * P.ps_unit;
+    const int64_t left = P.bpad - e0;
+    cnt = left < size ? (int)left : size;
+  };
   // The work counter is sharded (one word per shard, 64 bytes apart): shard x = blockIdx.x % S owns the units
   // congruent to x mod S, its workgroups draw from its own word.  With S = 8 a shard is one XCD as the hardware places
   // workgroups today (block b on XCD b % 8: MI355X_MICROARCH.md) -- an eighth of the contention on each word and the
@@ -719,9 +731,12 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   // the state words of unit `u` (and its tape actions) into the inbox; lanes past the unit's environments stay out
   auto ps_prefetch = [&](uint32_t u_any) {
     const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u_any);  // (uniform by construction; now provably)
-    const int64_t e0 = (int64_t)u * P.ps_unit;
-    const int64_t left = P.bpad - e0;
-    const int cnt = left < P.ps_unit ? (int)left : P.ps_unit;
+    int64_t e0_any;
+    int cnt;
+    ps_span(u, e0_any, cnt);
+    const uint32_t e0_lo = __builtin_amdgcn_readfirstlane((uint32_t)e0_any), e0_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)e0_any >> 32));
+    const int64_t e0 = (int64_t)(((uint64_t)e0_hi << 32) | e0_lo);
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
     const uint32_t ib = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_address(ps_inbox));
     if (lane < cnt) {
 #pragma unroll
@@ -760,9 +775,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   int cnt_logic = EPW, cnt_render = EPW;
   if constexpr (PS == 1 || PS == 3) {
     if (ps_u >= ps_n) break;
-    env0_logic = env0_render = (int64_t)ps_u * P.ps_unit;
-    const int64_t left = P.bpad - env0_logic;
-    cnt_logic = cnt_render = left < P.ps_unit ? (int)left : P.ps_unit;
+    ps_span(ps_u, env0_logic, cnt_logic);
+    env0_render = env0_logic;
+    cnt_render = cnt_logic;
     have_logic = have_render = true;
     pt_mark = ps_now();
   } else if constexpr (PS == 2) {
@@ -774,9 +789,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
         ps_ring[2] = 1u;
         break;
       }
-      env0_logic = (int64_t)ps_u * P.ps_unit;
-      const int64_t left = P.bpad - env0_logic;
-      cnt_logic = left < P.ps_unit ? (int)left : P.ps_unit;
+      ps_span(ps_u, env0_logic, cnt_logic);
       have_logic = true;
       have_render = false;
       uint32_t spins = 0;  // the slot's previous unit must have been streamed
@@ -2236,7 +2249,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   if (const char* pad = getenv("PCX_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   if (lds > 64 * 1024) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds);
   Ptrs P{walls_.ptr, backdrop4_.ptr, coinbits_.ptr, rowbase_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_,
-         ps_ctr_.ptr, WAVE, 1, 2, 0, 1, nullptr};
+         ps_ctr_.ptr, WAVE, 1, 2, 0, 1, 16, 0, 0, nullptr};
   // Specialised instance for the shipped scrolly_maze shape (10x30 board,
   // 8 characters, 'abcP' sprites); anything else takes the generic instance.
   const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
@@ -2283,10 +2296,11 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
       // two workers per workgroup, one of them streaming.  Few units per worker (config 5's shard: 2,048 units): four
       // workgroups per CU, every unit somebody's first, no tickets; up to a few units per worker: three per CU,
       // static round-robin (a drawn ticket commits a worker to one more unit -- the tail -- which costs more than the
-      // imbalance it removes until a worker walks half a dozen units); beyond: three per CU, tickets
+      // imbalance it removes until a worker walks four or five units: 262,144 environments 0.178 static / 0.187 tickets,
+      // 524,288: 0.330 / 0.323); beyond: three per CU, tickets
       const int64_t units64 = bpad_ / WAVE;
       per_cu = units64 <= (int64_t)num_cus_ * 8 ? 4 : 3;
-      dynamic = units64 >= (int64_t)num_cus_ * 6 * 6;
+      dynamic = units64 >= (int64_t)num_cus_ * 6 * 4;
     }
     if (const char* e = getenv("PCX_SM_UNIT")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) unit = v; }
     if (const char* e = getenv("PCX_SM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
@@ -2344,7 +2358,24 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     }
     const int64_t want_wgs = shape == 3 ? (n_units + waves - 1) / waves : n_units;  // (no workgroup without a unit)
     const dim3 pgrid((unsigned)(want_wgs < resident ? want_wgs : resident));
-    if ((int64_t)pgrid.x * (shape == 3 ? waves : 1) >= n_units) P.ps_dynamic = 0;  // every unit is some worker's first: nothing to draw
+    const int64_t workers = (int64_t)pgrid.x * (shape == 3 ? waves : 1);
+    if (workers >= n_units) P.ps_dynamic = 0;  // every unit is some worker's first: nothing to draw
+    P.ps_n1 = P.ps_n = (uint32_t)n_units;
+    {
+      // PCX_SM_TAIL=t: with tickets, the last t small units per worker go in units of PCX_SM_TAIL_UNIT environments.  Off by
+      // default: measured, every setting loses (1,048,576 environments: 0.614 ms without, 0.617 / 0.631 / 0.642 with
+      // t = 1 / 2 / 3 -- a small unit still costs a whole logic phase; profiles/r04_tuning.md)
+      int tail = 0, small = 16;
+      if (const char* e = getenv("PCX_SM_TAIL")) tail = atoi(e);
+      if (const char* e = getenv("PCX_SM_TAIL_UNIT")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) small = v; }
+      const int64_t tail_envs = ((workers * tail * small + unit - 1) / unit) * unit;
+      if (P.ps_dynamic && tail > 0 && small < unit && tail_envs * 4 <= bpad_) {
+        const int64_t n1 = (bpad_ - tail_envs) / unit;
+        P.ps_tail_unit = small;
+        P.ps_n1 = (uint32_t)n1;
+        P.ps_n = (uint32_t)(n1 + (bpad_ - n1 * unit + small - 1) / small);
+      }
+    }
     if (getenv("PCX_SM_PROF")) {
       if (!ps_prof_.ptr) { int rc = ps_prof_.alloc((size_t)16 * 65536); if (rc) return rc; }
       if (pgrid.x <= 65536) P.ps_prof = ps_prof_.ptr;

@@ -392,7 +392,20 @@ class Engine(object):
     N.check(N.lib().pcx_engine_state_size(self._native, int(bool(with_observation)), ctypes.byref(n)))
     blob = np.empty((n.value,), np.uint8)
     N.check(N.lib().pcx_engine_export_state(self._native, blob.ctypes.data, n.value, int(bool(with_observation))))
-    return blob
+    # the croppers attached to this engine carry state of their own -- every environment's window corner, the margin
+    # hysteresis of cropping.py:393-426 lives in it -- and, with the observation, their cropped planes: appended in
+    # attachment order behind a trailer [b'PCXT', count, sizes...] (a resumed ScrollingCropper must not re-centre)
+    parts = []
+    for cropper in self._croppers:
+      if getattr(cropper, '_native', None) is None:
+        cropper._create_native()
+      m = N.c_u64(0)
+      N.check(N.lib().pcx_cropper_state_size(cropper._native, int(bool(with_observation)), ctypes.byref(m)))
+      part = np.empty((m.value,), np.uint8)
+      N.check(N.lib().pcx_cropper_export_state(cropper._native, part.ctypes.data, m.value, int(bool(with_observation))))
+      parts.append(part)
+    trailer = np.array([0x54584350, len(parts)] + [p.size for p in parts], np.uint64).view(np.uint8)
+    return np.concatenate([blob] + parts + [trailer, np.array([trailer.size], np.uint64).view(np.uint8)])
 
   def import_state(self, blob):
     """Restores a checkpoint made by an engine of the same template and batch
@@ -400,9 +413,37 @@ class Engine(object):
     are exactly the steps the exporting engine would have taken."""
     self._b  # (raises after close())
     blob = np.ascontiguousarray(blob, np.uint8)
+    parts = []
+    if blob.size >= 24:  # the croppers' trailer (export_state): [magic, count, sizes...] and its own length at the very end
+      tsize = int(blob[-8:].view(np.uint64)[0])
+      if 16 <= tsize <= blob.size - 8 and tsize % 8 == 0:
+        words = blob[-8 - tsize:-8].view(np.uint64)
+        if int(words[0]) == 0x54584350 and words.size == 2 + int(words[1]):
+          sizes = [int(x) for x in words[2:]]
+          end = blob.size - 8 - tsize
+          for size in reversed(sizes):
+            parts.insert(0, blob[end - size:end])
+            end -= size
+          blob = blob[:end]
+    croppers = list(self._croppers)
+    if len(parts) != len(croppers):
+      raise ValueError('the checkpoint holds the state of {} cropper(s), this engine has {} attached: attach the same '
+                       'croppers, in the same order, before import_state()'.format(len(parts), len(croppers)))
+    blob = np.ascontiguousarray(blob)
     N.check(N.lib().pcx_engine_import_state(self._native, blob.ctypes.data, blob.nbytes))
-    self._steps_launched += 1
+    for cropper, part in zip(croppers, parts):
+      if getattr(cropper, '_native', None) is None:
+        cropper._create_native()
+      part = np.ascontiguousarray(part)
+      N.check(N.lib().pcx_cropper_import_state(cropper._native, part.ctypes.data, part.nbytes))
     dev.synchronize(self._device_id)
+    # a fused post-processor's array was written by the exporting engine's step kernel, not by this one: refill it
+    # from the restored observation where there is one; otherwise it counts as not written (the converter falls back
+    # to its own kernel, which raises for an engine that writes no planes) until the next step
+    if self._epilogue is not None:
+      converter, out = self._epilogue
+      restored = bool(blob[48:52].view(np.int32)[0]) if blob.size >= 64 else False  # StateHeader.with_observation
+      converter._after_import(self, out, restored and not self._epilogue_only)
 
   def check_errors(self):
     """Synchronises and raises if a device program hit a condition the
@@ -440,6 +481,7 @@ class Engine(object):
       # converter's call) returns what the step wrote
       sc = None if self._batch > 1 else self._read_scalars()
       stale = self._tag(rendering.Observation(board=None, layers={}))
+      stale._planes_stale = True  # (a post-processor or cropper that would read the engine's planes raises instead)
       if self._batch == 1:
         self.check_errors()
         return stale, (int(sc['reward'][0]) if sc['reward_set'][0] else None), float(sc['discount'][0])

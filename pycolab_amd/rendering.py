@@ -106,6 +106,10 @@ def _source_of(observation):
   if source is None:
     raise TypeError('this post-processor runs on the device and needs an Observation returned by a '
                     'pycolab_amd Engine or cropper')
+  if getattr(observation, '_planes_stale', False):
+    raise RuntimeError('this Observation is a placeholder: its engine no longer writes the full-board planes '
+                       '(fuse_croppers(..., only_crops=True) or fuse_into(..., skip_board=True)); only the fused '
+                       'croppers / the fused converter have something to return')
   return source
 
 
@@ -193,12 +197,19 @@ class ObservationToArray(object):
     d.dtype = _DTYPES[self._dtype.name]
     d.lut = lut.ctypes.data
     d.mapped = mapped.ctypes.data
+    # start from the current observation (environments a later step leaves untouched keep values that match their
+    # board) -- computed BEFORE the kernel's epilogue is switched: if the engine has no planes to start from (an
+    # earlier epilogue with skip_board) the array starts as zeros and nothing is left half-installed
+    try:
+      seed = ObservationToArray(self._value_mapping, self._dtype, self._permute)(engine._result()[0])
+    except RuntimeError:
+      seed = None
     try:
       N.check(N.lib().pcx_engine_set_epilogue(engine._native, ctypes.byref(d)))
     except NotImplementedError:
       return False
-    # start from the current observation (environments a later step leaves untouched keep values that match their board)
-    out.copy_(ObservationToArray(self._value_mapping, self._dtype, self._permute)(engine._result()[0]))
+    if seed is not None:
+      out.copy_(seed)
     engine._install_epilogue(self, out, only=skip_board)  # the ENGINE owns the epilogue (see ObservationToFeatureArray.fuse_into)
     self._fused = (engine, out, engine._steps_launched)
     return True
@@ -210,6 +221,15 @@ class ObservationToArray(object):
 
   def _epilogue_gone(self):
     self._fused = None
+
+  def _after_import(self, engine, out, restored):
+    """Engine.import_state(): `out` holds what the EXPORTING engine's kernel wrote.  With the observation restored it
+    is refilled from the restored planes; without, it counts as not written until the next step."""
+    if restored:
+      out.copy_(ObservationToArray(self._value_mapping, self._dtype, self._permute)(engine._result()[0]))
+      self._fused = (engine, out, engine._steps_launched - 1)
+    else:
+      self._fused = (engine, out, engine._steps_launched)
 
   def __call__(self, observation):
     """Batch 1: a NumPy array as in the reference.  Batch > 1: a device tensor
@@ -304,13 +324,18 @@ class ObservationToFeatureArray(object):
     d.out_dev = out.data_ptr()
     d.skip_layers = 2 if skip_board else int(bool(skip_layers))  # skip_board: not even the board plane (observations carry board=None)
     d.channels_last = int(channels_last)
+    # start from the current observation (environments a later step leaves untouched keep features that match their
+    # planes), computed before the kernel's epilogue is switched (see ObservationToArray.fuse_into)
+    try:
+      seed = ObservationToFeatureArray(self._layers, self._permute)(engine._result()[0])
+    except RuntimeError:
+      seed = None
     try:
       N.check(N.lib().pcx_engine_set_epilogue(engine._native, ctypes.byref(d)))
     except NotImplementedError:
       return False
-    # start from the current observation (environments a later step leaves
-    # untouched keep features that match their planes)
-    out.copy_(ObservationToFeatureArray(self._layers, self._permute)(engine._result()[0]))
+    if seed is not None:
+      out.copy_(seed)
     # The ENGINE owns the epilogue: it keeps this converter and the tensor the
     # kernel writes alive for as long as it may launch (a converter that was
     # garbage-collected would leave the kernel writing freed memory), tells the
@@ -327,6 +352,14 @@ class ObservationToFeatureArray(object):
 
   def _epilogue_gone(self):
     self._fused = None
+
+  def _after_import(self, engine, out, restored):
+    """Engine.import_state(): see ObservationToArray._after_import."""
+    if restored:
+      out.copy_(ObservationToFeatureArray(self._layers, self._permute)(engine._result()[0]))
+      self._fused = (engine, out, engine._steps_launched - 1)
+    else:
+      self._fused = (engine, out, engine._steps_launched)
 
   def __call__(self, observation):
     if self._fused is not None and getattr(observation, '_source', None) is self._fused[0]:
@@ -414,6 +447,12 @@ class ObservationCharacterRepainter(object):
 
   def _epilogue_gone(self):
     self._fused = None
+
+  def _after_import(self, engine, out, restored):
+    """Engine.import_state(): the repainted planes are the exporting engine's; the next call repaints the restored
+    observation with the stand-alone kernel (into the same planes), later ones take what the step kernel writes."""
+    del out, restored
+    self._fused = (engine, engine._steps_launched)
 
   def __call__(self, original_observation):
     fused_now = (self._fused is not None and getattr(original_observation, '_source', None) is self._fused[0] and

@@ -279,3 +279,62 @@ def test_c_abi_gather_scalars_over_rccl():
   for i, name in enumerate(('reward', 'reward_set', 'discount', 'done')):
     np.testing.assert_array_equal(got[i], eng.buffers[name].numpy(), err_msg=name)
   eng.close()
+
+
+@pytest.mark.gpu
+def test_c_abi_gather_two_engines_two_devices():
+  """pcx_gather_create over n = 2 engines on two devices of one process (ncclCommInitAll over both; one grouped
+  ncclAllGather): every device receives both records, each laid out with its own batch.  Needs two GPUs: the
+  one-GPU test box skips it (RCCL refuses two ranks on one device), the 8-GPU node runs it."""
+  import ctypes
+  import torch
+  from pycolab_amd import _native as N
+  if torch.cuda.device_count() < 2:
+    pytest.skip('pcx_gather_create with n = 2 needs two GPUs (this box has %d); the n = 1 path is '
+                'test_c_abi_gather_scalars_over_rccl' % torch.cuda.device_count())
+  lib = N.lib()
+  t = helpers.load_template('scrolly_maze_L0')
+  ct, keep = t.to_ctypes()
+  batches, steps = (1003, 517), 40
+  engines = []
+  for dev, batch in enumerate(batches):
+    h = ctypes.c_void_p()
+    N.check(lib.pcx_engine_create(ctypes.byref(ct), batch, dev, ctypes.byref(h)))
+    N.check(lib.pcx_engine_reset(h, None, None))
+    N.check(lib.pcx_engine_step_hashed(h, 0xABCD, 1000 * dev, 0, steps, 1, None))
+    engines.append(h)
+  g = ctypes.c_void_p()
+  try:
+    arr = (ctypes.c_void_p * 2)(*engines)
+    N.check(lib.pcx_gather_create(arr, 2, ctypes.byref(g)))
+    N.check(lib.pcx_gather_scalars(g, None))
+    want = []
+    for h, batch in zip(engines, batches):
+      bufs = N.Buffers()
+      N.check(lib.pcx_engine_buffers(h, ctypes.byref(bufs)))
+      rec = {}
+      for name, dt in (('reward', np.int32), ('discount', np.float32), ('reward_set', np.uint8), ('done', np.uint8)):
+        rec[name] = np.empty((batch,), dt)
+        N.check(lib.pcx_memcpy_d2h(rec[name].ctypes.data, getattr(bufs, name), rec[name].nbytes))
+      want.append(rec)
+    for dev in range(2):
+      torch.cuda.synchronize(dev)
+      recv, slot = ctypes.c_void_p(), N.c_i64()
+      N.check(lib.pcx_gather_buffers(g, dev, ctypes.byref(recv), ctypes.byref(slot)))
+      assert slot.value == (10 * max(batches) + 15) // 16 * 16
+      host = np.empty((2 * slot.value,), np.uint8)
+      torch.cuda.set_device(dev)
+      N.check(lib.pcx_memcpy_d2h(host.ctypes.data, recv, host.nbytes))
+      for r, batch in enumerate(batches):
+        rec = host[r * slot.value:(r + 1) * slot.value]
+        np.testing.assert_array_equal(rec[:4 * batch].view(np.int32), want[r]['reward'], err_msg='device %d record %d reward' % (dev, r))
+        np.testing.assert_array_equal(rec[4 * batch:8 * batch].view(np.float32), want[r]['discount'])
+        np.testing.assert_array_equal(rec[8 * batch:9 * batch], want[r]['reward_set'])
+        np.testing.assert_array_equal(rec[9 * batch:10 * batch], want[r]['done'])
+  finally:
+    if g:
+      lib.pcx_gather_destroy(g)
+    for h in engines:
+      lib.pcx_engine_destroy(h)
+    torch.cuda.set_device(0)
+  del keep

@@ -16,7 +16,7 @@ from tests.hip_adapter import HipAdapter
 pytestmark = pytest.mark.gpu
 
 KNOBS = ('PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_GRID', 'PCX_SM_PER_CU', 'PCX_COOP_BELOW', 'PCX_SM_WAVES',
-         'PCX_SM_LOCK', 'PCX_SM_CODES')
+         'PCX_SM_LOCK', 'PCX_SM_CODES', 'PCX_SM_TAIL', 'PCX_SM_TAIL_UNIT')
 
 
 class Knobs(object):
@@ -98,6 +98,21 @@ def test_persistent_shapes_match_oracle(shape, unit, dynamic, grid, waves):
       t0 += n
       assert_same(hip, orc, 'shape %d unit %d after step %d' % (shape, unit, t0))
     assert int(orc.read('frame').min()) < T  # episodes ended and restarted inside the run
+
+
+@pytest.mark.parametrize('shape,tail,small', [(3, 2, 16), (3, 3, 8), (1, 1, 32), (2, 2, 16)])
+def test_small_units_at_the_end_of_the_batch(shape, tail, small):
+  """With tickets the batch's last environments go in small units (so that what the workers hold when the tickets run out
+  is short): 20,000 environments on four workgroups -- a few dozen 64-environment units, then units of `small`."""
+  t = helpers.load_template('scrolly_maze_L0')
+  B, T = 20000 + 13, 48
+  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=shape, PCX_SM_GRID=4, PCX_SM_DYNAMIC=1, PCX_SM_TAIL=tail, PCX_SM_TAIL_UNIT=small):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    for t0 in range(0, T, 8):
+      hip.step_hashed(0x5EED, t0, 8); orc.step_hashed(0x5EED, t0, 8)
+      assert shape_of(hip) == shape
+      assert_same(hip, orc, 'shape %d tail %d x %d after step %d' % (shape, tail, small, t0 + 8))
 
 
 @pytest.mark.parametrize('shape', [1, 2, 3])

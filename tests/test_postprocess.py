@@ -504,3 +504,143 @@ def test_fused_epilogue_belongs_to_the_engine():
   assert c.fuse_into(eng)
   eng.close()
   assert c._fused is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['planes kept', 'skip_layers', 'skip_board'])
+@pytest.mark.parametrize('name', POSTED)
+def test_fused_postprocessors_match_reference(name, mode):
+  """The parity chain closed on FUSED outputs: the traces' recorded post-processors (outputs of the reference's own
+  rendering.ObservationToArray / ObservationToFeatureArray / ObservationCharacterRepainter, rendering.py:340-661),
+  each installed as the step kernel's epilogue with fuse_into() -- planes kept, uint8 layers dropped, every plane
+  dropped -- must reproduce the reference's arrays at every recorded frame.  A converter the kernel cannot carry
+  (fuse_into() answers False) is compared through the stand-alone kernel instead, so that nothing is skipped."""
+  from pycolab_amd.engine import Engine
+  tr = helpers.load_trace(name)
+  specs, every = specs_of(tr)
+  t = helpers.load_template(tr['template'])
+  T, E = tr['actions'].shape
+  fused_any = 0
+  for i, sp in enumerate(specs):
+    eng = Engine.from_template(t, batch=E, auto_reset=True, seed=helpers.GOLDEN_RNG_SEED)
+    obs = eng.its_showtime()[0]
+    po = make_post(sp)
+    fused = po.fuse_into(eng, skip_layers=mode == 'skip_layers', skip_board=mode == 'skip_board')
+    fused_any += bool(fused)
+    if not fused and mode != 'planes kept':
+      eng.close()
+      continue  # (the stand-alone kernel is the 'planes kept' leg's business)
+    fi = 0
+    for step in range(T + 1):
+      if step:
+        obs = eng.play(tr['actions'][step - 1])[0]
+      if step == 0 or step % every == 0:
+        want = tr['post_%d' % i][fi]
+        out = po(obs)
+        where = '%s spec %d (%s) %s frame %d' % (name, i, sp['kind'], 'fused' if fused else 'stand-alone', step)
+        if sp['kind'] == 'repaint':
+          np.testing.assert_array_equal(helpers.to_np(out.board), want, err_msg=where)
+          for c, layer in out.layers.items():
+            np.testing.assert_array_equal(helpers.to_np(layer).astype(bool), want == ord(c), err_msg=where + ' layer ' + c)
+        else:
+          got = helpers.to_np(out)
+          assert got.dtype == want.dtype and got.shape == want.shape, (where, got.shape, want.shape)
+          np.testing.assert_array_equal(got, want, err_msg=where)
+        fi += 1
+    eng.close()
+  assert fused_any, 'no recorded post-processor of %s could be fused' % name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['planes kept', 'skip_layers', 'skip_board'])
+@pytest.mark.parametrize('name,n_actions,batch', [('scrolly_maze_L0', 5, 300), ('scrolly_maze_L0', 5, 70000), ('scrolly_maze_L0', 5, 140000),
+                                                  ('marauders', 4, 600), ('hello_world', 4, 400), ('warehouse_custom_B', 5, 700)])
+def test_fused_outputs_match_the_numpy_oracle(name, n_actions, batch, mode):
+  """Every fused converter against oracle/postprocess.py (the numpy restatement pinned on the reference's recorded
+  outputs) instead of against another HIP kernel: value arrays, planar and channels-last feature stacks and the
+  repainter, on the board the same actions produce (a twin engine's, so that the check also holds when the fused engine
+  writes no board at all).  Environments are sampled at large batches; auto-resets and frozen environments included."""
+  import torch
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template(name)
+  chars = [chr(c) for c in t.chars]
+  rng = np.random.RandomState(9)
+  rgb = {c: tuple(int(x) for x in rng.randint(0, 256, size=3)) for c in chars}
+  scal = {c: float(i) * 0.5 - 2.0 for i, c in enumerate(chars)}
+  remap = {chars[0]: '-', chars[1]: chars[2], chars[-1]: 'Z'}
+  sel = ''.join(chars[:5])
+  kinds = [('rgb', lambda: rendering.ObservationToArray(rgb, dtype=np.uint8), lambda b: opost.to_array(b, rgb, np.uint8)),
+           ('scalar', lambda: rendering.ObservationToArray(scal, dtype=np.float32), lambda b: opost.to_array(b, scal, np.float32)),
+           ('features', lambda: rendering.ObservationToFeatureArray(sel),
+            lambda b: opost.feature_array({c: b == ord(c) for c in chars}, list(sel), b.shape)),
+           ('features hwc', lambda: rendering.ObservationToFeatureArray(sel, permute=(1, 2, 0)),
+            lambda b: opost.feature_array({c: b == ord(c) for c in chars}, list(sel), b.shape, (1, 2, 0))),
+           ('repaint', lambda: rendering.ObservationCharacterRepainter(remap), lambda b: opost.repaint(b, chars, remap))]
+  sample = np.unique(np.concatenate([np.arange(min(batch, 96)), rng.randint(0, batch, size=96), np.arange(max(0, batch - 96), batch)]))
+  a = Engine.from_template(t, batch=batch, auto_reset=True, seed=6)
+  b = Engine.from_template(t, batch=batch, auto_reset=True, seed=6)
+  a.its_showtime(); b.its_showtime()
+  a.step_hashed(3, 0, 10); b.step_hashed(3, 0, 10)
+  checked = 0
+  for kind, make, oracle in kinds:
+    po = make()
+    if not po.fuse_into(a, skip_layers=mode == 'skip_layers', skip_board=mode == 'skip_board'):
+      continue
+    for step in range(5):
+      a._auto_reset = b._auto_reset = step % 3 != 2
+      acts = torch.randint(0, n_actions, (batch,), dtype=torch.int32, device='cuda')
+      oa, ob = a.play(acts)[0], b.play(acts)[0]
+      out = po(oa)
+      boards = helpers.to_np(ob.board[torch.from_numpy(sample).to(ob.board.device)]) if batch > 2000 else helpers.to_np(ob.board)[sample]
+      idx = torch.from_numpy(sample).to('cuda')
+      if kind == 'repaint':
+        got_board = helpers.to_np(out.board[idx])
+        got_layers = {c: helpers.to_np(l[idx]) for c, l in out.layers.items()}
+        for j in range(len(sample)):
+          wb, wl = oracle(boards[j])
+          np.testing.assert_array_equal(got_board[j], wb, err_msg='%s %s step %d env %d' % (name, kind, step, sample[j]))
+          assert sorted(got_layers) == sorted(wl)
+          for c in wl:
+            np.testing.assert_array_equal(got_layers[c][j].astype(bool), wl[c], err_msg='%s %s layer %s' % (name, kind, c))
+      else:
+        got = helpers.to_np(out[idx])
+        for j in range(len(sample)):
+          want = oracle(boards[j])
+          assert got[j].dtype == want.dtype and got[j].shape == want.shape, (kind, got[j].shape, want.shape)
+          np.testing.assert_array_equal(got[j], want, err_msg='%s %s step %d env %d' % (name, kind, step, sample[j]))
+      checked += 1
+    po.unfuse()
+  assert checked, 'nothing could be fused into %s' % name
+  a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_device_outputs_cross_dlpack_without_a_copy():
+  """observations, cropped observations and feature arrays are handed on "via DLPack": the device
+  tensors the engine returns export through the DLPack protocol and come back as views of the SAME device memory
+  (no copy, no synchronisation) -- the board, a cropper's planes, a stand-alone and a fused feature array."""
+  import torch
+  from torch.utils import dlpack
+  from pycolab_amd import cropping
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('scrolly_maze_L0')
+  eng = Engine.from_template(t, batch=512, auto_reset=True)
+  crop = cropping.ScrollingCropper(rows=5, cols=11, to_track=['P'], pad_char=' ')
+  crop.set_engine(eng)
+  obs = eng.its_showtime()[0]
+  obs = eng.play(torch.randint(0, 5, (512,), dtype=torch.int32, device='cuda'))[0]
+  cropped = crop.crop(obs)
+  feats = rendering.ObservationToFeatureArray('P@#')(obs)
+  fused = rendering.ObservationToFeatureArray('P@# ')
+  assert fused.fuse_into(eng)
+  obs2 = eng.play(torch.randint(0, 5, (512,), dtype=torch.int32, device='cuda'))[0]
+  for what, ten in (('board', obs2.board), ('layer', obs2.layers['P']), ('cropped board', cropped.board),
+                    ('feature array', feats), ('fused feature array', fused(obs2))):
+    assert isinstance(ten, torch.Tensor) and ten.is_cuda, what
+    back = torch.from_dlpack(dlpack.to_dlpack(ten))
+    assert back.data_ptr() == ten.data_ptr() and back.shape == ten.shape and back.dtype == ten.dtype, what
+    assert back.stride() == ten.stride(), what
+    back2 = torch.from_dlpack(ten)  # (the __dlpack__ protocol a consumer framework calls)
+    assert back2.data_ptr() == ten.data_ptr(), what
+    assert torch.equal(back, ten)
+  eng.close()

@@ -14,11 +14,19 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KNOBS = ('PCX_DEBUG', 'PCX_SM_WAVES', 'PCX_SM_LOCK', 'PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_PER_CU', 'PCX_WAVES_PER_CU', 'PCX_WAVES_PER_WG',
+KNOBS = ('PCX_SM_TAIL', 'PCX_SM_TAIL_UNIT', 'PCX_DEBUG', 'PCX_SM_WAVES', 'PCX_SM_LOCK', 'PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_PER_CU', 'PCX_WAVES_PER_CU', 'PCX_WAVES_PER_WG',
          'PCX_WGS_PER_CU', 'PCX_SM_CODES', 'PCX_SM_PRIO', 'PCX_SM_NB', 'PCX_SM_GRID')
 
 VARIANTS = {
     'auto':        {},
+    'auto_t0':     {'PCX_SM_TAIL': 0},
+    'auto_t1':     {'PCX_SM_TAIL': 1},
+    'auto_t3':     {'PCX_SM_TAIL': 3},
+    'auto_t2_u32': {'PCX_SM_TAIL': 2, 'PCX_SM_TAIL_UNIT': 32},
+    'auto_t2_u8':  {'PCX_SM_TAIL': 2, 'PCX_SM_TAIL_UNIT': 8},
+    'auto_dyn':    {'PCX_SM_DYNAMIC': 1},
+    'auto_dyn_t0': {'PCX_SM_DYNAMIC': 1, 'PCX_SM_TAIL': 0},
+    'auto_static': {'PCX_SM_DYNAMIC': 0},
     'head':        {'PCX_SM_SHAPE': 0},
     'head_w7':     {'PCX_SM_SHAPE': 0, 'PCX_WAVES_PER_CU': 7},
     'A':           {'PCX_SM_SHAPE': 1},
