@@ -271,16 +271,14 @@ int main() {
   const char* names[18] = {"dword seq", "dwordx2 seq", "dwordx4 seq", "9-plane dword", "render loop", "render burst", "loop+state io",
                            "loop+unit-major io", "loop+unit-major ld", "loop+unit-major st", "loop+dma ld", "loop+dma ld (L2)", "loop+dma x4", "loop+dma x4+1",
                            "loop+dma sc1", "loop+dma sc0sc1", "loop+dma nt", "loop+s_load"};
-  for (int rep2 = 0; rep2 < 2; ++rep2)
-  for (int mode : {4, 18, 19, 21})
-    for (int w : {3, 6}) {
+  for (int mode : {0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 18, 19, 21, 35})
+    for (int w : {1, 2, 3, 6, 8}) {
       size_t lds = (160 * 1024 / w) & ~255; if (lds < 64 * 94 * 4) lds = 64 * 94 * 4; const size_t l = lds > 65536 ? 65536 : lds;
       float best = 1e9f;
       for (int rep = 0; rep < 6; ++rep) {
         CHECK(hipEventRecord(e0));
         const dim3 g(256 * w), b(64);
         if (mode == 0) hipLaunchKernelGGL(fill<0>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 1) hipLaunchKernelGGL(fill<1>, g, b, l, 0, dst, n_chunks, ctr, 0);
         if (mode == 2) hipLaunchKernelGGL(fill<2>, g, b, l, 0, dst, n_chunks, ctr, 0);
         if (mode == 3) hipLaunchKernelGGL(fill<3>, g, b, l, 0, dst, n_chunks, ctr, 0);
         if (mode == 4) hipLaunchKernelGGL(fill<4>, g, b, l, 0, dst, n_chunks, ctr, 0);
@@ -292,19 +290,10 @@ int main() {
         if (mode == 10) hipLaunchKernelGGL(fill<10>, g, b, l, 0, dst, n_chunks, ctr, 0);
         if (mode == 11) hipLaunchKernelGGL(fill<11>, g, b, l, 0, dst, n_chunks, ctr, 0);
         if (mode == 12) hipLaunchKernelGGL(fill<12>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 13) hipLaunchKernelGGL(fill<13>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 14) hipLaunchKernelGGL(fill<14>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 15) hipLaunchKernelGGL(fill<15>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 16) hipLaunchKernelGGL(fill<16>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 17) hipLaunchKernelGGL(fill<17>, g, b, l, 0, dst, n_chunks, ctr, 0);
         if (mode == 18) hipLaunchKernelGGL(fill<18>, g, b, l, 0, dst, n_chunks, ctr, 0);
         if (mode == 19) hipLaunchKernelGGL(fill<19>, g, b, l, 0, dst, n_chunks, ctr, 0);
         if (mode == 21) hipLaunchKernelGGL(fill<21>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 22) hipLaunchKernelGGL(fill<22>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 24) hipLaunchKernelGGL(fill<24>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 28) hipLaunchKernelGGL(fill<28>, g, b, l, 0, dst, n_chunks, ctr, 0);
         if (mode == 35) hipLaunchKernelGGL(fill<35>, g, b, l, 0, dst, n_chunks, ctr, 0);
-        if (mode == 50) hipLaunchKernelGGL(fill<50>, g, b, l, 0, dst, n_chunks, ctr, 0);
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (rep > 0 && ms < best) best = ms;
