@@ -192,6 +192,47 @@ def measure_config(game, level, batch, steps, warmup, device, repeats=3):
   return out
 
 
+def measure_step_n(game, level, batch, steps, device, repeats=3):
+  """BASELINE config 2 through `Engine.step_n(tape)`: the launches take several steps each at this batch size (the
+  cooperative instance walks them with the state words in registers; include/pcx.h pcx_engine_step_n) -- every step
+  still writes its full observation.  ms per step by HIP events around the whole tape."""
+  import torch
+  from pycolab_amd import _native as N
+  from pycolab_amd import device as pdev
+  from pycolab_amd.compiler import GameTemplate
+  from pycolab_amd.engine import Engine
+  fixture = FIXTURES[game] % level if '%' in FIXTURES[game] else FIXTURES[game]
+  template = GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', fixture + '.npz'))
+  eng = Engine.from_template(template, batch=batch, device=device, auto_reset=True, seed=0x5EED)
+  eng.its_showtime()
+  g = torch.Generator(device='cuda')
+  g.manual_seed(0x5EED)
+  tape = torch.randint(0, template.n_actions, (steps, batch), dtype=torch.int32, device='cuda', generator=g)
+  stream = pdev.current_stream(device)
+  run = lambda: N.check(N.lib().pcx_engine_step_n(eng._native, tape.data_ptr(), steps, 1, stream))
+  run()
+  runs = []
+  for _ in range(repeats):
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    run()
+    ev1.record()
+    torch.cuda.synchronize(device)
+    runs.append(ev0.elapsed_time(ev1) / steps)
+  ms = median(runs)
+  eng.check_errors()
+  bps = int(N.lib().pcx_engine_bytes_per_step(eng._native))
+  out = {'workload': 'examples/%s, %d envs, Engine.step_n(tape of %d steps): several steps per launch, every step writes its '
+                     'observation' % (fixture, batch, steps),
+         'ms_per_step': ms, 'ms_per_step_min_max': [min(runs), max(runs)], 'env_steps_per_s': batch / (ms * 1e-3),
+         'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(),
+         'launch_shape': int(N.lib().pcx_engine_launch_shape(eng._native)), 'algorithmic_bytes_per_env_step': bps,
+         'hbm_frac': bps * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None}
+  eng.close()
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -447,6 +488,7 @@ def main():
       line['other_configs'] = [measure_config('scrolly_maze', 0, 131072, 200, 20, device),
                                measure_config('scrolly_maze', 0, 262144, 200, 20, device),
                                measure_config('scrolly_maze', 0, 4096, 200, 20, device),
+                               measure_step_n('scrolly_maze', 0, 4096, 1000, device),
                                measure_config('marauders', 0, 32768, 200, 20, device),
                                measure_config('warehouse', 0, 262144, 100, 10, device),
                                measure_config('better_scrolly_maze', 0, 65536, 50, 10, device),

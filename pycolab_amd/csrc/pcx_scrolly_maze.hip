@@ -764,11 +764,15 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   const bool single = PS == 1 || PS == 3 || (PS == 0 && (solo || COOP));  // logic and render of the same group in the same round
   for (int round = (single || PS != 0) ? 0 : -1;; ++round) {
   // TFUSE: the rounds are the launch's steps of one and the same group
-  const int64_t g_render = TFUSE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
+  // COOP (round 4): too -- a cooperative workgroup owns ONE group, and a launch of several steps (StepArgs::n_steps:
+  // pcx_engine_step_n / _step_hashed at small batches) walks them here, the state words staying in registers from
+  // one step to the next (no state-in / state-out chain, no kernel boundary per step)
+  const int64_t g_render = (TFUSE || COOP) ? (int64_t)blockIdx.x : (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
   const int64_t g_logic = (single || TFUSE) ? g_render : g_render + gridDim.x;
-  const int tstep = TFUSE ? round + 1 : 0;  // which of the launch's steps the logic wave is on
-  bool have_render = round >= 0 && g_render < ngroups && (!TFUSE || round < a.n_steps);
-  bool have_logic = g_logic < ngroups && (!TFUSE || tstep < a.n_steps);
+  const int tstep = TFUSE ? round + 1 : COOP ? round : 0;  // which of the launch's steps the logic wave is on
+  const int coop_steps = a.n_steps > 1 ? a.n_steps : 1;
+  bool have_render = round >= 0 && g_render < ngroups && (!TFUSE || round < a.n_steps) && (!COOP || round < coop_steps);
+  bool have_logic = g_logic < ngroups && (!TFUSE || tstep < a.n_steps) && (!COOP || round < coop_steps);
   // the environments this round's logic phase steps / its render phase streams: a group of EPW, or (persistent
   // shapes) a work unit
   int64_t env0_logic = g_logic * EPW, env0_render = g_render * EPW;
@@ -876,6 +880,10 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
       if (ps_un < ps_n) ps_prefetch(ps_un);
     }
   }
+  if constexpr (COOP) {
+    // (steps after the launch's first: their tape action; the state words are in the registers the step before left)
+    if (round > 0 && live && !a.hashed) pre_action = a.actions[(int64_t)tstep * a.action_stride + env];
+  }
   if constexpr (COOP || PS != 0) {  // (asked for at the top of the kernel / taken from the inbox)
     flags = pre_flags; ld_frame = pre_frame; ld_permit = pre_permit; ld_mz = pre_mz; ld_cs = pre_cs;
     ld_stale = pre_stale; ld_sflags = pre_sflags; ld_action = pre_action;
@@ -939,7 +947,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
       sflags = ld_sflags;
 #pragma unroll
       for (int s = 0; s < NS; ++s) spos[s] = ld_spos[s];
-      for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + col] = ((COOP || PS != 0) && i < 4) ? (i == 0 ? pre_cm[0] : i == 1 ? pre_cm[1] : i == 2 ? pre_cm[2] : pre_cm[3]) : st[(W_SPOS + NS + i) * bp];
+      // (a launch's later steps in the cooperative shape: the coin masks are still in LDS, as the step before left them)
+      if (!COOP || round == 0)
+        for (int i = 0; i < k.CW; ++i) l.cmask[i * WAVE + col] = ((COOP || PS != 0) && i < 4) ? (i == 0 ? pre_cm[0] : i == 1 ? pre_cm[1] : i == 2 ? pre_cm[2] : pre_cm[3]) : st[(W_SPOS + NS + i) * bp];
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -1297,6 +1307,15 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
                               ((int)do_reset << 24);
     }
     st[W_SFLAGS * bp] = sf;
+    if constexpr (COOP) {
+      // the next step of this launch (if any) starts from these registers, not from memory
+      pre_flags = flags; pre_frame = (uint32_t)p.frame; pre_permit = (uint32_t)p.permit_frame;
+      pre_mz = pack_pos(maze.r, maze.c); pre_cs = pack_pos(cash.r, cash.c); pre_stale = stale; pre_sflags = sf;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) pre_spos[s] = pack_pos(w[s].vr, w[s].vc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (i < k.CW) pre_cm[i] = l.cmask[i * WAVE + col];
+    }
     if constexpr (FUSABLE) {
       // (a cropper may follow the maze or the cash drape where this lane has exported the raw curtains above: the
       // single-wave shapes; the cooperative shape exports them later, from all waves -- refused on the host)
@@ -2260,14 +2279,15 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   if (fused_.on) use_codes = false;  // the windows are cut from the curtain bit vectors
   int coop_below = 4;  // groups per CU (measured crossover: profiles/r03_tuning.md; round 1: 5)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
-  if (a.n_steps > 1) {
+  const bool old_tfuse = getenv("PCX_TFUSE_OLD") && atoi(getenv("PCX_TFUSE_OLD")) != 0;  // round 1's multi-step instance (A/B)
+  if (a.n_steps > 1 && (!shipped_shape || !fused_ok_ || a.mode != 0 || epi_.out))
+    return set_error(PCX_E_INVALID, "scrolly_maze backend: %d steps in one launch are not available here", a.n_steps);
+  if (a.n_steps > 1 && old_tfuse) {
     // several steps in this launch: the logic wave runs ahead of the render waves
-    if (!shipped_shape || !fused_ok_ || a.mode != 0 || epi_.out)
-      return set_error(PCX_E_INVALID, "scrolly_maze backend: %d steps in one launch are not available here", a.n_steps);
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), dim3((unsigned)groups),
                        dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_, fused_.ptr());
     last_shape_ = 11;
-  } else if (shipped_shape && waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) {
+  } else if (shipped_shape && waves_per_wg == 1 && (groups < (int64_t)num_cus_ * coop_below || a.n_steps > 1)) {
     int coop_waves = groups <= num_cus_ ? 8 : 4;  // at most one group per CU: split the render loop eight ways
     if (const char* e = getenv("PCX_COOP_WAVES")) coop_waves = atoi(e) == 4 ? 4 : 8;
     // ... and while CUs would still stand empty, halve the environments per workgroup (32, 16): the
@@ -2279,7 +2299,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     if (const char* e = getenv("PCX_COOP_EPW")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) epw = v; }
     ac.envs_per_group = epw;
     const unsigned coop_groups = (unsigned)(bpad_ / epw);
-    last_shape_ = 10;
+    last_shape_ = a.n_steps > 1 ? 12 : 10;  // (12: the cooperative shape walking several steps of the launch)
     if (epi_.out) {
       size_t lds_e = (size_t)k_.lds_words * 4;
       const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_e, coop_waves);

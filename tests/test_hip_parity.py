@@ -247,6 +247,42 @@ def test_hip_step_n_fused_and_unfused_match_oracle(fuse, monkeypatch):
   assert_same(hip, orc, 'after the tape')
 
 
+@pytest.mark.parametrize('old_tfuse', ['0', '1'])
+@pytest.mark.parametrize('name,B', [('scrolly_maze_L0', 250), ('scrolly_maze_L0', 4096), ('scrolly_maze_L0', 16384 + 7),
+                                    ('scrolly_maze_L1', 3000), ('scrolly_maze_L2', 2000)])
+def test_hip_several_steps_per_launch_in_the_cooperative_shape(name, B, old_tfuse, monkeypatch):
+  """Round 4: a launch of several steps (pcx_engine_step_n / _step_hashed at small batches) is the cooperative
+  instance walking the steps with the state words in registers -- 16, 32 or 64 environments per workgroup, four lanes
+  per environment at the small end, six coin words (level 2: the words past the fourth stay in LDS) -- against the
+  oracle: odd chunk lengths, chunks that leave finished environments frozen, explicit tapes with quirky actions.
+  PCX_TFUSE_OLD=1 is round 1's multi-step instance, kept for A/B runs."""
+  monkeypatch.setenv('PCX_TFUSE_OLD', old_tfuse)
+  from pycolab_amd import _native as N
+  t = helpers.load_template(name)
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  t0 = 0
+  for i, n in enumerate((1, 2, 3, 9, 64, 5, 200, 31)):
+    auto = i % 3 != 2
+    hip.step_hashed(0xABCD, t0, n, auto_reset=auto); orc.step_hashed(0xABCD, t0, n, auto_reset=auto)
+    if n > 1:
+      assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == (11 if old_tfuse == '1' else 12)
+    t0 += n
+    assert_same(hip, orc, '%s x %d after %d steps (chunk %d)' % (name, B, t0, n))
+  rng = np.random.RandomState(11)
+  tape = rng.randint(0, 5, size=(41, B)).astype(np.int32)
+  r = rng.rand(41, B)
+  tape[r < 0.03] = -1
+  tape[(r >= 0.03) & (r < 0.04)] = 5
+  tape[(r >= 0.04) & (r < 0.06)] = 17
+  for auto in (True, False):
+    hip.eng._auto_reset = auto
+    hip.eng.step_n(tape)
+    for row in tape:
+      orc.step(row, auto_reset=auto)
+    assert_same(hip, orc, '%s x %d after the tape (auto_reset %s)' % (name, B, auto))
+
+
 @pytest.mark.parametrize('name', ['scrolly_maze_L1', 'scrolly_custom_B', 'warehouse_L1', 'marauders', 'hello_world',
                                   'better_scrolly_maze_L1', 'walkers_scroll_margins', 'marauders_unoccluded'])
 def test_hip_matches_oracle_quirky_actions(name):
