@@ -113,6 +113,19 @@ def _source_of(observation):
   return source
 
 
+# Where the general epilogue body loses to step + stand-alone kernel (profiles/r04_post_kernels.md: scrolly_maze at
+# 1,048,576 environments, value array next to the planes 1.33 against 0.95 ms, repainter 1.94 against 1.42; hello_world
+# at 262,144: 0.40 / 0.36 and 0.64 / 0.51) and where it wins (4,096: 0.018 / 0.027; marauders 32,768: 0.059 / 0.071):
+# the dividing line is whether the step's own planes still fit the 256 MiB Infinity Cache -- beyond it the separate
+# kernel streams the board back at cache speed while the fused body is bound by its scalar bookkeeping.
+_FUSED_BODY_PAYS_UP_TO = 256 << 20
+
+
+def _general_epilogue_pays(engine):
+  """Do this engine's observation planes fit the Infinity Cache (the fused value-array / repainter body wins)?"""
+  return engine.batch * (1 + len(engine.template.chars)) * engine._pitch <= _FUSED_BODY_PAYS_UP_TO
+
+
 def _strides(shape3, permute):
   """Element strides of (d, r, c) in the contiguous array whose axes are
   `permute` of (d, r, c) -- np.transpose(result, permute) made contiguous."""
@@ -157,7 +170,7 @@ class ObservationToArray(object):
     self._post = None
     self._fused = None  # (engine, device tensor, step count) once fuse_into() succeeded
 
-  def fuse_into(self, engine, skip_layers=False, skip_board=False):
+  def fuse_into(self, engine, skip_layers=False, skip_board=False, force=False):
     """Have `engine`'s step kernel write this array itself, as an epilogue of
     its render loop (the board dword is in a register there, the value table in
     LDS): from the next `play()` / `step()` on, calling this object with one of
@@ -170,11 +183,16 @@ class ObservationToArray(object):
     for step + post-processor).  Returns False, and changes nothing, where the
     engine's kernel cannot do it (batch 1, a permuted axis order, boards that
     are not a whole number of dwords, a character of the game without a value,
-    the table-driven kernel, unoccluded layers, fused croppers): calls then run
-    the post-processor as its own kernel, as before."""
+    the table-driven kernel, unoccluded layers, fused croppers) -- or where it
+    would be SLOWER than the two kernels: with the planes kept (or only the
+    layers dropped) on batches whose planes no longer fit the Infinity Cache
+    (`_general_epilogue_pays`; `force=True` fuses regardless, for A/B runs).
+    Calls then run the post-processor as its own kernel, as before."""
     torch = dev.torch_module()
     identity = self._permute is None or tuple(self._permute) == tuple(range(len(self._permute)))
     if not identity or torch is None or engine._native is None or engine.batch == 1:
+      return False
+    if not (force or skip_board or _general_epilogue_pays(engine)):
       return False
     tdtype = getattr(torch, self._dtype.name)
     shape = (self._depth, engine.rows, engine.cols) if self._is_3d else (engine.rows, engine.cols)
@@ -398,7 +416,7 @@ class ObservationCharacterRepainter(object):
     self._repainted = None
     self._fused = None  # (engine, step count) once fuse_into() succeeded
 
-  def fuse_into(self, engine, skip_layers=False, skip_board=False):
+  def fuse_into(self, engine, skip_layers=False, skip_board=False, force=False):
     """Have `engine`'s step kernel write the repainted observation itself (the
     board dword through the character table, every output layer by a byte-wise
     compare): from the next `play()` / `step()` on, calling this object with
@@ -408,9 +426,13 @@ class ObservationCharacterRepainter(object):
     no longer writes the original layer planes / any original plane.  Returns
     False, and changes nothing, where the engine's kernel cannot do it (batch
     1, boards that are not a whole number of dwords, the table-driven kernel,
-    unoccluded layers, fused croppers)."""
+    unoccluded layers, fused croppers) or where it would be slower than step +
+    stand-alone kernel: batches whose planes no longer fit the Infinity Cache
+    (`_general_epilogue_pays`; `force=True` fuses regardless)."""
     torch = dev.torch_module()
     if torch is None or engine._native is None or engine.batch == 1:
+      return False
+    if not (force or _general_epilogue_pays(engine)):
       return False
     obs = engine._result()[0]
     if obs.board is None:

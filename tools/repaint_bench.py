@@ -37,7 +37,7 @@ for name, batch in (('marauders', 32768), ('scrolly_maze_L0', 4096), ('scrolly_m
       conv(obs)
       fn = lambda: (one(), conv(obs))
     else:
-      assert conv.fuse_into(eng, skip_board=mode != 'fused')
+      assert conv.fuse_into(eng, skip_board=mode != 'fused', force=True)
       fn = one
     res.append(sorted(timed(fn, 50 if batch > 500000 else 100) for _ in range(3))[1])
     eng.close()

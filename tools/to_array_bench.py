@@ -42,7 +42,7 @@ for name, batch in (('scrolly_maze_L0', 1048576), ('scrolly_maze_L0', 4096), ('m
         conv(obs)
         fn = lambda: (one(), conv(obs))
       else:
-        assert conv.fuse_into(eng, skip_layers=mode != 'fused', skip_board=mode == 'fused, skip_board')
+        assert conv.fuse_into(eng, skip_layers=mode != 'fused', skip_board=mode == 'fused, skip_board', force=True)
         fn = one
       res.append(sorted(timed(fn, 50 if batch > 500000 else 100) for _ in range(3))[1])
       eng.close()
