@@ -515,6 +515,16 @@ typedef struct pcx_epilogue_desc {
   const uint8_t* mapped;  /* [128] */
 } pcx_epilogue_desc;
 int pcx_engine_set_epilogue(pcx_engine* e, const pcx_epilogue_desc* d);
+/* Crop, THEN post-process, in the step kernel's launch -- the order the reference's own pipeline has
+ * (human_ui.py:252-265 crop_and_repaint; better_scrolly_maze.py:237-247 followed by rendering.py:545-661): a cropper
+ * that is fused into its engine's step kernel (pcx_engine_fuse_croppers) also writes the float32 feature stack of ITS
+ * WINDOW -- out_dev [batch][depth][rows*cols] of the window (channels_last: [batch][rows*cols][depth]), layer k = window
+ * board == chars[k] -- from the window's board dword while it is in a register.  skip_layers 1: the window's uint8
+ * layer planes are no longer written, 2: nor its board plane (with only_crops the launch then writes
+ * rows*cols*depth*4 bytes per environment and nothing else of the observation).  depth <= 16; to_array / lut unused.
+ * d == NULL clears.  PCX_E_STATE: the cropper is not fused; PCX_E_UNSUPPORTED: the table-driven kernel (its window
+ * loop is its own), a layer stacked twice.  The stack stays attached while the cropper is fused. */
+int pcx_cropper_set_features(pcx_cropper* c, const pcx_epilogue_desc* d);
 
 /* out_dev: TO_ARRAY/FEATURE_ARRAY [batch][depth*rows*cols] elements; REPAINT a
  * planes array [batch][1 + depth][pitch], pitch = pcx_post_plane_pitch() =

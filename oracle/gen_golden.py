@@ -184,6 +184,17 @@ POST = {  # keyed by trace name: post-processor specs (JSON-able)
 }
 POST_EVERY = 8  # frames between recorded post-processor outputs
 
+# crop, THEN post-process (human_ui.py:252-265; better_scrolly_maze.py:237-247 into rendering.py:545-661): the
+# post-processor of the second element applied to what cropper #first returned, recorded at the POST frames
+CROP_POST = {  # keyed by trace name: [(index into CROPPERS[name], post-processor spec)]
+    'better_scrolly_maze_L0': [(0, dict(kind='features', layers='P@#abc +', permute=None)),
+                               (0, dict(kind='features', layers='@P#a', permute=[1, 2, 0])),
+                               (1, dict(kind='features', layers='P#', permute=None))],
+    'warehouse_L1': [(1, dict(kind='features', layers='P.#1_x', permute=None)),     # 7 x 7 window, padded with '.': 49 cells
+                     (3, dict(kind='features', layers='XP _', permute=[1, 2, 0]))],  # 3 x 9, padded with ' '
+    'marauders': [(1, dict(kind='features', layers='aPyB |', permute=None))],        # 9 x 11 = 99 cells, egocentric on a / y / P
+}
+
 
 def make_reference_post(spec):
   from pycolab import rendering
@@ -220,6 +231,8 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
   crops = [[] for _ in specs]
   post_specs = POST.get(name, [])
   posts = [[] for _ in post_specs]
+  crop_post_specs = CROP_POST.get(name, [])
+  crop_posts = [[] for _ in crop_post_specs]
   actions = np.zeros((T, E), np.int32)
   chars = sprite_chars = None
   for e in range(E):
@@ -232,12 +245,22 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
     croppers = make_reference_croppers(specs)
     env_crops = [[] for _ in specs]
 
+    last_crop = [None] * len(specs)
+
     def crop_all(obs):
       for i, cr in enumerate(croppers):
         out = cr.crop(obs)
         for c in chars:  # cropped layers stay board == c (pad included)
           assert np.array_equal(out.layers[c], out.board == ord(c)), (name, i, c)
         env_crops[i].append(out.board.copy())
+        last_crop[i] = out
+
+    crop_post_objs = [make_reference_post(sp) for _, sp in crop_post_specs]
+    env_crop_posts = [[] for _ in crop_post_specs]
+
+    def crop_post_all():
+      for i, ((ci, sp), po) in enumerate(zip(crop_post_specs, crop_post_objs)):
+        env_crop_posts[i].append(np.array(po(last_crop[ci])).copy())
 
     post_objs = [make_reference_post(sp) for sp in post_specs]
     env_posts = [[] for _ in post_specs]
@@ -263,6 +286,7 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
     rec.append(record(obs, r, d, game, chars, sprite_chars))
     crop_all(obs)
     post_all(obs)
+    crop_post_all()
     for t in range(T):
       if game.game_over:
         game = make_game()
@@ -280,8 +304,11 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
       crop_all(obs)
       if (t + 1) % POST_EVERY == 0:
         post_all(obs)
+        crop_post_all()
     for i in range(len(post_specs)):
       posts[i].append(env_posts[i])
+    for i in range(len(crop_post_specs)):
+      crop_posts[i].append(env_crop_posts[i])
     for i in range(len(specs)):
       crops[i].append(env_crops[i])
     boards.append([x[0] for x in rec]); rewards.append([x[1] for x in rec])
@@ -299,6 +326,10 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
   for i in range(len(post_specs)):
     extra['post_%d' % i] = np.ascontiguousarray(np.swapaxes(np.array(posts[i]), 0, 1))  # [frames, E, ...]
   extra['post_specs'] = np.frombuffer(json.dumps(post_specs).encode(), np.uint8)
+  for i in range(len(crop_post_specs)):
+    extra['crop_post_%d' % i] = np.ascontiguousarray(np.swapaxes(np.array(crop_posts[i]), 0, 1))  # [frames, E, ...]
+  if crop_post_specs:
+    extra['crop_post_specs'] = np.frombuffer(json.dumps([[ci, sp] for ci, sp in crop_post_specs]).encode(), np.uint8)
   extra['post_every'] = np.array([POST_EVERY])
   if unoccluded:
     extra['layers'] = sw(layers, np.uint8)  # [T+1, E, L, R, C]

@@ -164,6 +164,7 @@ SYMBOLS = [
     ('pcx_cropper_buffers', c_i32, [_VP, ctypes.POINTER(_VP), ctypes.POINTER(_VP)]),
     ('pcx_cropper_errors', c_i32, [_VP, _VP]),
     ('pcx_cropper_plane_pitch', c_i32, [_VP]),
+    ('pcx_cropper_set_features', c_i32, [_VP, _VP]),
     ('pcx_cropper_state_size', c_i32, [_VP, c_i32, ctypes.POINTER(c_u64)]),
     ('pcx_cropper_export_state', c_i32, [_VP, _VP, c_u64, c_i32]),
     ('pcx_cropper_import_state', c_i32, [_VP, _VP, c_u64]),

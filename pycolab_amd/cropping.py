@@ -31,6 +31,9 @@ class ObservationCropper(object):
     self._pitch = 0
     self._generation = 0    # bumped whenever the native cropper (and its buffers) is rebuilt
     self._fused = False     # the engine's step kernel moves the window and writes the planes (fuse_croppers)
+    self._features = None   # (converter, float tensor): the window's feature stack the step kernel writes too
+                            # (rendering.ObservationToFeatureArray.fuse_into(engine, source=cropper)); the cropper
+                            # holds the tensor for as long as the kernel may write it
 
   def set_engine(self, engine):
     if engine is not self._engine:
@@ -52,6 +55,7 @@ class ObservationCropper(object):
     all of them (a device cropper holds ONE engine's window state)."""
     other = copy.copy(self)
     other._engine, other._native, other._out, other._fused = None, None, None, False
+    other._features = None
     other._generation = 0
     return other
 
@@ -73,6 +77,9 @@ class ObservationCropper(object):
       self._native = None
       self._out = None
       self._fused = False
+      if self._features is not None:
+        self._features[0]._window_gone()
+        self._features = None
       self._generation += 1
 
   def __del__(self):

@@ -348,6 +348,7 @@ class BetterScrollyBackend : public Backend {
   }
   int plane_pitch() const override { return lay_.pitch; }
   int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc, false, R_, C_); }
+  bool fused_window_features() const override { return true; }
   size_t base_lds_bytes() const {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
     return ((size_t)lay_.QW * (2 + NB) + lay_.FW + WAVE * (MAX_CW | 1) + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4;
   }

@@ -217,6 +217,10 @@ struct pcx_cropper {
   // a checkpoint restored the window but not the output planes (pcx_cropper_import_state): the next crop() cuts them
   // from the engine's restored observation with the stand-alone kernels, also while the step kernel runs this cropper
   bool refresh = false;
+  // the window's fused float32 feature stack (pcx_cropper_set_features), written by the step kernel while fused
+  float* feat = nullptr;
+  int feat_depth = 0, feat_hwc = 0, feat_skip = 0;
+  uint8_t feat_ch[pcx::crop::MAX_FUSED_FEATURES] = {};
   uint8_t* out_planes() const { return bound ? bound : planes.ptr; }
   int ensure_planes() {  // own output planes only when the caller bound none
     if (bound || planes.ptr) return 0;
@@ -296,6 +300,8 @@ static int push_fused(pcx_engine* e) {
     w.out_pitch = p.out_pitch;
     w.pad_planes = 0;
     for (int k = 0; k < p.L; ++k) if (p.pad_char >= 0 && (uint32_t)p.pad_char == p.chars[k]) w.pad_planes |= 1u << k;
+    w.feat = c->feat; w.feat_depth = c->feat_depth; w.feat_hwc = c->feat_hwc; w.feat_skip = c->feat ? c->feat_skip : 0;
+    for (int k = 0; k < pcx::crop::MAX_FUSED_FEATURES; ++k) w.feat_ch[k] = c->feat_ch[k];
   }
   return e->backend->set_fused_croppers(&fc);
 }
@@ -355,6 +361,41 @@ int pcx_engine_fuse_croppers(pcx_engine* e, pcx_cropper* const* croppers, int32_
     if (e->showtime && !was_fused(c))
       if (int rc = pcx_cropper_crop(c, stream)) return rc;
     c->fused = true;
+  }
+  return 0;
+}
+
+int pcx_cropper_set_features(pcx_cropper* c, const pcx_epilogue_desc* d) {
+  if (!c) return set_error(PCX_E_INVALID, "pcx_cropper_set_features: null cropper");
+  pcx_engine* e = c->e;
+  PCX_HIP(hipSetDevice(e->device));
+  if (d) {
+    if (!c->fused) return set_error(PCX_E_STATE, "pcx_cropper_set_features: the cropper is not fused into its engine's step kernel (pcx_engine_fuse_croppers)");
+    if (!e->backend->fused_window_features())
+      return set_error(PCX_E_UNSUPPORTED, "%s does not write a fused window's feature stack", e->backend->kernel_name());
+    if (d->depth < 1 || d->depth > pcx::crop::MAX_FUSED_FEATURES || !d->out_dev || (reinterpret_cast<uintptr_t>(d->out_dev) & 15u) || d->to_array)
+      return set_error(PCX_E_INVALID, "pcx_cropper_set_features: bad descriptor (1..%d layers, a 16-byte aligned float32 array, no value table)", pcx::crop::MAX_FUSED_FEATURES);
+    if ((uint64_t)64 * d->depth * c->p.rows * c->p.cols * 4 >= (1ull << 32))
+      return set_error(PCX_E_UNSUPPORTED, "pcx_cropper_set_features: window x depth too large for 32-bit lane offsets");
+    for (int i = 0; i < d->depth; ++i)
+      for (int j = 0; j < i; ++j)
+        if (d->chars[i] == d->chars[j]) return set_error(PCX_E_UNSUPPORTED, "pcx_cropper_set_features: a layer is stacked twice");
+  }
+  const auto before_feat = c->feat;
+  const int before_depth = c->feat_depth, before_hwc = c->feat_hwc, before_skip = c->feat_skip;
+  uint8_t before_ch[pcx::crop::MAX_FUSED_FEATURES];
+  memcpy(before_ch, c->feat_ch, sizeof before_ch);
+  c->feat = d ? d->out_dev : nullptr;
+  c->feat_depth = d ? d->depth : 0;
+  c->feat_hwc = d ? d->channels_last != 0 : 0;
+  c->feat_skip = d ? d->skip_layers : 0;
+  memset(c->feat_ch, 0, sizeof c->feat_ch);
+  for (int i = 0; d && i < d->depth; ++i) c->feat_ch[i] = d->chars[i];
+  if (!c->fused) return 0;  // (cleared on a cropper that is on its own: nothing to tell the kernel)
+  if (int rc = push_fused(e)) {  // refused: nothing changed
+    c->feat = before_feat; c->feat_depth = before_depth; c->feat_hwc = before_hwc; c->feat_skip = before_skip;
+    memcpy(c->feat_ch, before_ch, sizeof before_ch);
+    return rc;
   }
   return 0;
 }

@@ -77,6 +77,7 @@ __device__ __forceinline__ bool window_leaves_observation(const WindowRule& p, i
 // _do_crop (cropping.py:118-227) without a second pass over the observation.
 constexpr int MAX_FUSED_CROPPERS = 4;
 constexpr int MAX_FUSED_TRACK = 4;
+constexpr int MAX_FUSED_FEATURES = 16;  // layers of a window's fused feature stack
 
 struct FusedWindow {
   uint8_t* out;         // [batch][1 + L][out_pitch]: the cropper's output planes
@@ -91,6 +92,14 @@ struct FusedWindow {
   int32_t track_kind[MAX_FUSED_TRACK];    // 0 sprite (its position while visible), 1 drape (median of its curtain, :590-598)
   int32_t out_pitch;    // bytes per output plane (rows * cols rounded up to 4)
   uint32_t pad_planes;  // bit k: layer k (plane 1 + k) is 1 where the pad character fills (pad_char == chars[k])
+  // crop -> post-process in the same launch (pcx_cropper_set_features; human_ui.py:252-265, better_scrolly_maze.py:
+  // 237-247 -> rendering.py:545-661): the float32 stack of `feat_depth` layers OF THE WINDOW, [batch][depth][rows x cols]
+  // (feat_hwc: [batch][rows x cols][depth]), written by the loop that has the window's board dword in a register.
+  // feat_skip: 1 the window's uint8 layer planes are not written, 2 nor its board plane.  Kernels built on
+  // pcx_stream.h stream_windows only (Backend::fused_window_features).
+  float* feat;
+  int32_t feat_depth, feat_hwc, feat_skip;
+  uint8_t feat_ch[MAX_FUSED_FEATURES];
 };
 
 struct FusedCrops {

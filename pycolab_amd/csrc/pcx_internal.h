@@ -162,6 +162,8 @@ class Backend {
   // kernel cannot answer PCX_E_UNSUPPORTED (the croppers then run as their own
   // kernels, pcx_crop.hip).
   virtual int set_fused_croppers(const crop::FusedCrops* fc);
+  // include/pcx.h pcx_cropper_set_features: does the kernel's window loop also write a window's float32 feature stack?
+  virtual bool fused_window_features() const { return false; }
   // the installed epilogue's kernel arguments (the engine hangs the ObservationToArray value table in), null: none
   virtual stream::EpilogueArgs* epilogue_args() { return nullptr; }
 };

@@ -485,6 +485,7 @@ class MaraudersBackend : public Backend {
   }
   int plane_pitch() const override { return pitch; }
   int set_fused_croppers(const crop::FusedCrops* fc) override { return fused_.set(fc, false, R, C); }
+  bool fused_window_features() const override { return true; }
   static size_t base_lds_bytes() {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
     return ((size_t)QW * (1 + NB) + (ND + 1) * WAVE * FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS) * 4;
   }

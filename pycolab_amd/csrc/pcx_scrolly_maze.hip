@@ -1890,6 +1890,7 @@ class ScrollyMazeBackend : public Backend {
   int max_fused_steps() const override { return fused_ok_ && !epi_.out && !fused_.on ? 256 : 1; }  // the epilogue / fused croppers have no multi-step instance
   // include/pcx.h pcx_engine_fuse_croppers: the instances that render from curtain bit vectors + sprite
   // descriptors cut the windows too (pcx_stream.h stream_windows); the owner-code and multi-step instances step aside
+  bool fused_window_features() const override { return true; }
   int set_fused_croppers(const crop::FusedCrops* fc) override {
     if (fc && fc->n > 0 && (unoccluded_ || epi_.out))
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: fused croppers need occluded layers and no feature-array epilogue");

@@ -689,14 +689,45 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
       if (active) {
         const uint32_t voff = e * ostride + 4u * q;
         auto put = [&](uint8_t* base, uint32_t v) { saddr_store_dword<true>(voff, v, base); };  // (compute-bound loop)
-        put(obase, od);
+        const int fskip = fw.feat ? fw.feat_skip : 0;
+        if (fskip < 2) put(obase, od);
+        if (fskip < 1) {
 #pragma unroll
-        for (int d = 0; d < ND; ++d) put(pb_d[d], eq01(od, pm.drape_ch4[d]));
+          for (int d = 0; d < ND; ++d) put(pb_d[d], eq01(od, pm.drape_ch4[d]));
 #pragma unroll
-        for (int s = 0; s < NS; ++s) put(pb_s[s], eq01(od, pm.sprite_ch4[s]));
+          for (int s = 0; s < NS; ++s) put(pb_s[s], eq01(od, pm.sprite_ch4[s]));
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-          if (b < nbv) put(pb_b[b], eq01(od, bchar_ch4[b]));
+          for (int b = 0; b < NB; ++b)
+            if (b < nbv) put(pb_b[b], eq01(od, bchar_ch4[b]));
+        }
+        if (fw.feat) {
+          // crop -> post-process in this launch: the window's feature stack (rendering.py:610-661 on the cropped
+          // observation): layer k of the window is (window board == feat_ch[k]), as float32.  The window's cells
+          // are rows x cols exactly (no plane padding in the array): its last dword may hold fewer than four.
+          const uint32_t wcells = (uint32_t)(rows * cols), depth = (uint32_t)fw.feat_depth;
+          const uint32_t valid = wcells - 4u * q >= 4u ? 4u : wcells - 4u * q;
+          uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(fw.feat) + (size_t)env0 * depth * wcells * 4u);
+          const uint32_t fenv = e * depth * wcells * 4u;
+          if (!fw.feat_hwc) {
+            for (uint32_t kk = 0; kk < depth; ++kk) {
+              const uint32_t m = eq01(od, (uint32_t)fw.feat_ch[kk] * 0x01010101u);
+              const uint32_t fo = fenv + (kk * wcells + 4u * q) * 4u;
+              if (valid == 4u) {
+                f32x4 f;
+                f.x = (float)(m & 0xFFu); f.y = (float)((m >> 8) & 0xFFu); f.z = (float)((m >> 16) & 0xFFu); f.w = (float)(m >> 24);
+                saddr_store_dwordx4<true>(fo, f, fbase);
+              } else {
+                for (uint32_t j = 0; j < valid; ++j) *reinterpret_cast<float*>(fbase + fo + 4u * j) = (float)((m >> (8u * j)) & 0xFFu);
+              }
+            }
+          } else {
+            for (uint32_t j = 0; j < valid; ++j) {
+              const uint32_t ch = (od >> (8u * j)) & 0xFFu;
+              float* const cellp = reinterpret_cast<float*>(fbase + fenv + (4u * q + j) * depth * 4u);
+              for (uint32_t kk = 0; kk < depth; ++kk) cellp[kk] = ch == (uint32_t)fw.feat_ch[kk] ? 1.0f : 0.0f;
+            }
+          }
+        }
       }
     }
   }

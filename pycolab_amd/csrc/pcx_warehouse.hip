@@ -352,6 +352,7 @@ class WarehouseBackend : public Backend {
     out.push_back({track_.ptr, track_.count * sizeof(int32_t)});
   }
   int plane_pitch() const override { return lay_.pitch; }
+  bool fused_window_features() const override { return true; }
   int set_fused_croppers(const crop::FusedCrops* fc) override {
     if (fc && fc->n > 0 && unoccluded_)  // (the windows derive their layers from the board they cut)
       return set_error(PCX_E_UNSUPPORTED, "warehouse backend: fused croppers need occluded layers");

@@ -312,8 +312,9 @@ class ObservationToFeatureArray(object):
       raise NotImplementedError('more than {} layers'.format(N.POST_MAX_DEPTH))
     self._post = None
     self._fused = None  # (engine, device tensor) once fuse_into() succeeded
+    self._fused_window = None  # (cropper, device tensor, step count): fuse_into(engine, source=cropper)
 
-  def fuse_into(self, engine, skip_layers=False, skip_board=False):
+  def fuse_into(self, engine, skip_layers=False, skip_board=False, source=None):
     """Have `engine`'s step kernel write this feature array itself, as an
     epilogue of its render loop (the layer masks are in registers there):
     from the next `play()` / `step()` on, calling this object with one of the
@@ -327,7 +328,24 @@ class ObservationToFeatureArray(object):
     last, `permute=(1, 2, 0)` -- the latter on boards of whole dwords): calls
     then run the post-processor as its own kernel, as before.  The
     engine owns the installed epilogue: when this object goes away, or another
-    post-processor fuses, the kernel stops writing into this one's tensor."""
+    post-processor fuses, the kernel stops writing into this one's tensor.
+
+    `source=cropper` -- crop, THEN post-process, in the one launch (the order
+    of the reference's pipeline: human_ui.py:252-265, better_scrolly_maze.py:
+    237-247 into rendering.py:545-661): `cropper` must be fused into the
+    engine's step kernel (`cropping.fuse_croppers`); the kernel then also
+    writes the feature stack OF ITS WINDOW, [B, depth, rows, cols] of the
+    window (channels last: [B, rows, cols, depth]), and calling this object
+    with one of the cropper's observations returns that tensor.  Here
+    `skip_layers` / `skip_board` stop the kernel from writing the WINDOW's
+    uint8 layer planes / board plane (with `fuse_croppers(..., only_crops=
+    True)` a learner that ingests the egocentric feature stack gets exactly
+    that and nothing else: better_scrolly_maze, 10x30 window of the 45x89
+    board, eight layers: 9.6 KB per environment instead of 32 KB of planes
+    plus a second pass).  False for the table-driven kernel, more than 16
+    layers, a cropper that is not fused."""
+    if source is not None:
+      return self._fuse_into_window(engine, source, skip_layers, skip_board)
     torch = dev.torch_module()
     if (self._permute not in (None, (0, 1, 2), (1, 2, 0)) or torch is None or engine._native is None or engine.batch == 1 or
         len(set(self._layers)) != len(self._layers) or any(ord(c) > 255 for c in self._layers)):
@@ -367,9 +385,47 @@ class ObservationToFeatureArray(object):
     the post-processor as its own kernel)."""
     if self._fused is not None:
       self._fused[0]._clear_epilogue(self)
+    if self._fused_window is not None:
+      cropper = self._fused_window[0]
+      if cropper._native is not None:
+        N.check(N.lib().pcx_cropper_set_features(cropper._native, None))
+      cropper._features = None
+      self._fused_window = None
 
   def _epilogue_gone(self):
     self._fused = None
+
+  def _fuse_into_window(self, engine, cropper, skip_layers, skip_board):
+    torch = dev.torch_module()
+    if (torch is None or engine._native is None or engine.batch == 1 or cropper._engine is not engine or not cropper._fused or
+        cropper._native is None or self._permute not in (None, (0, 1, 2), (1, 2, 0)) or
+        len(set(self._layers)) != len(self._layers) or any(ord(c) > 255 for c in self._layers) or self._depth > 16):
+      return False
+    channels_last = self._permute == (1, 2, 0)
+    shape = (cropper.rows, cropper.cols, self._depth) if channels_last else (self._depth, cropper.rows, cropper.cols)
+    out = torch.zeros((engine.batch,) + shape, dtype=torch.float32, device='cuda:%d' % engine._device_id)
+    d = N.EpilogueDesc()
+    d.depth = self._depth
+    for i, ch in enumerate(self._layers):
+      d.chars[i] = ord(ch)
+    d.out_dev = out.data_ptr()
+    d.skip_layers = 2 if skip_board else int(bool(skip_layers))
+    d.channels_last = int(channels_last)
+    # (the window as it stands, through the stand-alone kernel: environments a later step leaves alone keep it)
+    seed = ObservationToFeatureArray(self._layers, self._permute)(cropper.crop(None))
+    try:
+      N.check(N.lib().pcx_cropper_set_features(cropper._native, ctypes.byref(d)))
+    except NotImplementedError:
+      return False
+    out.copy_(seed)
+    if cropper._features is not None and cropper._features[0] is not self:
+      cropper._features[0]._window_gone()
+    cropper._features = (self, out)
+    self._fused_window = (cropper, out, engine._steps_launched)
+    return True
+
+  def _window_gone(self):
+    self._fused_window = None
 
   def _after_import(self, engine, out, restored):
     """Engine.import_state(): see ObservationToArray._after_import."""
@@ -380,6 +436,10 @@ class ObservationToFeatureArray(object):
       self._fused = (engine, out, engine._steps_launched)
 
   def __call__(self, observation):
+    if self._fused_window is not None and getattr(observation, '_source', None) is self._fused_window[0]:
+      cropper, out, attached_at = self._fused_window
+      if cropper._fused and cropper._engine is not None and cropper._engine._steps_launched > attached_at:
+        return out  # the step kernel cut the window and wrote its stack
     if self._fused is not None and getattr(observation, '_source', None) is self._fused[0]:
       engine, out, attached_at = self._fused
       if engine._steps_launched > attached_at:  # a step has run since: the kernel wrote `out`

@@ -518,3 +518,111 @@ def test_the_kernels_drape_median_is_the_references():
     got = _centroid_like_the_kernels(curtain)
     want = tuple(int(np.median(dim)) for dim in curtain.nonzero()) if curtain.any() else None
     assert got == want, (R, C, density, got, want)
+
+
+# ---- crop, THEN post-process (human_ui.py:252-265; better_scrolly_maze.py:237-247 into rendering.py:545-661) ----------
+CROP_POSTED = ['better_scrolly_maze_L0', 'warehouse_L1', 'marauders']
+
+
+def crop_post_specs_of(trace):
+  return [(int(ci), sp) for ci, sp in json.loads(bytes(trace['crop_post_specs']).decode())]
+
+
+def _post_frames(T, every):
+  return [0] + [t for t in range(1, T + 1) if t % every == 0]
+
+
+@pytest.mark.parametrize('name', CROP_POSTED)
+def test_oracle_feature_stack_of_a_cropped_observation_matches_reference(name):
+  """The numpy restatement of ObservationToFeatureArray (oracle/postprocess.py) on the reference's recorded CROPPED
+  boards against what the reference's own post-processor made of its own cropper's output (the traces' crop_post_*)."""
+  from oracle import postprocess as opost
+  tr = helpers.load_trace(name)
+  chars = [chr(c) for c in tr['chars']]
+  T, E = tr['actions'].shape
+  every = int(tr['post_every'][0])
+  for i, (ci, sp) in enumerate(crop_post_specs_of(tr)):
+    for fi, t in enumerate(_post_frames(T, every)):
+      for e in range(0, E, 3):
+        board = tr['crop_%d' % ci][t, e]
+        got = opost.feature_array({c: board == ord(c) for c in chars}, list(sp['layers']), board.shape, sp['permute'])
+        want = tr['crop_post_%d' % i][fi, e]
+        assert got.shape == want.shape and got.dtype == want.dtype
+        np.testing.assert_array_equal(got, want, err_msg='%s spec %d frame %d env %d' % (name, i, t, e))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['planes kept', 'skip_layers', 'skip_board', 'only_crops + skip_board'])
+@pytest.mark.parametrize('name', CROP_POSTED)
+def test_fused_window_feature_stack_matches_reference(name, mode):
+  """ObservationToFeatureArray.fuse_into(engine, source=cropper): the step kernel cuts the window AND writes its float32
+  stack in the same launch (pcx_cropper_set_features).  Against the reference's cropper -> post-processor outputs
+  recorded in the traces, frame 0 included, windows of 300, 70, 49, 27 and 99 cells (whole dwords and not), planar and
+  channels last, with the window's uint8 planes kept / dropped, and with the full-board planes dropped as well."""
+  from pycolab_amd import rendering
+  from pycolab_amd.engine import Engine
+  tr = helpers.load_trace(name)
+  t = helpers.load_template(tr['template'])
+  T, E = tr['actions'].shape
+  every = int(tr['post_every'][0])
+  specs = specs_of(tr)
+  cps = crop_post_specs_of(tr)
+  drapes = {chr(d['ch']) for d in t.drapes}
+  for i, (ci, sp) in enumerate(cps):
+    if any(c in drapes for c in specs[ci]['to_track']):
+      continue  # (this kernel does not fuse a drape tracker: nothing to attach the stack to)
+    eng = Engine.from_template(t, batch=E, auto_reset=True, seed=helpers.GOLDEN_RNG_SEED)
+    cr = cropping.cropper_from_spec(specs[ci])
+    only = mode.startswith('only_crops')
+    assert cropping.fuse_croppers(eng, [cr], only_crops=only) is None  # deferred to showtime
+    obs = eng.its_showtime()[0]
+    assert cr._fused
+    conv = rendering.ObservationToFeatureArray(list(sp['layers']), permute=sp['permute'])
+    assert conv.fuse_into(eng, source=cr, skip_layers=mode == 'skip_layers', skip_board=mode.endswith('skip_board')), (name, i)
+    fi = 0
+    for step in range(T + 1):
+      if step:
+        obs = eng.play(tr['actions'][step - 1])[0]
+      cropped = cr.crop(obs)
+      if step == 0 or step % every == 0:
+        got = helpers.to_np(conv(cropped))
+        want = tr['crop_post_%d' % i][fi]
+        assert got.shape == want.shape and got.dtype == want.dtype, (got.shape, want.shape)
+        np.testing.assert_array_equal(got, want, err_msg='%s spec %d (%s) frame %d' % (name, i, mode, step))
+        if mode == 'planes kept':  # the window's own planes are still the reference's cropped observation
+          np.testing.assert_array_equal(helpers.to_np(cropped.board), tr['crop_%d' % ci][step])
+        fi += 1
+    conv.unfuse()
+    obs = eng.play(tr['actions'][0])[0]
+    np.testing.assert_array_equal(helpers.to_np(conv(cr.crop(obs))).shape, tr['crop_post_%d' % i][0].shape)  # stand-alone again
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_fused_window_feature_stack_refusals_and_big_batch():
+  from pycolab_amd import rendering
+  from pycolab_amd.engine import Engine
+  import torch
+  t = helpers.load_template('better_scrolly_maze_L0')
+  eng = Engine.from_template(t, batch=70000, auto_reset=True, seed=3)
+  cr = cropping.ScrollingCropper(rows=10, cols=30, to_track=['P'], scroll_margins=(2, 3), initial_offset=(-3, -9))
+  loose = cropping.ScrollingCropper(rows=5, cols=5, to_track=['P'], pad_char=' ', scroll_margins=(1, 1))
+  loose.set_engine(eng)
+  eng.its_showtime()
+  conv = rendering.ObservationToFeatureArray('P@#abc +')
+  assert not conv.fuse_into(eng, source=cr)             # not fused (not even attached)
+  assert cropping.fuse_croppers(eng, [cr])
+  assert not conv.fuse_into(eng, source=loose)          # attached, but runs as its own kernel
+  assert not rendering.ObservationToFeatureArray('PP').fuse_into(eng, source=cr)   # a layer twice
+  assert conv.fuse_into(eng, source=cr)
+  plain = rendering.ObservationToFeatureArray('P@#abc +')
+  for step in range(6):  # the single-wave launch shape, 70,000 environments: fused == stand-alone on the same window
+    obs = eng.play(torch.randint(0, 5, (70000,), dtype=torch.int32, device='cuda'))[0]
+    cropped = cr.crop(obs)
+    assert torch.equal(conv(cropped), plain(cropped)), step
+  gen = Engine.from_template(helpers.load_template('walkers_room'), batch=64)   # the table-driven kernel
+  g = cropping.FixedCropper((0, 0), 4, 4)
+  gen.its_showtime()
+  if cropping.fuse_croppers(gen, [g]):
+    assert not rendering.ObservationToFeatureArray('w').fuse_into(gen, source=g)
+  eng.close(); gen.close()
