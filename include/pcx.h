@@ -402,9 +402,8 @@ int pcx_cropper_bind_output(pcx_cropper* c, uint8_t* planes_dev);
  * fixed or scrolling after at most four entities each: sprites, drapes (the
  * median of the raw curtain, cropping.py:590-598) and priority lists that
  * mix the two.  Drape trackers: the table-driven kernel on any board, the
- * hand-written kernels on boards of at most 63 x 64 cells (and not in
- * pcx_scrolly_maze_step's cooperative launch shape, i.e. batches of fewer
- * than four groups of 64 per CU: PCX_E_UNSUPPORTED).  only_crops != 0: the full-board
+ * hand-written kernels on boards of at most 63 x 128 cells (PCX_E_UNSUPPORTED
+ * beyond).  only_crops != 0: the full-board
  * planes are no longer written (pcx_buffers.planes goes stale; the consumer
  * ingests the windows only).  n == 0 releases the croppers again.  When the
  * engine is already in play the croppers are brought up to date once, on

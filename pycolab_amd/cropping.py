@@ -285,8 +285,7 @@ def fuse_croppers(engine, croppers, only_crops=False):
 
   Returns False, and changes nothing, where the engine's kernel cannot do it
   (more than four croppers, unoccluded layers, a cropper that tracks a drape
-  on a board wider than 64 cells, or in scrolly_maze's kernel at batches too
-  small for its single-wave launch shape): the croppers then run as their
+  on a board wider than 128 cells or taller than 63): the croppers then run as their
   own kernels, as before.  `croppers=[]` releases
   them again."""
   croppers = list(croppers)

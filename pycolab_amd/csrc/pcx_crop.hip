@@ -303,6 +303,7 @@ static int push_fused(pcx_engine* e) {
     w.feat = c->feat; w.feat_depth = c->feat_depth; w.feat_hwc = c->feat_hwc; w.feat_skip = c->feat ? c->feat_skip : 0;
     for (int k = 0; k < pcx::crop::MAX_FUSED_FEATURES; ++k) w.feat_ch[k] = c->feat_ch[k];
   }
+  fc.drapes = pcx::crop::tracks_drapes(&fc);
   return e->backend->set_fused_croppers(&fc);
 }
 

@@ -105,6 +105,8 @@ struct FusedWindow {
 struct FusedCrops {
   int32_t n;     // windows in use
   int32_t only;  // the full-board planes are not written any more
+  int32_t drapes;  // some window follows a drape (tracks_drapes): kernels that export the raw curtains from all waves of a
+                   // cooperative workgroup move their windows after that export instead of in the logic phase
   FusedWindow w[MAX_FUSED_CROPPERS];
 };
 

@@ -1317,10 +1317,11 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
       for (int i = 0; i < 4; ++i) if (i < k.CW) pre_cm[i] = l.cmask[i * WAVE + col];
     }
     if constexpr (FUSABLE) {
-      // (a cropper may follow the maze or the cash drape where this lane has exported the raw curtains above: the
-      // single-wave shapes; the cooperative shape exports them later, from all waves -- refused on the host)
+      // (a cropper may follow the maze or the cash drape: in the single-wave shapes this lane has exported the raw
+      // curtains above and takes the median here; the cooperative shape exports them later, from all waves, and moves
+      // windows that follow a drape after that export -- below, "late windows")
       const stream::CurtainSrc csrc{P.curtains, bp, FW, R, C};
-      if (fc)  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
+      if (fc && !(COOP && fc->drapes))  // fused croppers: the windows follow this step's positions (cropping.py:393-426)
         stream::move_fused_windows(fc, [&](int ti) {  // ti: the TEMPLATE's sprite index
           int32_t t = 0;
 #pragma unroll
@@ -1395,6 +1396,22 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
           P.curtains[((size_t)cs2 * FW + i) * P.bpad + env_base + e] = l.flat[FLAT(1, i, e)];
         }
         __syncthreads();
+      }
+      if constexpr (FUSABLE) {
+        if (fc && fc->drapes) {
+          // late windows (round 4): the raw curtains of the workgroup's environments are in memory now; one lane per
+          // environment takes the medians (pcx_stream.h curtain_centroid) and moves every window exactly as the logic
+          // phase of the single-wave shapes does -- the sprites' track words and the frame counter it needs were
+          // written there by this workgroup's logic wave
+          const int64_t envw = g_render * EPW + (int64_t)threadIdx.x;
+          if ((int)threadIdx.x < EPW && envw < P.batch && !l.skip[threadIdx.x]) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            const stream::CurtainSrc csrc{P.curtains, P.bpad, FW, R, C};
+            stream::move_fused_windows(fc, [&](int ti) { return P.track[(int64_t)ti * P.bpad + envw] & 0x1FFFF; },
+                                       out.frame[envw] == 0, envw, (int)threadIdx.x, lds_raw + k.lds_wcorner, &csrc);
+          }
+          __syncthreads();
+        }
       }
       if (fc) {  // the fused croppers' windows paint the curtains in index order: resolve them first
         for (int task = (int)threadIdx.x; task < EPW * FW; task += (int)blockDim.x) {
@@ -1894,8 +1911,7 @@ class ScrollyMazeBackend : public Backend {
   int set_fused_croppers(const crop::FusedCrops* fc) override {
     if (fc && fc->n > 0 && (unoccluded_ || epi_.out))
       return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: fused croppers need occluded layers and no feature-array epilogue");
-    if (crop::tracks_drapes(fc) && coop_shape())  // (the cooperative shape exports the curtains after the windows have moved)
-      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: at this batch size a cropper that tracks a drape runs as its own kernel");
+    // (round 4: the cooperative shape moves windows that follow a drape after its export of the curtains)
     return fused_.set(fc, false, k_.R, k_.C);
   }
   const int32_t* sprite_track() const override { return track_.ptr; }

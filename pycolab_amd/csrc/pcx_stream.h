@@ -454,35 +454,42 @@ constexpr uint32_t WCORNER_NONE = 0x00008000u;                  // "this environ
 struct CurtainSrc { const uint32_t* bits; int64_t bpad; int FW, R, C; };
 
 // ScrollingCropper._centroid of a drape (cropping.py:590-598): int(np.median(.)) of the set cells' row and column
-// indices, one environment per lane, from the words this lane exported a moment ago.  Rows are read as C-bit
-// vectors (C <= 64, R <= 63: checked on the host); the per-column counts are kept bit-sliced (six 64-bit
-// planes, a ripple-carry add per row), so the whole thing is a few loads and ~50 operations per row.
+// indices, one environment per lane, from the words this lane exported a moment ago.  A row is read as one or two
+// 64-bit column vectors (C <= 128, R <= 63: checked on the host -- better_scrolly_maze's 45 x 89 board takes two);
+// the per-column counts are kept bit-sliced (six 64-bit planes per half, a ripple-carry add per row), so the whole
+// thing is a few loads and ~50 operations per row and half.
+constexpr int CENTROID_MAX_ROWS = 63, CENTROID_MAX_COLS = 128;
 __device__ __forceinline__ bool curtain_centroid(const CurtainSrc& cs, int d, int64_t env, int& crow, int& ccol) {
   const uint32_t* const base = cs.bits + (size_t)d * cs.FW * cs.bpad + env;
   const int R = cs.R, C = cs.C, FW = cs.FW;
+  const int halves = C > 64 ? 2 : 1;
   auto word = [&](int w) { return w < FW ? base[(size_t)w * cs.bpad] : 0u; };
-  auto row_bits = [&](int r) {
-    const uint32_t bit0 = (uint32_t)(r * C), w0 = bit0 >> 5, sh = bit0 & 31u;
+  auto row_bits = [&](int r, int half) {  // columns [64 half, 64 half + 64) of row r
+    const int width = C - 64 * half;
+    const uint32_t bit0 = (uint32_t)(r * C + 64 * half), w0 = bit0 >> 5, sh = bit0 & 31u;
     const uint64_t lo = (uint64_t)word((int)w0) | ((uint64_t)word((int)w0 + 1) << 32);
     const uint64_t hi = word((int)w0 + 2);
     uint64_t v = lo >> sh;
     v |= sh ? hi << (64u - sh) : 0ull;
-    return C >= 64 ? v : v & ((1ull << C) - 1ull);
+    return width >= 64 ? v : v & ((1ull << width) - 1ull);
   };
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // (this lane's own export stores, read back below)
   int n = 0;
-  uint64_t plane[6] = {0, 0, 0, 0, 0, 0};  // bit c of plane[k]: bit k of the number of set cells in column c
-  for (int r = 0; r < R; ++r) {
-    uint64_t carry = row_bits(r);
-    n += __popcll(carry);
+  uint64_t plane[2][6] = {};  // bit c of plane[h][k]: bit k of the number of set cells in column 64 h + c
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) { const uint64_t t = plane[kk] & carry; plane[kk] ^= carry; carry = t; }
-  }
+    for (int h = 0; h < 2; ++h) {
+      if (h >= halves) break;
+      uint64_t carry = row_bits(r, h);
+      n += __popcll(carry);
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk) { const uint64_t t = plane[h][kk] & carry; plane[h][kk] ^= carry; carry = t; }
+    }
   // the two middle order statistics (0-based) of the sorted index list; their mean, truncated
   const int lo_rank = (n - 1) / 2, hi_rank = n / 2;
   int seen = 0, lo = -1, hi = -1;
   for (int r = 0; r < R; ++r) {
-    const int cnt = __popcll(row_bits(r));
+    const int cnt = __popcll(row_bits(r, 0)) + (halves > 1 ? __popcll(row_bits(r, 1)) : 0);
     lo = lo < 0 && seen + cnt > lo_rank ? r : lo;
     hi = hi < 0 && seen + cnt > hi_rank ? r : hi;
     seen += cnt;
@@ -491,8 +498,9 @@ __device__ __forceinline__ bool curtain_centroid(const CurtainSrc& cs, int d, in
   seen = 0; lo = -1; hi = -1;
   for (int c = 0; c < C; ++c) {
     int cnt = 0;
+    const int h = c >> 6, b = c & 63;
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) cnt |= (int)((plane[kk] >> c) & 1ull) << kk;
+    for (int kk = 0; kk < 6; ++kk) cnt |= (int)(((h ? plane[1][kk] : plane[0][kk]) >> b) & 1ull) << kk;
     lo = lo < 0 && seen + cnt > lo_rank ? c : lo;
     hi = hi < 0 && seen + cnt > hi_rank ? c : hi;
     seen += cnt;
@@ -815,10 +823,11 @@ struct FusedCropsHolder {
   bool only = false;  // windows only: the full-board planes are not written (the launch is a few KB per environment:
                       // the backends then share a group among four waves up to many more groups per CU)
   // rows, cols: the board, for kernels that take a drape's median from the curtains they export (curtain_centroid:
-  // rows of at most 64 cells, at most 63 of them); drapes_ok: the kernel has its own way (pcx_generic.hip)
+  // rows of at most 128 cells, at most 63 of them); drapes_ok: the kernel has its own way (pcx_generic.hip)
   int set(const crop::FusedCrops* fc, bool drapes_ok = false, int rows = 0, int cols = 0) {
-    if (!drapes_ok && crop::tracks_drapes(fc) && !(rows > 0 && rows <= 63 && cols > 0 && cols <= 64))
-      return set_error(PCX_E_UNSUPPORTED, "fused croppers: a cropper that tracks a drape is fused on boards of at most 63 x 64 cells (this one: %d x %d)", rows, cols);
+    if (!drapes_ok && crop::tracks_drapes(fc) && !(rows > 0 && rows <= CENTROID_MAX_ROWS && cols > 0 && cols <= CENTROID_MAX_COLS))
+      return set_error(PCX_E_UNSUPPORTED, "fused croppers: a cropper that tracks a drape is fused on boards of at most %d x %d cells (this one: %d x %d)",
+                       CENTROID_MAX_ROWS, CENTROID_MAX_COLS, rows, cols);
     PCX_HIP(hipDeviceSynchronize());  // no launch in flight may still read the old description
     if (!fc || fc->n <= 0) { on = false; only = false; return 0; }
     if (!dev.ptr) { if (int rc = dev.alloc(1)) return rc; }

@@ -268,12 +268,18 @@ def test_fused_croppers_equal_stand_alone_croppers(name, batch, shape, monkeypat
     (n, b, k, sh) for n, b, k in [('warehouse_L0', 1500, 'pcx_warehouse_step'), ('warehouse_custom_B', 700, 'pcx_warehouse_step'),
                                   ('marauders', 900, 'pcx_marauders_step'), ('hello_world', 600, 'pcx_hello_world_step'),
                                   ('better_scrolly_maze_L1', 500, 'pcx_better_scrolly_step'),
+                                  ('better_scrolly_maze_L0', 300, 'pcx_better_scrolly_step'),   # 45 x 89: two 64-bit column halves
+                                  ('better_scrolly_maze_L2', 300, 'pcx_better_scrolly_step'),   # 29 x 89
                                   ('better_scrolly_custom_B', 800, 'pcx_better_scrolly_step')] for sh in ('coop', 'single')] + [
     # pcx_scrolly_maze_step: its single-wave shapes (shipped 10x30 instance, run-time-shape instance)
     ('scrolly_maze_L0', 900, 'pcx_scrolly_maze_step', 'single'), ('scrolly_maze_L2', 400, 'pcx_scrolly_maze_step', 'single'),
-    ('scrolly_custom_B', 700, 'pcx_scrolly_maze_step', 'single'), ('scrolly_custom_D', 500, 'pcx_scrolly_maze_step', 'coop')])
+    ('scrolly_custom_B', 700, 'pcx_scrolly_maze_step', 'single'), ('scrolly_custom_D', 500, 'pcx_scrolly_maze_step', 'coop'),
+    # ... and its cooperative shape (round 4: windows that follow a drape move after the workgroup's export of the
+    # curtains): 64, 32 and 16 environments per workgroup, the last with four lanes per environment in the logic phase
+    ('scrolly_maze_L0', 900, 'pcx_scrolly_maze_step', 'coop'), ('scrolly_maze_L1', 20000, 'pcx_scrolly_maze_step', 'coop'),
+    ('scrolly_maze_L2', 9000, 'pcx_scrolly_maze_step', 'coop'), ('scrolly_maze_L0', 8, 'pcx_scrolly_maze_step', 'coop')])
 def test_hand_written_kernels_fuse_drape_tracking_croppers(name, batch, kernel, shape, monkeypatch):
-  """A fused cropper may follow a drape in the hand-written kernels too (boards of at most 63 x 64 cells): the
+  """A fused cropper may follow a drape in the hand-written kernels too (boards of at most 63 x 128 cells): the
   logic wave takes the median of the raw curtain it has just exported (pcx_stream.h curtain_centroid).  Windows
   equal the stand-alone cropper kernels' on a twin engine, every step, drapes emptying and refilling across
   episodes, priority lists that fall through to a sprite."""
@@ -458,13 +464,8 @@ def test_fuse_croppers_answers_false_where_the_kernel_cannot():
   cu.set_engine(um)
   um.its_showtime()
   assert cropping.fuse_croppers(um, [cu]) is False                  # unoccluded layers: the windows derive layers from the board
-  for wide, ch in (('better_scrolly_maze_L0', '@'), ('scrolly_maze_L0', '@')):   # 89 columns; the metric game's kernel
-    e3 = Engine.from_template(helpers.load_template(wide), batch=8, auto_reset=True)
-    d3 = cropping.ScrollingCropper(3, 3, [ch], pad_char=' ', scroll_margins=(None, None))
-    d3.set_engine(e3)
-    e3.its_showtime()
-    assert cropping.fuse_croppers(e3, [d3]) is False, wide       # these drape trackers stay stand-alone
-    e3.close()
+  # (round 4: drape trackers fuse on better_scrolly_maze's 89-column boards and in pcx_scrolly_maze_step's cooperative
+  # shape too: test_hand_written_kernels_fuse_drape_tracking_croppers)
   t2 = helpers.load_template('warehouse_L0')
   eng2 = Engine.from_template(t2, batch=8, auto_reset=True)
   drape = cropping.ScrollingCropper(3, 3, ['X'], pad_char=' ', scroll_margins=(None, None))
@@ -477,16 +478,21 @@ def test_fuse_croppers_answers_false_where_the_kernel_cannot():
 
 def _centroid_like_the_kernels(curtain):
   """pcx_stream.h curtain_centroid / pcx_generic.hip drape_centroid, restated step by step on a bool curtain: rows
-  as C-bit integers, per-column counts kept bit-sliced in six planes (a ripple-carry add per row), the two middle
-  order statistics by prefix counts, their mean truncated."""
+  as one or two 64-bit column vectors (round 4: boards up to 128 columns), per-column counts kept bit-sliced in six
+  planes per half (a ripple-carry add per row), the two middle order statistics by prefix counts, their mean
+  truncated."""
   R, C = curtain.shape
+  M64 = (1 << 64) - 1
   rows = [sum(1 << c for c in range(C) if curtain[r, c]) for r in range(R)]
-  n, planes = 0, [0] * 6
+  halves = 2 if C > 64 else 1
+  n, half_planes = 0, [[0] * 6 for _ in range(halves)]
   for v in rows:
-    carry = v
-    n += bin(v).count('1')
-    for k in range(6):
-      planes[k], carry = planes[k] ^ carry, planes[k] & carry
+    for h in range(halves):
+      carry = (v >> (64 * h)) & M64
+      n += bin(carry).count('1')
+      for k in range(6):
+        half_planes[h][k], carry = half_planes[h][k] ^ carry, half_planes[h][k] & carry
+  planes = [sum(half_planes[h][k] << (64 * h) for h in range(halves)) for k in range(6)]
   if n == 0:
     return None
   lo_rank, hi_rank = (n - 1) // 2, n // 2
@@ -506,10 +512,10 @@ def _centroid_like_the_kernels(curtain):
 
 def test_the_kernels_drape_median_is_the_references():
   """cropping.py:590-598: `tuple(int(np.median(dim)) for dim in curtain.nonzero())` -- the arithmetic the fused
-  croppers use for it (no sort, no division) on random curtains up to the 63 x 64 limit, dense, sparse and empty."""
+  croppers use for it (no sort, no division) on random curtains up to the 63 x 128 limit, dense, sparse and empty."""
   rng = np.random.RandomState(12)
-  for trial in range(400):
-    R, C = int(rng.randint(1, 64)), int(rng.randint(1, 65))
+  for trial in range(500):
+    R, C = int(rng.randint(1, 64)), int(rng.randint(1, 129))
     density = rng.choice([0.0, 0.02, 0.3, 0.9, 1.0])
     curtain = rng.rand(R, C) < density
     if trial % 7 == 0 and curtain.size > 1:
