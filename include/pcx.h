@@ -36,7 +36,9 @@
 #ifndef PCX_H_
 #define PCX_H_
 
+#ifndef __HIPCC_RTC__ /* (a run-time build of a kernel gets the fixed-width types from csrc/pcx_device.h) */
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -331,9 +333,20 @@ const char* pcx_engine_kernel_name(const pcx_engine* e);
 /* Which launch shape the engine's LAST step / reset launch took (tests and benchmarks assert that the shape they
  * mean to measure is the one that ran; no reference counterpart).  pcx_scrolly_maze_step: 0 one single-wave
  * workgroup per group of 64 environments, 1 persistent single-wave workgroups with the next unit's state words
- * prefetched into LDS, 2 persistent logic/render wave pairs, 3 two-wave workgroups (round 1), 10 cooperative
- * (several waves per group), 11 several steps per launch, 20 shape-generic instance; -1: the backend does not say. */
+ * prefetched into LDS, 2 persistent logic/render wave pairs, 3 persistent workgroups of W workers with a streaming
+ * semaphore (the default from 98,304 environments up), 4 two-wave pipeline workgroups (round 1, PCX_WAVES_PER_WG=2),
+ * 10 cooperative (several waves per group), 11 / 12 several steps per launch (round 1's instance / the cooperative
+ * shape walking them), 20 shape-generic instance; pcx_generic_step: 30 the
+ * table-driven build, 31 the build specialised for the engine's template at run time; -1: the backend does not say. */
 int32_t pcx_engine_launch_shape(const pcx_engine* e);
+/* pcx_generic_step (the table-driven kernel every Engine the hand-written kernels do not cover runs on: engine.py:583-847
+ * around arbitrary Sprites / Drapes of the supported programs) is also built per template at run time, with the
+ * template's tables and schedule as compile-time constants (hiprtc; engines of PCX_GENERIC_JIT_MIN = 4,096
+ * environments and more, PCX_GENERIC_JIT=0 / 1 never / always; code objects cached under $PCX_JIT_CACHE, default
+ * <directory of libpcx.so>/jit_cache).  This entry plans the template and compiles that build -- or finds it in the
+ * cache -- without creating an engine and WITHOUT a device: what `build` checks and the CPU tests call.  code_bytes: the
+ * size of the code object; log: the compiler's words when it fails (PCX_E_UNSUPPORTED).  No reference counterpart. */
+int pcx_generic_specialise_check(const pcx_template* t, char* log, int64_t log_bytes, int64_t* code_bytes);
 /* Profiling aid (no reference counterpart): the phase timers the last launch left when the backend was asked to keep
  * them (pcx_scrolly_maze_step's persistent shapes under PCX_SM_PROF=1: 16 words per workgroup, 10 ns ticks; layout in
  * pcx_scrolly_maze.hip Ptrs::ps_prof).  out_host == NULL with words == -1 clears them.  Synchronous.  PCX_E_UNSUPPORTED from

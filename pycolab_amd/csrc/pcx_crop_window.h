@@ -6,7 +6,7 @@
 // gfx950 only.
 #pragma once
 
-#include <cstdint>
+#include "pcx_device.h"
 
 namespace pcx {
 namespace crop {

@@ -500,6 +500,10 @@ int32_t pcx_engine_plane_pitch(const pcx_engine* e) { return e ? e->backend->pla
 int64_t pcx_engine_bytes_per_step(const pcx_engine* e) { return e ? e->backend->bytes_per_step() : 0; }
 const char* pcx_engine_kernel_name(const pcx_engine* e) { return e ? e->backend->kernel_name() : ""; }
 int32_t pcx_engine_launch_shape(const pcx_engine* e) { return e ? e->backend->launch_shape() : -1; }
+int pcx_generic_specialise_check(const pcx_template* t, char* log, int64_t log_bytes, int64_t* code_bytes) {
+  if (!t) return set_error(PCX_E_INVALID, "pcx_generic_specialise_check: null template");
+  return pcx::generic_specialise_check(*t, log, log_bytes, code_bytes);
+}
 int pcx_engine_debug_counters(pcx_engine* e, uint32_t* out_host, int64_t words) {
   if (!e || (!out_host && words != -1) || words < -1) return set_error(PCX_E_INVALID, "pcx_engine_debug_counters: bad arguments");
   PCX_HIP(hipSetDevice(e->device));

@@ -2304,7 +2304,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), dim3((unsigned)groups),
                        dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_, fused_.ptr());
     last_shape_ = 11;
-  } else if (shipped_shape && waves_per_wg == 1 && (groups < (int64_t)num_cus_ * coop_below || a.n_steps > 1)) {
+  } else if (shipped_shape && ((waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) || a.n_steps > 1)) {  // (several steps: this shape whatever the knobs say)
     int coop_waves = groups <= num_cus_ ? 8 : 4;  // at most one group per CU: split the render loop eight ways
     if (const char* e = getenv("PCX_COOP_WAVES")) coop_waves = atoi(e) == 4 ? 4 : 8;
     // ... and while CUs would still stand empty, halve the environments per workgroup (32, 16): the
@@ -2441,7 +2441,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true>), grid, block, lds_c, s, k_, P, a, out, epi_, fused_.ptr());
   } else if (shipped_shape) {
-    last_shape_ = waves_per_wg == 2 ? 3 : 0;
+    last_shape_ = waves_per_wg == 2 ? 4 : 0;
     if (epi_.out && waves_per_wg == 1) {
       size_t lds_e = (size_t)k_.lds_words * 4;
       const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_e, 1);

@@ -20,7 +20,11 @@
 // layer is a mask already at hand: nothing is read back from HBM.
 #pragma once
 
+#ifdef __HIPCC_RTC__  // (a run-time build of a kernel: the device side only)
+#include "pcx_device.h"
+#else
 #include "pcx_internal.h"
+#endif
 #include "pcx_crop_window.h"
 
 namespace pcx {
@@ -32,6 +36,27 @@ __device__ __forceinline__ uint8_t* uniform_ptr(uint8_t* p) {  // pin a wave-uni
   const uint64_t v = reinterpret_cast<uint64_t>(p);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return reinterpret_cast<uint8_t*>(((uint64_t)hi << 32) | lo);
+}
+
+// LDS-DMA (global_load_lds_dword): lane i's dword base[i] lands at LDS byte address lds_addr + 4 i -- no VGPR, nothing
+// the compiler waits for; the issuer waits on vmcnt itself before reading the row.  M0 is written in the statement
+// that uses it and restored (the compiler owns it); the base is copied by an SALU instruction so that an SGPR pair
+// fresh from v_readfirstlane is never read by the VMEM instruction within the hazard window.  `base` and `lds_addr`
+// must be wave-uniform (readfirstlane them where the compiler cannot prove it).
+__device__ __forceinline__ void lds_dma_row(const uint32_t* base, uint32_t voff, uint32_t lds_addr) {
+  uint32_t keep;
+  uint64_t own;
+  asm volatile(
+      "s_mov_b64 %1, %3\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(own)
+      : "v"(voff), "s"(base), "s"(lds_addr)
+      : "memory");
+}
+__device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)p;
+}
+__device__ __forceinline__ const uint32_t* uniform_words(const uint32_t* p) {
+  return reinterpret_cast<const uint32_t*>(uniform_ptr(reinterpret_cast<uint8_t*>(const_cast<uint32_t*>(p))));
 }
 
 // engine.py:751-757 for the last repaint of a step: a sprite is painted iff it
@@ -741,6 +766,7 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
   }
 }
 
+#ifndef __HIPCC_RTC__  // ---- host side from here to the matching #endif (a run-time build of a kernel has no use for it) ----
 // Host side: an epilogue descriptor (include/pcx.h) as EpilogueArgs for a backend
 // whose sprites / drape slots / backdrop-only characters paint the given
 // characters.  (Boards that are not a whole number of dwords are fine: stream_planes writes the
@@ -838,6 +864,7 @@ struct FusedCropsHolder {
   }
   const crop::FusedCrops* ptr() const { return on ? dev.ptr : nullptr; }
 };
+#endif
 
 // Constants of the streaming phase every backend derives the same way.
 struct Layout {

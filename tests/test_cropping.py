@@ -3,6 +3,8 @@ observations recorded from the reference's own croppers (oracle/gen_golden.py),
 plus the constructor guards of cropping.py."""
 import json
 
+import os
+
 import numpy as np
 import pytest
 
@@ -309,7 +311,8 @@ def test_hand_written_kernels_fuse_drape_tracking_croppers(name, batch, kernel, 
     cr.set_engine(b)
   assert cropping.fuse_croppers(a, ca) is None
   oa, ob = a.its_showtime()[0], b.its_showtime()[0]
-  assert N.lib().pcx_engine_kernel_name(a._native).decode() == kernel
+  if os.environ.get('PCX_FORCE_GENERIC') != '1':  # (the whole suite is also run through the table-driven kernel)
+    assert N.lib().pcx_engine_kernel_name(a._native).decode() == kernel
   assert all(cr._fused for cr in ca) and not any(cr._fused for cr in cb)
   n_act = max(1, int(t.n_actions))
   rng = np.random.RandomState(8)

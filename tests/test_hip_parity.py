@@ -113,8 +113,15 @@ def test_hip_two_wave_pipeline_shape_matches_oracle(monkeypatch):
   B = 64 * 700 + 5
   hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
   hip.reset(); orc.reset()
-  for t0 in range(0, 48, 12):
+  from pycolab_amd import _native as N
+  for t0 in range(0, 12):  # one step per launch: the pipeline shape itself (launches of several steps take the cooperative shape)
+    hip.step_hashed(0xBEE, t0, 1); orc.step_hashed(0xBEE, t0, 1)
+    assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 4
+    if t0 % 4 == 3:
+      assert_same(hip, orc, 'after step %d' % (t0 + 1))
+  for t0 in range(12, 48, 12):
     hip.step_hashed(0xBEE, t0, 12); orc.step_hashed(0xBEE, t0, 12)
+    assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 12
     assert_same(hip, orc, 'after step %d' % (t0 + 12))
 
 
