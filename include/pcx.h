@@ -339,8 +339,8 @@ const char* pcx_engine_kernel_name(const pcx_engine* e);
  * shape walking them), 20 shape-generic instance; pcx_generic_step: 30 the
  * table-driven build, 31 the build specialised for the engine's template at run time; -1: the backend does not say. */
 int32_t pcx_engine_launch_shape(const pcx_engine* e);
-/* pcx_generic_step (the table-driven kernel every Engine the hand-written kernels do not cover runs on: engine.py:583-847
- * around arbitrary Sprites / Drapes of the supported programs) is also built per template at run time, with the
+/* The table-driven kernel pcx_generic_step -- what every Engine the hand-written kernels do not cover runs on:
+ * engine.py:583-847 around arbitrary Sprites / Drapes of the supported programs -- is also built per template at run time, with the
  * template's tables and schedule as compile-time constants (hiprtc; engines of PCX_GENERIC_JIT_MIN = 4,096
  * environments and more, PCX_GENERIC_JIT=0 / 1 never / always; code objects cached under $PCX_JIT_CACHE, default
  * <directory of libpcx.so>/jit_cache).  This entry plans the template and compiles that build -- or finds it in the
