@@ -42,7 +42,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 REFERENCE = os.environ.get('PCX_REFERENCE', '/root/reference')
 
 FIXTURES = {'scrolly_maze': 'scrolly_maze_L%d', 'warehouse': 'warehouse_L%d', 'marauders': 'marauders',
-            'hello_world': 'hello_world', 'better_scrolly_maze': 'better_scrolly_maze_L%d'}
+            'hello_world': 'hello_world', 'better_scrolly_maze': 'better_scrolly_maze_L%d',
+            # games only the table-driven kernel steps (an unshipped marauders board; prefab MazeWalkers and Scrolly drapes in two scrolling groups)
+            'marauders_custom_A': 'marauders_custom_A', 'walkers_scroll_groups': 'walkers_scroll_groups'}
 
 
 def cpu_worker(args):
@@ -181,7 +183,8 @@ def measure_config(game, level, batch, steps, warmup, device, repeats=3):
   kernel_ms = median(runs)
   eng.check_errors()
   bps = int(N.lib().pcx_engine_bytes_per_step(eng._native))
-  out = {'workload': 'examples/%s, %d envs' % (fixture, batch), 'ms_per_step': kernel_ms,
+  where = 'examples' if game in ('scrolly_maze', 'warehouse', 'marauders', 'hello_world', 'better_scrolly_maze') else 'tests/golden/templates'
+  out = {'workload': '%s/%s, %d envs' % (where, fixture, batch), 'ms_per_step': kernel_ms,
          'ms_per_step_min_max': [min(runs), max(runs)],
          'env_steps_per_s': batch / (kernel_ms * 1e-3),
          'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(),
@@ -492,7 +495,10 @@ def main():
                                measure_config('marauders', 0, 32768, 200, 20, device),
                                measure_config('warehouse', 0, 262144, 100, 10, device),
                                measure_config('better_scrolly_maze', 0, 65536, 50, 10, device),
-                               measure_config('hello_world', 0, 1048576, 50, 10, device)]
+                               measure_config('hello_world', 0, 1048576, 50, 10, device),
+                               # pcx_generic_step (built for the template at run time: launch_shape 31) at VERDICT r3's fixtures
+                               measure_config('marauders_custom_A', 0, 32768, 200, 30, device),
+                               measure_config('walkers_scroll_groups', 0, 262144, 100, 30, device)]
     if not args.no_cpu_baseline:  # (rank 0's host cores, N > 1 included)
       line['cpu_baseline'] = cpu_baseline(template_path)
       ref = cpu_reference_python(args.game, args.level)
