@@ -493,9 +493,10 @@ int pcx_post_run(pcx_post* p, void* stream);
  * (the board plane is) -- for consumers that only ingest the feature array;
  * skip_layers == 2: nor is the board plane (pcx_buffers.planes goes stale
  * altogether: the consumer ingests the epilogue's array and nothing else).
- * Answers PCX_E_UNSUPPORTED where the backend's render loop cannot do it (the
- * table-driven kernel, occlusion_in_layers=False, fused croppers in the same
- * kernel): run pcx_post_* then.  Boards of any size (a plane's last dword is
+ * Answers PCX_E_UNSUPPORTED where the backend's render loop cannot do it
+ * (occlusion_in_layers=False, fused croppers in the same kernel; the
+ * table-driven kernel writes this planar float32 array and none of the other
+ * kinds below): run pcx_post_* then.  Boards of any size (a plane's last dword is
  * stored cell by cell when rows*cols is no multiple of 4).
  * A NULL desc clears the epilogue. */
 typedef struct pcx_epilogue_desc {

@@ -72,6 +72,12 @@ struct Ptrs {
   unsigned long long* stats;  // PCX_DEBUG & 8: cycles per program id (64 slots) and per section (64..)
   uint64_t seed;       // the engine's seed and the global index of its environment 0 (pcx_template::param[0..3]):
   int64_t env_offset;  // per engine, not per template -- a specialised build of the kernel serves every engine of a template
+  // include/pcx.h pcx_engine_set_epilogue, the planar feature array (rendering.py:545-661, default axis order): float32
+  // [batch][feat_depth][rows * cols], plane f = (board == feat_ch[f]); null: none.  feat_skip: 1 the uint8 layer planes
+  // are not written, 2 nor is the board plane.
+  float* feat;
+  int32_t feat_depth, feat_skip;
+  uint8_t feat_ch[PCX_POST_MAX_DEPTH];
 };
 
 // A build of this file for ONE template (round 4): PCX_GENERIC_SPEC names a header that defines `static constexpr
@@ -805,7 +811,7 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
 // the per-thing loop is unrolled and what describes a thing (where its mask
 // lives, its character, its layer plane) is read once, into scalar registers.
 template <int NTC>
-__device__ __forceinline__ void render_planes(const Consts& k, const L& l, const pcx_buffers& out, int64_t env0, int lane,
+__device__ __forceinline__ void render_planes(const Consts& k, const L& l, const Ptrs& P, const pcx_buffers& out, int64_t env0, int lane,
                                               int wave, int nwaves, bool any_skip) {
   const int QW = k.QW, FWP = k.FW | 1, pitch = k.pitch, NT = k.NT;
   const uint32_t env_stride = (uint32_t)(1 + k.L) * (uint32_t)pitch;
@@ -827,6 +833,12 @@ __device__ __forceinline__ void render_planes(const Consts& k, const L& l, const
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) bplane[b] = b < NB ? uni32((1 + l.laybc[b]) * (uint32_t)pitch) : 0u;
   const bool occl = k.occl != 0;
+  // the feature-array epilogue: the board dword is in a register, plane f of the array is (board == feat_ch[f]) as
+  // four float32 -- one 16-byte store per plane where boards are whole dwords, cell by cell otherwise (a plane of
+  // rows * cols floats then starts at any multiple of 4 bytes)
+  const bool feat = P.feat != nullptr, put_layers = !(feat && P.feat_skip >= 1), put_board = !(feat && P.feat_skip >= 2);
+  const int cells = k.cells;
+  const bool feat_x4 = (cells & 3) == 0;
 #pragma unroll 1
   for (int it = wave; it < QW; it += nwaves) {
     const uint32_t f = (uint32_t)it * WAVE + lane;
@@ -862,18 +874,37 @@ __device__ __forceinline__ void render_planes(const Consts& k, const L& l, const
       uni |= m;
       d = (d & ~m) | (ch4[t] & m);
       // rendering.py:177-179: after occlusion a thing's layer is its own mask
-      *reinterpret_cast<uint32_t*>(dst + plane[t]) = lay & 0x01010101u;
+      if (put_layers) *reinterpret_cast<uint32_t*>(dst + plane[t]) = lay & 0x01010101u;
     }
-    *reinterpret_cast<uint32_t*>(dst) = d;
+    if (put_board) *reinterpret_cast<uint32_t*>(dst) = d;
+    if (feat) {
+      float* const fe = P.feat + ((size_t)(env0 + e) * (size_t)P.feat_depth) * (size_t)cells + (size_t)q * 4;
+      for (int f = 0; f < P.feat_depth; ++f) {
+        const uint32_t x = d ^ ((uint32_t)P.feat_ch[f] * 0x01010101u);  // a zero byte where the cell shows the character
+        const pcx_f32x4 v = {(x & 0xFFu) ? 0.0f : 1.0f, (x & 0xFF00u) ? 0.0f : 1.0f, (x & 0xFF0000u) ? 0.0f : 1.0f, (x & 0xFF000000u) ? 0.0f : 1.0f};
+        float* const fp = fe + (size_t)f * (size_t)cells;
+        const int left = cells - (int)q * 4;  // (< 4: the last dword of a plane, its cells beyond the board are padding)
+        if (feat_x4) {
+          *reinterpret_cast<pcx_f32x4*>(fp) = v;
+        } else if (left >= 4) {  // boards that are no whole number of dwords: planes start at any multiple of 4 bytes --
+          struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };  // still one global_store_dwordx4 (dword-aligned is enough)
+          *reinterpret_cast<F4*>(fp) = F4{v.x, v.y, v.z, v.w};
+        } else {
+          fp[0] = v.x;
+          if (left > 1) fp[1] = v.y;
+          if (left > 2) fp[2] = v.z;
+        }
+      }
+    }
     // characters only the backdrop paints: their layer is the precomputed mask,
     // minus (with occlusion) whatever a thing covers
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) {
       if (b >= NB) break;
       const uint32_t m = l.bdmask[b * QW + q];
-      *reinterpret_cast<uint32_t*>(dst + bplane[b]) = occl ? m & ~uni : m;
+      if (put_layers) *reinterpret_cast<uint32_t*>(dst + bplane[b]) = occl ? m & ~uni : m;
     }
-    for (int b = MAXB; b < NB; ++b)
+    for (int b = MAXB; b < NB && put_layers; ++b)
       *reinterpret_cast<uint32_t*>(dst + (1 + l.laybc[b]) * pitch) = occl ? l.bdmask[b * QW + q] & ~uni : l.bdmask[b * QW + q];
   }
 }
@@ -1087,10 +1118,10 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
       if (fc->only) return;  // the consumer ingests the windows only: no full-board planes
     }
     switch ((k.NT + 3) / 4) {
-      case 0: case 1: render_planes<4>(k, lr, out, env0r, lane, w, nw, any_skip); break;
-      case 2: render_planes<8>(k, lr, out, env0r, lane, w, nw, any_skip); break;
-      case 3: render_planes<12>(k, lr, out, env0r, lane, w, nw, any_skip); break;
-      default: render_planes<16>(k, lr, out, env0r, lane, w, nw, any_skip); break;
+      case 0: case 1: render_planes<4>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
+      case 2: render_planes<8>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
+      case 3: render_planes<12>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
+      default: render_planes<16>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
     }
   };
   const int64_t env0 = (int64_t)blockIdx.x * WAVE, env = env0 + lane;

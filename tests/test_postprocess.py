@@ -236,10 +236,12 @@ def test_feature_array_fused_into_the_step_kernel(skip_layers):
     if not skip_layers:
       np.testing.assert_array_equal(helpers.to_np(got), helpers.to_np(plain(obs)))
   assert helpers.to_np(eng.game_over).any() or True
-  # engines whose kernel has no epilogue say so and change nothing
-  tb = Engine.from_template(helpers.load_template('walkers_room'), batch=8)     # the table-driven kernel
+  # an epilogue kind the engine's kernel does not write is refused and changes nothing (the table-driven kernel:
+  # planar feature arrays only -- test_table_driven_kernel_writes_the_feature_array)
+  tb = Engine.from_template(helpers.load_template('walkers_room'), batch=8)
   tb.its_showtime()
-  assert not rendering.ObservationToFeatureArray('w').fuse_into(tb)
+  assert not rendering.ObservationToFeatureArray('w', permute=(1, 2, 0)).fuse_into(tb)
+  assert not rendering.ObservationToArray({c: 1.0 for c in (chr(x) for x in tb.template.chars)}, dtype=np.float32).fuse_into(tb)
 
 
 @pytest.mark.gpu
@@ -646,3 +648,105 @@ def test_device_outputs_cross_dlpack_without_a_copy():
     assert back2.data_ptr() == ten.data_ptr(), what
     assert torch.equal(back, ten)
   eng.close()
+
+
+# ---- the table-driven kernel's feature-array epilogue (round 4) --------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('jit', ['0', '1'])
+@pytest.mark.parametrize('mode', ['planes kept', 'skip_layers', 'skip_board'])
+@pytest.mark.parametrize('name', ['warehouse_L1'])  # (the trace with a planar feature array among its recorded post-processors)
+def test_table_driven_kernel_feature_array_matches_reference(name, mode, jit, monkeypatch, tmp_path):
+  """pcx_generic_step (both builds: table-driven and specialised per template) writes rendering.ObservationToFeatureArray
+  in its default axis order from its render loop: the traces' recorded feature arrays (outputs of the reference's own
+  class, rendering.py:545-661) at every recorded frame, with the uint8 planes kept, the layers dropped, everything dropped."""
+  from pycolab_amd import _native as N
+  from pycolab_amd.engine import Engine
+  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+  monkeypatch.setenv('PCX_GENERIC_JIT', jit)
+  monkeypatch.setenv('PCX_JIT_CACHE', str(tmp_path))
+  tr = helpers.load_trace(name)
+  specs, every = specs_of(tr)
+  t = helpers.load_template(tr['template'])
+  T, E = tr['actions'].shape
+  seen = 0
+  for i, sp in enumerate(specs):
+    if sp['kind'] != 'features' or tuple(sp['permute'] or (0, 1, 2)) != (0, 1, 2):
+      continue
+    eng = Engine.from_template(t, batch=E, auto_reset=True, seed=helpers.GOLDEN_RNG_SEED)
+    obs = eng.its_showtime()[0]
+    assert N.lib().pcx_engine_kernel_name(eng._native).decode() == 'pcx_generic_step'
+    assert int(N.lib().pcx_engine_launch_shape(eng._native)) == (31 if jit == '1' else 30)
+    po = make_post(sp)
+    assert po.fuse_into(eng, skip_layers=mode == 'skip_layers', skip_board=mode == 'skip_board'), (name, i)
+    fi = 0
+    for step in range(T + 1):
+      if step:
+        obs = eng.play(tr['actions'][step - 1])[0]
+      if step == 0 or step % every == 0:
+        want = tr['post_%d' % i][fi]
+        got = helpers.to_np(po(obs))
+        assert got.dtype == want.dtype and got.shape == want.shape
+        np.testing.assert_array_equal(got, want, err_msg='%s spec %d frame %d (%s)' % (name, i, step, mode))
+        if mode != 'skip_board':
+          np.testing.assert_array_equal(helpers.to_np(obs.board), tr['boards'][step], err_msg='board, frame %d' % step)
+        fi += 1
+    eng.close()
+    seen += 1
+  assert seen, 'no planar feature array among the recorded post-processors of %s' % name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('jit', ['0', '1'])
+@pytest.mark.parametrize('name,chars,batch', [('walkers_scroll_groups', None, 777), ('directives_z_order', None, 500), ('marauders_custom_A', 'PXB ab~', 333),
+                                               ('walkers_room', None, 4300), ('warehouse_custom_B', None, 650)])
+def test_table_driven_kernel_writes_the_feature_array(name, chars, batch, jit, monkeypatch, tmp_path):
+  """... on games only that kernel steps (prefab walkers in scrolling groups, z-order directives, an unshipped marauders
+  board) and on boards that are no whole number of dwords (7x11, 3x7): equal to the numpy oracle's feature array of the
+  board (oracle/postprocess.py) and to the stand-alone kernel every step, through auto-resets, with finished environments
+  left frozen; the three plane modes; a character the game does not have gives a plane of zeros; croppers and the epilogue
+  exclude each other."""
+  import torch
+  from pycolab_amd import _native as N
+  from pycolab_amd import cropping
+  from pycolab_amd.engine import Engine
+  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+  monkeypatch.setenv('PCX_GENERIC_JIT', jit)
+  monkeypatch.setenv('PCX_JIT_CACHE', str(tmp_path))
+  t = helpers.load_template(name)
+  game_chars = [chr(c) for c in t.chars]
+  chars = list(chars) if chars else game_chars[::-1] + ['~']
+  n_act = max(1, int(t.n_actions))
+  for mode in ('planes kept', 'skip_layers', 'skip_board'):
+    eng = Engine.from_template(t, batch=batch, auto_reset=True, seed=9)
+    twin = Engine.from_template(t, batch=batch, auto_reset=True, seed=9)
+    eng.its_showtime(); twin.its_showtime()
+    assert N.lib().pcx_engine_kernel_name(eng._native).decode() == 'pcx_generic_step'
+    assert int(N.lib().pcx_engine_launch_shape(eng._native)) == (31 if jit == '1' else 30)
+    fused, plain = rendering.ObservationToFeatureArray(chars), rendering.ObservationToFeatureArray(chars)
+    assert fused.fuse_into(eng, skip_layers=mode == 'skip_layers', skip_board=mode == 'skip_board')
+    rng = np.random.RandomState(2)
+    for step in range(40):
+      eng._auto_reset = twin._auto_reset = step % 4 != 3  # every fourth step leaves finished environments untouched
+      a = rng.randint(0, n_act, size=batch).astype(np.int32)
+      eng.step(a); twin.step(a)  # (step(): random actions make these games raise scrolling.Error now and then -- not this test's business)
+      obs, ref = eng._result()[0], twin._result()[0]
+      got = helpers.to_np(fused(obs))
+      board = helpers.to_np(ref.board)
+      layers = {c: helpers.to_np(ref.layers[c]) for c in game_chars}  # (occluded layers: layers[c] == (board == c))
+      want = np.stack([opost.feature_array({c: layers[c][e] for c in game_chars}, chars, board.shape[1:]) for e in range(batch)])
+      np.testing.assert_array_equal(got, want, err_msg='%s %s step %d' % (name, mode, step))
+      np.testing.assert_array_equal(got, helpers.to_np(plain(ref)), err_msg='stand-alone kernel, step %d' % step)
+      if mode != 'skip_board':
+        np.testing.assert_array_equal(helpers.to_np(obs.board), board)
+      if mode == 'planes kept':
+        for c in game_chars:
+          np.testing.assert_array_equal(helpers.to_np(obs.layers[c]), helpers.to_np(ref.layers[c]))
+    assert got[:, chars.index('~')].sum() == 0
+    if mode == 'planes kept':  # one or the other: croppers are refused while the epilogue is installed, taken once it is gone
+      crop = cropping.ScrollingCropper(3, 3, [chr(t.z_order[-1])], scroll_margins=(1, 1))
+      assert cropping.fuse_croppers(eng, [crop]) is False and not crop._fused
+      fused.unfuse()
+      assert cropping.fuse_croppers(eng, [crop]) is True
+      assert not rendering.ObservationToFeatureArray(chars).fuse_into(eng)
+    eng.close(); twin.close()
