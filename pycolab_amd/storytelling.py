@@ -79,6 +79,7 @@ class Story(object):
       self._engines = {}
       self._chapter_of = np.full((self._batch,), self._keys.index(first_chapter), np.int32)  # -1: story over
       self._next_override = None
+      self._entity_next_at_override = {}
       self._union = sorted(self._chars_sprites | self._chars_drapes | self._chars_backdrops)
       self._current_game = self._engine_for(first_chapter)
 
@@ -166,15 +167,27 @@ class Story(object):
       if len(key) != self._batch:
         raise ValueError('one next chapter per environment')
       self._next_override = list(key)
+    # "The last call before termination determines what happens" (plot.py:310-311), as at batch 1 (plot.py here):
+    # note what the entities' next_chapter words hold now -- only a word that changes afterwards is a later assignment
+    self._entity_next_at_override = {}
+    if self._next_override is not None:
+      for k, eng in self._engines.items():
+        if eng._native is not None and eng._assigns_next_chapter():
+          self._entity_next_at_override[k] = eng.entities_next_chapter().copy()
 
   def _next_of(self, env, chapter_index, assigned=None):
     """Where environment `env` goes after chapter `chapter_index`: what the host said
     (`set_next_chapter`), else what the chapter's entities assigned to
     `the_plot.next_chapter` (plot.py:299-324; `assigned`: the engine's per-environment
-    values), else the next chapter of a list."""
+    values), else the next chapter of a list -- and of the first two whichever spoke
+    LAST (the rule of batch 1: plot.py's next_chapter getter)."""
+    entity = assigned is not None and assigned[env] != _N.CHAPTER_UNSET
     if self._next_override is not None:
-      return self._next_override[env]
-    if assigned is not None and assigned[env] != _N.CHAPTER_UNSET:
+      before = self._entity_next_at_override.get(self._keys[chapter_index])
+      later = entity and (before is None or before[env] != assigned[env])  # an entity spoke after the host did
+      if not later:
+        return self._next_override[env]
+    if entity:
       return None if assigned[env] == _N.CHAPTER_NONE else int(assigned[env])
     if not self._auto_advance:
       return None

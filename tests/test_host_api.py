@@ -249,3 +249,31 @@ def test_class_fingerprint_is_of_the_normalised_source(tmp_path):
   # every digest in the shipped table has the AST form (16 hex digits) and no bytecode dependence
   from pycolab_amd._shipped_fingerprints import SHIPPED_FINGERPRINTS
   assert all(isinstance(fp, str) and len(fp) == 16 for _, fp in SHIPPED_FINGERPRINTS)
+
+
+import numpy as np  # noqa: E402
+
+
+def test_batched_story_last_assignment_of_next_chapter_wins():
+  """plot.py:310-311: "the last call before termination determines what happens".  Batch > 1: the host's
+  set_next_chapter() and the entities' the_plot.next_chapter assignments (device words) -- whichever spoke last; the
+  same rule the batch-1 plot applies.  Host logic only: no device."""
+  from pycolab_amd import _native as N
+  from pycolab_amd import storytelling
+  s = object.__new__(storytelling.Story)
+  s._keys, s._chapters, s._auto_advance, s._batch = [0, 1, 2, 3], {0: None, 1: None, 2: None, 3: None}, True, 4
+  s._next_override, s._entity_next_at_override = None, {}
+  U, NONE = N.CHAPTER_UNSET, N.CHAPTER_NONE
+  assigned = np.array([U, 2, 3, NONE], np.int32)
+  # nobody on the host spoke: the entities' words, else the list order
+  assert [s._next_of(e, 0, assigned) for e in range(4)] == [1, 2, 3, None]
+  assert s._next_of(0, 3, assigned) is None  # (the last chapter of the list)
+  # the host speaks when the words held [U, 2, 2, U]: environment 1's word has not changed since (the host is later),
+  # environments 2 and 3 were assigned after it (the entities are later), environment 0's entities never spoke
+  s._next_override = [0, 0, 0, 0]
+  s._entity_next_at_override = {0: np.array([U, 2, 2, U], np.int32)}
+  assert [s._next_of(e, 0, assigned) for e in range(4)] == [0, 0, 3, None]
+  # a chapter whose engine had no words yet when the host spoke: any word is a later assignment
+  assert [s._next_of(e, 1, assigned) for e in range(4)] == [0, 2, 3, None]
+  # engines whose entities never assign (assigned is None): the host's value
+  assert [s._next_of(e, 0, None) for e in range(4)] == [0, 0, 0, 0]
