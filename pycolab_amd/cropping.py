@@ -174,9 +174,7 @@ class FixedCropper(ObservationCropper):
 
   def __init__(self, top_left_corner, rows, cols, pad_char=None):
     super(FixedCropper, self).__init__()
-    self._top_row, self._left_col = top_left_corner
-    self._rows = rows
-    self._cols = cols
+    (self._top_row, self._left_col), (self._rows, self._cols) = top_left_corner, (rows, cols)
     self._pad_char = pad_char
 
   def crop(self, observation):
@@ -205,27 +203,27 @@ class ScrollingCropper(ObservationCropper):
   def __init__(self, rows, cols, to_track, pad_char=None,
                scroll_margins=(2, 3), initial_offset=None, saccade=True):
     super(ScrollingCropper, self).__init__()
-    self._rows = rows
-    self._cols = cols
-    self._to_track = copy.copy(to_track)
+    self._rows, self._cols = rows, cols
+    self._to_track = copy.copy(to_track)  # (the caller's list may change later: cropping.py:336)
     self._pad_char = pad_char
-    if ((scroll_margins[0] is None and (rows % 2 == 0)) or
-        (scroll_margins[1] is None and (cols % 2 == 0))):
-      raise ValueError(
-          'A ScrollingCropper can\'t perform perfectly-egocentric scrolling '
-          'with a window that has an even number of rows or columns. Either '
-          'specify looser scroll margins or use a window with odd dimensions.')
-    scroll_margins = (
-        (rows // 2) if scroll_margins[0] is None else scroll_margins[0],
-        (cols // 2) if scroll_margins[1] is None else scroll_margins[1])
-    if (2 * scroll_margins[0]) >= rows or (2 * scroll_margins[1]) >= cols:
+    # Margins per axis (cropping.py:338-357): None = keep the entity on the window's centre line, which an even
+    # window does not have; a margin that reaches the centre leaves no room to stand in.
+    window, margins = (rows, cols), []
+    for size, margin in zip(window, scroll_margins):
+      if margin is None and size % 2 == 0:
+        raise ValueError(
+            'A ScrollingCropper can\'t perform perfectly-egocentric scrolling '
+            'with a window that has an even number of rows or columns. Either '
+            'specify looser scroll margins or use a window with odd dimensions.')
+      margins.append(size // 2 if margin is None else margin)
+    if any(2 * margin >= size for size, margin in zip(window, margins)):
       raise ValueError(
           'A ScrollingCropper can\'t use scroll margins which extend to or '
           'beyond the very centre of the scrolling window. (Note that if you '
           'haven\'t specified scroll margins and your window is very small or '
           'thin, the default scroll_margins argument might be too big!)')
-    self._scroll_margins = scroll_margins
-    self._initial_offset = initial_offset if initial_offset is not None else (0, 0)
+    self._scroll_margins = tuple(margins)
+    self._initial_offset = (0, 0) if initial_offset is None else initial_offset
     self._saccade = saccade
 
   def set_engine(self, engine):

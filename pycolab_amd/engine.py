@@ -91,86 +91,89 @@ class Engine(object):
     if cropper in self._croppers:
       self._croppers.remove(cropper)
 
+  # The builder keeps the reference's surface (names, argument order, error texts: SURVEY 8b) around three steps of
+  # its own: _claim() = "may this be called now, and are these characters free", _plane() = a private, exactly-typed
+  # copy of a prefill, _adopt() = a new Sprite or Drape enters the z-order (in front) and the current update group.
+  def _claim(self, method_name, characters, single=False):
+    self._forbid_after_showtime(method_name)
+    self._require_good_characters(characters, mandatory_len=1 if single else None)
+    self._require_unclaimed(characters)
+
+  def _plane(self, prefill, dtype):
+    """A rows x cols array of `dtype` holding `prefill`, which must have that very dtype ('equiv' casting, as the
+    reference copies it: engine.py:325-327, :408-410) and broadcast to the board."""
+    plane = np.empty((self._rows, self._cols), dtype=dtype)
+    np.copyto(plane, prefill, casting='equiv')
+    return plane
+
+  def _adopt(self, character, thing):
+    self._sprites_and_drapes[character] = thing
+    self._update_groups[self._current_update_group].append(thing)
+    return thing
+
   def set_backdrop(self, characters, backdrop_class, *args, **kwargs):
-    """engine.py:248-279."""
-    return self.set_prefilled_backdrop(
-        characters, np.zeros((self._rows, self._cols), dtype=np.uint8),
-        backdrop_class, *args, **kwargs)
+    """engine.py:248-279: a backdrop whose curtain starts as all zeros."""
+    blank = np.zeros((self._rows, self._cols), dtype=np.uint8)
+    return self.set_prefilled_backdrop(characters, blank, backdrop_class, *args, **kwargs)
 
   def set_prefilled_backdrop(self, characters, prefill, backdrop_class,
                              *args, **kwargs):
     """engine.py:281-337."""
-    self._forbid_after_showtime('set_prefilled_backdrop')
-    self._require_good_characters(characters)
-    self._require_unclaimed(characters)
+    self._claim('set_prefilled_backdrop', characters)
     if self._backdrop:
       raise RuntimeError('A backdrop of type {} has already been supplied to '
                          'this Engine.'.format(type(self._backdrop)))
     if not issubclass(backdrop_class, things.Backdrop):
       raise TypeError('backdrop_class arguments to Engine.set_backdrop must '
                       'either be a Backdrop class or one of its subclasses.')
-    curtain = np.zeros((self._rows, self._cols), dtype=np.uint8)
-    np.copyto(dst=curtain, src=prefill, casting='equiv')
-    self._backdrop = backdrop_class(curtain, Palette(characters), *args, **kwargs)
+    self._backdrop = backdrop_class(self._plane(prefill, np.uint8), Palette(characters), *args, **kwargs)
     return self._backdrop
 
   def add_drape(self, character, drape_class, *args, **kwargs):
-    """engine.py:339-369."""
-    return self.add_prefilled_drape(
-        character, np.zeros((self._rows, self._cols), dtype=np.bool_),
-        drape_class, *args, **kwargs)
+    """engine.py:339-369: a drape whose curtain starts empty."""
+    nothing = np.zeros((self._rows, self._cols), dtype=np.bool_)
+    return self.add_prefilled_drape(character, nothing, drape_class, *args, **kwargs)
 
   def add_prefilled_drape(self, character, prefill, drape_class,
                           *args, **kwargs):
     """engine.py:371-421."""
-    self._forbid_after_showtime('add_prefilled_drape')
-    self._require_good_characters(character, mandatory_len=1)
-    self._require_unclaimed(character)
+    self._claim('add_prefilled_drape', character, single=True)
     if not issubclass(drape_class, things.Drape):
       raise TypeError('drape_class arguments to Engine.add_drape must be a '
                       'subclass of Drape')
-    curtain = np.zeros((self._rows, self._cols), dtype=np.bool_)
-    np.copyto(dst=curtain, src=prefill, casting='equiv')
-    drape = drape_class(curtain, character, *args, **kwargs)
-    self._sprites_and_drapes[character] = drape
-    self._update_groups[self._current_update_group].append(drape)
-    return drape
+    return self._adopt(character, drape_class(self._plane(prefill, np.bool_), character, *args, **kwargs))
 
   def add_sprite(self, character, position, sprite_class, *args, **kwargs):
     """engine.py:423-470."""
-    self._forbid_after_showtime('add_sprite')
-    self._require_good_characters(character, mandatory_len=1)
-    self._require_unclaimed(character)
+    self._claim('add_sprite', character, single=True)
     if not issubclass(sprite_class, things.Sprite):
       raise TypeError('sprite_class arguments to Engine.add_sprite must be a '
                       'subclass of Sprite')
-    if (not 0 <= position[0] < self._rows or
-        not 0 <= position[1] < self._cols):
+    row, col = position[0], position[1]
+    if not (0 <= row < self._rows and 0 <= col < self._cols):
       raise ValueError('Position {} does not fall inside a {}x{} game board.'
                        ''.format(position, self._rows, self._cols))
-    corner = things.Sprite.Position(self._rows, self._cols)
-    position = things.Sprite.Position(*position)
-    sprite = sprite_class(corner, position, character, *args, **kwargs)
-    self._sprites_and_drapes[character] = sprite
-    self._update_groups[self._current_update_group].append(sprite)
-    return sprite
+    board_corner = things.Sprite.Position(self._rows, self._cols)  # (what the reference hands a Sprite as `corner`)
+    return self._adopt(character, sprite_class(board_corner, things.Sprite.Position(*position), character, *args, **kwargs))
 
   def update_group(self, group_name):
-    """engine.py:472-489."""
+    """engine.py:472-489: what is added from now on updates in this group."""
     self._forbid_after_showtime('update_group')
     self._current_update_group = group_name
 
   def set_z_order(self, z_order):
-    """engine.py:491-518."""
+    """engine.py:491-518: `z_order` back to front, every Sprite and Drape exactly once."""
     self._forbid_after_showtime('set_z_order')
-    if (set(z_order) != set(self._sprites_and_drapes.keys()) or
-        len(z_order) != len(self._sprites_and_drapes)):
+    current = self._sprites_and_drapes
+    if len(z_order) != len(current) or any(c not in current for c in z_order) or len(set(z_order)) != len(current):
       raise ValueError('The z_order argument {} to Engine.set_z_order is not a '
                        'proper permutation of the characters corresponding to '
                        'Sprites and Drapes in this game, which are {}.'.format(
-                           repr(z_order), self._sprites_and_drapes.keys()))
-    self._sprites_and_drapes = collections.OrderedDict(
-        (c, self._sprites_and_drapes[c]) for c in z_order)
+                           repr(z_order), current.keys()))
+    reordered = collections.OrderedDict()
+    for character in z_order:
+      reordered[character] = current[character]
+    self._sprites_and_drapes = reordered
 
   def _frozen_update_groups(self):
     """Update groups sorted by name (engine.py:557-558)."""
