@@ -175,3 +175,23 @@ def test_default_policy_specialises_large_engines_only(monkeypatch, tmp_path):
   other = HipAdapter(t, 4096)
   other.reset()
   assert shape_of(other) == 30
+
+
+@pytest.mark.gpu
+def test_a_damaged_cache_entry_is_recompiled(monkeypatch, tmp_path):
+  """A code object that will not load (a file cut short on disk) is compiled again and replaced: the engine still gets
+  its specialised build."""
+  from tests.hip_adapter import HipAdapter
+  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+  monkeypatch.setenv('PCX_GENERIC_JIT', '1')
+  t = helpers.load_template('directives_reward_discount')
+  assert check(t, tmp_path)[0] == 0
+  monkeypatch.setenv('PCX_JIT_CACHE', str(tmp_path))
+  (entry,) = [f for f in os.listdir(tmp_path) if f.endswith('.hsaco')]
+  good = os.path.getsize(tmp_path / entry)
+  with open(tmp_path / entry, 'wb') as f:
+    f.write(b'not a code object')
+  hip = HipAdapter(t, 300)
+  hip.reset()
+  assert shape_of(hip) == 31
+  assert os.path.getsize(tmp_path / entry) == good
