@@ -45,6 +45,23 @@ def test_specialised_build_compiles_without_a_device(name, tmp_path):
   assert len(files) == 1 and os.path.getsize(tmp_path / files[0]) == size
 
 
+def test_every_golden_template_the_kernel_accepts_has_a_specialised_build(tmp_path):
+  """All of tests/golden/templates: a template either is refused by the table-driven kernel's plan (the scrolly_maze
+  programs have no device program there) or compiles -- no template may plan and then fail to build."""
+  import glob
+  built = refused = 0
+  for path in sorted(glob.glob(os.path.join(helpers.ROOT, 'tests', 'golden', 'templates', '*.npz'))):
+    name = os.path.basename(path)[:-4]
+    rc, size, log, _ = check(helpers.load_template(name), tmp_path)
+    if rc == 0:
+      assert size > 4096, name
+      built += 1
+    else:
+      assert rc == N.E_UNSUPPORTED and 'hiprtc' not in log and name.startswith('scrolly_'), (name, log[:500])
+      refused += 1
+  assert built >= 24 and refused >= 10, (built, refused)
+
+
 def test_code_objects_are_cached_by_content(tmp_path):
   t = helpers.load_template('walkers_room')
   rc, size, _, cold = check(t, tmp_path)
