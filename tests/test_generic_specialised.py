@@ -201,7 +201,10 @@ def test_a_damaged_cache_entry_is_recompiled(monkeypatch, tmp_path):
   from tests.hip_adapter import HipAdapter
   monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
   monkeypatch.setenv('PCX_GENERIC_JIT', '1')
-  t = helpers.load_template('directives_reward_discount')
+  t = helpers.load_template('walkers_room')
+  # (a board of its own: a build some earlier test of this process loaded would be served from memory, not from the cache)
+  free = np.argwhere(t.backdrop == ord(' '))
+  t.backdrop[tuple(free[len(free) // 2])] = ord('w')
   assert check(t, tmp_path)[0] == 0
   monkeypatch.setenv('PCX_JIT_CACHE', str(tmp_path))
   (entry,) = [f for f in os.listdir(tmp_path) if f.endswith('.hsaco')]
