@@ -70,3 +70,21 @@ def replay_trace(engine_factory, trace):
     eng.step(trace['actions'][t], auto_reset=True)
     check(t + 1)
   return eng
+
+
+_JIT_DIR = []
+
+
+def force_generic(monkeypatch, build='table-driven'):
+  """Step every game of this test with pcx_generic_step -- its table-driven build, or (build='specialised') the build
+  hiprtc makes for the engine's template, which only engines of 4,096 environments and more get by themselves.  The
+  code objects of a test process share one scratch cache directory."""
+  import tempfile
+  if not _JIT_DIR:
+    _JIT_DIR.append(tempfile.mkdtemp(prefix='pcx_jit_'))
+  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+  monkeypatch.setenv('PCX_GENERIC_JIT', '1' if build == 'specialised' else '0')
+  monkeypatch.setenv('PCX_JIT_CACHE', _JIT_DIR[0])
+
+
+BUILDS = ['table-driven', 'specialised']

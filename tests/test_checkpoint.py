@@ -9,14 +9,15 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 CASES = [('scrolly_maze_L0', 700, 0), ('marauders', 500, 0), ('warehouse_L1', 600, 0), ('better_scrolly_maze_L1', 300, 0),
-         ('hello_world', 400, 0), ('walkers_scroll_groups', 300, 0), ('directives_z_order', 300, 0), ('marauders', 300, 1)]
+         ('hello_world', 400, 0), ('walkers_scroll_groups', 300, 0), ('directives_z_order', 300, 0), ('marauders', 300, 1),
+         ('marauders', 300, 2), ('walkers_scroll_groups', 300, 2)]  # (2: through the table-driven kernel's build specialised for the template)
 
 
 @pytest.mark.parametrize('name,batch,force_generic', CASES)
 def test_resume_equals_uninterrupted(name, batch, force_generic, monkeypatch):
   from tests.hip_adapter import HipAdapter
   if force_generic:
-    monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+    helpers.force_generic(monkeypatch, 'specialised' if force_generic == 2 else 'table-driven')
   t = helpers.load_template(name)
   a = HipAdapter(t, batch, seed=7)
   a.reset()

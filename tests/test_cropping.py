@@ -333,18 +333,19 @@ def test_hand_written_kernels_fuse_drape_tracking_croppers(name, batch, kernel, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('build', helpers.BUILDS)
 @pytest.mark.parametrize('waves', ['1', '4'])
 @pytest.mark.parametrize('name,batch', [('walkers_room', 900), ('walkers_scroll_groups', 700), ('directives_z_order', 500),
                                         ('marauders', 600), ('warehouse_L0', 1000), ('hello_world', 400),
                                         ('better_scrolly_custom_B', 300)])
-def test_table_driven_kernel_fuses_croppers_drape_trackers_included(name, batch, waves, monkeypatch):
+def test_table_driven_kernel_fuses_croppers_drape_trackers_included(name, batch, waves, build, monkeypatch):
   """pcx_generic_step runs croppers itself, also those that follow a drape
   (the median of its raw curtain, cropping.py:590-598) or a priority list of
   drapes and sprites: step by step the windows equal those of the stand-alone
   cropper kernels on a twin engine; joining and leaving mid-episode."""
   import torch
   from pycolab_amd.engine import Engine
-  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+  helpers.force_generic(monkeypatch, build)  # (both builds of the kernel: the one hiprtc makes for the template too)
   monkeypatch.setenv('PCX_GENERIC_WAVES', waves)
   t = helpers.load_template(name)
   sprites = [chr(sp['ch']) for sp in t.sprites]

@@ -125,15 +125,16 @@ def test_hip_two_wave_pipeline_shape_matches_oracle(monkeypatch):
     assert_same(hip, orc, 'after step %d' % (t0 + 12))
 
 
+@pytest.mark.parametrize('build', helpers.BUILDS)
 @pytest.mark.parametrize('waves', ['1', '2', '4'])
 @pytest.mark.parametrize('name', ['marauders', 'warehouse_L2', 'walkers_scroll_groups', 'directives_z_order', 'hello_world',
                                   'warehouse_L0_unoccluded'])
-def test_hip_table_driven_kernel_waves_per_workgroup(name, waves, monkeypatch):
+def test_hip_table_driven_kernel_waves_per_workgroup(name, waves, build, monkeypatch):
   """The table-driven kernel picks 2, 4 or 8 waves per workgroup from the
   batch and the LDS footprint; test-size batches always get 8.  Force the
   others (what BASELINE-size batches run) and compare with the oracle."""
   from pycolab_amd import _native as N
-  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+  helpers.force_generic(monkeypatch, build)
   monkeypatch.setenv('PCX_GENERIC_WAVES', waves)
   t = helpers.load_template(name)
   t.param[0] = 0xD1CE

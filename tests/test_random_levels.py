@@ -8,6 +8,8 @@ boxes, one to six walkers, windows of 12 to 900 cells)."""
 import numpy as np
 import pytest
 
+from tests import helpers
+
 from oracle import binding
 from pycolab_amd import _native as N
 from pycolab_amd import ascii_art
@@ -221,10 +223,11 @@ def test_random_levels_match_oracle(maker, kernel, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('build', helpers.BUILDS)
 @pytest.mark.parametrize('maker', [random_warehouse, random_better_scrolly])
 @pytest.mark.parametrize('seed', range(4))
-def test_random_levels_match_oracle_through_the_table_driven_kernel(maker, seed, monkeypatch):
-  monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+def test_random_levels_match_oracle_through_the_table_driven_kernel(maker, seed, build, monkeypatch):
+  helpers.force_generic(monkeypatch, build)
   rng = np.random.RandomState(2000 + seed)
   t = GameTemplate.from_engine(maker(rng))
   _compare(t, 'pcx_generic_step', batch=int(rng.choice([70, 200])), steps=48, seed=0xBEAD + seed)
@@ -261,7 +264,8 @@ def _random_croppers(rng, t, track):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('maker,track,generic', [(random_warehouse, 'P', False), (random_better_scrolly, 'bP', False),
-                                                 (random_warehouse, 'XP', True), (random_better_scrolly, '@b', True)])
+                                                 (random_warehouse, 'XP', True), (random_better_scrolly, '@b', True),
+                                                 (random_warehouse, 'XP', 'specialised'), (random_better_scrolly, '@b', 'specialised')])
 @pytest.mark.parametrize('seed', range(6))
 def test_random_levels_fused_croppers_equal_stand_alone(maker, track, generic, seed, monkeypatch):
   """Random windows (padded and not, larger than the board, off the board, every
@@ -273,7 +277,7 @@ def test_random_levels_fused_croppers_equal_stand_alone(maker, track, generic, s
   from pycolab_amd import cropping
   from pycolab_amd.engine import Engine
   if generic:
-    monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+    helpers.force_generic(monkeypatch, 'specialised' if generic == 'specialised' else 'table-driven')
   rng = np.random.RandomState(3000 + seed)
   t = GameTemplate.from_engine(maker(rng))
   have = {chr(sp['ch']) for sp in t.sprites} | {chr(d['ch']) for d in t.drapes}
@@ -414,11 +418,11 @@ def random_marauders(rng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('generic', [False, True])
+@pytest.mark.parametrize('generic', [False, True, 'specialised'])
 @pytest.mark.parametrize('seed', range(5))
 def test_random_marauders_layouts_match_oracle(seed, generic, monkeypatch):
   if generic:
-    monkeypatch.setenv('PCX_FORCE_GENERIC', '1')
+    helpers.force_generic(monkeypatch, 'specialised' if generic == 'specialised' else 'table-driven')
   rng = np.random.RandomState(5000 + seed)
   t = GameTemplate.from_engine(random_marauders(rng))
   t.param[0] = 0xA11CE + seed  # seeds the marauders' return fire (np.random.choice, :253)
