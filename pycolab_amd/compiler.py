@@ -7,6 +7,7 @@ chosen for each entity.  It round-trips through `.npz` so that benchmark and
 GPU tests can run where the game files themselves are absent.
 """
 
+import ctypes
 import json
 
 import numpy as np
@@ -241,6 +242,23 @@ class GameTemplate(object):
 
   def thing_chars(self):
     return [chr(c) for c in self.z_order]
+
+  # -- the table-driven kernel's run-time build -----------------------------------
+  def prebuild(self):
+    """Compile (or find in the cache) the build of `pcx_generic_step` specialised for this template -- what an engine
+    of 4,096 environments or more would do at `its_showtime()` (1-3 s once per template; include/pcx.h
+    pcx_generic_specialise_check, csrc/pcx_generic.hip).  Needs no GPU: a deployment can fill `$PCX_JIT_CACHE` at
+    build time, or rank 0 for the others.  Returns the code object's size in bytes; raises `NotImplementedError` for
+    templates only the hand-written kernels step (scrolly_maze's programs) and `RuntimeError` with the compiler's
+    words if the build fails."""
+    ct, _keep = self.to_ctypes()
+    log, size = ctypes.create_string_buffer(1 << 16), N.c_i64(0)
+    rc = N.lib().pcx_generic_specialise_check(ctypes.byref(ct), log, len(log), ctypes.byref(size))
+    if rc == N.E_UNSUPPORTED and not log.value:
+      raise NotImplementedError(N.lib().pcx_last_error().decode())
+    if rc != 0:
+      raise RuntimeError('no specialised build of pcx_generic_step: ' + (log.value.decode() or N.lib().pcx_last_error().decode()))
+    return int(size.value)
 
   # -- ctypes image --------------------------------------------------------------
   def to_ctypes(self):

@@ -77,6 +77,21 @@ def test_code_objects_are_cached_by_content(tmp_path):
   assert len(os.listdir(tmp_path)) == 2
 
 
+def test_prebuild_from_python(tmp_path, monkeypatch):
+  """GameTemplate.prebuild(): a deployment fills the cache without a GPU (and a game built from pycolab's own API does)."""
+  monkeypatch.setenv('PCX_JIT_CACHE', str(tmp_path))
+  size = helpers.load_template('directives_z_order').prebuild()
+  assert size > 4096 and [os.path.getsize(tmp_path / f) for f in os.listdir(tmp_path)] == [size]
+  with pytest.raises(NotImplementedError):
+    helpers.load_template('scrolly_maze_L1').prebuild()
+  from oracle import directive_scenarios as ds
+  from pycolab_amd import ascii_art
+  from pycolab_amd.prefab_parts import tabled
+  game = ds.build_twin(ds.STORY[0], ascii_art, tabled)  # (a game assembled through ascii_art / the prefab parts)
+  assert game.template.prebuild() > 4096
+  assert len(os.listdir(tmp_path)) == 2
+
+
 def test_templates_the_table_driven_kernel_refuses(tmp_path):
   rc, size, _, _ = check(helpers.load_template('scrolly_maze_L0'), tmp_path)  # (pcx_scrolly_maze_step's programs: no device program here)
   assert rc == N.E_UNSUPPORTED
