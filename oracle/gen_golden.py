@@ -182,6 +182,14 @@ POST = {  # keyed by trace name: post-processor specs (JSON-able)
              permute=None),
     ],
 }
+# games only the table-driven kernel steps (round 4: its render loop writes the planar feature array itself): the
+# reference's ObservationToFeatureArray on prefab walkers in two scrolling groups, z-order directives, an unshipped
+# marauders board -- 'q' / '~' are characters the games do not have (planes of zeros)
+POST['walkers_scroll_groups'] = [dict(kind='features', layers='P%Qa# bq', permute=None)]
+POST['directives_z_order'] = [dict(kind='features', layers='cbaD.~', permute=None),
+                              dict(kind='to_array', mapping={'.': 0.0, 'D': 0.5, 'a': 1.0, 'b': 2.0, 'c': 4.0}, dtype='float32', permute=None)]
+POST['marauders_custom_A'] = [dict(kind='features', layers='XPB ayq', permute=None)]
+
 POST_EVERY = 8  # frames between recorded post-processor outputs
 
 # crop, THEN post-process (human_ui.py:252-265; better_scrolly_maze.py:237-247 into rendering.py:545-661): the

@@ -11,6 +11,8 @@ from pycolab_amd import rendering
 from tests import helpers
 
 POSTED = ['marauders', 'warehouse_L1']
+# games only the table-driven kernel steps: the reference's feature arrays (and one value array) recorded on them (round 4)
+POSTED_TABLE_DRIVEN = ['walkers_scroll_groups', 'directives_z_order', 'marauders_custom_A']
 
 
 def specs_of(trace):
@@ -29,7 +31,7 @@ def make_post(spec):
   return rendering.ObservationToArray(dict(spec['mapping']), dtype=np.dtype(spec['dtype']), permute=spec['permute'])
 
 
-@pytest.mark.parametrize('name', POSTED)
+@pytest.mark.parametrize('name', POSTED + POSTED_TABLE_DRIVEN)
 def test_oracle_postprocessors_match_reference(name):
   tr = helpers.load_trace(name)
   specs, every = specs_of(tr)
@@ -77,7 +79,7 @@ def test_constructor_guards():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', POSTED)
+@pytest.mark.parametrize('name', POSTED + POSTED_TABLE_DRIVEN)
 def test_device_postprocessors_match_reference(name):
   from pycolab_amd.engine import Engine
   tr = helpers.load_trace(name)
@@ -655,7 +657,7 @@ def test_device_outputs_cross_dlpack_without_a_copy():
 @pytest.mark.gpu
 @pytest.mark.parametrize('jit', ['0', '1'])
 @pytest.mark.parametrize('mode', ['planes kept', 'skip_layers', 'skip_board'])
-@pytest.mark.parametrize('name', ['warehouse_L1'])  # (the trace with a planar feature array among its recorded post-processors)
+@pytest.mark.parametrize('name', ['warehouse_L1'] + POSTED_TABLE_DRIVEN)  # (the traces with a planar feature array among their recorded post-processors)
 def test_table_driven_kernel_feature_array_matches_reference(name, mode, jit, monkeypatch, tmp_path):
   """pcx_generic_step (both builds: table-driven and specialised per template) writes rendering.ObservationToFeatureArray
   in its default axis order from its render loop: the traces' recorded feature arrays (outputs of the reference's own
