@@ -60,6 +60,22 @@ def test_every_golden_template_the_kernel_accepts_has_a_specialised_build(tmp_pa
       assert rc == N.E_UNSUPPORTED and 'hiprtc' not in log and name.startswith('scrolly_'), (name, log[:500])
       refused += 1
   assert built >= 24 and refused >= 10, (built, refused)
+  # The build's assembly scan (tools/sgpr_hazard_scan.py: an inline-asm VMEM instruction reading an SGPR a VALU wrote
+  # less than five wait states earlier) cannot see these kernels -- they are compiled at run time -- so the code
+  # objects are disassembled and scanned here.
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('sgpr_hazard_scan', os.path.join(helpers.ROOT, 'tools', 'sgpr_hazard_scan.py'))
+  scan = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(scan)
+  if not os.path.exists(scan.OBJDUMP):
+    pytest.skip('no llvm-objdump at ' + scan.OBJDUMP)
+  objects = sorted(f for f in os.listdir(tmp_path) if f.endswith('.hsaco'))
+  assert len(objects) == built
+  for f in objects:
+    lines = scan.disassemble(str(tmp_path / f))
+    assert sum('global_load_lds_dword' in l for l in lines) > 10 and any(l.startswith('_Zpcx_generic_step') for l in lines), f
+    body = [(i, l) for i, l in enumerate(lines, 1)]
+    assert scan.scan_kernel(f, 'pcx_generic_step', body) == [], f
 
 
 def test_code_objects_are_cached_by_content(tmp_path):

@@ -9,7 +9,8 @@ or offset.  The ISA wants 5 wait states there; the compiler inserts them for its
 Control flow is followed: the pending VALU writes at a branch travel to its target label (and fall through a
 conditional branch), merged at every label with the youngest age per register, iterated to a fixed point -- a write at
 the end of a predecessor block followed by an unguarded store at the head of a branch target is a hit.
-Usage: sgpr_hazard_scan.py file.s [...]; exit status 1 if anything was found."""
+Usage: sgpr_hazard_scan.py file.s | file.hsaco [...]; exit status 1 if anything was found.  (A code object is
+disassembled first: what the run-time builds of pcx_generic_step are checked with, tests/test_generic_specialised.py.)"""
 import re
 import sys
 
@@ -101,10 +102,35 @@ def scan_kernel(path, kernel, lines):
   return [hits[k] for k in sorted(hits)]
 
 
+OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+DIS_LABEL = re.compile(r'^[0-9a-f]+ <(L\d+)>:')
+DIS_SYMBOL = re.compile(r'^[0-9a-f]+ <(\w+)>:')
+
+
+def disassemble(path):
+  """A code object (the run-time builds of pcx_generic_step have no .s file) as lines this scanner reads: llvm-objdump
+  with symbolised branch targets, `<L5>:` as `L5:`, kernel symbols as `_Z...:` headers, encodings stripped."""
+  import subprocess
+  out = subprocess.check_output([OBJDUMP, '-d', '--symbolize-operands', '--no-show-raw-insn', path]).decode()
+  lines = []
+  for line in out.splitlines():
+    line = line.split('//')[0].rstrip()
+    m = DIS_LABEL.match(line)
+    if m:
+      lines.append(m.group(1) + ':')
+      continue
+    m = DIS_SYMBOL.match(line)
+    if m:
+      lines.append('_Z' + m.group(1) + ':')
+      continue
+    lines.append(line)
+  return lines
+
+
 def main(argv):
   bad = 0
   for path in argv:
-    text = open(path).read().splitlines()
+    text = disassemble(path) if path.endswith(('.hsaco', '.co', '.o')) else open(path).read().splitlines()
     kernel, body = '?', []
     out = []
     for n, line in enumerate(text, 1):
