@@ -334,7 +334,8 @@ const char* pcx_engine_kernel_name(const pcx_engine* e);
  * mean to measure is the one that ran; no reference counterpart).  pcx_scrolly_maze_step: 0 one single-wave
  * workgroup per group of 64 environments, 1 persistent single-wave workgroups with the next unit's state words
  * prefetched into LDS, 2 persistent logic/render wave pairs, 3 persistent workgroups of W workers with a streaming
- * semaphore (the default from 98,304 environments up), 4 two-wave pipeline workgroups (round 1, PCX_WAVES_PER_WG=2),
+ * semaphore (the default from 98,304 environments up), 5 the same with the shipped level's constants compiled in
+ * (pcx_debug_scrolly_consts), 4 two-wave pipeline workgroups (round 1, PCX_WAVES_PER_WG=2),
  * 10 cooperative (several waves per group), 11 / 12 several steps per launch (round 1's instance / the cooperative
  * shape walking them), 20 shape-generic instance; pcx_generic_step: 30 the
  * table-driven build, 31 the build specialised for the engine's template at run time; -1: the backend does not say. */
@@ -347,6 +348,13 @@ int32_t pcx_engine_launch_shape(const pcx_engine* e);
  * cache -- without creating an engine and WITHOUT a device: what `build` checks and the CPU tests call.  code_bytes: the
  * size of the code object; log: the compiler's words when it fails (PCX_E_UNSUPPORTED).  No reference counterpart. */
 int pcx_generic_specialise_check(const pcx_template* t, char* log, int64_t log_bytes, int64_t* code_bytes);
+/* Build-time aid (no reference counterpart): pcx_scrolly_maze_step exists once more with the constants of the reference's
+ * shipped level 0 (examples/scrolly_maze.py, MAZES_ART[0]) compiled in -- csrc/pcx_sm_shipped.h, generated by
+ * tools/gen_sm_shipped.py from what this entry answers.  It plans `t` for that kernel WITHOUT a device and copies the
+ * kernel's constants for work units of `unit` environments (64, 32, 16) as 32-bit words; returns their number (words ==
+ * NULL: only that), or a negative PCX_E_* when the kernel does not take the template.  An engine runs the baked
+ * instance only while its own constants equal the header's, word for word (pcx_engine_launch_shape 5). */
+int64_t pcx_debug_scrolly_consts(const pcx_template* t, int32_t unit, uint32_t* words, int64_t cap);
 /* Profiling aid (no reference counterpart): the phase timers the last launch left when the backend was asked to keep
  * them (pcx_scrolly_maze_step's persistent shapes under PCX_SM_PROF=1: 16 words per workgroup, 10 ns ticks; layout in
  * pcx_scrolly_maze.hip Ptrs::ps_prof).  out_host == NULL with words == -1 clears them.  Synchronous.  PCX_E_UNSUPPORTED from

@@ -97,9 +97,34 @@ struct Consts {
   // logic/render wave pair, and the owner-code buffers (code table + skip flags each)
   int32_t lds_ps_inbox, lds_ps_ring, lds_ps_cmask, lds_ps_buf0, lds_ps_buf_words, lds_ps_words1, lds_ps_words2;
   int32_t lds_ps_wave_words;  // PS == 3: from one wave's {inbox, coin masks, buffer} to the next wave's
+  int32_t lds_ps_lut;         // persistent owner-code shapes: 256 words "eight cell bits -> eight nibble masks", then the backdrop's owner codes as nibbles
   uint32_t chars_lo, chars_hi;  // characters 0..3 / 4..7 as bytes
   int32_t sprite_by_z[MAX_NS];  // sprites back to front
 };
+
+// The shipped level 0 with its Consts baked in (template parameter LV of the kernel).  pcx_sm_shipped.h is GENERATED
+// (tools/gen_sm_shipped.py: the words pcx_debug_scrolly_consts() answers for tests/golden/templates/scrolly_maze_L0.npz)
+// and committed; tests/test_host_api.py requires it to be what this library plans today, and launch() takes the baked
+// instance only when the engine's own Consts are the same words -- any other level, cast or layout keeps the instance
+// that reads them from the kernel arguments.  A header of another size (Consts changed, header not yet regenerated)
+// compiles to an instance nobody launches.
+#include "pcx_sm_shipped.h"
+constexpr int CONSTS_WORDS = (int)(sizeof(Consts) / 4);
+static_assert(sizeof(Consts) % 4 == 0, "Consts is a struct of 32-bit fields");
+struct ShippedWords { uint32_t w[PCX_SM_SHIPPED_L0_N > 0 ? PCX_SM_SHIPPED_L0_N : 1]; };
+static constexpr ShippedWords SHIPPED_L0_WORDS = {{PCX_SM_SHIPPED_L0_WORDS}};
+constexpr bool SHIPPED_L0_VALID = sizeof(ShippedWords) == sizeof(Consts);
+template <typename T>
+constexpr Consts consts_from_words(const T& raw) {
+  if constexpr (sizeof(T) == sizeof(Consts)) return __builtin_bit_cast(Consts, raw);
+  else return Consts{};
+}
+static constexpr Consts SHIPPED_L0 = consts_from_words(SHIPPED_L0_WORDS);
+template <int LV>
+__device__ __forceinline__ const Consts& baked_consts(const Consts& from_args) {
+  if constexpr (LV == 1) return SHIPPED_L0;
+  else return from_args;
+}
 
 struct Ptrs {
   const uint32_t* walls_bits;   // [PR][WPR]
@@ -600,11 +625,17 @@ __device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) {
 // CODES: the logic phase paints an owner-code byte per cell (LDS), the render loop
 // is one LDS read and one v_perm_b32 per plane (static shape, <= 8 characters).
 // PS: persistent launch shape of the owner-code instance (0: none; 1, 2: above).
+// LV: the instance of ONE level whose Consts are compile-time constants (pcx_sm_shipped.h; 0: none, Consts from the
+// kernel arguments).  Round 5: with every table entry, stride and z-order bit known, the probes' index arithmetic folds,
+// irrelevant probes disappear, and nothing of Consts competes for SGPRs (the run-time instance parked ~2,000 of its
+// 15,000 instructions' operands in VGPR lanes: v_readlane / v_writelane).
 template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false, bool EPI = false,
-          bool CODES = false, int PS = 0>
-__global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k, const Ptrs P, const StepArgs a,
+          bool CODES = false, int PS = 0, int LV = 0>
+__global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k_arg, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                   const crop::FusedCrops* fc_arg) {
+  static_assert(LV == 0 || (PS == 3 && CODES), "baked constants: the persistent owner-code instance");
+  const Consts& k = baked_consts<LV>(k_arg);
   // Fused croppers (include/pcx.h pcx_engine_fuse_croppers): the instances that keep the frame as curtain
   // bit vectors + sprite descriptors (pcx_stream.h's contract) and render a group in the round they step it
   constexpr bool FUSABLE = !TFUSE && !CODES && !UNOCC && !EPI;
@@ -756,6 +787,18 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   if constexpr (CODES) {
     uint32_t* lbc = lds_raw + k.lds_bdcode;
     for (int i = threadIdx.x; i < QW; i += blockDim.x) lbc[i] = P.backdrop4[QW * (1 + k.n_bchars) + i];
+  }
+  if constexpr (CODES && PS != 0) {
+    // (round 5) the owner-code table is built eight cells at a time: entry x of the first table turns eight cell bits
+    // into eight nibble masks in the code buffer's layout (bit b -> low nibble of byte b, bit 4 + b -> its high nibble);
+    // the second is the backdrop's owner codes in that layout
+    uint32_t* const lut = lds_raw + k.lds_ps_lut;
+    for (int x = threadIdx.x; x < 256; x += blockDim.x) {
+      const uint32_t lo = (((uint32_t)x & 0xFu) * 0x00204081u) & 0x01010101u, hi = (((uint32_t)x >> 4) * 0x00204081u) & 0x01010101u;
+      lut[x] = (lo | (hi << 4)) * 15u;
+    }
+    const uint32_t* const bd = P.backdrop4 + QW * (1 + k.n_bchars);
+    for (int m = threadIdx.x; m < (QW + 1) / 2; m += blockDim.x) lut[256 + m] = bd[2 * m] | (2 * m + 1 < QW ? bd[2 * m + 1] << 4 : 0u);
   }
   __syncthreads();  // LDS constants visible
 
@@ -1182,7 +1225,38 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
           }
         }
       }
-      if constexpr (CODES) {
+      if constexpr (CODES && PS != 0 && SR != 0) {
+        // (round 5) owner codes eight cells at a time: the cells' wall bits and coin bits are one byte each of the flat
+        // vectors; a 256-entry table turns a byte into the eight nibble masks of one code dword, and the curtains are laid
+        // over the backdrop's nibbles back to front with one v_bfi_b32 each (~9 instructions per eight cells; the
+        // arithmetic expansion below costs ~40)
+        const uint32_t* const lut = lds_raw + k.lds_ps_lut;
+        const uint32_t wcode8 = (uint32_t)k.lay_drape[0] * 0x11111111u, ccode8 = (uint32_t)k.lay_drape[1] * 0x11111111u;
+        constexpr int NM = (SR * SC / 4 + 1) / 2;
+        // (in chunks: a chunk's table reads are all in flight before its first code is composed -- the compiler cannot tell
+        // that the code buffer and the tables never overlap, so read / write pairs written one after the other stay that
+        // way, one LDS round trip each)
+        constexpr int CH = 13;
+#pragma unroll
+        for (int m0 = 0; m0 < NM; m0 += CH) {
+          uint32_t mw[CH], mc[CH], bd[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const int m = m0 + j < NM ? m0 + j : NM - 1;
+            mw[j] = lut[(accw[m >> 2] >> (8 * (m & 3))) & 0xFFu];
+            mc[j] = lut[(accc[m >> 2] >> (8 * (m & 3))) & 0xFFu];
+            bd[j] = lut[256 + m];
+          }
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            if (m0 + j >= NM) break;
+            uint32_t code = bd[j];
+            if (cash_in_front) { code = (code & ~mw[j]) | (wcode8 & mw[j]); code = (code & ~mc[j]) | (ccode8 & mc[j]); }
+            else               { code = (code & ~mc[j]) | (ccode8 & mc[j]); code = (code & ~mw[j]) | (wcode8 & mw[j]); }
+            codes[col * CODE_PITCH + m0 + j] = code;
+          }
+        }
+      } else if constexpr (CODES) {
         // owner codes of the backdrop, then the two curtains painted over them
         // (one in front of the other where both are set): four cells per dword
         const uint32_t* const bdcode = lds_raw + k.lds_bdcode;
@@ -1904,6 +1978,36 @@ class ScrollyMazeBackend : public Backend {
     if (!asked && bpad_ / WAVE < (int64_t)num_cus_ * 6) shape = 0;
     return shape;
   }
+  // The Consts a persistent launch hands to the kernel: the LDS buffers are sized by the unit (units of 32 or 16
+  // environments let more workers, or deeper rings, share a CU) and the mask path lays the level out differently.
+  Consts ps_consts(int unit, bool use_codes, int nb) const {
+    Consts kk = k_;
+    kk.lds_ps_buf_words = unit * (((k_.QW + 1) / 2) | 1) + WAVE;  // (owner codes as nibbles: the kernel's CODE_PITCH for NIB)
+    if (!use_codes) {
+      // mask path: the staged level ends with the backdrop-character masks instead of the backdrop's owner codes; a
+      // buffer is both curtains as flat bit vectors + the sprite descriptors of 64 environments + the skip flags
+      int o = k_.lds_bdcode;
+      kk.lds_bdmask = o; o += k_.n_bchars * k_.QW;
+      kk.lds_ps_ring = o; o += 4 + 2 * PS_NB_MAX;
+      kk.lds_ps_inbox = o; o += PS_IB_ROWS * WAVE;
+      kk.lds_ps_cmask = o; o += (k_.CW ? k_.CW : 1) * WAVE;
+      o = (o + 1) & ~1;  // (uint2 descriptors)
+      kk.lds_ps_buf0 = o;
+      kk.lds_ps_buf_words = 2 * WAVE * (k_.FW | 1) + 2 * k_.NS * WAVE + WAVE;
+    }
+    kk.lds_ps_words1 = kk.lds_ps_buf0 + kk.lds_ps_buf_words;
+    kk.lds_ps_words2 = kk.lds_ps_buf0 + nb * kk.lds_ps_buf_words;
+    kk.lds_ps_wave_words = kk.lds_ps_words1 - kk.lds_ps_inbox;  // PS == 3: a worker's {inbox, coin masks, buffer}
+    return kk;
+  }
+  void set_plan_only() { plan_only_ = true; }
+  const Consts& consts() const { return k_; }
+  // Are these launch-time Consts the baked ones (pcx_sm_shipped.h)?  PCX_SM_BAKED=0: never (A/B runs, tests of the other instance)
+  static bool baked_l0(const Consts& kk) {
+    if (!SHIPPED_L0_VALID) return false;
+    if (const char* e = getenv("PCX_SM_BAKED")) if (atoi(e) == 0) return false;
+    return memcmp(&kk, &SHIPPED_L0, sizeof kk) == 0;
+  }
   int max_fused_steps() const override { return fused_ok_ && !epi_.out && !fused_.on ? 256 : 1; }  // the epilogue / fused croppers have no multi-step instance
   // include/pcx.h pcx_engine_fuse_croppers: the instances that render from curtain bit vectors + sprite
   // descriptors cut the windows too (pcx_stream.h stream_windows); the owner-code and multi-step instances step aside
@@ -1974,6 +2078,7 @@ class ScrollyMazeBackend : public Backend {
   int num_cus_ = 256;
   int max_lds_ = 64 * 1024;  // per workgroup (hipDeviceProp_t::sharedMemPerBlock)
   bool unoccluded_ = false;
+  bool plan_only_ = false;
 };
 
 int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
@@ -2216,6 +2321,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     k.lds_words_codes = o;
     // persistent shapes: the same constants, then inbox, ring, coin masks and one / PS_NB owner-code buffers
     o = k.lds_bdcode + k.QW;
+    k.lds_ps_lut = o; o += 256 + (k.QW + 1) / 2;  // (the owner-code instances' bit -> nibble table and nibble backdrop)
     k.lds_ps_ring = o; o += 4 + 2 * PS_NB_MAX;  // [3]: PS == 3's streaming mutex
     k.lds_ps_inbox = o; o += PS_IB_ROWS * WAVE;
     k.lds_ps_cmask = o; o += (k.CW ? k.CW : 1) * WAVE;
@@ -2225,6 +2331,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     k.lds_ps_words2 = o + 2 * k.lds_ps_buf_words;  // (launch() sizes the buffers by the unit and the ring by PCX_SM_NB)
   }
 
+  if (plan_only_) return 0;  // (pcx_debug_scrolly_consts: the host half only, no device)
   {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -2348,27 +2455,11 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     P.ps_unit = unit;
     P.ps_dynamic = dynamic;
     P.ps_nb = nb;
-    Consts kk = k_;  // buffers sized by the unit: units of 32 or 16 environments let more pairs (or deeper rings) share a CU
-    kk.lds_ps_buf_words = unit * (((k_.QW + 1) / 2) | 1) + WAVE;  // (owner codes as nibbles: the kernel's CODE_PITCH for NIB)
-    if (!use_codes) {
-      // mask path: the staged level ends with the backdrop-character masks instead of the backdrop's owner codes; a
-      // buffer is both curtains as flat bit vectors + the sprite descriptors of 64 environments + the skip flags
-      int o = k_.lds_bdcode;
-      kk.lds_bdmask = o; o += k_.n_bchars * k_.QW;
-      kk.lds_ps_ring = o; o += 4 + 2 * PS_NB_MAX;
-      kk.lds_ps_inbox = o; o += PS_IB_ROWS * WAVE;
-      kk.lds_ps_cmask = o; o += (k_.CW ? k_.CW : 1) * WAVE;
-      o = (o + 1) & ~1;  // (uint2 descriptors)
-      kk.lds_ps_buf0 = o;
-      kk.lds_ps_buf_words = 2 * WAVE * (k_.FW | 1) + 2 * k_.NS * WAVE + WAVE;
-    }
-    kk.lds_ps_words1 = kk.lds_ps_buf0 + kk.lds_ps_buf_words;
-    kk.lds_ps_words2 = kk.lds_ps_buf0 + nb * kk.lds_ps_buf_words;
+    const Consts kk = ps_consts(unit, use_codes, nb);
     // PS == 3: `waves` workers per workgroup, each with its own {inbox, coin masks, buffer}
     int waves = 2;
     if (const char* e = getenv("PCX_SM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) waves = v; }
     if (const char* e = getenv("PCX_SM_LOCK")) P.ps_lock = atoi(e);
-    kk.lds_ps_wave_words = kk.lds_ps_words1 - kk.lds_ps_inbox;
     const int words3 = kk.lds_ps_inbox + waves * kk.lds_ps_wave_words;
     int64_t n_units = (bpad_ + unit - 1) / unit, resident = (int64_t)num_cus_ * per_cu;
     if (const char* e = getenv("PCX_SM_GRID")) { const int v = atoi(e); if (v >= 1) resident = v; }  // (tests: few workgroups, many units each)
@@ -2382,6 +2473,8 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
         PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
         PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
+        PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
         raised = true;
       }
@@ -2421,7 +2514,11 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
     else if (shape == 1 && !use_codes)
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 1>), pgrid, dim3(WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
-    else if (shape == 3)
+    else if (shape == 3 && baked_l0(kk)) {
+      // the engine's Consts are the shipped level 0's, word for word: the instance that has them as compile-time constants
+      last_shape_ = 5;
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3, 1>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
+    } else if (shape == 3)
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
     else if (shape == 2)
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 2>), pgrid, dim3(2 * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
@@ -2513,6 +2610,21 @@ int ScrollyMazeBackend::read_things(int64_t env0, int64_t n, pcx_sprite_state* s
 }
 
 }  // namespace sm
+
+// include/pcx.h pcx_debug_scrolly_consts
+int64_t scrolly_maze_consts(const pcx_template& t, int32_t unit, uint32_t* words, int64_t cap) {
+  sm::ScrollyMazeBackend b;
+  b.set_plan_only();
+  const int rc = b.init(t, 64);
+  if (rc) return rc;
+  if (unit != 16 && unit != 32 && unit != 64) return set_error(PCX_E_INVALID, "pcx_debug_scrolly_consts: units are 16, 32 or 64 environments");
+  const sm::Consts kk = b.ps_consts(unit, true, 2);
+  if (words) {
+    if (cap < sm::CONSTS_WORDS) return set_error(PCX_E_INVALID, "pcx_debug_scrolly_consts: room for %d words needed", sm::CONSTS_WORDS);
+    memcpy(words, &kk, sizeof kk);
+  }
+  return sm::CONSTS_WORDS;
+}
 
 Backend* make_scrolly_maze_backend() { return new sm::ScrollyMazeBackend(); }
 

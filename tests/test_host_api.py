@@ -277,3 +277,24 @@ def test_batched_story_last_assignment_of_next_chapter_wins():
   assert [s._next_of(e, 1, assigned) for e in range(4)] == [0, 2, 3, None]
   # engines whose entities never assign (assigned is None): the host's value
   assert [s._next_of(e, 0, None) for e in range(4)] == [0, 0, 0, 0]
+
+
+def test_baked_level_constants_header_is_what_the_library_plans():
+  """csrc/pcx_sm_shipped.h (the shipped scrolly_maze level 0's kernel constants, compiled into one instance of
+  pcx_scrolly_maze_step) is generated from pcx_debug_scrolly_consts and committed: it must be what the library plans for
+  the golden template today, or the fast instance silently stops being used.  Other levels answer other words."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('gen_sm_shipped', os.path.join(helpers.ROOT, 'tools', 'gen_sm_shipped.py'))
+  gen = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(gen)
+  words = gen.planned_words()
+  assert gen.header_words() == words, 'run tools/gen_sm_shipped.py and rebuild libpcx.so'
+  assert open(gen.HEADER).read() == gen.render(words)
+  t1 = helpers.load_template('scrolly_maze_L1')
+  ct, _keep = t1.to_ctypes()
+  buf = (ctypes.c_uint32 * len(words))()
+  n = N.lib().pcx_debug_scrolly_consts(ctypes.byref(ct), 64, buf, len(words))
+  assert n == len(words) and list(buf) != words
+  wh = helpers.load_template('warehouse_L0')
+  ct, _keep = wh.to_ctypes()
+  assert N.lib().pcx_debug_scrolly_consts(ctypes.byref(ct), 64, None, 0) < 0  # (not a scrolly_maze template)

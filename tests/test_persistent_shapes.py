@@ -52,9 +52,15 @@ def assert_same(hip, orc, where):
   np.testing.assert_array_equal(hip.curtains(), orc.curtains(), err_msg=where + ': curtains')
 
 
-def shape_of(hip):
+def raw_shape_of(hip):
   from pycolab_amd import _native as N
   return int(N.lib().pcx_engine_launch_shape(hip.eng._native))
+
+
+def shape_of(hip):
+  """The launch shape; 5 is shape 3 run by the instance with the shipped level's constants compiled in."""
+  s = raw_shape_of(hip)
+  return 3 if s == 5 else s
 
 
 @pytest.mark.parametrize('shape,codes,waves,lock,grid,dynamic', [(3, 0, 4, 1, 2, 1), (3, 0, 3, 2, 3, 0), (3, 0, 12, 3, 1, 1), (1, 0, 1, 0, 5, 1),
@@ -171,4 +177,72 @@ def test_persistent_shapes_at_config_5_shard_size(shape, unit):
   chars = torch.tensor(list(t.chars), dtype=torch.uint8, device=planes.device)
   want = (planes[:, :1] == chars.view(1, -1, 1, 1)).to(torch.uint8)
   assert torch.equal(planes[:, 1:], want)
+  assert not hip.eng.buffers['error'].tensor.any()
+
+
+@pytest.mark.parametrize('baked,waves,lock,grid,dynamic', [(1, 2, 1, 5, 1), (0, 2, 1, 5, 1), (1, 3, 2, 3, 0), (1, 6, 2, 1, 1), (1, 2, 0, 4096, 1)])
+def test_instance_with_the_shipped_levels_constants_compiled_in(baked, waves, lock, grid, dynamic):
+  """Round 5: shape 3 exists twice -- Consts from the kernel arguments, and the shipped level 0's Consts as compile-time
+  constants (csrc/pcx_sm_shipped.h); an engine whose own constants equal the header's runs the second (launch shape 5),
+  PCX_SM_BAKED=0 keeps the first.  Both against the oracle on a ragged batch, resets included."""
+  t = helpers.load_template('scrolly_maze_L0')
+  B, T = 2999, 160
+  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=3, PCX_SM_BAKED=baked, PCX_SM_WAVES=waves, PCX_SM_LOCK=lock, PCX_SM_GRID=grid, PCX_SM_DYNAMIC=dynamic):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    assert_same(hip, orc, 'frame 0')
+    t0 = 0
+    while t0 < T:
+      n = 1 if t0 < 24 else 8
+      hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
+      assert raw_shape_of(hip) == (5 if baked else 3)
+      t0 += n
+      assert_same(hip, orc, 'baked %d after step %d' % (baked, t0))
+    assert int(orc.read('frame').min()) < T
+
+
+def test_other_levels_keep_the_run_time_constants():
+  """Level 1 has the shipped shape but other constants: the baked instance must not take it."""
+  t = helpers.load_template('scrolly_maze_L1')
+  B = 1500
+  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=3, PCX_SM_GRID=4):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    for t0 in range(0, 64, 8):
+      hip.step_hashed(0x5EED, t0, 8); orc.step_hashed(0x5EED, t0, 8)
+      assert raw_shape_of(hip) in (3, 20)
+      assert_same(hip, orc, 'level 1 after step %d' % (t0 + 8))
+
+
+def test_headline_batch_default_shape_equals_one_workgroup_per_group_shape_everywhere():
+  """1,048,576 environments (the headline): what the default launch shape writes -- persistent workers, LDS-DMA state
+  prefetch that relies on vmcnt retiring in order, the baked-constants instance -- equals, over the WHOLE batch, what the
+  one-workgroup-per-group shape writes for the same tape; the first, the last and 2,048 environments from the middle
+  against the oracle."""
+  import torch
+  t = helpers.load_template('scrolly_maze_L0')
+  B, T, K = 1048576, 24, 2048
+  hip = HipAdapter(t, B)
+  hip.reset()
+  hip.step_hashed(0xC0FFEE, 0, T)
+  assert raw_shape_of(hip) == 5
+  planes = hip.eng.planes_view()
+  with Knobs(PCX_SM_SHAPE=0):
+    ref = HipAdapter(t, B)
+    ref.reset()
+    ref.step_hashed(0xC0FFEE, 0, T)
+    assert raw_shape_of(ref) == 0
+  step = 65536
+  for lo in range(0, B, step):  # (piecewise: no 2.8 GB temporary)
+    assert torch.equal(planes[lo:lo + step], ref.eng.planes_view()[lo:lo + step]), 'planes differ in environments %d..' % lo
+  for name in ('reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+    assert torch.equal(hip.eng.buffers[name].tensor, ref.eng.buffers[name].tensor), name
+  del ref
+  for off in (0, B // 2 - 1000, B - K):
+    orc = OracleAdapter(t, K)
+    orc.reset()
+    orc.step_hashed(0xC0FFEE, 0, T, env_offset=off)
+    np.testing.assert_array_equal(planes[off:off + K].cpu().numpy(), orc.read('planes'), err_msg='environments from %d' % off)
+    for name in ('reward', 'reward_set', 'discount', 'done', 'frame'):
+      np.testing.assert_array_equal(hip.eng.buffers[name].tensor[off:off + K].cpu().numpy(), orc.read(name), err_msg=name)
   assert not hip.eng.buffers['error'].tensor.any()

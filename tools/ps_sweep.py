@@ -14,11 +14,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KNOBS = ('PCX_SM_TAIL', 'PCX_SM_TAIL_UNIT', 'PCX_DEBUG', 'PCX_SM_WAVES', 'PCX_SM_LOCK', 'PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_PER_CU', 'PCX_WAVES_PER_CU', 'PCX_WAVES_PER_WG',
+KNOBS = ('PCX_SM_BAKED', 'PCX_SM_TAIL', 'PCX_SM_TAIL_UNIT', 'PCX_DEBUG', 'PCX_SM_WAVES', 'PCX_SM_LOCK', 'PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_PER_CU', 'PCX_WAVES_PER_CU', 'PCX_WAVES_PER_WG',
          'PCX_WGS_PER_CU', 'PCX_SM_CODES', 'PCX_SM_PRIO', 'PCX_SM_NB', 'PCX_SM_GRID')
 
 VARIANTS = {
     'auto':        {},
+    'unbaked':     {'PCX_SM_BAKED': 0},
     'auto_t0':     {'PCX_SM_TAIL': 0},
     'auto_t1':     {'PCX_SM_TAIL': 1},
     'auto_t3':     {'PCX_SM_TAIL': 3},
@@ -188,7 +189,7 @@ def main():
         torch.cuda.synchronize()
         times[name].append(ev0.elapsed_time(ev1) / K)
         shapes[name] = int(N.lib().pcx_engine_launch_shape(eng._native))
-        if args.prof and rep == 0 and shapes[name] in (1, 2, 3):
+        if args.prof and rep == 0 and shapes[name] in (1, 2, 3, 5):
           profile(eng, tape[W], name, B)
     eng.check_errors()
     for name in variants:
