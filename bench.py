@@ -39,7 +39,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-REFERENCE = os.environ.get('PCX_REFERENCE', '/root/reference')
+
+
+def reference_dir():
+  """Where the reference can be imported from for the CPU-baseline leg: /root/reference (the build container) or the
+  bytecode oracle/make_ref.py built from it under oracle/_ref (travels to the GPU box with the other build products)."""
+  from oracle import make_ref
+  return make_ref.available()
 
 FIXTURES = {'scrolly_maze': 'scrolly_maze_L%d', 'warehouse': 'warehouse_L%d', 'marauders': 'marauders',
             'hello_world': 'hello_world', 'better_scrolly_maze': 'better_scrolly_maze_L%d',
@@ -71,19 +77,18 @@ def cpu_baseline(template_path, budget_envs=1024, steps=512, max_procs=64):
   total = cores * budget_envs * steps
   return {'value': total / wall, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
           'sample': 'oracle/pcx_oracle.c, %d procs x %d envs x %d steps of the same workload '
-                    '(stepping wall %.1f s); the imported Python reference itself measured 7.6 k env-steps/s '
-                    'per core in the build container (BASELINE.md) and is absent on the GPU box'
-                    % (cores, budget_envs, steps, wall)}
+                    '(stepping wall %.1f s)' % (cores, budget_envs, steps, wall)}
 
 
 def cpu_reference_python(game, level, seconds=10.0, max_procs=64):
-  """The REAL reference (`/root/reference`, imported) on this box's host cores:
-  present in the build container only, so a run there carries the reference's own
-  env-steps/s next to the C port's.  TEST INFRASTRUCTURE leg (oracle/ref_timing.py)."""
-  if not os.path.isdir(os.path.join(REFERENCE, 'pycolab')):
+  """The REAL reference (google-deepmind/pycolab, imported: engine.py:520-639 around the unchanged example game) on this
+  box's host cores, same run, same workload (hashed actions, rebuild on game over): one Engine per core for `seconds`.
+  TEST INFRASTRUCTURE leg (oracle/ref_timing.py); None where the reference is not available."""
+  ref = reference_dir()
+  if ref is None:
     return None
   from oracle import ref_timing
-  return ref_timing.measure(REFERENCE, game, level, seconds=seconds, max_procs=max_procs)
+  return ref_timing.measure(ref, game, level, seconds=seconds, max_procs=max_procs)
 
 
 def pmc_traffic(game, level, batch):
@@ -504,10 +509,16 @@ def main():
                                measure_config('walkers_scroll_groups', 0, 262144, 100, 30, device,
                                               raises='uniform random actions give conflicting scroll orders (scrolling.Error, protocols/scrolling.py:372-434); the error bit is per environment and the step goes on')]
     if not args.no_cpu_baseline:  # (rank 0's host cores, N > 1 included)
-      line['cpu_baseline'] = cpu_baseline(template_path)
-      ref = cpu_reference_python(args.game, args.level)
+      # north_star: "the reference CPU Engine timed on the same box's host cores (core count stated) in the same run" --
+      # the imported reference where it is available (kind "reference"), with the C restatement of it ("port") next to
+      # it; the port alone where it is not
+      port = cpu_baseline(template_path)
+      ref = cpu_reference_python(args.game, args.level) if args.game in ('scrolly_maze', 'warehouse', 'marauders', 'hello_world', 'better_scrolly_maze') else None
       if ref is not None:
-        line['cpu_reference_python'] = ref
+        line['cpu_baseline'] = ref
+        line['cpu_baseline_port'] = port
+      else:
+        line['cpu_baseline'] = port
     print(json.dumps(line))
   if distributed:
     dist.barrier()

@@ -59,8 +59,8 @@ def measure(reference, game, level, seconds=10.0, max_procs=64):
   wall = max(r[1] for r in res)
   return {'value': steps / wall, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'reference',
           'per_core': steps / wall / cores,
-          'sample': 'the imported Python reference (%s/pycolab/examples/%s.py), %d procs x one Engine each, '
-                    '%.1f s of stepping, hashed actions + rebuild-on-game-over' % (reference, GAMES[game][0], cores, wall)}
+          'sample': 'the imported Python reference (pycolab.examples.%s.make_game -> engine.py its_showtime / play, from %s), %d procs x one Engine each, '
+                    '%.1f s of stepping, hashed actions + rebuild-on-game-over' % (GAMES[game][0], reference, cores, wall)}
 
 
 if __name__ == '__main__':

@@ -31,6 +31,7 @@ class ObservationCropper(object):
     self._pitch = 0
     self._generation = 0    # bumped whenever the native cropper (and its buffers) is rebuilt
     self._fused = False     # the engine's step kernel moves the window and writes the planes (fuse_croppers)
+    self._feat_skip = 0     # ... and which of the window's own uint8 planes the kernel then no longer writes (1 layers, 2 board too)
     self._features = None   # (converter, float tensor): the window's feature stack the step kernel writes too
                             # (rendering.ObservationToFeatureArray.fuse_into(engine, source=cropper)); the cropper
                             # holds the tensor for as long as the kernel may write it
@@ -56,6 +57,7 @@ class ObservationCropper(object):
     other = copy.copy(self)
     other._engine, other._native, other._out, other._fused = None, None, None, False
     other._features = None
+    other._feat_skip = 0
     other._generation = 0
     return other
 
@@ -80,6 +82,7 @@ class ObservationCropper(object):
       if self._features is not None:
         self._features[0]._window_gone()
         self._features = None
+      self._feat_skip = 0
       self._generation += 1
 
   def __del__(self):
@@ -126,6 +129,13 @@ class ObservationCropper(object):
       view = self._out.tensor.as_strided((B, P, r, c), (P * self._pitch, self._pitch, c, 1))
       obs = rendering.Observation(board=view[:, 0], layers={chr(ch): view[:, 1 + k] for k, ch in enumerate(chars)})
     obs._source = self
+    if self._fused and self._feat_skip:
+      # the step kernel writes this window's float32 stack INSTEAD of (some of) its uint8 planes (fuse_into(...,
+      # source=cropper, skip_layers / skip_board)): what is left here is frozen, so it is not handed out -- as
+      # Engine._result() does for the full board -- and a post-processor that would read it raises
+      obs = rendering.Observation(board=None if self._feat_skip == 2 else obs.board, layers={})
+      obs._source = self
+      obs._planes_stale = True
     return obs
 
   def check_errors(self):

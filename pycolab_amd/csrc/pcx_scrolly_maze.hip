@@ -143,6 +143,7 @@ struct Ptrs {
   int32_t ps_nb;    // owner-code buffers of a logic/render pair (the logic wave runs up to ps_nb - 1 units ahead)
   int32_t ps_prio;  // s_setprio of the pair's render wave (0: leave alone)
   int32_t ps_lock;  // PS == 3: at most this many waves of a workgroup in their render loop at a time (0: no limit)
+  int32_t ps_steal; // tickets: a worker whose shard of the work counter is dry draws from the other shards (PCX_SM_STEAL=0: goes home)
   // the batch's last environments go in SMALL units (ps_tail_unit environments each; units ps_n1 and up), so that what the
   // workers hold when the tickets run out -- the launch's tail -- is short; ps_n1 = all units when there is no such region
   int32_t ps_tail_unit;
@@ -754,6 +755,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   const uint32_t ps_local = (blockIdx.x / ps_shards) * ps_wpw + (PS == 3 ? (uint32_t)wave : 0u);
   uint32_t* const ps_ctr_mine = P.ps_ctr + 16u * ps_x;
   uint32_t ps_u = P.ps_dynamic ? ps_x + ps_shards * ps_local : ps_wid, ps_un = 0;
+  uint32_t ps_steal = 0;  // shards this worker has found dry (it draws from shard ps_x + ps_steal)
   bool ps_need_wait = true;
   const bool ps_prof = PS != 0 && P.ps_prof != nullptr;
   uint32_t pt_units = 0, pt_a = 0, pt_b = 0, pt_c = 0, pt_d = 0, pt_mark = 0;
@@ -1541,7 +1543,23 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
     // the next unit is drawn (scalar atomic, ~1 us) and its state words start travelling now, in front of this unit's
     // plane stores: they have landed when the loop below is through (vmcnt is in order, 63 at most)
     if (ps_prof) { const uint32_t t = ps_now(); pt_c += t - pt_mark; pt_mark = t; ++pt_units; }
-    ps_un = P.ps_dynamic ? ps_x + ps_shards * (ps_shard_nwk + ps_ticket(ps_ctr_mine)) : ps_u + ps_nwk;
+    if (P.ps_dynamic) {
+      // (round 5) ... from its own shard's counter while that has units, then from the other shards' in turn: the XCDs do
+      // not finish together (phase timers: worker lifetimes 435-558 us around a mean of 493 at 1,048,576 environments --
+      // the launch ended 65 us after its average worker), and a worker whose shard is dry takes what a slower one has left
+      // instead of going home.  A shard found dry stays dry, so a worker asks every counter at most once too often.
+      ps_un = ps_n;
+      while (ps_steal < ps_shards) {
+        const uint32_t y = ps_x + ps_steal >= ps_shards ? ps_x + ps_steal - ps_shards : ps_x + ps_steal;
+        const uint32_t nwk_y = ((gridDim.x - y + ps_shards - 1u) / ps_shards) * ps_wpw;
+        const uint32_t cand = y + ps_shards * (nwk_y + ps_ticket(P.ps_ctr + 16u * y));
+        if (cand < ps_n) { ps_un = cand; break; }
+        if (!P.ps_steal) { ps_steal = ps_shards; break; }
+        ++ps_steal;
+      }
+    } else {
+      ps_un = ps_u + ps_nwk;
+    }
     if (ps_un < ps_n) ps_prefetch(ps_un);
     if (PS == 3 && P.ps_lock) {
       // at most ps_lock streaming waves per workgroup: a counting semaphore in LDS (lane 0 alone adds; a wave that
@@ -1865,6 +1883,11 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   }  // passes
   };  // sweeps
   if constexpr (PS == 1 || PS == 3) {
+    // (round 5, measured and dropped: composing board-dword PAIRS and storing them with global_store_dwordx2 -- half the
+    // iterations and store instructions -- runs at 0.97-1.04 ms per 1,048,576 environments against 0.58-0.61 for this
+    // dword loop, 8-byte aligned or not: the CU's write path moves a unit in ~13 us with dwordx2 stores whatever the
+    // number of streaming waves, in ~8.3 us with dword stores; profiles/r05_tuning.md)
+    const int stores_behind = n_iter * (1 + SL);
     sweeps(std::integral_constant<int, 0>{});
     if (PS == 3 && P.ps_prio) __builtin_amdgcn_s_setprio(0);
     if (PS == 3 && P.ps_lock) {  // (the last plane store is issued: the next wave may stream)
@@ -1875,7 +1898,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
     }
     // fewer than 64 plane stores behind the DMA and the ticket (units with environments left alone, ablation
     // runs): wait for them; otherwise the next unit's logic phase starts at once
-    ps_need_wait = any_skip || a.debug != 0 || n_iter * (1 + SL) < 64 || !planes_on;
+    ps_need_wait = any_skip || a.debug != 0 || stores_behind < 64 || !planes_on;
     if (ps_need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ps_u = ps_un;
     if (ps_prof) pt_d += ps_now() - pt_mark;
@@ -2392,7 +2415,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   if (const char* pad = getenv("PCX_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   if (lds > 64 * 1024) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds);
   Ptrs P{walls_.ptr, backdrop4_.ptr, coinbits_.ptr, rowbase_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_,
-         ps_ctr_.ptr, WAVE, 1, 2, 0, 1, 16, 0, 0, nullptr};
+         ps_ctr_.ptr, WAVE, 1, 2, 0, 1, 1, 16, 0, 0, nullptr};
   // Specialised instance for the shipped scrolly_maze shape (10x30 board,
   // 8 characters, 'abcP' sprites); anything else takes the generic instance.
   const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
@@ -2435,9 +2458,14 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   } else if (shipped_shape && waves_per_wg == 1 && ps_shape(a) != 0 && (use_codes || ps_shape(a) != 2)) {
     // persistent shapes of the owner-code instance (see the kernel): workgroups stay and draw work units
     const int shape = ps_shape(a);
-    int unit = WAVE, per_cu = shape == 2 ? 3 : 8, dynamic = 1;
-    if (shape == 3) {
-      // two workers per workgroup, one of them streaming.  Few units per worker (config 5's shard: 2,048 units): four
+    int unit = WAVE, per_cu = shape == 2 ? 3 : 8, dynamic = 1, waves = 2;
+    if (const char* e = getenv("PCX_SM_UNIT")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) unit = v; }
+    int nb = 2;
+    if (const char* e = getenv("PCX_SM_NB")) { const int v = atoi(e); if (v >= 2 && v <= PS_NB_MAX) nb = v; }
+    const Consts kk = ps_consts(unit, use_codes, nb);
+    const bool baked = shape == 3 && use_codes && baked_l0(kk);  // the instance with the level's constants compiled in steps a unit in ~9 us, the other in ~20
+    if (shape == 3 && !baked) {
+      // (round 4) two workers per workgroup, one of them streaming.  Few units per worker (config 5's shard: 2,048 units): four
       // workgroups per CU, every unit somebody's first, no tickets; up to a few units per worker: three per CU,
       // static round-robin (a drawn ticket commits a worker to one more unit -- the tail -- which costs more than the
       // imbalance it removes until a worker walks four or five units: 262,144 environments 0.178 static / 0.187 tickets,
@@ -2445,21 +2473,29 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
       const int64_t units64 = bpad_ / WAVE;
       per_cu = units64 <= (int64_t)num_cus_ * 8 ? 4 : 3;
       dynamic = units64 >= (int64_t)num_cus_ * 6 * 4;
+    } else if (shape == 3) {
+      // (round 5) with a 9 us logic phase fewer workers keep the streaming slots busy, and slots SHARED by all workers of a CU
+      // (one workgroup of four, two slots) beat private ones (two workgroups of two, one slot each): 1,048,576 environments
+      // 0.562 / 0.576 ms, 524,288: 0.300 / 0.303, 262,144: 0.152 / 0.156 on one box, 0.574 / 0.587 (2 x 3: 0.560) on
+      // another; config 5's shard (every worker steps ONE unit): two workgroups of four, two slots each -- 0.078 against
+      // 0.084-0.087 for 2 x 4 (profiles/r05_ps_sweep_call4_shapes.txt, _call5_steal.txt; the boxes differ by more than
+      // the shapes do)
+      const int64_t units64 = bpad_ / WAVE;
+      waves = 4;
+      per_cu = units64 <= (int64_t)num_cus_ * 8 ? 2 : 1;
+      P.ps_lock = 2;
+      dynamic = units64 >= (int64_t)num_cus_ * 6 * 4;
     }
-    if (const char* e = getenv("PCX_SM_UNIT")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) unit = v; }
     if (const char* e = getenv("PCX_SM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
     if (const char* e = getenv("PCX_SM_DYNAMIC")) dynamic = atoi(e) != 0;
-    int nb = 2;
-    if (const char* e = getenv("PCX_SM_NB")) { const int v = atoi(e); if (v >= 2 && v <= PS_NB_MAX) nb = v; }
     if (const char* e = getenv("PCX_SM_PRIO")) P.ps_prio = atoi(e) != 0;
     P.ps_unit = unit;
     P.ps_dynamic = dynamic;
     P.ps_nb = nb;
-    const Consts kk = ps_consts(unit, use_codes, nb);
     // PS == 3: `waves` workers per workgroup, each with its own {inbox, coin masks, buffer}
-    int waves = 2;
     if (const char* e = getenv("PCX_SM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) waves = v; }
     if (const char* e = getenv("PCX_SM_LOCK")) P.ps_lock = atoi(e);
+    if (const char* e = getenv("PCX_SM_STEAL")) P.ps_steal = atoi(e) != 0;
     const int words3 = kk.lds_ps_inbox + waves * kk.lds_ps_wave_words;
     int64_t n_units = (bpad_ + unit - 1) / unit, resident = (int64_t)num_cus_ * per_cu;
     if (const char* e = getenv("PCX_SM_GRID")) { const int v = atoi(e); if (v >= 1) resident = v; }  // (tests: few workgroups, many units each)
@@ -2514,7 +2550,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
     else if (shape == 1 && !use_codes)
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 1>), pgrid, dim3(WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
-    else if (shape == 3 && baked_l0(kk)) {
+    else if (shape == 3 && baked) {
       // the engine's Consts are the shipped level 0's, word for word: the instance that has them as compile-time constants
       last_shape_ = 5;
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3, 1>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());

@@ -402,6 +402,11 @@ class Engine(object):
     for cropper in self._croppers:
       if getattr(cropper, '_native', None) is None:
         cropper._create_native()
+      if getattr(cropper, '_native', None) is None:
+        # the pass-through base ObservationCropper (what a Story installs by default) has no device object and no
+        # state: a zero-length part keeps the attachment order of the trailer intact
+        parts.append(np.empty((0,), np.uint8))
+        continue
       m = N.c_u64(0)
       N.check(N.lib().pcx_cropper_state_size(cropper._native, int(bool(with_observation)), ctypes.byref(m)))
       part = np.empty((m.value,), np.uint8)
@@ -437,9 +442,20 @@ class Engine(object):
     for cropper, part in zip(croppers, parts):
       if getattr(cropper, '_native', None) is None:
         cropper._create_native()
+      if getattr(cropper, '_native', None) is None:  # (a pass-through cropper: nothing to restore)
+        if part.size:
+          raise ValueError('the checkpoint holds window state for a cropper that has none here: attach the same croppers, in the same order')
+        continue
       part = np.ascontiguousarray(part)
       N.check(N.lib().pcx_cropper_import_state(cropper._native, part.ctypes.data, part.nbytes))
     dev.synchronize(self._device_id)
+    # a feature stack fused into a cropper's window (ObservationToFeatureArray.fuse_into(engine, source=cropper)) was
+    # written by the exporting engine's step kernel: recompute it from the window as restored (or recut), so that the
+    # converter does not hand out the pre-import tensor as this step's
+    for cropper in croppers:
+      feats = getattr(cropper, '_features', None)
+      if feats is not None:
+        feats[0]._window_after_import(cropper, feats[1])
     # a fused post-processor's array was written by the exporting engine's step kernel, not by this one: refill it
     # from the restored observation where there is one; otherwise it counts as not written (the converter falls back
     # to its own kernel, which raises for an engine that writes no planes) until the next step

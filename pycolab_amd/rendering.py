@@ -390,6 +390,7 @@ class ObservationToFeatureArray(object):
       if cropper._native is not None:
         N.check(N.lib().pcx_cropper_set_features(cropper._native, None))
       cropper._features = None
+      cropper._feat_skip = 0
       self._fused_window = None
 
   def _epilogue_gone(self):
@@ -421,11 +422,26 @@ class ObservationToFeatureArray(object):
     if cropper._features is not None and cropper._features[0] is not self:
       cropper._features[0]._window_gone()
     cropper._features = (self, out)
+    cropper._feat_skip = int(d.skip_layers)
     self._fused_window = (cropper, out, engine._steps_launched)
     return True
 
   def _window_gone(self):
     self._fused_window = None
+
+  def _window_after_import(self, cropper, out):
+    """Engine.import_state() with a stack fused into `cropper`'s window: the tensor holds what the step kernel wrote
+    before the import.  Refill it from the restored window through the stand-alone kernels (the window's uint8 planes
+    are restored with the checkpoint's observation or recut by crop()); a window whose planes the kernel no longer
+    writes (skip_layers / skip_board) cannot be recomputed and counts as not written until the next step."""
+    if self._fused_window is None or self._fused_window[0] is not cropper:
+      return
+    engine = cropper._engine
+    if getattr(cropper, '_feat_skip', 0):
+      self._fused_window = (cropper, out, engine._steps_launched)  # (stale until a step rewrites it)
+      return
+    out.copy_(ObservationToFeatureArray(self._layers, self._permute)(cropper.crop(None)))
+    self._fused_window = (cropper, out, engine._steps_launched - 1)
 
   def _after_import(self, engine, out, restored):
     """Engine.import_state(): see ObservationToArray._after_import."""

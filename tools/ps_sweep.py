@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KNOBS = ('PCX_SM_BAKED', 'PCX_SM_TAIL', 'PCX_SM_TAIL_UNIT', 'PCX_DEBUG', 'PCX_SM_WAVES', 'PCX_SM_LOCK', 'PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_PER_CU', 'PCX_WAVES_PER_CU', 'PCX_WAVES_PER_WG',
+KNOBS = ('PCX_SM_STEAL', 'PCX_SM_BAKED', 'PCX_SM_TAIL', 'PCX_SM_TAIL_UNIT', 'PCX_DEBUG', 'PCX_SM_WAVES', 'PCX_SM_LOCK', 'PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_PER_CU', 'PCX_WAVES_PER_CU', 'PCX_WAVES_PER_WG',
          'PCX_WGS_PER_CU', 'PCX_SM_CODES', 'PCX_SM_PRIO', 'PCX_SM_NB', 'PCX_SM_GRID')
 
 VARIANTS = {
