@@ -31,6 +31,7 @@ class ObservationCropper(object):
     self._pitch = 0
     self._generation = 0    # bumped whenever the native cropper (and its buffers) is rebuilt
     self._fused = False     # the engine's step kernel moves the window and writes the planes (fuse_croppers)
+    self._feat_skip_since = 0
     self._feat_skip = 0     # ... and which of the window's own uint8 planes the kernel then no longer writes (1 layers, 2 board too)
     self._features = None   # (converter, float tensor): the window's feature stack the step kernel writes too
                             # (rendering.ObservationToFeatureArray.fuse_into(engine, source=cropper)); the cropper
@@ -129,7 +130,7 @@ class ObservationCropper(object):
       view = self._out.tensor.as_strided((B, P, r, c), (P * self._pitch, self._pitch, c, 1))
       obs = rendering.Observation(board=view[:, 0], layers={chr(ch): view[:, 1 + k] for k, ch in enumerate(chars)})
     obs._source = self
-    if self._fused and self._feat_skip:
+    if self._fused and self._feat_skip and eng._steps_launched > self._feat_skip_since:  # (until a step has run, the planes are what the last launch wrote)
       # the step kernel writes this window's float32 stack INSTEAD of (some of) its uint8 planes (fuse_into(...,
       # source=cropper, skip_layers / skip_board)): what is left here is frozen, so it is not handed out -- as
       # Engine._result() does for the full board -- and a post-processor that would read it raises

@@ -423,6 +423,7 @@ class ObservationToFeatureArray(object):
       cropper._features[0]._window_gone()
     cropper._features = (self, out)
     cropper._feat_skip = int(d.skip_layers)
+    cropper._feat_skip_since = engine._steps_launched
     self._fused_window = (cropper, out, engine._steps_launched)
     return True
 

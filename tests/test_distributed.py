@@ -146,9 +146,9 @@ def test_hashed_tape_is_the_device_generator():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('scaling,batch', [('strong', 1001), ('weak', 512)])
-def test_bench_two_ranks_equal_one_unsharded_engine(tmp_path, scaling, batch):
-  """The N>1 path of bench.py, executed: two ranks spawned by bench.py itself through
+@pytest.mark.parametrize('scaling,batch,ranks', [('strong', 1001, 2), ('weak', 512, 2), ('strong', 10007, 8), ('weak', 300, 8)])
+def test_bench_n_ranks_equal_one_unsharded_engine(tmp_path, scaling, batch, ranks):
+  """The N>1 path of bench.py, executed: two and EIGHT ranks (ragged shards: 10,007 environments over eight) spawned by bench.py itself through
   torch.distributed.run -- over RCCL where the node has two GPUs; on a one-GPU box with
   `--oversubscribe` (both ranks share the GPU, so the group is gloo; launcher, shard_range /
   env_offset, weak and strong accounting, ScalarGather with padded sends and the rank-0 JSON
@@ -158,19 +158,19 @@ def test_bench_two_ranks_equal_one_unsharded_engine(tmp_path, scaling, batch):
   import torch
   from tests.hip_adapter import HipAdapter
   dump = str(tmp_path / 'gathered.npz')
-  real = torch.cuda.device_count() >= 2
-  r = _run_bench('--gpus', '2', *([] if real else ['--oversubscribe']), '--steps', '5', '--warmup', '2', '--repeats', '2',
+  real = torch.cuda.device_count() >= ranks
+  r = _run_bench('--gpus', str(ranks), *([] if real else ['--oversubscribe']), '--steps', '5', '--warmup', '2', '--repeats', '2',
                  '--batch', str(batch), '--scaling', scaling, '--gather', '--actions', 'hashed',
                  '--dump-scalars', dump, '--no-cpu-baseline')
   assert r.returncode == 0, r.stderr[-3000:]
   line = json.loads(r.stdout.strip().splitlines()[-1])
-  global_batch = batch if scaling == 'strong' else 2 * batch
-  sizes = [hi - lo for lo, hi in (pdist.shard_range(global_batch, k, 2) for k in range(2))]
-  assert line['n_gpus'] == 2 and line['scaling'] == scaling
+  global_batch = batch if scaling == 'strong' else ranks * batch
+  sizes = [hi - lo for lo, hi in (pdist.shard_range(global_batch, k, ranks) for k in range(ranks))]
+  assert line['n_gpus'] == ranks and line['scaling'] == scaling
   assert line['config']['global_batch'] == global_batch and line['config']['batch_per_gpu'] == sizes[0]
-  assert line['dist']['world_size'] == 2 and line['dist']['backend'] == ('nccl' if real else 'gloo')
+  assert line['dist']['world_size'] == ranks and line['dist']['collective_ranks_seen'] == ranks and line['dist']['backend'] == ('nccl' if real else 'gloo')
   assert line['dist']['oversubscribed'] == (not real)
-  assert line['dist']['per_rank_envs'] == sizes and len(line['dist']['per_rank_kernel_ms']) == 2
+  assert line['dist']['per_rank_envs'] == sizes and len(line['dist']['per_rank_kernel_ms']) == ranks
   assert all(ms > 0 for ms in line['dist']['per_rank_kernel_ms'])
   assert line['repeats']['k'] == 2 and len(line['repeats']['ms_per_step_all']) == 2
   assert line['gather']['bytes_per_rank_per_step'] == 10 * sizes[0]
@@ -186,7 +186,7 @@ def test_bench_two_ranks_equal_one_unsharded_engine(tmp_path, scaling, batch):
   planes = whole.read('planes').reshape(global_batch, -1).astype(np.int64).sum(axis=1)
   frames = whole.read('frame').astype(np.int64)
   checks = json.loads(bytes(got['checks']).decode())
-  assert [c['rank'] for c in checks] == [0, 1] and [c['n'] for c in checks] == sizes
+  assert [c['rank'] for c in checks] == list(range(ranks)) and [c['n'] for c in checks] == sizes
   for c in checks:
     lo, hi = c['lo'], c['lo'] + c['n']
     assert c['planes_sum'] == int(planes[lo:hi].sum())
