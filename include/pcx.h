@@ -332,12 +332,11 @@ int64_t pcx_engine_bytes_per_step(const pcx_engine* e);
 const char* pcx_engine_kernel_name(const pcx_engine* e);
 /* Which launch shape the engine's LAST step / reset launch took (tests and benchmarks assert that the shape they
  * mean to measure is the one that ran; no reference counterpart).  pcx_scrolly_maze_step: 0 one single-wave
- * workgroup per group of 64 environments, 1 persistent single-wave workgroups with the next unit's state words
- * prefetched into LDS, 2 persistent logic/render wave pairs, 3 persistent workgroups of W workers with a streaming
- * semaphore (the default from 98,304 environments up), 5 the same with the shipped level's constants compiled in
- * (pcx_debug_scrolly_consts), 4 two-wave pipeline workgroups (round 1, PCX_WAVES_PER_WG=2),
- * 10 cooperative (several waves per group), 11 / 12 several steps per launch (round 1's instance / the cooperative
- * shape walking them), 20 shape-generic instance; pcx_generic_step: 30 the
+ * workgroup per group of 64 environments, 3 persistent workgroups of W workers (waves) that draw work units, with the
+ * next unit's state words prefetched into LDS and a streaming semaphore (the default from 65,536 environments up), 5 the
+ * same with the shipped level's constants compiled in (pcx_debug_scrolly_consts), 10 cooperative (several waves per
+ * group), 12 the cooperative shape walking several steps per launch, 20 shape-generic instance (1, 2, 4 and 11 were
+ * launch shapes of rounds 1-4, measured slower and removed in round 5); pcx_generic_step: 30 the
  * table-driven build, 31 the build specialised for the engine's template at run time; -1: the backend does not say. */
 int32_t pcx_engine_launch_shape(const pcx_engine* e);
 /* The table-driven kernel pcx_generic_step -- what every Engine the hand-written kernels do not cover runs on:

@@ -95,7 +95,7 @@ struct Consts {
   int32_t lds_bdcode, lds_codes, lds_cmask_c, lds_skip_c, lds_words_codes;  // its own, compact LDS layout
   // persistent shapes of the CODES instance (PS): the state inbox (LDS-DMA target), the hand-over ring of the
   // logic/render wave pair, and the owner-code buffers (code table + skip flags each)
-  int32_t lds_ps_inbox, lds_ps_ring, lds_ps_cmask, lds_ps_buf0, lds_ps_buf_words, lds_ps_words1, lds_ps_words2;
+  int32_t lds_ps_inbox, lds_ps_ring, lds_ps_cmask, lds_ps_buf0, lds_ps_buf_words, lds_ps_words1;
   int32_t lds_ps_wave_words;  // PS == 3: from one wave's {inbox, coin masks, buffer} to the next wave's
   int32_t lds_ps_lut;         // persistent owner-code shapes: 256 words "eight cell bits -> eight nibble masks", then the backdrop's owner codes as nibbles
   uint32_t chars_lo, chars_hi;  // characters 0..3 / 4..7 as bytes
@@ -112,7 +112,8 @@ struct Consts {
 constexpr int CONSTS_WORDS = (int)(sizeof(Consts) / 4);
 static_assert(sizeof(Consts) % 4 == 0, "Consts is a struct of 32-bit fields");
 struct ShippedWords { uint32_t w[PCX_SM_SHIPPED_L0_N > 0 ? PCX_SM_SHIPPED_L0_N : 1]; };
-static constexpr ShippedWords SHIPPED_L0_WORDS = {{PCX_SM_SHIPPED_L0_WORDS}};
+static constexpr ShippedWords SHIPPED_L0_WORDS = {{PCX_SM_SHIPPED_L0_WORDS}};              // as the persistent shape launches them (units of 64)
+static constexpr ShippedWords SHIPPED_L0_PLAIN_WORDS = {{PCX_SM_SHIPPED_L0_PLAIN_WORDS}};  // as init() leaves them (the cooperative shape)
 constexpr bool SHIPPED_L0_VALID = sizeof(ShippedWords) == sizeof(Consts);
 template <typename T>
 constexpr Consts consts_from_words(const T& raw) {
@@ -120,9 +121,11 @@ constexpr Consts consts_from_words(const T& raw) {
   else return Consts{};
 }
 static constexpr Consts SHIPPED_L0 = consts_from_words(SHIPPED_L0_WORDS);
+static constexpr Consts SHIPPED_L0_PLAIN = consts_from_words(SHIPPED_L0_PLAIN_WORDS);
 template <int LV>
 __device__ __forceinline__ const Consts& baked_consts(const Consts& from_args) {
   if constexpr (LV == 1) return SHIPPED_L0;
+  else if constexpr (LV == 2) return SHIPPED_L0_PLAIN;
   else return from_args;
 }
 
@@ -140,8 +143,6 @@ struct Ptrs {
   // done} the units beyond every workgroup's first two are drawn from, or static round-robin when `ps_dynamic` is 0
   uint32_t* ps_ctr;
   int32_t ps_unit, ps_dynamic;
-  int32_t ps_nb;    // owner-code buffers of a logic/render pair (the logic wave runs up to ps_nb - 1 units ahead)
-  int32_t ps_prio;  // s_setprio of the pair's render wave (0: leave alone)
   int32_t ps_lock;  // PS == 3: at most this many waves of a workgroup in their render loop at a time (0: no limit)
   int32_t ps_steal; // tickets: a worker whose shard of the work counter is dry draws from the other shards (PCX_SM_STEAL=0: goes home)
   // the batch's last environments go in SMALL units (ps_tail_unit environments each; units ps_n1 and up), so that what the
@@ -562,25 +563,21 @@ __device__ __forceinline__ Walker pick(const Walker (&w)[NS], int dyn) {
   }
 }
 
-// ---- persistent launch shapes (PS) of the owner-code instance -------------------------------------------
-// A workgroup stays on its CU and draws work units (64, 32 or 16 consecutive environments) until none are
-// left; the state words of its NEXT unit travel from HBM straight into an LDS inbox (LDS-DMA,
-// global_load_lds_dword: no VGPR in between, nothing for the compiler to wait for) while the current
-// unit is stepped / streamed, so that a unit's logic phase starts on words that are already there instead of
-// queueing fourteen loads behind the chip's plane stores.
-//   PS == 1: one wave per workgroup does both phases back to back; the inbox fills under the render loop.
-//            vmcnt counts in order and holds at most 63, so after 64 or more plane stores the DMA issued in
-//            front of them has landed -- no wait at all.
-//   PS == 2: two waves per workgroup: wave 0 only steps (and runs ahead by one owner-code buffer), wave 1
-//            only streams; they hand buffers over through a two-slot ring of LDS counters, no barrier.
-//   PS == 3: several waves per workgroup, each one a PS == 1 worker with its own inbox, coin masks and owner-code
-//            buffer (they share the staged level), and ONE of them streams at a time (an LDS mutex around the render
-//            loop): a CU's write path is saturated by one or two streaming waves and loses efficiency with every further
-//            concurrent stream (tools/experiments/store_width.hip, profiles/r04_tuning.md), while a unit's logic phase
-//            is latency-bound and wants many waves in flight -- the mutex decouples the two counts.
+// ---- the persistent launch shape (PS == 3) of the owner-code instance -----------------------------------
+// A workgroup stays on its CU; each of its waves is a WORKER that draws work units (64, 32 or 16 consecutive
+// environments) until none are left, steps a unit (lane == environment) and streams it.  The state words of a
+// worker's NEXT unit travel from HBM straight into its LDS inbox (LDS-DMA, global_load_lds_dword: no VGPR in
+// between, nothing for the compiler to wait for) issued in front of the current unit's plane stores: vmcnt counts
+// in order and holds at most 63, so after 64 or more plane stores the DMA has landed -- the next logic phase starts
+// without a wait instead of queueing fourteen loads behind the chip's plane stores.  Workers have their own inbox,
+// coin masks and owner-code buffer and share the staged level; at most `ps_lock` of a workgroup's workers stream at
+// a time (a counting semaphore in LDS around the render loop): a CU's write path is saturated by one or two streaming
+// waves and loses efficiency with every further concurrent stream (tools/experiments/store_width.hip,
+// profiles/r04_tuning.md), while the logic phase wants several waves in flight -- the semaphore decouples the counts.
+// (Rounds 4's other persistent shapes -- single-wave workgroups, logic/render wave pairs over a ring of buffers, the
+// mask-composing render loop as the persistent body -- were measured slower and are gone: profiles/r04_tuning.md.)
 constexpr int PS_IB_ACTION = 15;  // inbox rows: the state words (at most 15), then the tape action
 constexpr int PS_IB_ROWS = 16;
-constexpr int PS_NB_MAX = 6;      // owner-code buffers of a logic/render pair, at most (ring words in LDS)
 constexpr uint32_t PS_SPIN_LIMIT = 1u << 22;  // (x s_sleep 2: seconds) a broken hand-over gives up instead of hanging the GPU
 
 // One row of the inbox: lane i's dword base[i] lands at LDS byte address lds_addr + 4 i.  M0 is written in the
@@ -619,36 +616,26 @@ __device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) {
 // the egocentric sprite when known at compile time (-1 = from Consts).
 // COOP: small batches.  A workgroup is four or eight waves around one group:
 // wave 0 steps it, then all of them share the render loop (iterations round-robin).
-// TFUSE: small batches, several consecutive steps in one launch
-// (StepArgs::n_steps): wave 0 steps the group for step i + 1 while waves 1-3
-// render step i out of the other descriptor buffer; one barrier per step.
 // EPI: the render loop also writes the float32 feature-array epilogue (pcx_stream.h).
 // CODES: the logic phase paints an owner-code byte per cell (LDS), the render loop
 // is one LDS read and one v_perm_b32 per plane (static shape, <= 8 characters).
-// PS: persistent launch shape of the owner-code instance (0: none; 1, 2: above).
+// PS: 3 = the persistent launch shape of the owner-code instance (above), 0 = a workgroup per group.
 // LV: the instance of ONE level whose Consts are compile-time constants (pcx_sm_shipped.h; 0: none, Consts from the
 // kernel arguments).  Round 5: with every table entry, stride and z-order bit known, the probes' index arithmetic folds,
 // irrelevant probes disappear, and nothing of Consts competes for SGPRs (the run-time instance parked ~2,000 of its
 // 15,000 instructions' operands in VGPR lanes: v_readlane / v_writelane).
-template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool TFUSE = false, bool EPI = false,
+template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP = false, bool EPI = false,
           bool CODES = false, int PS = 0, int LV = 0>
-__global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 * WAVE : 2 * WAVE) void pcx_scrolly_maze_step(const Consts k_arg, const Ptrs P, const StepArgs a,
+__global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void pcx_scrolly_maze_step(const Consts k_arg, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                   const crop::FusedCrops* fc_arg) {
-  static_assert(LV == 0 || (PS == 3 && CODES), "baked constants: the persistent owner-code instance");
+  static_assert(LV == 0 || (LV == 1 && PS == 3 && CODES) || (LV == 2 && COOP && !EPI), "baked constants: the persistent owner-code instance and the cooperative one");
   const Consts& k = baked_consts<LV>(k_arg);
   // Fused croppers (include/pcx.h pcx_engine_fuse_croppers): the instances that keep the frame as curtain
   // bit vectors + sprite descriptors (pcx_stream.h's contract) and render a group in the round they step it
-  constexpr bool FUSABLE = !TFUSE && !CODES && !UNOCC && !EPI;
-  static_assert(PS == 0 || (!COOP && !TFUSE && !EPI && !UNOCC && SR != 0 && (CODES || PS == 1 || PS == 3)),
-                "persistent shapes: the static-shape instances (pairs: owner codes only)");
+  constexpr bool FUSABLE = !CODES && !UNOCC && !EPI;
+  static_assert(PS == 0 || (PS == 3 && !COOP && !EPI && !UNOCC && SR != 0 && CODES), "the persistent shape: the static-shape owner-code instance");
   const crop::FusedCrops* const fc = FUSABLE ? fc_arg : nullptr;
-  // A workgroup is two wavefronts with different jobs, looping over groups of
-  // 64 environments: wave 0 (logic) steps group i+1 and leaves its render
-  // descriptors in one LDS buffer while wave 1 (render) streams the
-  // observation of group i out of the other; they meet at a barrier and swap.
-  // The latency-bound entity logic thus runs under the HBM-bound streaming
-  // instead of in front of it.
   extern __shared__ uint32_t lds_raw[];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x >> 6;
@@ -727,14 +714,14 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   uint32_t* codes = lds_raw + k.lds_codes;
   // persistent shapes: this wave's unit, the one after it (whose state words are on their way into the inbox) and,
   // in the single-wave shape, the ticket in flight for the one after that
-  const int ps_mine = PS == 3 ? __builtin_amdgcn_readfirstlane(wave) * k.lds_ps_wave_words : 0;  // this wave's own LDS region
+  const int ps_mine = PS == 3 ? __builtin_amdgcn_readfirstlane(wave) * k.lds_ps_wave_words : 0;  // this worker's own LDS region
   uint32_t* const ps_inbox = lds_raw + k.lds_ps_inbox + ps_mine;
   // workers: the waves that draw units (PS == 3: every wave; else one per workgroup)
   const uint32_t ps_wid = PS == 3 ? blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave : blockIdx.x;
   const uint32_t ps_nwk = PS == 3 ? gridDim.x * (blockDim.x >> 6) : gridDim.x;
   // (an LDS-address-space pointer: as a generic one its volatile accesses become FLAT instructions, which count on vmcnt)
   typedef __attribute__((address_space(3))) volatile uint32_t lds_volatile_u32;
-  lds_volatile_u32* const ps_ring = (lds_volatile_u32*)(lds_raw + k.lds_ps_ring);  // [0] produced, [1] consumed, [2] no more units, [4 + 2 slot] env0, count
+  lds_volatile_u32* const ps_ring = (lds_volatile_u32*)(lds_raw + k.lds_ps_ring);  // [3]: the streaming semaphore (how many of the workgroup's workers stream)
   const uint32_t ps_n = PS ? P.ps_n : 0u;
   // unit -> its first environment and how many it has
   auto ps_span = [&](uint32_t u, int64_t& e0, int& cnt) {
@@ -779,12 +766,8 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
     if (!a.hashed && lane < cnt && e0 + lane < P.batch) ps_dma_row(reinterpret_cast<const uint32_t*>(a.actions) + e0, 4u * lane, ib + (uint32_t)PS_IB_ACTION * (4u * WAVE));
   };
   if constexpr (PS != 0) {
-    if (PS == 3 || threadIdx.x < WAVE) {
-      if (threadIdx.x == 0) { ps_ring[0] = 0; ps_ring[1] = 0; ps_ring[2] = 0; ps_ring[3] = 0; }
-      if (ps_u < ps_n) ps_prefetch(ps_u);  // (under the staging of the level below)
-    } else if (P.ps_prio) {
-      __builtin_amdgcn_s_setprio(3);  // (constant argument; the knob is on / off)
-    }
+    if (threadIdx.x == 0) ps_ring[3] = 0;  // (the streaming semaphore)
+    if (ps_u < ps_n) ps_prefetch(ps_u);  // (under the staging of the level below)
   }
   if constexpr (CODES) {
     uint32_t* lbc = lds_raw + k.lds_bdcode;
@@ -804,82 +787,43 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   }
   __syncthreads();  // LDS constants visible
 
-  // blockDim.x == 64: one wave does both jobs back to back (no overlap).
-  const bool solo = blockDim.x == WAVE;
-  const bool single = PS == 1 || PS == 3 || (PS == 0 && (solo || COOP));  // logic and render of the same group in the same round
-  for (int round = (single || PS != 0) ? 0 : -1;; ++round) {
-  // TFUSE: the rounds are the launch's steps of one and the same group
-  // COOP (round 4): too -- a cooperative workgroup owns ONE group, and a launch of several steps (StepArgs::n_steps:
-  // pcx_engine_step_n / _step_hashed at small batches) walks them here, the state words staying in registers from
-  // one step to the next (no state-in / state-out chain, no kernel boundary per step)
-  const int64_t g_render = (TFUSE || COOP) ? (int64_t)blockIdx.x : (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
-  const int64_t g_logic = (single || TFUSE) ? g_render : g_render + gridDim.x;
-  const int tstep = TFUSE ? round + 1 : COOP ? round : 0;  // which of the launch's steps the logic wave is on
+  // One wave steps a group / unit and then streams it (cooperative shape: wave 0 steps, all waves of the workgroup
+  // stream).  Rounds: the groups of a workgroup one after the other; the cooperative shape owns ONE group, and a launch
+  // of several steps (StepArgs::n_steps: pcx_engine_step_n / _step_hashed at small batches) walks them here, the state
+  // words staying in registers from one step to the next (no state-in / state-out chain, no kernel boundary per step);
+  // the persistent shape: a worker's units.  (Rounds 1-4 also carried logic/render wave PAIRS in three variants -- a
+  // barrier pipeline, a multi-step pipeline, a ring of LDS counters; all measured slower than what is here and removed in
+  // round 5: profiles/r01_tuning.md, r04_tuning.md.)
+  for (int round = 0;; ++round) {
+  const int64_t g_render = COOP ? (int64_t)blockIdx.x : (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
+  const int64_t g_logic = g_render;
+  const int tstep = COOP ? round : 0;  // which of the launch's steps the logic wave is on
   const int coop_steps = a.n_steps > 1 ? a.n_steps : 1;
-  bool have_render = round >= 0 && g_render < ngroups && (!TFUSE || round < a.n_steps) && (!COOP || round < coop_steps);
-  bool have_logic = g_logic < ngroups && (!TFUSE || tstep < a.n_steps) && (!COOP || round < coop_steps);
+  bool have_render = g_render < ngroups && (!COOP || round < coop_steps);
+  bool have_logic = have_render;
   // the environments this round's logic phase steps / its render phase streams: a group of EPW, or (persistent
-  // shapes) a work unit
+  // shape) a work unit
   int64_t env0_logic = g_logic * EPW, env0_render = g_render * EPW;
   int cnt_logic = EPW, cnt_render = EPW;
-  if constexpr (PS == 1 || PS == 3) {
+  if constexpr (PS == 3) {
     if (ps_u >= ps_n) break;
     ps_span(ps_u, env0_logic, cnt_logic);
     env0_render = env0_logic;
     cnt_render = cnt_logic;
     have_logic = have_render = true;
     pt_mark = ps_now();
-  } else if constexpr (PS == 2) {
-    const int slot = round % P.ps_nb;
-    codes = lds_raw + k.lds_ps_buf0 + slot * k.lds_ps_buf_words;
-    if (wave == 0) {
-      if (ps_u >= ps_n) {  // nothing left: tell the render wave, after everything this wave has published
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ps_ring[2] = 1u;
-        break;
-      }
-      ps_span(ps_u, env0_logic, cnt_logic);
-      have_logic = true;
-      have_render = false;
-      uint32_t spins = 0;  // the slot's previous unit must have been streamed
-      pt_mark = ps_now();
-      while ((uint32_t)round - ps_ring[1] >= (uint32_t)P.ps_nb && ++spins < PS_SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
-      if (ps_prof) { const uint32_t t = ps_now(); pt_b += t - pt_mark; pt_mark = t; }
-    } else {
-      uint32_t spins = 0;
-      bool more = true;
-      pt_mark = ps_now();
-      while (ps_ring[0] <= (uint32_t)round) {
-        if (ps_ring[2] != 0u && ps_ring[0] <= (uint32_t)round) { more = false; break; }
-        if (++spins >= PS_SPIN_LIMIT) { more = false; break; }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (!more) break;
-      asm volatile("" ::: "memory");
-      if (ps_prof) { const uint32_t t = ps_now(); pt_a += t - pt_mark; pt_mark = t; }
-      env0_render = (int64_t)ps_ring[4 + 2 * slot];
-      cnt_render = (int)ps_ring[5 + 2 * slot];
-      have_logic = false;
-      have_render = true;
-    }
   } else {
-    if (!have_render && !have_logic) break;
+    if (!have_render) break;
   }
   if constexpr (PS != 0) {
-    if constexpr (PS == 1 || PS == 3) codes = lds_raw + k.lds_ps_buf0 + ps_mine;
-    // a buffer: the code table of the unit's environments -- or (mask path) both curtains as flat bit vectors and the
-    // sprite descriptors of 64 environments -- then 64 skip flags
-    if constexpr (!CODES) {
-      l.flat = codes;
-      l.sdesc = reinterpret_cast<uint2*>(codes + 2 * WAVE * FWP);
-    }
+    codes = lds_raw + k.lds_ps_buf0 + ps_mine;
+    // a buffer: the code table of the unit's environments, then 64 skip flags
     l.skip = codes + k.lds_ps_buf_words - WAVE;
     l.cmask = lds_raw + k.lds_ps_cmask + ps_mine;
   } else {
-    const int buf = single ? 0 : (wave == 0) ? ((round + 1) & 1) : (round & 1);
-    l.flat = lds_raw + k.lds_flat + buf * k.lds_buf_words;
-    l.sdesc = reinterpret_cast<uint2*>(lds_raw + k.lds_sdesc + buf * k.lds_buf_words);
-    l.skip = CODES ? lds_raw + k.lds_skip_c : lds_raw + k.lds_skip + buf * k.lds_buf_words;
+    l.flat = lds_raw + k.lds_flat;
+    l.sdesc = reinterpret_cast<uint2*>(lds_raw + k.lds_sdesc);
+    l.skip = CODES ? lds_raw + k.lds_skip_c : lds_raw + k.lds_skip;
   }
   if (wave == 0 || PS == 3) {
   if (have_logic) {
@@ -907,7 +851,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   if constexpr (PS != 0) {
     // the unit's state words are in the inbox (ps_prefetch): the first unit's, and whatever was asked for with
     // fewer than 64 plane stores behind it, must be waited for; the pair's logic wave always waits (it has the time)
-    if (PS == 2 || ps_need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ps_need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (ps_prof) { const uint32_t t = ps_now(); pt_a += t - pt_mark; pt_mark = t; }
     const uint32_t* const ib = ps_inbox + lane;
     pre_flags = ib[W_FLAGS * WAVE]; pre_frame = ib[W_FRAME * WAVE]; pre_permit = ib[W_PERMIT_FRAME * WAVE];
@@ -917,13 +861,6 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
 #pragma unroll
     for (int i = 0; i < 4; ++i) pre_cm[i] = i < k.CW ? ib[(W_SPOS + NS + i) * WAVE] : 0u;
     pre_action = a.hashed ? PCX_ACTION_NONE : (int)ib[PS_IB_ACTION * WAVE];
-    if constexpr (PS == 2) {
-      // the inbox is free again: the words of the unit after this one travel while this one is stepped
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // every unit after the worker's first is drawn from the work counter: unit = workers + ticket
-      ps_un = P.ps_dynamic ? ps_x + ps_shards * (ps_shard_nwk + ps_ticket(ps_ctr_mine)) : ps_u + ps_nwk;
-      if (ps_un < ps_n) ps_prefetch(ps_un);
-    }
   }
   if constexpr (COOP) {
     // (steps after the launch's first: their tape action; the state words are in the registers the step before left)
@@ -1426,20 +1363,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
     for (int i = (int)threadIdx.x - WAVE; i < 2 * WAVE * FWP; i += (int)blockDim.x - WAVE) l.flat[i] = 0;
   }
   if constexpr (PS == 0) {
-    if (single) __syncthreads();
-  } else if constexpr (PS == 1 || PS == 3) {
-    asm volatile("" ::: "memory");  // one wave: its LDS instructions execute in order
+    __syncthreads();
   } else {
-    if (wave == 0) {  // hand the buffer over: codes and skip flags first, then the counter the render wave polls
-      const int slot = round % P.ps_nb;
-      ps_ring[4 + 2 * slot] = (uint32_t)env0_logic;
-      ps_ring[5 + 2 * slot] = (uint32_t)cnt_logic;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ps_ring[0] = (uint32_t)round + 1u;
-      if (ps_prof) { const uint32_t t = ps_now(); pt_c += t - pt_mark; pt_mark = t; ++pt_units; }
-      ps_u = ps_un;
-      if (ps_prof) { const uint32_t t = ps_now(); pt_d += t - pt_mark; pt_mark = t; }
-    }
+    asm volatile("" ::: "memory");  // one wave: its LDS instructions execute in order
   }
   if constexpr (COOP) {
     if (have_render && !(a.debug & 4)) {
@@ -1527,7 +1453,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
       __syncthreads();
     }
   }
-  if ((single || (TFUSE ? wave >= 1 : wave == 1)) && have_render && !(a.debug & 2)) {
+  if (have_render && !(a.debug & 2)) {
 
 
   // ---- phase B: the wavefront streams the observation planes ---------------
@@ -1539,7 +1465,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   uint32_t sch4[NS], dch4[2];
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
   const int64_t env0 = env0_render;
-  if constexpr (PS == 1 || PS == 3) {
+  if constexpr (PS == 3) {
     // the next unit is drawn (scalar atomic, ~1 us) and its state words start travelling now, in front of this unit's
     // plane stores: they have landed when the loop below is through (vmcnt is in order, 63 at most)
     if (ps_prof) { const uint32_t t = ps_now(); pt_c += t - pt_mark; pt_mark = t; ++pt_units; }
@@ -1561,7 +1487,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
       ps_un = ps_u + ps_nwk;
     }
     if (ps_un < ps_n) ps_prefetch(ps_un);
-    if (PS == 3 && P.ps_lock) {
+    if (P.ps_lock) {
       // at most ps_lock streaming waves per workgroup: a counting semaphore in LDS (lane 0 alone adds; a wave that
       // finds the count at the limit takes its increment back and tries again a little later)
       const uint32_t la = lds_byte_address(lds_raw + k.lds_ps_ring + 3);
@@ -1577,7 +1503,6 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
       }
       if (ps_prof) { const uint32_t t = ps_now(); pt_b += t - pt_mark; pt_mark = t; }
     }
-    if (PS == 3 && P.ps_prio) __builtin_amdgcn_s_setprio(3);  // a streaming wave outranks the stepping waves on its SIMD
   }
   // Uniform per-plane base pointers: every store below is `scalar base +
   // 32-bit lane offset`, and the lane offset is the same for all nine planes.
@@ -1687,7 +1612,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   // The multi-wave instances are under SGPR pressure (the register allocator parks plane bases in
   // VGPR lanes and fetches them with v_readlane right in front of a store) and are latency-bound,
   // not store-issue-bound: their stores take the hazard-proof form (pcx_internal.h).
-  constexpr bool GUARD_SADDR = COOP || TFUSE;
+  constexpr bool GUARD_SADDR = COOP;
   {
   // Direct path.  Each wave store covers 256 contiguous bytes of one plane of
   // one or two environment records; all nine planes of a 64-dword span leave
@@ -1704,7 +1629,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   // divisions in the loop (v_mul_lo/_hi are quarter rate).
   // Static shape with at least 64 dwords per board: a lane wraps into the next
   // environment at most once per iteration, so the update is four selects.
-  constexpr bool INCR = !COOP && !TFUSE && SR != 0 && (SR * SC / 4) >= WAVE;
+  constexpr bool INCR = !COOP && SR != 0 && (SR * SC / 4) >= WAVE;
   uint32_t e = 0, q = lane, voff = 4u * lane, eF = 0;
   // epilogue (EPI): float32 planes of the selected layers, 16 bytes per board dword
   const bool layers_on = !(EPI && epi.skip_layers);
@@ -1776,8 +1701,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
     hw_sel ^= 1u;
   };
 #pragma unroll 1
-  for (int it = !planes_on ? n_iter : COOP ? wave : TFUSE ? wave - 1 : 0; it < n_iter;
-       it += COOP ? (int)(blockDim.x >> 6) : TFUSE ? (int)(blockDim.x >> 6) - 1 : 1) {
+  for (int it = !planes_on ? n_iter : COOP ? wave : 0; it < n_iter; it += COOP ? (int)(blockDim.x >> 6) : 1) {
     uint32_t e_now, q_now, voff_now, eF_now, foff_now = 0;
     uint32_t code_cur = 0;
     if constexpr (INCR) {
@@ -1882,15 +1806,14 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   }
   }  // passes
   };  // sweeps
-  if constexpr (PS == 1 || PS == 3) {
+  if constexpr (PS == 3) {
     // (round 5, measured and dropped: composing board-dword PAIRS and storing them with global_store_dwordx2 -- half the
     // iterations and store instructions -- runs at 0.97-1.04 ms per 1,048,576 environments against 0.58-0.61 for this
     // dword loop, 8-byte aligned or not: the CU's write path moves a unit in ~13 us with dwordx2 stores whatever the
     // number of streaming waves, in ~8.3 us with dword stores; profiles/r05_tuning.md)
     const int stores_behind = n_iter * (1 + SL);
     sweeps(std::integral_constant<int, 0>{});
-    if (PS == 3 && P.ps_prio) __builtin_amdgcn_s_setprio(0);
-    if (PS == 3 && P.ps_lock) {  // (the last plane store is issued: the next wave may stream)
+    if (P.ps_lock) {  // (the last plane store is issued: the next wave may stream)
       const uint32_t la = lds_byte_address(lds_raw + k.lds_ps_ring + 3);
       uint32_t one = 1u;
       uint64_t save;
@@ -1898,15 +1821,10 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
     }
     // fewer than 64 plane stores behind the DMA and the ticket (units with environments left alone, ablation
     // runs): wait for them; otherwise the next unit's logic phase starts at once
-    ps_need_wait = any_skip || a.debug != 0 || stores_behind < 64 || !planes_on;
+    ps_need_wait = any_skip || (a.debug & ~16) != 0 || stores_behind < 64 || !planes_on;
     if (ps_need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ps_u = ps_un;
     if (ps_prof) pt_d += ps_now() - pt_mark;
-  } else if constexpr (PS == 2) {
-    sweeps(std::integral_constant<int, 0>{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the buffer has been read: the logic wave may fill it again
-    ps_ring[1] = (uint32_t)round + 1u;
-    if (ps_prof) { pt_c += ps_now() - pt_mark; ++pt_units; }
   } else if constexpr (!EPI) {
     sweeps(std::integral_constant<int, 0>{});
   } else {  // (uniform: one of the three runs)
@@ -1935,15 +1853,13 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : TFUSE ? 4 * WAVE : PS == 3 ? 12 *
   }  // rounds
   if constexpr (PS != 0) {
     if (ps_prof && lane == 0) {
-      uint32_t* const pp = P.ps_prof + (PS == 3 ? (size_t)ps_wid * 16 : (size_t)blockIdx.x * 16 + (wave ? 8 : 0));
+      uint32_t* const pp = P.ps_prof + (size_t)ps_wid * 16;
       const uint32_t life = ps_now() - pt_start;
-      if (PS == 1 || PS == 3) { pp[0] = pt_units; pp[1] = pt_a; pp[2] = pt_b; pp[3] = pt_c; pp[10] = pt_d; pp[5] = life; }
-      else if (wave == 0) { pp[0] = pt_units; pp[1] = pt_a; pp[2] = pt_b; pp[3] = pt_c; pp[4] = pt_d; pp[5] = life; }
-      else { pp[0] = pt_units; pp[1] = pt_a; pp[2] = pt_c; pp[3] = life; }
+      pp[0] = pt_units; pp[1] = pt_a; pp[2] = pt_b; pp[3] = pt_c; pp[10] = pt_d; pp[5] = life;
     }
     // the last workgroup out rewinds the work counter for the next launch (every ticket of this launch was drawn
     // before its workgroup got here)
-    if (P.ps_dynamic && (PS == 3 ? lane == 0 : threadIdx.x == 0)) {
+    if (P.ps_dynamic && lane == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (atomicAdd(P.ps_ctr + 8 * 16, 1u) == ps_nwk - 1u) {
         for (int x = 0; x <= 8; ++x) atomicExch(P.ps_ctr + 16 * x, 0u);
@@ -1964,6 +1880,74 @@ static uint32_t magic20(uint32_t divisor, uint32_t max_numerator, bool* ok) {
     if (((uint64_t)x * m) >> 20 != x / divisor || (uint64_t)x * m > 0xFFFFFFFFull) { *ok = false; break; }
   return m;
 }
+
+// Which of a few equivalent launch configurations is fastest ON THIS BOX, measured on the engine's own launches (as
+// GenericBackend::Tuner does for pcx_generic_step's waves per workgroup).  The persistent shape's best worker / slot counts
+// differ from box to box by more than they differ from each other (profiles/r05_tuning.md: 2 x 3 workers with private
+// slots 0.560 ms on one box where 4 x 1 with two shared slots gives 0.574, 0.569 / 0.562 on another, 0.617 / 0.592 (2 x 2)
+// on a third), and the result does not depend on the choice.  After WARM step launches on the default, the candidates take
+// turns in BLOCKS of three consecutive launches, twice round (a clock still ramping up after the engine's creation must
+// not favour whoever is measured last); a block is timed over its second and third launch only -- single launches timed
+// between neighbours of another shape overlap with those neighbours' tails and measured up to 20 % off the steady state
+// (r05_ps_sweep_call7_pruned_tuner.txt: 0.068 against 0.086 ms).  Once the last block has completed (polled, never waited
+// for) the candidate with the smallest time stays -- the default unless another beats it by 1.5 %.  Launches under stream
+// capture and reset launches leave the tuner alone; any PCX_SM_WAVES / _PER_CU / _LOCK knob or PCX_SM_TUNE=0 turns it off.
+struct ShapeTuner {
+  static constexpr int WARM = 8, NC = 4, ROUNDS = 2, BLOCK = 3, NB = NC * ROUNDS;
+  int phase = 0, chosen = -1;
+  bool off = false, measuring_begin = false, measuring_end = false, have_events = false;
+  hipEvent_t ev[NB][2] = {};
+  float ms[NC] = {};
+  ~ShapeTuner() { drop(); }
+  void drop() {
+    if (have_events) for (auto& e : ev) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
+    have_events = false;
+  }
+  // the candidate this launch takes (0 = the default)
+  int pick(const StepArgs& a, hipStream_t s) {
+    measuring_begin = measuring_end = false;
+    if (chosen >= 0) return chosen;
+    if (off || a.mode != 0) return 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    const int i = phase - WARM;
+    if (i < 0) { ++phase; return 0; }
+    if (i < NB * BLOCK) {
+      if (!have_events) {
+        for (auto& e : ev)
+          if (hipEventCreate(&e[0]) != hipSuccess || hipEventCreate(&e[1]) != hipSuccess) { (void)hipGetLastError(); off = true; return 0; }
+        have_events = true;
+      }
+      const int block = i / BLOCK, pos = i % BLOCK;
+      if (pos == 1 && hipEventRecord(ev[block][0], s) != hipSuccess) { (void)hipGetLastError(); off = true; return 0; }
+      measuring_begin = true;
+      measuring_end = pos == BLOCK - 1;
+      return block % NC;
+    }
+    if (hipEventQuery(ev[NB - 1][1]) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (not through yet: the default meanwhile)
+    float best = 0.0f;
+    for (int c = 0; c < NC; ++c) {
+      ms[c] = 0.0f;
+      for (int r = 0; r < ROUNDS; ++r) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, ev[r * NC + c][0], ev[r * NC + c][1]) != hipSuccess) { (void)hipGetLastError(); off = true; drop(); return 0; }
+        ms[c] += t / ((BLOCK - 1) * ROUNDS);
+      }
+      if (chosen < 0 || ms[c] < best * 0.985f) { best = ms[c]; chosen = c; }
+    }
+    drop();
+    const char* dbg = getenv("PCX_DEBUG");
+    if (dbg && (atoi(dbg) & 16))
+      fprintf(stderr, "[pcx scrolly_maze] launch shape candidate %d of %d (%.4f %.4f %.4f %.4f ms per launch)\n", chosen, NC, ms[0], ms[1], ms[2], ms[3]);
+    return chosen;
+  }
+  void launched(hipStream_t s) {
+    if (!measuring_begin) return;
+    if (measuring_end && hipEventRecord(ev[(phase - WARM) / BLOCK][1], s) != hipSuccess) { (void)hipGetLastError(); off = true; }
+    ++phase;
+    measuring_begin = measuring_end = false;
+  }
+};
 
 class ScrollyMazeBackend : public Backend {
  public:
@@ -1987,49 +1971,34 @@ class ScrollyMazeBackend : public Backend {
     if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
     return shipped_shape && bpad_ / WAVE < (int64_t)num_cus_ * coop_below;
   }
-  // Which persistent launch shape a plain step of the shipped shape takes (0: one workgroup per group; kernel: PS)
-  // Default: 3 -- workers with a streaming semaphore (profiles/r04_tuning.md: 6-23 % faster than shape 0 from 65,536
-  // to 2,097,152 environments on the same box); PCX_SM_SHAPE picks another for A/B runs.
+  // Does a plain step of the shipped shape take the persistent launch shape (3; 0: one workgroup per group)?  From four
+  // units per CU up, i.e. wherever the cooperative shape does not apply (round 4: 6-23 % faster than shape 0 from 131,072
+  // to 2,097,152 environments on the same box, slower at 65,536; round 5, with the 9 us logic phase: 0.045 against 0.052
+  // ms at 65,536 too -- profiles/r05_tuning.md); PCX_SM_SHAPE=0 / 3 forces one for A/B runs.
   int ps_shape(const StepArgs& a) const {
     int shape = 3;
     bool asked = false;
-    if (const char* e = getenv("PCX_SM_SHAPE")) { shape = atoi(e); asked = true; }
-    if (shape < 0 || shape > 3) shape = 0;
-    if (a.mode != 0 || a.n_steps > 1 || (a.debug & ~5) != 0 || epi_.out || fused_.on || k_.CW > 4 || k_.NW > PS_IB_ACTION) shape = 0;
-    if (!asked && getenv("PCX_SM_CODES") && atoi(getenv("PCX_SM_CODES")) == 0) shape = 0;  // (the mask path's A/B runs mean shape 0)
-    // (up to ~5 units per CU one wave per unit, all resident at once, is faster: 65,536 environments 0.053 vs 0.065 ms)
-    if (!asked && bpad_ / WAVE < (int64_t)num_cus_ * 6) shape = 0;
+    if (const char* e = getenv("PCX_SM_SHAPE")) { shape = atoi(e) == 3 ? 3 : 0; asked = true; }
+    if (a.mode != 0 || a.n_steps > 1 || (a.debug & ~(5 | 16)) != 0 || epi_.out || fused_.on || k_.CW > 4 || k_.NW > PS_IB_ACTION) shape = 0;
+    if (!asked && bpad_ / WAVE < (int64_t)num_cus_ * 4) shape = 0;
     return shape;
   }
-  // The Consts a persistent launch hands to the kernel: the LDS buffers are sized by the unit (units of 32 or 16
-  // environments let more workers, or deeper rings, share a CU) and the mask path lays the level out differently.
-  Consts ps_consts(int unit, bool use_codes, int nb) const {
+  // The Consts a persistent launch hands to the kernel: the workers' LDS buffers are sized by the unit (units of 32 or 16
+  // environments let more workers share a CU).
+  Consts ps_consts(int unit) const {
     Consts kk = k_;
     kk.lds_ps_buf_words = unit * (((k_.QW + 1) / 2) | 1) + WAVE;  // (owner codes as nibbles: the kernel's CODE_PITCH for NIB)
-    if (!use_codes) {
-      // mask path: the staged level ends with the backdrop-character masks instead of the backdrop's owner codes; a
-      // buffer is both curtains as flat bit vectors + the sprite descriptors of 64 environments + the skip flags
-      int o = k_.lds_bdcode;
-      kk.lds_bdmask = o; o += k_.n_bchars * k_.QW;
-      kk.lds_ps_ring = o; o += 4 + 2 * PS_NB_MAX;
-      kk.lds_ps_inbox = o; o += PS_IB_ROWS * WAVE;
-      kk.lds_ps_cmask = o; o += (k_.CW ? k_.CW : 1) * WAVE;
-      o = (o + 1) & ~1;  // (uint2 descriptors)
-      kk.lds_ps_buf0 = o;
-      kk.lds_ps_buf_words = 2 * WAVE * (k_.FW | 1) + 2 * k_.NS * WAVE + WAVE;
-    }
     kk.lds_ps_words1 = kk.lds_ps_buf0 + kk.lds_ps_buf_words;
-    kk.lds_ps_words2 = kk.lds_ps_buf0 + nb * kk.lds_ps_buf_words;
-    kk.lds_ps_wave_words = kk.lds_ps_words1 - kk.lds_ps_inbox;  // PS == 3: a worker's {inbox, coin masks, buffer}
+    kk.lds_ps_wave_words = kk.lds_ps_words1 - kk.lds_ps_inbox;  // a worker's {inbox, coin masks, buffer}
     return kk;
   }
   void set_plan_only() { plan_only_ = true; }
   const Consts& consts() const { return k_; }
   // Are these launch-time Consts the baked ones (pcx_sm_shipped.h)?  PCX_SM_BAKED=0: never (A/B runs, tests of the other instance)
-  static bool baked_l0(const Consts& kk) {
+  static bool baked_l0(const Consts& kk, const Consts& baked = SHIPPED_L0) {
     if (!SHIPPED_L0_VALID) return false;
     if (const char* e = getenv("PCX_SM_BAKED")) if (atoi(e) == 0) return false;
-    return memcmp(&kk, &SHIPPED_L0, sizeof kk) == 0;
+    return memcmp(&kk, &baked, sizeof kk) == 0;
   }
   int max_fused_steps() const override { return fused_ok_ && !epi_.out && !fused_.on ? 256 : 1; }  // the epilogue / fused croppers have no multi-step instance
   // include/pcx.h pcx_engine_fuse_croppers: the instances that render from curtain bit vectors + sprite
@@ -2079,6 +2048,7 @@ class ScrollyMazeBackend : public Backend {
   DevArray<uint16_t> rowbase_;
   DevArray<int32_t> track_;
   DevArray<uint32_t> ps_ctr_, ps_prof_;
+  ShapeTuner tuner_;
   int last_shape_ = -1;
  public:
   // the phase timers of the last persistent launch (PCX_SM_PROF=1): 16 words per workgroup, see Ptrs::ps_prof
@@ -2317,7 +2287,7 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   k.lds_rowstart = off; off += k.PR * CWPR;      // the coin pattern's bit-rows
   k.lds_coincol = off; off += (int)rs.size() / 2;  // coins before every row
   k.FW = (k.cells + 31) / 32 + 1;
-  // per-group render descriptors, double-buffered between the two waves
+  // per-group render descriptors
   const int buf0 = off;
   k.lds_flat = off; off += 2 * (k.FW | 1) * WAVE;
   off = (off + 1) & ~1;  // uint2 alignment
@@ -2325,7 +2295,6 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
   k.lds_skip = off; off += WAVE;
   off = (off + 1) & ~1;
   k.lds_buf_words = off - buf0;
-  off += k.lds_buf_words;  // second buffer
   k.lds_cmask = off; off += (k.CW ? k.CW : 1) * WAVE;
   k.lds_bdmask = off; off += k.n_bchars * k.QW;
   k.lds_flatraw = off; if (unoccluded_) off += 2 * (k.FW | 1) * WAVE;
@@ -2345,13 +2314,12 @@ int ScrollyMazeBackend::init(const pcx_template& t, int64_t batch) {
     // persistent shapes: the same constants, then inbox, ring, coin masks and one / PS_NB owner-code buffers
     o = k.lds_bdcode + k.QW;
     k.lds_ps_lut = o; o += 256 + (k.QW + 1) / 2;  // (the owner-code instances' bit -> nibble table and nibble backdrop)
-    k.lds_ps_ring = o; o += 4 + 2 * PS_NB_MAX;  // [3]: PS == 3's streaming mutex
+    k.lds_ps_ring = o; o += 4;  // [3]: the streaming semaphore
     k.lds_ps_inbox = o; o += PS_IB_ROWS * WAVE;
     k.lds_ps_cmask = o; o += (k.CW ? k.CW : 1) * WAVE;
     k.lds_ps_buf0 = o;
     k.lds_ps_buf_words = WAVE * ((k.QW | 1) + 2) + WAVE;  // code table (CODE_PITCH dwords per environment) + skip flags
     k.lds_ps_words1 = o + k.lds_ps_buf_words;
-    k.lds_ps_words2 = o + 2 * k.lds_ps_buf_words;  // (launch() sizes the buffers by the unit and the ring by PCX_SM_NB)
   }
 
   if (plan_only_) return 0;  // (pcx_debug_scrolly_consts: the host half only, no device)
@@ -2391,23 +2359,21 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     int rc = curtains_.alloc((size_t)2 * k_.FW * bpad_);
     if (rc) return rc;
   }
-  // Launch shape.  Default: one single-wave workgroup per group of 64
-  // environments (logic, then render), with the LDS footprint padded so that
-  // about 8 waves share a CU -- on MI355X the nine interleaved write streams
-  // per wave thrash less and go faster with 7-9 waves per CU than with 15+
-  // (profiles/r01_tuning.md).  PCX_WAVES_PER_WG=2 selects the two-wave
-  // logic/render pipeline with PCX_WGS_PER_CU persistent workgroups per CU.
-  int64_t groups = bpad_ / WAVE;
-  int wgs_per_cu = 0, waves_per_wg = 1, waves_per_cu = 8;
-  if (const char* e = getenv("PCX_WGS_PER_CU")) wgs_per_cu = atoi(e);
-  if (const char* e = getenv("PCX_WAVES_PER_WG")) waves_per_wg = atoi(e) == 2 ? 2 : 1;
+  // Launch shapes (pcx_engine_launch_shape says which one ran):
+  //   10 / 12  cooperative: below four groups per CU (and for several steps per launch) a workgroup is four or eight waves
+  //            around ONE group of 16-64 environments -- the steps are latency-bound there (profiles/r03_tuning.md);
+  //   3 / 5    persistent workers with streaming slots: the shipped shape from 65,536 environments up (5: the instance
+  //            with the shipped level's constants compiled in);
+  //   0        one single-wave workgroup per group of 64 environments (logic, then render), LDS padded so that about 8
+  //            share a CU -- nine interleaved write streams per wave go faster with 7-9 waves per CU than with 15+
+  //            (profiles/r01_tuning.md): the shipped shape in between and whenever an epilogue or croppers are fused;
+  //   20       the shape-generic instances (other boards, casts, unoccluded layers), launched like 0.
+  const int64_t groups = bpad_ / WAVE;
+  int waves_per_cu = 8;
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
-  if (fused_.on) waves_per_wg = 1;  // fused croppers: a group is rendered in the round that steps it
-  if (waves_per_wg == 2 && wgs_per_cu == 0) wgs_per_cu = 4;
-  int64_t max_wgs = wgs_per_cu > 0 ? (int64_t)num_cus_ * wgs_per_cu : groups;
-  dim3 grid((unsigned)(groups < max_wgs ? groups : max_wgs)), block(waves_per_wg * WAVE);
+  const dim3 grid((unsigned)groups), block(WAVE);
   size_t lds = (size_t)k_.lds_words * 4;
-  if (waves_per_wg == 1 && waves_per_cu > 0) {
+  if (waves_per_cu > 0) {
     size_t want = (size_t)(160 * 1024) / (size_t)waves_per_cu;
     want &= ~(size_t)255;
     if (want > lds) lds = want;
@@ -2415,26 +2381,18 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   if (const char* pad = getenv("PCX_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   if (lds > 64 * 1024) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds);
   Ptrs P{walls_.ptr, backdrop4_.ptr, coinbits_.ptr, rowbase_.ptr, state_.ptr, track_.ptr, curtains_.ptr, maze_di_, batch_, bpad_,
-         ps_ctr_.ptr, WAVE, 1, 2, 0, 1, 1, 16, 0, 0, nullptr};
-  // Specialised instance for the shipped scrolly_maze shape (10x30 board,
-  // 8 characters, 'abcP' sprites); anything else takes the generic instance.
+         ps_ctr_.ptr, WAVE, 1, 1, 1, 16, 0, 0, nullptr};
+  // Specialised instances for the shipped scrolly_maze shape (10x30 board, 8 characters, 'abcP' sprites); anything else
+  // takes a shape-generic instance.
   const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
-  // Small batches leave most CUs with one wave or none: let four waves share
-  // each group's render loop (COOP instance), one group per workgroup.
-  bool use_codes = true;  // PCX_SM_CODES=0: the mask-composing render loop of round 1 (A/B)
+  bool use_codes = true;  // PCX_SM_CODES=0: the mask-composing render loop of round 1 (A/B; shape 0 only)
   if (const char* e = getenv("PCX_SM_CODES")) use_codes = atoi(e) != 0;
   if (fused_.on) use_codes = false;  // the windows are cut from the curtain bit vectors
   int coop_below = 4;  // groups per CU (measured crossover: profiles/r03_tuning.md; round 1: 5)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
-  const bool old_tfuse = getenv("PCX_TFUSE_OLD") && atoi(getenv("PCX_TFUSE_OLD")) != 0;  // round 1's multi-step instance (A/B)
   if (a.n_steps > 1 && (!shipped_shape || !fused_ok_ || a.mode != 0 || epi_.out))
     return set_error(PCX_E_INVALID, "scrolly_maze backend: %d steps in one launch are not available here", a.n_steps);
-  if (a.n_steps > 1 && old_tfuse) {
-    // several steps in this launch: the logic wave runs ahead of the render waves
-    hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), dim3((unsigned)groups),
-                       dim3(4 * WAVE), (size_t)k_.lds_words * 4, s, k_, P, a, out, epi_, fused_.ptr());
-    last_shape_ = 11;
-  } else if (shipped_shape && ((waves_per_wg == 1 && groups < (int64_t)num_cus_ * coop_below) || a.n_steps > 1)) {  // (several steps: this shape whatever the knobs say)
+  if (shipped_shape && (groups < (int64_t)num_cus_ * coop_below || a.n_steps > 1)) {  // (several steps: this shape whatever the knobs say)
     int coop_waves = groups <= num_cus_ ? 8 : 4;  // at most one group per CU: split the render loop eight ways
     if (const char* e = getenv("PCX_COOP_WAVES")) coop_waves = atoi(e) == 4 ? 4 : 8;
     // ... and while CUs would still stand empty, halve the environments per workgroup (32, 16): the
@@ -2450,87 +2408,88 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     if (epi_.out) {
       size_t lds_e = (size_t)k_.lds_words * 4;
       const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_e, coop_waves);
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, true>), dim3(coop_groups),
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, true>), dim3(coop_groups),
                          dim3(coop_waves * WAVE), lds_e, s, k_, P, ac, out, ep, fused_.ptr());
-    } else
+    } else if (!fused_.on && baked_l0(k_, SHIPPED_L0_PLAIN))  // (round 5: config 2's latency-bound steps with the level's constants compiled in)
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, false, 0, 2>), dim3(coop_groups),
+                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
+    else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3(coop_groups),
                          dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
-  } else if (shipped_shape && waves_per_wg == 1 && ps_shape(a) != 0 && (use_codes || ps_shape(a) != 2)) {
-    // persistent shapes of the owner-code instance (see the kernel): workgroups stay and draw work units
-    const int shape = ps_shape(a);
-    int unit = WAVE, per_cu = shape == 2 ? 3 : 8, dynamic = 1, waves = 2;
+  } else if (shipped_shape && use_codes && ps_shape(a) == 3) {
+    // persistent workers (see the kernel): workgroups stay on their CU, their waves draw work units
+    int unit = WAVE, per_cu = 3, dynamic = 1, waves = 2;
     if (const char* e = getenv("PCX_SM_UNIT")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) unit = v; }
-    int nb = 2;
-    if (const char* e = getenv("PCX_SM_NB")) { const int v = atoi(e); if (v >= 2 && v <= PS_NB_MAX) nb = v; }
-    const Consts kk = ps_consts(unit, use_codes, nb);
-    const bool baked = shape == 3 && use_codes && baked_l0(kk);  // the instance with the level's constants compiled in steps a unit in ~9 us, the other in ~20
-    if (shape == 3 && !baked) {
+    const Consts kk = ps_consts(unit);
+    const bool baked = baked_l0(kk);  // the instance with the level's constants compiled in steps a unit in ~9 us, the other in ~20
+    const int64_t units64 = bpad_ / WAVE;
+    if (!baked) {
       // (round 4) two workers per workgroup, one of them streaming.  Few units per worker (config 5's shard: 2,048 units): four
       // workgroups per CU, every unit somebody's first, no tickets; up to a few units per worker: three per CU,
       // static round-robin (a drawn ticket commits a worker to one more unit -- the tail -- which costs more than the
       // imbalance it removes until a worker walks four or five units: 262,144 environments 0.178 static / 0.187 tickets,
       // 524,288: 0.330 / 0.323); beyond: three per CU, tickets
-      const int64_t units64 = bpad_ / WAVE;
       per_cu = units64 <= (int64_t)num_cus_ * 8 ? 4 : 3;
-      dynamic = units64 >= (int64_t)num_cus_ * 6 * 4;
-    } else if (shape == 3) {
+    } else {
       // (round 5) with a 9 us logic phase fewer workers keep the streaming slots busy, and slots SHARED by all workers of a CU
       // (one workgroup of four, two slots) beat private ones (two workgroups of two, one slot each): 1,048,576 environments
       // 0.562 / 0.576 ms, 524,288: 0.300 / 0.303, 262,144: 0.152 / 0.156 on one box, 0.574 / 0.587 (2 x 3: 0.560) on
       // another; config 5's shard (every worker steps ONE unit): two workgroups of four, two slots each -- 0.078 against
       // 0.084-0.087 for 2 x 4 (profiles/r05_ps_sweep_call4_shapes.txt, _call5_steal.txt; the boxes differ by more than
       // the shapes do)
-      const int64_t units64 = bpad_ / WAVE;
-      waves = 4;
-      per_cu = units64 <= (int64_t)num_cus_ * 8 ? 2 : 1;
-      P.ps_lock = 2;
-      dynamic = units64 >= (int64_t)num_cus_ * 6 * 4;
+      // ... so the engine measures: the default and three alternatives, on its own first launches (ShapeTuner)
+      struct Cand { int waves, per_cu, lock; };
+      static const Cand few[ShapeTuner::NC] = {{4, 2, 2}, {8, 1, 3}, {3, 3, 1}, {2, 4, 1}};    // every worker steps one unit
+      static const Cand many[ShapeTuner::NC] = {{4, 1, 2}, {2, 3, 1}, {6, 1, 3}, {4, 2, 2}};
+      const bool knobs = getenv("PCX_SM_WAVES") || getenv("PCX_SM_PER_CU") || getenv("PCX_SM_LOCK") || getenv("PCX_SM_GRID") ||
+                         getenv("PCX_SM_UNIT") || getenv("PCX_SM_PROF") || (getenv("PCX_SM_TUNE") && atoi(getenv("PCX_SM_TUNE")) == 0);
+      if (knobs || (a.debug & ~16)) tuner_.off = true;  // (PCX_DEBUG=16: say what was chosen)
+      const Cand& c = (units64 <= (int64_t)num_cus_ * 8 ? few : many)[tuner_.pick(a, s)];
+      waves = c.waves;
+      per_cu = c.per_cu;
+      P.ps_lock = c.lock;
     }
+    dynamic = units64 >= (int64_t)num_cus_ * 6 * 4;
     if (const char* e = getenv("PCX_SM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
     if (const char* e = getenv("PCX_SM_DYNAMIC")) dynamic = atoi(e) != 0;
-    if (const char* e = getenv("PCX_SM_PRIO")) P.ps_prio = atoi(e) != 0;
-    P.ps_unit = unit;
-    P.ps_dynamic = dynamic;
-    P.ps_nb = nb;
-    // PS == 3: `waves` workers per workgroup, each with its own {inbox, coin masks, buffer}
-    if (const char* e = getenv("PCX_SM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) waves = v; }
+    if (const char* e = getenv("PCX_SM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) waves = v; }  // workers per workgroup
     if (const char* e = getenv("PCX_SM_LOCK")) P.ps_lock = atoi(e);
     if (const char* e = getenv("PCX_SM_STEAL")) P.ps_steal = atoi(e) != 0;
-    const int words3 = kk.lds_ps_inbox + waves * kk.lds_ps_wave_words;
-    int64_t n_units = (bpad_ + unit - 1) / unit, resident = (int64_t)num_cus_ * per_cu;
+    P.ps_unit = unit;
+    P.ps_dynamic = dynamic;
+    const int words3 = kk.lds_ps_inbox + waves * kk.lds_ps_wave_words;  // the staged level, then every worker's {inbox, coin masks, buffer}
+    const int64_t n_units = (bpad_ + unit - 1) / unit;
+    int64_t resident = (int64_t)num_cus_ * per_cu;
     if (const char* e = getenv("PCX_SM_GRID")) { const int v = atoi(e); if (v >= 1) resident = v; }  // (tests: few workgroups, many units each)
-    last_shape_ = shape;
-    size_t lds_p = (size_t)(shape == 3 ? words3 : shape == 2 ? kk.lds_ps_words2 : kk.lds_ps_words1) * 4;
+    const size_t lds_p = (size_t)words3 * 4;
     // (no LDS padding here: the grid is sized to what is resident at once, so the occupancy is the grid's)
     if (lds_p > (size_t)max_lds_) return set_error(PCX_E_INVALID, "scrolly_maze backend: %zu bytes of LDS per workgroup", lds_p);
-    if (lds_p > 64 * 1024 && shape == 3) {
+    if (lds_p > 64 * 1024) {
       static bool raised = false;  // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel)
       if (!raised) {
-        PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3>),
+        PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
-        PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 3>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
-        PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3, 1>),
+        PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
         raised = true;
       }
     }
-    {  // no more workgroups than are resident at once: a workgroup that starts late would step its first unit late
+    if (!getenv("PCX_SM_GRID")) {  // no more workgroups than are resident at once: a workgroup that starts late would step its first unit late
       const int64_t fit = (int64_t)(160 * 1024) / (int64_t)((lds_p + 511) & ~(size_t)511);
-      const int64_t by_regs = shape == 3 ? (waves <= 12 ? 12 / waves : 1) : shape == 2 ? 6 : 12;  // (130-170 VGPRs: three waves per SIMD)
+      const int64_t by_regs = waves <= 12 ? 12 / waves : 1;  // (130-170 VGPRs: three waves per SIMD)
       int64_t per = per_cu < fit ? per_cu : fit;
       if (per > by_regs) per = by_regs;
-      if (!getenv("PCX_SM_GRID")) resident = (int64_t)num_cus_ * (per < 1 ? 1 : per);
+      resident = (int64_t)num_cus_ * (per < 1 ? 1 : per);
     }
-    const int64_t want_wgs = shape == 3 ? (n_units + waves - 1) / waves : n_units;  // (no workgroup without a unit)
+    const int64_t want_wgs = (n_units + waves - 1) / waves;  // (no workgroup without a unit)
     const dim3 pgrid((unsigned)(want_wgs < resident ? want_wgs : resident));
-    const int64_t workers = (int64_t)pgrid.x * (shape == 3 ? waves : 1);
+    const int64_t workers = (int64_t)pgrid.x * waves;
     if (workers >= n_units) P.ps_dynamic = 0;  // every unit is some worker's first: nothing to draw
     P.ps_n1 = P.ps_n = (uint32_t)n_units;
     {
       // PCX_SM_TAIL=t: with tickets, the last t small units per worker go in units of PCX_SM_TAIL_UNIT environments.  Off by
       // default: measured, every setting loses (1,048,576 environments: 0.614 ms without, 0.617 / 0.631 / 0.642 with
-      // t = 1 / 2 / 3 -- a small unit still costs a whole logic phase; profiles/r04_tuning.md)
+      // t = 1 / 2 / 3 in round 4, 0.569 / 0.572 in round 5 -- a small unit still costs a whole logic phase; profiles/r04_tuning.md)
       int tail = 0, small = 16;
       if (const char* e = getenv("PCX_SM_TAIL")) tail = atoi(e);
       if (const char* e = getenv("PCX_SM_TAIL_UNIT")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) small = v; }
@@ -2544,23 +2503,18 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     }
     if (getenv("PCX_SM_PROF")) {
       if (!ps_prof_.ptr) { int rc = ps_prof_.alloc((size_t)16 * 65536); if (rc) return rc; }
-      if (pgrid.x <= 65536) P.ps_prof = ps_prof_.ptr;
+      if (workers <= 65536) P.ps_prof = ps_prof_.ptr;
     }
-    if (shape == 3 && !use_codes)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
-    else if (shape == 1 && !use_codes)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, false, 1>), pgrid, dim3(WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
-    else if (shape == 3 && baked) {
+    if (baked) {
       // the engine's Consts are the shipped level 0's, word for word: the instance that has them as compile-time constants
       last_shape_ = 5;
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3, 1>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
-    } else if (shape == 3)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
-    else if (shape == 2)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 2>), pgrid, dim3(2 * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
-    else
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true, 1>), pgrid, dim3(WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
-  } else if (shipped_shape && waves_per_wg == 1 && use_codes) {
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3, 1>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
+      tuner_.launched(s);
+    } else {
+      last_shape_ = 3;
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
+    }
+  } else if (shipped_shape && use_codes) {
     // owner-code render path: its own, smaller LDS layout, padded to the same workgroups-per-CU target
     last_shape_ = 0;
     size_t lds_c = (size_t)k_.lds_words_codes * 4;
@@ -2570,19 +2524,17 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
       if (want > lds_c) lds_c = want;
     }
     if (epi_.out)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, true>), grid, block, lds_c, s, k_, P, a, out, ep, fused_.ptr());
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true, true>), grid, block, lds_c, s, k_, P, a, out, ep, fused_.ptr());
     else
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, false, true>), grid, block, lds_c, s, k_, P, a, out, epi_, fused_.ptr());
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true>), grid, block, lds_c, s, k_, P, a, out, epi_, fused_.ptr());
   } else if (shipped_shape) {
-    last_shape_ = waves_per_wg == 2 ? 4 : 0;
-    if (epi_.out && waves_per_wg == 1) {
+    last_shape_ = 0;
+    if (epi_.out) {
       size_t lds_e = (size_t)k_.lds_words * 4;
       const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_e, 1);
       if (lds > lds_e) lds_e = lds;  // (the padding towards `waves_per_cu` workgroups per CU)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true>), grid, block, lds_e, s, k_, P, a, out, ep, fused_.ptr());
-    } else if (epi_.out)
-      return set_error(PCX_E_UNSUPPORTED, "scrolly_maze backend: the epilogue needs the single-wave launch shape");
-    else
+      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, true>), grid, block, lds_e, s, k_, P, a, out, ep, fused_.ptr());
+    } else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false>), grid, block, lds, s, k_, P, a, out, epi_, fused_.ptr());
   } else {
     last_shape_ = 20;
@@ -2653,8 +2605,8 @@ int64_t scrolly_maze_consts(const pcx_template& t, int32_t unit, uint32_t* words
   b.set_plan_only();
   const int rc = b.init(t, 64);
   if (rc) return rc;
-  if (unit != 16 && unit != 32 && unit != 64) return set_error(PCX_E_INVALID, "pcx_debug_scrolly_consts: units are 16, 32 or 64 environments");
-  const sm::Consts kk = b.ps_consts(unit, true, 2);
+  if (unit != 0 && unit != 16 && unit != 32 && unit != 64) return set_error(PCX_E_INVALID, "pcx_debug_scrolly_consts: units are 16, 32 or 64 environments (0: the constants as init() leaves them)");
+  const sm::Consts kk = unit ? b.ps_consts(unit) : b.consts();
   if (words) {
     if (cap < sm::CONSTS_WORDS) return set_error(PCX_E_INVALID, "pcx_debug_scrolly_consts: room for %d words needed", sm::CONSTS_WORDS);
     memcpy(words, &kk, sizeof kk);

@@ -55,6 +55,91 @@ __device__ __forceinline__ void lds_dma_row(const uint32_t* base, uint32_t voff,
 __device__ __forceinline__ uint32_t lds_byte_address(const uint32_t* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)p;
 }
+// ---- persistent workers (round 5: the launch shape of pcx_scrolly_maze_step, for the kernels built on this header) ----------
+// A workgroup stays on its CU; each of its waves is a WORKER that draws work units (64 consecutive environments), steps a
+// unit (lane == environment) and streams it, with the next unit's state words travelling into its LDS inbox by LDS-DMA in
+// front of the current unit's plane stores (vmcnt counts in order and holds 63: after 64 plane stores they have landed),
+// and at most `lock` workers of a workgroup in the streaming loop at a time.  pcx_scrolly_maze.hip has the measurements.
+
+// The next ticket of a work counter: a SCALAR atomic (s_atomic_add; coherent across the XCDs: tools/experiments/
+// satomic_probe.hip) -- through the scalar cache, not behind the CU's queue of plane stores; waited for on lgkmcnt.
+__device__ __forceinline__ uint32_t scalar_ticket(uint32_t* ctr_any) {
+  const uint64_t v = reinterpret_cast<uint64_t>(ctr_any);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  uint32_t* const ctr = reinterpret_cast<uint32_t*>(((uint64_t)hi << 32) | lo);
+  uint32_t t = 1u;
+  uint64_t own;
+  asm volatile("s_mov_b64 %1, %2\n\ts_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t), "=&s"(own) : "s"(ctr) : "memory");
+  return t;
+}
+// A counting semaphore in LDS around the streaming loop: lane 0 alone adds; a wave that finds the count at the limit takes
+// its increment back and tries again a little later.  Giving up after SLOT_SPINS tries (seconds) costs nothing but speed:
+// the wave then streams without a slot -- results never depend on the semaphore.
+constexpr uint32_t SLOT_SPINS = 1u << 22;
+__device__ __forceinline__ void slot_acquire(uint32_t lds_addr, int limit) {
+  uint32_t one = 1u;
+  uint32_t spins = 0;
+  for (;;) {
+    uint32_t old;
+    uint64_t save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(old), "=&s"(save) : "v"(lds_addr), "v"(one) : "memory");
+    if (__builtin_amdgcn_readfirstlane((int)old) < limit || ++spins >= SLOT_SPINS) break;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_sub_u32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(save) : "v"(lds_addr), "v"(one) : "memory");
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+__device__ __forceinline__ void slot_release(uint32_t lds_addr) {
+  uint32_t one = 1u;
+  uint64_t save;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_sub_u32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(save) : "v"(lds_addr), "v"(one) : "memory");
+}
+// What a kernel's arguments carry for the scheduler (host: WorkerLaunch below fills it).
+struct WorkArgs {
+  uint32_t* ctr = nullptr;  // nine words 64 bytes apart: eight ticket shards (one per XCD as the hardware places workgroups: block b on XCD b % 8) and the workers-done count
+  uint32_t n_units = 0;
+  int32_t dynamic = 0;      // tickets (with stealing across the shards) or static round-robin
+  int32_t lock = 0;         // streaming slots per workgroup (0: no limit)
+};
+// One worker's view of the units: first() its first unit, next(u) the one after u (>= n_units: none left).  Static:
+// round-robin over all workers.  Dynamic: the first unit by position, every further one by ticket from the worker's own
+// shard of the counter, then -- a shard found dry stays dry -- from the other shards (the XCDs do not finish together).
+struct WorkQueue {
+  uint32_t* ctr;
+  uint32_t n, shards, x, wpw, nwk, wid, local, stolen;
+  bool dynamic;
+  __device__ __forceinline__ void init(const WorkArgs& w, int wave) {
+    ctr = w.ctr; n = w.n_units; dynamic = w.dynamic != 0;
+    wpw = blockDim.x >> 6;
+    shards = gridDim.x < 8u ? gridDim.x : 8u;
+    x = blockIdx.x % shards;
+    nwk = gridDim.x * wpw;
+    wid = blockIdx.x * wpw + (uint32_t)wave;
+    local = (blockIdx.x / shards) * wpw + (uint32_t)wave;
+    stolen = 0;
+  }
+  __device__ __forceinline__ uint32_t first() const { return dynamic ? x + shards * local : wid; }
+  __device__ __forceinline__ uint32_t next(uint32_t u) {
+    if (!dynamic) return u + nwk;
+    while (stolen < shards) {
+      const uint32_t y = x + stolen >= shards ? x + stolen - shards : x + stolen;
+      const uint32_t nwk_y = ((gridDim.x - y + shards - 1u) / shards) * wpw;
+      const uint32_t cand = y + shards * (nwk_y + scalar_ticket(ctr + 16u * y));
+      if (cand < n) return cand;
+      ++stolen;
+    }
+    return n;
+  }
+  // the last worker out rewinds the counters for the next launch (every ticket of this launch was drawn before its worker got here)
+  __device__ __forceinline__ void finish(int lane) const {
+    if (dynamic && lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (atomicAdd(ctr + 8 * 16, 1u) == nwk - 1u)
+        for (int i = 0; i <= 8; ++i) atomicExch(ctr + 16 * i, 0u);
+    }
+  }
+};
+
 __device__ __forceinline__ const uint32_t* uniform_words(const uint32_t* p) {
   return reinterpret_cast<const uint32_t*>(uniform_ptr(reinterpret_cast<uint8_t*>(const_cast<uint32_t*>(p))));
 }
@@ -260,7 +345,7 @@ __device__ __forceinline__ void to_array_emit(const EpilogueArgs& epi, const uin
 //   MODE (epilogue instances): 0 the float32 feature planes, 1 channels last, 2 ObservationToArray -- a compile-time
 //     choice per loop (stream_planes() below picks one at run time): as run-time flags inside ONE loop body the two
 //     later kinds cost the first a fifth of its speed (marauders 262,144: 1.61 -> 1.95 ms; profiles/r03_post_kernels.md).
-template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI, bool UNOCC, int MODE>
+template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI, bool UNOCC, int MODE, bool DRAIN = true>
 __device__ __forceinline__ void stream_planes_mode(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
                                                    const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
                                                    const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
@@ -283,7 +368,9 @@ __device__ __forceinline__ void stream_planes_mode(const PlaneMap<NS, ND, NB>& p
   // Drain the logic phase's own loads/stores once, here: the loop's stores are
   // inline asm the compiler cannot count, and without this it would protect a
   // register of an older store with a vmcnt(0) inside the loop.
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt/lgkmcnt untouched
+  // (DRAIN = false: the persistent workers -- their next unit's state words are on the way into LDS and must not be
+  // waited for here; the logic phase's own stores drain under the plane stores)
+  if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt/lgkmcnt untouched
 
   const bool two_pass = EPI && epi.two_pass;  // (with skip_layers the first sweep writes the board plane only)
   constexpr int lwaves = NWAVES;
@@ -440,7 +527,7 @@ __device__ __forceinline__ void stream_planes_mode(const PlaneMap<NS, ND, NB>& p
   }  // passes
 }
 
-template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI, bool UNOCC = false>
+template <int NS, int ND, int NB, int QW, int NWAVES, bool EPI, bool UNOCC = false, bool DRAIN = true>
 __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
                                               const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
                                               const uint2* sdesc, const uint32_t* skip, int FWP, int lane, int wave,
@@ -448,7 +535,7 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
                                               int qw_rt = 0, const uint32_t* flatraw = nullptr, const uint2* sdescraw = nullptr,
                                               uint32_t* lds_base = nullptr) {
 #define PCX_STREAM_MODE(m)                                                                                                       \
-  stream_planes_mode<NS, ND, NB, QW, NWAVES, EPI, UNOCC, m>(pm, group_base, env_stride, backdrop4, bdmask, flat, sdesc, skip, FWP, lane, \
+  stream_planes_mode<NS, ND, NB, QW, NWAVES, EPI, UNOCC, m, DRAIN>(pm, group_base, env_stride, backdrop4, bdmask, flat, sdesc, skip, FWP, lane, \
                                                             wave, epi, env0, cell_ids, qw_rt, flatraw, sdescraw, lds_base)
   if constexpr (!EPI) {
     PCX_STREAM_MODE(0);

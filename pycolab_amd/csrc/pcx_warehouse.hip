@@ -59,6 +59,7 @@ struct Ptrs {
   int32_t* track;          // [NS][bpad], template sprite order
   uint32_t* curtains;      // [1][FW][bpad] raw judge curtain (export_curtains)
   int64_t batch, bpad;
+  stream::WorkArgs work;   // PW instances: the persistent workers' scheduler (pcx_stream.h)
 };
 
 __device__ __forceinline__ uint32_t action_hash(uint64_t seed, uint64_t env, uint64_t t) {
@@ -77,8 +78,12 @@ __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16
 // per workgroup (wave 0 steps the group, all of them share the render loop).
 // SR x SC: the board's shape when the instance is compiled for it; 0 x 0: read from k.rows / k.cols
 // (levels that are neither shipped nor among the fixtures' compiled shapes).
-template <int NS, int SR, int SC, int NB, int NWAVES, bool EPI = false, bool UNOCC = false>
-__global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts k, const Ptrs P, const StepArgs a,
+// PW (round 5): persistent workers -- the workgroup stays on its CU and each of its (up to eight) waves draws units of 64
+// environments, steps one and streams it ALONE (NWAVES == 1), the next unit's state words prefetched into its LDS inbox, at
+// most `work.lock` workers of the workgroup streaming at a time (pcx_stream.h; the launch shape pcx_scrolly_maze_step took
+// in round 4).  Plain steps of the compiled shapes only: no epilogue, no fused croppers, occluded layers.
+template <int NS, int SR, int SC, int NB, int NWAVES, bool EPI = false, bool UNOCC = false, bool PW = false>
+__global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_warehouse_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                     const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                     const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
@@ -91,19 +96,45 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
   const int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
   const int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   const int O_FLATRAW = O_WCORNER + stream::WCORNER_WORDS, O_SDESCRAW = (O_FLATRAW + WAVE * FWP + 1) & ~1;  // UNOCC only
+  static_assert(!PW || (NWAVES == 1 && !EPI && !UNOCC && SR != 0), "persistent workers: plain steps of the compiled shapes");
+  // PW: a worker's own LDS region {flat, sdesc, skip, inbox}; the inbox holds the unit's state rows and its tape actions
+  constexpr int NW = W_POS + NS, IB_ROWS = NW + 1;
+  const int O_SEM = O_FLAT, O_W0 = O_FLAT + 2, W_WORDS = ((O_WCORNER - O_FLAT) + IB_ROWS * WAVE + 1) & ~1;
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
+  const int mine = PW ? O_W0 - O_FLAT + __builtin_amdgcn_readfirstlane(wave) * W_WORDS : 0;  // (word offset of this worker's region)
+  for (int i = threadIdx.x; i < O_TAB_END; i += (int)blockDim.x) lds[i] = P.tables[i];
   const uint32_t* const goal_rows = lds + O_GOAL;
   const uint32_t* const box_blocked = lds + O_BBLK;
   const uint32_t* const player_blocked = lds + O_PBLK;
-  uint32_t* const flat = lds + O_FLAT;
-  uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC);
-  uint32_t* const skipv = lds + O_SKIP;
+  uint32_t* const flat = lds + O_FLAT + mine;
+  uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC + mine);
+  uint32_t* const skipv = lds + O_SKIP + mine;
   uint32_t* const wcorner = lds + O_WCORNER;
+  uint32_t* const inbox = lds + O_WCORNER + mine;  // (PW only: behind the worker's skip flags)
+  if (PW && threadIdx.x == 0) lds[O_SEM] = 0;      // the streaming semaphore
+  stream::WorkQueue wq;
+  uint32_t unit = blockIdx.x;
+  bool need_wait = true;
+  // the state rows of unit `u` (and its tape actions) into the inbox
+  auto prefetch = [&](uint32_t u_any) {
+    const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u_any);
+    const int64_t e0 = (int64_t)u * WAVE;
+    const uint32_t ib = (uint32_t)__builtin_amdgcn_readfirstlane((int)stream::lds_byte_address(inbox));
+#pragma unroll
+    for (int w = 0; w < NW; ++w) stream::lds_dma_row(P.state + (int64_t)w * P.bpad + e0, 4u * lane, ib + (uint32_t)w * (4u * WAVE));
+    if (!a.hashed && e0 + lane < P.batch) stream::lds_dma_row(reinterpret_cast<const uint32_t*>(a.actions) + e0, 4u * lane, ib + (uint32_t)NW * (4u * WAVE));
+  };
+  if constexpr (PW) {
+    wq.init(P.work, wave);
+    unit = wq.first();
+    if (unit < wq.n) prefetch(unit);  // (under the staging of the tables)
+  }
   __syncthreads();
 
-  const int64_t env0 = (int64_t)blockIdx.x * WAVE;
-  if (wave == 0) {
+  for (;;) {  // (PW: this worker's units; else one round)
+  if constexpr (PW) { if (unit >= wq.n) break; }
+  const int64_t env0 = (int64_t)unit * WAVE;
+  if (wave == 0 || PW) {
     // ---- logic phase: lane == environment -------------------------------------
     const int64_t env = env0 + lane, bp = P.bpad;
     const bool live = env < P.batch;
@@ -112,9 +143,17 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
     int ld_action = PCX_ACTION_NONE;
     bool skip = !live, do_reset = false;
     int action = PCX_ACTION_NONE;
+    if constexpr (PW) {  // the unit's state rows are in the inbox (the first unit's must be waited for)
+      if (need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t* const ib = inbox + lane;
+      flags = ib[W_FLAGS * WAVE]; ld_frame = ib[W_FRAME * WAVE]; ld_sflags = ib[W_SFLAGS * WAVE];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ld_pos[s] = ib[(W_POS + s) * WAVE];
+      if (!a.hashed && live) ld_action = (int)ib[NW * WAVE];
+    }
     if (live) {  // every state word is requested up front: one memory round trip
-      flags = st[W_FLAGS * bp];
-      if (a.mode != 1) {
+      if constexpr (!PW) flags = st[W_FLAGS * bp];
+      if (!PW && a.mode != 1) {
         ld_frame = st[W_FRAME * bp];
         ld_sflags = st[W_SFLAGS * bp];
 #pragma unroll
@@ -302,8 +341,10 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
     }
     skipv[lane] = skip;
   }
-  __syncthreads();
-  if (a.debug & 2) return;
+  if constexpr (!PW) {
+    __syncthreads();
+    if (a.debug & 2) return;
+  }
 
   // ---- render phase --------------------------------------------------------------
   stream::PlaneMap<NS, 1, NB> pm;
@@ -314,13 +355,34 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_warehouse_step(const Consts 
 #pragma unroll
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  if (!(fc && fc->only))
-    stream::stream_planes<NS, 1, NB, SQW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                        flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, QW, lds + O_FLATRAW,
-                                                        reinterpret_cast<const uint2*>(lds + O_SDESCRAW), lds);
-  if (fc)
-    stream::stream_windows<NS, 1, NB, SQW, NWAVES, SR, SC>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner,
-                                                         nullptr, stream::BoardShape{R, C, QW});
+  if constexpr (PW) {
+    // the next unit is drawn and its state rows start travelling now, in front of this unit's plane stores
+    const uint32_t next = wq.next(unit);
+    if (next < wq.n) prefetch(next);
+    const bool any_skip = __ballot(skipv[lane] != 0) != 0ull;
+    if (!(a.debug & 2)) {
+      const uint32_t sem = stream::lds_byte_address(lds + O_SEM);
+      if (P.work.lock) stream::slot_acquire(sem, P.work.lock);
+      stream::stream_planes<NS, 1, NB, SQW, 1, false, false, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                                    flat, sdesc, skipv, FWP, lane, 0, epi, env0, nullptr, QW, nullptr, nullptr, lds);
+      if (P.work.lock) stream::slot_release(sem);
+    }
+    // fewer than 64 plane stores behind the prefetch (environments left alone, ablation runs): wait for it
+    need_wait = any_skip || a.debug != 0 || QW * (1 + L) < 64;
+    if (need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unit = next;
+  } else {
+    if (!(fc && fc->only))
+      stream::stream_planes<NS, 1, NB, SQW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                          flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, QW, lds + O_FLATRAW,
+                                                          reinterpret_cast<const uint2*>(lds + O_SDESCRAW), lds);
+    if (fc)
+      stream::stream_windows<NS, 1, NB, SQW, NWAVES, SR, SC>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner,
+                                                           nullptr, stream::BoardShape{R, C, QW});
+    break;
+  }
+  }  // units
+  if constexpr (PW) wq.finish(lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -342,6 +404,7 @@ class WarehouseBackend : public Backend {
     return 4 + 8 * (int64_t)NW_ + (int64_t)(1 + L_) * lay_.cells + 15;
   }
   const char* kernel_name() const override { return "pcx_warehouse_step"; }
+  int launch_shape() const override { return last_shape_; }  // 0 a workgroup per group, 10 cooperative, 3 persistent workers (include/pcx.h)
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
   int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)lay_.FW * bpad_); }
@@ -382,7 +445,8 @@ class WarehouseBackend : public Backend {
   int num_cus_ = 256;
   bool static_shape_ = false;  // a compiled instance for exactly this shape exists
   std::vector<uint8_t> goal_;  // host copy for read_things
-  DevArray<uint32_t> tables_, state_, curtains_;
+  DevArray<uint32_t> tables_, state_, curtains_, work_ctr_;
+  int last_shape_ = -1;
   DevArray<int32_t> track_;
 };
 
@@ -529,7 +593,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     int rc = curtains_.alloc((size_t)lay_.FW * bpad_);
     if (rc) return rc;
   }
-  Ptrs P{tables_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
+  Ptrs P{tables_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_, {}};
   const int64_t groups = bpad_ / WAVE;
   // Launch shape as for scrolly_maze (profiles/r01_tuning.md): single-wave
   // workgroups with LDS padded so that about four of them share a CU; four
@@ -548,6 +612,42 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   }
   bool launched = false;
   const bool epi = epi_.out != nullptr;  // the feature-array epilogue has its own instances (whole-dword boards only)
+  // (round 5) persistent workers: plain steps of the compiled shapes from four units per CU up.  One workgroup of W workers per
+  // CU, `lock` of them streaming at a time, tickets (with stealing) from 24 units per CU up; PCX_WM_PW=0: the round-2 shape.
+  bool pw = !coop && !epi && !fused_.on && !unoccluded_ && static_shape_ && a.mode == 0 && !a.export_curtains && a.debug == 0;
+  if (const char* e = getenv("PCX_WM_PW")) pw = pw && atoi(e) != 0;
+  if (pw) {
+    int workers = 6, per_cu = 1, lock = 2;
+    if (const char* e = getenv("PCX_WM_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 8) workers = v; }
+    if (const char* e = getenv("PCX_WM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
+    if (const char* e = getenv("PCX_WM_LOCK")) lock = atoi(e);
+    int dynamic = groups >= (int64_t)num_cus_ * 24;
+    if (const char* e = getenv("PCX_WM_DYNAMIC")) dynamic = atoi(e) != 0;
+    const size_t tab_words = (size_t)lay_.QW * (1 + NB_) + 3 * R_;
+    const size_t o_sdesc = (tab_words + (size_t)WAVE * lay_.FWP + 1) & ~(size_t)1;
+    const size_t region = o_sdesc + 2 * NS_ * WAVE + WAVE - tab_words;  // flat, sdesc, skip: the kernel's O_WCORNER - O_FLAT
+    const size_t w_words = (region + (size_t)(W_POS + NS_ + 1) * WAVE + 1) & ~(size_t)1;
+    size_t lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4;
+    while (workers > 1 && lds_pw > 64 * 1024) { --workers; lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4; }
+    int64_t wgs = (int64_t)num_cus_ * per_cu;
+    const int64_t want = (groups + workers - 1) / workers;
+    if (wgs > want) wgs = want;
+    if (wgs * workers >= groups) dynamic = 0;  // every unit is some worker's first
+    if (!work_ctr_.ptr) { int rc = work_ctr_.alloc(16 * 9); if (rc) return rc; }
+    P.work.ctr = work_ctr_.ptr;
+    P.work.n_units = (uint32_t)groups;
+    P.work.dynamic = dynamic;
+    P.work.lock = lock;
+#define X(ns, r, c, nb)                                                                                     \
+  if (!launched && NS_ == ns && R_ == r && C_ == c && NB_ == nb) {                                          \
+    hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, 1, false, false, true>), dim3((unsigned)wgs), dim3(workers * WAVE), lds_pw, s, k_, P, a, out, epi_, fused_.ptr()); \
+    launched = true;                                                                                        \
+  }
+    PCX_WM_SHAPES(X)
+#undef X
+    last_shape_ = launched ? 3 : last_shape_;
+  }
+  if (!launched) last_shape_ = coop ? 10 : 0;
 #define PCX_WM_LAUNCH(ns, r, c, nb, nw, ep)                                                                  \
   hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, nw, ep>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr())
 #define X(ns, r, c, nb)                                                                                     \

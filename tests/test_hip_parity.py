@@ -104,27 +104,6 @@ def test_hip_matches_oracle_single_wave_launch_shape(name, monkeypatch):
     assert_same(hip, orc, 'after step %d' % (t0 + 16))
 
 
-def test_hip_two_wave_pipeline_shape_matches_oracle(monkeypatch):
-  """PCX_WAVES_PER_WG=2: persistent two-wave workgroups, wave 0 steps group
-  i + 1 while wave 1 renders group i (an opt-in launch shape)."""
-  monkeypatch.setenv('PCX_WAVES_PER_WG', '2')
-  monkeypatch.setenv('PCX_WGS_PER_CU', '1')  # fewer workgroups than groups: every workgroup loops
-  t = helpers.load_template('scrolly_maze_L2')
-  B = 64 * 700 + 5
-  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
-  hip.reset(); orc.reset()
-  from pycolab_amd import _native as N
-  for t0 in range(0, 12):  # one step per launch: the pipeline shape itself (launches of several steps take the cooperative shape)
-    hip.step_hashed(0xBEE, t0, 1); orc.step_hashed(0xBEE, t0, 1)
-    assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 4
-    if t0 % 4 == 3:
-      assert_same(hip, orc, 'after step %d' % (t0 + 1))
-  for t0 in range(12, 48, 12):
-    hip.step_hashed(0xBEE, t0, 12); orc.step_hashed(0xBEE, t0, 12)
-    assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 12
-    assert_same(hip, orc, 'after step %d' % (t0 + 12))
-
-
 @pytest.mark.parametrize('build', helpers.BUILDS)
 @pytest.mark.parametrize('waves', ['1', '2', '4'])
 @pytest.mark.parametrize('name', ['marauders', 'warehouse_L2', 'walkers_scroll_groups', 'directives_z_order', 'hello_world',
@@ -255,16 +234,13 @@ def test_hip_step_n_fused_and_unfused_match_oracle(fuse, monkeypatch):
   assert_same(hip, orc, 'after the tape')
 
 
-@pytest.mark.parametrize('old_tfuse', ['0', '1'])
 @pytest.mark.parametrize('name,B', [('scrolly_maze_L0', 250), ('scrolly_maze_L0', 4096), ('scrolly_maze_L0', 16384 + 7),
                                     ('scrolly_maze_L1', 3000), ('scrolly_maze_L2', 2000)])
-def test_hip_several_steps_per_launch_in_the_cooperative_shape(name, B, old_tfuse, monkeypatch):
+def test_hip_several_steps_per_launch_in_the_cooperative_shape(name, B):
   """Round 4: a launch of several steps (pcx_engine_step_n / _step_hashed at small batches) is the cooperative
   instance walking the steps with the state words in registers -- 16, 32 or 64 environments per workgroup, four lanes
   per environment at the small end, six coin words (level 2: the words past the fourth stay in LDS) -- against the
-  oracle: odd chunk lengths, chunks that leave finished environments frozen, explicit tapes with quirky actions.
-  PCX_TFUSE_OLD=1 is round 1's multi-step instance, kept for A/B runs."""
-  monkeypatch.setenv('PCX_TFUSE_OLD', old_tfuse)
+  oracle: odd chunk lengths, chunks that leave finished environments frozen, explicit tapes with quirky actions."""
   from pycolab_amd import _native as N
   t = helpers.load_template(name)
   hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
@@ -274,7 +250,7 @@ def test_hip_several_steps_per_launch_in_the_cooperative_shape(name, B, old_tfus
     auto = i % 3 != 2
     hip.step_hashed(0xABCD, t0, n, auto_reset=auto); orc.step_hashed(0xABCD, t0, n, auto_reset=auto)
     if n > 1:
-      assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == (11 if old_tfuse == '1' else 12)
+      assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 12
     t0 += n
     assert_same(hip, orc, '%s x %d after %d steps (chunk %d)' % (name, B, t0, n))
   rng = np.random.RandomState(11)

@@ -63,11 +63,10 @@ def shape_of(hip):
   return 3 if s == 5 else s
 
 
-@pytest.mark.parametrize('shape,codes,waves,lock,grid,dynamic', [(3, 0, 4, 1, 2, 1), (3, 0, 3, 2, 3, 0), (3, 0, 12, 3, 1, 1), (1, 0, 1, 0, 5, 1),
+@pytest.mark.parametrize('shape,codes,waves,lock,grid,dynamic', [(3, 1, 4, 1, 2, 1), (3, 1, 3, 2, 3, 0), (3, 1, 10, 3, 1, 1), (3, 1, 1, 0, 5, 1),
                                                           (3, 1, 6, 2, 1, 1), (3, 1, 2, 0, 3, 0)])
 def test_persistent_workers_with_streaming_semaphore_match_oracle(shape, codes, waves, lock, grid, dynamic):
-  """Shape 3 (and shape 1) on both render paths -- owner codes and curtain masks -- with `waves` workers per workgroup of
-  which at most `lock` stream at a time (0: no limit)."""
+  """`waves` workers per workgroup of which at most `lock` stream at a time (0: no limit)."""
   t = helpers.load_template('scrolly_maze_L0')
   B, T = 2999, 120
   with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=shape, PCX_SM_CODES=codes, PCX_SM_WAVES=waves, PCX_SM_LOCK=lock, PCX_SM_GRID=grid,
@@ -84,8 +83,7 @@ def test_persistent_workers_with_streaming_semaphore_match_oracle(shape, codes, 
 
 
 @pytest.mark.parametrize('shape,unit,dynamic,grid,waves', [
-    (1, 64, 1, 5, 1), (1, 64, 0, 5, 1), (1, 32, 1, 7, 1), (1, 16, 1, 3, 1), (1, 64, 1, 1, 1), (1, 64, 1, 4096, 1),
-    (2, 64, 1, 5, 2), (2, 64, 0, 5, 2), (2, 32, 1, 7, 2), (2, 16, 1, 3, 2), (2, 64, 1, 1, 2), (2, 64, 1, 4096, 2),
+    (3, 64, 1, 5, 1), (3, 64, 0, 5, 1), (3, 32, 1, 7, 1), (3, 16, 1, 3, 1), (3, 64, 1, 4096, 1),
     (3, 64, 1, 5, 2), (3, 64, 0, 5, 2), (3, 32, 1, 3, 4), (3, 16, 1, 2, 6), (3, 64, 1, 1, 2), (3, 64, 1, 4096, 2), (3, 64, 1, 2, 1),
 ])
 def test_persistent_shapes_match_oracle(shape, unit, dynamic, grid, waves):
@@ -106,7 +104,7 @@ def test_persistent_shapes_match_oracle(shape, unit, dynamic, grid, waves):
     assert int(orc.read('frame').min()) < T  # episodes ended and restarted inside the run
 
 
-@pytest.mark.parametrize('shape,tail,small', [(3, 2, 16), (3, 3, 8), (1, 1, 32), (2, 2, 16)])
+@pytest.mark.parametrize('shape,tail,small', [(3, 2, 16), (3, 3, 8), (3, 1, 32)])
 def test_small_units_at_the_end_of_the_batch(shape, tail, small):
   """With tickets the batch's last environments go in small units (so that what the workers hold when the tickets run out
   is short): 20,000 environments on four workgroups -- a few dozen 64-environment units, then units of `small`."""
@@ -121,10 +119,10 @@ def test_small_units_at_the_end_of_the_batch(shape, tail, small):
       assert_same(hip, orc, 'shape %d tail %d x %d after step %d' % (shape, tail, small, t0 + 8))
 
 
-@pytest.mark.parametrize('shape', [1, 2, 3])
+@pytest.mark.parametrize('shape', [3])
 def test_persistent_shapes_tape_actions_and_environments_left_alone(shape):
   """Action tapes from the host (illegal and quit actions among them), and steps without auto-reset: finished
-  environments are skipped (their units stream fewer planes: the wait-for-the-prefetch path of shape 1)."""
+  environments are skipped (their units stream fewer planes: the wait-for-the-prefetch path)."""
   t = helpers.load_template('scrolly_maze_L1')
   B, T = 1500, 120
   rng = np.random.RandomState(7)
@@ -143,7 +141,7 @@ def test_persistent_shapes_tape_actions_and_environments_left_alone(shape):
       assert_same(hip, orc, 'shape %d step %d' % (shape, step))
 
 
-@pytest.mark.parametrize('shape,unit', [(1, 64), (2, 64), (2, 32), (3, 64), (3, 32)])
+@pytest.mark.parametrize('shape,unit', [(3, 64), (3, 32)])
 def test_persistent_shapes_at_config_5_shard_size(shape, unit):
   """131,072 environments (BASELINE config 5's per-GPU shard) at the default residency: the first and the last
   2,048 environments against the oracle, layer == (board == c) over the whole batch, and everything equal to what
@@ -246,3 +244,22 @@ def test_headline_batch_default_shape_equals_one_workgroup_per_group_shape_every
     for name in ('reward', 'reward_set', 'discount', 'done', 'frame'):
       np.testing.assert_array_equal(hip.eng.buffers[name].tensor[off:off + K].cpu().numpy(), orc.read(name), err_msg=name)
   assert not hip.eng.buffers['error'].tensor.any()
+
+
+@pytest.mark.parametrize('baked', [1, 0])
+@pytest.mark.parametrize('B', [250, 4096, 16391])
+def test_cooperative_shape_with_the_levels_constants_compiled_in(B, baked):
+  """Small batches (BASELINE config 2): the cooperative instance also exists with the shipped level's constants compiled in
+  (PCX_SM_BAKED=0: the instance that reads them from the kernel arguments); single launches and launches of several steps,
+  16 / 32 / 64 environments per workgroup, against the oracle."""
+  t = helpers.load_template('scrolly_maze_L0')
+  with Knobs(PCX_SM_BAKED=baked):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    t0 = 0
+    for n in (1, 1, 1, 7, 64, 3, 1, 120):
+      hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
+      assert raw_shape_of(hip) == (12 if n > 1 else 10)
+      t0 += n
+      assert_same(hip, orc, 'B %d baked %d after step %d' % (B, baked, t0))
+    assert int(orc.read('frame').min()) < t0

@@ -14,8 +14,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KNOBS = ('PCX_SM_STEAL', 'PCX_SM_BAKED', 'PCX_SM_TAIL', 'PCX_SM_TAIL_UNIT', 'PCX_DEBUG', 'PCX_SM_WAVES', 'PCX_SM_LOCK', 'PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_PER_CU', 'PCX_WAVES_PER_CU', 'PCX_WAVES_PER_WG',
-         'PCX_WGS_PER_CU', 'PCX_SM_CODES', 'PCX_SM_PRIO', 'PCX_SM_NB', 'PCX_SM_GRID')
+KNOBS = ('PCX_SM_STEAL', 'PCX_SM_BAKED', 'PCX_SM_TAIL', 'PCX_SM_TAIL_UNIT', 'PCX_DEBUG', 'PCX_SM_WAVES', 'PCX_SM_LOCK', 'PCX_SM_SHAPE', 'PCX_SM_UNIT', 'PCX_SM_DYNAMIC', 'PCX_SM_PER_CU', 'PCX_WAVES_PER_CU',
+         'PCX_SM_CODES', 'PCX_SM_GRID')
 
 VARIANTS = {
     'auto':        {},
@@ -30,32 +30,12 @@ VARIANTS = {
     'auto_static': {'PCX_SM_DYNAMIC': 0},
     'head':        {'PCX_SM_SHAPE': 0},
     'head_w7':     {'PCX_SM_SHAPE': 0, 'PCX_WAVES_PER_CU': 7},
-    'A':           {'PCX_SM_SHAPE': 1},
-    'A_static':    {'PCX_SM_SHAPE': 1, 'PCX_SM_DYNAMIC': 0},
-    'A_cu6':       {'PCX_SM_SHAPE': 1, 'PCX_SM_PER_CU': 6},
-    'A_cu7':       {'PCX_SM_SHAPE': 1, 'PCX_SM_PER_CU': 7},
-    'A_cu10':      {'PCX_SM_SHAPE': 1, 'PCX_SM_PER_CU': 10},
-    'A_u32':       {'PCX_SM_SHAPE': 1, 'PCX_SM_UNIT': 32},
     'C':           {'PCX_SM_SHAPE': 3},
     'C_nolock':    {'PCX_SM_SHAPE': 3, 'PCX_SM_LOCK': 0},
     'C_static':    {'PCX_SM_SHAPE': 3, 'PCX_SM_DYNAMIC': 0},
     'C_cu2':       {'PCX_SM_SHAPE': 3, 'PCX_SM_PER_CU': 2},
-    'M_w4x3_k1':   {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 4, 'PCX_SM_PER_CU': 3, 'PCX_SM_LOCK': 1},
-    'M_w4x3_k2':   {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 4, 'PCX_SM_PER_CU': 3, 'PCX_SM_LOCK': 2},
-    'M_w3x3_k1':   {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 3, 'PCX_SM_PER_CU': 3, 'PCX_SM_LOCK': 1},
-    'M_w3x4_k1':   {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 3, 'PCX_SM_PER_CU': 4, 'PCX_SM_LOCK': 1},
-    'M_w6x2_k2':   {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 6, 'PCX_SM_PER_CU': 2, 'PCX_SM_LOCK': 2},
-    'M_w6x2_k1':   {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 6, 'PCX_SM_PER_CU': 2, 'PCX_SM_LOCK': 1},
-    'M_w12x1_k3':  {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 12, 'PCX_SM_PER_CU': 1, 'PCX_SM_LOCK': 3},
-    'M_w12x1_k4':  {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 12, 'PCX_SM_PER_CU': 1, 'PCX_SM_LOCK': 4},
-    'M_w12x1_k0':  {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 12, 'PCX_SM_PER_CU': 1, 'PCX_SM_LOCK': 0},
-    'M_w2x4_k1':   {'PCX_SM_SHAPE': 3, 'PCX_SM_CODES': 0, 'PCX_SM_WAVES': 2, 'PCX_SM_PER_CU': 4, 'PCX_SM_LOCK': 1},
-    'M1_cu8':      {'PCX_SM_SHAPE': 1, 'PCX_SM_CODES': 0, 'PCX_SM_PER_CU': 8},
-    'M1_cu12':     {'PCX_SM_SHAPE': 1, 'PCX_SM_CODES': 0, 'PCX_SM_PER_CU': 12},
-    'head_mask':   {'PCX_SM_SHAPE': 0, 'PCX_SM_CODES': 0},
     'C_w6x1_k3':   {'PCX_SM_SHAPE': 3, 'PCX_SM_WAVES': 6, 'PCX_SM_PER_CU': 1, 'PCX_SM_LOCK': 3},
     'C_w6x1_k2':   {'PCX_SM_SHAPE': 3, 'PCX_SM_WAVES': 6, 'PCX_SM_PER_CU': 1, 'PCX_SM_LOCK': 2},
-    'C_prio':      {'PCX_SM_SHAPE': 3, 'PCX_SM_PRIO': 1},
     'C2x3s':       {'PCX_SM_SHAPE': 3, 'PCX_SM_WAVES': 2, 'PCX_SM_PER_CU': 3, 'PCX_SM_LOCK': 1, 'PCX_SM_DYNAMIC': 0},
     'C2x4s':       {'PCX_SM_SHAPE': 3, 'PCX_SM_WAVES': 2, 'PCX_SM_PER_CU': 4, 'PCX_SM_LOCK': 1, 'PCX_SM_DYNAMIC': 0},
     'C4x2_k2s':    {'PCX_SM_SHAPE': 3, 'PCX_SM_WAVES': 4, 'PCX_SM_PER_CU': 2, 'PCX_SM_LOCK': 2, 'PCX_SM_DYNAMIC': 0},
@@ -72,24 +52,12 @@ VARIANTS = {
     'C5x2_k2':     {'PCX_SM_SHAPE': 3, 'PCX_SM_WAVES': 5, 'PCX_SM_PER_CU': 2, 'PCX_SM_LOCK': 2},
     'C10x1_k3':    {'PCX_SM_SHAPE': 3, 'PCX_SM_WAVES': 10, 'PCX_SM_PER_CU': 1, 'PCX_SM_LOCK': 3},
     'C10x1_k4':    {'PCX_SM_SHAPE': 3, 'PCX_SM_WAVES': 10, 'PCX_SM_PER_CU': 1, 'PCX_SM_LOCK': 4},
-    'A8s':         {'PCX_SM_SHAPE': 1, 'PCX_SM_PER_CU': 8, 'PCX_SM_DYNAMIC': 0},
-    'A10s':        {'PCX_SM_SHAPE': 1, 'PCX_SM_PER_CU': 10, 'PCX_SM_DYNAMIC': 0},
     'Cs':          {'PCX_SM_SHAPE': 3, 'PCX_SM_DYNAMIC': 0},
     'Cs_nolock':   {'PCX_SM_SHAPE': 3, 'PCX_SM_DYNAMIC': 0, 'PCX_SM_LOCK': 0},
     'Cs_w3':       {'PCX_SM_SHAPE': 3, 'PCX_SM_DYNAMIC': 0, 'PCX_SM_WAVES': 3, 'PCX_SM_PER_CU': 2},
     'Cs_w4':       {'PCX_SM_SHAPE': 3, 'PCX_SM_DYNAMIC': 0, 'PCX_SM_WAVES': 4, 'PCX_SM_PER_CU': 1},
     'Cs_w6':       {'PCX_SM_SHAPE': 3, 'PCX_SM_DYNAMIC': 0, 'PCX_SM_WAVES': 6, 'PCX_SM_PER_CU': 1},
     'Cs_w1_cu6':   {'PCX_SM_SHAPE': 3, 'PCX_SM_DYNAMIC': 0, 'PCX_SM_WAVES': 1, 'PCX_SM_PER_CU': 6},
-    'B':           {'PCX_SM_SHAPE': 2},
-    'B_cu2':       {'PCX_SM_SHAPE': 2, 'PCX_SM_PER_CU': 2},
-    'B_static':    {'PCX_SM_SHAPE': 2, 'PCX_SM_DYNAMIC': 0},
-    'B_prio':      {'PCX_SM_SHAPE': 2, 'PCX_SM_PRIO': 1},
-    'B_u32':       {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32},
-    'B_u32_cu4':   {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32, 'PCX_SM_PER_CU': 4},
-    'B_u32_cu5':   {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32, 'PCX_SM_PER_CU': 5},
-    'B_u32_nb4':   {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32, 'PCX_SM_NB': 4},
-    'B_u32_nb3_cu4': {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 32, 'PCX_SM_NB': 3, 'PCX_SM_PER_CU': 4},
-    'B_u16_cu6':   {'PCX_SM_SHAPE': 2, 'PCX_SM_UNIT': 16, 'PCX_SM_PER_CU': 6},
 }
 
 
