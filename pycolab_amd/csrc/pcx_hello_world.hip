@@ -42,6 +42,7 @@ struct Ptrs {
   int32_t* track;                // [NS][bpad]
   uint32_t* curtains;            // [1][FW][bpad] (export_curtains)
   int64_t batch, bpad;
+  stream::WorkArgs work;         // PW instances: the persistent workers' scheduler (pcx_stream.h)
 };
 
 __device__ __forceinline__ uint32_t action_hash(uint64_t seed, uint64_t env, uint64_t t) {
@@ -86,8 +87,11 @@ struct Bits {
   }
 };
 
-template <int R, int C, int NWAVES, bool EPI = false, bool UNOCC = false>
-__global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Consts k, const Ptrs P, const StepArgs a,
+// PW (round 5): persistent workers, as in pcx_warehouse_step -- the workgroup stays on its CU, each of its waves draws units
+// of 64 environments, steps one and streams it alone, the next unit's state rows prefetched into its LDS inbox by LDS-DMA,
+// at most `work.lock` workers of a workgroup streaming at a time (pcx_stream.h).  Plain steps only.
+template <int R, int C, int NWAVES, bool EPI = false, bool UNOCC = false, bool PW = false>
+__global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_hello_world_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                       const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                       const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
@@ -98,16 +102,41 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
   constexpr int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
   constexpr int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   constexpr int O_FLATRAW = O_WCORNER + stream::WCORNER_WORDS, O_SDESCRAW = (O_FLATRAW + WAVE * FWP + 1) & ~1;  // UNOCC only
+  static_assert(!PW || (NWAVES == 1 && !EPI && !UNOCC), "persistent workers: plain steps");
+  // PW: a worker's own LDS region {flat, sdesc, skip, inbox}; the inbox holds the unit's state rows and its tape actions
+  constexpr int NWORDS = W_D + FW, IB_ROWS = NWORDS + 1;
+  constexpr int O_SEM = O_FLAT, O_W0 = O_FLAT + 2, W_WORDS = ((O_WCORNER - O_FLAT) + IB_ROWS * WAVE + 1) & ~1;
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < O_TAB_END; i += NWAVES * WAVE) lds[i] = P.tables[i];
-  uint32_t* const flat = lds + O_FLAT;
-  uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC);
-  uint32_t* const skipv = lds + O_SKIP;
+  const int mine = PW ? O_W0 - O_FLAT + __builtin_amdgcn_readfirstlane(wave) * W_WORDS : 0;  // (word offset of this worker's region)
+  for (int i = threadIdx.x; i < O_TAB_END; i += (int)blockDim.x) lds[i] = P.tables[i];
+  uint32_t* const flat = lds + O_FLAT + mine;
+  uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC + mine);
+  uint32_t* const skipv = lds + O_SKIP + mine;
   uint32_t* const wcorner = lds + O_WCORNER;
+  uint32_t* const inbox = lds + O_WCORNER + mine;  // (PW only: behind the worker's skip flags)
+  if (PW && threadIdx.x == 0) lds[O_SEM] = 0;      // the streaming semaphore
+  stream::WorkQueue wq;
+  uint32_t unit = blockIdx.x;
+  bool need_wait = true;
+  auto prefetch = [&](uint32_t u_any) {  // the state rows of unit `u` (and its tape actions) into the inbox
+    const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u_any);
+    const int64_t e0 = (int64_t)u * WAVE;
+    const uint32_t ib = (uint32_t)__builtin_amdgcn_readfirstlane((int)stream::lds_byte_address(inbox));
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) stream::lds_dma_row(P.state + (int64_t)w * P.bpad + e0, 4u * lane, ib + (uint32_t)w * (4u * WAVE));
+    if (!a.hashed && e0 + lane < P.batch) stream::lds_dma_row(reinterpret_cast<const uint32_t*>(a.actions) + e0, 4u * lane, ib + (uint32_t)NWORDS * (4u * WAVE));
+  };
+  if constexpr (PW) {
+    wq.init(P.work, wave);
+    unit = wq.first();
+    if (unit < wq.n) prefetch(unit);  // (under the staging of the tables)
+  }
   __syncthreads();
 
-  const int64_t env0 = (int64_t)blockIdx.x * WAVE;
-  if (wave == 0) {
+  for (;;) {  // (PW: this worker's units; else one round)
+  if constexpr (PW) { if (unit >= wq.n) break; }
+  const int64_t env0 = (int64_t)unit * WAVE;
+  if (wave == 0 || PW) {
     const int64_t env = env0 + lane, bp = P.bpad;
     const bool live = env < P.batch;
     uint32_t* const st = P.state + env;
@@ -117,9 +146,19 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
     int action = PCX_ACTION_NONE;
 #pragma unroll
     for (int i = 0; i < FW; ++i) x[i] = 0;
+    if constexpr (PW) {  // the unit's state rows are in the inbox (the first unit's must be waited for)
+      if (need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t* const ib = inbox + lane;
+      flags = ib[W_FLAGS * WAVE]; ld_frame = ib[W_FRAME * WAVE];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ld_pos[s] = ib[(W_POS + s) * WAVE];
+#pragma unroll
+      for (int i = 0; i < FW; ++i) x[i] = ib[(W_D + i) * WAVE];
+      if (!a.hashed && live) ld_action = (int)ib[NWORDS * WAVE];
+    }
     if (live) {  // every state word is requested up front: one memory round trip
-      flags = st[W_FLAGS * bp];
-      if (a.mode != 1) {
+      if constexpr (!PW) flags = st[W_FLAGS * bp];
+      if (!PW && a.mode != 1) {
         ld_frame = st[W_FRAME * bp];
 #pragma unroll
         for (int s = 0; s < NS; ++s) ld_pos[s] = st[(W_POS + s) * bp];
@@ -240,8 +279,10 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
     }
     skipv[lane] = skip;
   }
-  __syncthreads();
-  if (a.debug & 2) return;
+  if constexpr (!PW) {
+    __syncthreads();
+    if (a.debug & 2) return;
+  }
 
   stream::PlaneMap<NS, ND, NB> pm;
 #pragma unroll
@@ -251,12 +292,32 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_hello_world_step(const Const
 #pragma unroll
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  if (!(fc && fc->only))
-    stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                               flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, 0, lds + O_FLATRAW,
-                                                               reinterpret_cast<const uint2*>(lds + O_SDESCRAW), lds);
-  if (fc)
-    stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
+  if constexpr (PW) {
+    // the next unit is drawn and its state rows start travelling now, in front of this unit's plane stores
+    const uint32_t next = wq.next(unit);
+    if (next < wq.n) prefetch(next);
+    const bool any_skip = __ballot(skipv[lane] != 0) != 0ull;
+    if (!(a.debug & 2)) {
+      const uint32_t sem = stream::lds_byte_address(lds + O_SEM);
+      if (P.work.lock) stream::slot_acquire(sem, P.work.lock);
+      stream::stream_planes<NS, ND, NB, QW, 1, false, false, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                                    flat, sdesc, skipv, FWP, lane, 0, epi, env0, nullptr, 0, nullptr, nullptr, lds);
+      if (P.work.lock) stream::slot_release(sem);
+    }
+    need_wait = any_skip || a.debug != 0 || QW * (1 + L) < 64;  // fewer than 64 plane stores behind the prefetch: wait for it
+    if (need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unit = next;
+  } else {
+    if (!(fc && fc->only))
+      stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                                 flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, 0, lds + O_FLATRAW,
+                                                                 reinterpret_cast<const uint2*>(lds + O_SDESCRAW), lds);
+    if (fc)
+      stream::stream_windows<NS, ND, NB, QW, NWAVES, R, C>(fc, pm, bch4, env0, lds + O_BD, flat, sdesc, skipv, FWP, lane, wave, wcorner);
+    break;
+  }
+  }  // units
+  if constexpr (PW) wq.finish(lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -272,6 +333,7 @@ class HelloWorldBackend : public Backend {
   int read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) override;
   int64_t bytes_per_step() const override { return 4 + 8 * (int64_t)NW_ + (int64_t)(1 + L_) * lay_.cells + 15; }
   const char* kernel_name() const override { return "pcx_hello_world_step"; }
+  int launch_shape() const override { return last_shape_; }  // 0 a workgroup per group, 10 cooperative, 3 persistent workers (include/pcx.h)
   const int32_t* sprite_track() const override { return track_.ptr; }
   const uint32_t* curtain_bits() const override { return curtains_.ptr; }
   int ensure_curtains() override { return curtains_.ptr ? 0 : curtains_.alloc((size_t)lay_.FW * bpad_); }
@@ -312,7 +374,8 @@ class HelloWorldBackend : public Backend {
   bool unoccluded_ = false;  // Engine(..., occlusion_in_layers=False)
   int64_t batch_ = 0, bpad_ = 0;
   int num_cus_ = 256;
-  DevArray<uint32_t> tables_, initc_, state_, curtains_;
+  DevArray<uint32_t> tables_, initc_, state_, curtains_, work_ctr_;
+  int last_shape_ = -1;
   DevArray<int32_t> track_;
 };
 
@@ -404,7 +467,7 @@ int HelloWorldBackend::init(const pcx_template& t, int64_t batch) {
 int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) {
   if (a.n_steps != 1) return set_error(PCX_E_INVALID, "hello_world backend: one step per launch");
   if (a.export_curtains) { int rc = ensure_curtains(); if (rc) return rc; }
-  Ptrs P{tables_.ptr, initc_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_};
+  Ptrs P{tables_.ptr, initc_.ptr, state_.ptr, track_.ptr, curtains_.ptr, batch_, bpad_, {}};
   const int64_t groups = bpad_ / WAVE;
   int coop_below = 5, waves_per_cu = 6;
   if (fused_.only) coop_below = 17;  // windows only: little to stream per group, latency-bound (see pcx_better_scrolly.hip)
@@ -419,6 +482,42 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
     if (want > lds) lds = want;
   }
   bool launched = false;
+  // (round 5) persistent workers for plain steps, as in pcx_warehouse.hip (PCX_HW_PW=0: the round-2 shape)
+  bool pw = !coop && !epi_.out && !fused_.on && !unoccluded_ && a.mode == 0 && !a.export_curtains && a.debug == 0;
+  if (const char* e = getenv("PCX_HW_PW")) pw = pw && atoi(e) != 0;
+  if (pw) {
+    const bool many = groups >= (int64_t)num_cus_ * 32;
+    int workers = many ? 1 : 8, per_cu = many ? 4 : 1, lock = many ? 0 : 4;
+    if (const char* e = getenv("PCX_HW_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 8) workers = v; }
+    if (const char* e = getenv("PCX_HW_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
+    if (const char* e = getenv("PCX_HW_LOCK")) lock = atoi(e);
+    int dynamic = groups >= (int64_t)num_cus_ * 24;
+    if (const char* e = getenv("PCX_HW_DYNAMIC")) dynamic = atoi(e) != 0;
+    const size_t tab_words = (size_t)lay_.QW * (1 + NB);
+    const size_t o_sdesc = (tab_words + (size_t)WAVE * lay_.FWP + 1) & ~(size_t)1;
+    const size_t region = o_sdesc + 2 * NS * WAVE + WAVE - tab_words;  // flat, sdesc, skip: the kernel's O_WCORNER - O_FLAT
+    const size_t w_words = (region + (size_t)(NW_ + 1) * WAVE + 1) & ~(size_t)1;
+    size_t lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4;
+    while (workers > 1 && lds_pw > 64 * 1024) { --workers; lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4; }
+    int64_t wgs = (int64_t)num_cus_ * per_cu;
+    if (const char* e = getenv("PCX_HW_GRID")) { const int v = atoi(e); if (v >= 1) wgs = v; }  // (tests: few workgroups, many units each)
+    const int64_t want = (groups + workers - 1) / workers;
+    if (wgs > want) wgs = want;
+    if (wgs * workers >= groups) dynamic = 0;  // every unit is some worker's first
+    if (!work_ctr_.ptr) { int rc = work_ctr_.alloc(16 * 9); if (rc) return rc; }
+    P.work.ctr = work_ctr_.ptr;
+    P.work.n_units = (uint32_t)groups;
+    P.work.dynamic = dynamic;
+    P.work.lock = lock;
+#define X(r, c)                                                                                                  \
+  if (!launched && R_ == r && C_ == c) {                                                                         \
+    hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, false, false, true>), dim3((unsigned)wgs), dim3(workers * WAVE), lds_pw, s, k_, P, a, out, epi_, fused_.ptr()); \
+    launched = true;                                                                                             \
+  }
+    PCX_HW_SHAPES(X)
+#undef X
+  }
+  last_shape_ = launched ? 3 : coop ? 10 : 0;
 #define X(r, c)                                                                                                  \
   if (!launched && R_ == r && C_ == c) {                                                                         \
     if (unoccluded_ && coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4, false, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \

@@ -617,7 +617,13 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   bool pw = !coop && !epi && !fused_.on && !unoccluded_ && static_shape_ && a.mode == 0 && !a.export_curtains && a.debug == 0;
   if (const char* e = getenv("PCX_WM_PW")) pw = pw && atoi(e) != 0;
   if (pw) {
-    int workers = 6, per_cu = 1, lock = 2;
+    // Measured (profiles/r05_warehouse_workers_sweep.txt; the round-2 shape: 0.0824 / 0.3203 ms at 262,144 / 1,048,576
+    // environments, same box): this kernel's render loop composes every dword from masks -- one streaming wave moves a unit at
+    // half the CU's rate (one slot: 0.167 ms), so four stream at a time: ONE workgroup of eight workers with four slots
+    // 0.0712 / 0.3128; from 32 units per CU up four single-worker workgroups per CU (the round-2 residency, persistent,
+    // state prefetched) 0.0775 / 0.2981.
+    const bool many = groups >= (int64_t)num_cus_ * 32;
+    int workers = many ? 1 : 8, per_cu = many ? 4 : 1, lock = many ? 0 : 4;
     if (const char* e = getenv("PCX_WM_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 8) workers = v; }
     if (const char* e = getenv("PCX_WM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     if (const char* e = getenv("PCX_WM_LOCK")) lock = atoi(e);
@@ -630,6 +636,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     size_t lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4;
     while (workers > 1 && lds_pw > 64 * 1024) { --workers; lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4; }
     int64_t wgs = (int64_t)num_cus_ * per_cu;
+    if (const char* e = getenv("PCX_WM_GRID")) { const int v = atoi(e); if (v >= 1) wgs = v; }  // (tests: few workgroups, many units each)
     const int64_t want = (groups + workers - 1) / workers;
     if (wgs > want) wgs = want;
     if (wgs * workers >= groups) dynamic = 0;  // every unit is some worker's first

@@ -263,3 +263,87 @@ def test_cooperative_shape_with_the_levels_constants_compiled_in(B, baked):
       t0 += n
       assert_same(hip, orc, 'B %d baked %d after step %d' % (B, baked, t0))
     assert int(orc.read('frame').min()) < t0
+
+
+# ---- the kernels built on pcx_stream.h: persistent workers (round 5) ------------------------------------------------------
+
+STREAM_KERNELS = [('PCX_WM_', 'warehouse_L0', 5), ('PCX_WM_', 'warehouse_L1', 5), ('PCX_WM_', 'warehouse_L2', 5), ('PCX_WM_', 'warehouse_custom_A', 5),
+                  ('PCX_WM_', 'warehouse_custom_B', 5), ('PCX_HW_', 'hello_world', 4), ('PCX_HW_', 'hello_custom_A', 4)]
+
+
+@pytest.mark.parametrize('prefix,name,n_ordinary', STREAM_KERNELS)
+@pytest.mark.parametrize('workers,lock,dynamic,grid', [(8, 4, 0, 1), (3, 1, 1, 2), (1, 0, 0, 4), (4, 2, 1, 3)])
+def test_stream_kernels_persistent_workers_match_oracle(prefix, name, n_ordinary, workers, lock, dynamic, grid):
+  """pcx_warehouse_step / pcx_hello_world_step with persistent workers (launch shape 3) against the oracle: a ragged batch
+  that every worker walks several units of (a handful of workgroups: PCX_xx_GRID), hashed actions and host tapes with
+  quirky actions, steps without auto-reset."""
+  from pycolab_amd import _native as N
+  t = helpers.load_template(name)
+  B, T = 64 * 37 + 13, 64
+  rng = np.random.RandomState(5)
+  with Knobs(**{'PCX_COOP_BELOW': 0, prefix + 'WORKERS': workers, prefix + 'LOCK': lock, prefix + 'DYNAMIC': dynamic, prefix + 'GRID': grid}):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    assert_same(hip, orc, 'frame 0')
+    t0 = 0
+    while t0 < T:
+      n = 1 if t0 < 8 else 8
+      hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
+      assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 3
+      t0 += n
+      assert_same(hip, orc, '%s workers %d lock %d after step %d' % (name, workers, lock, t0))
+    for step in range(12):
+      a = rng.randint(0, n_ordinary, size=B).astype(np.int32)
+      r = rng.rand(B)
+      a[r < 0.04] = -1
+      a[(r >= 0.04) & (r < 0.06)] = n_ordinary
+      a[(r >= 0.06) & (r < 0.08)] = rng.randint(n_ordinary + 1, 40)
+      auto = step % 3 != 0
+      hip.step(a, auto_reset=auto); orc.step(a, auto_reset=auto)
+      assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 3
+      assert_same(hip, orc, '%s tape step %d' % (name, step))
+
+
+@pytest.mark.parametrize('prefix,name,B', [('PCX_HW_', 'hello_world', 262144)])
+def test_stream_kernels_persistent_workers_equal_the_round_2_shape(prefix, name, B):
+  import torch
+  from pycolab_amd import _native as N
+  t = helpers.load_template(name)
+  T = 32
+  hip = HipAdapter(t, B)
+  hip.reset(); hip.step_hashed(0xC0FFEE, 0, T)
+  assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 3
+  with Knobs(**{prefix + 'PW': 0}):
+    ref = HipAdapter(t, B)
+    ref.reset(); ref.step_hashed(0xC0FFEE, 0, T)
+    assert int(N.lib().pcx_engine_launch_shape(ref.eng._native)) == 0
+  assert torch.equal(hip.eng.planes_view(), ref.eng.planes_view())
+  for key in ('reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+    assert torch.equal(hip.eng.buffers[key].tensor, ref.eng.buffers[key].tensor), key
+
+
+def test_warehouse_persistent_workers_equal_the_round_2_shape_at_config_4():
+  """262,144 environments (BASELINE config 4): persistent workers == one workgroup per group over the whole batch, and
+  layer == (board == c) everywhere."""
+  import torch
+  from pycolab_amd import _native as N
+  t = helpers.load_template('warehouse_L0')
+  B, T = 262144, 48
+  hip = HipAdapter(t, B)
+  hip.reset(); hip.step_hashed(0xC0FFEE, 0, T)
+  assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 3
+  with Knobs(PCX_WM_PW=0):
+    ref = HipAdapter(t, B)
+    ref.reset(); ref.step_hashed(0xC0FFEE, 0, T)
+    assert int(N.lib().pcx_engine_launch_shape(ref.eng._native)) == 0
+  planes = hip.eng.planes_view()
+  assert torch.equal(planes, ref.eng.planes_view())
+  for name in ('reward', 'reward_set', 'discount', 'done', 'frame', 'error'):
+    assert torch.equal(hip.eng.buffers[name].tensor, ref.eng.buffers[name].tensor), name
+  chars = torch.tensor(list(t.chars), dtype=torch.uint8, device=planes.device)
+  assert torch.equal(planes[:, 1:], (planes[:, :1] == chars.view(1, -1, 1, 1)).to(torch.uint8))
+  K = 2048
+  for off in (0, B - K):
+    orc = OracleAdapter(t, K)
+    orc.reset(); orc.step_hashed(0xC0FFEE, 0, T, env_offset=off)
+    np.testing.assert_array_equal(planes[off:off + K].cpu().numpy(), orc.read('planes'))
