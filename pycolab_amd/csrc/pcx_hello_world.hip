@@ -486,8 +486,10 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   bool pw = !coop && !epi_.out && !fused_.on && !unoccluded_ && a.mode == 0 && !a.export_curtains && a.debug == 0;
   if (const char* e = getenv("PCX_HW_PW")) pw = pw && atoi(e) != 0;
   if (pw) {
-    const bool many = groups >= (int64_t)num_cus_ * 32;
-    int workers = many ? 1 : 8, per_cu = many ? 4 : 1, lock = many ? 0 : 4;
+    // Measured (profiles/r05_hello_world_workers_sweep.txt; round-2 shape 0.2256 / 0.8428 ms at 262,144 / 1,048,576 environments):
+    // four single-worker workgroups per CU -- the round-2 residency made persistent, state prefetched -- 0.2128 / 0.7900;
+    // workgroups of several workers with streaming slots lose here (five workers, four slots: 0.2639 / 0.8121).
+    int workers = 1, per_cu = 4, lock = 0;
     if (const char* e = getenv("PCX_HW_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 8) workers = v; }
     if (const char* e = getenv("PCX_HW_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     if (const char* e = getenv("PCX_HW_LOCK")) lock = atoi(e);
