@@ -1,6 +1,6 @@
 """Every committed golden fixture is what its generator produces from the
-reference TODAY: the four generators (oracle/gen_templates.py, gen_golden.py,
-harvest_reference_tests.py, gen_story_golden.py) are re-run against
+reference TODAY: the generators (oracle/gen_templates.py, gen_golden.py,
+harvest_reference_tests.py, gen_story_golden.py, gen_raise_golden.py; a sample of gen_digests.py) are re-run against
 /root/reference into a scratch directory and every array of every file must
 equal the committed one.  Runs where the reference exists (the build
 container); the GPU box has no /root/reference and skips it."""
@@ -14,7 +14,7 @@ import pytest
 from tests import helpers
 
 REFERENCE = os.environ.get('PCX_REFERENCE', '/root/reference')
-GENERATORS = ['gen_templates.py', 'harvest_reference_tests.py', 'gen_story_golden.py', 'gen_golden.py']
+GENERATORS = ['gen_templates.py', 'harvest_reference_tests.py', 'gen_story_golden.py', 'gen_golden.py', 'gen_raise_golden.py']
 
 
 @pytest.fixture(scope='module')
@@ -38,7 +38,7 @@ def _same_npz(a, b):
     np.testing.assert_array_equal(za[k], zb[k], err_msg='%s: %s' % (os.path.basename(a), k))
 
 
-@pytest.mark.parametrize('sub', ['templates', 'reftests', 'traces'])
+@pytest.mark.parametrize('sub', ['templates', 'reftests', 'traces', 'raises'])
 def test_committed_fixtures_are_what_the_generators_produce(regenerated, sub):
   committed = os.path.join(helpers.GOLDEN, sub)
   fresh = os.path.join(regenerated, sub)

@@ -406,17 +406,19 @@ def test_observation_planes_beyond_4_gib(name, B, T, generic, monkeypatch):
   hip.eng.close()
 
 
-def test_engine_facade_batch1_matches_trace():
-  """`Engine.play()` with batch 1 returns the reference's types and values."""
-  tr = helpers.load_trace('scrolly_maze_L0')
-  t = helpers.load_template('scrolly_maze_L0')
+@pytest.mark.parametrize('name,e', [('scrolly_maze_L0', 5), ('hello_world', 3), ('hello_world', 11), ('warehouse_L0', 2), ('marauders', 7)])
+def test_engine_facade_batch1_matches_trace(name, e):
+  """`Engine.play()` with batch 1 -- BASELINE config 1's shape; hello_world is the game it names -- returns the reference's
+  types and values: one environment of the reference's recorded trace, step by step."""
+  tr = helpers.load_trace(name)
+  t = helpers.load_template(name)
   from pycolab_amd.engine import Engine
-  e = 5  # one environment of the trace
-  eng = Engine.from_template(t, batch=1)
+  eng = Engine.from_template(t, batch=1, seed=helpers.GOLDEN_RNG_SEED, env_offset=e)  # (marauders draws by global environment index)
   obs, reward, discount = eng.its_showtime()
   np.testing.assert_array_equal(obs.board, tr['boards'][0, e])
-  assert reward is None and discount == 1.0 and obs.board.shape == (t.rows, t.cols)
-  assert obs.layers['#'].dtype == np.bool_
+  want_r0 = int(tr['reward'][0, e]) if tr['reward_set'][0, e] else None
+  assert reward == want_r0 and discount == 1.0 and obs.board.shape == (t.rows, t.cols)
+  assert obs.layers[chr(t.chars[1])].dtype == np.bool_ and isinstance(obs.board, np.ndarray)
   for step in range(tr['actions'].shape[0]):
     if eng.game_over:
       with pytest.raises(RuntimeError):
