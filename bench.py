@@ -527,6 +527,9 @@ def main():
                                measure_config('scrolly_maze', 0, 262144, 200, 20, device),
                                measure_config('scrolly_maze', 0, 4096, 200, 20, device),
                                measure_step_n('scrolly_maze', 0, 4096, 1000, device),
+                               # the headline batch through Engine.step_n: launches of up to 64 steps in which every persistent
+                               # worker keeps its units from step to step (launch shape 13); every step still writes its observation
+                               measure_step_n('scrolly_maze', 0, 1048576, 128, device),
                                measure_config('marauders', 0, 32768, 200, 20, device),
                                measure_config('warehouse', 0, 262144, 100, 10, device),
                                measure_config('better_scrolly_maze', 0, 65536, 50, 10, device),

@@ -335,7 +335,8 @@ const char* pcx_engine_kernel_name(const pcx_engine* e);
  * workgroup per group of 64 environments, 3 persistent workgroups of W workers (waves) that draw work units, with the
  * next unit's state words prefetched into LDS and a streaming semaphore (the default from 65,536 environments up), 5 the
  * same with the shipped level's constants compiled in (pcx_debug_scrolly_consts), 10 cooperative (several waves per
- * group), 12 the cooperative shape walking several steps per launch, 20 shape-generic instance (1, 2, 4 and 11 were
+ * group), 12 the cooperative shape walking several steps per launch, 13 the persistent workers walking several steps per
+ * launch (every worker keeps its units from step to step), 20 shape-generic instance (1, 2, 4 and 11 were
  * launch shapes of rounds 1-4, measured slower and removed in round 5); pcx_generic_step: 30 the
  * table-driven build, 31 the build specialised for the engine's template at run time; -1: the backend does not say. */
 int32_t pcx_engine_launch_shape(const pcx_engine* e);

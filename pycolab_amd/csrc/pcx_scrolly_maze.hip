@@ -743,14 +743,19 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void 
   uint32_t* const ps_ctr_mine = P.ps_ctr + 16u * ps_x;
   uint32_t ps_u = P.ps_dynamic ? ps_x + ps_shards * ps_local : ps_wid, ps_un = 0;
   uint32_t ps_steal = 0;  // shards this worker has found dry (it draws from shard ps_x + ps_steal)
+  // A launch of several steps (StepArgs::n_steps; round 5): every worker keeps ITS units (static round-robin) and walks them
+  // step after step -- no ramp and no tail between the steps, the only wait is for the worker's own state stores of the step
+  // before (same wave, same CU: coherent through the CU's vL1D) when it wraps around to its first unit.
+  int ps_step = 0, ps_step_next = 0;
   bool ps_need_wait = true;
   const bool ps_prof = PS != 0 && P.ps_prof != nullptr;
   uint32_t pt_units = 0, pt_a = 0, pt_b = 0, pt_c = 0, pt_d = 0, pt_mark = 0;
   auto ps_now = [&]() { return ps_prof ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u; };
   const uint32_t pt_start = ps_now();
   // the state words of unit `u` (and its tape actions) into the inbox; lanes past the unit's environments stay out
-  auto ps_prefetch = [&](uint32_t u_any) {
+  auto ps_prefetch = [&](uint32_t u_any, int step_any = 0) {
     const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u_any);  // (uniform by construction; now provably)
+    const int64_t step = (int64_t)__builtin_amdgcn_readfirstlane(step_any);
     int64_t e0_any;
     int cnt;
     ps_span(u, e0_any, cnt);
@@ -763,7 +768,8 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void 
       for (int w = 0; w < W_SPOS + NS + 4; ++w)
         if (w < k.NW) ps_dma_row(P.state + (int64_t)w * P.bpad + e0, 4u * lane, ib + (uint32_t)w * (4u * WAVE));
     }
-    if (!a.hashed && lane < cnt && e0 + lane < P.batch) ps_dma_row(reinterpret_cast<const uint32_t*>(a.actions) + e0, 4u * lane, ib + (uint32_t)PS_IB_ACTION * (4u * WAVE));
+    if (!a.hashed && lane < cnt && e0 + lane < P.batch)
+      ps_dma_row(reinterpret_cast<const uint32_t*>(a.actions) + step * a.action_stride + e0, 4u * lane, ib + (uint32_t)PS_IB_ACTION * (4u * WAVE));
   };
   if constexpr (PS != 0) {
     if (threadIdx.x == 0) ps_ring[3] = 0;  // (the streaming semaphore)
@@ -797,7 +803,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void 
   for (int round = 0;; ++round) {
   const int64_t g_render = COOP ? (int64_t)blockIdx.x : (int64_t)blockIdx.x + (int64_t)round * gridDim.x;
   const int64_t g_logic = g_render;
-  const int tstep = COOP ? round : 0;  // which of the launch's steps the logic wave is on
+  const int tstep = COOP ? round : PS == 3 ? ps_step : 0;  // which of the launch's steps the logic wave is on
   const int coop_steps = a.n_steps > 1 ? a.n_steps : 1;
   bool have_render = g_render < ngroups && (!COOP || round < coop_steps);
   bool have_logic = have_render;
@@ -1485,8 +1491,14 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void 
       }
     } else {
       ps_un = ps_u + ps_nwk;
+      ps_step_next = ps_step;
+      if (ps_un >= ps_n && ps_step + 1 < a.n_steps) {  // this step's last unit of mine: on to the next step, from my first unit
+        ps_un = ps_wid;
+        ps_step_next = ps_step + 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (its state words may be the ones this wave has just stored)
+      }
     }
-    if (ps_un < ps_n) ps_prefetch(ps_un);
+    if (ps_un < ps_n) ps_prefetch(ps_un, ps_step_next);
     if (P.ps_lock) {
       // at most ps_lock streaming waves per workgroup: a counting semaphore in LDS (lane 0 alone adds; a wave that
       // finds the count at the limit takes its increment back and tries again a little later)
@@ -1824,6 +1836,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void 
     ps_need_wait = any_skip || (a.debug & ~16) != 0 || stores_behind < 64 || !planes_on;
     if (ps_need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ps_u = ps_un;
+    ps_step = ps_step_next;
     if (ps_prof) pt_d += ps_now() - pt_mark;
   } else if constexpr (!EPI) {
     sweeps(std::integral_constant<int, 0>{});
@@ -1907,7 +1920,7 @@ struct ShapeTuner {
   int pick(const StepArgs& a, hipStream_t s) {
     measuring_begin = measuring_end = false;
     if (chosen >= 0) return chosen;
-    if (off || a.mode != 0) return 0;
+    if (off || a.mode != 0 || a.n_steps > 1) return 0;  // (launches of several steps are not comparable with single steps)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
     const int i = phase - WARM;
@@ -1979,7 +1992,7 @@ class ScrollyMazeBackend : public Backend {
     int shape = 3;
     bool asked = false;
     if (const char* e = getenv("PCX_SM_SHAPE")) { shape = atoi(e) == 3 ? 3 : 0; asked = true; }
-    if (a.mode != 0 || a.n_steps > 1 || (a.debug & ~(5 | 16)) != 0 || epi_.out || fused_.on || k_.CW > 4 || k_.NW > PS_IB_ACTION) shape = 0;
+    if (a.mode != 0 || (a.debug & ~(5 | 16)) != 0 || epi_.out || fused_.on || k_.CW > 4 || k_.NW > PS_IB_ACTION) shape = 0;
     if (!asked && bpad_ / WAVE < (int64_t)num_cus_ * 4) shape = 0;
     return shape;
   }
@@ -2000,7 +2013,17 @@ class ScrollyMazeBackend : public Backend {
     if (const char* e = getenv("PCX_SM_BAKED")) if (atoi(e) == 0) return false;
     return memcmp(&kk, &baked, sizeof kk) == 0;
   }
-  int max_fused_steps() const override { return fused_ok_ && !epi_.out && !fused_.on ? 256 : 1; }  // the epilogue / fused croppers have no multi-step instance
+  // the epilogue / fused croppers have no multi-step instance; small batches: the cooperative shape walks up to 256 steps
+  // per launch; large batches of the shipped shape: the persistent workers walk up to 64 (a launch of 64 steps of
+  // 1,048,576 environments is ~35 ms: error polls and host-side cancellation stay that fine-grained)
+  int max_fused_steps() const override {
+    if (epi_.out || fused_.on) return 1;
+    if (fused_ok_) return 256;
+    StepArgs probe;
+    const bool shipped_shape = !unoccluded_ && k_.NS == 4 && k_.R == 10 && k_.C == 30 && k_.L == 8 && k_.ip == 3 && k_.ie == 3;
+    if (const char* f = getenv("PCX_FUSE_STEPS")) if (atoi(f) == 0) return 1;
+    return shipped_shape && ps_shape(probe) == 3 && !(getenv("PCX_SM_CODES") && atoi(getenv("PCX_SM_CODES")) == 0) ? 64 : 1;
+  }
   // include/pcx.h pcx_engine_fuse_croppers: the instances that render from curtain bit vectors + sprite
   // descriptors cut the windows too (pcx_stream.h stream_windows); the owner-code and multi-step instances step aside
   bool fused_window_features() const override { return true; }
@@ -2390,9 +2413,10 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
   if (fused_.on) use_codes = false;  // the windows are cut from the curtain bit vectors
   int coop_below = 4;  // groups per CU (measured crossover: profiles/r03_tuning.md; round 1: 5)
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
-  if (a.n_steps > 1 && (!shipped_shape || !fused_ok_ || a.mode != 0 || epi_.out))
+  const bool coop_steps = a.n_steps > 1 && fused_ok_;  // (several steps of a small batch: the cooperative shape whatever the knobs say)
+  if (a.n_steps > 1 && (!shipped_shape || a.mode != 0 || epi_.out || fused_.on || (!fused_ok_ && !(use_codes && ps_shape(a) == 3))))
     return set_error(PCX_E_INVALID, "scrolly_maze backend: %d steps in one launch are not available here", a.n_steps);
-  if (shipped_shape && (groups < (int64_t)num_cus_ * coop_below || a.n_steps > 1)) {  // (several steps: this shape whatever the knobs say)
+  if (shipped_shape && (groups < (int64_t)num_cus_ * coop_below || coop_steps)) {
     int coop_waves = groups <= num_cus_ ? 8 : 4;  // at most one group per CU: split the render loop eight ways
     if (const char* e = getenv("PCX_COOP_WAVES")) coop_waves = atoi(e) == 4 ? 4 : 8;
     // ... and while CUs would still stand empty, halve the environments per workgroup (32, 16): the
@@ -2452,6 +2476,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     dynamic = units64 >= (int64_t)num_cus_ * 6 * 4;
     if (const char* e = getenv("PCX_SM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
     if (const char* e = getenv("PCX_SM_DYNAMIC")) dynamic = atoi(e) != 0;
+    if (a.n_steps > 1) dynamic = 0;  // several steps per launch: every worker keeps its own units from step to step
     if (const char* e = getenv("PCX_SM_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) waves = v; }  // workers per workgroup
     if (const char* e = getenv("PCX_SM_LOCK")) P.ps_lock = atoi(e);
     if (const char* e = getenv("PCX_SM_STEAL")) P.ps_steal = atoi(e) != 0;
@@ -2507,11 +2532,11 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     }
     if (baked) {
       // the engine's Consts are the shipped level 0's, word for word: the instance that has them as compile-time constants
-      last_shape_ = 5;
+      last_shape_ = a.n_steps > 1 ? 13 : 5;  // (13: persistent workers walking several steps of the launch)
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3, 1>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
       tuner_.launched(s);
     } else {
-      last_shape_ = 3;
+      last_shape_ = a.n_steps > 1 ? 13 : 3;
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
     }
   } else if (shipped_shape && use_codes) {

@@ -60,7 +60,7 @@ def raw_shape_of(hip):
 def shape_of(hip):
   """The launch shape; 5 is shape 3 run by the instance with the shipped level's constants compiled in."""
   s = raw_shape_of(hip)
-  return 3 if s == 5 else s
+  return 3 if s in (5, 13) else s  # (13: the same workers walking several steps of one launch)
 
 
 @pytest.mark.parametrize('shape,codes,waves,lock,grid,dynamic', [(3, 1, 4, 1, 2, 1), (3, 1, 3, 2, 3, 0), (3, 1, 10, 3, 1, 1), (3, 1, 1, 0, 5, 1),
@@ -193,7 +193,7 @@ def test_instance_with_the_shipped_levels_constants_compiled_in(baked, waves, lo
     while t0 < T:
       n = 1 if t0 < 24 else 8
       hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
-      assert raw_shape_of(hip) == (5 if baked else 3)
+      assert raw_shape_of(hip) == (13 if n > 1 else 5 if baked else 3)
       t0 += n
       assert_same(hip, orc, 'baked %d after step %d' % (baked, t0))
     assert int(orc.read('frame').min()) < T
@@ -208,7 +208,7 @@ def test_other_levels_keep_the_run_time_constants():
     hip.reset(); orc.reset()
     for t0 in range(0, 64, 8):
       hip.step_hashed(0x5EED, t0, 8); orc.step_hashed(0x5EED, t0, 8)
-      assert raw_shape_of(hip) in (3, 20)
+      assert raw_shape_of(hip) in (3, 13, 20)
       assert_same(hip, orc, 'level 1 after step %d' % (t0 + 8))
 
 
@@ -222,8 +222,11 @@ def test_headline_batch_default_shape_equals_one_workgroup_per_group_shape_every
   B, T, K = 1048576, 24, 2048
   hip = HipAdapter(t, B)
   hip.reset()
-  hip.step_hashed(0xC0FFEE, 0, T)
-  assert raw_shape_of(hip) == 5
+  for t0 in range(T // 2):  # single-step launches: the shape Engine.play() takes ...
+    hip.step_hashed(0xC0FFEE, t0, 1)
+    assert raw_shape_of(hip) == 5
+  hip.step_hashed(0xC0FFEE, T // 2, T - T // 2)  # ... then one launch of twelve steps, every worker on its own units
+  assert raw_shape_of(hip) == 13
   planes = hip.eng.planes_view()
   with Knobs(PCX_SM_SHAPE=0):
     ref = HipAdapter(t, B)
@@ -347,3 +350,36 @@ def test_warehouse_persistent_workers_equal_the_round_2_shape_at_config_4():
     orc = OracleAdapter(t, K)
     orc.reset(); orc.step_hashed(0xC0FFEE, 0, T, env_offset=off)
     np.testing.assert_array_equal(planes[off:off + K].cpu().numpy(), orc.read('planes'))
+
+
+@pytest.mark.parametrize('baked,waves,grid', [(1, 4, 2), (0, 2, 3), (1, 1, 5), (1, 3, 4096)])
+def test_persistent_workers_walk_several_steps_per_launch(baked, waves, grid):
+  """Round 5: `step_n` / `step_hashed` at large batches are launches of up to 64 steps in which every persistent worker keeps
+  its own units from step to step (launch shape 13: no ramp and no tail between the steps; the state words round-trip
+  through HBM and come back by LDS-DMA, waited for where a worker wraps around to a unit it has just written).  Against the
+  oracle: hashed actions and host tapes with quirky actions, chunks that leave finished environments frozen, a grid of one
+  unit per worker (every step wraps onto the unit just written) and of many."""
+  t = helpers.load_template('scrolly_maze_L0')
+  B = 64 * 23 + 13
+  rng = np.random.RandomState(3)
+  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=3, PCX_SM_BAKED=baked, PCX_SM_WAVES=waves, PCX_SM_GRID=grid):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    t0 = 0
+    for i, n in enumerate((1, 2, 7, 64, 100, 3, 1, 31)):
+      auto = i % 3 != 2
+      hip.step_hashed(0xABCD, t0, n, auto_reset=auto); orc.step_hashed(0xABCD, t0, n, auto_reset=auto)
+      assert raw_shape_of(hip) == (13 if n > 1 else (5 if baked else 3)), (n, raw_shape_of(hip))
+      t0 += n
+      assert_same(hip, orc, 'baked %d waves %d grid %d after %d steps (chunk %d)' % (baked, waves, grid, t0, n))
+    tape = rng.randint(0, 5, size=(70, B)).astype(np.int32)
+    r = rng.rand(70, B)
+    tape[r < 0.03] = -1
+    tape[(r >= 0.03) & (r < 0.04)] = 5
+    tape[(r >= 0.04) & (r < 0.06)] = 17
+    hip.eng._auto_reset = True
+    hip.eng.step_n(tape)
+    for row in tape:
+      orc.step(row)
+    assert raw_shape_of(hip) == 13
+    assert_same(hip, orc, 'after the tape')
