@@ -738,9 +738,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void 
   const uint32_t ps_shards = gridDim.x < 8u ? gridDim.x : 8u;
   const uint32_t ps_x = blockIdx.x % ps_shards;
   const uint32_t ps_wpw = PS == 3 ? (blockDim.x >> 6) : 1u;                                  // workers per workgroup
-  const uint32_t ps_shard_nwk = ((gridDim.x - ps_x + ps_shards - 1u) / ps_shards) * ps_wpw;  // workers of this shard
   const uint32_t ps_local = (blockIdx.x / ps_shards) * ps_wpw + (PS == 3 ? (uint32_t)wave : 0u);
-  uint32_t* const ps_ctr_mine = P.ps_ctr + 16u * ps_x;
   uint32_t ps_u = P.ps_dynamic ? ps_x + ps_shards * ps_local : ps_wid, ps_un = 0;
   uint32_t ps_steal = 0;  // shards this worker has found dry (it draws from shard ps_x + ps_steal)
   // A launch of several steps (StepArgs::n_steps; round 5): every worker keeps ITS units (static round-robin) and walks them

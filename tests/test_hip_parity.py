@@ -2,6 +2,8 @@
 (1) golden traces recorded from the imported reference, and
 (2) the CPU oracle on seeded inputs, and
 (3) size-independent properties at the BASELINE batch sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -249,7 +251,7 @@ def test_hip_several_steps_per_launch_in_the_cooperative_shape(name, B):
   for i, n in enumerate((1, 2, 3, 9, 64, 5, 200, 31)):
     auto = i % 3 != 2
     hip.step_hashed(0xABCD, t0, n, auto_reset=auto); orc.step_hashed(0xABCD, t0, n, auto_reset=auto)
-    if n > 1:
+    if n > 1 and 'PCX_COOP_BELOW' not in os.environ:  # (a suite run with the cooperative shape forced off / on compares results only)
       assert int(N.lib().pcx_engine_launch_shape(hip.eng._native)) == 12
     t0 += n
     assert_same(hip, orc, '%s x %d after %d steps (chunk %d)' % (name, B, t0, n))

@@ -262,7 +262,8 @@ def test_cooperative_shape_with_the_levels_constants_compiled_in(B, baked):
     t0 = 0
     for n in (1, 1, 1, 7, 64, 3, 1, 120):
       hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
-      assert raw_shape_of(hip) == (12 if n > 1 else 10)
+      if 'PCX_COOP_BELOW' not in os.environ or os.environ['PCX_COOP_BELOW'] not in ('0',):  # (a suite run with the cooperative shape forced off compares results only)
+        assert raw_shape_of(hip) == (12 if n > 1 else 10)
       t0 += n
       assert_same(hip, orc, 'B %d baked %d after step %d' % (B, baked, t0))
     assert int(orc.read('frame').min()) < t0
