@@ -304,7 +304,7 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_hello_world_
                                                                     flat, sdesc, skipv, FWP, lane, 0, epi, env0, nullptr, 0, nullptr, nullptr, lds);
       if (P.work.lock) stream::slot_release(sem);
     }
-    need_wait = any_skip || a.debug != 0 || QW * (1 + L) < 64;  // fewer than 64 plane stores behind the prefetch: wait for it
+    need_wait = any_skip || (a.debug & ~16) != 0 || QW * (1 + L) < 64;  // fewer than 64 plane stores behind the prefetch: wait for it
     if (need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unit = next;
   } else {
@@ -375,6 +375,7 @@ class HelloWorldBackend : public Backend {
   int64_t batch_ = 0, bpad_ = 0;
   int num_cus_ = 256;
   DevArray<uint32_t> tables_, initc_, state_, curtains_, work_ctr_;
+  ShapeTuner tuner_;
   int last_shape_ = -1;
   DevArray<int32_t> track_;
 };
@@ -483,13 +484,20 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   }
   bool launched = false;
   // (round 5) persistent workers for plain steps, as in pcx_warehouse.hip (PCX_HW_PW=0: the round-2 shape)
-  bool pw = !coop && !epi_.out && !fused_.on && !unoccluded_ && a.mode == 0 && !a.export_curtains && a.debug == 0;
+  bool pw = !coop && !epi_.out && !fused_.on && !unoccluded_ && a.mode == 0 && !a.export_curtains && (a.debug & ~16) == 0;
   if (const char* e = getenv("PCX_HW_PW")) pw = pw && atoi(e) != 0;
   if (pw) {
     // Measured (profiles/r05_hello_world_workers_sweep.txt; round-2 shape 0.2256 / 0.8428 ms at 262,144 / 1,048,576 environments):
     // four single-worker workgroups per CU -- the round-2 residency made persistent, state prefetched -- 0.2128 / 0.7900;
     // workgroups of several workers with streaming slots lose here (five workers, four slots: 0.2639 / 0.8121).
-    int workers = 1, per_cu = 4, lock = 0;
+    // The alternatives are measured on the engine's own first launches (ShapeTuner, pcx_internal.h), this one first.
+    struct Cand { int workers, per_cu, lock; };
+    static const Cand cands[ShapeTuner::NC] = {{1, 4, 0}, {2, 4, 1}, {2, 3, 1}, {5, 1, 4}};
+    const bool knobs = getenv("PCX_HW_WORKERS") || getenv("PCX_HW_PER_CU") || getenv("PCX_HW_LOCK") || getenv("PCX_HW_GRID") ||
+                       (getenv("PCX_HW_TUNE") && atoi(getenv("PCX_HW_TUNE")) == 0);
+    if (knobs) tuner_.off = true;
+    const Cand& cand = cands[tuner_.pick(a, s)];
+    int workers = cand.workers, per_cu = cand.per_cu, lock = cand.lock;
     if (const char* e = getenv("PCX_HW_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 8) workers = v; }
     if (const char* e = getenv("PCX_HW_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     if (const char* e = getenv("PCX_HW_LOCK")) lock = atoi(e);
@@ -518,6 +526,7 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
   }
     PCX_HW_SHAPES(X)
 #undef X
+    if (launched) tuner_.launched(s);
   }
   last_shape_ = launched ? 3 : coop ? 10 : 0;
 #define X(r, c)                                                                                                  \

@@ -5,6 +5,7 @@
 #include "pcx_device.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -60,6 +61,76 @@ struct ErrorPoll {
   int poll(const uint8_t* errors_dev, int64_t n, hipStream_t s, int32_t* seen);
   // host copy of (sticky | live); clear != 0 forgets the sticky part.  Synchronous.
   int errors_seen(const uint8_t* errors_dev, int64_t n, uint8_t* out_host, int clear);
+};
+
+// Which of a few equivalent launch configurations is fastest ON THIS BOX, measured on the engine's own launches (as
+// GenericBackend::Tuner does for pcx_generic_step's waves per workgroup).  The persistent shape's best worker / slot counts
+// differ from box to box by more than they differ from each other (profiles/r05_tuning.md: 2 x 3 workers with private
+// slots 0.560 ms on one box where 4 x 1 with two shared slots gives 0.574, 0.569 / 0.562 on another, 0.617 / 0.592 (2 x 2)
+// on a third), and the result does not depend on the choice.  After WARM step launches on the default, the candidates take
+// turns in BLOCKS of three consecutive launches, twice round (a clock still ramping up after the engine's creation must
+// not favour whoever is measured last); a block is timed over its second and third launch only -- single launches timed
+// between neighbours of another shape overlap with those neighbours' tails and measured up to 20 % off the steady state
+// (r05_ps_sweep_call7_pruned_tuner.txt: 0.068 against 0.086 ms).  Once the last block has completed (polled, never waited
+// for) the candidate with the smallest time stays -- the default unless another beats it by 1.5 %.  Launches under stream
+// capture and reset launches leave the tuner alone; the backends turn it off (`off = true`) when a knob fixes the shape
+// (PCX_SM_WAVES / _PER_CU / _LOCK ..., PCX_SM_TUNE=0 / PCX_WM_TUNE=0 / PCX_HW_TUNE=0).  Shared by pcx_scrolly_maze_step's
+// persistent shape and the persistent workers of pcx_warehouse_step / pcx_hello_world_step.
+struct ShapeTuner {
+  static constexpr int WARM = 8, NC = 4, ROUNDS = 2, BLOCK = 3, NB = NC * ROUNDS;
+  int phase = 0, chosen = -1;
+  bool off = false, measuring_begin = false, measuring_end = false, have_events = false;
+  hipEvent_t ev[NB][2] = {};
+  float ms[NC] = {};
+  ~ShapeTuner() { drop(); }
+  void drop() {
+    if (have_events) for (auto& e : ev) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
+    have_events = false;
+  }
+  // the candidate this launch takes (0 = the default)
+  int pick(const StepArgs& a, hipStream_t s) {
+    measuring_begin = measuring_end = false;
+    if (chosen >= 0) return chosen;
+    if (off || a.mode != 0 || a.n_steps > 1) return 0;  // (launches of several steps are not comparable with single steps)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    const int i = phase - WARM;
+    if (i < 0) { ++phase; return 0; }
+    if (i < NB * BLOCK) {
+      if (!have_events) {
+        for (auto& e : ev)
+          if (hipEventCreate(&e[0]) != hipSuccess || hipEventCreate(&e[1]) != hipSuccess) { (void)hipGetLastError(); off = true; return 0; }
+        have_events = true;
+      }
+      const int block = i / BLOCK, pos = i % BLOCK;
+      if (pos == 1 && hipEventRecord(ev[block][0], s) != hipSuccess) { (void)hipGetLastError(); off = true; return 0; }
+      measuring_begin = true;
+      measuring_end = pos == BLOCK - 1;
+      return block % NC;
+    }
+    if (hipEventQuery(ev[NB - 1][1]) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (not through yet: the default meanwhile)
+    float best = 0.0f;
+    for (int c = 0; c < NC; ++c) {
+      ms[c] = 0.0f;
+      for (int r = 0; r < ROUNDS; ++r) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, ev[r * NC + c][0], ev[r * NC + c][1]) != hipSuccess) { (void)hipGetLastError(); off = true; drop(); return 0; }
+        ms[c] += t / ((BLOCK - 1) * ROUNDS);
+      }
+      if (chosen < 0 || ms[c] < best * 0.985f) { best = ms[c]; chosen = c; }
+    }
+    drop();
+    const char* dbg = getenv("PCX_DEBUG");
+    if (dbg && (atoi(dbg) & 16))
+      fprintf(stderr, "[pcx] launch shape candidate %d of %d (%.4f %.4f %.4f %.4f ms per launch)\n", chosen, NC, ms[0], ms[1], ms[2], ms[3]);
+    return chosen;
+  }
+  void launched(hipStream_t s) {
+    if (!measuring_begin) return;
+    if (measuring_end && hipEventRecord(ev[(phase - WARM) / BLOCK][1], s) != hipSuccess) { (void)hipGetLastError(); off = true; }
+    ++phase;
+    measuring_begin = measuring_end = false;
+  }
 };
 
 namespace stream { struct EpilogueArgs; }

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_warehouse_st
       if (P.work.lock) stream::slot_release(sem);
     }
     // fewer than 64 plane stores behind the prefetch (environments left alone, ablation runs): wait for it
-    need_wait = any_skip || a.debug != 0 || QW * (1 + L) < 64;
+    need_wait = any_skip || (a.debug & ~16) != 0 || QW * (1 + L) < 64;
     if (need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unit = next;
   } else {
@@ -446,6 +446,7 @@ class WarehouseBackend : public Backend {
   bool static_shape_ = false;  // a compiled instance for exactly this shape exists
   std::vector<uint8_t> goal_;  // host copy for read_things
   DevArray<uint32_t> tables_, state_, curtains_, work_ctr_;
+  ShapeTuner tuner_;
   int last_shape_ = -1;
   DevArray<int32_t> track_;
 };
@@ -614,7 +615,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   const bool epi = epi_.out != nullptr;  // the feature-array epilogue has its own instances (whole-dword boards only)
   // (round 5) persistent workers: plain steps of the compiled shapes from four units per CU up.  One workgroup of W workers per
   // CU, `lock` of them streaming at a time, tickets (with stealing) from 24 units per CU up; PCX_WM_PW=0: the round-2 shape.
-  bool pw = !coop && !epi && !fused_.on && !unoccluded_ && static_shape_ && a.mode == 0 && !a.export_curtains && a.debug == 0;
+  bool pw = !coop && !epi && !fused_.on && !unoccluded_ && static_shape_ && a.mode == 0 && !a.export_curtains && (a.debug & ~16) == 0;
   if (const char* e = getenv("PCX_WM_PW")) pw = pw && atoi(e) != 0;
   if (pw) {
     // Measured (profiles/r05_warehouse_workers_sweep.txt; the round-2 shape: 0.0824 / 0.3203 ms at 262,144 / 1,048,576
@@ -622,8 +623,17 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     // half the CU's rate (one slot: 0.167 ms), so four stream at a time: ONE workgroup of eight workers with four slots
     // 0.0712 / 0.3128; from 32 units per CU up four single-worker workgroups per CU (the round-2 residency, persistent,
     // state prefetched) 0.0775 / 0.2981.
+    // ... and which of the two it is differs from box to box (262,144 environments: 0.0712 / 0.0775 on one, 0.0850 / 0.0806 on
+    // another), so the engine measures on its own first launches (ShapeTuner, pcx_internal.h): the rule's choice first.
     const bool many = groups >= (int64_t)num_cus_ * 32;
-    int workers = many ? 1 : 8, per_cu = many ? 4 : 1, lock = many ? 0 : 4;
+    struct Cand { int workers, per_cu, lock; };
+    static const Cand few_c[ShapeTuner::NC] = {{8, 1, 4}, {1, 4, 0}, {2, 4, 1}, {6, 1, 4}};
+    static const Cand many_c[ShapeTuner::NC] = {{1, 4, 0}, {6, 1, 4}, {8, 1, 4}, {2, 3, 1}};
+    const bool knobs = getenv("PCX_WM_WORKERS") || getenv("PCX_WM_PER_CU") || getenv("PCX_WM_LOCK") || getenv("PCX_WM_GRID") ||
+                       (getenv("PCX_WM_TUNE") && atoi(getenv("PCX_WM_TUNE")) == 0);
+    if (knobs) tuner_.off = true;
+    const Cand& cand = (many ? many_c : few_c)[tuner_.pick(a, s)];
+    int workers = cand.workers, per_cu = cand.per_cu, lock = cand.lock;
     if (const char* e = getenv("PCX_WM_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 8) workers = v; }
     if (const char* e = getenv("PCX_WM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     if (const char* e = getenv("PCX_WM_LOCK")) lock = atoi(e);
@@ -652,6 +662,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   }
     PCX_WM_SHAPES(X)
 #undef X
+    if (launched) tuner_.launched(s);
     last_shape_ = launched ? 3 : last_shape_;
   }
   if (!launched) last_shape_ = coop ? 10 : 0;
