@@ -157,3 +157,72 @@ def test_checkpoint_of_another_level_is_refused():
   e.reset()
   with pytest.raises(ValueError, match='template hash|level'):
     e.eng.import_state(c.eng.export_state())
+
+
+def test_checkpoint_with_a_pass_through_cropper_attached():
+  """a base ObservationCropper() (what a Story installs for every chapter by default) registers itself with the
+  engine but has no device object and no state: export_state() / import_state() must carry on (a zero-length part keeps
+  the trailer's attachment order), next to a real cropper whose window IS state."""
+  import torch
+  from pycolab_amd import cropping
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('better_scrolly_maze_L1')
+
+  def build(steps, seed):
+    eng = Engine.from_template(t, batch=200, auto_reset=True, seed=7)
+    plain = cropping.ObservationCropper()
+    real = cropping.ScrollingCropper(rows=7, cols=11, to_track=['P'], pad_char=' ', scroll_margins=(2, 3))
+    plain.set_engine(eng); real.set_engine(eng)
+    eng.its_showtime()
+    for s in range(steps):
+      eng.step_hashed(seed, s, 1)
+      real.crop(None)
+    return eng, plain, real
+  a, pa, ra = build(33, 0xC0FFEE)
+  blob = a.export_state(with_observation=True)
+  b, pb, rb = build(5, 0xBAD)
+  b.import_state(blob)
+  assert torch.equal(ra.crop(None).board, rb.crop(None).board)
+  for s in range(33, 53):
+    a.step_hashed(0xC0FFEE, s, 1); b.step_hashed(0xC0FFEE, s, 1)
+    assert torch.equal(ra.crop(None).board, rb.crop(None).board), s
+  obs = b._result()[0]
+  assert pb.crop(obs) is obs  # (the identity cropper stays the identity)
+  a.close(); b.close()
+
+
+def test_resume_with_a_feature_stack_fused_into_a_window():
+  """ObservationToFeatureArray.fuse_into(engine, source=cropper) -- the step kernel writes the window's float32
+  stack.  After import_state() the converter must hand out the stack of the RESTORED window, not the tensor the
+  importing engine's own last step wrote."""
+  import torch
+  from pycolab_amd import cropping, rendering
+  from pycolab_amd.engine import Engine
+  t = helpers.load_template('better_scrolly_maze_L1')
+  chars = ''.join(chr(c) for c in t.chars)
+
+  def build(steps, seed):
+    eng = Engine.from_template(t, batch=200, auto_reset=True, seed=7)
+    cr = cropping.ScrollingCropper(rows=7, cols=11, to_track=['P'], pad_char=' ', scroll_margins=(2, 3))
+    assert cropping.fuse_croppers(eng, [cr]) is None
+    eng.its_showtime()
+    conv = rendering.ObservationToFeatureArray(chars)
+    assert conv.fuse_into(eng, source=cr)
+    for s in range(steps):
+      eng.step_hashed(seed, s, 1)
+    return eng, cr, conv
+  a, ca, fa = build(29, 0xC0FFEE)
+  want = fa(ca.crop(None)).clone()
+  blob = a.export_state(with_observation=True)
+  b, cb, fb = build(7, 0xBAD)
+  stale = fb(cb.crop(None)).clone()
+  assert not torch.equal(stale, want)
+  b.import_state(blob)
+  got = fb(cb.crop(None))
+  assert torch.equal(got, want), 'the converter handed out the pre-import stack'
+  plain = rendering.ObservationToFeatureArray(chars)
+  assert torch.equal(got, plain(cb.crop(None)))
+  for s in range(29, 40):
+    a.step_hashed(0xC0FFEE, s, 1); b.step_hashed(0xC0FFEE, s, 1)
+    assert torch.equal(fa(ca.crop(None)), fb(cb.crop(None))), s
+  a.close(); b.close()
