@@ -714,7 +714,9 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void 
   uint32_t* codes = lds_raw + k.lds_codes;
   // persistent shapes: this wave's unit, the one after it (whose state words are on their way into the inbox) and,
   // in the single-wave shape, the ticket in flight for the one after that
-  const int ps_mine = PS == 3 ? __builtin_amdgcn_readfirstlane(wave) * k.lds_ps_wave_words : 0;  // this worker's own LDS region
+  // (the three layout words that depend on the work unit's size are read from the kernel arguments even by the instance with
+  // the level's constants compiled in: units of 16 / 32 / 64 environments share it)
+  const int ps_mine = PS == 3 ? __builtin_amdgcn_readfirstlane(wave) * k_arg.lds_ps_wave_words : 0;  // this worker's own LDS region
   uint32_t* const ps_inbox = lds_raw + k.lds_ps_inbox + ps_mine;
   // workers: the waves that draw units (PS == 3: every wave; else one per workgroup)
   const uint32_t ps_wid = PS == 3 ? blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave : blockIdx.x;
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void 
   if constexpr (PS != 0) {
     codes = lds_raw + k.lds_ps_buf0 + ps_mine;
     // a buffer: the code table of the unit's environments, then 64 skip flags
-    l.skip = codes + k.lds_ps_buf_words - WAVE;
+    l.skip = codes + k_arg.lds_ps_buf_words - WAVE;
     l.cmask = lds_raw + k.lds_ps_cmask + ps_mine;
   } else {
     l.flat = lds_raw + k.lds_flat;
@@ -1941,7 +1943,9 @@ class ScrollyMazeBackend : public Backend {
   static bool baked_l0(const Consts& kk, const Consts& baked = SHIPPED_L0) {
     if (!SHIPPED_L0_VALID) return false;
     if (const char* e = getenv("PCX_SM_BAKED")) if (atoi(e) == 0) return false;
-    return memcmp(&kk, &baked, sizeof kk) == 0;
+    Consts x = kk;  // (the unit-dependent layout words travel as kernel arguments)
+    x.lds_ps_buf_words = baked.lds_ps_buf_words; x.lds_ps_words1 = baked.lds_ps_words1; x.lds_ps_wave_words = baked.lds_ps_wave_words;
+    return memcmp(&x, &baked, sizeof x) == 0;
   }
   // the epilogue / fused croppers have no multi-step instance; small batches: the cooperative shape walks up to 256 steps
   // per launch; large batches of the shipped shape: the persistent workers walk up to 64 (a launch of 64 steps of
