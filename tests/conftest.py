@@ -26,6 +26,9 @@ HAND_WRITTEN_KERNELS_ONLY = {
     'test_value_array_fused_into_the_step_kernel', 'test_repainter_fused_into_the_step_kernel', 'test_epilogue_without_any_plane',
     'test_fused_epilogue_belongs_to_the_engine', 'test_fused_postprocessors_match_reference', 'test_fused_outputs_match_the_numpy_oracle',
     'test_fused_window_feature_stack_matches_reference', 'test_fused_window_feature_stack_refusals_and_big_batch',
+    # round 5: the persistent workers of pcx_warehouse_step / pcx_hello_world_step (their launch shape is asserted)
+    'test_stream_kernels_persistent_workers_match_oracle', 'test_stream_kernels_persistent_workers_equal_the_round_2_shape',
+    'test_warehouse_persistent_workers_equal_the_round_2_shape_at_config_4', 'test_resume_with_a_feature_stack_fused_into_a_window',
 }
 
 
