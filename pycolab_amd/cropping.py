@@ -59,6 +59,7 @@ class ObservationCropper(object):
     other._engine, other._native, other._out, other._fused = None, None, None, False
     other._features = None
     other._feat_skip = 0
+    other._feat_skip_since = 0
     other._generation = 0
     return other
 
