@@ -348,10 +348,10 @@ int32_t pcx_engine_launch_shape(const pcx_engine* e);
  * cache -- without creating an engine and WITHOUT a device: what `build` checks and the CPU tests call.  code_bytes: the
  * size of the code object; log: the compiler's words when it fails (PCX_E_UNSUPPORTED).  No reference counterpart. */
 int pcx_generic_specialise_check(const pcx_template* t, char* log, int64_t log_bytes, int64_t* code_bytes);
-/* Build-time aid (no reference counterpart): pcx_scrolly_maze_step exists once more with the constants of the reference's
- * shipped level 0 (examples/scrolly_maze.py, MAZES_ART[0]) compiled in -- csrc/pcx_sm_shipped.h, generated by
+/* Build-time aid (no reference counterpart): pcx_scrolly_maze_step exists once more per shipped level with the constants of
+ * that level (examples/scrolly_maze.py, MAZES_ART[0..2]) compiled in -- csrc/pcx_sm_shipped.h, generated by
  * tools/gen_sm_shipped.py from what this entry answers.  It plans `t` for that kernel WITHOUT a device and copies the
- * kernel's constants for work units of `unit` environments (64, 32, 16) as 32-bit words; returns their number (words ==
+ * kernel's constants for work units of `unit` environments (64, 32, 16; 0: as the cooperative shape takes them) as 32-bit words; returns their number (words ==
  * NULL: only that), or a negative PCX_E_* when the kernel does not take the template.  An engine runs the baked
  * instance only while its own constants equal the header's, word for word (pcx_engine_launch_shape 5). */
 int64_t pcx_debug_scrolly_consts(const pcx_template* t, int32_t unit, uint32_t* words, int64_t cap);

@@ -102,30 +102,38 @@ struct Consts {
   int32_t sprite_by_z[MAX_NS];  // sprites back to front
 };
 
-// The shipped level 0 with its Consts baked in (template parameter LV of the kernel).  pcx_sm_shipped.h is GENERATED
-// (tools/gen_sm_shipped.py: the words pcx_debug_scrolly_consts() answers for tests/golden/templates/scrolly_maze_L0.npz)
-// and committed; tests/test_host_api.py requires it to be what this library plans today, and launch() takes the baked
-// instance only when the engine's own Consts are the same words -- any other level, cast or layout keeps the instance
-// that reads them from the kernel arguments.  A header of another size (Consts changed, header not yet regenerated)
-// compiles to an instance nobody launches.
+// The shipped levels with their Consts compiled in (template parameter LV of the kernel).  pcx_sm_shipped.h is GENERATED
+// (tools/gen_sm_shipped.py: the words pcx_debug_scrolly_consts() answers for tests/golden/templates/scrolly_maze_L0 / _L1 /
+// _L2.npz -- the reference's examples/scrolly_maze.py MAZES_ART[0..2] as pycolab_amd/compiler.py compiles them) and
+// committed; tests/test_host_api.py requires it to be what this library plans today, and launch() takes a compiled-in
+// instance only when the engine's own Consts are the same words -- any other level, cast or layout keeps the instance that
+// reads them from the kernel arguments.  A header of another size (Consts changed, header not yet regenerated) compiles to
+// instances nobody launches.  LV: 0 none; odd = a level's constants as the persistent shape launches them (1, 3: levels
+// 0, 1; level 2 has six coin words and does not take that shape), even = as init() leaves them, for the cooperative
+// shape (2, 4, 6: levels 0, 1, 2).
 #include "pcx_sm_shipped.h"
 constexpr int CONSTS_WORDS = (int)(sizeof(Consts) / 4);
 static_assert(sizeof(Consts) % 4 == 0, "Consts is a struct of 32-bit fields");
-struct ShippedWords { uint32_t w[PCX_SM_SHIPPED_L0_N > 0 ? PCX_SM_SHIPPED_L0_N : 1]; };
-static constexpr ShippedWords SHIPPED_L0_WORDS = {{PCX_SM_SHIPPED_L0_WORDS}};              // as the persistent shape launches them (units of 64)
-static constexpr ShippedWords SHIPPED_L0_PLAIN_WORDS = {{PCX_SM_SHIPPED_L0_PLAIN_WORDS}};  // as init() leaves them (the cooperative shape)
-constexpr bool SHIPPED_L0_VALID = sizeof(ShippedWords) == sizeof(Consts);
+struct ShippedWords { uint32_t w[PCX_SM_SHIPPED_N > 0 ? PCX_SM_SHIPPED_N : 1]; };
+constexpr bool SHIPPED_VALID = sizeof(ShippedWords) == sizeof(Consts);
 template <typename T>
 constexpr Consts consts_from_words(const T& raw) {
   if constexpr (sizeof(T) == sizeof(Consts)) return __builtin_bit_cast(Consts, raw);
   else return Consts{};
 }
-static constexpr Consts SHIPPED_L0 = consts_from_words(SHIPPED_L0_WORDS);
-static constexpr Consts SHIPPED_L0_PLAIN = consts_from_words(SHIPPED_L0_PLAIN_WORDS);
+constexpr int N_BAKED = 7;  // LV 1..6
+static constexpr ShippedWords SHIPPED_WORDS[N_BAKED] = {{{0}}, {{PCX_SM_SHIPPED_L0_WORDS}}, {{PCX_SM_SHIPPED_L0_PLAIN_WORDS}}, {{PCX_SM_SHIPPED_L1_WORDS}},
+                                                        {{PCX_SM_SHIPPED_L1_PLAIN_WORDS}}, {{0}}, {{PCX_SM_SHIPPED_L2_PLAIN_WORDS}}};
+static constexpr Consts SHIPPED_1 = consts_from_words(SHIPPED_WORDS[1]), SHIPPED_2 = consts_from_words(SHIPPED_WORDS[2]),
+                        SHIPPED_3 = consts_from_words(SHIPPED_WORDS[3]), SHIPPED_4 = consts_from_words(SHIPPED_WORDS[4]),
+                        SHIPPED_6 = consts_from_words(SHIPPED_WORDS[6]);
 template <int LV>
 __device__ __forceinline__ const Consts& baked_consts(const Consts& from_args) {
-  if constexpr (LV == 1) return SHIPPED_L0;
-  else if constexpr (LV == 2) return SHIPPED_L0_PLAIN;
+  if constexpr (LV == 1) return SHIPPED_1;
+  else if constexpr (LV == 2) return SHIPPED_2;
+  else if constexpr (LV == 3) return SHIPPED_3;
+  else if constexpr (LV == 4) return SHIPPED_4;
+  else if constexpr (LV == 6) return SHIPPED_6;
   else return from_args;
 }
 
@@ -629,7 +637,8 @@ template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP 
 __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void pcx_scrolly_maze_step(const Consts k_arg, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                   const crop::FusedCrops* fc_arg) {
-  static_assert(LV == 0 || (LV == 1 && PS == 3 && CODES) || (LV == 2 && COOP && !EPI), "baked constants: the persistent owner-code instance and the cooperative one");
+  static_assert(LV == 0 || ((LV == 1 || LV == 3) && PS == 3 && CODES) || ((LV == 2 || LV == 4 || LV == 6) && COOP && !EPI),
+                "compiled-in constants: odd LV = the persistent owner-code instance, even LV = the cooperative one");
   const Consts& k = baked_consts<LV>(k_arg);
   // Fused croppers (include/pcx.h pcx_engine_fuse_croppers): the instances that keep the frame as curtain
   // bit vectors + sprite descriptors (pcx_stream.h's contract) and render a group in the round they step it
@@ -1939,13 +1948,20 @@ class ScrollyMazeBackend : public Backend {
   }
   void set_plan_only() { plan_only_ = true; }
   const Consts& consts() const { return k_; }
-  // Are these launch-time Consts the baked ones (pcx_sm_shipped.h)?  PCX_SM_BAKED=0: never (A/B runs, tests of the other instance)
-  static bool baked_l0(const Consts& kk, const Consts& baked = SHIPPED_L0) {
-    if (!SHIPPED_L0_VALID) return false;
-    if (const char* e = getenv("PCX_SM_BAKED")) if (atoi(e) == 0) return false;
-    Consts x = kk;  // (the unit-dependent layout words travel as kernel arguments)
-    x.lds_ps_buf_words = baked.lds_ps_buf_words; x.lds_ps_words1 = baked.lds_ps_words1; x.lds_ps_wave_words = baked.lds_ps_wave_words;
-    return memcmp(&x, &baked, sizeof x) == 0;
+  // Which compiled-in instance (pcx_sm_shipped.h) has these launch-time Consts, word for word?  LV of the kernel, 0: none.
+  // `persistent`: the constants as the persistent shape launches them (odd LV) or as init() leaves them (even LV).
+  // PCX_SM_BAKED=0: never (A/B runs, tests of the run-time instance)
+  static int baked_lv(const Consts& kk, bool persistent) {
+    if (!SHIPPED_VALID) return 0;
+    if (const char* e = getenv("PCX_SM_BAKED")) if (atoi(e) == 0) return 0;
+    for (int lv = persistent ? 1 : 2; lv < N_BAKED; lv += 2) {
+      if (lv == 5) continue;
+      const Consts baked = consts_from_words(SHIPPED_WORDS[lv]);
+      Consts x = kk;  // (the unit-dependent layout words travel as kernel arguments)
+      x.lds_ps_buf_words = baked.lds_ps_buf_words; x.lds_ps_words1 = baked.lds_ps_words1; x.lds_ps_wave_words = baked.lds_ps_wave_words;
+      if (memcmp(&x, &baked, sizeof x) == 0) return lv;
+    }
+    return 0;
   }
   // the epilogue / fused croppers have no multi-step instance; small batches: the cooperative shape walks up to 256 steps
   // per launch; large batches of the shipped shape: the persistent workers walk up to 64 (a launch of 64 steps of
@@ -2368,10 +2384,12 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
       const stream::EpilogueArgs ep = stream::with_hwc_scratch(epi_, lds_e, coop_waves);
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, true>), dim3(coop_groups),
                          dim3(coop_waves * WAVE), lds_e, s, k_, P, ac, out, ep, fused_.ptr());
-    } else if (!fused_.on && baked_l0(k_, SHIPPED_L0_PLAIN))  // (round 5: config 2's latency-bound steps with the level's constants compiled in)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, false, 0, 2>), dim3(coop_groups),
-                         dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
-    else
+    } else if (const int lv = fused_.on ? 0 : baked_lv(k_, false)) {  // (round 5: config 2's latency-bound steps with the level's constants compiled in)
+#define PCX_SM_COOP_LV(n) hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, false, 0, n>), dim3(coop_groups), \
+                                             dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr())
+      if (lv == 2) PCX_SM_COOP_LV(2); else if (lv == 4) PCX_SM_COOP_LV(4); else PCX_SM_COOP_LV(6);
+#undef PCX_SM_COOP_LV
+    } else
       hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true>), dim3(coop_groups),
                          dim3(coop_waves * WAVE), (size_t)k_.lds_words * 4, s, k_, P, ac, out, epi_, fused_.ptr());
   } else if (shipped_shape && use_codes && ps_shape(a) == 3) {
@@ -2379,7 +2397,7 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     int unit = WAVE, per_cu = 3, dynamic = 1, waves = 2;
     if (const char* e = getenv("PCX_SM_UNIT")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) unit = v; }
     const Consts kk = ps_consts(unit);
-    const bool baked = baked_l0(kk);  // the instance with the level's constants compiled in steps a unit in ~9 us, the other in ~20
+    const int baked = baked_lv(kk, true);  // (LV) an instance with the level's constants compiled in steps a unit in ~9 us, the other in ~20
     const int64_t units64 = bpad_ / WAVE;
     if (!baked) {
       // (round 4) two workers per workgroup, one of them streaming.  Few units per worker (config 5's shard: 2,048 units): four
@@ -2430,6 +2448,8 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
                                     hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
         PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
+        PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_));
         raised = true;
       }
     }
@@ -2467,7 +2487,10 @@ int ScrollyMazeBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStr
     if (baked) {
       // the engine's Consts are the shipped level 0's, word for word: the instance that has them as compile-time constants
       last_shape_ = a.n_steps > 1 ? 13 : 5;  // (13: persistent workers walking several steps of the launch)
-      hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3, 1>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
+      if (baked == 1)
+        hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3, 1>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
+      else
+        hipLaunchKernelGGL((pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3, 3>), pgrid, dim3(waves * WAVE), lds_p, s, kk, P, a, out, epi_, fused_.ptr());
       tuner_.launched(s);
     } else {
       last_shape_ = a.n_steps > 1 ? 13 : 3;

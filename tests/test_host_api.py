@@ -280,16 +280,18 @@ def test_batched_story_last_assignment_of_next_chapter_wins():
 
 
 def test_baked_level_constants_header_is_what_the_library_plans():
-  """csrc/pcx_sm_shipped.h (the shipped scrolly_maze level 0's kernel constants, compiled into one instance of
+  """csrc/pcx_sm_shipped.h (the shipped scrolly_maze levels' kernel constants, compiled into instances of
   pcx_scrolly_maze_step) is generated from pcx_debug_scrolly_consts and committed: it must be what the library plans for
-  the golden template today, or the fast instance silently stops being used.  Other levels answer other words."""
+  the golden templates today, or the fast instances silently stop being used.  Every level answers its own words."""
   import importlib.util
   spec = importlib.util.spec_from_file_location('gen_sm_shipped', os.path.join(helpers.ROOT, 'tools', 'gen_sm_shipped.py'))
   gen = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(gen)
-  words = gen.planned_words()
-  assert gen.header_words() == words, 'run tools/gen_sm_shipped.py and rebuild libpcx.so'
-  assert open(gen.HEADER).read() == gen.render(words)
+  arrs = gen.arrays()
+  assert gen.header_arrays() == arrs, 'run tools/gen_sm_shipped.py and rebuild libpcx.so'
+  assert open(gen.HEADER).read() == gen.render(arrs)
+  assert len(set(tuple(w) for w in arrs.values())) == len(arrs) == 6  # three levels x {persistent, plain}: all different
+  words = arrs['PCX_SM_SHIPPED_L0_WORDS']
   t1 = helpers.load_template('scrolly_maze_L1')
   ct, _keep = t1.to_ctypes()
   buf = (ctypes.c_uint32 * len(words))()

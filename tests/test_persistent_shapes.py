@@ -199,17 +199,38 @@ def test_instance_with_the_shipped_levels_constants_compiled_in(baked, waves, lo
     assert int(orc.read('frame').min()) < T
 
 
-def test_other_levels_keep_the_run_time_constants():
-  """Level 1 has the shipped shape but other constants: the baked instance must not take it."""
+@pytest.mark.parametrize('baked', [1, 0])
+def test_shipped_level_1_has_its_own_compiled_in_instance(baked):
+  """Level 1 has the shipped shape and its own constants: its own compiled-in instances (persistent: launch shape 5 / 13),
+  PCX_SM_BAKED=0 keeps the run-time instance; both against the oracle."""
   t = helpers.load_template('scrolly_maze_L1')
+  B = 1500
+  with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=3, PCX_SM_GRID=4, PCX_SM_BAKED=baked):
+    hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+    hip.reset(); orc.reset()
+    for t0, n in ((0, 1), (1, 1), (2, 6), (8, 8), (16, 48)):
+      hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
+      assert raw_shape_of(hip) == (13 if n > 1 else 5 if baked else 3)
+      assert_same(hip, orc, 'level 1 after step %d' % (t0 + n))
+
+
+def test_a_level_of_ones_own_keeps_the_run_time_constants():
+  """The shipped level 0 with one patroller moved: the same shape, other constants -- no compiled-in instance may take it."""
+  t = helpers.load_template('scrolly_maze_L0')
+  t.sprites[0]['vcol'] += 2
   B = 1500
   with Knobs(PCX_COOP_BELOW=0, PCX_SM_SHAPE=3, PCX_SM_GRID=4):
     hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
     hip.reset(); orc.reset()
-    for t0 in range(0, 64, 8):
-      hip.step_hashed(0x5EED, t0, 8); orc.step_hashed(0x5EED, t0, 8)
-      assert raw_shape_of(hip) in (3, 13, 20)
-      assert_same(hip, orc, 'level 1 after step %d' % (t0 + 8))
+    for t0 in range(0, 48, 1):
+      hip.step_hashed(0x5EED, t0, 1); orc.step_hashed(0x5EED, t0, 1)
+      assert raw_shape_of(hip) == 3
+    assert_same(hip, orc, 'after 48 steps')
+  with Knobs(PCX_SM_BAKED=1):  # ... nor the cooperative one (small batch, default knobs): results are the oracle's either way
+    hip, orc = HipAdapter(t, 700), OracleAdapter(t, 700)
+    hip.reset(); orc.reset()
+    hip.step_hashed(0x5EED, 0, 40); orc.step_hashed(0x5EED, 0, 40)
+    assert_same(hip, orc, 'cooperative shape')
 
 
 def test_headline_batch_default_shape_equals_one_workgroup_per_group_shape_everywhere():
@@ -250,12 +271,12 @@ def test_headline_batch_default_shape_equals_one_workgroup_per_group_shape_every
 
 
 @pytest.mark.parametrize('baked', [1, 0])
-@pytest.mark.parametrize('B', [250, 4096, 16391])
-def test_cooperative_shape_with_the_levels_constants_compiled_in(B, baked):
+@pytest.mark.parametrize('B,level', [(250, 0), (4096, 0), (16391, 0), (3000, 1), (2000, 2)])
+def test_cooperative_shape_with_the_levels_constants_compiled_in(B, level, baked):
   """Small batches (BASELINE config 2): the cooperative instance also exists with the shipped level's constants compiled in
   (PCX_SM_BAKED=0: the instance that reads them from the kernel arguments); single launches and launches of several steps,
   16 / 32 / 64 environments per workgroup, against the oracle."""
-  t = helpers.load_template('scrolly_maze_L0')
+  t = helpers.load_template('scrolly_maze_L%d' % level)
   with Knobs(PCX_SM_BAKED=baked):
     hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
     hip.reset(); orc.reset()
@@ -265,8 +286,8 @@ def test_cooperative_shape_with_the_levels_constants_compiled_in(B, baked):
       if 'PCX_COOP_BELOW' not in os.environ or os.environ['PCX_COOP_BELOW'] not in ('0',):  # (a suite run with the cooperative shape forced off compares results only)
         assert raw_shape_of(hip) == (12 if n > 1 else 10)
       t0 += n
-      assert_same(hip, orc, 'B %d baked %d after step %d' % (B, baked, t0))
-    assert int(orc.read('frame').min()) < t0
+      assert_same(hip, orc, 'B %d level %d baked %d after step %d' % (B, level, baked, t0))
+    assert level == 2 or int(orc.read('frame').min()) < t0  # (level 2's patrollers are boxed in: nobody is caught within 198 steps)
 
 
 # ---- the kernels built on pcx_stream.h: persistent workers (round 5) ------------------------------------------------------
