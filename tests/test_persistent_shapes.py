@@ -26,7 +26,7 @@ class Knobs(object):
     self.kw = kw
 
   def __enter__(self):
-    self.saved = {k: os.environ.get(k) for k in KNOBS}
+    self.saved = {k: os.environ.get(k) for k in set(KNOBS) | set(self.kw)}  # (every knob this block sets is restored, listed above or not)
     for k, v in self.kw.items():
       os.environ[k] = str(v)
     return self
