@@ -401,7 +401,7 @@ def main():
   from pycolab import ascii_art as ref_art
   from pycolab.tests import test_things as tt
   names = walker_scenarios.MOTION_NAMES
-  seeds = {'walkers_room': 51, 'walkers_scroll_always': 52, 'walkers_scroll_margins': 53, 'walkers_scroll_groups': 54}
+  seeds = {'walkers_room': 51, 'walkers_scroll_always': 52, 'walkers_scroll_margins': 53, 'walkers_scroll_groups': 54, 'walkers_hidden': 55}
   for name, spec in sorted(walker_scenarios.SCENARIOS.items()):
     i = seeds[name] - 51  # fixed per scenario: adding a scenario must not move the others' tapes
     if spec['kind'] == 'scroll2':  # two scrolling groups, one action field each

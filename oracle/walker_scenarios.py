@@ -52,6 +52,15 @@ SCENARIOS = {
                  'Q': dict(impassable='', confined=True, field=(4, 15)),
                  'x': dict(impassable='wP', field=(8, 15))},
         schedule=[['P'], ['Q', 'x']], z_order='xQP', n_fields=3),
+    # the same room with Q made INVISIBLE by its constructor and free to leave the board: what comes back on re-entry is
+    # the visibility saved at the exit (sprites.py:223-275), not "visible" -- the one quirk of MazeWalker no other
+    # fixture pinned (found by oracle/mutants.py: the mutant `re_entry_always_visible` survived every fixture)
+    'walkers_hidden': dict(
+        kind='room', art=ROOM, beneath=' ',
+        walkers={'P': dict(impassable='w', field=(0, 15)),
+                 'Q': dict(impassable='', field=(4, 15), hidden=True),
+                 'x': dict(impassable='wP', field=(8, 15))},
+        schedule=[['P'], ['Q', 'x']], z_order='xQP', n_fields=3),
     # Scrolly with margins, one egocentric walker, one wanderer; one shared action
     'walkers_scroll_margins': dict(
         kind='scroll', world=WORLD, board=(7, 11), mark='+', beneath=' ',
@@ -94,7 +103,7 @@ def build(spec, ascii_art, walker_cls, scrolly_cls, use_fields):
       kw = dict(impassable=w['impassable'], confined_to_board=w.get('confined', False))
       if use_fields:
         kw['action_field'] = w['field']
-      sprites[ch] = P(walker_cls, **kw)
+      sprites[ch] = P(_hidden(walker_cls) if w.get('hidden') else walker_cls, **kw)
     return ascii_art.ascii_art_to_game(spec['art'], spec['beneath'], sprites=sprites,
                                        update_schedule=spec['schedule'], z_order=spec['z_order'])
   if spec['kind'] == 'scroll2':
@@ -139,6 +148,20 @@ def _positioned(walker_cls):
     Positioned.__name__ = 'Positioned' + walker_cls.__name__
     _CACHE[walker_cls] = Positioned
   return _CACHE[walker_cls]
+
+
+def _hidden(walker_cls):
+  """walker_cls, but invisible from its construction on (things.py:309-319: `_visible` is the sprite's to set)."""
+  key = (walker_cls, 'hidden')
+  if key not in _CACHE:
+    class Hidden(walker_cls):
+
+      def __init__(self, corner, position, character, **kwargs):
+        super(Hidden, self).__init__(corner, position, character, **kwargs)
+        self._visible = False
+    Hidden.__name__ = 'Hidden' + walker_cls.__name__
+    _CACHE[key] = Hidden
+  return _CACHE[key]
 
 
 MOTION_NAMES = ['n', 'ne', 'e', 'se', 's', 'sw', 'w', 'nw', 'stay']

@@ -17,7 +17,7 @@ from pycolab_amd import _native as N
 from tests import helpers
 
 GENERIC = ['warehouse_L0', 'warehouse_L2', 'warehouse_custom_B', 'warehouse_L0_unoccluded', 'marauders', 'marauders_custom_A',
-           'marauders_unoccluded', 'walkers_room', 'walkers_scroll_groups', 'walkers_scroll_always', 'walkers_scroll_margins',
+           'marauders_unoccluded', 'walkers_room', 'walkers_hidden', 'walkers_scroll_groups', 'walkers_scroll_always', 'walkers_scroll_margins',
            'directives_z_order', 'directives_reward_discount', 'hello_world', 'hello_custom_A', 'better_scrolly_maze_L1',
            'better_scrolly_custom_B']
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 LEVELS = ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2']
 ALL_GAMES = LEVELS + ['warehouse_L0', 'warehouse_L1', 'warehouse_L2', 'hello_world', 'marauders',
                       'scrolly_maze_L1_unoccluded', 'warehouse_L0_unoccluded', 'marauders_unoccluded',
-                      'walkers_room', 'walkers_scroll_margins', 'walkers_scroll_always', 'walkers_scroll_groups',
+                      'walkers_room', 'walkers_hidden', 'walkers_scroll_margins', 'walkers_scroll_always', 'walkers_scroll_groups',
                       'better_scrolly_maze_L0', 'better_scrolly_maze_L1', 'better_scrolly_maze_L2',
                       # the step kernel's shape-generic instances (oracle/custom_levels.py)
                       'scrolly_custom_A', 'scrolly_custom_B', 'scrolly_custom_C', 'scrolly_custom_D', 'scrolly_custom_E',

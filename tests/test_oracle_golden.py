@@ -15,7 +15,7 @@ class OracleAdapter(binding.OracleEngine):
 
 ALL_TRACES = ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2', 'warehouse_L0', 'warehouse_L1',
               'warehouse_L2', 'hello_world', 'marauders', 'scrolly_maze_L1_unoccluded',
-              'warehouse_L0_unoccluded', 'marauders_unoccluded', 'walkers_room',
+              'warehouse_L0_unoccluded', 'marauders_unoccluded', 'walkers_room', 'walkers_hidden',
               'walkers_scroll_margins', 'walkers_scroll_always', 'walkers_scroll_groups', 'better_scrolly_maze_L0',
               'better_scrolly_maze_L1', 'better_scrolly_maze_L2',
               # unshipped scrolly_maze levels (oracle/custom_levels.py): other board shapes, sprite sets, z-orders

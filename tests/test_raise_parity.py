@@ -81,6 +81,31 @@ def test_numpy_oracle_to_array_raises_where_the_reference_raised():
   assert len(set(first.tolist())) > 5  # (the frames differ from environment to environment)
 
 
+def test_oracle_fixed_cropper_without_pad_raises_where_the_reference_does():
+  """cropping.py:175-183: the window of the fixture leaves the board and there is no pad character -- the reference
+  raised (fix['raises']); the oracle flags every environment, and neither the window inside the board nor the padded
+  one (oracle/mutants.py `crop_overhang_never_raises` survived every fixture before this test)."""
+  from pycolab_amd import cropping
+  fix = load('fixed_crop_overhang')
+  assert int(fix['raises'][0]) == 1
+  corner, rows, cols = tuple(int(x) for x in fix['corner']), int(fix['rows'][0]), int(fix['cols'][0])
+  orc = binding.OracleEngine(helpers.load_template('scrolly_maze_L0'), 3)
+  orc.reset()
+  over = binding.OracleCropper(orc, cropping.FixedCropper(corner, rows, cols, None))
+  inside = binding.OracleCropper(orc, cropping.FixedCropper((2, 3), 5, 7, None))
+  padded = binding.OracleCropper(orc, cropping.FixedCropper(corner, rows, cols, ' '))
+  assert over.crop()[1].all()
+  assert not inside.crop()[1].any()
+  window, err = padded.crop()
+  assert not err.any()
+  board = np.array(orc.planes)[:, 0]
+  r0, c0 = corner
+  want = np.full((3, rows, cols), ord(' '), np.uint8)
+  rs, cs = slice(max(r0, 0), min(r0 + rows, board.shape[1])), slice(max(c0, 0), min(c0 + cols, board.shape[2]))
+  want[:, rs.start - r0:rs.stop - r0, cs.start - c0:cs.stop - c0] = board[:, rs, cs]
+  np.testing.assert_array_equal(window[:, 0], want)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', WALKERS)
 def test_hip_error_bit_rises_where_the_reference_raised(name):
