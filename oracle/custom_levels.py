@@ -129,13 +129,35 @@ WAREHOUSE_ART = {
                            '........'],
 }
 WAREHOUSE_NAMES = sorted(WAREHOUSE_ART)
-for _name, _art in WAREHOUSE_ART.items():
+# Warehouses WITHOUT walls around them, as RAISE fixtures only (oracle/gen_raise_golden.py; no golden trace: sooner or
+# later a box reaches the last row or column and `layers['P'][row + 1, col]` is an IndexError, warehouse_manager.py:219-226).
+# What they pin before that: numpy's NEGATIVE indices.  A box in row 0 asked to go south looks for the player at
+# `layers['P'][-1, col]` -- the LAST row -- and in open_A the player starts exactly there: the box moves, pushed from the
+# other side of the board (open_B: the same across the columns).  Boxes and player also walk off the open board
+# (MazeWalkers are unconfined by default): a box out there has position (0, 0) for the Judge (warehouse_manager.py:248-250),
+# which is a goal cell here.  (oracle/mutants.py: `negative_indices_do_not_wrap` survived every other fixture.)
+WAREHOUSE_OPEN_ART = {
+    'warehouse_open_A': ['_  1   _',
+                         '     2  ',
+                         ' _      ',
+                         '3    _  ',
+                         '    4   ',
+                         '_  P   _'],
+    'warehouse_open_B': ['_   _  ',
+                         '  3    ',
+                         '1     P',
+                         '   _ 2 ',
+                         ' 4     ',
+                         '_     _'],
+}
+WAREHOUSE_OPEN_NAMES = sorted(WAREHOUSE_OPEN_ART)
+for _name, _art in list(WAREHOUSE_ART.items()) + list(WAREHOUSE_OPEN_ART.items()):
   assert len(set(len(_row) for _row in _art)) == 1, _name
 
 
 def make_warehouse(name, example, ascii_art):
   """warehouse_manager.make_game (warehouse_manager.py:139-178) for WAREHOUSE_ART[name]."""
-  art = WAREHOUSE_ART[name]
+  art = WAREHOUSE_ART.get(name) or WAREHOUSE_OPEN_ART[name]
   boxes = [c for c in '1234567890' if c in ''.join(art)]
   sprites = {c: example.BoxSprite for c in boxes}
   sprites['P'] = example.PlayerSprite
@@ -219,12 +241,16 @@ def make_hello(name, example, ascii_art):
 BETTER_SPECS = {
     'better_scrolly_custom_A': (201, 17, 38),
     'better_scrolly_custom_B': (202, 12, 20),
+    # (seed, rows, cols, coins kept): a small board with only the two coins nearest the player, so that tapes collect
+    # them ALL -- "no coins left ends the episode" (better_scrolly_maze.py:317-320) is pinned by no other fixture
+    # (oracle/mutants.py: `better_last_coin_does_not_end_the_episode` survived)
+    'better_scrolly_custom_C': (203, 9, 14, 2),
 }
 BETTER_NAMES = sorted(BETTER_SPECS)
 
 
 def better_art(name):
-  seed, rows, cols = BETTER_SPECS[name]
+  seed, rows, cols = BETTER_SPECS[name][:3]
   rng = np.random.RandomState(seed)
   art = np.full((rows, cols), ' ', dtype='<U1')
   art[0, :] = art[-1, :] = art[:, 0] = art[:, -1] = '#'
@@ -239,6 +265,11 @@ def better_art(name):
         break
     else:
       raise RuntimeError('no room for sprite ' + ch)
+  if len(BETTER_SPECS[name]) > 3:  # only the coins nearest the player stay
+    (pr,), (pc,) = np.nonzero(art == 'P')
+    coins = sorted(zip(*np.nonzero(art == '@')), key=lambda rc: (abs(rc[0] - pr) + abs(rc[1] - pc), rc))
+    for r, c in coins[BETTER_SPECS[name][3]:]:
+      art[r, c] = ' '
   return [''.join(row) for row in art]
 
 

@@ -385,7 +385,7 @@ def main():
     run(name, lambda: bsm.make_game(level), E=12, T=160, n_ordinary=5, quit_action=5, seed=61 + level,
         template_name=name)
   for i, name in enumerate(custom_levels.BETTER_NAMES):  # boards without a compiled kernel instance, with croppers
-    rows, cols = custom_levels.BETTER_SPECS[name][1:]
+    rows, cols = custom_levels.BETTER_SPECS[name][1:3]
     CROPPERS[name] = [S(7, 11, 'P', None, (2, 3)), S(5, 9, 'bP', ' ', (None, None), (1, -2)),
                       F((rows - 4, cols - 6), 6, 10, '#')]
     run(name, lambda: custom_levels.make_better_scrolly(name, bsm, ref_ascii_art), E=12, T=160, n_ordinary=5,

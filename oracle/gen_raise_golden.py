@@ -33,7 +33,9 @@ warnings.filterwarnings('ignore', category=DeprecationWarning)
 from oracle import binding, ref_live, walker_scenarios  # noqa: E402
 
 SEED = 0x5EED
-KINDS = {'IndexError': 1, 'Error': 2, 'RuntimeError': 2}  # -> pcx error bits (pcx_device.h ERR_INDEX / ERR_SCROLL)
+# -> pcx error bits (pcx_device.h ERR_INDEX / ERR_SCROLL).  ValueError: a Scrolly ordered beyond its own pattern --
+# np.copyto cannot broadcast the clamped slice (drapes.py:689-695); the engine files it with the index errors.
+KINDS = {'IndexError': 1, 'ValueError': 1, 'Error': 2, 'RuntimeError': 2}
 
 
 def out_path(name):
@@ -46,7 +48,7 @@ def walkers(name, E, T):
   from pycolab import ascii_art as ref_art
   from pycolab.tests import test_things as tt
   from pycolab_amd.compiler import GameTemplate
-  spec = walker_scenarios.SCENARIOS[name]
+  spec = walker_scenarios.SCENARIOS.get(name) or walker_scenarios.RAISING_SCENARIOS[name]
   n_actions = GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', name + '.npz')).n_actions
   names = walker_scenarios.MOTION_NAMES
   if spec['kind'] == 'scroll2':
@@ -81,6 +83,54 @@ def walkers(name, E, T):
                       raise_type=np.frombuffer('\n'.join(raise_type).encode(), np.uint8))
   print('%s: %d of %d environments raised within %d steps (%s)' % (name, int((raise_frame >= 0).sum()), E, T,
                                                                      sorted(set(k for k in raise_type if k))), flush=True)
+
+
+def warehouse_open(name, E, T):
+  """An unwalled warehouse (oracle/custom_levels.py WAREHOUSE_OPEN_ART) on the hashed tape, episodes restarted the way
+  the batched engines restart them (a finished environment is rebuilt at the next step), until the reference raises."""
+  from pycolab import ascii_art as ref_art
+  from pycolab.examples import warehouse_manager
+  from oracle import custom_levels
+  from pycolab_amd.compiler import GameTemplate
+  n_actions = GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', name + '.npz')).n_actions
+  make = lambda: custom_levels.make_warehouse(name, warehouse_manager, ref_art)
+  boards, raise_frame, raise_bit, raise_type = None, np.full(E, -1, np.int32), np.zeros(E, np.uint8), []
+  episodes = wrapped = 0
+  for e in range(E):
+    game = make()
+    obs, _, _ = game.its_showtime()
+    if boards is None:
+      boards = np.zeros((T + 1, E) + obs.board.shape, np.uint8)
+    boards[0, e] = obs.board
+    kind = ''
+    for t in range(T):
+      try:
+        if game.game_over:
+          game = make()
+          obs, _, _ = game.its_showtime()
+          episodes += 1
+        else:
+          a = int(binding.action_hash(SEED, e, t) % n_actions)
+          # (statistics only: a box in row / column 0 that looks for the player at index -1 and finds it)
+          for c, box in game.things.items():
+            if c.isdigit() and box.visible:
+              r, col = box.position
+              P = game.things['P']
+              if P.visible and ((a == 1 and r == 0 and tuple(P.position) == (obs.board.shape[0] - 1, col)) or
+                                (a == 3 and col == 0 and tuple(P.position) == (r, obs.board.shape[1] - 1))):
+                wrapped += 1
+          obs, _, _ = game.play(a)
+      except Exception as ex:  # pylint: disable=broad-except
+        kind = type(ex).__name__
+        raise_frame[e], raise_bit[e] = t + 1, KINDS[kind]
+        break
+      boards[t + 1, e] = obs.board
+    raise_type.append(kind)
+  np.savez_compressed(out_path(name), template=np.frombuffer(name.encode(), np.uint8), seed=np.array([SEED], np.uint64),
+                      boards=boards, raise_frame=raise_frame, raise_bit=raise_bit,
+                      raise_type=np.frombuffer('\n'.join(raise_type).encode(), np.uint8))
+  print('%s: %d of %d environments raised within %d steps (%s); %d episodes restarted, %d pushes through index -1'
+        % (name, int((raise_frame >= 0).sum()), E, T, sorted(set(k for k in raise_type if k)), episodes, wrapped), flush=True)
 
 
 def marauders_to_array(E, T):
@@ -137,8 +187,10 @@ def fixed_crop_overhang():
 
 
 def main():
-  for name in ('walkers_scroll_always', 'walkers_scroll_margins', 'walkers_scroll_groups', 'walkers_room'):
+  for name in ('walkers_scroll_always', 'walkers_scroll_margins', 'walkers_scroll_groups', 'walkers_room', 'walkers_scroll_disagree'):
     walkers(name, E=128, T=320)
+  for name in ('warehouse_open_A', 'warehouse_open_B'):
+    warehouse_open(name, E=96, T=256)
   marauders_to_array(E=32, T=96)
   fixed_crop_overhang()
 

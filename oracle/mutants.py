@@ -9,7 +9,7 @@ changed), `loaded()` swaps the library in under oracle.binding, and tests/test_o
 fixtures named in `killed_by` to FAIL on it (and, for the mutant the shipped levels cannot tell apart,
 `survives` to pass: DESIGN.md section 2).
 
-  python -m oracle.mutants            prints the whole kill matrix (every mutant x every fixture; minutes)
+  python -m oracle.mutants [name ...]   prints the kill matrix (every mutant, or those named, x every fixture; minutes)
 
 Never imported by the product package.
 """
@@ -27,9 +27,13 @@ SOURCES = ['pcx_oracle.c', 'pcx_oracle_crop.c']
 
 class Mutant(object):
 
-  def __init__(self, name, cite, source, old, new, killed_by, survives=()):
+  def __init__(self, name, cite, source, old, new, killed_by, survives=(), equivalent=None):
     self.name, self.cite, self.source, self.old, self.new = name, cite, source, old, new
     self.killed_by, self.survives = tuple(killed_by), tuple(survives)
+    # why NO fixture can tell it apart (then killed_by is empty): the mutated line restates the reference faithfully,
+    # but through the reference's own entities its other reading can never be observed
+    self.equivalent = equivalent
+    assert bool(self.killed_by) != bool(equivalent), name
 
 
 # fixture ids: 'trace:<name>' (tests/golden/traces, test_oracle_golden), 'crop:<name>' (the croppers recorded with a
@@ -139,6 +143,279 @@ MUTANTS = [
            'initialise(c, corner, 1, crow, ccol, rows / 2, cols / 2);',
            'initialise(c, corner, 1, crow, ccol, rows / 2 + c->d.initial_offset_rows, cols / 2 + c->d.initial_offset_cols);',
            killed_by=['reftest:testScrollingInitialOffset_0', 'crop:better_scrolly_maze_L1']),
+    # ---- second batch ---------------------------------------------------------------------------------------------
+    Mutant('permits_from_before_the_move', 'prefab_parts/sprites.py:356-389: the permits for the next frame are worked out AFTER the move',
+           'pcx_oracle.c',
+           '  if (!blocked) mw_teleport(e, s, s->vrow + dr, s->vcol + dc); /* _raw_move :391-411 */\n  mw_update_permits(e, env, id, board);',
+           '  mw_update_permits(e, env, id, board);\n  if (!blocked) mw_teleport(e, s, s->vrow + dr, s->vcol + dc);',
+           killed_by=['reftest:testScrolly_0', 'reftest:testScrolly_1']),
+    Mutant('permits_last_forever', 'protocols/scrolling.py:437-485: a permit counts only in the frame it was given for',
+           'pcx_oracle.c',
+           'if (!p->permit_frame_valid[id] || p->permit_frame[id] != p->frame) return 0;',
+           'if (!p->permit_frame_valid[id]) return 0;',
+           killed_by=['crop:scrolly_maze_L0', 'trace:scrolly_custom_A']),
+    Mutant('stale_permits_accumulate', 'protocols/scrolling.py:418-431: permits of an older frame are dropped before the new ones are added',
+           'pcx_oracle.c',
+           '    p->permit_frame[id] = my_frame;\n    p->permit_mask[id] = 0;',
+           '    p->permit_frame[id] = my_frame;',
+           killed_by=['crop:scrolly_maze_L0', 'trace:scrolly_custom_A']),
+    Mutant('orders_last_forever', 'protocols/scrolling.py:339-369: an order is obeyed only in the frame it was issued in',
+           'pcx_oracle.c',
+           'if (!p->sg[p->cur].order_frame_valid || p->sg[p->cur].order_frame != p->frame) return 0;',
+           'if (!p->sg[p->cur].order_frame_valid) return 0;',
+           killed_by=['reftest:testScrolly_0', 'reftest:testScrolly_1']),
+    Mutant('always_scroll_needs_both_axes', 'prefab_parts/drapes.py:551-585: without margins each axis scrolls if IT can',
+           'pcx_oracle.c',
+           'int o0 = can_v ? dr : 0, o1 = can_h ? dc : 0;\n      s->corner[0] += o0;',
+           'int o0 = can_v && can_h ? dr : 0, o1 = can_v && can_h ? dc : 0;\n      s->corner[0] += o0;',
+           killed_by=['reftest:testScrolly_1', 'raise:walkers_scroll_always']),
+    Mutant('margin_reached_one_cell_later', 'prefab_parts/drapes.py:661-687: a sprite burrows when it steps ONTO the margin line',
+           'pcx_oracle.c',
+           '*vert = (old_r > new_r && new_r <= margin_north) || (old_r < new_r && new_r >= margin_south);',
+           '*vert = (old_r > new_r && new_r < margin_north) || (old_r < new_r && new_r > margin_south);',
+           killed_by=['reftest:testScrolly_0', 'crop:scrolly_maze_L0']),
+    Mutant('margins_measured_from_virtual_positions', 'prefab_parts/drapes.py:661-687: margins look at the sprite\'s TRUE position',
+           'pcx_oracle.c',
+           'int old_r = sp->row, old_c = sp->col, new_r = old_r + dr, new_c = old_c + dc;',
+           'int old_r = sp->vrow, old_c = sp->vcol, new_r = old_r + dr, new_c = old_c + dc;',
+           killed_by=['trace:scrolly_custom_F', 'trace:walkers_scroll_groups']),
+    Mutant('margin_scroll_needs_every_axis_free', 'prefab_parts/drapes.py:620-659: only the axes that burrow are ordered',
+           'pcx_oracle.c',
+           'int o0 = vert ? dr : 0, o1 = horiz ? dc : 0;\n  int pr',
+           'int o0 = dr, o1 = dc;\n  int pr',
+           killed_by=['reftest:testScrolly_0', 'trace:walkers_scroll_margins']),
+    Mutant('patroller_sees_the_wall_after_the_scroll', 'examples/scrolly_maze.py:295-296: pattern_position_PRESCROLL',
+           'pcx_oracle.c',
+           '  out[0] = vr + s->prescroll[0];\n  out[1] = vc + s->prescroll[1];',
+           '  out[0] = vr + s->corner[0];\n  out[1] = vc + s->corner[1];',
+           killed_by=['crop:scrolly_maze_L0', 'trace:scrolly_custom_A']),
+    Mutant('patroller_moves_on_odd_frames', 'examples/scrolly_maze.py:288-290: stays put on odd frames',
+           'pcx_oracle.c',
+           '  if (env->plot.frame % 2) { /* :288-290 (Python %, frame >= 0) */',
+           '  if (!(env->plot.frame % 2)) {',
+           killed_by=['crop:scrolly_maze_L0', 'trace:scrolly_custom_A']),
+    Mutant('last_coin_does_not_end_the_episode', 'examples/scrolly_maze.py:347-351: no coins left -> terminate_episode',
+           'pcx_oracle.c',
+           '    for (size_t i = 0; i < (size_t)d->pattern_rows * d->pattern_cols; ++i) any |= s->pattern[i];\n    if (!any) plot_terminate(&env->plot, 0.0f);',
+           '',
+           killed_by=['trace:scrolly_custom_C', 'trace:scrolly_custom_C_unoccluded']),
+    Mutant('cash_quit_forgotten', 'examples/scrolly_maze.py:363-364: action 5 quits',
+           'pcx_oracle.c',
+           '  else if (x->action == 5) plot_terminate(&env->plot, 0.0f); /* :363-364 */',
+           '',
+           killed_by=['crop:scrolly_maze_L0', 'trace:scrolly_custom_A']),
+    Mutant('better_patroller_turns_the_other_way_in_a_corridor', 'examples/better_scrolly_maze.py:291-294: a wall on both sides: west wins',
+           'pcx_oracle.c',
+           "  if (layer_char_at(x, '#', row, col - 1)) s->var[0] = 1;\n  if (layer_char_at(x, '#', row, col + 1)) s->var[0] = 0;",
+           "  if (layer_char_at(x, '#', row, col + 1)) s->var[0] = 0;\n  if (layer_char_at(x, '#', row, col - 1)) s->var[0] = 1;",
+           killed_by=[],
+           equivalent='walls do not move in better_scrolly_maze: a patroller with a wall on both sides is stuck for good, and which way it would like to go is never seen'),
+    Mutant('better_last_coin_does_not_end_the_episode', 'examples/better_scrolly_maze.py:317-320',
+           'pcx_oracle.c',
+           '    for (int i = 0; i < cells(e); ++i) any |= d->curtain[i];\n    if (!any) plot_terminate(&env->plot, 0.0f);',
+           '',
+           killed_by=['trace:better_scrolly_custom_C']),
+    Mutant('box_pushed_by_the_board_not_the_layer', 'examples/warehouse_manager.py:219-226: the box looks for P one cell BEHIND it',
+           'pcx_oracle.c',
+           "case 0: if (layer_at(x, 'P', r + 1, c)) mw_move(x->e, x->env, id, x->board, -1, 0); break;",
+           "case 0: if (layer_at(x, 'P', r - 1, c)) mw_move(x->e, x->env, id, x->board, -1, 0); break;",
+           killed_by=['crop:warehouse_L1', 'crop:warehouse_custom_C']),
+    Mutant('warehouse_never_solved', 'examples/warehouse_manager.py:264-266: all boxes on goals -> terminate_episode',
+           'pcx_oracle.c',
+           'if (x->action == 5 || on_goals == num_boxes) plot_terminate(&env->plot, 0.0f);',
+           'if (x->action == 5) plot_terminate(&env->plot, 0.0f);',
+           killed_by=['trace:warehouse_custom_A', 'trace:warehouse_custom_D']),
+    Mutant('marauders_never_land', 'examples/extraterrestrial_marauders.py:151-152: a marauder in row 10 ends the episode',
+           'pcx_oracle.c',
+           'if (total == 0 || row10) { plot_terminate(&env->plot, 0.0f); return; } /* :151-152 */',
+           'if (total == 0) { plot_terminate(&env->plot, 0.0f); return; }',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('marauders_turn_without_descending', 'examples/extraterrestrial_marauders.py:160-162: at the edge: turn AND one row down',
+           'pcx_oracle.c',
+           '    for (int r = 0; r < R; ++r) memcpy(tmp + ((r + 1) % R) * C, d->curtain + r * C, C);\n    memcpy(d->curtain, tmp, n);',
+           '',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('bolt_flies_before_it_hits', 'examples/extraterrestrial_marauders.py:240-246: the hit is tested at the position BEFORE the move',
+           'pcx_oracle.c',
+           '    if (s->row == P->row && s->col == P->col) plot_terminate(&env->plot, 0.0f);\n    mw_move(e, env, id, x->board, 1, 0);',
+           '    mw_move(e, env, id, x->board, 1, 0);\n    if (s->row == P->row && s->col == P->col) plot_terminate(&env->plot, 0.0f);',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('down_bolt_starts_on_the_marauder', 'examples/extraterrestrial_marauders.py:253-256: one row BELOW the lowest marauder of the column',
+           'pcx_oracle.c',
+           '    mw_teleport(e, s, row + 1, col);',
+           '    mw_teleport(e, s, row, col);',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('spent_bolt_keeps_flying', 'examples/extraterrestrial_marauders.py:206-209: a bolt that hit something retires off the board',
+           'pcx_oracle.c',
+           '    if ((env->plot.kv[EM_BUNKER_HITTERS] >> id) & 1) { mw_teleport(e, s, -1, -1); return; }',
+           '',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('hello_world_rolls_the_other_way', 'examples/hello_world.py:84-89',
+           'pcx_oracle.c',
+           'static const int AX[4] = {0, 0, 1, 1}, SH[4] = {-1, 1, -1, 1};',
+           'static const int AX[4] = {0, 0, 1, 1}, SH[4] = {1, -1, 1, -1};',
+           killed_by=['trace:hello_custom_A', 'trace:hello_world']),
+    Mutant('default_discount_zero', 'plot.py:343-353: the discount of an ordinary step is 1.0',
+           'pcx_oracle.c',
+           '  p->discount = 1.0f;\n  p->game_over = 0;',
+           '  p->discount = 0.0f;\n  p->game_over = 0;',
+           killed_by=['engine_test:reward', 'trace:better_scrolly_custom_A']),
+    Mutant('second_reward_replaces_the_first', 'plot.py:200-226: rewards of one step ADD UP',
+           'pcx_oracle.c',
+           '  else p->reward += r;',
+           '  else p->reward = r;',
+           killed_by=['engine_test:reward', 'trace:directives_reward_discount']),
+    Mutant('invisible_sprites_painted', 'engine.py:751-757: only visible sprites are painted',
+           'pcx_oracle.c',
+           '      if (!s->visible) continue;',
+           '',
+           killed_by=['reftest:testNotConfinedToBoard_0', 'reftest:testScrolly_0']),
+    Mutant('showtime_skips_the_first_repaint', 'engine.py:578: a repaint BEFORE the first play(None)',
+           'pcx_oracle.c',
+           '  render(e, b);                          /* :578 */',
+           '',
+           killed_by=['crop:better_scrolly_custom_B', 'crop:marauders']),
+    Mutant('unoccluded_sprite_layers_cleared', 'rendering.py:187-301: unoccluded layers hold the raw masks',
+           'pcx_oracle.c',
+           '      if (!occl) env_layer(e, b, char_index(e, e->t.sprites[id].ch))[s->row * C + s->col] = 1;',
+           '',
+           killed_by=['trace:scrolly_custom_A_unoccluded', 'trace:scrolly_custom_C_unoccluded']),
+    Mutant('median_takes_the_lower_middle', 'cropping.py:598: int(np.median(...)) of an even count is the truncated MEAN of the two middle values',
+           'pcx_oracle.c',
+           '  return (int)((v[n / 2 - 1] + v[n / 2]) / 2.0);',
+           '  return v[n / 2 - 1];',
+           killed_by=['crop:marauders', 'crop:scrolly_maze_L0']),
+    Mutant('both_axes_get_the_edge_exception', 'cropping.py:491-504: `elif`: the horizontal exception only if the vertical test already passed',
+           'pcx_oracle_crop.c',
+           '        } else if (!can_horiz) {',
+           '        }\n        if (!can_horiz) {',
+           killed_by=[],
+           equivalent='both exceptions at once need the window in a corner of the board with the centroid inside both margins towards that corner: panning, not panning and a saccade all end, rectified, in that same corner'),
+    Mutant('pad_layers_all_zero', 'cropping.py:190-191: the layer of the pad character is True where the window is padding',
+           'pcx_oracle_crop.c',
+           'memset(out + (size_t)(1 + k) * n, c->d.pad_char == pcxo__char(e, k), n); /* :190-191 */',
+           'memset(out + (size_t)(1 + k) * n, 0, n);',
+           killed_by=['crop:better_scrolly_custom_A', 'crop:better_scrolly_custom_B']),
+    Mutant('unpadded_window_not_rectified', 'cropping.py:539-542: without padding the window is pushed back onto the board',
+           'pcx_oracle_crop.c',
+           '        corner[1] = wcol + dcol;\n        if (c->d.pad_char < 0) rectify(c, corner);',
+           '        corner[1] = wcol + dcol;',
+           killed_by=['reftest:testEgocentricScrolling_0', 'reftest:testEgocentricScrolling_1']),
+    Mutant('window_keeps_its_corner_over_episodes', 'cropping.py:378-391: set_engine() forgets the window',
+           'pcx_oracle_crop.c',
+           '    if (pcxo__frame(e, b) == 0) c->has_corner[b] = 0; /* a new episode == a new Engine */',
+           '',
+           killed_by=['crop:better_scrolly_custom_A', 'crop:better_scrolly_custom_B']),
+    Mutant('saccade_whenever_panning_fails', 'cropping.py:414-415: only croppers made with saccade=True jump',
+           'pcx_oracle_crop.c',
+           '      } else if (c->d.saccade) { /* :414-415 */',
+           '      } else if (1) {',
+           killed_by=['reftest:testScrollingInitialOffset_0', 'reftest:testScrollingSaccade_0']),
+    # ---- third batch ----------------------------------------------------------------------------------------------
+    Mutant('leaving_the_board_keeps_the_sprite_visible', 'prefab_parts/sprites.py:223-275: off the board a walker is invisible',
+           'pcx_oracle.c',
+           'if (old_on && !new_on) { s->prior_visible = s->visible; s->visible = 0; }',
+           'if (old_on && !new_on) { s->prior_visible = s->visible; }',
+           killed_by=['reftest:testNotConfinedToBoard_0', 'reftest:testScrollingSaccade_0']),
+    Mutant('permit_from_a_stranger_accepted', 'protocols/scrolling.py:406-410: permit() from a non-participant raises',
+           'pcx_oracle.c',
+           'if (!(p->sg[p->cur].egocentrists & (1u << id))) return OX_ERR_SCROLL; /* :406-410 */',
+           '',
+           killed_by=[],
+           equivalent='unreachable through the prefabs: only egocentric MazeWalkers call permit(), and _obey_scrolling_order registers them first (sprites.py:413-477)'),
+    Mutant('second_order_of_a_frame_accepted', 'protocols/scrolling.py:519-524: a second order in one frame raises',
+           'pcx_oracle.c',
+           'if (p->sg[p->cur].order_frame_valid && p->sg[p->cur].order_frame == p->frame) return OX_ERR_SCROLL;',
+           '',
+           killed_by=[],
+           equivalent='unreachable through the prefabs: a Scrolly looks for an existing order before it issues one (drapes.py:523-535), so a group sees one order() per frame'),
+    Mutant('scrolly_follows_any_order', 'prefab_parts/drapes.py:523-535: a Scrolly whose own motion shares no axis with the order raises',
+           'pcx_oracle.c',
+           'if (dr != order[0] && dc != order[1]) { env->error |= OX_ERR_SCROLL; return; }',
+           '',
+           killed_by=['raise:walkers_scroll_disagree']),
+    Mutant('negative_indices_do_not_wrap', 'numpy indexing: pattern[r, c] with c == -1 reads the last column',
+           'pcx_oracle.c',
+           '  if (i < 0) i += n;\n',
+           '',
+           killed_by=['raise:warehouse_open_A', 'raise:warehouse_open_B']),
+    Mutant('bunker_hits_cost_nothing', 'examples/extraterrestrial_marauders.py:113-120: -1 per eroded bunker cell',
+           'pcx_oracle.c',
+           '  plot_add_reward(&x->env->plot, -hits);',
+           '  if (hits) plot_add_reward(&x->env->plot, -hits);',
+           killed_by=[],
+           equivalent="masked: MarauderDrape adds its own (possibly zero) reward every frame, so the step's reward is never None either way"),
+    Mutant('hitters_are_all_bolts_on_the_cell', 'examples/extraterrestrial_marauders.py:118: the_plot[...] = board[hits]: the FRONT-most character',
+           'pcx_oracle.c',
+           '      int id = thing_id(e, x->board[i]); /* board[hits] */\n      if (id >= 0) *hitters |= (int64_t)1 << id;',
+           '      for (const char* c = bolt_chars; *c; ++c) { int id2 = thing_id(e, *c); if (id2 < 0) continue; const ox_sprite* s2 = &x->env->sprites[id2]; if (s2->visible && s2->row * e->t.cols + s2->col == i) *hitters |= (int64_t)1 << id2; }',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('marauders_march_every_frame', 'examples/extraterrestrial_marauders.py:157-158: every `period` frames',
+           'pcx_oracle.c',
+           '  if (env->plot.frame % period) return;',
+           '',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('up_bolt_starts_on_the_player', 'examples/extraterrestrial_marauders.py:217-220: one row ABOVE the player',
+           'pcx_oracle.c',
+           '    mw_teleport(e, s, P->row - 1, P->col);',
+           '    mw_teleport(e, s, P->row, P->col);',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('marauders_quit_forgotten', 'examples/extraterrestrial_marauders.py:185-186: action 4 quits',
+           'pcx_oracle.c',
+           '  else if (x->action == 4) plot_terminate(&x->env->plot, 0.0f);\n}\n\n/* extraterrestrial_marauders.py:198-220',
+           '}\n\n/* extraterrestrial_marauders.py:198-220',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('goals_anywhere', 'examples/warehouse_manager.py:255-258: boxes count where the BACKDROP shows a goal',
+           'pcx_oracle.c',
+           "d->curtain[i] &= e->backdrop[i] == '_';",
+           "d->curtain[i] &= e->backdrop[i] != '#';",
+           killed_by=['crop:warehouse_L1', 'crop:warehouse_custom_C']),
+    Mutant('frame_counter_starts_at_zero', 'engine.py:716, plot.py: the frame of the first play(None) is 0',
+           'pcx_oracle.c',
+           '  env->plot.frame = -1;',
+           '  env->plot.frame = 0;',
+           killed_by=['crop:better_scrolly_custom_A', 'crop:better_scrolly_custom_B']),
+    Mutant('finished_environments_keep_playing', 'engine.py:619-624 / SURVEY 8(d): a finished episode is rebuilt at the next step',
+           'pcx_oracle.c',
+           '    if (env->game_over) {\n      if (auto_reset) rc = env_showtime(e, b);\n      else frozen_step(e, b);\n    } else {',
+           '    if (0) {\n    } else {',
+           killed_by=['crop:better_scrolly_custom_A', 'crop:better_scrolly_custom_B']),
+    Mutant('centroid_of_an_invisible_sprite', 'cropping.py:551-560: an invisible sprite has no centroid',
+           'pcx_oracle.c',
+           '    if (!s->visible) return 0;\n    *row = s->row; *col = s->col;',
+           '    *row = s->row; *col = s->col;',
+           killed_by=['reftest:testScrollingSaccade_0', 'crop:marauders']),
+    Mutant('only_the_first_tracked_entity_counts', 'cropping.py:544-549: the first entity of to_track that HAS a centroid',
+           'pcx_oracle_crop.c',
+           '    for (int i = 0; i < c->d.n_track && !have; ++i) /* :544-549 */',
+           '    for (int i = 0; i < 1 && !have; ++i)',
+           killed_by=['reftest:testScrollingSaccade_0', 'crop:marauders']),
+    Mutant('pan_margin_one_cell_tighter', 'cropping.py:484-487: panning is possible one row/column OUTSIDE the margin-padded region',
+           'pcx_oracle_crop.c',
+           'int can_vert = (mrow - 1) <= (crow - wrow) && (crow - wrow) <= (rows - mrow);   /* :484 */',
+           'int can_vert = mrow <= (crow - wrow) && (crow - wrow) <= (rows - mrow - 1);',
+           killed_by=['reftest:testScrollingMargins_2', 'reftest:testScrollingMargins_3']),
+    Mutant('pan_down_even_after_panning_up', 'cropping.py:527-528: the downward pan only if no upward pan was needed',
+           'pcx_oracle_crop.c',
+           '        if (drow == 0) drow += imax(0, crow - wrow - rows + mrow + 1);',
+           '        drow += imax(0, crow - wrow - rows + mrow + 1);',
+           killed_by=[],
+           equivalent='needs a centroid above the top margin AND below the bottom one, i.e. 2 * margin >= rows, which the constructor refuses (cropping.py:353-359)'),
+    Mutant('no_centroid_window_at_the_centre', 'cropping.py:438-458: without a centroid the first window sits at (0, 0)',
+           'pcx_oracle_crop.c',
+           '  if (!have) { corner[0] = corner[1] = 0; return; }',
+           '  if (!have) { corner[0] = (pcxo__rows(c->e) - c->d.rows) / 2; corner[1] = (pcxo__cols(c->e) - c->d.cols) / 2; return; }',
+           killed_by=['crop:scrolly_maze_L0']),
+    Mutant('first_window_always_rectified', 'cropping.py:438-458: only croppers WITHOUT padding keep the first window on the board',
+           'pcx_oracle_crop.c',
+           '  corner[1] = ccol - off_c;\n  if (c->d.pad_char < 0) rectify(c, corner);',
+           '  corner[1] = ccol - off_c;\n  rectify(c, corner);',
+           killed_by=['reftest:testScrollingInitialOffset_0', 'reftest:testScrollingSaccade_0']),
+    Mutant('window_copy_starts_at_the_corner', 'cropping.py:193-227: a window hanging over the top/left edge is filled from its first ON-BOARD row/column',
+           'pcx_oracle_crop.c',
+           'int to_tr = imax(0, -top), to_lc = imax(0, -left);',
+           'int to_tr = 0, to_lc = 0;',
+           killed_by=['reftest:testEgocentricScrolling_0', 'reftest:testFixedCropper_0']),
 ]
 
 
@@ -221,7 +498,7 @@ def all_fixtures():
   from tests import test_oracle_golden, test_cropping, test_reference_known_answers, test_raise_parity
   return (['trace:' + n for n in test_oracle_golden.ALL_TRACES] + ['crop:' + n for n in test_cropping.CROPPED] +
           ['reftest:' + n for n in test_reference_known_answers.NAMES] + ['engine_test:z_order', 'engine_test:reward'] +
-          ['raise:' + n for n in test_raise_parity.WALKERS + ('fixed_crop_overhang',)])
+          ['raise:' + n for n in test_raise_parity.STEPPED + ('fixed_crop_overhang',)])
 
 
 def main():
@@ -229,9 +506,12 @@ def main():
   fixtures = all_fixtures()
   with tempfile.TemporaryDirectory(prefix='pcx_mutants_') as tmp:
     for m in MUTANTS:
+      if sys.argv[1:] and not any(a in m.name for a in sys.argv[1:]):
+        continue
       with loaded(build(m, tmp)):
         killers = [f for f in fixtures if not fixture_passes(f)]
-      print('%-42s killed by %d of %d: %s' % (m.name, len(killers), len(fixtures), ' '.join(killers) or '-- SURVIVES --'))
+      print('%-42s killed by %d of %d: %s' % (m.name, len(killers), len(fixtures), ' '.join(killers) or
+                                               '-- SURVIVES -- (%s)' % (m.equivalent or 'UNEXPLAINED')))
       sys.stdout.flush()
 
 

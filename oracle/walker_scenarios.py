@@ -93,6 +93,25 @@ SCENARIOS = {
 }
 
 
+# Scenarios that exist only as RAISE fixtures (oracle/gen_raise_golden.py): under any tape worth recording the reference
+# raises sooner or later, so there is no golden trace of them.
+RAISING_SCENARIOS = {
+    # two Scrollys of ONE scrolling group steered by different action fields: '#' decides (P is the group's only
+    # egocentrist), '%' has to follow -- and a Scrolly whose own motion shares no axis with the order it finds raises
+    # (drapes.py:523-535).  No walker of '%''s world is egocentric, so that raise is the only one its field can cause
+    # (oracle/mutants.py: `scrolly_follows_any_order` survived every other fixture).
+    'walkers_scroll_disagree': dict(
+        kind='scroll2', board=(7, 11), beneath=' ',
+        worlds=[dict(world=WORLD, mark='+', group='both', field=(0, 15),
+                     scrollies={'#': dict(margins=None)},
+                     walkers={'P': dict(impassable='#', egocentric=True), 'a': dict(impassable='#')}),
+                dict(world=WORLD2, mark='+', group='both', field=(4, 15),
+                     scrollies={'%': dict(margins=None)},
+                     walkers={'Q': dict(impassable=''), 'b': dict(impassable='')})],
+        schedule=[['#', '%'], ['a', 'P', 'b', 'Q']], z_order='a#b%QP', n_fields=2),
+}
+
+
 def build(spec, ascii_art, walker_cls, scrolly_cls, use_fields):
   """make_game() for one scenario with the given module/classes.
   `use_fields`: pass action_field=... (pycolab_amd tabled prefabs only)."""

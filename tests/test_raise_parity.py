@@ -3,6 +3,8 @@ reason, with everything before that frame equal to what the reference returned (
 
 tests/golden/raises/*.npz are recorded from the reference itself (oracle/gen_raise_golden.py) on tapes that DO raise:
 egocentric walkers handed scroll orders with no component in common with their motion (prefab_parts/sprites.py:449-454),
+a Scrolly that cannot follow its group's order or is ordered beyond its pattern (prefab_parts/drapes.py:523-535, 689-695),
+boxes of an unwalled warehouse looking for the player beyond the last row (examples/warehouse_manager.py:219-226),
 an ObservationToArray without a value for a character that turns up (rendering.py:517-522), a FixedCropper whose window
 leaves the board without a pad character (cropping.py:175-183).  The C / numpy oracle is checked here on the CPU, the HIP
 path -- error bits, the error polls and what check_errors() raises -- in the GPU suite."""
@@ -14,7 +16,10 @@ import pytest
 from oracle import binding, postprocess
 from tests import helpers
 
-WALKERS = ('walkers_scroll_always', 'walkers_scroll_groups', 'walkers_scroll_margins', 'walkers_room')
+WALKERS = ('walkers_scroll_always', 'walkers_scroll_groups', 'walkers_scroll_margins', 'walkers_room', 'walkers_scroll_disagree')
+# unwalled warehouses (oracle/custom_levels.py WAREHOUSE_OPEN_ART): pushes through numpy's index -1 until a box reaches
+# the last row or column and `layers['P'][row + 1, col]` is an IndexError (warehouse_manager.py:219-226)
+STEPPED = WALKERS + ('warehouse_open_A', 'warehouse_open_B')
 
 
 def load(name):
@@ -38,7 +43,7 @@ def check_walkers(fix, frames):
   return int((want_frame >= 0).sum())
 
 
-@pytest.mark.parametrize('name', WALKERS)
+@pytest.mark.parametrize('name', STEPPED)
 def test_oracle_error_bit_rises_where_the_reference_raised(name):
   fix = load(name)
   t = helpers.load_template(name)
@@ -107,7 +112,7 @@ def test_oracle_fixed_cropper_without_pad_raises_where_the_reference_does():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', WALKERS)
+@pytest.mark.parametrize('name', STEPPED)
 def test_hip_error_bit_rises_where_the_reference_raised(name):
   from pycolab_amd.engine import Engine
   fix = load(name)
@@ -123,8 +128,9 @@ def test_hip_error_bit_rises_where_the_reference_raised(name):
           eng.step_hashed(int(fix['seed'][0]), f - 1, 1)
         yield f, eng.planes_view(host=True)[:E, 0], eng.buffers['error'].numpy()[:E]
     raised = check_walkers(fix, frames())
-    if raised:  # ... and the host learns: check_errors() raises, naming the kind
-      with pytest.raises(RuntimeError, match='scrolling.Error'):
+    if raised:  # ... and the host learns: check_errors() raises, naming the kind (of the first environment affected)
+      first_bit = int(fix['raise_bit'][np.flatnonzero(fix['raise_frame'] >= 0)[0]])
+      with pytest.raises(RuntimeError, match='IndexError' if first_bit == 1 else 'scrolling.Error'):
         eng.check_errors()
     else:
       eng.check_errors()
