@@ -249,7 +249,28 @@ BETTER_SPECS = {
 BETTER_NAMES = sorted(BETTER_SPECS)
 
 
+# An UNWALLED board: everybody can walk off it, and a thing off the board has position (0, 0) (sprites.py:391-411) --
+# which is where better_scrolly_maze's kill test (TRUE positions, better_scrolly_maze.py:300) and coin pickup (:313)
+# then happen: patroller `a` leaves the board to the west every lap (row 1 has no wall in its last column, which is
+# where `layers['#'][row, -1]` looks), turns on the wall it then "sees" at [0, -1], and kills a player who stands at
+# (0, 0) or is off the board too; the coin at (0, 0) is collected from anywhere outside.  `b` turns in column 0 on the
+# wall numpy's index -1 finds in the LAST column.  No patroller can reach the last column (the IndexError of
+# `col + 1`), so tapes never raise.  (oracle/mutants.py: `coin_taken_at_the_virtual_position` survived every other fixture.)
+BETTER_ART = {
+    'better_scrolly_custom_D': ['@          #',
+                                '  a     #   ',
+                                '      P     ',
+                                '   b      ##',
+                                '   @    @   ',
+                                ' #      c # ',
+                                '@           '],
+}
+BETTER_NAMES = BETTER_NAMES + sorted(BETTER_ART)
+
+
 def better_art(name):
+  if name in BETTER_ART:
+    return BETTER_ART[name]
   seed, rows, cols = BETTER_SPECS[name][:3]
   rng = np.random.RandomState(seed)
   art = np.full((rows, cols), ' ', dtype='<U1')

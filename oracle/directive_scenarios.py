@@ -49,6 +49,21 @@ SCENARIOS = {
             'R': dict(kind='sprite', motion=None, directive=(2, 3),
                       calls={1: [('add_reward', 7)], 2: [('add_reward', 11)], 3: [('add_reward', -3), ('add_reward', 4)]}),
         }),
+    # plot.py:176-198: every terminate_episode(discount) of a step overwrites the discount -- the LAST one stands,
+    # within one entity's update and across entities (Q updates before R).  No other fixture ends an episode twice in
+    # one step (oracle/mutants.py: `later_terminate_keeps_the_first_discount` survived them all).
+    'directives_two_discounts': dict(
+        art=['.......',
+             '..Q.R..',
+             '.......'],
+        beneath='.', z_order='QR', schedule=[['Q', 'R']],
+        entities={
+            'Q': dict(kind='sprite', motion=None, directive=(0, 3),
+                      calls={1: [('terminate_episode', 0.5)], 2: [('terminate_episode', 0.75), ('terminate_episode', 0.25)],
+                             3: [('add_reward', 3), ('terminate_episode', 0.125)]}),
+            'R': dict(kind='sprite', motion=None, directive=(2, 3),
+                      calls={1: [('terminate_episode', 0.0625)], 2: [('add_reward', 1)], 3: [('terminate_episode',)]}),
+        }),
 }
 
 MOTION_NAMES = ['n', 'ne', 'e', 'se', 's', 'sw', 'w', 'nw', 'stay']

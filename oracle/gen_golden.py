@@ -385,7 +385,8 @@ def main():
     run(name, lambda: bsm.make_game(level), E=12, T=160, n_ordinary=5, quit_action=5, seed=61 + level,
         template_name=name)
   for i, name in enumerate(custom_levels.BETTER_NAMES):  # boards without a compiled kernel instance, with croppers
-    rows, cols = custom_levels.BETTER_SPECS[name][1:3]
+    art = custom_levels.better_art(name)
+    rows, cols = len(art), len(art[0])
     CROPPERS[name] = [S(7, 11, 'P', None, (2, 3)), S(5, 9, 'bP', ' ', (None, None), (1, -2)),
                       F((rows - 4, cols - 6), 6, 10, '#')]
     run(name, lambda: custom_levels.make_better_scrolly(name, bsm, ref_ascii_art), E=12, T=160, n_ordinary=5,
@@ -432,9 +433,10 @@ def main():
   # Plot directives (add_reward / terminate_episode(discount) / change_z_order)
   # issued by the reference's own test entities: tests/engine_test.py:169-295
   from oracle import directive_scenarios as ds
-  for i, (name, spec) in enumerate(sorted(ds.SCENARIOS.items())):
+  seeds = {'directives_reward_discount': 151, 'directives_z_order': 152, 'directives_two_discounts': 153}  # fixed per scenario
+  for name, spec in sorted(ds.SCENARIOS.items()):
     run(name, lambda spec=spec: ds.build_reference(spec, ref_art, tt), E=24, T=160, n_ordinary=9, quit_action=99,
-        seed=151 + i, template_name=name, ref_action=lambda a, spec=spec: ds.reference_action(spec, a),
+        seed=seeds[name], template_name=name, ref_action=lambda a, spec=spec: ds.reference_action(spec, a),
         tapes=lambda rng, T, spec=spec: ds.tape(spec, rng, T),
         before_play=lambda game, a, spec=spec: ds.inject(spec, game, a, tt))
 

@@ -85,17 +85,14 @@ def walkers(name, E, T):
                                                                      sorted(set(k for k in raise_type if k))), flush=True)
 
 
-def warehouse_open(name, E, T):
-  """An unwalled warehouse (oracle/custom_levels.py WAREHOUSE_OPEN_ART) on the hashed tape, episodes restarted the way
-  the batched engines restart them (a finished environment is rebuilt at the next step), until the reference raises."""
-  from pycolab import ascii_art as ref_art
-  from pycolab.examples import warehouse_manager
-  from oracle import custom_levels
+def unwalled(name, make, E, T, count=None):
+  """A level without walls around it (oracle/custom_levels.py) on the hashed tape, episodes restarted the way the
+  batched engines restart them (a finished environment is rebuilt at the next step), until the reference raises.
+  `count(game, action, board)`: statistics of the events the fixture is there for (printed, not stored)."""
   from pycolab_amd.compiler import GameTemplate
   n_actions = GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', name + '.npz')).n_actions
-  make = lambda: custom_levels.make_warehouse(name, warehouse_manager, ref_art)
   boards, raise_frame, raise_bit, raise_type = None, np.full(E, -1, np.int32), np.zeros(E, np.uint8), []
-  episodes = wrapped = 0
+  episodes = events = 0
   for e in range(E):
     game = make()
     obs, _, _ = game.its_showtime()
@@ -111,14 +108,8 @@ def warehouse_open(name, E, T):
           episodes += 1
         else:
           a = int(binding.action_hash(SEED, e, t) % n_actions)
-          # (statistics only: a box in row / column 0 that looks for the player at index -1 and finds it)
-          for c, box in game.things.items():
-            if c.isdigit() and box.visible:
-              r, col = box.position
-              P = game.things['P']
-              if P.visible and ((a == 1 and r == 0 and tuple(P.position) == (obs.board.shape[0] - 1, col)) or
-                                (a == 3 and col == 0 and tuple(P.position) == (r, obs.board.shape[1] - 1))):
-                wrapped += 1
+          if count:
+            events += count(game, a, obs.board)
           obs, _, _ = game.play(a)
       except Exception as ex:  # pylint: disable=broad-except
         kind = type(ex).__name__
@@ -129,8 +120,24 @@ def warehouse_open(name, E, T):
   np.savez_compressed(out_path(name), template=np.frombuffer(name.encode(), np.uint8), seed=np.array([SEED], np.uint64),
                       boards=boards, raise_frame=raise_frame, raise_bit=raise_bit,
                       raise_type=np.frombuffer('\n'.join(raise_type).encode(), np.uint8))
-  print('%s: %d of %d environments raised within %d steps (%s); %d episodes restarted, %d pushes through index -1'
-        % (name, int((raise_frame >= 0).sum()), E, T, sorted(set(k for k in raise_type if k)), episodes, wrapped), flush=True)
+  print('%s: %d of %d environments raised within %d steps (%s); %d episodes restarted, %d of the events it is there for'
+        % (name, int((raise_frame >= 0).sum()), E, T, sorted(set(k for k in raise_type if k)), episodes, events), flush=True)
+
+
+def warehouse_open(name, E, T):
+  from pycolab import ascii_art as ref_art
+  from pycolab.examples import warehouse_manager
+  from oracle import custom_levels
+
+  def pushes_through_index_minus_one(game, a, board):
+    n, P = 0, game.things['P']
+    for c, box in game.things.items():
+      if c.isdigit() and box.visible and P.visible:
+        r, col = box.position
+        n += ((a == 1 and r == 0 and tuple(P.position) == (board.shape[0] - 1, col)) or
+              (a == 3 and col == 0 and tuple(P.position) == (r, board.shape[1] - 1)))
+    return n
+  unwalled(name, lambda: custom_levels.make_warehouse(name, warehouse_manager, ref_art), E, T, pushes_through_index_minus_one)
 
 
 def marauders_to_array(E, T):

@@ -39,7 +39,8 @@ class Mutant(object):
 # fixture ids: 'trace:<name>' (tests/golden/traces, test_oracle_golden), 'crop:<name>' (the croppers recorded with a
 # trace, test_cropping), 'reftest:<name>' (the reference's own known-answer tests, tests/golden/reftests),
 # 'engine_test:<what>' (tests/engine_test.py:169-295 restated in test_reference_known_answers), 'raise:<name>'
-# (tests/golden/raises: where the reference raised, test_raise_parity)
+# (tests/golden/raises: where the reference raised, test_raise_parity), 'story:<name>' (the reference's own Story over
+# three chapter games, test_story_oracle)
 MUTANTS = [
     Mutant('kill_test_on_true_positions', 'examples/scrolly_maze.py:304 compares VIRTUAL positions',
            'pcx_oracle.c',
@@ -416,6 +417,112 @@ MUTANTS = [
            'int to_tr = imax(0, -top), to_lc = imax(0, -left);',
            'int to_tr = 0, to_lc = 0;',
            killed_by=['reftest:testEgocentricScrolling_0', 'reftest:testFixedCropper_0']),
+    # ---- fourth batch ---------------------------------------------------------------------------------------------
+    Mutant('later_terminate_keeps_the_first_discount', 'plot.py:176-198: terminate_episode(d) overwrites an earlier discount',
+           'pcx_oracle.c',
+           '  p->game_over = 1;\n  p->discount = discount;',
+           '  if (!p->game_over) p->discount = discount;\n  p->game_over = 1;',
+           killed_by=['trace:directives_two_discounts']),
+    Mutant('to_the_back_means_behind_the_backmost_only', 'engine.py:796-835: change_z_order(move, None) puts it ALL the way back',
+           'pcx_oracle.c',
+           '    if (front < 0) order[n++] = move; /* all the way to the back */',
+           '    if (front < 0) { order[n++] = env->z_id[0] == move ? env->z_id[1] : env->z_id[0]; order[n++] = move; }',
+           killed_by=['engine_test:z_order', 'trace:directives_z_order']),
+    Mutant('z_directives_applied_last_first', 'plot.py:173-174, engine.py:796: the directives of a step are applied in the order they were issued',
+           'pcx_oracle.c',
+           '    int move = env->plot.z_move[u], front = env->plot.z_front[u];',
+           '    int move = env->plot.z_move[env->plot.n_z_updates - 1 - u], front = env->plot.z_front[env->plot.n_z_updates - 1 - u];',
+           killed_by=['trace:directives_z_order']),
+    Mutant('first_next_chapter_stands', 'plot.py:299-324: the LAST assignment of next_chapter in a step stands',
+           'pcx_oracle.c',
+           '      case PCX_DIR_NEXT_CHAPTER: p->next_chapter = d->reward; break; /* plot.py:299-324: the last call stands */',
+           '      case PCX_DIR_NEXT_CHAPTER: if (p->next_chapter == PCX_CHAPTER_UNSET) p->next_chapter = d->reward; break;',
+           killed_by=['story:story_entity_chapters']),
+    Mutant('unoccluded_backdrop_layers_show_what_is_on_top', 'rendering.py:220-233: unoccluded backdrop layers are the RAW backdrop',
+           'pcx_oracle.c',
+           '      for (int i = 0; i < n; ++i) layer[i] = e->backdrop[i] == e->t.chars[k];\n    }\n  }\n  for (int z = 0;',
+           '      for (int i = 0; i < n; ++i) layer[i] = 0;\n    }\n  }\n  for (int z = 0;',
+           killed_by=['trace:scrolly_custom_A_unoccluded', 'trace:scrolly_custom_C_unoccluded']),
+    Mutant('unoccluded_drape_layers_occluded', 'rendering.py:187-301: an unoccluded drape layer is the whole curtain',
+           'pcx_oracle.c',
+           '      if (!occl) memcpy(env_layer(e, b, char_index(e, ch)), d->curtain, n);',
+           '      if (!occl) for (int i = 0; i < n; ++i) env_layer(e, b, char_index(e, ch))[i] = d->curtain[i];\n      if (!occl) for (int zz = z + 1; zz < e->t.n_things; ++zz) { int id2 = env->z_id[zz]; if (id2 < PCX_MAX_SPRITES && env->sprites[id2].visible) env_layer(e, b, char_index(e, ch))[env->sprites[id2].row * C + env->sprites[id2].col] = 0; }',
+           killed_by=['trace:scrolly_custom_A_unoccluded', 'trace:scrolly_custom_E_unoccluded']),
+    Mutant('up_bolt_ignores_marauder_hits', 'examples/extraterrestrial_marauders.py:206-209: a bolt that hit a marauder retires too',
+           'pcx_oracle.c',
+           '    if (((env->plot.kv[EM_BUNKER_HITTERS] | env->plot.kv[EM_MARAUDER_HITTERS]) >> id) & 1) {',
+           '    if ((env->plot.kv[EM_BUNKER_HITTERS] >> id) & 1) {',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('marauders_bounce_without_an_edge', 'examples/extraterrestrial_marauders.py:160: the turn happens when a marauder TOUCHES the side',
+           'pcx_oracle.c',
+           '  for (int r = 0; r < R; ++r) edge |= d->curtain[r * C] | d->curtain[r * C + C - 1];',
+           '  for (int r = 0; r < R; ++r) edge |= d->curtain[r * C + 1] | d->curtain[r * C + C - 2];',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('down_bolt_from_the_top_marauder', 'examples/extraterrestrial_marauders.py:253-256: below the LOWEST marauder of the column',
+           'pcx_oracle.c',
+           '    for (int r = 0; r < R; ++r) if (lx[r * C + col]) row = r;',
+           '    for (int r = R - 1; r >= 0; --r) if (lx[r * C + col]) row = r;',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('down_bolt_spares_the_player', 'examples/extraterrestrial_marauders.py:240-246: a bolt on the player ends the episode',
+           'pcx_oracle.c',
+           '    if (s->row == P->row && s->col == P->col) plot_terminate(&env->plot, 0.0f);\n    mw_move(e, env, id, x->board, 1, 0);',
+           '    mw_move(e, env, id, x->board, 1, 0);',
+           killed_by=['crop:marauders', 'trace:marauders_custom_A']),
+    Mutant('hello_world_quit_forgotten', 'examples/hello_world.py:82-83: action 4 quits',
+           'pcx_oracle.c',
+           '  if (a == 4) plot_terminate(&x->env->plot, 0.0f);\n  if (a < 4) {',
+           '  if (a < 4) {',
+           killed_by=['trace:hello_custom_A', 'trace:hello_world']),
+    Mutant('hello_world_sprites_stop_at_the_edge', 'examples/hello_world.py:117-123: positions wrap around the board',
+           'pcx_oracle.c',
+           '  s->col = ((s->col + dx) % e->t.cols + e->t.cols) % e->t.cols;',
+           '  s->col = s->col + dx < 0 ? 0 : s->col + dx >= e->t.cols ? e->t.cols - 1 : s->col + dx;',
+           killed_by=['trace:hello_custom_A', 'trace:hello_world']),
+    Mutant('warehouse_quit_forgotten', 'examples/warehouse_manager.py:264-266: action 5 quits',
+           'pcx_oracle.c',
+           'if (x->action == 5 || on_goals == num_boxes) plot_terminate(&env->plot, 0.0f);',
+           'if (on_goals == num_boxes) plot_terminate(&env->plot, 0.0f);',
+           killed_by=['crop:warehouse_L1', 'crop:warehouse_custom_C']),
+    Mutant('judge_marks_every_box', 'examples/warehouse_manager.py:255-258: X only over boxes ON goals',
+           'pcx_oracle.c',
+           "  for (int i = 0; i < n; ++i) { d->curtain[i] &= e->backdrop[i] == '_'; on_goals += d->curtain[i]; }",
+           "  for (int i = 0; i < n; ++i) { on_goals += d->curtain[i] && e->backdrop[i] == '_'; }",
+           killed_by=['crop:warehouse_L1', 'crop:warehouse_custom_C']),
+    Mutant('coin_taken_at_the_virtual_position', 'examples/better_scrolly_maze.py:313: the coin under the player\'s TRUE position',
+           'pcx_oracle.c',
+           '  uint8_t* cell = &d->curtain[P->row * e->t.cols + P->col];',
+           '  uint8_t* cell = &d->curtain[(P->vrow < 0 ? 0 : P->vrow >= e->t.rows ? e->t.rows - 1 : P->vrow) * e->t.cols + (P->vcol < 0 ? 0 : P->vcol >= e->t.cols ? e->t.cols - 1 : P->vcol)];',
+           killed_by=['trace:better_scrolly_custom_D']),
+    Mutant('better_kill_test_on_virtual_positions', 'examples/better_scrolly_maze.py:300: the kill test compares TRUE positions: off the board everybody is at (0, 0)',
+           'pcx_oracle.c',
+           '  if (s->row == P->row && s->col == P->col) plot_terminate(&env->plot, 0.0f);\n}\n\n/* better_scrolly_maze.py:311-320',
+           '  if (s->vrow == P->vrow && s->vcol == P->vcol) plot_terminate(&env->plot, 0.0f);\n}\n\n/* better_scrolly_maze.py:311-320',
+           killed_by=['trace:better_scrolly_custom_D']),
+    Mutant('better_patroller_looks_around_its_virtual_position', 'examples/better_scrolly_maze.py:288-294: row, col = self.position: (0, 0) off the board',
+           'pcx_oracle.c',
+           '  int row = s->row, col = s->col;\n  if (layer_char_at',
+           '  int row = s->vrow, col = s->vcol;\n  if (layer_char_at',
+           killed_by=['trace:better_scrolly_custom_D']),
+    Mutant('better_quit_forgotten', 'examples/better_scrolly_maze.py:271-272: action 5 quits',
+           'pcx_oracle.c',
+           '  if (x->action == 5) plot_terminate(&x->env->plot, 0.0f);\n}\n\n/* ---- examples/warehouse_manager.py',
+           '}\n\n/* ---- examples/warehouse_manager.py',
+           killed_by=['crop:better_scrolly_custom_A', 'crop:better_scrolly_custom_B']),
+    Mutant('fixed_window_follows_the_sprite', 'cropping.py:255-268: a FixedCropper never moves',
+           'pcx_oracle_crop.c',
+           '    if (c->d.kind == PCX_CROP_FIXED) { do_crop(c, b, c->d.top, c->d.left); continue; }',
+           '    if (c->d.kind == PCX_CROP_FIXED) { do_crop(c, b, c->d.top + (pcxo__frame(e, b) & 1), c->d.left); continue; }',
+           killed_by=['reftest:testFixedCropper_0', 'reftest:testWeirdFixedCrops_0']),
+    Mutant('window_centred_with_rounding_up', 'cropping.py:438-458: the first window puts the centroid at rows // 2',
+           'pcx_oracle_crop.c',
+           'initialise(c, corner, have, crow, ccol, rows / 2 + c->d.initial_offset_rows, cols / 2 + c->d.initial_offset_cols);',
+           'initialise(c, corner, have, crow, ccol, (rows + 1) / 2 + c->d.initial_offset_rows, (cols + 1) / 2 + c->d.initial_offset_cols);',
+           killed_by=['reftest:testScrollingInitialOffset_0', 'reftest:testScrollingMargins_0']),
+    Mutant('initial_offset_other_sign', 'cropping.py:320-325: initial_offset shifts the ENTITY down/right in the window',
+           'pcx_oracle_crop.c',
+           'initialise(c, corner, have, crow, ccol, rows / 2 + c->d.initial_offset_rows, cols / 2 + c->d.initial_offset_cols);',
+           'initialise(c, corner, have, crow, ccol, rows / 2 - c->d.initial_offset_rows, cols / 2 - c->d.initial_offset_cols);',
+           killed_by=['reftest:testScrollingInitialOffset_0', 'crop:better_scrolly_custom_A']),
 ]
 
 
@@ -481,6 +588,9 @@ def fixture_passes(fixture):
       else:
         for discount in (None, 0.5):
           t.test_oracle_reward_and_episode_end_known_answer(discount)
+    elif kind == 'story':
+      from tests import test_story_oracle
+      test_story_oracle.test_oracle_story_matches_reference_story(name)
     elif kind == 'raise':
       from tests import test_raise_parity
       if name == 'fixed_crop_overhang':
@@ -495,9 +605,9 @@ def fixture_passes(fixture):
 
 
 def all_fixtures():
-  from tests import test_oracle_golden, test_cropping, test_reference_known_answers, test_raise_parity
+  from tests import test_oracle_golden, test_cropping, test_reference_known_answers, test_raise_parity, test_story_oracle
   return (['trace:' + n for n in test_oracle_golden.ALL_TRACES] + ['crop:' + n for n in test_cropping.CROPPED] +
-          ['reftest:' + n for n in test_reference_known_answers.NAMES] + ['engine_test:z_order', 'engine_test:reward'] +
+          ['reftest:' + n for n in test_reference_known_answers.NAMES] + ['engine_test:z_order', 'engine_test:reward'] + ['story:' + n for n in sorted(test_story_oracle.STORIES)] +
           ['raise:' + n for n in test_raise_parity.STEPPED + ('fixed_crop_overhang',)])
 
 

@@ -13,7 +13,7 @@ from pycolab_amd import cropping
 from tests import helpers
 
 CROPPED = ['scrolly_maze_L0', 'warehouse_L1', 'marauders', 'better_scrolly_maze_L0', 'better_scrolly_maze_L1',
-           'better_scrolly_maze_L2', 'warehouse_custom_C', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C']
+           'better_scrolly_maze_L2', 'warehouse_custom_C', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C', 'better_scrolly_custom_D']
 
 
 def specs_of(trace):
@@ -152,7 +152,7 @@ def test_device_cropper_outputs_are_zero_copy_device_tensors_and_survive_a_new_e
 # ---- croppers fused into the step kernel (cropping.fuse_croppers, pcx_engine_fuse_croppers) ----
 
 FUSABLE = ['scrolly_maze_L0', 'warehouse_L1', 'marauders', 'better_scrolly_maze_L0', 'better_scrolly_maze_L1', 'better_scrolly_maze_L2',
-           'warehouse_custom_C', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C']
+           'warehouse_custom_C', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C', 'better_scrolly_custom_D']
 
 
 def _fusable(specs, drapes):
