@@ -1,0 +1,150 @@
+"""The oracle against the reference ITSELF on randomised levels (CPU).  tests/test_random_levels.py draws levels of
+warehouse_manager, better_scrolly_maze and scrolly_maze at random and holds the HIP path to the oracle on them; here
+the same level -- same random art, same cast, same z-order -- is built a second time with the reference's own
+ascii_art and the example files' own classes (imported from /root/reference or from oracle/_ref's bytecode) and stepped
+live next to the oracle on random tapes (quit, None and out-of-range actions mixed in), resets included.  So the
+checker of the randomised GPU tests is itself checked against the reference on the very shapes it is used on, not only
+on the recorded fixtures."""
+import importlib
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import binding, ref_live
+from pycolab_amd.compiler import GameTemplate
+from tests import test_random_levels as levels
+
+pytestmark = pytest.mark.skipif(ref_live.reference_path() is None, reason='the reference is neither under /root/reference nor built under oracle/_ref')
+
+
+def reference_kit():
+  path = ref_live.reference_path()
+  if path not in sys.path:
+    sys.path.insert(0, path)
+  warnings.filterwarnings('ignore', category=DeprecationWarning)
+  art = importlib.import_module('pycolab.ascii_art')
+  drapes = importlib.import_module('pycolab.prefab_parts.drapes')
+  wm = importlib.import_module('pycolab.examples.warehouse_manager')
+  bs = importlib.import_module('pycolab.examples.better_scrolly_maze')
+  sm = importlib.import_module('pycolab.examples.scrolly_maze')
+
+  # (the random levels start their patrollers in a direction that depends on the character: test_random_levels.py)
+  class BetterPatroller(bs.PatrollerSprite):
+
+    def __init__(self, corner, position, character):
+      super(BetterPatroller, self).__init__(corner, position, character)
+      self._moving_east = bool(ord(character) % 2)
+
+  class Guard(sm.PatrollerSprite):
+
+    def __init__(self, corner, position, character, virtual_position):
+      super(Guard, self).__init__(corner, position, character, virtual_position)
+      self._moving_east = bool(ord(character) % 2)
+
+  return levels.Kit(ascii_art=art, Box=wm.BoxSprite, Judge=wm.JudgeDrape, Pusher=wm.PlayerSprite, Walker=bs.PlayerSprite,
+                    Patroller=BetterPatroller, Cash=bs.CashDrape, Explorer=sm.PlayerSprite, Guard=Guard, Maze=sm.MazeDrape,
+                    Coins=sm.CashDrape, Scrolly=drapes.Scrolly)
+
+
+@pytest.mark.parametrize('maker', [levels.random_warehouse, levels.random_better_scrolly, levels.random_scrolly], ids=lambda m: m.__name__)
+@pytest.mark.parametrize('seed', range(10))
+def test_oracle_matches_the_live_reference_on_a_random_level(maker, seed):
+  kit = reference_kit()
+  template = GameTemplate.from_engine(maker(np.random.RandomState(7000 + seed)))
+  make = lambda: maker(np.random.RandomState(7000 + seed), kit)
+  n_actions, E, T = int(template.n_actions), 8, 160
+  # uniform ordinary actions with the quit action (= n_actions in all three games), None and garbage mixed in
+  rng = np.random.RandomState(8000 + seed)
+  tape = rng.randint(0, n_actions, size=(T, E)).astype(np.int32)
+  u = rng.rand(T, E)
+  tape[u < 0.03] = n_actions
+  tape[(u >= 0.03) & (u < 0.05)] = -1
+  tape[(u >= 0.05) & (u < 0.07)] = rng.randint(n_actions + 1, 40)
+  orc = binding.OracleEngine(template, E)
+  orc.reset()
+  now = lambda: (np.array(orc.planes)[:, 0].copy(), np.array(orc.reward), np.array(orc.reward_set), np.array(orc.discount), np.array(orc.done))
+  frames = [now()]
+  for t in range(T):
+    orc.step(tape[t], auto_reset=True)
+    assert not np.array(orc.error).any()
+    frames.append(now())
+  chars = [chr(c) for c in template.chars]
+  ended = 0
+  for e in range(E):
+    game = make()
+    obs, r, d = game.its_showtime()
+    assert sorted(obs.layers) == sorted(chars)
+    for t in range(T + 1):
+      if t:
+        if game.game_over:  # (a finished environment is rebuilt at the next step; that step's action is not used)
+          game = make()
+          obs, r, d = game.its_showtime()
+          ended += 1
+        else:
+          a = int(tape[t - 1, e])
+          obs, r, d = game.play(None if a < 0 else a)
+      board, reward, reward_set, discount, done = frames[t]
+      where = '%s seed %d: env %d frame %d' % (maker.__name__, seed, e, t)
+      np.testing.assert_array_equal(obs.board, board[e], err_msg=where)
+      assert (r is None) == (not reward_set[e]) and (r or 0) == reward[e], where
+      assert d == discount[e] and game.game_over == bool(done[e]), where
+  assert ended > 0  # (every level sees restarts)
+
+
+@pytest.mark.parametrize('maker,track', [(levels.random_warehouse, 'P'), (levels.random_warehouse, 'XP'), (levels.random_better_scrolly, 'bP'),
+                                         (levels.random_better_scrolly, '@b'), (levels.random_scrolly, 'P'), (levels.random_scrolly, '@aP')],
+                         ids=lambda x: getattr(x, '__name__', x))
+@pytest.mark.parametrize('seed', range(6))
+def test_oracle_croppers_match_the_live_reference_croppers_on_a_random_level(maker, track, seed):
+  """Random windows (padded and not, larger than the board, off the board, every margin / offset / saccade setting,
+  following sprites and drapes) of the reference's own croppers next to the oracle's, every step, resets included."""
+  from pycolab_amd import cropping
+  kit = reference_kit()
+  ref_cropping = importlib.import_module('pycolab.cropping')
+  template = GameTemplate.from_engine(maker(np.random.RandomState(7100 + seed)))
+  make = lambda: maker(np.random.RandomState(7100 + seed), kit)
+  have = {chr(sp['ch']) for sp in template.sprites} | {chr(d['ch']) for d in template.drapes}
+  track = ''.join(c for c in track if c in have) or chr(template.sprites[0]['ch'])
+  ours = levels._random_croppers(np.random.RandomState(7200 + seed), template, track, cropping)()
+  n_actions, E, T = int(template.n_actions), 4, 100
+  rng = np.random.RandomState(8100 + seed)
+  tape = rng.randint(0, n_actions, size=(T, E)).astype(np.int32)
+  tape[rng.rand(T, E) < 0.03] = n_actions
+  orc = binding.OracleEngine(template, E)
+  orc.reset()
+  crops = [binding.OracleCropper(orc, c) for c in ours]
+  windows = []
+  for t in range(T + 1):
+    if t:
+      orc.step(tape[t - 1], auto_reset=True)
+    per = [c.crop() for c in crops]
+    assert not any(err.any() for _, err in per)
+    windows.append([w for w, _ in per])
+  chars = [chr(c) for c in template.chars]
+  moved = 0
+  for e in range(E):
+    theirs = levels._random_croppers(np.random.RandomState(7200 + seed), template, track, ref_cropping)()
+    game = make()
+    for cr in theirs:
+      cr.set_engine(game)
+    obs = game.its_showtime()[0]
+    for t in range(T + 1):
+      if t:
+        if game.game_over:
+          game = make()
+          for cr in theirs:
+            cr.set_engine(game)
+          obs = game.its_showtime()[0]
+        else:
+          obs = game.play(int(tape[t - 1, e]))[0]
+      for i, cr in enumerate(theirs):
+        out = cr.crop(obs)
+        where = '%s seed %d: env %d frame %d cropper %d (%s)' % (maker.__name__, seed, e, t, i, type(cr).__name__)
+        np.testing.assert_array_equal(out.board, windows[t][i][e, 0], err_msg=where)
+        for k, c in enumerate(chars):
+          np.testing.assert_array_equal(out.layers[c], windows[t][i][e, 1 + k] != 0, err_msg=where + ' layer ' + c)
+        if t and not np.array_equal(windows[t][i][e, 0], windows[t - 1][i][e, 0]):
+          moved += 1
+  assert moved > 0
