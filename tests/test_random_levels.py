@@ -349,7 +349,8 @@ class Sliding(things.Sprite):
     self._dy = self._DY[direction_set]
 
 
-def random_hello(rng):
+def random_hello(rng, kit=None):
+  kit = kit or OURS
   rows, cols = int(rng.randint(2, 24)), int(rng.randint(2, 60))
   art = np.full((rows, cols), ' ', dtype='<U1')
   art[rng.rand(rows, cols) < 0.2] = '@'
@@ -364,10 +365,13 @@ def random_hello(rng):
     art[cells[-1]] = '@'
   z = list(names) + ['@']
   rng.shuffle(z)
-  return ascii_art.ascii_art_to_game(
+  return kit.ascii_art.ascii_art_to_game(
       [''.join(r) for r in art], ' ',
-      sprites={ch: ascii_art.Partial(Sliding, int(rng.randint(4))) for ch in names},
-      drapes={'@': Rolling}, z_order=''.join(z))
+      sprites={ch: kit.ascii_art.Partial(kit.Sliding, int(rng.randint(4))) for ch in names},
+      drapes={'@': kit.Rolling}, z_order=''.join(z))
+
+
+OURS.Rolling, OURS.Sliding = Rolling, Sliding
 
 
 @pytest.mark.gpu
@@ -414,7 +418,8 @@ class EMBunkers(things.Drape):
   pcx_program = 'marauders.bunker'
 
 
-def random_marauders(rng):
+def random_marauders(rng, kit=None):
+  kit = kit or OURS
   rows, cols = 16, 39  # (the hand-written kernel's cast and board; the layout is free)
   art = np.full((rows, cols), ' ', dtype='<U1')
   top = int(rng.randint(0, 4))
@@ -428,9 +433,12 @@ def random_marauders(rng):
   art[int(rng.choice([13, 14, 15])), int(rng.randint(0, cols))] = 'P'
   if not (art == 'X').any():
     art[1, 5] = 'X'
-  sprites = dict([('P', EMPlayer)] + [(c, EMUpBolt) for c in 'abcd'] + [(c, EMDownBolt) for c in 'yz'])
-  return ascii_art.ascii_art_to_game([''.join(r) for r in art], ' ', sprites, dict(X=EMMarauders, B=EMBunkers),
-                                     update_schedule=['P', 'B', 'X'] + list('abcdyz'))
+  sprites = dict([('P', kit.EMPlayer)] + [(c, kit.EMUpBolt) for c in 'abcd'] + [(c, kit.EMDownBolt) for c in 'yz'])
+  return kit.ascii_art.ascii_art_to_game([''.join(r) for r in art], ' ', sprites, dict(X=kit.EMMarauders, B=kit.EMBunkers),
+                                         update_schedule=['P', 'B', 'X'] + list('abcdyz'))
+
+
+OURS.EMPlayer, OURS.EMUpBolt, OURS.EMDownBolt, OURS.EMMarauders, OURS.EMBunkers = EMPlayer, EMUpBolt, EMDownBolt, EMMarauders, EMBunkers
 
 
 @pytest.mark.gpu

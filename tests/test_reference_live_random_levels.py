@@ -29,6 +29,8 @@ def reference_kit():
   wm = importlib.import_module('pycolab.examples.warehouse_manager')
   bs = importlib.import_module('pycolab.examples.better_scrolly_maze')
   sm = importlib.import_module('pycolab.examples.scrolly_maze')
+  hw = importlib.import_module('pycolab.examples.hello_world')
+  em = importlib.import_module('pycolab.examples.extraterrestrial_marauders')
 
   # (the random levels start their patrollers in a direction that depends on the character: test_random_levels.py)
   class BetterPatroller(bs.PatrollerSprite):
@@ -45,16 +47,24 @@ def reference_kit():
 
   return levels.Kit(ascii_art=art, Box=wm.BoxSprite, Judge=wm.JudgeDrape, Pusher=wm.PlayerSprite, Walker=bs.PlayerSprite,
                     Patroller=BetterPatroller, Cash=bs.CashDrape, Explorer=sm.PlayerSprite, Guard=Guard, Maze=sm.MazeDrape,
-                    Coins=sm.CashDrape, Scrolly=drapes.Scrolly)
+                    Coins=sm.CashDrape, Scrolly=drapes.Scrolly, Rolling=hw.RollingDrape, Sliding=hw.SlidingSprite,
+                    EMPlayer=em.PlayerSprite, EMUpBolt=em.UpwardLaserBoltSprite, EMDownBolt=em.DownwardLaserBoltSprite,
+                    EMMarauders=em.MarauderDrape, EMBunkers=em.BunkerDrape)
 
 
-@pytest.mark.parametrize('maker', [levels.random_warehouse, levels.random_better_scrolly, levels.random_scrolly], ids=lambda m: m.__name__)
+@pytest.mark.parametrize('maker', [levels.random_warehouse, levels.random_better_scrolly, levels.random_scrolly, levels.random_hello,
+                                   levels.random_marauders], ids=lambda m: m.__name__)
 @pytest.mark.parametrize('seed', range(10))
-def test_oracle_matches_the_live_reference_on_a_random_level(maker, seed):
+def test_oracle_matches_the_live_reference_on_a_random_level(maker, seed, monkeypatch):
   kit = reference_kit()
   template = GameTemplate.from_engine(maker(np.random.RandomState(7000 + seed)))
   make = lambda: maker(np.random.RandomState(7000 + seed), kit)
   n_actions, E, T = int(template.n_actions), 8, 160
+  # the marauders' return fire: np.random.choice (extraterrestrial_marauders.py:253) as the counter-based draw the oracle
+  # and the kernels implement (oracle/ref_live.py _Choice; the template carries the seed)
+  template.param[0], template.param[1] = 0xFACE + seed, 0
+  choice = ref_live._Choice(0xFACE + seed, binding.action_hash)
+  monkeypatch.setattr(np.random, 'choice', choice)
   # uniform ordinary actions with the quit action (= n_actions in all three games), None and garbage mixed in
   rng = np.random.RandomState(8000 + seed)
   tape = rng.randint(0, n_actions, size=(T, E)).astype(np.int32)
@@ -73,6 +83,7 @@ def test_oracle_matches_the_live_reference_on_a_random_level(maker, seed):
   chars = [chr(c) for c in template.chars]
   ended = 0
   for e in range(E):
+    choice.env = e
     game = make()
     obs, r, d = game.its_showtime()
     assert sorted(obs.layers) == sorted(chars)
