@@ -21,7 +21,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, '_ref')
-SKIP_DIRS = ('tests', '__pycache__')  # (the reference's own tests are harvested into tests/golden/reftests by harvest_reference_tests.py)
+SKIP_DIRS = ('__pycache__',)
+# of the reference's tests/ only the test ENTITIES (TestMazeWalker, TestScrolly, ...: what the prefab-only scenarios and the
+# random walker games are built from); the test cases themselves are harvested into tests/golden/reftests by
+# harvest_reference_tests.py
+TESTS_KEPT = ('__init__.py', 'test_things.py')
 
 
 def build(reference):
@@ -35,7 +39,7 @@ def build(reference):
     dirnames[:] = sorted(d for d in dirnames if d not in SKIP_DIRS)
     rel = os.path.relpath(dirpath, reference)
     for name in sorted(filenames):
-      if not name.endswith('.py'):
+      if not name.endswith('.py') or (os.path.basename(dirpath) == 'tests' and name not in TESTS_KEPT):
         continue
       dst = os.path.join(OUT, rel, name + 'c')
       os.makedirs(os.path.dirname(dst), exist_ok=True)
