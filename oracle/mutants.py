@@ -426,7 +426,7 @@ MUTANTS = [
     Mutant('to_the_back_means_behind_the_backmost_only', 'engine.py:796-835: change_z_order(move, None) puts it ALL the way back',
            'pcx_oracle.c',
            '    if (front < 0) order[n++] = move; /* all the way to the back */',
-           '    if (front < 0) { order[n++] = env->z_id[0] == move ? env->z_id[1] : env->z_id[0]; order[n++] = move; }',
+           '    if (front < 0 && e->t.n_things > 1) front = env->z_id[0] == move ? env->z_id[1] : env->z_id[0];\n    else if (front < 0) order[n++] = move;',
            killed_by=['engine_test:z_order', 'trace:directives_z_order']),
     Mutant('z_directives_applied_last_first', 'plot.py:173-174, engine.py:796: the directives of a step are applied in the order they were issued',
            'pcx_oracle.c',
