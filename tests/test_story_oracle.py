@@ -94,3 +94,55 @@ def test_oracle_story_matches_reference_story(which):
       check(story.play(int(tr['actions'][t, e])), t + 1)
       jumps += (not story.game_over) and story.this_chapter not in (before, before + 1)
   assert (jumps > 0) == (which == 'story_entity_chapters')  # (entities sent the story somewhere else than "the next one")
+
+
+@pytest.mark.parametrize('which', sorted(STORIES))
+@pytest.mark.parametrize('seed', range(6))
+def test_oracle_story_matches_the_live_reference_story_on_fresh_tapes(which, seed):
+  """The same chain next to the reference's own `storytelling.Story` stepped live (from /root/reference or oracle/_ref)
+  on tapes the fixture does not hold: 6 x 12 more stories of each kind, 120 steps each, restarted when they end."""
+  import collections
+  import collections.abc
+  import importlib
+  import sys
+  import warnings
+  from oracle import ref_live
+  path = ref_live.reference_path()
+  if path is None:
+    pytest.skip('the reference is neither under /root/reference nor built under oracle/_ref')
+  if path not in sys.path:
+    sys.path.insert(0, path)
+  warnings.filterwarnings('ignore', category=DeprecationWarning)
+  for name in ('Mapping', 'Sequence'):  # storytelling.py uses collections.Mapping, gone since Python 3.10 (oracle/gen_story_golden.py)
+    if not hasattr(collections, name):
+      setattr(collections, name, getattr(collections.abc, name))
+  ref_art = importlib.import_module('pycolab.ascii_art')
+  ref_story = importlib.import_module('pycolab.storytelling')
+  tt = importlib.import_module('pycolab.tests.test_things')
+  specs = STORIES[which]
+  ts = templates(specs)
+  make_story = lambda: ref_story.Story([lambda spec=spec: ds.build_reference(spec, ref_art, tt) for spec in specs])
+  T, chapters_seen = 120, set()
+  for e in range(12):
+    tape = ds.story_tape(np.random.RandomState(12000 + 100 * seed + e), T)
+    ours, theirs = OracleStory(ts), make_story()
+
+    def check(out, ref_out, row):
+      (board, r, d), (obs, rr, rd) = out, ref_out
+      where = '%s seed %d: story %d row %d' % (which, seed, e, row)
+      np.testing.assert_array_equal(board, obs.board, err_msg=where)
+      assert r == rr and d == rd and ours.game_over == theirs.game_over, where
+      if not ours.game_over:
+        assert ours.this_chapter == theirs.the_plot.this_chapter, where
+        chapters_seen.add(ours.this_chapter)
+    check(ours.its_showtime(), theirs.its_showtime(), 0)
+    for t in range(T):
+      if theirs.game_over:
+        ours, theirs = OracleStory(ts), make_story()
+        check(ours.its_showtime(), theirs.its_showtime(), t + 1)
+        continue
+      a = int(tape[t])
+      spec = specs[theirs.the_plot.this_chapter]
+      ds.inject(spec, theirs.current_game, a, tt)
+      check(ours.play(a), theirs.play(ds.reference_action(spec, a)), t + 1)
+  assert chapters_seen == {0, 1, 2}
