@@ -52,12 +52,25 @@ def reference_kit():
                     EMMarauders=em.MarauderDrape, EMBunkers=em.BunkerDrape)
 
 
+class _Unoccluded(object):
+  """An ascii_art module whose games are built with occlusion_in_layers=False (engine.py:98; rendering.py:187-301)."""
+
+  def __init__(self, module):
+    import functools
+    self.Partial = module.Partial
+    self.ascii_art_to_game = functools.partial(module.ascii_art_to_game, occlusion_in_layers=False)
+
+
+@pytest.mark.parametrize('occlusion', [True, False], ids=['occluded', 'unoccluded'])
 @pytest.mark.parametrize('maker', [levels.random_warehouse, levels.random_better_scrolly, levels.random_scrolly, levels.random_hello,
                                    levels.random_marauders], ids=lambda m: m.__name__)
 @pytest.mark.parametrize('seed', range(10))
-def test_oracle_matches_the_live_reference_on_a_random_level(maker, seed, monkeypatch):
-  kit = reference_kit()
-  template = GameTemplate.from_engine(maker(np.random.RandomState(7000 + seed)))
+def test_oracle_matches_the_live_reference_on_a_random_level(maker, seed, occlusion, monkeypatch):
+  kit, ours = reference_kit(), levels.OURS
+  if not occlusion:  # the layers are then the things' raw masks: compared plane by plane below
+    kit = levels.Kit(**dict(kit.__dict__, ascii_art=_Unoccluded(kit.ascii_art)))
+    ours = levels.Kit(**dict(ours.__dict__, ascii_art=_Unoccluded(ours.ascii_art)))
+  template = GameTemplate.from_engine(maker(np.random.RandomState(7000 + seed), ours))
   make = lambda: maker(np.random.RandomState(7000 + seed), kit)
   n_actions, E, T = int(template.n_actions), 8, 160
   # the marauders' return fire: np.random.choice (extraterrestrial_marauders.py:253) as the counter-based draw the oracle
@@ -74,7 +87,7 @@ def test_oracle_matches_the_live_reference_on_a_random_level(maker, seed, monkey
   tape[(u >= 0.05) & (u < 0.07)] = rng.randint(n_actions + 1, 40)
   orc = binding.OracleEngine(template, E)
   orc.reset()
-  now = lambda: (np.array(orc.planes)[:, 0].copy(), np.array(orc.reward), np.array(orc.reward_set), np.array(orc.discount), np.array(orc.done))
+  now = lambda: (np.array(orc.planes).copy(), np.array(orc.reward), np.array(orc.reward_set), np.array(orc.discount), np.array(orc.done))
   frames = [now()]
   for t in range(T):
     orc.step(tape[t], auto_reset=True)
@@ -96,9 +109,11 @@ def test_oracle_matches_the_live_reference_on_a_random_level(maker, seed, monkey
         else:
           a = int(tape[t - 1, e])
           obs, r, d = game.play(None if a < 0 else a)
-      board, reward, reward_set, discount, done = frames[t]
+      planes, reward, reward_set, discount, done = frames[t]
       where = '%s seed %d: env %d frame %d' % (maker.__name__, seed, e, t)
-      np.testing.assert_array_equal(obs.board, board[e], err_msg=where)
+      assert np.array_equal(obs.board, planes[e, 0]), where
+      # occluded: board == c (rendering.py:177-179); unoccluded: the raw masks
+      assert np.array_equal(np.stack([obs.layers[c] for c in chars]), planes[e, 1:] != 0), where + ': layers'
       assert (r is None) == (not reward_set[e]) and (r or 0) == reward[e], where
       assert d == discount[e] and game.game_over == bool(done[e]), where
   assert ended > 0  # (every level sees restarts)
