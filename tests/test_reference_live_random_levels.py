@@ -174,3 +174,95 @@ def test_oracle_croppers_match_the_live_reference_croppers_on_a_random_level(mak
         if t and not np.array_equal(windows[t][i][e, 0], windows[t - 1][i][e, 0]):
           moved += 1
   assert moved > 0
+
+
+# ---- levels WITHOUT walls around them: numpy's index -1, IndexError past the last row / column, things off the board ------
+def random_open_warehouse(rng, kit):
+  rows, cols = int(rng.randint(4, 9)), int(rng.randint(5, 11))
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  art[rng.rand(rows, cols) < 0.08] = '#'
+  cells = [(r, c) for r in range(rows) for c in range(cols) if art[r, c] == ' ']
+  rng.shuffle(cells)
+  boxes = list('1234'[:int(rng.randint(1, 5))])
+  for ch in boxes + ['P'] + ['_'] * (len(boxes) + 1):
+    art[cells.pop()] = ch
+  sprites = {ch: kit.Box for ch in boxes}
+  sprites['P'] = kit.Pusher
+  return kit.ascii_art.ascii_art_to_game([''.join(r) for r in art], ' ', sprites, {'X': kit.Judge}, update_schedule=[boxes, ['X'], ['P']])
+
+
+def random_open_better_scrolly(rng, kit):
+  rows, cols = int(rng.randint(5, 10)), int(rng.randint(7, 15))
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  u = rng.rand(rows, cols)
+  art[u < 0.12] = '#'
+  art[(u >= 0.12) & (u < 0.2)] = '@'
+  art[:, -1][rng.rand(rows) < 0.6] = '#'  # (most rows end on a wall: fewer patrollers run into the IndexError of `col + 1`)
+  art[0, 0] = '@'                         # (where everything off the board "is")
+  cells = [(r, c) for r in range(rows) for c in range(cols - 1) if art[r, c] == ' ']
+  rng.shuffle(cells)
+  for ch in 'abcP':
+    art[cells.pop()] = ch
+  return kit.ascii_art.ascii_art_to_game(
+      [''.join(r) for r in art], ' ', sprites={'P': kit.Walker, 'a': kit.Patroller, 'b': kit.Patroller, 'c': kit.Patroller},
+      drapes={'@': kit.Cash}, update_schedule=['a', 'b', 'c', 'P', '@'], z_order='abc@P')
+
+
+@pytest.mark.parametrize('maker', [random_open_warehouse, random_open_better_scrolly], ids=lambda m: m.__name__)
+@pytest.mark.parametrize('seed', range(12))
+def test_oracle_matches_the_live_reference_on_a_random_unwalled_level(maker, seed):
+  """Where the reference raises (the IndexError of `layers[..][row + 1, col]` past the last row, warehouse_manager.py:
+  219-226, better_scrolly_maze.py:291-294), the oracle's error bit comes up in that frame; until then every board is the
+  reference's -- pushes "through" index -1, patrollers turning on walls they see at [row, -1], boxes and players off the
+  board at position (0, 0) included (tests/test_raise_parity.py check_walkers; the committed fixtures of this kind are
+  warehouse_open_A / _B and better_scrolly_custom_D)."""
+  from tests.test_raise_parity import check_walkers
+  kit = reference_kit()
+  template = GameTemplate.from_engine(maker(np.random.RandomState(7300 + seed), levels.OURS))
+  make = lambda: maker(np.random.RandomState(7300 + seed), kit)
+  n_actions, E, T = int(template.n_actions), 12, 120
+  rng = np.random.RandomState(8300 + seed)
+  tape = rng.randint(0, n_actions, size=(T, E)).astype(np.int32)
+  tape[rng.rand(T, E) < 0.01] = n_actions  # (the quit action, rarely: episodes should last)
+  boards, raise_frame, raise_bit = None, np.full(E, -1, np.int32), np.zeros(E, np.uint8)
+  off_board = 0
+  for e in range(E):
+    game = make()
+    obs = game.its_showtime()[0]
+    if boards is None:
+      boards = np.zeros((T + 1, E) + obs.board.shape, np.uint8)
+    boards[0, e] = obs.board
+    for t in range(T):
+      try:
+        if game.game_over:
+          game = make()
+          obs = game.its_showtime()[0]
+        else:
+          obs = game.play(int(tape[t, e]))[0]
+      except IndexError:
+        raise_frame[e], raise_bit[e] = t + 1, 1  # pcx_device.h ERR_INDEX
+        break
+      boards[t + 1, e] = obs.board
+      off_board += sum(1 for th in game.things.values() if hasattr(th, 'virtual_position') and not th.visible)
+  orc = binding.OracleEngine(template, E)
+  orc.reset()
+
+  def frames():
+    for f in range(T + 1):
+      if f:
+        orc.step(tape[f - 1], auto_reset=True)
+      yield f, np.array(orc.planes)[:, 0], np.array(orc.error)
+  check_walkers(dict(boards=boards, raise_frame=raise_frame, raise_bit=raise_bit), frames())
+  UNWALLED_STATS.append((maker.__name__, off_board, int((raise_frame >= 0).sum()), E))
+
+
+UNWALLED_STATS = []
+
+
+def test_the_random_unwalled_levels_see_things_off_the_board_and_raises():
+  if not UNWALLED_STATS:
+    pytest.skip('runs after test_oracle_matches_the_live_reference_on_a_random_unwalled_level in the same process')
+  for name in ('random_open_warehouse', 'random_open_better_scrolly'):
+    rows = [s for s in UNWALLED_STATS if s[0] == name]
+    if rows:
+      assert sum(s[1] for s in rows) > 0 and 0 < sum(s[2] for s in rows) < sum(s[3] for s in rows), (name, rows)
