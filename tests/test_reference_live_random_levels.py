@@ -266,3 +266,53 @@ def test_the_random_unwalled_levels_see_things_off_the_board_and_raises():
     rows = [s for s in UNWALLED_STATS if s[0] == name]
     if rows:
       assert sum(s[1] for s in rows) > 0 and 0 < sum(s[2] for s in rows) < sum(s[3] for s in rows), (name, rows)
+
+
+@pytest.mark.parametrize('maker', [levels.random_warehouse, levels.random_better_scrolly, levels.random_marauders], ids=lambda m: m.__name__)
+@pytest.mark.parametrize('seed', range(6))
+def test_numpy_oracle_postprocessors_match_the_live_reference_on_a_random_level(maker, seed, monkeypatch):
+  """oracle/postprocess.py (what the GPU suite checks the device post-processors and the fused epilogues against) next to
+  the reference's own ObservationToArray / ObservationToFeatureArray / ObservationCharacterRepainter (rendering.py:304-661)
+  on the observations of a random level: random value tables (scalars and vectors, several dtypes), random layer lists
+  with characters the game does not have, every axis order, random repaint tables -- and the RuntimeError for a
+  character without a value."""
+  from oracle import postprocess as opost
+  kit = reference_kit()
+  rendering = importlib.import_module('pycolab.rendering')
+  monkeypatch.setattr(np.random, 'choice', ref_live._Choice(0xBEE + seed, binding.action_hash))
+  rng = np.random.RandomState(7600 + seed)
+  game = maker(np.random.RandomState(7500 + seed), kit)
+  obs = game.its_showtime()[0]
+  chars = sorted(obs.layers)
+  n_actions = 4
+  for step in range(30):
+    depth = int(rng.choice([0, 1, 3]))
+    dtype = [np.float32, np.uint8, np.int32, np.float64][int(rng.randint(4))]
+    values = {c: (rng.randint(0, 200, size=depth).tolist() if depth else float(rng.randint(0, 200))) for c in chars}
+    permute = None if depth == 0 or rng.rand() < 0.4 else [int(x) for x in rng.permutation(3)]
+    want = rendering.ObservationToArray(values, dtype=dtype, permute=permute)(obs)
+    got = opost.to_array(obs.board, values, dtype, permute)
+    assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), ('to_array', step)
+    missing = dict(values)
+    gone = chr(int(rng.choice(np.unique(obs.board))))
+    del missing[gone]
+    with pytest.raises(RuntimeError):
+      rendering.ObservationToArray(missing, dtype=dtype)(obs)
+    with pytest.raises(RuntimeError):
+      opost.to_array(obs.board, missing, dtype)
+    layers = [c for c in chars if rng.rand() < 0.7] + ['~', 'q'][:int(rng.randint(3))]
+    rng.shuffle(layers)
+    if layers:
+      permute = None if rng.rand() < 0.4 else [int(x) for x in rng.permutation(3)]
+      want = rendering.ObservationToFeatureArray(layers, permute=permute)(obs)
+      got = opost.feature_array(obs.layers, layers, obs.board.shape, permute)
+      assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), ('features', step)
+    mapping = {c: chars[int(rng.randint(len(chars)))] if rng.rand() < 0.7 else '%' for c in chars if rng.rand() < 0.4}
+    want = rendering.ObservationCharacterRepainter(mapping)(obs)
+    board, got_layers = opost.repaint(obs.board, chars, mapping)
+    assert np.array_equal(board, want.board) and sorted(got_layers) == sorted(want.layers), ('repaint', step)
+    for c in want.layers:
+      assert np.array_equal(got_layers[c], want.layers[c]), ('repaint layer', c, step)
+    if game.game_over:
+      break
+    obs = game.play(int(rng.randint(n_actions)))[0]
