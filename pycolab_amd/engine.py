@@ -574,7 +574,7 @@ class Engine(object):
 
   @property
   def z_order(self):
-    if self._sprites_and_drapes:
+    if self._sprites_and_drapes or self._template is None:  # (an engine nothing was added to yet has an empty z-order, engine.py:664-667)
       return list(self._sprites_and_drapes.keys())
     return self._template.thing_chars()
 
