@@ -159,3 +159,102 @@ def test_cropper_constructors_and_set_engine_raise_what_the_reference_raises(see
       except Exception as ex:  # pylint: disable=broad-except
         outcome.append((None, type(ex).__name__))
     assert outcome[0] == outcome[1], (args, board, outcome)
+
+
+def _random_art_call(rng):
+  """A well-formed ascii_art_to_game() call with AT MOST ONE defect (which of two defects is reported first is nobody's
+  contract: it depends on the iteration order of dicts and sets)."""
+  rows, cols = int(rng.randint(1, 6)), int(rng.randint(2, 8))
+  floor = ' .'
+  art = np.array([[floor[int(rng.randint(2))] for _ in range(cols)] for _ in range(rows)], dtype='<U1')
+  art[rng.rand(rows, cols) < 0.2] = '#'
+  art[rng.rand(rows, cols) < 0.15] = '@'
+  cells = [(r, c) for r in range(rows) for c in range(cols)]
+  rng.shuffle(cells)
+  sprites = {}
+  for ch in 'ab':
+    if cells and rng.rand() < 0.7:
+      art[cells.pop()] = ch
+      sprites[ch] = 'S'
+  drapes = {c: 'D' for c in '@#' if (art == c).any() and rng.rand() < 0.8}
+  for c in '@#':
+    if c not in drapes:
+      art[art == c] = ' '
+  art = [''.join(r) for r in art]
+  under = str.maketrans('ab@#', ' . .')
+  beneath = ' ' if rng.rand() < 0.6 else [row.translate(under) for row in art]  # (a whole art: ascii_art.py:113-129)
+  entities = sorted(set(sprites) | set(drapes))
+  order = list(entities)
+  rng.shuffle(order)
+  v = rng.rand()
+  schedule = None if v < 0.35 else order if v < 0.65 else [order[:len(order) // 2], order[len(order) // 2:]]
+  z = list(entities)
+  rng.shuffle(z)
+  w = rng.rand()
+  z_order = None if w < 0.4 else ''.join(z) if w < 0.7 else z
+  defect = str(rng.choice(['none', 'none', 'ragged', 'empty', 'wrong base', 'unknown in art', 'claimed twice', 'sprite twice', 'beneath string',
+                           'beneath shape', 'schedule misses', 'schedule twice', 'z misses', 'z twice', 'z stranger']))
+  if defect == 'ragged':
+    art[int(rng.randint(rows))] += ' '
+  elif defect == 'empty':
+    art = []
+  elif defect == 'wrong base' and sprites:
+    sprites[sorted(sprites)[0]] = 'D'
+  elif defect == 'unknown in art':
+    art[0] = '?' + art[0][1:] if art[0][0] in floor else art[0]  # ('?' has no class: it becomes part of the backdrop -- no error)
+  elif defect == 'claimed twice' and drapes:
+    sprites[sorted(drapes)[0]] = 'S'
+  elif defect == 'sprite twice' and sprites and cells:
+    r, c = cells.pop()
+    art[r] = art[r][:c] + sorted(sprites)[0] + art[r][c + 1:]
+  elif defect == 'beneath string':
+    beneath = '. '
+  elif defect == 'beneath shape' and isinstance(beneath, list) and len(beneath) > 1:
+    beneath = beneath[:-1]
+  elif defect == 'schedule misses' and schedule and entities:
+    schedule = [e for e in order if e != entities[0]]
+  elif defect == 'schedule twice' and schedule and entities:
+    schedule = order + [order[0]]
+  elif defect == 'z misses' and z_order is not None and len(z) > 1:
+    z_order = ''.join(z[:-1])
+  elif defect == 'z twice' and z_order is not None and z:
+    z_order = ''.join(z + [z[0]])
+  elif defect == 'z stranger' and z_order is not None:
+    z_order = ''.join(z) + '?'
+  return dict(art=art, beneath=beneath, sprites=sprites, drapes=drapes, schedule=schedule, z_order=z_order, defect=defect)
+
+
+@pytest.mark.parametrize('seed', range(50))
+def test_ascii_art_to_game_raises_what_the_reference_raises(seed):
+  """ascii_art.py:31-291: ragged art, unknown and doubly claimed characters, sprites that appear twice, a
+  what_lies_beneath of the wrong kind or shape, update schedules (flat and nested) with entities missing or twice,
+  z-orders that are no permutation -- same exception type on both sides or none, and then the same game."""
+  (ref_engine, ref_things), (our_engine, our_things) = modules()
+  ref_art = importlib.import_module('pycolab.ascii_art')
+  from pycolab_amd import ascii_art as our_art
+  rng = np.random.RandomState(15000 + seed)
+  for n in range(20):
+    call = _random_art_call(rng)
+    outcome = []
+    for art_module, things_module in ((ref_art, ref_things), (our_art, our_things)):
+      classes = entity_classes(things_module)
+      kwargs = dict(sprites={c: classes[k] for c, k in call['sprites'].items()}, drapes={c: classes[k] for c, k in call['drapes'].items()})
+      if call['schedule'] is not None:
+        kwargs['update_schedule'] = call['schedule']
+      if call['z_order'] is not None:
+        kwargs['z_order'] = call['z_order']
+      try:
+        game = art_module.ascii_art_to_game(list(call['art']), call['beneath'], **kwargs)
+        groups = [[e.character for e in ents] for _, ents in sorted(game._update_groups.items())] if hasattr(game._update_groups, 'items') else None
+        # (without a schedule the order of updates -- and, without a z-order too, of painting -- is the iteration order of a
+        # set of characters in the reference, ascii_art.py:161: unspecified, compared as a set)
+        specified = call['schedule'] is not None or call['z_order'] is not None
+        outcome.append((None, list(game.z_order) if specified else sorted(game.z_order), sorted(game.things), groups if call['schedule'] is not None else None,
+                        np.asarray(game.backdrop.curtain).tolist()))
+      except Exception as ex:  # pylint: disable=broad-except
+        outcome.append((type(ex).__name__,))
+    assert outcome[0] == outcome[1], (seed, n, call, outcome)
+    SEEN.append((call['defect'], outcome[0][0]))
+
+
+SEEN = []
