@@ -258,3 +258,49 @@ def test_ascii_art_to_game_raises_what_the_reference_raises(seed):
 
 
 SEEN = []
+
+
+@pytest.mark.parametrize('seed', range(30))
+def test_scrolly_pattern_info_matches_the_reference(seed):
+  """prefab_parts/drapes.py:166-289 Scrolly.PatternInfo: the board's corner mark (missing, twice), boards given as art or
+  as a shape, boards larger than the world, a non-ASCII what_lies_beneath, characters looked up that are absent or
+  appear twice -- same exception type or the same kwargs() / virtual_position()."""
+  path = ref_live.reference_path()
+  if path not in sys.path:
+    sys.path.insert(0, path)
+  warnings.filterwarnings('ignore', category=DeprecationWarning)
+  ref_drapes = importlib.import_module('pycolab.prefab_parts.drapes')
+  from pycolab_amd.prefab_parts import drapes as our_drapes
+  rng = np.random.RandomState(16000 + seed)
+  for n in range(30):
+    rows, cols = int(rng.randint(2, 9)), int(rng.randint(2, 12))
+    world = np.full((rows, cols), ' ', dtype='<U1')
+    world[rng.rand(rows, cols) < 0.25] = '#'
+    world[rng.rand(rows, cols) < 0.1] = '@'
+    cells = [(r, c) for r in range(rows) for c in range(cols)]
+    rng.shuffle(cells)
+    for ch, count in (('+', int(rng.choice([1, 1, 1, 1, 0, 2]))), ('P', int(rng.choice([1, 1, 1, 0, 2]))), ('a', 1)):
+      for _ in range(count):
+        if cells:
+          world[cells.pop()] = ch
+    world = [''.join(r) for r in world]
+    shape = (int(rng.randint(1, rows + 2)), int(rng.randint(1, cols + 2)))
+    board = shape if rng.rand() < 0.5 else [' ' * shape[1]] * shape[0]
+    beneath = ' ' if rng.rand() < 0.9 else 'é'
+    outcome = []
+    for module in (ref_drapes, our_drapes):
+      try:
+        info = module.Scrolly.PatternInfo(world, board, '+', beneath)
+      except Exception as ex:  # pylint: disable=broad-except
+        outcome.append(('constructor', type(ex).__name__))
+        continue
+      seen = []
+      for ch in 'Pa#@?':
+        try:
+          seen.append(tuple(int(x) for x in info.virtual_position(ch)))
+        except Exception as ex:  # pylint: disable=broad-except
+          seen.append(type(ex).__name__)
+        kw = info.kwargs(ch)
+        seen.append((tuple(kw['board_shape']), tuple(int(x) for x in kw['board_northwest_corner']), np.asarray(kw['whole_pattern']).tolist()))
+      outcome.append(seen)
+    assert outcome[0] == outcome[1], (seed, n, world, board, outcome[0][:2], outcome[1][:2])
