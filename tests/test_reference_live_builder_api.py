@@ -304,3 +304,38 @@ def test_scrolly_pattern_info_matches_the_reference(seed):
         seen.append((tuple(kw['board_shape']), tuple(int(x) for x in kw['board_northwest_corner']), np.asarray(kw['whole_pattern']).tolist()))
       outcome.append(seen)
     assert outcome[0] == outcome[1], (seed, n, world, board, outcome[0][:2], outcome[1][:2])
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_postprocessor_constructors_raise_what_the_reference_raises(seed):
+  """rendering.py:340-360, 409-482, 545-608: value tables of scalars or vectors, `permute` arguments that are and are not
+  permutations of the right length, layer lists, repaint tables -- same exception type from the constructor or none."""
+  path = ref_live.reference_path()
+  if path not in sys.path:
+    sys.path.insert(0, path)
+  warnings.filterwarnings('ignore', category=DeprecationWarning)
+  ref_rendering = importlib.import_module('pycolab.rendering')
+  from pycolab_amd import rendering as our_rendering
+  rng = np.random.RandomState(17000 + seed)
+  for n in range(40):
+    kind = int(rng.randint(3))
+    perm_pool = [None, (0, 1), (1, 0), (0, 1, 2), (1, 2, 0), (2, 0, 1), (0, 0), (0, 1, 1), (1, 2), (0, 1, 2, 3), [1, 2, 0], (2, 1)]
+    permute = perm_pool[int(rng.randint(len(perm_pool)))]
+    if kind == 0:
+      depth = int(rng.choice([0, 1, 3, 4]))
+      values = {c: (rng.randint(0, 9, size=depth).tolist() if depth else float(rng.randint(9))) for c in 'ab# '[:int(rng.randint(1, 5))]}
+      dtype = [None, np.float32, np.uint8][int(rng.randint(3))]
+      args = ('ObservationToArray', (values,), dict(dtype=dtype, permute=permute))
+    elif kind == 1:
+      layers = ['ab# ~'[:int(rng.randint(1, 6))], list('ab'), 'a'][int(rng.randint(3))]
+      args = ('ObservationToFeatureArray', (layers,), dict(permute=permute))
+    else:
+      args = ('ObservationCharacterRepainter', ({c: 'x#.'[int(rng.randint(3))] for c in 'ab12'[:int(rng.randint(0, 5))]},), {})
+    outcome = []
+    for module in (ref_rendering, our_rendering):
+      try:
+        getattr(module, args[0])(*args[1], **args[2])
+        outcome.append(None)
+      except Exception as ex:  # pylint: disable=broad-except
+        outcome.append(type(ex).__name__)
+    assert outcome[0] == outcome[1], (seed, n, args, outcome)
