@@ -40,7 +40,8 @@ class Mutant(object):
 # trace, test_cropping), 'reftest:<name>' (the reference's own known-answer tests, tests/golden/reftests),
 # 'engine_test:<what>' (tests/engine_test.py:169-295 restated in test_reference_known_answers), 'raise:<name>'
 # (tests/golden/raises: where the reference raised, test_raise_parity), 'story:<name>' (the reference's own Story over
-# three chapter games, test_story_oracle)
+# three chapter games, test_story_oracle), 'live:<maker>:<seed>' (a random unwalled level next to the live reference,
+# test_reference_live_random_levels)
 MUTANTS = [
     Mutant('kill_test_on_true_positions', 'examples/scrolly_maze.py:304 compares VIRTUAL positions',
            'pcx_oracle.c',
@@ -209,8 +210,11 @@ MUTANTS = [
            'pcx_oracle.c',
            "  if (layer_char_at(x, '#', row, col - 1)) s->var[0] = 1;\n  if (layer_char_at(x, '#', row, col + 1)) s->var[0] = 0;",
            "  if (layer_char_at(x, '#', row, col + 1)) s->var[0] = 0;\n  if (layer_char_at(x, '#', row, col - 1)) s->var[0] = 1;",
-           killed_by=[],
-           equivalent='walls do not move in better_scrolly_maze: a patroller with a wall on both sides is stuck for good, and which way it would like to go is never seen'),
+           # (thought equivalent at first -- "walls do not move: a patroller walled in on both sides is stuck for good" -- until
+           # the live fuzz killed it: a patroller OFF the board looks around position (0, 0), not around where it is, and
+           # out there nothing stops it from going the way it then prefers.  No committed fixture has walls on both sides
+           # of (0, 0): the random unwalled levels stepped next to the live reference are what pins it.)
+           killed_by=['live:random_open_better_scrolly:1']),
     Mutant('better_last_coin_does_not_end_the_episode', 'examples/better_scrolly_maze.py:317-320',
            'pcx_oracle.c',
            '    for (int i = 0; i < cells(e); ++i) any |= d->curtain[i];\n    if (!any) plot_terminate(&env->plot, 0.0f);',
@@ -588,6 +592,10 @@ def fixture_passes(fixture):
       else:
         for discount in (None, 0.5):
           t.test_oracle_reward_and_episode_end_known_answer(discount)
+    elif kind == 'live':  # a random level next to the reference stepped live (needs the reference: /root/reference or oracle/_ref)
+      from tests import test_reference_live_random_levels as live
+      maker, seed = name.split(':')
+      live.test_oracle_matches_the_live_reference_on_a_random_unwalled_level(getattr(live, maker), int(seed))
     elif kind == 'story':
       from tests import test_story_oracle
       test_story_oracle.test_oracle_story_matches_reference_story(name)
@@ -606,9 +614,13 @@ def fixture_passes(fixture):
 
 def all_fixtures():
   from tests import test_oracle_golden, test_cropping, test_reference_known_answers, test_raise_parity, test_story_oracle
+  from oracle import ref_live
   return (['trace:' + n for n in test_oracle_golden.ALL_TRACES] + ['crop:' + n for n in test_cropping.CROPPED] +
           ['reftest:' + n for n in test_reference_known_answers.NAMES] + ['engine_test:z_order', 'engine_test:reward'] + ['story:' + n for n in sorted(test_story_oracle.STORIES)] +
-          ['raise:' + n for n in test_raise_parity.STEPPED + ('fixed_crop_overhang',)])
+          ['raise:' + n for n in test_raise_parity.STEPPED + ('fixed_crop_overhang',)] +
+          # (not fixtures: random unwalled levels next to the reference stepped live, where it can be imported)
+          (['live:%s:%d' % (m, k) for m in ('random_open_warehouse', 'random_open_better_scrolly') for k in range(12)]
+           if ref_live.reference_path() else []))
 
 
 def main():

@@ -16,13 +16,20 @@ def scratch(tmp_path_factory):
 
 
 def test_the_unmutated_oracle_passes_every_fixture_a_mutant_is_judged_by():
+  from oracle import ref_live
   for f in sorted({f for m in mutants.MUTANTS for f in m.killed_by + m.survives}):
+    if f.startswith('live:') and ref_live.reference_path() is None:
+      continue
     assert mutants.fixture_passes(f), f
 
 
 @pytest.mark.parametrize('mutant', mutants.MUTANTS, ids=[m.name for m in mutants.MUTANTS])
 def test_fixtures_kill_the_mutant(mutant, scratch):
   so = mutants.build(mutant, scratch)
+  if any(f.startswith('live:') for f in mutant.killed_by):
+    from oracle import ref_live
+    if ref_live.reference_path() is None:
+      pytest.skip('judged by a level stepped next to the live reference, which is neither under /root/reference nor built under oracle/_ref')
   if mutant.equivalent:  # no fixture CAN tell it apart (the reason is the mutant's `equivalent`); it still has to compile
     assert not mutant.killed_by
     return
