@@ -151,7 +151,7 @@ class Coins(prefab_drapes.Scrolly):
   pcx_program = 'scrolly_maze.cash'
 
 
-def random_scrolly(rng, kit=None):
+def random_scrolly(rng, kit=None, walled=True):
   kit = kit or OURS
   br, bc = int(rng.randint(4, 13)), int(rng.randint(6, 33))  # (the default scroll margins (2, 3) need at least 4 x 6)
   rows, cols = br + int(rng.randint(0, 25)), bc + int(rng.randint(0, 50))
@@ -160,7 +160,8 @@ def random_scrolly(rng, kit=None):
   patrollers = 'abcde'[:int(rng.randint(0, 6))]
   sprites = patrollers + 'P'
   art = np.full((rows, cols), ' ', dtype='<U1')
-  art[0, :] = art[-1, :] = art[:, 0] = art[:, -1] = '#'
+  if walled:  # (tests/test_reference_live_random_levels.py also draws worlds without a wall around them)
+    art[0, :] = art[-1, :] = art[:, 0] = art[:, -1] = '#'
   inner = rng.rand(rows - 2, cols - 2)
   art[1:-1, 1:-1][inner < 0.2] = '#'
   art[1:-1, 1:-1][(inner >= 0.2) & (inner < 0.27)] = '@'
@@ -177,7 +178,7 @@ def random_scrolly(rng, kit=None):
         placed.add(ch)
         break
   if 'P' not in placed:
-    return random_scrolly(rng, kit)
+    return random_scrolly(rng, kit, walled)
   sprites = ''.join(ch for ch in sprites if ch in placed)
   beneath = art[cr, cc] if art[cr, cc] in '# ' else ' '
   art[cr, cc] = '+'

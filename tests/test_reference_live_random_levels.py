@@ -208,7 +208,14 @@ def random_open_better_scrolly(rng, kit):
       drapes={'@': kit.Cash}, update_schedule=['a', 'b', 'c', 'P', '@'], z_order='abc@P')
 
 
-@pytest.mark.parametrize('maker', [random_open_warehouse, random_open_better_scrolly], ids=lambda m: m.__name__)
+def random_open_scrolly_maze(rng, kit):
+  """tests/test_random_levels.py random_scrolly without the wall around the world: patrollers reach the pattern's first
+  and last column (`whole_pattern[row, col - 1]` is the LAST column there, `[row, col + 1]` an IndexError:
+  scrolly_maze.py:295-299), the window scrolls up to the pattern's bare edge."""
+  return levels.random_scrolly(rng, kit, walled=False)
+
+
+@pytest.mark.parametrize('maker', [random_open_warehouse, random_open_better_scrolly, random_open_scrolly_maze], ids=lambda m: m.__name__)
 @pytest.mark.parametrize('seed', range(12))
 def test_oracle_matches_the_live_reference_on_a_random_unwalled_level(maker, seed):
   """Where the reference raises (the IndexError of `layers[..][row + 1, col]` past the last row, warehouse_manager.py:
@@ -262,7 +269,7 @@ UNWALLED_STATS = []
 def test_the_random_unwalled_levels_see_things_off_the_board_and_raises():
   if not UNWALLED_STATS:
     pytest.skip('runs after test_oracle_matches_the_live_reference_on_a_random_unwalled_level in the same process')
-  for name in ('random_open_warehouse', 'random_open_better_scrolly'):
+  for name in ('random_open_warehouse', 'random_open_better_scrolly', 'random_open_scrolly_maze'):
     rows = [s for s in UNWALLED_STATS if s[0] == name]
     if rows:
       assert sum(s[1] for s in rows) > 0 and 0 < sum(s[2] for s in rows) < sum(s[3] for s in rows), (name, rows)
