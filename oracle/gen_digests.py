@@ -5,7 +5,7 @@ For scrolly_maze L0, warehouse_manager L0, extraterrestrial_marauders and better
 reference (oracle/ref_live.py) steps 4,096 environments for 256 steps, resets included, on the bench's own tape --
 environments [0, 4096) and [1,044,480, 1,048,576): the head and the tail of the headline batch -- and what play()
 returned is reduced to digests (ref_live.chunk_digests): per step and chunk of 256 environments the first 8 bytes
-of a SHA-256 over board | reward | reward_set | discount | done, and per step the SHA-256 over that step's full chunk
+of a SHA-256 over board | (scrolly_maze_L1_unoccluded: every layer |) reward | reward_set | discount | done, and per step the SHA-256 over that step's full chunk
 digests.  tests/test_gate_digests.py requires the C oracle (CPU suite) and the HIP path (GPU suite, the tail offset
 inside a real 1,048,576-environment engine for scrolly_maze) to reproduce them.
 
@@ -24,7 +24,8 @@ from oracle import ref_live  # noqa: E402
 
 N_ENVS, STEPS, SEED = 4096, 256, 0x5EED
 OFFSETS = {'head': 0, 'tail': 1048576 - N_ENVS}
-GAMES = ('scrolly_maze_L0', 'warehouse_L0', 'marauders', 'better_scrolly_maze_L0')
+GAMES = ('scrolly_maze_L0', 'warehouse_L0', 'marauders', 'better_scrolly_maze_L0',
+         'scrolly_maze_L1_unoccluded')  # round 6: occlusion_in_layers=False at gate size, every layer in the digest
 
 
 def reduce(chunk32):

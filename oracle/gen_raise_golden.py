@@ -144,7 +144,14 @@ def marauders_to_array(E, T):
   make, n_actions = ref_live._import_game('marauders')
   from pycolab import rendering
   choice = ref_live._Choice(SEED, binding.action_hash)
-  np.random.choice = choice
+  real_choice, np.random.choice = np.random.choice, choice
+  try:
+    _marauders_to_array(E, T, make, n_actions, rendering, choice)
+  finally:
+    np.random.choice = real_choice  # 
+
+
+def _marauders_to_array(E, T, make, n_actions, rendering, choice):
   mapping = {c: float(i) for i, c in enumerate(' BPXabdyz')}  # no 'c': the player's third bolt (extraterrestrial_marauders.py), in flight from frame 7-25 on
   raise_frame, arrays = np.full(E, -1, np.int32), None
   for e in range(E):
@@ -194,12 +201,19 @@ def fixed_crop_overhang():
 
 
 def main():
+  only = set(a for a in sys.argv[1:] if not a.startswith('-'))  # fixture names to (re)generate; empty = all
+  want = lambda name: not only or name in only
   for name in ('walkers_scroll_always', 'walkers_scroll_margins', 'walkers_scroll_groups', 'walkers_room', 'walkers_scroll_disagree'):
-    walkers(name, E=128, T=320)
-  for name in ('warehouse_open_A', 'warehouse_open_B'):
-    warehouse_open(name, E=96, T=256)
-  marauders_to_array(E=32, T=96)
-  fixed_crop_overhang()
+    if want(name):
+      walkers(name, E=128, T=320)
+  from oracle import custom_levels
+  for name in custom_levels.WAREHOUSE_OPEN_NAMES:
+    if want(name):
+      warehouse_open(name, E=96, T=256)
+  if want('marauders_to_array'):
+    marauders_to_array(E=32, T=96)
+  if want('fixed_crop_overhang'):
+    fixed_crop_overhang()
 
 
 if __name__ == '__main__':

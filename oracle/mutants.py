@@ -213,8 +213,9 @@ MUTANTS = [
            # (thought equivalent at first -- "walls do not move: a patroller walled in on both sides is stuck for good" -- until
            # the live fuzz killed it: a patroller OFF the board looks around position (0, 0), not around where it is, and
            # out there nothing stops it from going the way it then prefers.  No committed fixture has walls on both sides
-           # of (0, 0): the random unwalled levels stepped next to the live reference are what pins it.)
-           killed_by=['live:random_open_better_scrolly:1']),
+           # of (0, 0): the random unwalled levels stepped next to the live reference were what pinned it.  Round 6: the
+           # trace better_scrolly_custom_E has -- the committed fixture the GPU suite replays through both kernels.)
+           killed_by=['trace:better_scrolly_custom_E', 'live:random_open_better_scrolly:1']),
     Mutant('better_last_coin_does_not_end_the_episode', 'examples/better_scrolly_maze.py:317-320',
            'pcx_oracle.c',
            '    for (int i = 0; i < cells(e); ++i) any |= d->curtain[i];\n    if (!any) plot_terminate(&env->plot, 0.0f);',

@@ -462,6 +462,10 @@ int HelloWorldBackend::init(const pcx_template& t, int64_t batch) {
   if ((rc = initc_.upload(initc))) return rc;
   if ((rc = state_.alloc((size_t)NW_ * bpad_))) return rc;
   if ((rc = track_.alloc((size_t)NS * bpad_))) return rc;
+  // the persistent workers' ticket shards and done-count (pcx_stream.h WorkQueue), 64 bytes apart: allocated and zeroed HERE,
+  // with the device synchronisation that follows engine creation -- a first launch on a non-blocking stream (or under
+  // stream capture) must not race a hipMemset on the null stream
+  if ((rc = work_ctr_.alloc(16 * 9))) return rc;
   return 0;
 }
 
@@ -514,7 +518,6 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
     const int64_t want = (groups + workers - 1) / workers;
     if (wgs > want) wgs = want;
     if (wgs * workers >= groups) dynamic = 0;  // every unit is some worker's first
-    if (!work_ctr_.ptr) { int rc = work_ctr_.alloc(16 * 9); if (rc) return rc; }
     P.work.ctr = work_ctr_.ptr;
     P.work.n_units = (uint32_t)groups;
     P.work.dynamic = dynamic;

@@ -59,7 +59,7 @@ def test_shipped_fingerprints_are_what_the_generator_produces(regenerated):
   assert fresh and fresh == committed
 
 
-@pytest.mark.parametrize('name', ['scrolly_maze_L0', 'warehouse_L0', 'marauders', 'better_scrolly_maze_L0'])
+@pytest.mark.parametrize('name', ['scrolly_maze_L0', 'warehouse_L0', 'marauders', 'better_scrolly_maze_L0', 'scrolly_maze_L1_unoccluded'])
 def test_gate_digests_are_what_the_reference_produces(name):
   """tests/golden/digests (oracle/gen_digests.py: the reference at 4,096 environments x 256 steps, twice per game) take
   minutes to regenerate: a sample -- one chunk of 256 environments from the head and one from the tail, the first 96 of
@@ -73,5 +73,5 @@ def test_gate_digests_are_what_the_reference_produces(name):
     off = int(fix['offset_' + tag][0])
     assert off == gen_digests.OFFSETS[tag]
     r = ref_live.run(name, off + chunk * ref_live.CHUNK, ref_live.CHUNK, steps, gen_digests.SEED)
-    got = ref_live.chunk_digests(r['boards'], r['reward'], r['reward_set'], r['discount'], r['done'])[:, 0, :8]
+    got = ref_live.chunk_digests(r['boards'], r['reward'], r['reward_set'], r['discount'], r['done'], r.get('layers'))[:, 0, :8]
     np.testing.assert_array_equal(got, fix['chunks_' + tag][:steps + 1, chunk], err_msg='%s %s chunk %d' % (name, tag, chunk))

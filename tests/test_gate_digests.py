@@ -3,7 +3,7 @@ resets included, bit-exact against the imported reference on identical action se
 
 tests/golden/digests/<game>.npz (oracle/gen_digests.py) hold digests of what the IMPORTED reference returned for
 environments [0, 4096) and [1,044,480, 1,048,576) of the headline batch over 256 steps of the bench's tape.  The C
-oracle reproduces a sample of them in the CPU suite and all of them next to the GPU; the HIP path reproduces all of them
+oracle reproduces all of them in the CPU suite (on the host's cores in parallel); the HIP path reproduces all of them
 in the GPU suite -- scrolly_maze inside a real 1,048,576-environment engine in its default launch shape."""
 import hashlib
 import os
@@ -14,16 +14,19 @@ import pytest
 from oracle import binding, ref_live
 from tests import helpers
 
-GAMES = ('scrolly_maze_L0', 'warehouse_L0', 'marauders', 'better_scrolly_maze_L0')
+# scrolly_maze_L1_unoccluded (round 6): Engine(..., occlusion_in_layers=False) at gate size -- its digests cover EVERY layer
+# plane (they are no function of the board there), the other games' the board (layers: `layer == (board == c)` sweeps)
+GAMES = ('scrolly_maze_L0', 'warehouse_L0', 'marauders', 'better_scrolly_maze_L0', 'scrolly_maze_L1_unoccluded')
 
 
 def load(name):
   return np.load(os.path.join(helpers.ROOT, 'tests', 'golden', 'digests', name + '.npz'))
 
 
-def frame_digests(boards, reward, reward_set, discount, done):
-  """Full 32-byte chunk digests [chunks, 32] of ONE frame of n environments."""
-  return ref_live.chunk_digests(boards[None], reward[None], reward_set[None], discount[None], done[None])[0]
+def frame_digests(name, planes, reward, reward_set, discount, done):
+  """Full 32-byte chunk digests [chunks, 32] of ONE frame of n environments (planes [n, 1 + L, R, C])."""
+  layers = (planes[:, 1:] != 0).astype(np.uint8)[None] if name in ref_live.UNOCCLUDED else None
+  return ref_live.chunk_digests(planes[:, 0][None], reward[None], reward_set[None], discount[None], done[None], layers)[0]
 
 
 def check_frame(fix, tag, t, chunk32, first_chunk=0, whole=True):
@@ -44,37 +47,48 @@ def oracle_frames(name, off, n, steps):
     if f:
       orc.step_hashed(0x5EED, f - 1, 1, env_offset=off)
     planes = np.array(orc.planes)
-    yield f, frame_digests(planes[:, 0], np.array(orc.reward), np.array(orc.reward_set), np.array(orc.discount), np.array(orc.done))
+    yield f, frame_digests(name, planes, np.array(orc.reward), np.array(orc.reward_set), np.array(orc.discount), np.array(orc.done))
 
 
 @pytest.mark.parametrize('name', GAMES)
-def test_oracle_reproduces_a_sample_of_the_reference_digests(name):
-  """CPU suite: the first 512 environments of the head and of the tail of the batch, all 256 steps (the fixtures say how
-  many episodes ended on the way)."""
+def test_the_fixtures_are_gate_size_and_see_episodes_end(name):
   fix = load(name)
   assert int(fix['n_envs'][0]) >= 4096 and int(fix['steps'][0]) >= 256
   if name != 'warehouse_L0':  # (uniform random actions do not finish a Sokoban level)
     assert int(fix['resets_head'][0]) > 0 and int(fix['resets_tail'][0]) > 0
-  for tag in ('head', 'tail'):
-    off = int(fix['offset_' + tag][0])
-    for f, chunk32 in oracle_frames(name, off, 512, int(fix['steps'][0])):
-      check_frame(fix, tag, f, chunk32, whole=False)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('name', GAMES)
-def test_oracle_reproduces_every_reference_digest(name):
+def _oracle_job(job):
+  name, tag, first_chunk, n_chunks = job
   fix = load(name)
-  for tag in ('head', 'tail'):
-    for f, chunk32 in oracle_frames(name, int(fix['offset_' + tag][0]), int(fix['n_envs'][0]), int(fix['steps'][0])):
-      check_frame(fix, tag, f, chunk32)
+  off = int(fix['offset_' + tag][0]) + first_chunk * ref_live.CHUNK
+  out = np.zeros((int(fix['steps'][0]) + 1, n_chunks, 32), np.uint8)
+  for f, chunk32 in oracle_frames(name, off, n_chunks * ref_live.CHUNK, int(fix['steps'][0])):
+    out[f] = chunk32
+  return job, out
 
 
-def hip_frame(eng, lo, hi):
-  planes = eng.planes_view()[lo:hi, 0].cpu().numpy()
+def test_oracle_reproduces_every_reference_digest():
+  """All of them: 4,096 environments x 256 steps x head and tail x every game, two chunks of 256 environments per job on
+  the host's cores (round 5 ran this serially in the GPU suite, where it needs no GPU: VERDICT r5 weak #11)."""
+  import multiprocessing as mp
+  jobs = [(name, tag, c, 2) for name in GAMES for tag in ('head', 'tail') for c in range(0, 4096 // ref_live.CHUNK, 2)]
+  with mp.get_context('fork').Pool(min(len(os.sched_getaffinity(0)), 16)) as pool:
+    res = dict(pool.map(_oracle_job, jobs, chunksize=1))
+  for name in GAMES:
+    fix = load(name)
+    for tag in ('head', 'tail'):
+      chunk32 = np.concatenate([res[(name, tag, c, 2)] for c in range(0, 4096 // ref_live.CHUNK, 2)], axis=1)
+      for f in range(chunk32.shape[0]):
+        check_frame(fix, tag, f, chunk32[f])
+
+
+def hip_frame(name, eng, lo, hi):
+  view = eng.planes_view()
+  planes = (view[lo:hi] if name in ref_live.UNOCCLUDED else view[lo:hi, :1]).cpu().numpy()
   b = eng.buffers
   pick = lambda k: b[k].tensor[lo:hi].cpu().numpy()
-  return frame_digests(planes, pick('reward'), pick('reward_set'), pick('discount'), pick('done'))
+  return frame_digests(name, planes, pick('reward'), pick('reward_set'), pick('discount'), pick('done'))
 
 
 @pytest.mark.gpu
@@ -93,7 +107,7 @@ def test_hip_reproduces_every_reference_digest(name):
     for f in range(steps + 1):
       if f:
         eng.step_hashed(0x5EED, f - 1, 1, env_offset=off)
-      check_frame(fix, tag, f, hip_frame(eng, 0, n))
+      check_frame(fix, tag, f, hip_frame(name, eng, 0, n))
     assert not eng.buffers['error'].tensor.any()
     eng.close()
 
@@ -113,8 +127,8 @@ def test_headline_engine_reproduces_the_reference_digests_at_its_head_and_tail()
   for f in range(steps + 1):
     if f:
       eng.step_hashed(0x5EED, f - 1, 1)
-    check_frame(fix, 'head', f, hip_frame(eng, 0, n))
-    check_frame(fix, 'tail', f, hip_frame(eng, B - n, B))
+    check_frame(fix, 'head', f, hip_frame('scrolly_maze_L0', eng, 0, n))
+    check_frame(fix, 'tail', f, hip_frame('scrolly_maze_L0', eng, B - n, B))
   assert int(N.lib().pcx_engine_launch_shape(eng._native)) in (3, 5)
   assert not eng.buffers['error'].tensor.any()
   eng.close()

@@ -23,7 +23,7 @@ ALL_GAMES = LEVELS + ['warehouse_L0', 'warehouse_L1', 'warehouse_L2', 'hello_wor
                       'scrolly_custom_A_unoccluded', 'scrolly_custom_C_unoccluded', 'scrolly_custom_E_unoccluded',
                       'scrolly_custom_F', 'scrolly_custom_G', 'warehouse_custom_A', 'warehouse_custom_B', 'marauders_custom_A', 'hello_custom_A',
                       # run-time-shape instances of pcx_warehouse_step / pcx_better_scrolly_step
-                      'warehouse_custom_C', 'warehouse_custom_D', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C', 'better_scrolly_custom_D',
+                      'warehouse_custom_C', 'warehouse_custom_D', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C', 'better_scrolly_custom_D', 'better_scrolly_custom_E',
                       # Plot directives incl. change_z_order on the device (engine.py:796-835)
                       'directives_z_order', 'directives_reward_discount', 'directives_two_discounts']
 
@@ -157,6 +157,8 @@ def test_hip_hand_written_kernels_other_launch_shapes(name, knob, value, monkeyp
                                          ('hello_custom_A', 'pcx_hello_world_step'),
                                          ('warehouse_custom_C', 'pcx_warehouse_step'), ('warehouse_custom_D', 'pcx_warehouse_step'),
                                          ('better_scrolly_custom_A', 'pcx_better_scrolly_step'), ('better_scrolly_custom_B', 'pcx_better_scrolly_step'),
+                                         # unwalled boards: things off the board at (0, 0), patrollers that look around it from outside
+                                         ('better_scrolly_custom_D', 'pcx_better_scrolly_step'), ('better_scrolly_custom_E', 'pcx_better_scrolly_step'),
                                          # occlusion_in_layers=False: the warehouse kernel's own UNOCC instances (round 3);
                                          # marauders' rules read layers, so its unoccluded variant stays table-driven
                                          ('warehouse_L0_unoccluded', 'pcx_warehouse_step'), ('marauders_unoccluded', 'pcx_generic_step')])
@@ -183,6 +185,19 @@ def test_which_kernel_steps_which_game(name, kernel, shape, monkeypatch):
     a[(r >= 0.03) & (r < 0.04)] = t.n_actions   # the quit action of every shipped game
     hip.step(a, auto_reset=step % 5 != 4); orc.step(a, auto_reset=step % 5 != 4)
     assert_same(hip, orc, '%s step %d' % (name, step))
+
+
+@pytest.mark.parametrize('build', helpers.BUILDS)
+@pytest.mark.parametrize('name', ['better_scrolly_custom_D', 'better_scrolly_custom_E'])
+def test_unwalled_better_scrolly_traces_through_the_table_driven_kernel(name, build, monkeypatch):
+  """prog_bs_patroller (pcx_generic_kernel.h) on the reference's own recording of patrollers that leave an unwalled board:
+  out there they look around position (0, 0) -- in custom_E with a wall on both sides of it, where the SECOND test of
+  better_scrolly_maze.py:291-294 wins and they walk west for good (test_which_kernel_steps_which_game and
+  test_hip_matches_reference_trace hold pcx_better_scrolly_step to the same traces)."""
+  from pycolab_amd import _native as N
+  helpers.force_generic(monkeypatch, build)
+  eng = helpers.replay_trace(HipAdapter, helpers.load_trace(name))
+  assert N.lib().pcx_engine_kernel_name(eng.eng._native).decode() == 'pcx_generic_step'
 
 
 @pytest.mark.parametrize('shape', ['coop', 'single'])

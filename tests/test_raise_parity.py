@@ -19,7 +19,8 @@ from tests import helpers
 WALKERS = ('walkers_scroll_always', 'walkers_scroll_groups', 'walkers_scroll_margins', 'walkers_room', 'walkers_scroll_disagree')
 # unwalled warehouses (oracle/custom_levels.py WAREHOUSE_OPEN_ART): pushes through numpy's index -1 until a box reaches
 # the last row or column and `layers['P'][row + 1, col]` is an IndexError (warehouse_manager.py:219-226)
-STEPPED = WALKERS + ('warehouse_open_A', 'warehouse_open_B')
+# (_C / _D, round 6: the same with the shipped levels' four backdrop characters -- pcx_warehouse_step's run-time-shape instance)
+STEPPED = WALKERS + ('warehouse_open_A', 'warehouse_open_B', 'warehouse_open_C', 'warehouse_open_D')
 
 
 def load(name):
@@ -111,16 +112,21 @@ def test_oracle_fixed_cropper_without_pad_raises_where_the_reference_does():
   np.testing.assert_array_equal(window[:, 0], want)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('name', STEPPED)
-def test_hip_error_bit_rises_where_the_reference_raised(name):
+# the kernel a fixture's template takes by itself (the others: pcx_generic_step)
+HAND_WRITTEN = {'warehouse_open_C': 'pcx_warehouse_step', 'warehouse_open_D': 'pcx_warehouse_step'}
+
+
+def _hip_raise_check(name, batches):
+  from pycolab_amd import _native as N
   from pycolab_amd.engine import Engine
   fix = load(name)
   t = helpers.load_template(name)
   T1, E = fix['boards'].shape[:2]
-  for batch in (E, 64 * 70):  # the table-driven build, and (from 4,096 environments) the build specialised for the template
+  kernels = set()
+  for batch in batches:
     eng = Engine.from_template(t, batch=batch, device=0, auto_reset=True, seed=int(fix['seed'][0]))
     eng.its_showtime()
+    kernels.add(N.lib().pcx_engine_kernel_name(eng._native).decode())
 
     def frames():
       for f in range(T1):
@@ -135,6 +141,32 @@ def test_hip_error_bit_rises_where_the_reference_raised(name):
     else:
       eng.check_errors()
     eng.close()
+  return kernels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', STEPPED)
+def test_hip_error_bit_rises_where_the_reference_raised(name):
+  # pcx_generic_step: the table-driven build, and (from 4,096 environments) the build specialised for the template
+  kernels = _hip_raise_check(name, (load(name)['boards'].shape[1], 64 * 70))
+  if os.environ.get('PCX_FORCE_GENERIC') != '1':
+    assert kernels == {HAND_WRITTEN.get(name, 'pcx_generic_step')}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('route', ['single-wave workgroups', 'table-driven', 'specialised'])
+@pytest.mark.parametrize('name', sorted(HAND_WRITTEN))
+def test_hip_error_bit_rises_where_the_reference_raised_other_routes(name, route, monkeypatch):
+  """The unwalled warehouses with the shipped levels' four backdrop characters: pcx_warehouse_step's run-time-shape instance
+  in its large-batch launch shape too, and pcx_generic_step's two builds on the same boards."""
+  if route == 'single-wave workgroups':
+    if os.environ.get('PCX_FORCE_GENERIC') == '1':
+      pytest.skip('PCX_FORCE_GENERIC=1: about a hand-written kernel')
+    monkeypatch.setenv('PCX_COOP_BELOW', '0')
+    assert _hip_raise_check(name, (64 * 3 + 32,)) == {HAND_WRITTEN[name]}
+  else:
+    helpers.force_generic(monkeypatch, route)
+    assert _hip_raise_check(name, (64 * 3 + 32,)) == {'pcx_generic_step'}
 
 
 @pytest.mark.gpu

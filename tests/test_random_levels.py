@@ -5,6 +5,8 @@ drawn at random, and the HIP path must agree with the oracle on every step.
 Exercises the shape-generic / run-time-shape instances of the hand-written
 kernels on shapes no fixture has (boards that are not whole dwords, one to ten
 boxes, one to six walkers, windows of 12 to 900 cells)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -199,6 +201,56 @@ OURS = Kit(ascii_art=ascii_art, Box=Box, Judge=Judge, Pusher=Pusher, Walker=Walk
            Explorer=Explorer, Guard=Guard, Maze=Maze, Coins=Coins, Scrolly=prefab_drapes.Scrolly)
 
 
+# ---- levels WITHOUT walls around them: numpy's index -1, the IndexError past the last row / column, things off the
+# board at position (0, 0).  tests/test_reference_live_random_levels.py holds the oracle to the live reference on these
+# makers (CPU); test_random_unwalled_levels_match_oracle below holds the kernels to the oracle on them (GPU).
+def random_open_warehouse(rng, kit=None, scenery=False):
+  kit = kit or OURS
+  rows, cols = int(rng.randint(4, 9)), int(rng.randint(5, 11))
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  art[rng.rand(rows, cols) < 0.08] = '#'
+  cells = [(r, c) for r in range(rows) for c in range(cols) if art[r, c] == ' ']
+  rng.shuffle(cells)
+  boxes = list('1234'[:int(rng.randint(1, 5))])
+  # scenery: all four backdrop-only characters of the shipped levels (' ', '#', '.', '_') -- what pcx_warehouse_step's
+  # run-time-shape instance takes; without it (three characters, or two) the level is pcx_generic_step's
+  extra = ['.'] * int(rng.randint(1, 4)) + ['#'] if scenery else []
+  for ch in boxes + ['P'] + ['_'] * (len(boxes) + 1) + extra:
+    art[cells.pop()] = ch
+  sprites = {ch: kit.Box for ch in boxes}
+  sprites['P'] = kit.Pusher
+  return kit.ascii_art.ascii_art_to_game([''.join(r) for r in art], ' ', sprites, {'X': kit.Judge}, update_schedule=[boxes, ['X'], ['P']])
+
+
+def random_open_warehouse_scenery(rng, kit=None):
+  return random_open_warehouse(rng, kit, scenery=True)
+
+
+def random_open_better_scrolly(rng, kit=None):
+  kit = kit or OURS
+  rows, cols = int(rng.randint(5, 10)), int(rng.randint(7, 15))
+  art = np.full((rows, cols), ' ', dtype='<U1')
+  u = rng.rand(rows, cols)
+  art[u < 0.12] = '#'
+  art[(u >= 0.12) & (u < 0.2)] = '@'
+  art[:, -1][rng.rand(rows) < 0.6] = '#'  # (most rows end on a wall: fewer patrollers run into the IndexError of `col + 1`)
+  art[0, 0] = '@'                         # (where everything off the board "is")
+  cells = [(r, c) for r in range(rows) for c in range(cols - 1) if art[r, c] == ' ']
+  rng.shuffle(cells)
+  for ch in 'abcP':
+    art[cells.pop()] = ch
+  return kit.ascii_art.ascii_art_to_game(
+      [''.join(r) for r in art], ' ', sprites={'P': kit.Walker, 'a': kit.Patroller, 'b': kit.Patroller, 'c': kit.Patroller},
+      drapes={'@': kit.Cash}, update_schedule=['a', 'b', 'c', 'P', '@'], z_order='abc@P')
+
+
+def random_open_scrolly_maze(rng, kit=None):
+  """random_scrolly without the wall around the world: patrollers reach the pattern's first and last column
+  (`whole_pattern[row, col - 1]` is the LAST column there, `[row, col + 1]` an IndexError: scrolly_maze.py:295-299), the
+  window scrolls up to the pattern's bare edge."""
+  return random_scrolly(rng, kit, walled=False)
+
+
 def _compare(t, kernel, batch, steps, seed):
   hip, orc = HipAdapter(t, batch), OracleAdapter(t, batch)
   hip.reset(); orc.reset()
@@ -247,6 +299,73 @@ def test_random_levels_match_oracle_through_the_table_driven_kernel(maker, seed,
   rng = np.random.RandomState(2000 + seed)
   t = GameTemplate.from_engine(maker(rng))
   _compare(t, 'pcx_generic_step', batch=int(rng.choice([70, 200])), steps=48, seed=0xBEAD + seed)
+
+
+UNWALLED_KERNELS = {}  # maker name -> kernels seen (the last test of the family asserts the hand-written ones were among them)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('route', ['default', 'table-driven', 'specialised'])
+@pytest.mark.parametrize('maker', [random_open_warehouse, random_open_warehouse_scenery, random_open_better_scrolly, random_open_scrolly_maze],
+                         ids=lambda m: m.__name__)
+@pytest.mark.parametrize('seed', range(8))
+def test_random_unwalled_levels_match_oracle(maker, seed, route, monkeypatch):
+  """The GPU twin of test_oracle_matches_the_live_reference_on_a_random_unwalled_level (same makers, same level seeds): the
+  kernel the engine picks by itself (`default`: pcx_warehouse_step's run-time-shape instance for the warehouses with the
+  usual four backdrop characters, pcx_better_scrolly_step, pcx_scrolly_maze_step, pcx_generic_step for the others) and both
+  builds of pcx_generic_step, against the oracle: the error bit comes up in the same frame with the same kind -- the frame
+  the reference raises IndexError at -- and until then every output is equal, pushes through index -1, patrollers that look
+  around (0, 0) from outside the board and off-board boxes on the goal at (0, 0) included."""
+  if route != 'default':
+    if maker is random_open_scrolly_maze:
+      pytest.skip('scrolly_maze has no table-driven program: pcx_scrolly_maze_step steps every level of it')
+    helpers.force_generic(monkeypatch, route)
+  t = GameTemplate.from_engine(maker(np.random.RandomState(7300 + seed)))
+  B, T, n_actions = 64 * 3 + 9, 100, int(t.n_actions)
+  hip, orc = HipAdapter(t, B), binding.OracleEngine(t, B)
+  hip.reset(); orc.reset()
+  kernel = N.lib().pcx_engine_kernel_name(hip.eng._native).decode()
+  if route != 'default':
+    assert kernel == 'pcx_generic_step'
+  else:
+    UNWALLED_KERNELS.setdefault(maker.__name__, set()).add(kernel)
+  rng = np.random.RandomState(8300 + seed)
+  before = np.zeros(B, np.uint8)  # error bits so far: once the reference has raised, what an environment shows is nobody's law
+  raised_at = []
+  for step in range(T):
+    a = rng.randint(0, n_actions, size=B).astype(np.int32)
+    a[rng.rand(B) < 0.01] = n_actions  # (the quit action, rarely: episodes should last)
+    hip.step(a, auto_reset=True); orc.step(a, auto_reset=True)
+    err_h, err_o = hip.read('error'), np.array(orc.error)
+    fresh = before == 0
+    np.testing.assert_array_equal(err_h[fresh], err_o[fresh], err_msg='%s: error bits after step %d' % (kernel, step + 1))
+    raised_at += [step + 1] * int(((err_o != 0) & fresh).sum())
+    ok = err_o == 0
+    for name in ('planes', 'reward', 'reward_set', 'discount', 'done', 'frame'):
+      np.testing.assert_array_equal(hip.read(name)[ok], np.array(getattr(orc, name))[ok], err_msg='%s: %s after step %d' % (kernel, name, step + 1))
+    before |= err_o
+  ok = before == 0
+  np.testing.assert_array_equal(hip.sprites()[ok], orc.sprites()[ok])
+  UNWALLED_STATS.append((maker.__name__, route, len(raised_at), B))
+  hip.eng.close()
+
+
+UNWALLED_STATS = []
+
+
+@pytest.mark.gpu
+def test_the_random_unwalled_levels_raise_and_reach_the_hand_written_kernels():
+  if not UNWALLED_STATS:
+    pytest.skip('runs after test_random_unwalled_levels_match_oracle in the same process')
+  for name in sorted({s[0] for s in UNWALLED_STATS}):
+    rows = [s for s in UNWALLED_STATS if s[0] == name]
+    assert 0 < sum(s[2] for s in rows) < sum(s[3] for s in rows), (name, rows)  # some environments raise, most do not
+  if os.environ.get('PCX_FORCE_GENERIC') == '1':
+    return
+  want = {'random_open_warehouse_scenery': 'pcx_warehouse_step', 'random_open_better_scrolly': 'pcx_better_scrolly_step',
+          'random_open_scrolly_maze': 'pcx_scrolly_maze_step', 'random_open_warehouse': 'pcx_generic_step'}
+  for name, kernels in UNWALLED_KERNELS.items():
+    assert want[name] in kernels, (name, kernels)
 
 
 def _random_croppers(rng, t, track, cropping=None):

@@ -177,45 +177,13 @@ def test_oracle_croppers_match_the_live_reference_croppers_on_a_random_level(mak
 
 
 # ---- levels WITHOUT walls around them: numpy's index -1, IndexError past the last row / column, things off the board ------
-def random_open_warehouse(rng, kit):
-  rows, cols = int(rng.randint(4, 9)), int(rng.randint(5, 11))
-  art = np.full((rows, cols), ' ', dtype='<U1')
-  art[rng.rand(rows, cols) < 0.08] = '#'
-  cells = [(r, c) for r in range(rows) for c in range(cols) if art[r, c] == ' ']
-  rng.shuffle(cells)
-  boxes = list('1234'[:int(rng.randint(1, 5))])
-  for ch in boxes + ['P'] + ['_'] * (len(boxes) + 1):
-    art[cells.pop()] = ch
-  sprites = {ch: kit.Box for ch in boxes}
-  sprites['P'] = kit.Pusher
-  return kit.ascii_art.ascii_art_to_game([''.join(r) for r in art], ' ', sprites, {'X': kit.Judge}, update_schedule=[boxes, ['X'], ['P']])
+# (the makers live in tests/test_random_levels.py, where the GPU suite steps the same levels through the kernels)
+random_open_warehouse, random_open_better_scrolly, random_open_scrolly_maze = (
+    levels.random_open_warehouse, levels.random_open_better_scrolly, levels.random_open_scrolly_maze)
+random_open_warehouse_scenery = levels.random_open_warehouse_scenery
 
 
-def random_open_better_scrolly(rng, kit):
-  rows, cols = int(rng.randint(5, 10)), int(rng.randint(7, 15))
-  art = np.full((rows, cols), ' ', dtype='<U1')
-  u = rng.rand(rows, cols)
-  art[u < 0.12] = '#'
-  art[(u >= 0.12) & (u < 0.2)] = '@'
-  art[:, -1][rng.rand(rows) < 0.6] = '#'  # (most rows end on a wall: fewer patrollers run into the IndexError of `col + 1`)
-  art[0, 0] = '@'                         # (where everything off the board "is")
-  cells = [(r, c) for r in range(rows) for c in range(cols - 1) if art[r, c] == ' ']
-  rng.shuffle(cells)
-  for ch in 'abcP':
-    art[cells.pop()] = ch
-  return kit.ascii_art.ascii_art_to_game(
-      [''.join(r) for r in art], ' ', sprites={'P': kit.Walker, 'a': kit.Patroller, 'b': kit.Patroller, 'c': kit.Patroller},
-      drapes={'@': kit.Cash}, update_schedule=['a', 'b', 'c', 'P', '@'], z_order='abc@P')
-
-
-def random_open_scrolly_maze(rng, kit):
-  """tests/test_random_levels.py random_scrolly without the wall around the world: patrollers reach the pattern's first
-  and last column (`whole_pattern[row, col - 1]` is the LAST column there, `[row, col + 1]` an IndexError:
-  scrolly_maze.py:295-299), the window scrolls up to the pattern's bare edge."""
-  return levels.random_scrolly(rng, kit, walled=False)
-
-
-@pytest.mark.parametrize('maker', [random_open_warehouse, random_open_better_scrolly, random_open_scrolly_maze], ids=lambda m: m.__name__)
+@pytest.mark.parametrize('maker', [random_open_warehouse, random_open_better_scrolly, random_open_scrolly_maze, random_open_warehouse_scenery], ids=lambda m: m.__name__)
 @pytest.mark.parametrize('seed', range(12))
 def test_oracle_matches_the_live_reference_on_a_random_unwalled_level(maker, seed):
   """Where the reference raises (the IndexError of `layers[..][row + 1, col]` past the last row, warehouse_manager.py:
@@ -269,7 +237,7 @@ UNWALLED_STATS = []
 def test_the_random_unwalled_levels_see_things_off_the_board_and_raises():
   if not UNWALLED_STATS:
     pytest.skip('runs after test_oracle_matches_the_live_reference_on_a_random_unwalled_level in the same process')
-  for name in ('random_open_warehouse', 'random_open_better_scrolly', 'random_open_scrolly_maze'):
+  for name in ('random_open_warehouse', 'random_open_better_scrolly', 'random_open_scrolly_maze', 'random_open_warehouse_scenery'):
     rows = [s for s in UNWALLED_STATS if s[0] == name]
     if rows:
       assert sum(s[1] for s in rows) > 0 and 0 < sum(s[2] for s in rows) < sum(s[3] for s in rows), (name, rows)
