@@ -50,7 +50,10 @@ def reference_dir():
 FIXTURES = {'scrolly_maze': 'scrolly_maze_L%d', 'warehouse': 'warehouse_L%d', 'marauders': 'marauders',
             'hello_world': 'hello_world', 'better_scrolly_maze': 'better_scrolly_maze_L%d',
             # games only the table-driven kernel steps (an unshipped marauders board; prefab MazeWalkers and Scrolly drapes in two scrolling groups)
-            'marauders_custom_A': 'marauders_custom_A', 'walkers_scroll_groups': 'walkers_scroll_groups'}
+            'marauders_custom_A': 'marauders_custom_A', 'walkers_scroll_groups': 'walkers_scroll_groups',
+            # warehouse_manager level 0 stepped by the table-driven kernel (PCX_FORCE_GENERIC=1 while the engine is created): the
+            # kernel's third timing fixture since round 3
+            'warehouse_generic': 'warehouse_L%d'}
 
 
 def cpu_worker(args):
@@ -91,18 +94,56 @@ def cpu_reference_python(game, level, seconds=10.0, max_procs=64):
   return ref_timing.measure(ref, game, level, seconds=seconds, max_procs=max_procs)
 
 
-def pmc_traffic(game, level, batch):
+def pmc_traffic(game, level, batch, kernel, launch_shape, api='step'):
   """HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json:
-  WRITE_SIZE + corrected FETCH_SIZE, collected as MI355X_MICROARCH.md prescribes),
-  or None when no record matches this workload."""
+  WRITE_SIZE + corrected FETCH_SIZE, collected as MI355X_MICROARCH.md prescribes) OF THE KERNEL INSTANCE THIS ROW TIMED:
+  a record counts only if it names the same kernel, the same launch shape (pcx_engine_launch_shape; the tuners pick per
+  box) and the same API (single steps / step_n) -- (bytes, the record's source), or (None, None)."""
   path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
   try:
     for rec in json.load(open(path)).get('records', []):
-      if rec.get('game') == game and rec.get('level') == level and rec.get('batch') == batch:
-        return rec['bytes_per_launch']
+      if (rec.get('game') == game and rec.get('level') == level and rec.get('batch') == batch and rec.get('kernel') == kernel and
+          rec.get('launch_shape') == launch_shape and rec.get('api', 'step') == api and rec.get('source')):
+        return rec['bytes_per_launch'], rec['source']
   except Exception:  # pylint: disable=broad-except
     pass
-  return None
+  return None, None
+
+
+def settle_tuner(eng, row, start, limit=96):
+  """Untimed: steps until the engine's launch-shape tuner has settled (include/pcx.h pcx_engine_tuner_done: 8 + 24 launches
+  for the persistent workers, 6 + 12 for pcx_generic_step's waves per workgroup), so that no timed repeat contains a
+  measuring launch (VERDICT r5 weak #7).  Returns the number of extra steps taken."""
+  import torch
+  extra = 0
+  while extra < limit:
+    if eng.tuner_done():
+      break
+    for _ in range(4):
+      eng.step(row(start + extra))
+      extra += 1
+    torch.cuda.synchronize()  # (the tuner settles on a completed event, polled at the next launch)
+  return extra
+
+
+def launch_floor_us(device):
+  """What one dependent kernel launch costs on this box: a near-empty kernel launched back to back on one stream."""
+  import ctypes
+  import torch
+  from pycolab_amd import _native as N
+  buf = torch.empty(1 << 16, dtype=torch.uint8, device='cuda:%d' % device)
+  stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+  best = float('inf')
+  for _ in range(3):
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(1000):
+      N.lib().pcx_device_fill_probe(buf.data_ptr(), 1024, stream)
+    e1.record()
+    torch.cuda.synchronize(device)
+    best = min(best, e0.elapsed_time(e1))
+  return best  # ms per 1000 launches = us per launch
 
 
 TRAFFIC_SOURCE = ('profiles/hbm_traffic.json (committed rocprofv3 --pmc passes of this kernel at this batch; '
@@ -168,7 +209,7 @@ def fill_probe_gbs(nbytes, device):
   return nbytes / (best * 1e-3) / 1e9
 
 
-def measure_config(game, level, batch, steps, warmup, device, repeats=3, raises=None, cardinal_fields=0):
+def measure_config(game, level, batch, steps, warmup, device, repeats=3, raises=None, cardinal_fields=0, cpu_seconds=0.0):
   """One of the other BASELINE configs on this GPU (reported inside the headline line).
   cardinal_fields = n: the game's action is n four-bit fields (one per scrolling group: oracle/walker_scenarios.py), and
   the synthetic tape draws every field from {north, east, south, west, stay} -- as oracle/gen_golden.py does for the
@@ -181,7 +222,14 @@ def measure_config(game, level, batch, steps, warmup, device, repeats=3, raises=
   from pycolab_amd.engine import Engine
   fixture = FIXTURES[game] % level if '%' in FIXTURES[game] else FIXTURES[game]
   template = GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', fixture + '.npz'))
-  eng = Engine.from_template(template, batch=batch, device=device, auto_reset=True, seed=0x5EED)
+  forced = game.endswith('_generic') and os.environ.get('PCX_FORCE_GENERIC') is None
+  if forced:
+    os.environ['PCX_FORCE_GENERIC'] = '1'
+  try:
+    eng = Engine.from_template(template, batch=batch, device=device, auto_reset=True, seed=0x5EED)
+  finally:
+    if forced:
+      del os.environ['PCX_FORCE_GENERIC']
   eng.its_showtime()
   g = torch.Generator(device='cuda')
   g.manual_seed(0x5EED)
@@ -194,6 +242,7 @@ def measure_config(game, level, batch, steps, warmup, device, repeats=3, raises=
     tape = torch.randint(0, template.n_actions, (warmup + steps, batch), dtype=torch.int32, device='cuda', generator=g)
   for t in range(warmup):
     eng.step(tape[t])
+  settled = settle_tuner(eng, lambda t: tape[t % warmup], 0)
   sync = lambda: torch.cuda.synchronize(device)
   runs = [time_steps(eng, lambda t: tape[t], warmup, warmup + steps, sync)[1] for _ in range(repeats)]
   kernel_ms = median(runs)
@@ -201,13 +250,16 @@ def measure_config(game, level, batch, steps, warmup, device, repeats=3, raises=
     eng.check_errors()
   bps = int(N.lib().pcx_engine_bytes_per_step(eng._native))
   where = 'examples' if game in ('scrolly_maze', 'warehouse', 'marauders', 'hello_world', 'better_scrolly_maze') else 'tests/golden/templates'
+  kernel, shape = N.lib().pcx_engine_kernel_name(eng._native).decode(), int(N.lib().pcx_engine_launch_shape(eng._native))
+  traffic, source = pmc_traffic(game, level, batch, kernel, shape)
   out = {'workload': '%s/%s, %d envs' % (where, fixture, batch), 'ms_per_step': kernel_ms,
          'ms_per_step_min_max': [min(runs), max(runs)],
          'env_steps_per_s': batch / (kernel_ms * 1e-3),
-         'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(),
-         'launch_shape': int(N.lib().pcx_engine_launch_shape(eng._native)), 'algorithmic_bytes_per_env_step': bps,
+         'kernel': kernel, 'launch_shape': shape, 'tuner_steps_before_timing': settled, 'algorithmic_bytes_per_env_step': bps,
          'hbm_frac': bps * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-         'traffic': pmc_traffic(game, level, batch)}
+         'traffic': traffic, 'traffic_source': source}
+  if cpu_seconds > 0 and reference_dir() is not None:  # the reference itself on this box's host cores, same workload
+    out['cpu_baseline'] = cpu_reference_python(game, level, seconds=cpu_seconds)
   if cardinal_fields:
     out['tape'] = '%d action fields, each drawn from {n, e, s, w, stay}' % cardinal_fields
     out['environments_that_raised'] = {'count': int(eng.buffers['error'].tensor.ne(0).sum())}  # (check_errors() above: none)
@@ -236,6 +288,8 @@ def measure_step_n(game, level, batch, steps, device, repeats=3):
   stream = pdev.current_stream(device)
   run = lambda: N.check(N.lib().pcx_engine_step_n(eng._native, tape.data_ptr(), steps, 1, stream))
   run()
+  kernel, shape = N.lib().pcx_engine_kernel_name(eng._native).decode(), int(N.lib().pcx_engine_launch_shape(eng._native))
+  traffic, source = pmc_traffic(game, level, batch, kernel, shape, api='step_n')
   runs = []
   for _ in range(repeats):
     torch.cuda.synchronize(device)
@@ -251,9 +305,8 @@ def measure_step_n(game, level, batch, steps, device, repeats=3):
   out = {'workload': 'examples/%s, %d envs, Engine.step_n(tape of %d steps): several steps per launch, every step writes its '
                      'observation' % (fixture, batch, steps),
          'ms_per_step': ms, 'ms_per_step_min_max': [min(runs), max(runs)], 'env_steps_per_s': batch / (ms * 1e-3),
-         'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(),
-         'launch_shape': int(N.lib().pcx_engine_launch_shape(eng._native)), 'algorithmic_bytes_per_env_step': bps,
-         'hbm_frac': bps * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None}
+         'kernel': kernel, 'launch_shape': shape, 'algorithmic_bytes_per_env_step': bps,
+         'hbm_frac': bps * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': source}
   eng.close()
   return out
 
@@ -282,7 +335,7 @@ def main():
                   help='after the last step: all-gather reward/reward_set/discount/done (ScalarGather) and per-rank '
                        'observation checksums, and have rank 0 save them with the number of steps taken')
   ap.add_argument('--level', type=int, default=0)
-  ap.add_argument('--game', default='scrolly_maze', choices=sorted(FIXTURES),
+  ap.add_argument('--game', default='scrolly_maze', choices=sorted(g for g in FIXTURES if not g.endswith('_generic')),
                   help='scrolly_maze is the headline metric; the others are the parity configs of BASELINE.json')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-other-configs', action='store_true',
@@ -384,6 +437,13 @@ def main():
 
   for t in range(W):
     eng.step(row(t))
+  # the launch-shape tuner measures on the engine's own first launches: to completion before anything is timed (every rank
+  # takes the same number of extra steps; they replay warm-up rows)
+  settled = settle_tuner(eng, lambda t: row(t % W if W else 0), 0) if W else 0
+  if distributed:
+    most = int(max_over_ranks(float(settled)))
+    for t in range(settled, most):
+      eng.step(row(t % W))
   walls, kernels = [], []
   for r in range(R):
     wall, kernel_ms = time_steps(eng, row, W + r * K, W + (r + 1) * K, barrier)
@@ -460,7 +520,8 @@ def main():
   if rank == 0:
     bytes_per_step = int(N.lib().pcx_engine_bytes_per_step(eng._native))
     achieved = bytes_per_step * B / (kernel_ms * 1e-3) / 1e9
-    traffic = pmc_traffic(args.game, args.level, B)
+    kernel_name, shape_now = N.lib().pcx_engine_kernel_name(eng._native).decode(), int(N.lib().pcx_engine_launch_shape(eng._native))
+    traffic, traffic_src = pmc_traffic(args.game, args.level, B, kernel_name, shape_now)
     L = len(template.chars)
     line = {
         'metric': 'env-steps/sec (whole node), scrolly_maze batch=1M; bit-exact vs CPU' if args.game == 'scrolly_maze'
@@ -486,9 +547,8 @@ def main():
                     'kernel_ms_all': kernels},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'traffic_source': TRAFFIC_SOURCE if traffic is not None else None,
-                     'kernel': N.lib().pcx_engine_kernel_name(eng._native).decode(),
-                     'launch_shape': int(N.lib().pcx_engine_launch_shape(eng._native)),
+                     'traffic_source': (TRAFFIC_SOURCE + ': ' + traffic_src) if traffic is not None else None,
+                     'kernel': kernel_name, 'launch_shape': shape_now, 'tuner_steps_before_timing': settled,
                      'kernel_ms': kernel_ms, 'algorithmic_bytes_per_env_step': bytes_per_step},
     }
     if world > 1:
@@ -530,13 +590,18 @@ def main():
                                # the headline batch through Engine.step_n: launches of up to 64 steps in which every persistent
                                # worker keeps its units from step to step (launch shape 13); every step still writes its observation
                                measure_step_n('scrolly_maze', 0, 1048576, 128, device),
-                               measure_config('marauders', 0, 32768, 200, 20, device),
-                               measure_config('warehouse', 0, 262144, 100, 10, device),
+                               measure_config('marauders', 0, 32768, 200, 20, device, cpu_seconds=0 if args.no_cpu_baseline else 4.0),
+                               measure_config('marauders', 0, 262144, 50, 10, device),
+                               measure_config('warehouse', 0, 262144, 100, 10, device, cpu_seconds=0 if args.no_cpu_baseline else 4.0),
                                measure_config('better_scrolly_maze', 0, 65536, 50, 10, device),
                                measure_config('hello_world', 0, 1048576, 50, 10, device),
                                # pcx_generic_step (built for the template at run time: launch_shape 31) at VERDICT r3's fixtures
                                measure_config('marauders_custom_A', 0, 32768, 200, 30, device),
-                               measure_config('walkers_scroll_groups', 0, 262144, 100, 30, device, cardinal_fields=2)]
+                               measure_config('walkers_scroll_groups', 0, 262144, 100, 30, device, cardinal_fields=2),
+                               measure_config('warehouse_generic', 0, 262144, 100, 30, device)]
+      # config 2's 11 us per play() against what a launch costs on this box at all
+      line['launch_floor_us'] = {'value': launch_floor_us(device), 'what': 'a near-empty kernel (pcx_device_fill_probe over 1 KiB), 1,000 '
+                                 'launches back to back on one stream, best of three: the floor under config 2\'s ms_per_step'}
     if not args.no_cpu_baseline:  # (rank 0's host cores, N > 1 included)
       # north_star: "the reference CPU Engine timed on the same box's host cores (core count stated) in the same run" --
       # the imported reference where it is available (kind "reference"), with the C restatement of it ("port") next to

@@ -340,6 +340,12 @@ const char* pcx_engine_kernel_name(const pcx_engine* e);
  * launch shapes of rounds 1-4, measured slower and removed in round 5); pcx_generic_step: 30 the
  * table-driven build, 31 the build specialised for the engine's template at run time; -1: the backend does not say. */
 int32_t pcx_engine_launch_shape(const pcx_engine* e);
+/* The kernels with persistent workers (and pcx_generic_step's waves per workgroup) try a few equivalent launch
+ * configurations on the engine's own first step launches and keep the fastest on this box (csrc/pcx_internal.h ShapeTuner:
+ * 8 + 24 launches; results never depend on it).  1 once nothing is being measured any more -- settled, switched off by a
+ * knob, or a launch shape without candidates; 0 while step launches still take turns.  A benchmark steps until this
+ * answers 1 before it times anything (bench.py); call it after at least one step.  No reference counterpart. */
+int32_t pcx_engine_tuner_done(const pcx_engine* e);
 /* The table-driven kernel pcx_generic_step -- what every Engine the hand-written kernels do not cover runs on:
  * engine.py:583-847 around arbitrary Sprites / Drapes of the supported programs -- is also built per template at run time, with the
  * template's tables and schedule as compile-time constants (hiprtc; engines of PCX_GENERIC_JIT_MIN = 4,096

@@ -500,6 +500,7 @@ int32_t pcx_engine_plane_pitch(const pcx_engine* e) { return e ? e->backend->pla
 int64_t pcx_engine_bytes_per_step(const pcx_engine* e) { return e ? e->backend->bytes_per_step() : 0; }
 const char* pcx_engine_kernel_name(const pcx_engine* e) { return e ? e->backend->kernel_name() : ""; }
 int32_t pcx_engine_launch_shape(const pcx_engine* e) { return e ? e->backend->launch_shape() : -1; }
+int32_t pcx_engine_tuner_done(const pcx_engine* e) { return e ? e->backend->tuner_done() : 1; }
 int pcx_generic_specialise_check(const pcx_template* t, char* log, int64_t log_bytes, int64_t* code_bytes) {
   if (!t) return set_error(PCX_E_INVALID, "pcx_generic_specialise_check: null template");
   return pcx::generic_specialise_check(*t, log, log_bytes, code_bytes);

@@ -332,6 +332,7 @@ class HelloWorldBackend : public Backend {
   int launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) override;
   int read_things(int64_t env0, int64_t n, pcx_sprite_state* sprites, uint8_t* curtains) override;
   int64_t bytes_per_step() const override { return 4 + 8 * (int64_t)NW_ + (int64_t)(1 + L_) * lay_.cells + 15; }
+  int tuner_done() const override { return tuner_.done(); }
   const char* kernel_name() const override { return "pcx_hello_world_step"; }
   int launch_shape() const override { return last_shape_; }  // 0 a workgroup per group, 10 cooperative, 3 persistent workers (include/pcx.h)
   const int32_t* sprite_track() const override { return track_.ptr; }

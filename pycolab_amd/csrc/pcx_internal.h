@@ -91,7 +91,13 @@ struct ShapeTuner {
   int pick(const StepArgs& a, hipStream_t s) {
     measuring_begin = measuring_end = false;
     if (chosen >= 0) return chosen;
-    if (off || a.mode != 0 || a.n_steps > 1) return 0;  // (launches of several steps are not comparable with single steps)
+    if (off || a.mode != 0 || a.n_steps > 1) {  // (launches of several steps are not comparable with single steps)
+      // ... and a launch the tuner does not own in the MIDDLE of a block would be charged to the block's candidate:
+      // the block starts over with its first launch
+      const int i = phase - WARM;
+      if (i >= 0 && i < NB * BLOCK) phase = WARM + (i / BLOCK) * BLOCK;
+      return 0;
+    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
     const int i = phase - WARM;
@@ -125,6 +131,8 @@ struct ShapeTuner {
       fprintf(stderr, "[pcx] launch shape candidate %d of %d (%.4f %.4f %.4f %.4f ms per launch)\n", chosen, NC, ms[0], ms[1], ms[2], ms[3]);
     return chosen;
   }
+  // nothing left to measure: settled, switched off, or never consulted (the launch shapes that have no candidates)
+  bool done() const { return off || chosen >= 0 || phase == 0; }
   void launched(hipStream_t s) {
     if (!measuring_begin) return;
     if (measuring_end && hipEventRecord(ev[(phase - WARM) / BLOCK][1], s) != hipSuccess) { (void)hipGetLastError(); off = true; }
@@ -137,6 +145,8 @@ namespace stream { struct EpilogueArgs; }
 class Backend {
  public:
   virtual ~Backend() {}
+  // include/pcx.h pcx_engine_tuner_done: no launch of this engine measures launch shapes any more
+  virtual int tuner_done() const { return 1; }
   // Validate the template and upload constants / allocate state.
   virtual int init(const pcx_template& t, int64_t batch) = 0;
   virtual int launch(const StepArgs& a, const pcx_buffers& out, hipStream_t s) = 0;

@@ -1916,6 +1916,7 @@ class ScrollyMazeBackend : public Backend {
     // frame 4, error 1).
     return 4 + 4 * (int64_t)k_.NW + 4 * (int64_t)(k_.NW - k_.CW) + (int64_t)(1 + k_.L) * k_.cells + 15;
   }
+  int tuner_done() const override { return tuner_.done(); }
   const char* kernel_name() const override { return "pcx_scrolly_maze_step"; }
   int launch_shape() const override { return last_shape_; }
   // Does a single step of this batch run in the cooperative launch shape (launch(): few groups per CU)?

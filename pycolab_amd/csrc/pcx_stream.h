@@ -175,6 +175,27 @@ __device__ __forceinline__ void resolve_sprites(const int (&cell)[NS], const uin
   }
 }
 
+// resolve_sprites for the owner-code loop (stream_codes below): the same test, and a sprite that is painted writes its
+// code byte over whatever the curtains left at its cell (`cb`: this environment's code bytes).  `flat` is read only.
+template <int NS, int ND>
+__device__ __forceinline__ void paint_sprites(const int (&cell)[NS], const uint32_t (&above)[NS], const uint32_t* flat, int FWP, int lane,
+                                              uint8_t* cb, const uint32_t (&code)[NS]) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int c = cell[s];
+    bool shown = c >= 0;
+    const uint32_t ab = above[s];
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+      if (j != s && ((ab >> j) & 1) && cell[j] == c) shown = false;
+    const int cc = c >= 0 ? c : 0, wi = cc >> 5, sh = cc & 31;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+      if (((ab >> (NS + d)) & 1) && ((flat[(d * WAVE + lane) * FWP + wi] >> sh) & 1)) shown = false;
+    if (shown) cb[c] = (uint8_t)code[s];
+  }
+}
+
 // Engine(..., occlusion_in_layers=False) (rendering.py:187-301 BaseUnoccludedObservationRenderer):
 // the board is painted as ever, the layers are the things' RAW masks -- a drape's whole curtain, a
 // visible sprite's own cell, the backdrop character wherever the backdrop has it.  Call before
@@ -545,6 +566,80 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
     else PCX_STREAM_MODE(0);
   }
 #undef PCX_STREAM_MODE
+}
+
+// ---------------------------------------------------------------------------
+// Owner codes (round 6; pcx_scrolly_maze_step has rendered this way since round 2).  Instead of masks per thing the
+// logic phase leaves, per environment, ONE BYTE PER BOARD CELL naming the character that shows there -- `codes`
+// [64][CP] dwords, CP odd -- painted the way the reference paints the board (rendering.py:98-179: backdrop first, then
+// the things back to front; here the backdrop's code dwords are a table staged once per workgroup and the things are
+// byte writes).  The streaming loop then needs ONE LDS read per iteration and one v_perm_b32 per plane: the board
+// dword picks each cell's character out of a table in SGPRs, layer i picks byte i of a one-hot table (layers[c] =
+// board == c, rendering.py:177-179).  A v_perm_b32 selects among eight bytes, so:
+//   L <= 8   code byte = i, the character's place in the template's sorted list (= its layer plane);
+//   L <= 16  code byte = 0xC0 | i for i < 8, 0x0C | (i - 8) << 4 otherwise: the low nibbles select among the first
+//            eight characters, the high nibbles among the others, and selector 12 is the constant 0x00 -- three more
+//            VALU for the two selector dwords, two more for the board.
+// Against the mask loop above (warehouse_manager: 12 LDS reads and ~60 VALU per 12 stores) this is 1 read and ~20 VALU.
+// ---------------------------------------------------------------------------
+template <int L>
+struct CodeMap {
+  uint32_t chars[4];  // the characters of codes 0-3, 4-7, 8-11, 12-15, a byte each
+};
+template <int L>
+__host__ __device__ constexpr uint32_t code_byte(int i) { return L <= 8 ? (uint32_t)i : i < 8 ? 0xC0u | (uint32_t)i : 0x0Cu | ((uint32_t)(i - 8) << 4); }
+
+template <int L, int QW, int NWAVES, bool DRAIN = true>
+__device__ __forceinline__ void stream_codes(const CodeMap<L>& cm, uint8_t* group_base, uint32_t env_stride, const uint32_t* codes,
+                                             int CP, const uint32_t* skip, int lane, int wave, int qw_rt = 0) {
+  static_assert(L >= 1 && L <= 16, "owner codes: at most sixteen characters");
+  const uint32_t QWv = QW ? (uint32_t)QW : (uint32_t)qw_rt;
+  uint8_t* pb[1 + L];
+  pb[0] = uniform_ptr(group_base);
+#pragma unroll
+  for (int i = 0; i < L; ++i) pb[1 + i] = uniform_ptr(pb[0] + (uint32_t)(1 + i) * 4u * QWv);
+  const uint32_t chA_lo = __builtin_amdgcn_readfirstlane(cm.chars[0]), chA_hi = __builtin_amdgcn_readfirstlane(cm.chars[1]);
+  const uint32_t chB_lo = __builtin_amdgcn_readfirstlane(cm.chars[2]), chB_hi = __builtin_amdgcn_readfirstlane(cm.chars[3]);
+  const bool any_skip = __ballot(skip[lane] != 0) != 0ull;
+  if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see stream_planes_mode
+  constexpr uint32_t ADV = (uint32_t)NWAVES * WAVE;
+  const uint32_t DE = ADV / QWv, DQ = ADV - DE * QWv;
+  const uint32_t f0 = (uint32_t)(wave * WAVE + lane);
+  uint32_t e = f0 / QWv, q = f0 - e * QWv;  // once
+  uint32_t voff = e * env_stride + 4u * q, ci = e * (uint32_t)CP + q;
+  const uint32_t dvoff = DE * env_stride + 4u * DQ, dci = DE * (uint32_t)CP + DQ;
+  const uint32_t wrap_voff = env_stride - 4u * QWv, wrap_ci = (uint32_t)CP - QWv;
+  const uint32_t ci_last = (uint32_t)(WAVE - 1) * (uint32_t)CP + QWv - 1u;  // (the prefetch of the iteration past the end reads here)
+  uint32_t code_pf = codes[ci];
+  constexpr bool GUARD = NWAVES > 1 || L > 11;  // (the bare store only where every plane base stays in SGPRs)
+#pragma unroll 1
+  for (int it = wave; it < (int)QWv; it += NWAVES) {
+    const uint32_t e_now = e, voff_now = voff, code = code_pf;
+    q += DQ; e += DE; voff += dvoff; ci += dci;
+    {
+      const bool wrap = q >= QWv;
+      q = wrap ? q - QWv : q;
+      e = wrap ? e + 1 : e;
+      voff = wrap ? voff + wrap_voff : voff;
+      ci = wrap ? ci + wrap_ci : ci;
+    }
+    code_pf = codes[ci < ci_last ? ci : ci_last];
+    if (any_skip && skip[e_now] != 0) continue;
+    if constexpr (L <= 8) {
+      saddr_store_dword<GUARD>(voff_now, __builtin_amdgcn_perm(chA_hi, chA_lo, code), pb[0]);
+#pragma unroll
+      for (int i = 0; i < L; ++i)
+        saddr_store_dword<GUARD>(voff_now, __builtin_amdgcn_perm(i >= 4 ? 1u << (8 * (i & 3)) : 0u, i < 4 ? 1u << (8 * (i & 3)) : 0u, code), pb[1 + i]);
+    } else {
+      const uint32_t sa = code & 0x0F0F0F0Fu, sb = (code >> 4) & 0x0F0F0F0Fu;
+      saddr_store_dword<GUARD>(voff_now, __builtin_amdgcn_perm(chA_hi, chA_lo, sa) | __builtin_amdgcn_perm(chB_hi, chB_lo, sb), pb[0]);
+#pragma unroll
+      for (int i = 0; i < L; ++i) {
+        const int j = i & 7;
+        saddr_store_dword<GUARD>(voff_now, __builtin_amdgcn_perm(j >= 4 ? 1u << (8 * (j & 3)) : 0u, j < 4 ? 1u << (8 * (j & 3)) : 0u, i < 8 ? sa : sb), pb[1 + i]);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -955,13 +1050,14 @@ struct FusedCropsHolder {
 
 // Constants of the streaming phase every backend derives the same way.
 struct Layout {
-  int cells = 0, pitch = 0, QW = 0, FW = 0, FWP = 0;
+  int cells = 0, pitch = 0, QW = 0, FW = 0, FWP = 0, CP = 0;
   void set(int rows, int cols) {
     cells = rows * cols;
     pitch = (cells + 3) & ~3;
     QW = pitch / 4;
     FW = (cells + 31) / 32;
     FWP = FW | 1;
+    CP = QW | 1;  // owner codes: dwords per environment, odd (the logic phase reads one word of 64 environments, the streaming loop consecutive words)
   }
 };
 

@@ -50,11 +50,13 @@ struct Consts {
   uint32_t above[MAX_NS];    // bit j: sprite j is in front of sprite s; bit NS: the judge drape is
   uint32_t init[W_POS + MAX_NS];
   uint32_t sprite_off[MAX_NS], sprite_ch4[MAX_NS], drape_off, drape_ch4, bchar_off[MAX_NB], bchar_ch4[MAX_NB];
+  // owner codes (pcx_stream.h stream_codes; the CODES instances): the code byte of every thing's character, the characters by code
+  uint32_t sprite_code[MAX_NS], drape_code, code_chars[4];
   int32_t tmpl_index[MAX_NS];  // sprite s here is sprite tmpl_index[s] of the template
 };
 
 struct Ptrs {
-  const uint32_t* tables;  // staged into LDS: backdrop4 [QW], bdmask [NB][QW], goal rows [R], box-blocked rows [R], player-blocked rows [R]
+  const uint32_t* tables;  // staged into LDS: backdrop4 [QW], bdmask [NB][QW], goal rows [R], box-blocked rows [R], player-blocked rows [R], backdrop codes [QW]
   uint32_t* state;         // [NW][bpad]
   int32_t* track;          // [NS][bpad], template sprite order
   uint32_t* curtains;      // [1][FW][bpad] raw judge curtain (export_curtains)
@@ -82,7 +84,10 @@ __device__ __forceinline__ int pos_c(uint32_t w) { return (int)(int16_t)(w >> 16
 // environments, steps one and streams it ALONE (NWAVES == 1), the next unit's state words prefetched into its LDS inbox, at
 // most `work.lock` workers of the workgroup streaming at a time (pcx_stream.h; the launch shape pcx_scrolly_maze_step took
 // in round 4).  Plain steps of the compiled shapes only: no epilogue, no fused croppers, occluded layers.
-template <int NS, int SR, int SC, int NB, int NWAVES, bool EPI = false, bool UNOCC = false, bool PW = false>
+// CODES (round 6): the render phase is pcx_stream.h's owner-code loop -- the logic lane leaves a code byte per board cell
+// (the backdrop's code dwords copied from a staged table, the judge's marks and the painted sprites as byte writes) instead
+// of a curtain and sprite descriptors for the mask-composing loop.  Plain steps (no epilogue, no fused croppers, occluded layers).
+template <int NS, int SR, int SC, int NB, int NWAVES, bool EPI = false, bool UNOCC = false, bool PW = false, bool CODES = false>
 __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_warehouse_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                     const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                     const crop::FusedCrops* fc) {
@@ -91,12 +96,15 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_warehouse_st
   constexpr int SQW = ((SR * SC + 3) & ~3) / 4;           // dwords per plane, 0: run-time shape
   const int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = (cells + 31) / 32, FWP = FW | 1;
   constexpr int L = NS + 1 + NB, IP = NS - 1, NBOX = NS - 1;
-  const int O_BD = 0, O_BDM = O_BD + QW, O_GOAL = O_BDM + NB * QW, O_BBLK = O_GOAL + R, O_PBLK = O_BBLK + R,
-            O_TAB_END = O_PBLK + R;
-  const int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
+  const int CP = QW | 1;
+  const int O_BD = 0, O_BDM = O_BD + QW, O_GOAL = O_BDM + NB * QW, O_BBLK = O_GOAL + R, O_PBLK = O_BBLK + R, O_BDC = O_PBLK + R,
+            O_TAB_END = O_BDC + QW;
+  // (CODES: the per-environment code dwords take the place of the sprite descriptors)
+  const int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + (CODES ? WAVE * CP : 2 * NS * WAVE);
   const int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   const int O_FLATRAW = O_WCORNER + stream::WCORNER_WORDS, O_SDESCRAW = (O_FLATRAW + WAVE * FWP + 1) & ~1;  // UNOCC only
   static_assert(!PW || (NWAVES == 1 && !EPI && !UNOCC && SR != 0), "persistent workers: plain steps of the compiled shapes");
+  static_assert(!CODES || (!EPI && !UNOCC), "owner codes: plain steps");
   // PW: a worker's own LDS region {flat, sdesc, skip, inbox}; the inbox holds the unit's state rows and its tape actions
   constexpr int NW = W_POS + NS, IB_ROWS = NW + 1;
   const int O_SEM = O_FLAT, O_W0 = O_FLAT + 2, W_WORDS = ((O_WCORNER - O_FLAT) + IB_ROWS * WAVE + 1) & ~1;
@@ -108,6 +116,7 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_warehouse_st
   const uint32_t* const player_blocked = lds + O_PBLK;
   uint32_t* const flat = lds + O_FLAT + mine;
   uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC + mine);
+  uint32_t* const codes = lds + O_SDESC + mine;  // (CODES)
   uint32_t* const skipv = lds + O_SKIP + mine;
   uint32_t* const wcorner = lds + O_WCORNER;
   uint32_t* const inbox = lds + O_WCORNER + mine;  // (PW only: behind the worker's skip flags)
@@ -308,7 +317,27 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_warehouse_st
       for (int s = 0; s < NS; ++s) { cellv[s] = vis[s] ? true_cell(vr[s], vc[s]) : -1; above[s] = k.above[s]; }
       if constexpr (UNOCC)  // occlusion_in_layers=False: the layers are the raw masks (rendering.py:236-278)
         stream::snapshot_raw<NS, 1>(cellv, flat, FW, FWP, lane, lds + O_FLATRAW, reinterpret_cast<uint2*>(lds + O_SDESCRAW));
-      stream::resolve_sprites<NS, 1>(cellv, above, flat, FWP, lane, sdesc);
+      if constexpr (CODES) {
+        // rendering.py:98-179 as byte writes: the backdrop's codes, the judge's marks, then every sprite nothing in front of it covers
+        uint32_t* const cd = codes + lane * CP;
+        const uint32_t* const bdc = lds + O_BDC;
+        if constexpr (SQW != 0) {
+#pragma unroll
+          for (int w = 0; w < SQW; ++w) cd[w] = bdc[w];
+        } else {
+          for (int w = 0; w < QW; ++w) cd[w] = bdc[w];
+        }
+        uint8_t* const cb = reinterpret_cast<uint8_t*>(cd);
+#pragma unroll
+        for (int j = 0; j < NBOX; ++j)
+          if ((on_goal_mask >> j) & 1) cb[tcell1[j]] = (uint8_t)k.drape_code;
+        uint32_t scode[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) scode[s] = k.sprite_code[s];
+        stream::paint_sprites<NS, 1>(cellv, above, flat, FWP, lane, cb, scode);
+      } else {
+        stream::resolve_sprites<NS, 1>(cellv, above, flat, FWP, lane, sdesc);
+      }
 
       // ---- _apply_and_clear_plot (engine.py:761-847) + state write-back ---------
       st[W_FRAME * bp] = (uint32_t)frame;
@@ -355,6 +384,9 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_warehouse_st
 #pragma unroll
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
+  stream::CodeMap<L> cmap;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cmap.chars[i] = k.code_chars[i];
   if constexpr (PW) {
     // the next unit is drawn and its state rows start travelling now, in front of this unit's plane stores
     const uint32_t next = wq.next(unit);
@@ -363,8 +395,11 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_warehouse_st
     if (!(a.debug & 2)) {
       const uint32_t sem = stream::lds_byte_address(lds + O_SEM);
       if (P.work.lock) stream::slot_acquire(sem, P.work.lock);
-      stream::stream_planes<NS, 1, NB, SQW, 1, false, false, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                                    flat, sdesc, skipv, FWP, lane, 0, epi, env0, nullptr, QW, nullptr, nullptr, lds);
+      if constexpr (CODES)
+        stream::stream_codes<L, SQW, 1, false>(cmap, out.planes + (size_t)env0 * env_stride, env_stride, codes, CP, skipv, lane, 0, QW);
+      else
+        stream::stream_planes<NS, 1, NB, SQW, 1, false, false, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                                      flat, sdesc, skipv, FWP, lane, 0, epi, env0, nullptr, QW, nullptr, nullptr, lds);
       if (P.work.lock) stream::slot_release(sem);
     }
     // fewer than 64 plane stores behind the prefetch (environments left alone, ablation runs): wait for it
@@ -372,6 +407,10 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_warehouse_st
     if (need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unit = next;
   } else {
+    if constexpr (CODES) {
+      stream::stream_codes<L, SQW, NWAVES>(cmap, out.planes + (size_t)env0 * env_stride, env_stride, codes, CP, skipv, lane, wave, QW);
+      break;
+    }
     if (!(fc && fc->only))
       stream::stream_planes<NS, 1, NB, SQW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                           flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, QW, lds + O_FLATRAW,
@@ -403,6 +442,7 @@ class WarehouseBackend : public Backend {
     // read: action 4 + state 4 NW; write: state 4 NW + planes (1 + L) cells + results 15
     return 4 + 8 * (int64_t)NW_ + (int64_t)(1 + L_) * lay_.cells + 15;
   }
+  int tuner_done() const override { return tuner_.done(); }
   const char* kernel_name() const override { return "pcx_warehouse_step"; }
   int launch_shape() const override { return last_shape_; }  // 0 a workgroup per group, 10 cooperative, 3 persistent workers (include/pcx.h)
   const int32_t* sprite_track() const override { return track_.ptr; }
@@ -421,8 +461,8 @@ class WarehouseBackend : public Backend {
       return set_error(PCX_E_UNSUPPORTED, "warehouse backend: fused croppers need occluded layers");
     return fused_.set(fc, false, R_, C_);
   }
-  size_t base_lds_bytes() const {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
-    return ((size_t)lay_.QW * (1 + NB_) + 3 * R_ + WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE + WAVE + stream::WCORNER_WORDS +
+  size_t base_lds_bytes(bool codes = false) const {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
+    return ((size_t)lay_.QW * (2 + NB_) + 3 * R_ + WAVE * lay_.FWP + 2 + (codes ? WAVE * lay_.CP : 2 * NS_ * WAVE) + WAVE + stream::WCORNER_WORDS +
             (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS_ * WAVE : 0)) * 4;
   }
   stream::EpilogueArgs* epilogue_args() override { return &epi_; }
@@ -533,7 +573,7 @@ int WarehouseBackend::init(const pcx_template& t, int64_t batch) {
   stream::fill_epilogue(epi_, nullptr, lay_.cells, sprite_ch_, NS_, &drape_ch_, 1, bchar_ch_, NB_);
 
   // tables staged into LDS
-  std::vector<uint32_t> tab((size_t)lay_.QW * (1 + NB_) + 3 * R_, 0);
+  std::vector<uint32_t> tab((size_t)lay_.QW * (2 + NB_) + 3 * R_, 0);
   memcpy(tab.data(), t.backdrop, lay_.cells);
   int nb = 0;
   for (int i = 0; i < L_; ++i) {
@@ -563,6 +603,19 @@ int WarehouseBackend::init(const pcx_template& t, int64_t batch) {
       for (int s = 1; s < ip; ++s)
         if (imp_has(s, ch) != imp_has(0, ch)) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: boxes must share their backdrop rules");
     }
+
+  // owner codes (pcx_stream.h): a character's code is its place in the template's sorted list = its layer plane
+  {
+    auto code_of = [&](int ch) { const int i = layer_of(ch); return L_ <= 8 ? (uint32_t)i : i < 8 ? 0xC0u | (uint32_t)i : 0x0Cu | ((uint32_t)(i - 8) << 4); };
+    if (L_ > 16) return set_error(PCX_E_UNSUPPORTED, "warehouse backend: more than sixteen characters");
+    for (int s = 0; s < NS_; ++s) k.sprite_code[s] = code_of(t.sprites[s].ch);
+    k.drape_code = code_of(dd.ch);
+    memset(k.code_chars, 0, sizeof k.code_chars);
+    for (int i = 0; i < L_; ++i) k.code_chars[i >> 2] |= (uint32_t)t.chars[i] << (8 * (i & 3));
+    uint8_t* bdc = reinterpret_cast<uint8_t*>(pblk + R_);
+    for (int c = 0; c < lay_.cells; ++c) bdc[c] = (uint8_t)code_of(t.backdrop[c]);
+    for (int c = lay_.cells; c < lay_.pitch; ++c) bdc[c] = (uint8_t)(L_ <= 8 ? 8 + 4 : 0xCC);  // plane padding: selector 12, zero bytes in every plane
+  }
 
   // initial state words
   NW_ = W_POS + NS_;
@@ -617,6 +670,17 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   }
   bool launched = false;
   const bool epi = epi_.out != nullptr;  // the feature-array epilogue has its own instances (whole-dword boards only)
+  // (round 6) owner codes: plain steps -- no epilogue, no fused croppers, occluded layers; PCX_WM_CODES=0: the mask loop
+  bool codes = !epi && !fused_.on && !unoccluded_;
+  if (const char* e = getenv("PCX_WM_CODES")) codes = codes && atoi(e) != 0;
+  if (codes) {
+    lds = base_lds_bytes(true);
+    if (!coop && waves_per_cu > 0) {
+      size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
+      if (want > 64 * 1024) want = 64 * 1024;
+      if (want > lds) lds = want;
+    }
+  }
   // (round 5) persistent workers: plain steps of the compiled shapes from four units per CU up.  One workgroup of W workers per
   // CU, `lock` of them streaming at a time, tickets (with stealing) from 24 units per CU up; PCX_WM_PW=0: the round-2 shape.
   bool pw = !coop && !epi && !fused_.on && !unoccluded_ && static_shape_ && a.mode == 0 && !a.export_curtains && (a.debug & ~16) == 0;
@@ -631,8 +695,16 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     // another), so the engine measures on its own first launches (ShapeTuner, pcx_internal.h): the rule's choice first.
     const bool many = groups >= (int64_t)num_cus_ * 32;
     struct Cand { int workers, per_cu, lock; };
-    static const Cand few_c[ShapeTuner::NC] = {{8, 1, 4}, {1, 4, 0}, {2, 4, 1}, {6, 1, 4}};
-    static const Cand many_c[ShapeTuner::NC] = {{1, 4, 0}, {6, 1, 4}, {8, 1, 4}, {2, 3, 1}};
+    static const Cand few_m[ShapeTuner::NC] = {{8, 1, 4}, {1, 4, 0}, {2, 4, 1}, {6, 1, 4}};
+    static const Cand many_m[ShapeTuner::NC] = {{1, 4, 0}, {6, 1, 4}, {8, 1, 4}, {2, 3, 1}};
+    // (round 6) the owner-code loop is a third of the instructions per store: one streaming wave moves a unit at 60 % of the CU's
+    // rate (one slot: 0.111 ms at 262,144 environments, the mask loop 0.167), TWO saturate it, and fewer concurrent streams
+    // leave shorter tails -- four workers with two shared slots 0.0771 / 0.3002 ms at 262,144 / 1,048,576 environments where
+    // the mask loop's best shapes measure 0.0811 / 0.2984 on the same box (profiles/r06_warehouse_codes_sweep.txt)
+    static const Cand few_k[ShapeTuner::NC] = {{4, 1, 2}, {1, 4, 0}, {2, 2, 2}, {6, 1, 3}};
+    static const Cand many_k[ShapeTuner::NC] = {{4, 1, 2}, {2, 2, 2}, {1, 4, 0}, {8, 1, 3}};
+    const Cand* const few_c = codes ? few_k : few_m;
+    const Cand* const many_c = codes ? many_k : many_m;
     const bool knobs = getenv("PCX_WM_WORKERS") || getenv("PCX_WM_PER_CU") || getenv("PCX_WM_LOCK") || getenv("PCX_WM_GRID") ||
                        (getenv("PCX_WM_TUNE") && atoi(getenv("PCX_WM_TUNE")) == 0);
     if (knobs) tuner_.off = true;
@@ -643,9 +715,9 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     if (const char* e = getenv("PCX_WM_LOCK")) lock = atoi(e);
     int dynamic = groups >= (int64_t)num_cus_ * 24;
     if (const char* e = getenv("PCX_WM_DYNAMIC")) dynamic = atoi(e) != 0;
-    const size_t tab_words = (size_t)lay_.QW * (1 + NB_) + 3 * R_;
+    const size_t tab_words = (size_t)lay_.QW * (2 + NB_) + 3 * R_;
     const size_t o_sdesc = (tab_words + (size_t)WAVE * lay_.FWP + 1) & ~(size_t)1;
-    const size_t region = o_sdesc + 2 * NS_ * WAVE + WAVE - tab_words;  // flat, sdesc, skip: the kernel's O_WCORNER - O_FLAT
+    const size_t region = o_sdesc + (codes ? WAVE * lay_.CP : 2 * NS_ * WAVE) + WAVE - tab_words;  // flat, sdesc / codes, skip: the kernel's O_WCORNER - O_FLAT
     const size_t w_words = (region + (size_t)(W_POS + NS_ + 1) * WAVE + 1) & ~(size_t)1;
     size_t lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4;
     while (workers > 1 && lds_pw > 64 * 1024) { --workers; lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4; }
@@ -660,7 +732,8 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     P.work.lock = lock;
 #define X(ns, r, c, nb)                                                                                     \
   if (!launched && NS_ == ns && R_ == r && C_ == c && NB_ == nb) {                                          \
-    hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, 1, false, false, true>), dim3((unsigned)wgs), dim3(workers * WAVE), lds_pw, s, k_, P, a, out, epi_, fused_.ptr()); \
+    if (codes) hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, 1, false, false, true, true>), dim3((unsigned)wgs), dim3(workers * WAVE), lds_pw, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, 1, false, false, true>), dim3((unsigned)wgs), dim3(workers * WAVE), lds_pw, s, k_, P, a, out, epi_, fused_.ptr()); \
     launched = true;                                                                                        \
   }
     PCX_WM_SHAPES(X)
@@ -670,7 +743,10 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
   }
   if (!launched) last_shape_ = coop ? 10 : 0;
 #define PCX_WM_LAUNCH(ns, r, c, nb, nw, ep)                                                                  \
-  hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, nw, ep>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr())
+  do {                                                                                                      \
+    if (!ep && codes) hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, nw, false, false, false, true>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else hipLaunchKernelGGL((pcx_warehouse_step<ns, r, c, nb, nw, ep>), dim3((unsigned)groups), dim3(nw * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+  } while (0)
 #define X(ns, r, c, nb)                                                                                     \
   if (!launched && !unoccluded_ && NS_ == ns && R_ == r && C_ == c && NB_ == nb) {                          \
     if (epi && coop) PCX_WM_LAUNCH(ns, r, c, nb, 4, true);                                                  \
@@ -689,7 +765,7 @@ int WarehouseBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStrea
     if (unoccluded_) {                                                                                      \
       if (coop) hipLaunchKernelGGL((pcx_warehouse_step<ns, 0, 0, 4, 4, false, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
       else hipLaunchKernelGGL((pcx_warehouse_step<ns, 0, 0, 4, 1, false, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());          \
-    } else if (coop) PCX_WM_LAUNCH(ns, 0, 0, 4, 4, false); else PCX_WM_LAUNCH(ns, 0, 0, 4, 1, false);      \
+    } else if (coop) { PCX_WM_LAUNCH(ns, 0, 0, 4, 4, false); } else { PCX_WM_LAUNCH(ns, 0, 0, 4, 1, false); } \
     launched = true;                                                                                        \
     break;
       PCX_WM_DYN(2) PCX_WM_DYN(3) PCX_WM_DYN(4) PCX_WM_DYN(5) PCX_WM_DYN(6) PCX_WM_DYN(7) PCX_WM_DYN(8) PCX_WM_DYN(9)

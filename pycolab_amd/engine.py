@@ -452,17 +452,22 @@ class Engine(object):
     # a feature stack fused into a cropper's window (ObservationToFeatureArray.fuse_into(engine, source=cropper)) was
     # written by the exporting engine's step kernel: recompute it from the window as restored (or recut), so that the
     # converter does not hand out the pre-import tensor as this step's
+    with_observation = bool(blob[48:52].view(np.int32)[0]) if blob.size >= 64 else False  # StateHeader.with_observation
     for cropper in croppers:
       feats = getattr(cropper, '_features', None)
       if feats is not None:
-        feats[0]._window_after_import(cropper, feats[1])
+        feats[0]._window_after_import(cropper, feats[1], with_observation)
     # a fused post-processor's array was written by the exporting engine's step kernel, not by this one: refill it
     # from the restored observation where there is one; otherwise it counts as not written (the converter falls back
     # to its own kernel, which raises for an engine that writes no planes) until the next step
     if self._epilogue is not None:
       converter, out = self._epilogue
-      restored = bool(blob[48:52].view(np.int32)[0]) if blob.size >= 64 else False  # StateHeader.with_observation
-      converter._after_import(self, out, restored and not self._epilogue_only)
+      converter._after_import(self, out, with_observation and not self._epilogue_only)
+
+  def tuner_done(self):
+    """False while the engine's first step launches still take turns measuring launch shapes (include/pcx.h
+    pcx_engine_tuner_done); a benchmark steps until this is True before it times anything."""
+    return bool(N.lib().pcx_engine_tuner_done(self._native))
 
   def check_errors(self):
     """Synchronises and raises if a device program hit a condition the

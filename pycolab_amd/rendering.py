@@ -430,15 +430,17 @@ class ObservationToFeatureArray(object):
   def _window_gone(self):
     self._fused_window = None
 
-  def _window_after_import(self, cropper, out):
+  def _window_after_import(self, cropper, out, restored=True):
     """Engine.import_state() with a stack fused into `cropper`'s window: the tensor holds what the step kernel wrote
     before the import.  Refill it from the restored window through the stand-alone kernels (the window's uint8 planes
     are restored with the checkpoint's observation or recut by crop()); a window whose planes the kernel no longer
-    writes (skip_layers / skip_board) cannot be recomputed and counts as not written until the next step."""
+    writes (skip_layers / skip_board) cannot be recomputed and counts as not written until the next step -- and so does
+    every window when the checkpoint carried no observation (`restored` False: crop(None) would recut it from the
+    engine's full-board planes, which then still show the frame BEFORE the import)."""
     if self._fused_window is None or self._fused_window[0] is not cropper:
       return
     engine = cropper._engine
-    if getattr(cropper, '_feat_skip', 0):
+    if getattr(cropper, '_feat_skip', 0) or not restored:
       self._fused_window = (cropper, out, engine._steps_launched)  # (stale until a step rewrites it)
       return
     out.copy_(ObservationToFeatureArray(self._layers, self._permute)(cropper.crop(None)))
@@ -461,6 +463,8 @@ class ObservationToFeatureArray(object):
       engine, out, attached_at = self._fused
       if engine._steps_launched > attached_at:  # a step has run since: the kernel wrote `out`
         return out
+    if getattr(observation, '_planes_stale', False):
+      _source_of(observation)  # (raises, saying what the placeholder is: BEFORE the layers check, which its empty `layers` would fail with a misleading text)
     if not any(l in observation.layers for l in self._layers):
       raise RuntimeError(
           'The layers argument to this ObservationToFeatureArray, {}, has no '

@@ -245,7 +245,7 @@ def test_headline_batch_default_shape_equals_one_workgroup_per_group_shape_every
   hip.reset()
   for t0 in range(T // 2):  # single-step launches: the shape Engine.play() takes ...
     hip.step_hashed(0xC0FFEE, t0, 1)
-    assert raw_shape_of(hip) == 5
+    assert raw_shape_of(hip) in (3, 5)  # (5: the constants-compiled-in instance; as tests/test_gate_digests.py)
   hip.step_hashed(0xC0FFEE, T // 2, T - T // 2)  # ... then one launch of twelve steps, every worker on its own units
   assert raw_shape_of(hip) == 13
   planes = hip.eng.planes_view()
