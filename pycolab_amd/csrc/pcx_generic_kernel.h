@@ -59,6 +59,7 @@ struct Consts {
   int32_t l_pos, l_flg, l_snap, l_cur, l_snapd, l_flat, l_sdesc, l_skip, l_flatraw, l_sdescraw, l_corner, l_pmask, l_pframe, l_words;
   int32_t l_wcorner;              // fused croppers: [MAX_FUSED_CROPPERS][lane] window corners (pcx_stream.h WCORNER_NONE)
   int32_t l_inbox;                // where the group's scalar state words land by LDS-DMA: [IB_ROWS + (NS + 3) / 4][lane], over what the render phase reads later
+  int32_t l_bdcode;               // owner codes (pcx_stream.h stream_codes): the backdrop's code dwords [QW], a staged table (-1: more than 16 characters)
   uint8_t chars[PCX_MAX_CHARS];   // character of layer plane 1 + i
 };
 
@@ -102,7 +103,13 @@ struct L {
   int32_t* snap;
   uint2 *sdesc, *sdescraw;
   uint32_t* wcorner;  // fused croppers: window corners [MAX_FUSED_CROPPERS][lane]
+  // owner codes (pcx_generic_step_pw): the staged backdrop code dwords, and where the logic phase leaves this group's code
+  // dwords [64][QW | 1] for the render worker (null: it leaves flat / sdesc for the mask-composing loop)
+  const uint32_t* bdcode;
+  uint32_t* codes;
 };
+// the code byte of layer i of L characters (pcx_stream.h: one v_perm_b32 selects among eight)
+__device__ __forceinline__ uint32_t code_of_layer(int L, uint32_t i) { return L <= 8 ? i : i < 8u ? 0xC0u | i : 0x0Cu | ((i - 8u) << 4); }
 
 __device__ __forceinline__ uint32_t action_hash(uint64_t seed, uint64_t env, uint64_t t) {
   uint64_t x = seed ^ (env * 0x9E3779B97F4A7C15ull) ^ (t * 0xBF58476D1CE4E5B9ull);
@@ -1063,30 +1070,17 @@ __device__ __forceinline__ void render_windows(const Consts& k, const L& l, cons
   }
 }
 
-#ifdef __HIPCC_RTC__
-extern "C"  // (the run-time build is looked up by this plain name)
-#endif
-__global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))) void pcx_generic_step(const Consts k_arg, const Ptrs P, const StepArgs a,
-                                                         const pcx_buffers out, const crop::FusedCrops* fc) {
-  extern __shared__ uint32_t lds[];
-#ifdef PCX_GENERIC_SPEC
-  const Consts& k = spec::K;
-#else
-  const Consts& k = k_arg;
-#endif
-  // A workgroup is 1, 2, 4 or 8 waves around one group of 64 environments: wave 0
-  // steps them (lane == environment), then all waves share the render loop.
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  // The group's state words (SoA over the batch: word w of 64 consecutive environments is one 256-byte row) travel
-  // straight into the per-lane LDS columns the logic phase keeps them in -- sprite positions, curtain rows, scrolling
-  // protocol words -- and the scalars into an inbox, all by LDS-DMA, issued back to back in front of the staging of
-  // the tables: ONE memory round trip instead of a dozen (a copy loop through registers has four loads in flight).
-  if (wave == 0) {
-    const uint32_t* const sb = stream::uniform_words(P.state + (int64_t)blockIdx.x * WAVE);
+// The state words of work unit `unit` (64 consecutive environments; SoA over the batch: word w of the unit is one 256-byte row)
+// straight into the per-lane LDS columns the logic phase keeps them in -- sprite positions, curtain rows, scrolling protocol words --
+// and the scalars into an inbox, all by LDS-DMA issued back to back: ONE memory round trip instead of a dozen (a copy loop through
+// registers has four loads in flight).  `off`: word offset of the worker's copy of the per-lane arrays (0: the one-group layout).
+// The issuing wave waits on vmcnt itself.
+__device__ __forceinline__ void dma_state_rows(const Consts& k, const Ptrs& P, const StepArgs& a, uint32_t* lds, int off, int64_t unit, int lane) {
+    const uint32_t* const sb = stream::uniform_words(P.state + unit * WAVE);
     const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)stream::lds_byte_address(lds));
     const uint32_t vo = 4u * (uint32_t)lane;
     const int64_t bpw = P.bpad;
-    auto row = [&](int word, int lds_word) { stream::lds_dma_row(sb + (int64_t)word * bpw, vo, l0 + 4u * (uint32_t)lds_word); };
+    auto row = [&](int word, int lds_word) { stream::lds_dma_row(sb + (int64_t)word * bpw, vo, l0 + 4u * (uint32_t)(lds_word + off)); };
     for (int w = 0; w < W_SPRITES; ++w) row(w, k.l_inbox + w * WAVE);
     for (int s = 0; s < k.NS; ++s) row(W_SPRITES + s, k.l_pos + s * WAVE);
     for (int w = 0; w < (k.NS + 3) / 4; ++w) row(k.w_sflags + w, k.l_inbox + (IB_SFLAGS + w) * WAVE);
@@ -1102,50 +1096,50 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
     if (k.zdyn) { row(k.w_z, k.l_inbox + IB_Z0 * WAVE); row(k.w_z + 1, k.l_inbox + IB_Z1 * WAVE); }
     if (k.w_next >= 0) row(k.w_next, k.l_inbox + IB_NEXT * WAVE);
-    if (a.mode == 0 && !a.hashed && (int64_t)blockIdx.x * WAVE + lane < P.batch)  // (the tape has `batch` entries, not the padded count)
-      stream::lds_dma_row(stream::uniform_words(reinterpret_cast<const uint32_t*>(a.actions) + (int64_t)blockIdx.x * WAVE), vo,
-                          l0 + 4u * (uint32_t)(k.l_inbox + IB_ACTION * WAVE));
-  }
-  for (int i = threadIdx.x; i < P.n_table_words; i += blockDim.x) lds[i] = P.tables[i];
-  if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed
-  __syncthreads();
+    if (a.mode == 0 && !a.hashed && unit * WAVE + lane < P.batch)  // (the tape has `batch` entries, not the padded count)
+      stream::lds_dma_row(stream::uniform_words(reinterpret_cast<const uint32_t*>(a.actions) + unit * WAVE), vo,
+                          l0 + 4u * (uint32_t)(k.l_inbox + IB_ACTION * WAVE + off));
+}
 
-  const bool timing = (a.debug & 8) != 0 && P.stats != nullptr;
-  auto render_all = [&](const L& lr, int64_t env0r, int w, int nw) {
-    const bool any_skip = __ballot(lr.skip[lane] != 0) != 0ull;
-    if (fc) {
-      render_windows(k, lr, fc, lr.wcorner, env0r, lane, w, nw);
-      if (fc->only) return;  // the consumer ingests the windows only: no full-board planes
-    }
-    switch ((k.NT + 3) / 4) {
-      case 0: case 1: render_planes<4>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
-      case 2: render_planes<8>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
-      case 3: render_planes<12>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
-      default: render_planes<16>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
-    }
-  };
-  const int64_t env0 = (int64_t)blockIdx.x * WAVE, env = env0 + lane;
+// The LDS pointers of one group: the staged tables (shared), the per-lane arrays at word offset `off` (0: the one-group layout).
+__device__ __forceinline__ L make_L(uint32_t* lds, const Consts& k, int off) {
   L l;
   l.things = lds + k.l_things; l.z = lds + k.l_z; l.sched = lds + k.l_sched;
   l.backdrop4 = lds + k.l_backdrop; l.bdmask = lds + k.l_bdmask; l.aux = lds + k.l_aux;
   l.init = lds + k.l_init; l.initd = lds + k.l_initd; l.laybc = lds + k.l_laybc; l.s2t = lds + k.l_s2t; l.d2t = lds + k.l_d2t;
-  l.pos = lds + k.l_pos; l.flg = lds + k.l_flg; l.snap = reinterpret_cast<int32_t*>(lds + k.l_snap);
-  l.cur = lds + k.l_cur; l.snapd = lds + k.l_snapd;
-  l.corner = lds + k.l_corner; l.pmask = lds + k.l_pmask; l.pframe = lds + k.l_pframe;
-  l.dir = lds + k.l_dir; l.zord = lds + k.l_zord; l.zabove = lds + k.l_zabove; l.zabove_s = lds + k.l_zabove_s;
-  l.zabove_d = lds + k.l_zabove_d; l.zq = lds + k.l_zq; l.ztmp = lds + k.l_ztmp;
-  l.flat = lds + k.l_flat; l.sdesc = reinterpret_cast<uint2*>(lds + k.l_sdesc); l.skip = lds + k.l_skip;
-  l.flatraw = lds + k.l_flatraw; l.sdescraw = reinterpret_cast<uint2*>(lds + k.l_sdescraw); l.wcorner = lds + k.l_wcorner;
+  l.pos = lds + off + k.l_pos; l.flg = lds + off + k.l_flg; l.snap = reinterpret_cast<int32_t*>(lds + off + k.l_snap);
+  l.cur = lds + off + k.l_cur; l.snapd = lds + off + k.l_snapd;
+  l.corner = lds + off + k.l_corner; l.pmask = lds + off + k.l_pmask; l.pframe = lds + off + k.l_pframe;
+  l.dir = lds + k.l_dir; l.zord = lds + off + k.l_zord; l.zabove = lds + off + k.l_zabove; l.zabove_s = lds + off + k.l_zabove_s;
+  l.zabove_d = lds + off + k.l_zabove_d; l.zq = lds + off + k.l_zq; l.ztmp = lds + off + k.l_ztmp;
+  l.flat = lds + off + k.l_flat; l.sdesc = reinterpret_cast<uint2*>(lds + off + k.l_sdesc); l.skip = lds + off + k.l_skip;
+  l.flatraw = lds + off + k.l_flatraw; l.sdescraw = reinterpret_cast<uint2*>(lds + off + k.l_sdescraw); l.wcorner = lds + off + k.l_wcorner;
 #ifdef PCX_GENERIC_SPEC  // tables that are only ever read at a uniform index: from the constants
   l.z = spec::TAB + k.l_z; l.sched = spec::TAB + k.l_sched; l.init = spec::TAB + k.l_init; l.initd = spec::TAB + k.l_initd;
   l.laybc = spec::TAB + k.l_laybc; l.s2t = spec::TAB + k.l_s2t; l.d2t = spec::TAB + k.l_d2t; l.dir = spec::TAB + k.l_dir;
 #endif
+  l.bdcode = lds + k.l_bdcode; l.codes = nullptr;
+  return l;
+}
+
+// The logic phase of one group of 64 environments, lane == environment (engine.py:583-847 for every lane's environment): the update
+// groups in order, _apply_and_clear_plot, the state write-back, and the occlusion of the final repaint left as render descriptors
+// (l.flat / l.sdesc / l.skip: what render_planes reads).  `ib_rows`: the inbox dma_state_rows() filled (row r at [r * WAVE]);
+// `logic_wave`: this wave steps the group (the others of a workgroup only share the render loop).
+// `slot_free()`: called (by the lanes that step, and once more by all) before anything is written where the render side reads --
+// l.codes and l.skip -- so that a persistent logic worker can wait for its hand-over slot as late as possible.
+struct NoWait { __device__ __forceinline__ void operator()() const {} };
+template <typename SlotFree = NoWait>
+__device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const Ptrs& P, const StepArgs& a, const pcx_buffers& out,
+                                            const crop::FusedCrops* fc, const uint32_t* ib_rows, int64_t env0, int lane, bool logic_wave, bool timing,
+                                            SlotFree slot_free = SlotFree()) {
+  const int64_t env = env0 + lane;
   const unsigned long long t_start = timing ? __builtin_readcyclecounter() : 0ull;
   unsigned long long c_sec[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c_prog[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool live = wave == 0 && env < P.batch;  // the logic phase is wave 0's
+  const bool live = logic_wave && env < P.batch;
   const int64_t bp = P.bpad;
   uint32_t* st = P.state + env;
-  const uint32_t* const ib = lds + k.l_inbox + lane;  // row r at [r * WAVE]
+  const uint32_t* const ib = ib_rows + lane;  // row r at [r * WAVE]
   uint32_t flags = 0;
   bool skip = !live, do_reset = false;
   int action = PCX_ACTION_NONE;
@@ -1374,6 +1368,32 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
       l.sdesc[s * WAVE + lane].y = shown ? 1u : 0u;
     }
     if (timing) c_sec[8] = __builtin_readcyclecounter() - t_occ;  // + sprites resolved
+    if (l.codes != nullptr) {
+      // Owner codes (rendering.py:98-179 as one byte per cell): the backdrop's code dwords, every curtain's cells (disjoint by
+      // now: a curtain lost what a curtain in front covers) merged in four at a time, then the painted sprites as byte writes.
+      slot_free();
+      const int CP = k.QW | 1;
+      uint32_t* const cd = l.codes + lane * CP;
+      for (int q = 0; q < k.QW; ++q) {
+        uint32_t d = l.bdcode[q];
+        PCX_SPEC_UNROLL
+        for (int t = 0; t < k.NT; ++t) {
+          if (tfield(x, t, T_KIND) != 1) continue;
+          const uint32_t bits = (l.flat[GFLAT(tfield(x, t, T_IDX), q >> 3, lane)] >> ((q & 7) * 4)) & 0xFu;
+          const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+          uint32_t hi8 = m01 << 8;
+          asm("" : "+v"(hi8));  // (keeps (x << 8) - x from becoming a quarter-rate multiply)
+          const uint32_t m = hi8 - m01;
+          d = (d & ~m) | ((code_of_layer(k.L, tfield(x, t, T_LAYER)) * 0x01010101u) & m);
+        }
+        cd[q] = d;
+      }
+      uint8_t* const cb = reinterpret_cast<uint8_t*>(cd);
+      for (int s = 0; s < k.NS; ++s) {
+        const uint2 cs = l.sdesc[s * WAVE + lane];
+        if (cs.y) cb[cs.x] = (uint8_t)code_of_layer(k.L, tfield(x, (int)l.s2t[s], T_LAYER));
+      }
+    }
     for (int s = 0; s < k.NS; ++s) {
       const uint2 cs = l.sdesc[s * WAVE + lane];
       const int cell = (int)cs.x;
@@ -1386,7 +1406,7 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     if (fc) move_windows(x, fc, env, l.wcorner);  // fused croppers follow this step's things
     if (timing) c_sec[3] = __builtin_readcyclecounter() - t_occ;  // occlusion + descriptors
   }
-  if (timing && wave == 0 && lane == 0) {
+  if (timing && logic_wave && lane == 0) {
     atomicAdd(P.stats + 67, __builtin_readcyclecounter() - t_start);  // whole logic phase
     atomicAdd(P.stats + 69, 1ull);
     atomicAdd(P.stats + 64, c_sec[0]); atomicAdd(P.stats + 65, c_sec[1]);
@@ -1395,10 +1415,213 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     atomicAdd(P.stats + 72, c_sec[7]); atomicAdd(P.stats + 73, c_sec[8]);
     for (int b2 = 0; b2 < 8; ++b2) atomicAdd(P.stats + b2, c_prog[b2]);
   }
-  if (wave == 0) l.skip[lane] = skip;
+  slot_free();
+  if (logic_wave) l.skip[lane] = skip;
+#undef GFLAT
+}
+
+#ifdef __HIPCC_RTC__
+extern "C"  // (the run-time build is looked up by this plain name)
+#endif
+__global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))) void pcx_generic_step(const Consts k_arg, const Ptrs P, const StepArgs a,
+                                                         const pcx_buffers out, const crop::FusedCrops* fc) {
+  extern __shared__ uint32_t lds[];
+#ifdef PCX_GENERIC_SPEC
+  const Consts& k = spec::K;
+#else
+  const Consts& k = k_arg;
+#endif
+  // A workgroup is 1, 2, 4 or 8 waves around one group of 64 environments: wave 0
+  // steps them (lane == environment), then all waves share the render loop.
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  // The group's state words (SoA over the batch: word w of 64 consecutive environments is one 256-byte row) travel
+  // straight into the per-lane LDS columns the logic phase keeps them in -- sprite positions, curtain rows, scrolling
+  // protocol words -- and the scalars into an inbox, all by LDS-DMA, issued back to back in front of the staging of
+  // the tables: ONE memory round trip instead of a dozen (a copy loop through registers has four loads in flight).
+  if (wave == 0) dma_state_rows(k, P, a, lds, 0, (int64_t)blockIdx.x, lane);
+  for (int i = threadIdx.x; i < P.n_table_words; i += blockDim.x) lds[i] = P.tables[i];
+  if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed
+  __syncthreads();
+
+  const bool timing = (a.debug & 8) != 0 && P.stats != nullptr;
+  auto render_all = [&](const L& lr, int64_t env0r, int w, int nw) {
+    const bool any_skip = __ballot(lr.skip[lane] != 0) != 0ull;
+    if (fc) {
+      render_windows(k, lr, fc, lr.wcorner, env0r, lane, w, nw);
+      if (fc->only) return;  // the consumer ingests the windows only: no full-board planes
+    }
+    switch ((k.NT + 3) / 4) {
+      case 0: case 1: render_planes<4>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
+      case 2: render_planes<8>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
+      case 3: render_planes<12>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
+      default: render_planes<16>(k, lr, P, out, env0r, lane, w, nw, any_skip); break;
+    }
+  };
+  const int64_t env0 = (int64_t)blockIdx.x * WAVE;
+  const L l = make_L(lds, k, 0);
+  logic_phase(k, l, P, a, out, fc, lds + k.l_inbox, env0, lane, wave == 0, timing);
   __syncthreads();
   if (!(a.debug & 2)) render_all(l, env0, wave, nwaves);  // every wave of the workgroup streams board + layers
-#undef GFLAT
+}
+
+// ---------------------------------------------------------------------------
+// Persistent workers with the logic phase DECOUPLED from the render phase (round 6).
+//
+// What bounds pcx_generic_step (profiles/r06_generic.md): a launch takes  units_per_CU x T / n_resident + the store floor,
+// where T is one unit's logic phase -- a serial chain of LDS round trips, 20-35 us -- and n_resident is how many groups'
+// per-lane arrays fit the CU's LDS (9-16).  A group holds its 16 KB of columns while it renders, and its render waves hold
+// their wave slots while it steps.  Here a workgroup stays on its CU: its first `n_logic` waves are LOGIC WORKERS -- each
+// owns one copy of the per-lane arrays, draws work units of 64 environments (pcx_stream.h WorkQueue) and steps one after
+// the other without ever streaming -- and the next `n_render` waves are RENDER WORKERS that do nothing else.
+// The hand-over is OWNER CODES (pcx_stream.h): the logic worker ends a unit by leaving one code byte per board cell in its
+// hand-over slot ([64][QW | 1] dwords + the skip flags), and the render worker streams the slot with one LDS read and one
+// v_perm_b32 per plane -- a loop light enough for TWO render waves to saturate the CU's store path (the mask-composing
+// render_planes needs ~18).  One slot per logic worker is enough: it is written in the last microseconds of a logic phase
+// of tens, so the worker waits for the slot -- one LDS flag word, 0 empty / unit + 1 full / DONE, one writer and one reader
+// at a time, polled -- only then, long after the render worker has streamed the unit before.  Results never depend on the
+// schedule: a unit is stepped by exactly one logic worker and streamed exactly once.
+// Plain step launches of occluded games with at most 16 characters (no fused croppers, no feature epilogue, no reset
+// launches: pcx_generic_step keeps those).
+struct PwArgs {
+  stream::WorkArgs work;      // the logic workers' scheduler
+  int32_t n_logic, n_render;  // waves [0, n_logic) step, waves [n_logic, n_logic + n_render) stream
+  int32_t lw_words;           // logic worker i's per-lane arrays lie i * lw_words behind the one-group layout's
+  int32_t slot0, slot_words;  // hand-over slot i starts at word slot0 + i * slot_words: codes [64][QW | 1], then skip [64]
+  int32_t flags;              // word offset of the n_logic flag words
+};
+constexpr uint32_t PW_DONE = 0xFFFFFFFFu;
+
+// The render worker's loop: pcx_stream.h stream_codes for one wave, with the number of characters a run-time value (a
+// constant in the build specialised for the template).  Every store is `scalar plane base + one shared 32-bit lane offset`.
+__device__ __forceinline__ void render_codes(const Consts& k, const uint32_t* codes, const uint32_t* skip, const pcx_buffers& out, int64_t env0,
+                                             int lane) {
+  const uint32_t QW = (uint32_t)k.QW, CP = QW | 1u, pitch = (uint32_t)k.pitch;
+  const int Lc = k.L;
+  const uint32_t env_stride = (uint32_t)(1 + Lc) * pitch;
+  uint8_t* const blk = stream::uniform_ptr(out.planes + (size_t)env0 * env_stride);
+  uint32_t ch[4] = {0, 0, 0, 0};
+  PCX_SPEC_UNROLL
+  for (int i = 0; i < Lc && i < 16; ++i) ch[i >> 2] |= (uint32_t)k.chars[i] << (8 * (i & 3));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ch[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch[i]);
+  const bool any_skip = __ballot(skip[lane] != 0) != 0ull;
+  const uint32_t DE = (uint32_t)WAVE / QW, DQ = (uint32_t)WAVE - DE * QW;
+  uint32_t e = (uint32_t)lane / QW, q = (uint32_t)lane - e * QW;
+  uint32_t voff = e * env_stride + 4u * q, ci = e * CP + q;
+  const uint32_t dvoff = DE * env_stride + 4u * DQ, dci = DE * CP + DQ;
+  const uint32_t wrap_voff = env_stride - 4u * QW, wrap_ci = CP - QW;
+  const uint32_t ci_last = (uint32_t)(WAVE - 1) * CP + QW - 1u;
+  uint32_t code_pf = codes[ci];
+#pragma unroll 1
+  for (uint32_t it = 0; it < QW; ++it) {
+    const uint32_t e_now = e, voff_now = voff, code = code_pf;
+    q += DQ; e += DE; voff += dvoff; ci += dci;
+    {
+      const bool wrap = q >= QW;
+      q = wrap ? q - QW : q;
+      e = wrap ? e + 1 : e;
+      voff = wrap ? voff + wrap_voff : voff;
+      ci = wrap ? ci + wrap_ci : ci;
+    }
+    code_pf = codes[ci < ci_last ? ci : ci_last];
+    if (any_skip && skip[e_now] != 0) continue;
+    if (Lc <= 8) {
+      saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(ch[1], ch[0], code), blk);
+      PCX_SPEC_UNROLL
+      for (int i = 0; i < Lc; ++i) {
+        const uint32_t one = 1u << (8 * (i & 3));
+        saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(i >= 4 ? one : 0u, i < 4 ? one : 0u, code), blk + (size_t)(1 + i) * pitch);
+      }
+    } else {
+      const uint32_t sa = code & 0x0F0F0F0Fu, sb = (code >> 4) & 0x0F0F0F0Fu;
+      saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(ch[1], ch[0], sa) | __builtin_amdgcn_perm(ch[3], ch[2], sb), blk);
+      PCX_SPEC_UNROLL
+      for (int i = 0; i < Lc; ++i) {
+        const int j = i & 7;
+        const uint32_t one = 1u << (8 * (j & 3));
+        saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(j >= 4 ? one : 0u, j < 4 ? one : 0u, i < 8 ? sa : sb), blk + (size_t)(1 + i) * pitch);
+      }
+    }
+  }
+}
+
+#ifdef __HIPCC_RTC__
+extern "C"
+#endif
+__global__ __launch_bounds__(16 * WAVE) void pcx_generic_step_pw(const Consts k_arg, const Ptrs P, const StepArgs a, const pcx_buffers out,
+                                                                const PwArgs w) {
+  extern __shared__ uint32_t lds[];
+#ifdef PCX_GENERIC_SPEC
+  const Consts& k = spec::K;
+#else
+  const Consts& k = k_arg;
+#endif
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int NLW = w.n_logic, NRW = w.n_render;
+  for (int i = threadIdx.x; i < P.n_table_words; i += blockDim.x) lds[i] = P.tables[i];
+  if ((int)threadIdx.x < NLW) lds[w.flags + threadIdx.x] = 0u;
+  __syncthreads();
+  const bool timing = (a.debug & 8) != 0 && P.stats != nullptr;
+  auto flag_load = [&](int i) {
+    const uint32_t v = __hip_atomic_load(lds + w.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  // Everything handed over lives in LDS, and a wave's LDS operations complete in order: `s_waitcnt lgkmcnt(0)` is all the
+  // ordering the hand-over needs.  (A workgroup-scope release FENCE also waits for vmcnt(0) -- the render worker would drain
+  // its plane stores after every unit, the logic worker its write-back: measured, 40 us of waiting per unit.)
+  auto lds_order = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  auto flag_store = [&](int i, uint32_t v) {  // (after everything this wave wrote to / read from the slot)
+    lds_order();
+    __hip_atomic_store(lds + w.flags + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (every lane the same word)
+  };
+  const int CP = k.QW | 1;
+  if (wave < NLW) {
+    // ---- a logic worker ----------------------------------------------------------
+    const int off = wave * w.lw_words;
+    L l = make_L(lds, k, off);
+    uint32_t* const slot = lds + w.slot0 + wave * w.slot_words;
+    l.codes = slot;
+    l.skip = slot + WAVE * CP;
+    stream::WorkQueue wq;
+    wq.init(w.work, wave, NLW);
+    auto slot_free = [&]() {  // the render worker has streamed the unit before
+      if (a.debug & 32) return;  // (timing experiment: no waiting -- the observation is then anybody's guess)
+      uint32_t spins = 0;
+      while (flag_load(wave) != 0u && ++spins < stream::SLOT_SPINS) __builtin_amdgcn_s_sleep(2);
+      lds_order();
+    };
+    for (uint32_t unit = wq.first(); unit < wq.n; unit = wq.next(unit)) {
+      dma_state_rows(k, P, a, lds, off, (int64_t)unit, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed (and this worker's write-back of the unit before)
+      logic_phase(k, l, P, a, out, nullptr, lds + k.l_inbox + off, (int64_t)unit * WAVE, lane, true, timing, slot_free);
+      flag_store(wave, unit + 1u);
+    }
+    slot_free();
+    flag_store(wave, PW_DONE);
+    wq.finish(lane);
+  } else if (wave < NLW + NRW) {
+    // ---- a render worker: the slots of logic workers j, j + n_render, ... as they fill them ----------
+    const int j = wave - NLW;
+    uint32_t done = 0;
+    int remaining = 0;
+    for (int i = j; i < NLW; i += NRW) ++remaining;
+    uint32_t idle = 0;
+    while (remaining > 0 && idle < stream::SLOT_SPINS) {
+      bool any = false;
+      for (int i = j; i < NLW; i += NRW) {
+        if ((done >> i) & 1u) continue;
+        const uint32_t v = flag_load(i);
+        if (v == 0u) continue;
+        if (v == PW_DONE) { done |= 1u << i; --remaining; continue; }
+        any = true;
+        lds_order();
+        const uint32_t* const slot = lds + w.slot0 + i * w.slot_words;
+        if (!(a.debug & 2)) render_codes(k, slot, slot + WAVE * CP, out, (int64_t)(v - 1u) * WAVE, lane);
+        flag_store(i, 0u);
+      }
+      if (any) idle = 0; else { ++idle; __builtin_amdgcn_s_sleep(2); }
+    }
+  }
 }
 
 }  // namespace gen

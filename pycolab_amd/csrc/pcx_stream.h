@@ -108,9 +108,10 @@ struct WorkQueue {
   uint32_t* ctr;
   uint32_t n, shards, x, wpw, nwk, wid, local, stolen;
   bool dynamic;
-  __device__ __forceinline__ void init(const WorkArgs& w, int wave) {
+  // (workers_per_wg > 0: only the first so many waves of a workgroup are workers -- pcx_generic_step_pw's logic workers)
+  __device__ __forceinline__ void init(const WorkArgs& w, int wave, int workers_per_wg = 0) {
     ctr = w.ctr; n = w.n_units; dynamic = w.dynamic != 0;
-    wpw = blockDim.x >> 6;
+    wpw = workers_per_wg > 0 ? (uint32_t)workers_per_wg : blockDim.x >> 6;
     shards = gridDim.x < 8u ? gridDim.x : 8u;
     x = blockIdx.x % shards;
     nwk = gridDim.x * wpw;
