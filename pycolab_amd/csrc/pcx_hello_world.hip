@@ -33,10 +33,12 @@ struct Consts {
   uint32_t above[NS];
   uint32_t init[W_D];
   uint32_t sprite_off[NS], sprite_ch4[NS], drape_off, drape_ch4, bchar_off[NB], bchar_ch4[NB];
+  // owner codes (pcx_stream.h stream_codes; the CODES instances): a character's code is its layer plane (7 characters: one v_perm_b32 per plane)
+  uint32_t sprite_code[NS], drape_code4, code_chars[4];
 };
 
 struct Ptrs {
-  const uint32_t* tables;        // staged into LDS: backdrop4 [QW], bdmask [NB][QW]
+  const uint32_t* tables;        // staged into LDS: backdrop4 [QW], bdmask [NB][QW], backdrop codes [QW]
   const uint32_t* init_curtain;  // [FW]
   uint32_t* state;               // [NW][bpad]
   int32_t* track;                // [NS][bpad]
@@ -90,7 +92,9 @@ struct Bits {
 // PW (round 5): persistent workers, as in pcx_warehouse_step -- the workgroup stays on its CU, each of its waves draws units
 // of 64 environments, steps one and streams it alone, the next unit's state rows prefetched into its LDS inbox by LDS-DMA,
 // at most `work.lock` workers of a workgroup streaming at a time (pcx_stream.h).  Plain steps only.
-template <int R, int C, int NWAVES, bool EPI = false, bool UNOCC = false, bool PW = false>
+// CODES (round 6): the render phase is pcx_stream.h's owner-code loop -- the logic lane leaves a code byte per board cell (the
+// backdrop's code dwords with the rolling drape's bits merged in four at a time, the painted sprites as byte writes).  Plain steps.
+template <int R, int C, int NWAVES, bool EPI = false, bool UNOCC = false, bool PW = false, bool CODES = false>
 __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_hello_world_step(const Consts k, const Ptrs P, const StepArgs a,
                                                                       const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                       const crop::FusedCrops* fc) {
@@ -98,8 +102,11 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_hello_world_
   using B = Bits<R, C>;
   constexpr int cells = R * C, pitch = (cells + 3) & ~3, QW = pitch / 4, FW = B::FW, FWP = FW | 1;
   constexpr int L = NS + ND + NB;
-  constexpr int O_BD = 0, O_BDM = O_BD + QW, O_TAB_END = O_BDM + NB * QW;
-  constexpr int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + 2 * NS * WAVE;
+  constexpr int CP = ((QW + 1) / 2) | 1;  // nibble codes: two board dwords per LDS dword (7 characters)
+  constexpr int O_BD = 0, O_BDM = O_BD + QW, O_BDC = O_BDM + NB * QW, O_TAB_END = O_BDC + QW;
+  // (CODES: the per-environment code dwords take the place of the sprite descriptors)
+  constexpr int O_FLAT = O_TAB_END, O_SDESC = (O_FLAT + WAVE * FWP + 1) & ~1, O_SKIP = O_SDESC + (CODES ? WAVE * CP : 2 * NS * WAVE);
+  static_assert(!CODES || (!EPI && !UNOCC), "owner codes: plain steps");
   constexpr int O_WCORNER = O_SKIP + WAVE;  // fused croppers' window corners
   constexpr int O_FLATRAW = O_WCORNER + stream::WCORNER_WORDS, O_SDESCRAW = (O_FLATRAW + WAVE * FWP + 1) & ~1;  // UNOCC only
   static_assert(!PW || (NWAVES == 1 && !EPI && !UNOCC), "persistent workers: plain steps");
@@ -111,6 +118,7 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_hello_world_
   for (int i = threadIdx.x; i < O_TAB_END; i += (int)blockDim.x) lds[i] = P.tables[i];
   uint32_t* const flat = lds + O_FLAT + mine;
   uint2* const sdesc = reinterpret_cast<uint2*>(lds + O_SDESC + mine);
+  uint32_t* const codes = lds + O_SDESC + mine;  // (CODES)
   uint32_t* const skipv = lds + O_SKIP + mine;
   uint32_t* const wcorner = lds + O_WCORNER;
   uint32_t* const inbox = lds + O_WCORNER + mine;  // (PW only: behind the worker's skip flags)
@@ -275,7 +283,27 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_hello_world_
       for (int s = 0; s < NS; ++s) { cellv[s] = ((k.visible >> s) & 1) ? row[s] * C + col[s] : -1; above[s] = k.above[s]; }
       if constexpr (UNOCC)  // occlusion_in_layers=False: the layers are the raw masks (rendering.py:236-278)
         stream::snapshot_raw<NS, ND>(cellv, flat, FW, FWP, lane, lds + O_FLATRAW, reinterpret_cast<uint2*>(lds + O_SDESCRAW));
-      stream::resolve_sprites<NS, ND>(cellv, above, flat, FWP, lane, sdesc);
+      if constexpr (CODES) {
+        // rendering.py:98-179 as byte writes: the backdrop's codes with the drape's cells merged in, then every sprite nothing in front of it covers
+        uint32_t* const cd = codes + lane * CP;
+        const uint32_t* const bdc = lds + O_BDC;
+        auto code_dword = [&](int q) {  // board dword q: the backdrop's codes, the drape's where its bits are set
+          const uint32_t bits = (x[q >> 3] >> ((q & 7) * 4)) & 0xFu;
+          const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;  // bit i -> byte i
+          uint32_t hi8 = m01 << 8;
+          asm("" : "+v"(hi8));  // (keeps (x << 8) - x from becoming a quarter-rate multiply)
+          const uint32_t m = hi8 - m01;
+          return (bdc[q] & ~m) | (k.drape_code4 & m);
+        };
+#pragma unroll
+        for (int j = 0; j < (QW + 1) / 2; ++j) cd[j] = code_dword(2 * j) | (2 * j + 1 < QW ? code_dword(2 * j + 1) << 4 : 0u);
+        uint32_t scode[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) scode[s] = k.sprite_code[s];
+        stream::paint_sprites_nib<NS, ND>(cellv, above, flat, FWP, lane, reinterpret_cast<uint8_t*>(cd), scode);
+      } else {
+        stream::resolve_sprites<NS, ND>(cellv, above, flat, FWP, lane, sdesc);
+      }
     }
     skipv[lane] = skip;
   }
@@ -292,6 +320,9 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_hello_world_
 #pragma unroll
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   constexpr uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
+  stream::CodeMap<L> cmap;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cmap.chars[i] = k.code_chars[i];
   if constexpr (PW) {
     // the next unit is drawn and its state rows start travelling now, in front of this unit's plane stores
     const uint32_t next = wq.next(unit);
@@ -300,14 +331,21 @@ __global__ __launch_bounds__(PW ? 8 * WAVE : NWAVES* WAVE) void pcx_hello_world_
     if (!(a.debug & 2)) {
       const uint32_t sem = stream::lds_byte_address(lds + O_SEM);
       if (P.work.lock) stream::slot_acquire(sem, P.work.lock);
-      stream::stream_planes<NS, ND, NB, QW, 1, false, false, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
-                                                                    flat, sdesc, skipv, FWP, lane, 0, epi, env0, nullptr, 0, nullptr, nullptr, lds);
+      if constexpr (CODES)
+        stream::stream_codes<L, QW, 1, false, true>(cmap, out.planes + (size_t)env0 * env_stride, env_stride, codes, CP, skipv, lane, 0);
+      else
+        stream::stream_planes<NS, ND, NB, QW, 1, false, false, false>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
+                                                                      flat, sdesc, skipv, FWP, lane, 0, epi, env0, nullptr, 0, nullptr, nullptr, lds);
       if (P.work.lock) stream::slot_release(sem);
     }
     need_wait = any_skip || (a.debug & ~16) != 0 || QW * (1 + L) < 64;  // fewer than 64 plane stores behind the prefetch: wait for it
     if (need_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unit = next;
   } else {
+    if constexpr (CODES) {
+      stream::stream_codes<L, QW, NWAVES, true, true>(cmap, out.planes + (size_t)env0 * env_stride, env_stride, codes, CP, skipv, lane, wave);
+      break;
+    }
     if (!(fc && fc->only))
       stream::stream_planes<NS, ND, NB, QW, NWAVES, EPI, UNOCC>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                                  flat, sdesc, skipv, FWP, lane, wave, epi, env0, nullptr, 0, lds + O_FLATRAW,
@@ -351,8 +389,8 @@ class HelloWorldBackend : public Backend {
       return set_error(PCX_E_UNSUPPORTED, "hello_world backend: fused croppers need occluded layers");
     return fused_.set(fc, false, R_, C_);
   }
-  size_t base_lds_bytes() const {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
-    return ((size_t)lay_.QW * (1 + NB) + WAVE * lay_.FWP + 2 + 2 * NS * WAVE + WAVE + stream::WCORNER_WORDS +
+  size_t base_lds_bytes(bool codes = false) const {  // the kernel's own dynamic LDS (before padding / the channels-last exchange areas)
+    return ((size_t)lay_.QW * (2 + NB) + WAVE * lay_.FWP + 2 + (codes ? WAVE * lay_.CPN : 2 * NS * WAVE) + WAVE + stream::WCORNER_WORDS +
             (unoccluded_ ? WAVE * lay_.FWP + 2 + 2 * NS * WAVE : 0)) * 4;
   }
   stream::EpilogueArgs* epilogue_args() override { return &epi_; }
@@ -426,7 +464,7 @@ int HelloWorldBackend::init(const pcx_template& t, int64_t batch) {
   }
   k.drape_off = (uint32_t)(1 + layer_of(dd.ch)) * lay_.pitch;
   k.drape_ch4 = dd.ch * 0x01010101u;
-  std::vector<uint32_t> tab((size_t)lay_.QW * (1 + NB), 0);
+  std::vector<uint32_t> tab((size_t)lay_.QW * (2 + NB), 0);
   memcpy(tab.data(), t.backdrop, lay_.cells);
   int nb = 0;
   for (int i = 0; i < L_; ++i) {
@@ -442,6 +480,15 @@ int HelloWorldBackend::init(const pcx_template& t, int64_t batch) {
     ++nb;
   }
   if (nb != NB) return set_error(PCX_E_INVALID, "hello_world backend: inconsistent character set");
+  {  // owner codes (pcx_stream.h): L = 7 characters, a character's code is its layer plane; plane padding is selector 12 (zero everywhere)
+    static_assert(NS + ND + NB <= 8, "one v_perm_b32 per plane");
+    for (int s = 0; s < NS; ++s) k.sprite_code[s] = (uint32_t)layer_of(t.sprites[s].ch);
+    k.drape_code4 = (uint32_t)layer_of(dd.ch) * 0x01010101u;
+    memset(k.code_chars, 0, sizeof k.code_chars);
+    for (int i = 0; i < L_; ++i) k.code_chars[i >> 2] |= (uint32_t)t.chars[i] << (8 * (i & 3));
+    uint8_t* bdc = reinterpret_cast<uint8_t*>(tab.data() + (size_t)lay_.QW * (1 + NB));
+    for (int c = 0; c < lay_.pitch; ++c) bdc[c] = c < lay_.cells ? (uint8_t)layer_of(t.backdrop[c]) : (uint8_t)12;
+  }
   std::vector<uint32_t> initc(lay_.FW, 0);
   for (int c = 0; c < lay_.cells; ++c) if (dd.curtain[c]) initc[c >> 5] |= 1u << (c & 31);
   memset(k.init, 0, sizeof k.init);
@@ -488,6 +535,17 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
     if (want > lds) lds = want;
   }
   bool launched = false;
+  // (round 6) owner codes: plain steps -- no epilogue, no fused croppers, occluded layers; PCX_HW_CODES=0: the mask loop
+  bool codes = !epi_.out && !fused_.on && !unoccluded_;
+  if (const char* e = getenv("PCX_HW_CODES")) codes = codes && atoi(e) != 0;
+  if (codes) {
+    lds = base_lds_bytes(true);
+    if (!coop && waves_per_cu > 0) {
+      size_t want = ((size_t)(160 * 1024) / (size_t)waves_per_cu) & ~(size_t)255;
+      if (want > 64 * 1024) want = 64 * 1024;
+      if (want > lds) lds = want;
+    }
+  }
   // (round 5) persistent workers for plain steps, as in pcx_warehouse.hip (PCX_HW_PW=0: the round-2 shape)
   bool pw = !coop && !epi_.out && !fused_.on && !unoccluded_ && a.mode == 0 && !a.export_curtains && (a.debug & ~16) == 0;
   if (const char* e = getenv("PCX_HW_PW")) pw = pw && atoi(e) != 0;
@@ -497,7 +555,10 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
     // workgroups of several workers with streaming slots lose here (five workers, four slots: 0.2639 / 0.8121).
     // The alternatives are measured on the engine's own first launches (ShapeTuner, pcx_internal.h), this one first.
     struct Cand { int workers, per_cu, lock; };
-    static const Cand cands[ShapeTuner::NC] = {{1, 4, 0}, {2, 4, 1}, {2, 3, 1}, {5, 1, 4}};
+    static const Cand cands_m[ShapeTuner::NC] = {{1, 4, 0}, {2, 4, 1}, {2, 3, 1}, {5, 1, 4}};
+    // (round 6, the owner-code loop: one streaming wave per workgroup is enough -- profiles/r06_hello_world_codes_sweep.txt)
+    static const Cand cands_k[ShapeTuner::NC] = {{1, 4, 0}, {2, 2, 1}, {1, 3, 0}, {2, 3, 1}};
+    const Cand* const cands = codes ? cands_k : cands_m;
     const bool knobs = getenv("PCX_HW_WORKERS") || getenv("PCX_HW_PER_CU") || getenv("PCX_HW_LOCK") || getenv("PCX_HW_GRID") ||
                        (getenv("PCX_HW_TUNE") && atoi(getenv("PCX_HW_TUNE")) == 0);
     if (knobs) tuner_.off = true;
@@ -508,9 +569,9 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
     if (const char* e = getenv("PCX_HW_LOCK")) lock = atoi(e);
     int dynamic = groups >= (int64_t)num_cus_ * 24;
     if (const char* e = getenv("PCX_HW_DYNAMIC")) dynamic = atoi(e) != 0;
-    const size_t tab_words = (size_t)lay_.QW * (1 + NB);
+    const size_t tab_words = (size_t)lay_.QW * (2 + NB);
     const size_t o_sdesc = (tab_words + (size_t)WAVE * lay_.FWP + 1) & ~(size_t)1;
-    const size_t region = o_sdesc + 2 * NS * WAVE + WAVE - tab_words;  // flat, sdesc, skip: the kernel's O_WCORNER - O_FLAT
+    const size_t region = o_sdesc + (codes ? WAVE * lay_.CPN : 2 * NS * WAVE) + WAVE - tab_words;  // flat, sdesc / codes, skip: the kernel's O_WCORNER - O_FLAT
     const size_t w_words = (region + (size_t)(NW_ + 1) * WAVE + 1) & ~(size_t)1;
     size_t lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4;
     while (workers > 1 && lds_pw > 64 * 1024) { --workers; lds_pw = (tab_words + 2 + (size_t)workers * w_words) * 4; }
@@ -525,7 +586,8 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
     P.work.lock = lock;
 #define X(r, c)                                                                                                  \
   if (!launched && R_ == r && C_ == c) {                                                                         \
-    hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, false, false, true>), dim3((unsigned)wgs), dim3(workers * WAVE), lds_pw, s, k_, P, a, out, epi_, fused_.ptr()); \
+    if (codes) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, false, false, true, true>), dim3((unsigned)wgs), dim3(workers * WAVE), lds_pw, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, false, false, true>), dim3((unsigned)wgs), dim3(workers * WAVE), lds_pw, s, k_, P, a, out, epi_, fused_.ptr()); \
     launched = true;                                                                                             \
   }
     PCX_HW_SHAPES(X)
@@ -539,6 +601,8 @@ int HelloWorldBackend::launch(const StepArgs& a, const pcx_buffers& out, hipStre
     else if (unoccluded_) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, false, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());       \
     else if (epi_.out && coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
     else if (epi_.out) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());       \
+    else if (coop && codes) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4, false, false, false, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else if (codes) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1, false, false, false, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
     else if (coop) hipLaunchKernelGGL((pcx_hello_world_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
     else hipLaunchKernelGGL((pcx_hello_world_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());          \
     launched = true;                                                                                             \

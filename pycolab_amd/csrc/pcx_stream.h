@@ -197,6 +197,30 @@ __device__ __forceinline__ void paint_sprites(const int (&cell)[NS], const uint3
   }
 }
 
+// ... into nibble codes (stream_codes<..., NIB>): cell c of an environment is nibble (c >> 2) & 1 of byte (c >> 3) * 4 + (c & 3)
+template <int NS, int ND>
+__device__ __forceinline__ void paint_sprites_nib(const int (&cell)[NS], const uint32_t (&above)[NS], const uint32_t* flat, int FWP, int lane,
+                                                  uint8_t* cb, const uint32_t (&code)[NS]) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int c = cell[s];
+    bool shown = c >= 0;
+    const uint32_t ab = above[s];
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+      if (j != s && ((ab >> j) & 1) && cell[j] == c) shown = false;
+    const int cc = c >= 0 ? c : 0, wi = cc >> 5, sh = cc & 31;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+      if (((ab >> (NS + d)) & 1) && ((flat[(d * WAVE + lane) * FWP + wi] >> sh) & 1)) shown = false;
+    if (shown) {
+      uint8_t* const b = cb + ((cc >> 3) << 2) + (cc & 3);
+      const int nsh = ((cc >> 2) & 1) << 2;
+      *b = (uint8_t)((*b & ~(0xFu << nsh)) | (code[s] << nsh));
+    }
+  }
+}
+
 // Engine(..., occlusion_in_layers=False) (rendering.py:187-301 BaseUnoccludedObservationRenderer):
 // the board is painted as ever, the layers are the things' RAW masks -- a drape's whole curtain, a
 // visible sprite's own cell, the backdrop character wherever the backdrop has it.  Call before
@@ -590,10 +614,13 @@ struct CodeMap {
 template <int L>
 __host__ __device__ constexpr uint32_t code_byte(int i) { return L <= 8 ? (uint32_t)i : i < 8 ? 0xC0u | (uint32_t)i : 0x0Cu | ((uint32_t)(i - 8) << 4); }
 
-template <int L, int QW, int NWAVES, bool DRAIN = true>
+// NIB (L <= 8 only): the codes are nibbles -- LDS dword j of an environment holds board dwords 2 j (low nibbles) and 2 j + 1
+// (high nibbles), CP counts those -- half the LDS per unit for one shift and one mask per iteration (pcx_scrolly_maze_step's layout).
+template <int L, int QW, int NWAVES, bool DRAIN = true, bool NIB = false>
 __device__ __forceinline__ void stream_codes(const CodeMap<L>& cm, uint8_t* group_base, uint32_t env_stride, const uint32_t* codes,
                                              int CP, const uint32_t* skip, int lane, int wave, int qw_rt = 0) {
   static_assert(L >= 1 && L <= 16, "owner codes: at most sixteen characters");
+  static_assert(!NIB || L <= 8, "nibble codes: at most eight characters");
   const uint32_t QWv = QW ? (uint32_t)QW : (uint32_t)qw_rt;
   uint8_t* pb[1 + L];
   pb[0] = uniform_ptr(group_base);
@@ -607,15 +634,18 @@ __device__ __forceinline__ void stream_codes(const CodeMap<L>& cm, uint8_t* grou
   const uint32_t DE = ADV / QWv, DQ = ADV - DE * QWv;
   const uint32_t f0 = (uint32_t)(wave * WAVE + lane);
   uint32_t e = f0 / QWv, q = f0 - e * QWv;  // once
-  uint32_t voff = e * env_stride + 4u * q, ci = e * (uint32_t)CP + q;
-  const uint32_t dvoff = DE * env_stride + 4u * DQ, dci = DE * (uint32_t)CP + DQ;
-  const uint32_t wrap_voff = env_stride - 4u * QWv, wrap_ci = (uint32_t)CP - QWv;
-  const uint32_t ci_last = (uint32_t)(WAVE - 1) * (uint32_t)CP + QWv - 1u;  // (the prefetch of the iteration past the end reads here)
-  uint32_t code_pf = codes[ci];
+  // ci: the LDS word of (e, q) -- e * CP + q, or counted in board dwords with the environment's pitch doubled (NIB: word ci >> 1)
+  constexpr uint32_t CS = NIB ? 2u : 1u;
+  uint32_t voff = e * env_stride + 4u * q, ci = e * (uint32_t)CP * CS + q;
+  const uint32_t dvoff = DE * env_stride + 4u * DQ, dci = DE * (uint32_t)CP * CS + DQ;
+  const uint32_t wrap_voff = env_stride - 4u * QWv, wrap_ci = (uint32_t)CP * CS - QWv;
+  const uint32_t ci_last = (uint32_t)(WAVE - 1) * (uint32_t)CP * CS + QWv - 1u;  // (the prefetch of the iteration past the end reads here)
+  uint32_t code_pf = codes[NIB ? ci >> 1 : ci];
+  uint32_t nib_pf = NIB ? (ci & 1u) << 2 : 0u;
   constexpr bool GUARD = NWAVES > 1 || L > 11;  // (the bare store only where every plane base stays in SGPRs)
 #pragma unroll 1
   for (int it = wave; it < (int)QWv; it += NWAVES) {
-    const uint32_t e_now = e, voff_now = voff, code = code_pf;
+    const uint32_t e_now = e, voff_now = voff, code = NIB ? (code_pf >> nib_pf) & 0x0F0F0F0Fu : code_pf;
     q += DQ; e += DE; voff += dvoff; ci += dci;
     {
       const bool wrap = q >= QWv;
@@ -624,7 +654,11 @@ __device__ __forceinline__ void stream_codes(const CodeMap<L>& cm, uint8_t* grou
       voff = wrap ? voff + wrap_voff : voff;
       ci = wrap ? ci + wrap_ci : ci;
     }
-    code_pf = codes[ci < ci_last ? ci : ci_last];
+    {
+      const uint32_t cn = ci < ci_last ? ci : ci_last;
+      code_pf = codes[NIB ? cn >> 1 : cn];
+      if constexpr (NIB) nib_pf = (cn & 1u) << 2;
+    }
     if (any_skip && skip[e_now] != 0) continue;
     if constexpr (L <= 8) {
       saddr_store_dword<GUARD>(voff_now, __builtin_amdgcn_perm(chA_hi, chA_lo, code), pb[0]);
@@ -1051,7 +1085,7 @@ struct FusedCropsHolder {
 
 // Constants of the streaming phase every backend derives the same way.
 struct Layout {
-  int cells = 0, pitch = 0, QW = 0, FW = 0, FWP = 0, CP = 0;
+  int cells = 0, pitch = 0, QW = 0, FW = 0, FWP = 0, CP = 0, CPN = 0;
   void set(int rows, int cols) {
     cells = rows * cols;
     pitch = (cells + 3) & ~3;
@@ -1059,6 +1093,7 @@ struct Layout {
     FW = (cells + 31) / 32;
     FWP = FW | 1;
     CP = QW | 1;  // owner codes: dwords per environment, odd (the logic phase reads one word of 64 environments, the streaming loop consecutive words)
+    CPN = ((QW + 1) / 2) | 1;  // ... as nibbles: two board dwords per LDS dword
   }
 };
 
