@@ -227,10 +227,10 @@ def measure_config(game, level, batch, steps, warmup, device, repeats=3, raises=
     os.environ['PCX_FORCE_GENERIC'] = '1'
   try:
     eng = Engine.from_template(template, batch=batch, device=device, auto_reset=True, seed=0x5EED)
+    eng.its_showtime()  # (the native engine -- and with it the kernel -- is chosen here)
   finally:
     if forced:
       del os.environ['PCX_FORCE_GENERIC']
-  eng.its_showtime()
   g = torch.Generator(device='cuda')
   g.manual_seed(0x5EED)
   if cardinal_fields:

@@ -304,11 +304,14 @@ def test_random_levels_match_oracle_through_the_table_driven_kernel(maker, seed,
 UNWALLED_KERNELS = {}  # maker name -> kernels seen (the last test of the family asserts the hand-written ones were among them)
 
 
+UNWALLED_MAKERS = [random_open_warehouse, random_open_warehouse_scenery, random_open_better_scrolly, random_open_scrolly_maze]
+# every level through the kernel the engine picks; through both builds of pcx_generic_step the first three of every maker
+UNWALLED_CASES = [(m, s, 'default') for m in UNWALLED_MAKERS for s in range(6)] + \
+                 [(m, s, r) for m in UNWALLED_MAKERS[:3] for s in range(3) for r in ('table-driven', 'specialised')]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize('route', ['default', 'table-driven', 'specialised'])
-@pytest.mark.parametrize('maker', [random_open_warehouse, random_open_warehouse_scenery, random_open_better_scrolly, random_open_scrolly_maze],
-                         ids=lambda m: m.__name__)
-@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('maker,seed,route', UNWALLED_CASES, ids=lambda x: getattr(x, '__name__', str(x)))
 def test_random_unwalled_levels_match_oracle(maker, seed, route, monkeypatch):
   """The GPU twin of test_oracle_matches_the_live_reference_on_a_random_unwalled_level (same makers, same level seeds): the
   kernel the engine picks by itself (`default`: pcx_warehouse_step's run-time-shape instance for the warehouses with the
@@ -316,9 +319,7 @@ def test_random_unwalled_levels_match_oracle(maker, seed, route, monkeypatch):
   builds of pcx_generic_step, against the oracle: the error bit comes up in the same frame with the same kind -- the frame
   the reference raises IndexError at -- and until then every output is equal, pushes through index -1, patrollers that look
   around (0, 0) from outside the board and off-board boxes on the goal at (0, 0) included."""
-  if route != 'default':
-    if maker is random_open_scrolly_maze:
-      pytest.skip('scrolly_maze has no table-driven program: pcx_scrolly_maze_step steps every level of it')
+  if route != 'default':  # (scrolly_maze has no table-driven program: pcx_scrolly_maze_step steps every level of it)
     helpers.force_generic(monkeypatch, route)
   t = GameTemplate.from_engine(maker(np.random.RandomState(7300 + seed)))
   B, T, n_actions = 64 * 3 + 9, 100, int(t.n_actions)
