@@ -66,7 +66,8 @@ struct Consts {
 struct Ptrs {
   const uint32_t* tables;  // everything staged into LDS, in l_* order
   int32_t n_table_words;
-  uint32_t* state;         // [NW][bpad]
+  uint32_t* state;         // word w of environment e at state[(e / 64) * state_unit + w * state_row + e % 64]:
+  int64_t state_unit, state_row;  // unit-major (round 6: state_unit = NW * 64, state_row = 64 -- a unit's NW rows are ONE contiguous piece) or [NW][bpad] (64, bpad)
   int32_t* track;          // [NS][bpad]
   uint32_t* curtains;      // [ND][FW][bpad] raw curtain bits (export_curtains)
   int64_t batch, bpad;
@@ -1076,10 +1077,10 @@ __device__ __forceinline__ void render_windows(const Consts& k, const L& l, cons
 // registers has four loads in flight).  `off`: word offset of the worker's copy of the per-lane arrays (0: the one-group layout).
 // The issuing wave waits on vmcnt itself.
 __device__ __forceinline__ void dma_state_rows(const Consts& k, const Ptrs& P, const StepArgs& a, uint32_t* lds, int off, int64_t unit, int lane) {
-    const uint32_t* const sb = stream::uniform_words(P.state + unit * WAVE);
+    const uint32_t* const sb = stream::uniform_words(P.state + unit * P.state_unit);
     const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)stream::lds_byte_address(lds));
     const uint32_t vo = 4u * (uint32_t)lane;
-    const int64_t bpw = P.bpad;
+    const int64_t bpw = P.state_row;
     auto row = [&](int word, int lds_word) { stream::lds_dma_row(sb + (int64_t)word * bpw, vo, l0 + 4u * (uint32_t)(lds_word + off)); };
     for (int w = 0; w < W_SPRITES; ++w) row(w, k.l_inbox + w * WAVE);
     for (int s = 0; s < k.NS; ++s) row(W_SPRITES + s, k.l_pos + s * WAVE);
@@ -1137,8 +1138,8 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
   const unsigned long long t_start = timing ? __builtin_readcyclecounter() : 0ull;
   unsigned long long c_sec[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c_prog[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool live = logic_wave && env < P.batch;
-  const int64_t bp = P.bpad;
-  uint32_t* st = P.state + env;
+  const int64_t bp = P.bpad, srow = P.state_row;
+  uint32_t* st = P.state + (env0 >> 6) * P.state_unit + lane;  // word w at st[w * srow]
   const uint32_t* const ib = ib_rows + lane;  // row r at [r * WAVE]
   uint32_t flags = 0;
   bool skip = !live, do_reset = false;
@@ -1271,28 +1272,28 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
         const uint32_t t = l.zord[z * WAVE + lane] & 0xFu;
         if (z < 8) z0 |= t << (4 * z); else z1 |= t << (4 * (z - 8));
       }
-      st[k.w_z * bp] = z0;
-      st[(k.w_z + 1) * bp] = z1;
+      st[k.w_z * srow] = z0;
+      st[(k.w_z + 1) * srow] = z1;
     }
     flags = (x.game_over ? F_OVER : 0u) | ((x.err & 7u) << F_ERR_SHIFT) | ((uint32_t)((dxv + 1) & 0xFF) << 8);
-    st[W_RNG * bp] = draws;
-    if (k.w_next >= 0) st[k.w_next * bp] = (uint32_t)x.next;
-    st[W_FRAME * bp] = (uint32_t)x.frame;
-    st[W_FLAGS * bp] = flags;
-    for (int j = 0; j < 4; ++j) st[(W_V0 + j) * bp] = (uint32_t)x.v[j];
-    for (int s = 0; s < k.NS; ++s) st[(W_SPRITES + s) * bp] = l.pos[s * WAVE + lane];
+    st[W_RNG * srow] = draws;
+    if (k.w_next >= 0) st[k.w_next * srow] = (uint32_t)x.next;
+    st[W_FRAME * srow] = (uint32_t)x.frame;
+    st[W_FLAGS * srow] = flags;
+    for (int j = 0; j < 4; ++j) st[(W_V0 + j) * srow] = (uint32_t)x.v[j];
+    for (int s = 0; s < k.NS; ++s) st[(W_SPRITES + s) * srow] = l.pos[s * WAVE + lane];
     for (int w = 0; w < (k.NS + 3) / 4; ++w) {
       uint32_t f = 0;
       for (int j = 0; j < 4 && 4 * w + j < k.NS; ++j) f |= (l.flg[(4 * w + j) * WAVE + lane] & 0xFF) << (8 * j);
-      st[(k.w_sflags + w) * bp] = f;
+      st[(k.w_sflags + w) * srow] = f;
     }
-    for (int i2 = 0; i2 < ndw; ++i2) st[(k.w_drapes + i2) * bp] = l.cur[i2 * WAVE + lane];
+    for (int i2 = 0; i2 < ndw; ++i2) st[(k.w_drapes + i2) * srow] = l.cur[i2 * WAVE + lane];
     if (k.has_scroll) {
-      st[k.w_scroll * bp] = x.registered;
-      for (int d = 0; d < k.ND; ++d) st[(k.w_scroll + 1 + d) * bp] = l.corner[d * WAVE + lane];
+      st[k.w_scroll * srow] = x.registered;
+      for (int d = 0; d < k.ND; ++d) st[(k.w_scroll + 1 + d) * srow] = l.corner[d * WAVE + lane];
       for (int s = 0; s < k.NS; ++s) {
-        st[(k.w_scroll + 1 + k.ND + 2 * s) * bp] = l.pmask[s * WAVE + lane];
-        st[(k.w_scroll + 2 + k.ND + 2 * s) * bp] = l.pframe[s * WAVE + lane];
+        st[(k.w_scroll + 1 + k.ND + 2 * s) * srow] = l.pmask[s * WAVE + lane];
+        st[(k.w_scroll + 2 + k.ND + 2 * s) * srow] = l.pframe[s * WAVE + lane];
       }
     }
     out.reward[env] = x.reward;
