@@ -306,7 +306,8 @@ UNWALLED_KERNELS = {}  # maker name -> kernels seen (the last test of the family
 
 UNWALLED_MAKERS = [random_open_warehouse, random_open_warehouse_scenery, random_open_better_scrolly, random_open_scrolly_maze]
 # every level through the kernel the engine picks; through both builds of pcx_generic_step the first three of every maker
-UNWALLED_CASES = [(m, s, 'default') for m in UNWALLED_MAKERS for s in range(6)] + \
+# (an unwalled scrolly_maze world raises for every environment at once or for none: level seed 7 is one that raises)
+UNWALLED_CASES = [(m, s, 'default') for m in UNWALLED_MAKERS for s in ((0, 1, 2, 3, 4, 7) if m is random_open_scrolly_maze else range(6))] + \
                  [(m, s, r) for m in UNWALLED_MAKERS[:3] for s in range(3) for r in ('table-driven', 'specialised')]
 
 
