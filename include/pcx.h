@@ -334,7 +334,8 @@ const char* pcx_engine_kernel_name(const pcx_engine* e);
  * mean to measure is the one that ran; no reference counterpart).  pcx_scrolly_maze_step: 0 one single-wave
  * workgroup per group of 64 environments, 3 persistent workgroups of W workers (waves) that draw work units, with the
  * next unit's state words prefetched into LDS and a streaming semaphore (the default from 65,536 environments up), 5 the
- * same with the shipped level's constants compiled in (pcx_debug_scrolly_consts), 10 cooperative (several waves per
+ * same with the shipped level's constants compiled in (pcx_debug_scrolly_consts), 7 the same on the instance compiled for
+ * the engine's own level at run time (pcx_scrolly_maze_specialise_check), 10 cooperative (several waves per
  * group), 12 the cooperative shape walking several steps per launch, 13 the persistent workers walking several steps per
  * launch (every worker keeps its units from step to step), 20 shape-generic instance (1, 2, 4 and 11 were
  * launch shapes of rounds 1-4, measured slower and removed in round 5); pcx_generic_step: 30 the
@@ -354,6 +355,14 @@ int32_t pcx_engine_tuner_done(const pcx_engine* e);
  * cache -- without creating an engine and WITHOUT a device: what `build` checks and the CPU tests call.  code_bytes: the
  * size of the code object; log: the compiler's words when it fails (PCX_E_UNSUPPORTED).  No reference counterpart. */
 int pcx_generic_specialise_check(const pcx_template* t, char* log, int64_t log_bytes, int64_t* code_bytes);
+/* The same for the kernel pcx_scrolly_maze_step, round 6: a scrolly_maze level of one's own on the example's 10x30 board with its
+ * 'abcP' cast (a new entry of examples/scrolly_maze.py MAZES_ART, scrolly_maze.py:212-242) gets, at pcx_engine_create, the two
+ * instances the shipped levels have in the library -- the persistent owner-code one and the cooperative small-batch one with
+ * the level's constants compiled in (engines of PCX_SM_JIT_MIN = 4,096 environments and more; PCX_SM_JIT=0 / 1 never /
+ * always; the same cache).  This entry plans the template and compiles that build without an engine and WITHOUT a device.
+ * PCX_E_UNSUPPORTED with an empty log: a template of another shape (it keeps the shape-generic instance).  No reference
+ * counterpart. */
+int pcx_scrolly_maze_specialise_check(const pcx_template* t, char* log, int64_t log_bytes, int64_t* code_bytes);
 /* Build-time aid (no reference counterpart): pcx_scrolly_maze_step exists once more per shipped level with the constants of
  * that level (examples/scrolly_maze.py, MAZES_ART[0..2]) compiled in -- csrc/pcx_sm_shipped.h, generated by
  * tools/gen_sm_shipped.py from what this entry answers.  It plans `t` for that kernel WITHOUT a device and copies the

@@ -58,6 +58,11 @@ SPECS = {
     'scrolly_custom_E': (105, 30, 24, (10, 24), 'cbP', 'c#Pb@'),
     'scrolly_custom_F': (106, 16, 40, (8, 20), 'abcdP', 'dcba@#P'),
     'scrolly_custom_G': (107, 18, 30, (9, 16), 'abcdeP', 'Pe@d#cba'),
+    # round 6: the EXAMPLE'S OWN shape -- its 10x30 board, 'abcP' cast and z-order (scrolly_maze.py:212-242) -- around a maze
+    # the reference does not ship: what a new entry of MAZES_ART looks like to the library.  Such a level takes the
+    # instances pcx_scrolly_maze_step builds for it at run time (persistent workers and the cooperative shape with the
+    # level's constants compiled in, csrc/pcx_scrolly_maze.hip jit), where the shipped levels take the ones in libpcx.so.
+    'scrolly_custom_H': (108, 26, 64, (10, 30), 'abcP', 'abc@#P'),
 }
 NAMES = sorted(SPECS)
 # also recorded with Engine(occlusion_in_layers=False): one, two and three sprites

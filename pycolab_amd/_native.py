@@ -157,6 +157,7 @@ SYMBOLS = [
     ('pcx_engine_launch_shape', c_i32, [_VP]),
     ('pcx_engine_tuner_done', c_i32, [_VP]),
     ('pcx_generic_specialise_check', c_i32, [ctypes.POINTER(Template), ctypes.c_char_p, c_i64, ctypes.POINTER(c_i64)]),
+    ('pcx_scrolly_maze_specialise_check', c_i32, [ctypes.POINTER(Template), ctypes.c_char_p, c_i64, ctypes.POINTER(c_i64)]),
     ('pcx_engine_debug_counters', c_i32, [_VP, ctypes.POINTER(c_u32), c_i64]),
     ('pcx_debug_scrolly_consts', c_i64, [ctypes.POINTER(Template), c_i32, ctypes.POINTER(c_u32), c_i64]),
     ('pcx_last_error', ctypes.c_char_p, []),

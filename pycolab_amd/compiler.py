@@ -247,17 +247,25 @@ class GameTemplate(object):
   def prebuild(self):
     """Compile (or find in the cache) the build of `pcx_generic_step` specialised for this template -- what an engine
     of 4,096 environments or more would do at `its_showtime()` (1-3 s once per template; include/pcx.h
-    pcx_generic_specialise_check, csrc/pcx_generic.hip).  Needs no GPU: a deployment can fill `$PCX_JIT_CACHE` at
+    pcx_generic_specialise_check, csrc/pcx_generic.hip) -- or, for a scrolly_maze level of one's own on the example's 10x30
+    board, the two instances of `pcx_scrolly_maze_step` with the level's constants compiled in (~25 s once per level).  Needs no GPU: a deployment can fill `$PCX_JIT_CACHE` at
     build time, or rank 0 for the others.  Returns the code object's size in bytes; raises `NotImplementedError` for
     templates only the hand-written kernels step (scrolly_maze's programs) and `RuntimeError` with the compiler's
     words if the build fails."""
     ct, _keep = self.to_ctypes()
     log, size = ctypes.create_string_buffer(1 << 16), N.c_i64(0)
     rc = N.lib().pcx_generic_specialise_check(ctypes.byref(ct), log, len(log), ctypes.byref(size))
+    kernel = 'pcx_generic_step'
     if rc == N.E_UNSUPPORTED and not log.value:
-      raise NotImplementedError(N.lib().pcx_last_error().decode())
+      # not a template of the table-driven kernel: a scrolly_maze level of one's own on the example's board gets the
+      # run-time instances of pcx_scrolly_maze_step (round 6: include/pcx.h pcx_scrolly_maze_specialise_check)
+      why = N.lib().pcx_last_error().decode()
+      rc = N.lib().pcx_scrolly_maze_specialise_check(ctypes.byref(ct), log, len(log), ctypes.byref(size))
+      kernel = 'pcx_scrolly_maze_step'
+      if rc == N.E_UNSUPPORTED and not log.value:
+        raise NotImplementedError(why + '; ' + N.lib().pcx_last_error().decode())
     if rc != 0:
-      raise RuntimeError('no specialised build of pcx_generic_step: ' + (log.value.decode() or N.lib().pcx_last_error().decode()))
+      raise RuntimeError('no specialised build of %s: ' % kernel + (log.value.decode() or N.lib().pcx_last_error().decode()))
     return int(size.value)
 
   # -- ctypes image --------------------------------------------------------------

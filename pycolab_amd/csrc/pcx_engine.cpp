@@ -505,6 +505,10 @@ int pcx_generic_specialise_check(const pcx_template* t, char* log, int64_t log_b
   if (!t) return set_error(PCX_E_INVALID, "pcx_generic_specialise_check: null template");
   return pcx::generic_specialise_check(*t, log, log_bytes, code_bytes);
 }
+int pcx_scrolly_maze_specialise_check(const pcx_template* t, char* log, int64_t log_bytes, int64_t* code_bytes) {
+  if (!t) return set_error(PCX_E_INVALID, "pcx_scrolly_maze_specialise_check: null template");
+  return pcx::scrolly_maze_specialise_check(*t, log, log_bytes, code_bytes);
+}
 int64_t pcx_debug_scrolly_consts(const pcx_template* t, int32_t unit, uint32_t* words, int64_t cap) {
   if (!t || cap < 0) return set_error(PCX_E_INVALID, "pcx_debug_scrolly_consts: bad arguments");
   return pcx::scrolly_maze_consts(*t, unit, words, cap);

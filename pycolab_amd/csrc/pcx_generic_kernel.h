@@ -60,6 +60,8 @@ struct Consts {
   int32_t l_wcorner;              // fused croppers: [MAX_FUSED_CROPPERS][lane] window corners (pcx_stream.h WCORNER_NONE)
   int32_t l_inbox;                // where the group's scalar state words land by LDS-DMA: [IB_ROWS + (NS + 3) / 4][lane], over what the render phase reads later
   int32_t l_bdcode;               // owner codes (pcx_stream.h stream_codes): the backdrop's code dwords [QW], a staged table (-1: more than 16 characters)
+  int32_t l_codes;                // pcx_generic_step rendering from owner codes (round 6): the group's code dwords [64][QW | 1], laid over the per-lane
+                                  // arrays that are dead by the time the logic phase writes them (-1: not laid out -- unoccluded layers, more than 16 characters)
   uint8_t chars[PCX_MAX_CHARS];   // character of layer plane 1 + i
 };
 
@@ -80,6 +82,7 @@ struct Ptrs {
   float* feat;
   int32_t feat_depth, feat_skip;
   uint8_t feat_ch[PCX_POST_MAX_DEPTH];
+  int32_t use_codes;  // pcx_generic_step: this launch renders from owner codes (Consts::l_codes) instead of masks -- plain steps without fused croppers / epilogue
 };
 
 // A build of this file for ONE template (round 4): PCX_GENERIC_SPEC names a header that defines `static constexpr
@@ -94,6 +97,54 @@ namespace spec {
 #define PCX_SPEC_UNROLL _Pragma("unroll")
 #else
 #define PCX_SPEC_UNROLL
+#endif
+// Round 6, the specialised build only.  Its logic phase is a chain of LDS round trips (profiles/r06_generic.md), so:
+//  * PCX_SREGS: every sprite's position word, flag byte and snapshot cell live in REGISTERS (arrays indexed by compile-time
+//    constants once the loops over the sprites are unrolled; an index that is a lane's own goes through a select chain) --
+//    the LDS columns l.pos only receive the state rows (LDS-DMA) and l.flg / l.snap are not touched at all;
+//  * PCX_PROBE_UNROLL: the probes of one MazeWalker move (target + two flanks; the eight neighbours of an egocentric walker)
+//    are unrolled, so that their LDS reads are in flight together instead of one probe after the other (the table-driven
+//    build keeps ONE copy of the probe walked by a loop: it is bound by instruction issue, not by latency).
+// Measured (profiles/r06_generic.md): registers -5 % on the launch, -12 % on its logic phase with up to eight sprites, a loss with
+// the ten of the marauders' cast (their programs index sprites by a lane's own values: select chains of ten) -- hence the bound,
+// PCX_SPEC_NS being the template's sprite count as the constants' header states it (GenericBackend::sregs_layout decides the
+// same way); the probes side by side LOSE 5-10 % everywhere (three probes' worth of work for a cardinal move), so that one is
+// opt-in (PCX_GENERIC_SPEC_DEFS=-DPCX_X_PROBE_UNROLL).
+#if defined(PCX_GENERIC_SPEC) && !defined(PCX_X_NO_SPRITE_REGS) && defined(PCX_SPEC_NS) && PCX_SPEC_NS <= 8
+#define PCX_SREGS 1
+#endif
+#if defined(PCX_GENERIC_SPEC) && defined(PCX_X_PROBE_UNROLL)
+#define PCX_PROBE_UNROLL _Pragma("unroll")
+#else
+#define PCX_PROBE_UNROLL _Pragma("unroll 1")
+#endif
+#ifdef PCX_GENERIC_SPEC
+// N values that must end up in registers: a recursive struct of scalars, read and written through select chains -- no array,
+// no loop, nothing but constant member offsets from the first optimisation pass on.  (An array indexed in `#pragma unroll`
+// loops was tried first: the loops are unrolled after the pass that splits aggregates has given up on the whole Ctx, which
+// then lives in scratch -- 470 bytes of it.)
+template <typename T, int N>
+struct RegList {
+  T head;
+  RegList<T, N - 1> tail;
+};
+template <typename T>
+struct RegList<T, 1> {
+  T head;
+};
+template <typename T, int N>
+__device__ __forceinline__ T reg_get(const RegList<T, N>& r, int s) {
+  if constexpr (N == 1) return r.head;
+  else return s == 0 ? r.head : reg_get(r.tail, s - 1);
+}
+template <typename T, int N>
+__device__ __forceinline__ void reg_put(RegList<T, N>& r, int s, T v) {
+  r.head = s == 0 ? v : r.head;
+  if constexpr (N > 1) reg_put(r.tail, s - 1, v);
+}
+#endif
+#ifdef PCX_SREGS
+constexpr int SREG_N = spec::K.NS > 0 ? spec::K.NS : 1;
 #endif
 
 struct L {
@@ -146,7 +197,54 @@ struct Ctx {
   int mv_dr, mv_dc, mv_post;  // mv_post: 0 no move, 1 move, 2 move + BS patroller's catch check
   int next;                   // the_plot.next_chapter as the episode's entities left it (PCX_CHAPTER_UNSET: untouched)
   uint64_t rng_seed;          // Ptrs::seed
+#ifdef PCX_SREGS
+  mutable RegList<uint32_t, SREG_N> rpos, rflg;  // sprite s: packed virtual position; flag byte (visible, prior, program bits)
+  mutable RegList<int32_t, SREG_N> rsnap;        // the cell the last repaint painted it at (-1: not painted)
+#endif
 };
+// sprite state: per-lane LDS columns, or (PCX_SREGS) registers
+__device__ __forceinline__ uint32_t spos(const Ctx& x, int s) {
+#ifdef PCX_SREGS
+  return reg_get(x.rpos, s);
+#else
+  return x.l.pos[s * WAVE + x.lane];
+#endif
+}
+__device__ __forceinline__ void spos_set(const Ctx& x, int s, uint32_t v) {
+#ifdef PCX_SREGS
+  reg_put(x.rpos, s, v);
+#else
+  x.l.pos[s * WAVE + x.lane] = v;
+#endif
+}
+__device__ __forceinline__ uint32_t sflg(const Ctx& x, int s) {
+#ifdef PCX_SREGS
+  return reg_get(x.rflg, s);
+#else
+  return x.l.flg[s * WAVE + x.lane];
+#endif
+}
+__device__ __forceinline__ void sflg_set(const Ctx& x, int s, uint32_t v) {
+#ifdef PCX_SREGS
+  reg_put(x.rflg, s, v);
+#else
+  x.l.flg[s * WAVE + x.lane] = v;
+#endif
+}
+__device__ __forceinline__ int ssnap(const Ctx& x, int s) {
+#ifdef PCX_SREGS
+  return reg_get(x.rsnap, s);
+#else
+  return x.l.snap[s * WAVE + x.lane];
+#endif
+}
+__device__ __forceinline__ void ssnap_set(const Ctx& x, int s, int v) {
+#ifdef PCX_SREGS
+  reg_put(x.rsnap, s, (int32_t)v);
+#else
+  x.l.snap[s * WAVE + x.lane] = v;
+#endif
+}
 
 __device__ __forceinline__ bool on_board(const Consts& k, int r, int c) {
   return (unsigned)r < (unsigned)k.R && (unsigned)c < (unsigned)k.C;
@@ -185,16 +283,16 @@ __device__ __forceinline__ void derive_above(const Ctx& x) {  // masks from the 
 
 // ---- sprite state in per-lane LDS columns ---------------------------------
 __device__ __forceinline__ void sprite_get(const Ctx& x, int s, int& vr, int& vc, int& vis, int& prior) {
-  uint32_t p = x.l.pos[s * WAVE + x.lane], f = x.l.flg[s * WAVE + x.lane];
+  uint32_t p = spos(x, s), f = sflg(x, s);
   vr = pos_r(p); vc = pos_c(p); vis = f & 1; prior = (f >> 1) & 1;
 }
 __device__ __forceinline__ void sprite_put(const Ctx& x, int s, int vr, int vc, int vis, int prior) {
-  x.l.pos[s * WAVE + x.lane] = pack_pos(vr, vc);
-  x.l.flg[s * WAVE + x.lane] = (x.l.flg[s * WAVE + x.lane] & ~3u) | (uint32_t)vis | ((uint32_t)prior << 1);
+  spos_set(x, s, pack_pos(vr, vc));
+  sflg_set(x, s, (sflg(x, s) & ~3u) | (uint32_t)vis | ((uint32_t)prior << 1));
 }
 // Sprite.position (true position): virtual if on board, else (0, 0) for walkers
 __device__ __forceinline__ void sprite_true(const Ctx& x, int s, int& r, int& c) {
-  uint32_t p = x.l.pos[s * WAVE + x.lane];
+  uint32_t p = spos(x, s);
   r = pos_r(p); c = pos_c(p);
   if (!on_board(x.k, r, c)) { r = 0; c = 0; }
 }
@@ -235,7 +333,8 @@ __device__ __forceinline__ void row_put(const Ctx& x, uint32_t* base, int d, int
 
 // engine.py:735 repaint == remember what every probe of the next group sees
 __device__ __forceinline__ void snapshot(const Ctx& x) {
-  for (int s = 0; s < x.k.NS; ++s) x.l.snap[s * WAVE + x.lane] = sprite_cell(x, s);
+  PCX_SPEC_UNROLL
+  for (int s = 0; s < x.k.NS; ++s) ssnap_set(x, s, sprite_cell(x, s));
   const int n = x.k.ND * x.k.R * x.k.RW;
   for (int i0 = 0; i0 < n; i0 += 4) {  // four LDS reads in flight
     uint32_t v[4];
@@ -253,9 +352,13 @@ __device__ __forceinline__ void snapshot(const Ctx& x) {
 __device__ __forceinline__ uint32_t present_at(const Ctx& x, int r, int c) {
   const int cell = r * x.k.C + c, NS = x.k.NS, ND = x.k.ND;
   uint32_t m = 0;
+#ifdef PCX_SREGS
+#pragma unroll
+#else
 #pragma unroll 2
+#endif
   for (int s = 0; s < NS; ++s) {
-    const int at = x.l.snap[s * WAVE + x.lane];
+    const int at = ssnap(x, s);
     const uint32_t bit = 1u << __builtin_amdgcn_readfirstlane((int)x.l.s2t[s]);
     m |= at == cell ? bit : 0u;
   }
@@ -309,7 +412,7 @@ __device__ __forceinline__ uint64_t drape_layer_row(const Ctx& x, int thing, int
     if (tfield(x, u, T_KIND) == 1) {
       bits &= ~row_get(x, x.l.snapd, idx, r);
     } else {
-      const int cell = x.l.snap[idx * WAVE + x.lane];
+      const int cell = ssnap(x, (int)idx);
       if (cell >= lo && cell < hi) bits &= ~(1ull << (cell - lo));
     }
   }
@@ -340,6 +443,12 @@ __device__ __forceinline__ bool blocked_at(Ctx& x, int thing, int vr, int vc, in
 // two flanks (sprites.py:539-543: blocked by its own cell, or by both flanks).
 __device__ __forceinline__ bool check_motion(Ctx& x, int thing, int vr, int vc, int dr, int dc) {
   if (dr == 0 && dc == 0) return false;
+#if defined(PCX_GENERIC_SPEC) && defined(PCX_X_PROBE_UNROLL)
+  // (opt-in, measured slower) the target cell and both flanks side by side, their LDS reads in flight together --
+  // a probe writes nothing, and the flanks only count for a diagonal
+  const bool b0 = blocked_at(x, thing, vr, vc, dr, dc), b1 = blocked_at(x, thing, vr, vc, dr, 0), b2 = blocked_at(x, thing, vr, vc, 0, dc);
+  return b0 || (dr != 0 && dc != 0 && b1 && b2);
+#else
   const int n = (dr != 0 && dc != 0) ? 3 : 1;
   bool hit[3] = {false, false, false};
 #pragma unroll 1
@@ -348,6 +457,7 @@ __device__ __forceinline__ bool check_motion(Ctx& x, int thing, int vr, int vc, 
     hit[0] = i == 0 ? b : hit[0]; hit[1] = i == 1 ? b : hit[1]; hit[2] = i == 2 ? b : hit[2];
   }
   return hit[0] || (hit[1] && hit[2]);
+#endif
 }
 __device__ __forceinline__ int motion_bit(int dr, int dc) { return (dr + 1) * 3 + (dc + 1); }
 __device__ __forceinline__ void request_move(Ctx& x, int dr, int dc, int post = 1) { x.mv_dr = dr; x.mv_dc = dc; x.mv_post = post; }
@@ -370,7 +480,7 @@ __device__ __forceinline__ bool mw_move(Ctx& x, int thing, int dr, int dc) {
     // the eight neighbours, each probed once (sprites.py:539-543: a diagonal is blocked by its
     // own cell or by both of its flanks)
     uint32_t nb = 0;  // bit motion_bit(a, b): the neighbour at (a, b) is impassable
-#pragma unroll 1
+    PCX_PROBE_UNROLL
     for (int i = 0; i < 9; ++i) {
       const int a = i / 3 - 1, b = i - 3 * (i / 3) - 1;
       if (i != 4 && blocked_at(x, thing, vr, vc, a, b)) nb |= 1u << i;
@@ -562,10 +672,10 @@ __device__ __forceinline__ void prog_bs_patroller(Ctx& x, int thing) {  // :284-
   if (x.frame & 1) { request_move(x, 0, 0); return; }
   int r, c;
   sprite_true(x, s, r, c);
-  uint32_t f = x.l.flg[s * WAVE + x.lane];  // bit 2: _moving_east
+  uint32_t f = sflg(x, s);  // bit 2: _moving_east
   if (char_layer_at(x, '#', r, c - 1)) f |= 4u;
   if (char_layer_at(x, '#', r, c + 1)) f &= ~4u;
-  x.l.flg[s * WAVE + x.lane] = f;
+  sflg_set(x, s, f);
   request_move(x, 0, (f & 4u) ? 1 : -1, 2);  // ... then :298-301, in after_move()
 }
 // what follows the move in a program's update()
@@ -677,7 +787,7 @@ __device__ __forceinline__ int em_erode(Ctx& x, int d, int bolt_mask, int& hitte
   hitters = 0;
   for (int s = 0; s < x.k.NS; ++s) {
     if (!((bolt_mask >> s) & 1)) continue;
-    const int cell = x.l.snap[s * WAVE + x.lane];
+    const int cell = ssnap(x, s);
     if (cell < 0) continue;
     const int r = cell / x.k.C, c = cell - r * x.k.C;
     if (!bit_at(x, x.l.cur, d, r, c)) continue;
@@ -770,7 +880,7 @@ __device__ __forceinline__ void prog_em_downbolt(Ctx& x, int thing, uint32_t& dr
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
         const bool has = m != 0u;
-        const int cell = has ? x.l.snap[(__ffs((int)m) - 1) * WAVE + x.lane] : -1;
+        const int cell = has ? ssnap(x, __ffs((int)m) - 1) : -1;
         const uint32_t r = __umulhi((uint32_t)(cell >= 0 ? cell : 0), x.k.magic_c);
         cpos[i] = cell >= 0 ? (r << 8) | ((uint32_t)cell - r * (uint32_t)x.k.C) : 0xFFFFFFFFu;
         m &= m - 1u;
@@ -972,7 +1082,7 @@ __device__ __forceinline__ void move_windows(const Ctx& x, const crop::FusedCrop
         bool ok;
         if (fw.track_kind[i] == 0) {
           sprite_true(x, fw.track_sprite[i], r, c);
-          ok = (x.l.flg[fw.track_sprite[i] * WAVE + x.lane] & 1u) != 0;
+          ok = (sflg(x, fw.track_sprite[i]) & 1u) != 0;
         } else {
           ok = drape_centroid(x, fw.track_sprite[i], r, c);
         }
@@ -1166,9 +1276,10 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
       x.frame = (int)l.init[W_FRAME];
       for (int j = 0; j < 4; ++j) x.v[j] = (int32_t)l.init[W_V0 + j];
       dxv = (int)((l.init[W_FLAGS] >> 8) & 0xFF) - 1;
+      PCX_SPEC_UNROLL
       for (int s = 0; s < k.NS; ++s) {
-        l.pos[s * WAVE + lane] = l.init[W_SPRITES + s];
-        l.flg[s * WAVE + lane] = (l.init[k.w_sflags + (s >> 2)] >> (8 * (s & 3))) & 0xFF;
+        spos_set(x, s, l.init[W_SPRITES + s]);
+        sflg_set(x, s, (l.init[k.w_sflags + (s >> 2)] >> (8 * (s & 3))) & 0xFF);
       }
       for (int i = 0; i < ndw; ++i) l.cur[i * WAVE + lane] = l.initd[i];
       if (k.has_scroll) {
@@ -1184,9 +1295,15 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
       for (int j = 0; j < 4; ++j) x.v[j] = (int32_t)ib[(W_V0 + j) * WAVE];
       dxv = (int)((flags >> 8) & 0xFF) - 1;
       // (positions, curtain rows, window corners and the protocol's per-sprite words are in their columns already)
+#ifdef PCX_SREGS
+      PCX_SPEC_UNROLL
+      for (int s = 0; s < k.NS; ++s) spos_set(x, s, l.pos[s * WAVE + lane]);  // ... the positions on their way to the registers
+#endif
+      PCX_SPEC_UNROLL
       for (int w = 0; w < (k.NS + 3) / 4; ++w) {
         const uint32_t f = ib[(IB_SFLAGS + w) * WAVE];
-        for (int j = 0; j < 4 && 4 * w + j < k.NS; ++j) l.flg[(4 * w + j) * WAVE + lane] = (f >> (8 * j)) & 0xFF;
+        PCX_SPEC_UNROLL
+        for (int j = 0; j < 4; ++j) if (4 * w + j < k.NS) sflg_set(x, 4 * w + j, (f >> (8 * j)) & 0xFF);
       }
       if (k.has_scroll) x.registered = ib[IB_SCROLL * WAVE];
     }
@@ -1272,28 +1389,45 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
         const uint32_t t = l.zord[z * WAVE + lane] & 0xFu;
         if (z < 8) z0 |= t << (4 * z); else z1 |= t << (4 * (z - 8));
       }
-      st[k.w_z * srow] = z0;
+      st[k.w_z * srow] = z0;  // (before WB is declared: two words of the games that change the z-order)
       st[(k.w_z + 1) * srow] = z1;
     }
     flags = (x.game_over ? F_OVER : 0u) | ((x.err & 7u) << F_ERR_SHIFT) | ((uint32_t)((dxv + 1) & 0xFF) << 8);
-    st[W_RNG * srow] = draws;
-    if (k.w_next >= 0) st[k.w_next * srow] = (uint32_t)x.next;
-    st[W_FRAME * srow] = (uint32_t)x.frame;
-    st[W_FLAGS * srow] = flags;
-    for (int j = 0; j < 4; ++j) st[(W_V0 + j) * srow] = (uint32_t)x.v[j];
-    for (int s = 0; s < k.NS; ++s) st[(W_SPRITES + s) * srow] = l.pos[s * WAVE + lane];
+#if defined(PCX_GENERIC_SPEC) && defined(PCX_X_WB4)
+    // TIMING EXPERIMENT ONLY (results are wrong: the state never advances): the state words leave in 16-byte stores, four
+    // words per lane and instruction, into the second half of a doubled allocation -- what a quad-interleaved state layout would cost
+    RegList<uint32_t, 4> wbq{};
+    int wbi = 0;
+    uint32_t* const wb_base = P.state + (size_t)k.NW * bp + ((size_t)(env0 >> 6) * (size_t)((k.NW + 3) / 4 + 1)) * 256 + lane * 4;
+    auto WB = [&](int, uint32_t v) {
+      reg_put(wbq, wbi & 3, v);
+      if ((wbi & 3) == 3) *reinterpret_cast<uint4*>(wb_base + (size_t)(wbi >> 2) * 256) = make_uint4(wbq.head, wbq.tail.head, wbq.tail.tail.head, wbq.tail.tail.tail.head);
+      ++wbi;
+    };
+#else
+    auto WB = [&](int w, uint32_t v) { st[w * srow] = v; };
+#endif
+    WB(W_RNG, draws);
+    if (k.w_next >= 0) WB(k.w_next, (uint32_t)x.next);
+    WB(W_FRAME, (uint32_t)x.frame);
+    WB(W_FLAGS, flags);
+    for (int j = 0; j < 4; ++j) WB((W_V0 + j), (uint32_t)x.v[j]);
+    PCX_SPEC_UNROLL
+    for (int s = 0; s < k.NS; ++s) WB((W_SPRITES + s), spos(x, s));
+    PCX_SPEC_UNROLL
     for (int w = 0; w < (k.NS + 3) / 4; ++w) {
       uint32_t f = 0;
-      for (int j = 0; j < 4 && 4 * w + j < k.NS; ++j) f |= (l.flg[(4 * w + j) * WAVE + lane] & 0xFF) << (8 * j);
-      st[(k.w_sflags + w) * srow] = f;
+      PCX_SPEC_UNROLL
+      for (int j = 0; j < 4; ++j) if (4 * w + j < k.NS) f |= (sflg(x, 4 * w + j) & 0xFF) << (8 * j);
+      WB((k.w_sflags + w), f);
     }
-    for (int i2 = 0; i2 < ndw; ++i2) st[(k.w_drapes + i2) * srow] = l.cur[i2 * WAVE + lane];
+    for (int i2 = 0; i2 < ndw; ++i2) WB((k.w_drapes + i2), l.cur[i2 * WAVE + lane]);
     if (k.has_scroll) {
-      st[k.w_scroll * srow] = x.registered;
-      for (int d = 0; d < k.ND; ++d) st[(k.w_scroll + 1 + d) * srow] = l.corner[d * WAVE + lane];
+      WB(k.w_scroll, x.registered);
+      for (int d = 0; d < k.ND; ++d) WB((k.w_scroll + 1 + d), l.corner[d * WAVE + lane]);
       for (int s = 0; s < k.NS; ++s) {
-        st[(k.w_scroll + 1 + k.ND + 2 * s) * srow] = l.pmask[s * WAVE + lane];
-        st[(k.w_scroll + 2 + k.ND + 2 * s) * srow] = l.pframe[s * WAVE + lane];
+        WB((k.w_scroll + 1 + k.ND + 2 * s), l.pmask[s * WAVE + lane]);
+        WB((k.w_scroll + 2 + k.ND + 2 * s), l.pframe[s * WAVE + lane]);
       }
     }
     out.reward[env] = x.reward;
@@ -1347,6 +1481,33 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
       }
     }
     if (timing) c_sec[5] = __builtin_readcyclecounter() - t_occ;  // + curtains over curtains
+#ifdef PCX_SREGS
+    // every sprite's cell once, in registers; who else is at the sprite's cell as masks over sprite and drape indices against
+    // the masks of what is in front of it (in any order: a shown sprite only takes its cell from curtains that are behind it or
+    // do not hold it); only the curtains' words come from LDS
+    RegList<int, SREG_N> rcell{};
+    PCX_SPEC_UNROLL
+    for (int s = 0; s < k.NS; ++s) reg_put(rcell, s, sprite_cell(x, s));  // (never indexed by anything but a constant: see reg_get)
+    if (timing) c_sec[7] = __builtin_readcyclecounter() - t_occ;  // + sprite cells
+    PCX_SPEC_UNROLL
+    for (int s = 0; s < k.NS; ++s) {
+      const int t = (int)l.s2t[s];
+      const int cell = reg_get(rcell, s);
+      const uint32_t ab_s = above_sprites(x, t), ab_d = above_drapes(x, t);
+      const bool vis = cell >= 0;
+      const int cc = vis ? cell : 0, wi = cc >> 5, sh = cc & 31;
+      uint32_t here_s = 0, here_d = 0;
+      PCX_SPEC_UNROLL
+      for (int j = 0; j < k.NS; ++j) here_s |= reg_get(rcell, j) == cell ? 1u << j : 0u;
+      PCX_SPEC_UNROLL
+      for (int d = 0; d < k.ND; ++d) here_d |= ((l.flat[GFLAT(d, wi, lane)] >> sh) & 1u) ? 1u << d : 0u;
+      const bool shown = vis && !(here_s & ab_s) && !(here_d & ab_d);
+      if (shown && here_d)
+        for (int d = 0; d < k.ND; ++d) l.flat[GFLAT(d, wi, lane)] &= ~(1u << sh);
+      l.sdesc[s * WAVE + lane] = make_uint2((uint32_t)cell, shown ? 1u : 0u);  // (what the owner codes and the descriptors below read)
+    }
+    if (timing) c_sec[8] = __builtin_readcyclecounter() - t_occ;  // + sprites resolved
+#else
     // every sprite's cell once (sdesc doubles as the scratch: x = cell, y = shown)
     for (int s = 0; s < k.NS; ++s) l.sdesc[s * WAVE + lane] = make_uint2((uint32_t)sprite_cell(x, s), 0u);
     if (timing) c_sec[7] = __builtin_readcyclecounter() - t_occ;  // + sprite cells
@@ -1369,6 +1530,22 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
       l.sdesc[s * WAVE + lane].y = shown ? 1u : 0u;
     }
     if (timing) c_sec[8] = __builtin_readcyclecounter() - t_occ;  // + sprites resolved
+#endif
+    // the tracked positions (croppers) and, for the mask-composing render loop, the sprites' paint descriptors -- BEFORE the owner
+    // codes are written: in pcx_generic_step they lie over the per-lane arrays this still reads (Consts::l_codes)
+    const bool to_codes = l.codes != nullptr;
+    for (int s = 0; s < k.NS; ++s) {
+      if (!to_codes) {
+        const uint2 cs = l.sdesc[s * WAVE + lane];
+        const int cell = (int)cs.x;
+        l.sdesc[s * WAVE + lane] = make_uint2(cs.y ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
+        if (!k.occl) l.sdescraw[s * WAVE + lane] = make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
+      }
+      int tr, tc;
+      sprite_true(x, s, tr, tc);
+      P.track[s * bp + env] = tr | (tc << 8) | ((int)(sflg(x, s) & 1) << 16) | ((int)do_reset << 24);
+    }
+    if (fc) move_windows(x, fc, env, l.wcorner);  // fused croppers follow this step's things
     if (l.codes != nullptr) {
       // Owner codes (rendering.py:98-179 as one byte per cell): the backdrop's code dwords, every curtain's cells (disjoint by
       // now: a curtain lost what a curtain in front covers) merged in four at a time, then the painted sprites as byte writes.
@@ -1395,16 +1572,6 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
         if (cs.y) cb[cs.x] = (uint8_t)code_of_layer(k.L, tfield(x, (int)l.s2t[s], T_LAYER));
       }
     }
-    for (int s = 0; s < k.NS; ++s) {
-      const uint2 cs = l.sdesc[s * WAVE + lane];
-      const int cell = (int)cs.x;
-      l.sdesc[s * WAVE + lane] = make_uint2(cs.y ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
-      if (!k.occl) l.sdescraw[s * WAVE + lane] = make_uint2(cell >= 0 ? (uint32_t)(cell >> 2) : 0xFFFFFFFFu, 0xFFu << ((cell & 3) * 8));
-      int tr, tc;
-      sprite_true(x, s, tr, tc);
-      P.track[s * bp + env] = tr | (tc << 8) | ((int)(l.flg[s * WAVE + lane] & 1) << 16) | ((int)do_reset << 24);
-    }
-    if (fc) move_windows(x, fc, env, l.wcorner);  // fused croppers follow this step's things
     if (timing) c_sec[3] = __builtin_readcyclecounter() - t_occ;  // occlusion + descriptors
   }
   if (timing && logic_wave && lane == 0) {
@@ -1421,10 +1588,69 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
 #undef GFLAT
 }
 
+// The render worker's loop: pcx_stream.h stream_codes for one wave, with the number of characters a run-time value (a
+// constant in the build specialised for the template).  Every store is `scalar plane base + one shared 32-bit lane offset`.
+// `wave` / `nwaves`: the waves of a pcx_generic_step workgroup take the iterations round-robin (a render worker: 0 / 1).
+__device__ __forceinline__ void render_codes(const Consts& k, const uint32_t* codes, const uint32_t* skip, const pcx_buffers& out, int64_t env0,
+                                             int lane, int wave = 0, int nwaves = 1) {
+  const uint32_t QW = (uint32_t)k.QW, CP = QW | 1u, pitch = (uint32_t)k.pitch;
+  const int Lc = k.L;
+  const uint32_t env_stride = (uint32_t)(1 + Lc) * pitch;
+  uint8_t* const blk = stream::uniform_ptr(out.planes + (size_t)env0 * env_stride);
+  uint32_t ch[4] = {0, 0, 0, 0};
+  PCX_SPEC_UNROLL
+  for (int i = 0; i < Lc && i < 16; ++i) ch[i >> 2] |= (uint32_t)k.chars[i] << (8 * (i & 3));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ch[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch[i]);
+  const bool any_skip = __ballot(skip[lane] != 0) != 0ull;
+  const uint32_t DE = (uint32_t)WAVE / QW, DQ = (uint32_t)WAVE - DE * QW;
+  uint32_t e = (uint32_t)lane / QW, q = (uint32_t)lane - e * QW;
+  uint32_t voff = e * env_stride + 4u * q, ci = e * CP + q;
+  const uint32_t dvoff = DE * env_stride + 4u * DQ, dci = DE * CP + DQ;
+  const uint32_t wrap_voff = env_stride - 4u * QW, wrap_ci = CP - QW;
+  const uint32_t ci_last = (uint32_t)(WAVE - 1) * CP + QW - 1u;
+  uint32_t code_pf = codes[ci];
+#pragma unroll 1
+  for (uint32_t it = 0; it < QW; ++it) {
+    const uint32_t e_now = e, voff_now = voff, code = code_pf;
+    q += DQ; e += DE; voff += dvoff; ci += dci;
+    {
+      const bool wrap = q >= QW;
+      q = wrap ? q - QW : q;
+      e = wrap ? e + 1 : e;
+      voff = wrap ? voff + wrap_voff : voff;
+      ci = wrap ? ci + wrap_ci : ci;
+    }
+    code_pf = codes[ci < ci_last ? ci : ci_last];
+    if (nwaves > 1 && (int)(it % (uint32_t)nwaves) != wave) continue;
+    if (any_skip && skip[e_now] != 0) continue;
+    if (Lc <= 8) {
+      saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(ch[1], ch[0], code), blk);
+      PCX_SPEC_UNROLL
+      for (int i = 0; i < Lc; ++i) {
+        const uint32_t one = 1u << (8 * (i & 3));
+        saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(i >= 4 ? one : 0u, i < 4 ? one : 0u, code), blk + (size_t)(1 + i) * pitch);
+      }
+    } else {
+      const uint32_t sa = code & 0x0F0F0F0Fu, sb = (code >> 4) & 0x0F0F0F0Fu;
+      saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(ch[1], ch[0], sa) | __builtin_amdgcn_perm(ch[3], ch[2], sb), blk);
+      PCX_SPEC_UNROLL
+      for (int i = 0; i < Lc; ++i) {
+        const int j = i & 7;
+        const uint32_t one = 1u << (8 * (j & 3));
+        saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(j >= 4 ? one : 0u, j < 4 ? one : 0u, i < 8 ? sa : sb), blk + (size_t)(1 + i) * pitch);
+      }
+    }
+  }
+}
+
 #ifdef __HIPCC_RTC__
 extern "C"  // (the run-time build is looked up by this plain name)
 #endif
-__global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))) void pcx_generic_step(const Consts k_arg, const Ptrs P, const StepArgs a,
+#ifndef PCX_X_WPE
+#define PCX_X_WPE 5  // (at least five waves per SIMD: at most 96 VGPRs)
+#endif
+__global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(PCX_X_WPE, 8))) void pcx_generic_step(const Consts k_arg, const Ptrs P, const StepArgs a,
                                                          const pcx_buffers out, const crop::FusedCrops* fc) {
   extern __shared__ uint32_t lds[];
 #ifdef PCX_GENERIC_SPEC
@@ -1459,10 +1685,18 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
   };
   const int64_t env0 = (int64_t)blockIdx.x * WAVE;
-  const L l = make_L(lds, k, 0);
+  // Round 6: plain steps render from OWNER CODES (P.use_codes; pcx_stream.h stream_codes: a byte per cell, one v_perm_b32 per plane)
+  // -- a wave streams a group in 3-4 us where the mask-composing render_planes, bound by LDS latency, takes ten times that, and
+  // a group holds its LDS for that much less time.  The code dwords lie over the per-lane arrays that are dead by then.
+  L lm = make_L(lds, k, 0);
+  if (P.use_codes && k.l_codes >= 0) lm.codes = lds + k.l_codes;
+  const L l = lm;
   logic_phase(k, l, P, a, out, fc, lds + k.l_inbox, env0, lane, wave == 0, timing);
   __syncthreads();
-  if (!(a.debug & 2)) render_all(l, env0, wave, nwaves);  // every wave of the workgroup streams board + layers
+  if (!(a.debug & 2)) {  // every wave of the workgroup streams board + layers
+    if (l.codes != nullptr) render_codes(k, l.codes, l.skip, out, env0, lane, wave, nwaves);
+    else render_all(l, env0, wave, nwaves);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1491,60 +1725,6 @@ struct PwArgs {
   int32_t flags;              // word offset of the n_logic flag words
 };
 constexpr uint32_t PW_DONE = 0xFFFFFFFFu;
-
-// The render worker's loop: pcx_stream.h stream_codes for one wave, with the number of characters a run-time value (a
-// constant in the build specialised for the template).  Every store is `scalar plane base + one shared 32-bit lane offset`.
-__device__ __forceinline__ void render_codes(const Consts& k, const uint32_t* codes, const uint32_t* skip, const pcx_buffers& out, int64_t env0,
-                                             int lane) {
-  const uint32_t QW = (uint32_t)k.QW, CP = QW | 1u, pitch = (uint32_t)k.pitch;
-  const int Lc = k.L;
-  const uint32_t env_stride = (uint32_t)(1 + Lc) * pitch;
-  uint8_t* const blk = stream::uniform_ptr(out.planes + (size_t)env0 * env_stride);
-  uint32_t ch[4] = {0, 0, 0, 0};
-  PCX_SPEC_UNROLL
-  for (int i = 0; i < Lc && i < 16; ++i) ch[i >> 2] |= (uint32_t)k.chars[i] << (8 * (i & 3));
-#pragma unroll
-  for (int i = 0; i < 4; ++i) ch[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch[i]);
-  const bool any_skip = __ballot(skip[lane] != 0) != 0ull;
-  const uint32_t DE = (uint32_t)WAVE / QW, DQ = (uint32_t)WAVE - DE * QW;
-  uint32_t e = (uint32_t)lane / QW, q = (uint32_t)lane - e * QW;
-  uint32_t voff = e * env_stride + 4u * q, ci = e * CP + q;
-  const uint32_t dvoff = DE * env_stride + 4u * DQ, dci = DE * CP + DQ;
-  const uint32_t wrap_voff = env_stride - 4u * QW, wrap_ci = CP - QW;
-  const uint32_t ci_last = (uint32_t)(WAVE - 1) * CP + QW - 1u;
-  uint32_t code_pf = codes[ci];
-#pragma unroll 1
-  for (uint32_t it = 0; it < QW; ++it) {
-    const uint32_t e_now = e, voff_now = voff, code = code_pf;
-    q += DQ; e += DE; voff += dvoff; ci += dci;
-    {
-      const bool wrap = q >= QW;
-      q = wrap ? q - QW : q;
-      e = wrap ? e + 1 : e;
-      voff = wrap ? voff + wrap_voff : voff;
-      ci = wrap ? ci + wrap_ci : ci;
-    }
-    code_pf = codes[ci < ci_last ? ci : ci_last];
-    if (any_skip && skip[e_now] != 0) continue;
-    if (Lc <= 8) {
-      saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(ch[1], ch[0], code), blk);
-      PCX_SPEC_UNROLL
-      for (int i = 0; i < Lc; ++i) {
-        const uint32_t one = 1u << (8 * (i & 3));
-        saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(i >= 4 ? one : 0u, i < 4 ? one : 0u, code), blk + (size_t)(1 + i) * pitch);
-      }
-    } else {
-      const uint32_t sa = code & 0x0F0F0F0Fu, sb = (code >> 4) & 0x0F0F0F0Fu;
-      saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(ch[1], ch[0], sa) | __builtin_amdgcn_perm(ch[3], ch[2], sb), blk);
-      PCX_SPEC_UNROLL
-      for (int i = 0; i < Lc; ++i) {
-        const int j = i & 7;
-        const uint32_t one = 1u << (8 * (j & 3));
-        saddr_store_dword<true>(voff_now, __builtin_amdgcn_perm(j >= 4 ? one : 0u, j < 4 ? one : 0u, i < 8 ? sa : sb), blk + (size_t)(1 + i) * pitch);
-      }
-    }
-  }
-}
 
 #ifdef __HIPCC_RTC__
 extern "C"

@@ -195,6 +195,7 @@ class Backend {
 Backend* make_scrolly_maze_backend();
 Backend* make_generic_backend();
 int generic_specialise_check(const pcx_template& t, char* log, int64_t log_bytes, int64_t* code_bytes);  // include/pcx.h pcx_generic_specialise_check
+int scrolly_maze_specialise_check(const pcx_template& t, char* log, int64_t log_bytes, int64_t* code_bytes);  // include/pcx.h pcx_scrolly_maze_specialise_check
 int64_t scrolly_maze_consts(const pcx_template& t, int32_t unit, uint32_t* words, int64_t cap);  // include/pcx.h pcx_debug_scrolly_consts
 Backend* make_warehouse_backend();  // hand-written; init() answers PCX_E_UNSUPPORTED for templates it leaves to the table-driven kernel
 Backend* make_marauders_backend();

@@ -21,7 +21,7 @@ ALL_GAMES = LEVELS + ['warehouse_L0', 'warehouse_L1', 'warehouse_L2', 'hello_wor
                       # the step kernel's shape-generic instances (oracle/custom_levels.py)
                       'scrolly_custom_A', 'scrolly_custom_B', 'scrolly_custom_C', 'scrolly_custom_D', 'scrolly_custom_E',
                       'scrolly_custom_A_unoccluded', 'scrolly_custom_C_unoccluded', 'scrolly_custom_E_unoccluded',
-                      'scrolly_custom_F', 'scrolly_custom_G', 'warehouse_custom_A', 'warehouse_custom_B', 'marauders_custom_A', 'hello_custom_A',
+                      'scrolly_custom_F', 'scrolly_custom_G', 'scrolly_custom_H', 'warehouse_custom_A', 'warehouse_custom_B', 'marauders_custom_A', 'hello_custom_A',
                       # run-time-shape instances of pcx_warehouse_step / pcx_better_scrolly_step
                       'warehouse_custom_C', 'warehouse_custom_D', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C', 'better_scrolly_custom_D', 'better_scrolly_custom_E',
                       # Plot directives incl. change_z_order on the device (engine.py:796-835)

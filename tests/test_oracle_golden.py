@@ -21,7 +21,7 @@ ALL_TRACES = ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2', 'warehous
               # unshipped scrolly_maze levels (oracle/custom_levels.py): other board shapes, sprite sets, z-orders
               'scrolly_custom_A', 'scrolly_custom_B', 'scrolly_custom_C', 'scrolly_custom_D', 'scrolly_custom_E',
                       'scrolly_custom_A_unoccluded', 'scrolly_custom_C_unoccluded', 'scrolly_custom_E_unoccluded',
-                      'scrolly_custom_F', 'scrolly_custom_G', 'warehouse_custom_A', 'warehouse_custom_B', 'marauders_custom_A', 'hello_custom_A',
+                      'scrolly_custom_F', 'scrolly_custom_G', 'scrolly_custom_H', 'warehouse_custom_A', 'warehouse_custom_B', 'marauders_custom_A', 'hello_custom_A',
               # shapes the hand-written kernels take with their run-time-shape instances
               'warehouse_custom_C', 'warehouse_custom_D', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C', 'better_scrolly_custom_D', 'better_scrolly_custom_E',
               # Plot directives from inside update(): add_reward, terminate_episode(discount), change_z_order

@@ -31,7 +31,7 @@ def main():
   variants = []
   for v in args.variants.split(';'):
     name, _, kv = v.partition(':')
-    variants.append((name, dict(x.split('=') for x in kv.split(',') if x)))
+    variants.append((name, dict(x.split('=', 1) for x in kv.split(',') if x)))
   keys = {k.lstrip('!') for _, kw in variants for k in kw}
   fresh = any(k.startswith('!') for _, kw in variants for k in kw)
   template = GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', (args.fixture or FIXTURE[args.game]) + '.npz'))
