@@ -312,9 +312,17 @@ __global__ __launch_bounds__(NWAVES* WAVE) void pcx_better_scrolly_step(const Co
 #pragma unroll
   for (int b = 0; b < NB; ++b) { pm.bchar_off[b] = k.bchar_off[b]; bch4[b] = k.bchar_ch4[b]; }
   const uint32_t env_stride = (uint32_t)(1 + L) * (uint32_t)pitch;
-  if (!(fc && fc->only))
+  if (!(fc && fc->only)) {
+    // (round 6) single-wave workgroups without an epilogue: the stores of KB iterations regrouped plane by plane
+    // (pcx_stream.h stream_planes_burst; PCX_DEBUG bits 64 / 128 / 256: KB = 4 / 8 / 2 -- A/B)
+    if constexpr (!EPI && NWAVES == 1) if (!fc) {
+      if (a.debug & 64) { stream::stream_planes_burst<NS, ND, NB, SQW, 4>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM, cm, sdesc, skipv, CWP, lane, cid, QW); return; }
+      if (a.debug & 128) { stream::stream_planes_burst<NS, ND, NB, SQW, 8>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM, cm, sdesc, skipv, CWP, lane, cid, QW); return; }
+      if (a.debug & 256) { stream::stream_planes_burst<NS, ND, NB, SQW, 2>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM, cm, sdesc, skipv, CWP, lane, cid, QW); return; }
+    }
     stream::stream_planes<NS, ND, NB, SQW, NWAVES, EPI>(pm, out.planes + (size_t)env0 * env_stride, env_stride, lds + O_BD, lds + O_BDM,
                                                          cm, sdesc, skipv, CWP, lane, wave, epi, env0, cid, QW, nullptr, nullptr, lds);
+  }
   if (fc)
     stream::stream_windows<NS, ND, NB, SQW, NWAVES, SR, SC, true>(fc, pm, bch4, env0, lds + O_BD, cm, sdesc, skipv, CWP, lane, wave, wcorner,
                                                                  cid, stream::BoardShape{R, C, QW});

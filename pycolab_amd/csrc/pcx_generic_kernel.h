@@ -106,11 +106,11 @@ namespace spec {
 //    are unrolled, so that their LDS reads are in flight together instead of one probe after the other (the table-driven
 //    build keeps ONE copy of the probe walked by a loop: it is bound by instruction issue, not by latency).
 // Measured (profiles/r06_generic.md): registers -5 % on the launch, -12 % on its logic phase with up to eight sprites, a loss with
-// the ten of the marauders' cast (their programs index sprites by a lane's own values: select chains of ten) -- hence the bound,
-// PCX_SPEC_NS being the template's sprite count as the constants' header states it (GenericBackend::sregs_layout decides the
-// same way); the probes side by side LOSE 5-10 % everywhere (three probes' worth of work for a cardinal move), so that one is
-// opt-in (PCX_GENERIC_SPEC_DEFS=-DPCX_X_PROBE_UNROLL).
-#if defined(PCX_GENERIC_SPEC) && !defined(PCX_X_NO_SPRITE_REGS) && defined(PCX_SPEC_NS) && PCX_SPEC_NS <= 8
+// the marauders' cast (their programs index sprites by a lane's own values: select chains) -- GenericBackend::plan decides and the
+// constants' header says so (PCX_SPEC_SREGS; the LDS layout in the same header has no flag / snapshot columns then); the probes
+// side by side LOSE 5-10 % everywhere (three probes' worth of work for a cardinal move), so that one is opt-in
+// (PCX_GENERIC_SPEC_DEFS=-DPCX_X_PROBE_UNROLL).
+#if defined(PCX_GENERIC_SPEC) && defined(PCX_SPEC_SREGS)
 #define PCX_SREGS 1
 #endif
 #if defined(PCX_GENERIC_SPEC) && defined(PCX_X_PROBE_UNROLL)

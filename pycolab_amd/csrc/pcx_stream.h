@@ -593,6 +593,115 @@ __device__ __forceinline__ void stream_planes(const PlaneMap<NS, ND, NB>& pm, ui
 #undef PCX_STREAM_MODE
 }
 
+// The plain loop of stream_planes for ONE wave with its stores regrouped (round 6): KB consecutive iterations' dwords are
+// composed first, then stored PLANE BY PLANE -- every plane receives KB x 256 contiguous bytes from the wave at a time instead
+// of 256.  For boards whose planes are kilobytes long (better_scrolly_maze: 4,005 bytes) the streams of a wave are that far
+// apart, and what the memory side sees from a CU is (planes x waves) interleaved streams of 256-byte pieces; boards of a few
+// hundred cells write a whole record densely either way.  No epilogue, occluded layers, single-wave workgroups.
+template <int NS, int ND, int NB, int QW, int KB, bool DRAIN = true>
+__device__ __forceinline__ void stream_planes_burst(const PlaneMap<NS, ND, NB>& pm, uint8_t* group_base, uint32_t env_stride,
+                                                    const uint32_t* backdrop4, const uint32_t* bdmask, const uint32_t* flat,
+                                                    const uint2* sdesc, const uint32_t* skip, int FWP, int lane,
+                                                    const uint32_t* cell_ids = nullptr, int qw_rt = 0) {
+  const uint32_t QWv = QW ? (uint32_t)QW : (uint32_t)qw_rt;
+  uint8_t* const pb_board = uniform_ptr(group_base);
+  uint8_t* pb_s[NS > 0 ? NS : 1];
+  uint8_t* pb_d[ND > 0 ? ND : 1];
+  uint8_t* pb_b[NB > 0 ? NB : 1];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) pb_s[s] = uniform_ptr(pb_board + pm.sprite_off[s]);
+#pragma unroll
+  for (int d = 0; d < ND; ++d) pb_d[d] = uniform_ptr(pb_board + pm.drape_off[d]);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) pb_b[b] = uniform_ptr(pb_board + pm.bchar_off[b]);
+  const bool any_skip = __ballot(skip[lane] != 0) != 0ull;
+  if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see stream_planes_mode
+  const uint32_t DE = (uint32_t)WAVE / QWv, DQ = (uint32_t)WAVE - DE * QWv;
+  uint32_t e = (uint32_t)lane / QWv, q = (uint32_t)lane - e * QWv;
+  uint32_t voff = e * env_stride + 4u * q, eF = e * (uint32_t)FWP;
+  const uint32_t dvoff = DE * env_stride + 4u * DQ, dF = DE * (uint32_t)FWP;
+  const uint32_t wrap_voff = env_stride - 4u * QWv;
+#pragma unroll 1
+  for (int it = 0; it < (int)QWv; it += KB) {
+    uint32_t dv[KB], vo[KB], mdv[KB][ND > 0 ? ND : 1], msv[KB][NS > 0 ? NS : 1], mbv[KB][NB > 0 ? NB : 1];
+    bool live[KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const bool in = it + kk < (int)QWv;  // (uniform)
+      const uint32_t e_now = in ? e : 0u, q_now = in ? q : 0u, eF_now = in ? eF : 0u;
+      vo[kk] = voff;
+      live[kk] = in && !(any_skip && skip[e_now] != 0);
+      if (in) {
+        q += DQ; e += DE; voff += dvoff; eF += dF;
+        const bool wrap = q >= QWv;
+        q = wrap ? q - QWv : q;
+        e = wrap ? e + 1 : e;
+        voff = wrap ? voff + wrap_voff : voff;
+        eF = wrap ? eF + FWP : eF;
+      }
+      uint32_t d = backdrop4[q_now];
+#pragma unroll
+      for (int dd = 0; dd < ND; ++dd) {
+        uint32_t bits;
+        if (cell_ids != nullptr) {
+          const uint32_t ids = cell_ids[q_now];
+          bits = 0;
+          if (ids != 0xFFFFFFFFu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t id = (ids >> (8 * j)) & 0xFFu;
+              if (id != 0xFFu) bits |= ((flat[eF_now + (id >> 5)] >> (id & 31)) & 1u) << j;
+            }
+          }
+        } else {
+          bits = (flat[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;
+        }
+        const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+        uint32_t hi8 = m01 << 8;
+        asm("" : "+v"(hi8));
+        mdv[kk][dd] = hi8 - m01;
+      }
+      uint32_t uni = 0;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const uint2 sd = sdesc[s * WAVE + e_now];
+        msv[kk][s] = sd.x == q_now ? sd.y : 0u;
+      }
+#pragma unroll
+      for (int dd = 0; dd < ND; ++dd) {
+        uni |= mdv[kk][dd];
+        d = (d & ~mdv[kk][dd]) | (pm.drape_ch4[dd] & mdv[kk][dd]);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        uni |= msv[kk][s];
+        d = (d & ~msv[kk][s]) | (pm.sprite_ch4[s] & msv[kk][s]);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) mbv[kk][b] = bdmask[b * QWv + q_now] & ~uni;
+      dv[kk] = d;
+    }
+    // plane by plane: KB stores to consecutive 256-byte pieces of one plane
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) if (live[kk]) saddr_store_dword<true>(vo[kk], dv[kk], pb_board);
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) if (live[kk]) saddr_store_dword<true>(vo[kk], mdv[kk][dd] & 0x01010101u, pb_d[dd]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) if (live[kk]) saddr_store_dword<true>(vo[kk], msv[kk][s] & 0x01010101u, pb_s[s]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) if (live[kk]) saddr_store_dword<true>(vo[kk], mbv[kk][b], pb_b[b]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Owner codes (round 6; pcx_scrolly_maze_step has rendered this way since round 2).  Instead of masks per thing the
 // logic phase leaves, per environment, ONE BYTE PER BOARD CELL naming the character that shows there -- `codes`
