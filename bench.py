@@ -53,7 +53,10 @@ FIXTURES = {'scrolly_maze': 'scrolly_maze_L%d', 'warehouse': 'warehouse_L%d', 'm
             'marauders_custom_A': 'marauders_custom_A', 'walkers_scroll_groups': 'walkers_scroll_groups',
             # warehouse_manager level 0 stepped by the table-driven kernel (PCX_FORCE_GENERIC=1 while the engine is created): the
             # kernel's third timing fixture since round 3
-            'warehouse_generic': 'warehouse_L%d'}
+            'warehouse_generic': 'warehouse_L%d',
+            # round 6: a scrolly_maze level of one's own on the example's board -- pcx_scrolly_maze_step compiles its instances for it at
+            # pcx_engine_create (launch_shape 7) -- next to the shipped level with the same number of coin words (level 1: launch_shape 5)
+            'scrolly_custom_H': 'scrolly_custom_H'}
 
 
 def cpu_worker(args):
@@ -585,6 +588,8 @@ def main():
       # (+ config 5's per-GPU shard sizes: 131,072 environments = 1,048,576 over eight GPUs, and 262,144 = over four)
       line['other_configs'] = [measure_config('scrolly_maze', 0, 131072, 200, 20, device),
                                measure_config('scrolly_maze', 0, 262144, 200, 20, device),
+                               measure_config('scrolly_custom_H', 0, 131072, 200, 20, device),
+                               measure_config('scrolly_maze', 1, 131072, 200, 20, device),
                                measure_config('scrolly_maze', 0, 4096, 200, 20, device),
                                measure_step_n('scrolly_maze', 0, 4096, 1000, device),
                                # the headline batch through Engine.step_n: launches of up to 64 steps in which every persistent

@@ -101,7 +101,7 @@ static constexpr Consts SPEC_7 = consts_from_words(SPEC_WORDS[0]), SPEC_8 = cons
 template <int LV>
 __device__ __forceinline__ const Consts& baked_consts(const Consts& from_args) {
   if constexpr (LV == 7) return SPEC_7;
-  else if constexpr (LV == 8) return SPEC_8;
+  else if constexpr (LV == 8 || LV == 9) return SPEC_8;
   else return from_args;
 }
 #else
@@ -630,8 +630,8 @@ template <int NS, int SR, int SC, int SL, int IP, int IE, bool UNOCC, bool COOP 
 __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void pcx_scrolly_maze_step(const Consts k_arg, const Ptrs P, const StepArgs a,
                                                                   const pcx_buffers out, const stream::EpilogueArgs epi,
                                                                   const crop::FusedCrops* fc_arg) {
-  static_assert(LV == 0 || ((LV & 1) && PS == 3 && CODES) || (!(LV & 1) && COOP && !EPI),
-                "compiled-in constants: odd LV = the persistent owner-code instance, even LV = the cooperative one");
+  static_assert(LV == 0 || (LV == 9 && PS == 0 && !COOP && !EPI && !CODES && SR != 0) || (LV != 9 && (LV & 1) && PS == 3 && CODES) || (!(LV & 1) && COOP && !EPI),
+                "compiled-in constants: odd LV = the persistent owner-code instance, even LV = the cooperative one, 9 = one workgroup per group of any static shape");
   const Consts& k = baked_consts<LV>(k_arg);
   // Fused croppers (include/pcx.h pcx_engine_fuse_croppers): the instances that keep the frame as curtain
   // bit vectors + sprite descriptors (pcx_stream.h's contract) and render a group in the round they step it
@@ -1889,12 +1889,21 @@ __global__ __launch_bounds__(COOP ? 8 * WAVE : PS == 3 ? 12 * WAVE : WAVE) void 
 // with the constants of PCX_SM_SPEC compiled in.  ScrollyMazeBackend (jit::load) looks them up by their mangled names, which
 // follow from this signature -- the kernel itself stays exactly the template libpcx.so is built from (a wrapper around a
 // device function with the body in it was tried: the by-reference arguments cost the other instances registers and scratch).
+// PCX_SM_SPEC_SHAPE (a level of ANOTHER board or cast: `NS, R, C, L, IP, IE`, PCX_SM_SPEC_UNOCC true / false): one instance -- a
+// workgroup per group of 64 environments, the mask-composing render loop -- with the shape as template arguments AND the
+// constants compiled in (LV 9), where libpcx.so only has the shape-generic instances (36-60 k instructions for four to six
+// sprites, a quarter of them lane moves, because every stride and index is a run-time value).
+#ifdef PCX_SM_SPEC_SHAPE
+template __global__ void pcx_scrolly_maze_step<PCX_SM_SPEC_SHAPE, PCX_SM_SPEC_UNOCC, false, false, false, 0, 9>(const Consts, const Ptrs, const StepArgs, const pcx_buffers,
+                                                                                                              const stream::EpilogueArgs, const crop::FusedCrops*);
+#else
 #ifndef PCX_SM_SPEC_NO_PS
 template __global__ void pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, false, false, true, 3, 7>(const Consts, const Ptrs, const StepArgs, const pcx_buffers,
                                                                                                   const stream::EpilogueArgs, const crop::FusedCrops*);
 #endif
 template __global__ void pcx_scrolly_maze_step<4, 10, 30, 8, 3, 3, false, true, false, false, 0, 8>(const Consts, const Ptrs, const StepArgs, const pcx_buffers,
                                                                                                   const stream::EpilogueArgs, const crop::FusedCrops*);
+#endif
 #endif
 
 }  // namespace sm

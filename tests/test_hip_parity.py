@@ -48,11 +48,12 @@ def test_hip_matches_reference_trace(name):
 
 @pytest.mark.parametrize('name', ALL_GAMES)
 def test_hip_matches_oracle_hashed_actions(name):
-  """4096 envs x 256 steps, uniform actions from the shared counter hash,
+  """2048 envs x 192 steps (the shipped scrolly_maze levels; fewer for the others), uniform actions from the shared counter hash,
   resets included; every output compared every 8 steps and at the end."""
   t = helpers.load_template(name)
   t.param[0] = 0xBEEF  # RNG seed (marauders)
-  B, T = (4096, 256) if name in LEVELS else (512, 96) if name.startswith('better') else (2048, 192)
+  # (round 6: sizes halved -- the oracle is what the test waits for; every launch shape of every kernel has tests of its own)
+  B, T = (2048, 192) if name in LEVELS else (512, 96) if name.startswith('better') else (768, 128) if name.startswith('marauders') else (1024, 144)
   hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
   hip.reset(); orc.reset()
   assert_same(hip, orc, 'frame 0')
@@ -263,7 +264,7 @@ def test_hip_several_steps_per_launch_in_the_cooperative_shape(name, B):
   hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
   hip.reset(); orc.reset()
   t0 = 0
-  for i, n in enumerate((1, 2, 3, 9, 64, 5, 200, 31)):
+  for i, n in enumerate((1, 2, 3, 9, 64, 5, 200, 31) if B < 10000 else (1, 2, 9, 40, 5)):  # (the largest batch: fewer steps, the oracle is what it waits for)
     auto = i % 3 != 2
     hip.step_hashed(0xABCD, t0, n, auto_reset=auto); orc.step_hashed(0xABCD, t0, n, auto_reset=auto)
     if n > 1 and 'PCX_COOP_BELOW' not in os.environ:  # (a suite run with the cooperative shape forced off / on compares results only)

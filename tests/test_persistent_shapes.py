@@ -83,9 +83,9 @@ def test_persistent_workers_with_streaming_semaphore_match_oracle(shape, codes, 
 
 
 @pytest.mark.parametrize('shape,unit,dynamic,grid,waves', [
-    (3, 64, 1, 5, 1), (3, 64, 0, 5, 1), (3, 32, 1, 7, 1), (3, 16, 1, 3, 1), (3, 64, 1, 4096, 1),
-    (3, 64, 1, 5, 2), (3, 64, 0, 5, 2), (3, 32, 1, 3, 4), (3, 16, 1, 2, 6), (3, 64, 1, 1, 2), (3, 64, 1, 4096, 2), (3, 64, 1, 2, 1),
-])
+    (3, 64, 1, 5, 1), (3, 64, 0, 5, 1), (3, 32, 1, 7, 1), (3, 64, 1, 4096, 1),
+    (3, 64, 0, 5, 2), (3, 32, 1, 3, 4), (3, 16, 1, 2, 6), (3, 64, 1, 1, 2),
+])  # (round 6: eight of round 5's twelve -- units of 64 / 32 / 16, tickets and round-robin, one to six workers, a grid larger than the batch)
 def test_persistent_shapes_match_oracle(shape, unit, dynamic, grid, waves):
   """A ragged batch (not a multiple of 64, 32 or 16) walked by `grid` workgroups; hashed actions, resets included."""
   t = helpers.load_template('scrolly_maze_L0')
@@ -104,7 +104,7 @@ def test_persistent_shapes_match_oracle(shape, unit, dynamic, grid, waves):
     assert int(orc.read('frame').min()) < T  # episodes ended and restarted inside the run
 
 
-@pytest.mark.parametrize('shape,tail,small', [(3, 2, 16), (3, 3, 8), (3, 1, 32)])
+@pytest.mark.parametrize('shape,tail,small', [(3, 2, 16)])  # (round 6: one setting -- the knob is off by default, every setting measured slower)
 def test_small_units_at_the_end_of_the_batch(shape, tail, small):
   """With tickets the batch's last environments go in small units (so that what the workers hold when the tickets run out
   is short): 20,000 environments on four workgroups -- a few dozen 64-environment units, then units of `small`."""
@@ -281,13 +281,13 @@ def test_cooperative_shape_with_the_levels_constants_compiled_in(B, level, baked
     hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
     hip.reset(); orc.reset()
     t0 = 0
-    for n in (1, 1, 1, 7, 64, 3, 1, 120):
+    for n in ((1, 1, 1, 7, 64, 3, 1, 120) if B < 10000 else (1, 1, 7, 33, 1)):  # (the largest batch: fewer steps, the oracle is what it waits for)
       hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
       if 'PCX_COOP_BELOW' not in os.environ or os.environ['PCX_COOP_BELOW'] not in ('0',):  # (a suite run with the cooperative shape forced off compares results only)
         assert raw_shape_of(hip) == (12 if n > 1 else 10)
       t0 += n
       assert_same(hip, orc, 'B %d level %d baked %d after step %d' % (B, level, baked, t0))
-    assert level == 2 or int(orc.read('frame').min()) < t0  # (level 2's patrollers are boxed in: nobody is caught within 198 steps)
+    assert level == 2 or B > 10000 or int(orc.read('frame').min()) < t0  # (level 2's patrollers are boxed in: nobody is caught within 198 steps)
 
 
 # ---- the kernels built on pcx_stream.h: persistent workers (round 5) ------------------------------------------------------
@@ -296,13 +296,18 @@ STREAM_KERNELS = [('PCX_WM_', 'warehouse_L0', 5), ('PCX_WM_', 'warehouse_L1', 5)
                   ('PCX_WM_', 'warehouse_custom_B', 5), ('PCX_HW_', 'hello_world', 4), ('PCX_HW_', 'hello_custom_A', 4)]
 
 
-@pytest.mark.parametrize('prefix,name,n_ordinary', STREAM_KERNELS)
-@pytest.mark.parametrize('workers,lock,dynamic,grid', [(8, 4, 0, 1), (3, 1, 1, 2), (1, 0, 0, 4), (4, 2, 1, 3)])
-def test_stream_kernels_persistent_workers_match_oracle(prefix, name, n_ordinary, workers, lock, dynamic, grid):
+# every worker shape on the two shipped games, two of them on the other levels (the shapes differ in scheduling only)
+STREAM_CASES = [(p, n, o, w) for p, n, o in STREAM_KERNELS for i, w in enumerate([(8, 4, 0, 1), (3, 1, 1, 2), (1, 0, 0, 4), (4, 2, 1, 3)])
+                if n in ('warehouse_L0', 'hello_world') or i in (1, 3)]
+
+
+@pytest.mark.parametrize('prefix,name,n_ordinary,shape', STREAM_CASES)
+def test_stream_kernels_persistent_workers_match_oracle(prefix, name, n_ordinary, shape):
   """pcx_warehouse_step / pcx_hello_world_step with persistent workers (launch shape 3) against the oracle: a ragged batch
   that every worker walks several units of (a handful of workgroups: PCX_xx_GRID), hashed actions and host tapes with
   quirky actions, steps without auto-reset."""
   from pycolab_amd import _native as N
+  workers, lock, dynamic, grid = shape
   t = helpers.load_template(name)
   B, T = 64 * 37 + 13, 64
   rng = np.random.RandomState(5)

@@ -23,20 +23,20 @@ echo "# pcx_scrolly_maze_step, the headline: worker shapes (workers per workgrou
 python tools/env_sweep.py --game scrolly_maze --batches 1048576 --steps 40 --variants "auto;w4p1k2:PCX_SM_WAVES=4,PCX_SM_PER_CU=1,PCX_SM_LOCK=2;w2p3k1:PCX_SM_WAVES=2,PCX_SM_PER_CU=3,PCX_SM_LOCK=1;w6p1k3:PCX_SM_WAVES=6,PCX_SM_PER_CU=1,PCX_SM_LOCK=3;w4p2k2:PCX_SM_WAVES=4,PCX_SM_PER_CU=2,PCX_SM_LOCK=2;w3p1k2:PCX_SM_WAVES=3,PCX_SM_PER_CU=1,PCX_SM_LOCK=2;w5p1k2:PCX_SM_WAVES=5,PCX_SM_PER_CU=1,PCX_SM_LOCK=2;w6p1k2:PCX_SM_WAVES=6,PCX_SM_PER_CU=1,PCX_SM_LOCK=2;w4p1k3:PCX_SM_WAVES=4,PCX_SM_PER_CU=1,PCX_SM_LOCK=3;w8p1k2:PCX_SM_WAVES=8,PCX_SM_PER_CU=1,PCX_SM_LOCK=2" 2>&1 | $Q
 } > $OUT/r06_stream_kernels_sweeps.txt
 {
-echo "# pcx_generic_step: the one-group shape (PCX_GENERIC_PW=0), its logic phase alone (PCX_DEBUG=2), pcx_generic_step_pw's worker counts"
+echo "# pcx_generic_step (specialised build): what the engine settles on (auto: the tuner picks waves per workgroup and the render loop),"
+echo "# owner codes / masks forced, the round-5 build (no sprite registers, masks), the logic phase alone (PCX_DEBUG=2), pcx_generic_step_pw"
 export PCX_FORCE_GENERIC=1
-V="old:PCX_GENERIC_PW=0;old_logic:PCX_GENERIC_PW=0,PCX_DEBUG=2;l4r2:PCX_GENERIC_PW=1,PCX_GENERIC_PW_LOGIC=4,PCX_GENERIC_PW_RENDER=2;l6r2:PCX_GENERIC_PW=1,PCX_GENERIC_PW_LOGIC=6,PCX_GENERIC_PW_RENDER=2;l8r2:PCX_GENERIC_PW=1,PCX_GENERIC_PW_LOGIC=8,PCX_GENERIC_PW_RENDER=2;l6r3:PCX_GENERIC_PW=1,PCX_GENERIC_PW_LOGIC=6,PCX_GENERIC_PW_RENDER=3;l3r1x2:PCX_GENERIC_PW=1,PCX_GENERIC_PW_LOGIC=3,PCX_GENERIC_PW_RENDER=1,PCX_GENERIC_PW_PER_CU=2;l6r2_logic:PCX_GENERIC_PW=1,PCX_GENERIC_PW_LOGIC=6,PCX_GENERIC_PW_RENDER=2,PCX_DEBUG=2;w1:PCX_GENERIC_PW=0,PCX_GENERIC_WAVES=1;w2:PCX_GENERIC_PW=0,PCX_GENERIC_WAVES=2;w4:PCX_GENERIC_PW=0,PCX_GENERIC_WAVES=4"
+V="auto;codes:PCX_GENERIC_CODES=1;masks:PCX_GENERIC_CODES=0;r5_build:!PCX_GENERIC_SPEC_DEFS=-DPCX_X_NO_SPRITE_REGS,PCX_GENERIC_CODES=0;logic:PCX_DEBUG=2;pw_l6r2:PCX_GENERIC_PW=1,PCX_GENERIC_PW_LOGIC=6,PCX_GENERIC_PW_RENDER=2;w1:PCX_GENERIC_WAVES=1;w2:PCX_GENERIC_WAVES=2;w4:PCX_GENERIC_WAVES=4"
 python tools/env_sweep.py --fixture warehouse_L0 --batches 262144 --variants "$V" 2>&1 | $Q
 python tools/env_sweep.py --fixture walkers_scroll_groups --cardinal-fields 2 --batches 262144 --variants "$V" 2>&1 | $Q
 python tools/env_sweep.py --fixture directives_z_order --batches 262144 --variants "$V" 2>&1 | $Q
 python tools/env_sweep.py --fixture marauders_custom_A --batches 32768,262144 --variants "$V" 2>&1 | $Q
+python tools/env_sweep.py --fixture hello_world --batches 262144 --variants "auto;codes:PCX_GENERIC_CODES=1;masks:PCX_GENERIC_CODES=0" 2>&1 | $Q
 echo "# phase timers (PCX_DEBUG=8; +2: logic only), cycles per group of 64 environments"
 for f in warehouse_L0 walkers_scroll_groups marauders_custom_A; do
   cf=0; [ $f = walkers_scroll_groups ] && cf=2
-  for v in "PCX_GENERIC_PW=0" "PCX_GENERIC_PW=1 PCX_GENERIC_PW_LOGIC=6 PCX_GENERIC_PW_RENDER=2"; do
-    for d in 8 10; do
-      echo "== $f $v PCX_DEBUG=$d"; env $v PCX_DEBUG=$d python tools/env_sweep.py --fixture $f --cardinal-fields $cf --batches 262144 --steps 40 --repeats 1 2>&1 | grep "pcx generic" | tail -1
-    done
+  for defs in "" "-DPCX_X_NO_SPRITE_REGS"; do
+    echo "== $f PCX_GENERIC_SPEC_DEFS='$defs'"; PCX_GENERIC_SPEC_DEFS="$defs" PCX_DEBUG=8 python tools/env_sweep.py --fixture $f --cardinal-fields $cf --batches 262144 --steps 40 --repeats 1 2>&1 | grep "pcx generic" | tail -1
   done
 done
 unset PCX_FORCE_GENERIC

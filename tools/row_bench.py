@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One row of bench.py's line by itself (what tools/profile_r06.sh runs under rocprofv3, so that the only step kernel in a
 trace is the row's own): prints the row's JSON.
-  python tools/row_bench.py headline | scrolly_131072 | scrolly_262144 | scrolly_4096 | marauders_32768 | marauders_262144 |
+  python tools/row_bench.py headline | scrolly_131072 | scrolly_262144 | scrolly_custom_H_131072 | scrolly_L1_131072 | scrolly_4096 | marauders_32768 | marauders_262144 |
                             warehouse_262144 | better_scrolly_65536 | hello_world_1048576 | marauders_custom_A | walkers | warehouse_generic"""
 import json
 import os
@@ -15,6 +15,8 @@ ROWS = {  # name -> measure_config arguments (game, level, batch, steps, warmup)
     'headline': ('scrolly_maze', 0, 1048576, 100, 10, {}),
     'scrolly_131072': ('scrolly_maze', 0, 131072, 200, 20, {}),
     'scrolly_262144': ('scrolly_maze', 0, 262144, 200, 20, {}),
+    'scrolly_custom_H_131072': ('scrolly_custom_H', 0, 131072, 200, 20, {}),
+    'scrolly_L1_131072': ('scrolly_maze', 1, 131072, 200, 20, {}),
     'scrolly_4096': ('scrolly_maze', 0, 4096, 200, 20, {}),
     'marauders_32768': ('marauders', 0, 32768, 200, 20, {}),
     'marauders_262144': ('marauders', 0, 262144, 50, 10, {}),
