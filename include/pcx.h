@@ -337,7 +337,8 @@ const char* pcx_engine_kernel_name(const pcx_engine* e);
  * same with the shipped level's constants compiled in (pcx_debug_scrolly_consts), 7 the same on the instance compiled for
  * the engine's own level at run time (pcx_scrolly_maze_specialise_check), 10 cooperative (several waves per
  * group), 12 the cooperative shape walking several steps per launch, 13 the persistent workers walking several steps per
- * launch (every worker keeps its units from step to step), 20 shape-generic instance (1, 2, 4 and 11 were
+ * launch (every worker keeps its units from step to step), 20 shape-generic instance, 21 the instance compiled for the engine's
+ * own board shape and level at run time (1, 2, 4 and 11 were
  * launch shapes of rounds 1-4, measured slower and removed in round 5); pcx_generic_step: 30 the
  * table-driven build, 31 the build specialised for the engine's template at run time; -1: the backend does not say. */
 int32_t pcx_engine_launch_shape(const pcx_engine* e);
@@ -358,10 +359,12 @@ int pcx_generic_specialise_check(const pcx_template* t, char* log, int64_t log_b
 /* The same for the kernel pcx_scrolly_maze_step, round 6: a scrolly_maze level of one's own on the example's 10x30 board with its
  * 'abcP' cast (a new entry of examples/scrolly_maze.py MAZES_ART, scrolly_maze.py:212-242) gets, at pcx_engine_create, the two
  * instances the shipped levels have in the library -- the persistent owner-code one and the cooperative small-batch one with
- * the level's constants compiled in (engines of PCX_SM_JIT_MIN = 4,096 environments and more; PCX_SM_JIT=0 / 1 never /
- * always; the same cache).  This entry plans the template and compiles that build without an engine and WITHOUT a device.
- * PCX_E_UNSUPPORTED with an empty log: a template of another shape (it keeps the shape-generic instance).  No reference
- * counterpart. */
+ * the level's constants compiled in (launch shape 7) -- and a level of ANOTHER board or cast (planes of whole dwords, one to six
+ * sprites) one instance with its shape as template arguments and its constants compiled in (launch shape 21), where the library
+ * has the shape-generic instances only.  Engines of PCX_SM_JIT_MIN = 4,096 environments and more; PCX_SM_JIT=0 / 1 never /
+ * always; the same cache.  This entry plans the template and compiles that build without an engine and WITHOUT a device.
+ * PCX_E_UNSUPPORTED with an empty log: a shipped level (its instances are part of the library), a template of another game,
+ * a board the static-shape code does not take.  No reference counterpart. */
 int pcx_scrolly_maze_specialise_check(const pcx_template* t, char* log, int64_t log_bytes, int64_t* code_bytes);
 /* Build-time aid (no reference counterpart): pcx_scrolly_maze_step exists once more per shipped level with the constants of
  * that level (examples/scrolly_maze.py, MAZES_ART[0..2]) compiled in -- csrc/pcx_sm_shipped.h, generated by

@@ -1407,6 +1407,9 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
 #else
     auto WB = [&](int w, uint32_t v) { st[w * srow] = v; };
 #endif
+#ifdef PCX_X_WB_PRIO  // (experiment: the logic wave's row stores at raised issue priority against the streaming waves of its SIMD)
+    __builtin_amdgcn_s_setprio(3);
+#endif
     WB(W_RNG, draws);
     if (k.w_next >= 0) WB(k.w_next, (uint32_t)x.next);
     WB(W_FRAME, (uint32_t)x.frame);
@@ -1436,6 +1439,9 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
     out.done[env] = (uint8_t)x.game_over;
     out.frame[env] = x.frame;
     out.error[env] = (uint8_t)x.err;
+#ifdef PCX_X_WB_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
     if (timing) c_sec[2] = __builtin_readcyclecounter() - t_wb;  // write-back
     const unsigned long long t_occ = timing ? __builtin_readcyclecounter() : 0ull;
@@ -1699,6 +1705,9 @@ __global__ __launch_bounds__(8 * WAVE) __attribute__((amdgpu_waves_per_eu(PCX_X_
   }
 }
 
+// (a run-time build holds this second kernel only when the engine asks for it -- PCX_GENERIC_PW=1 while it is created adds
+// -DPCX_GENERIC_WITH_PW: the shape is opt-in, and leaving it out halves hiprtc's time per template)
+#if !defined(PCX_GENERIC_SPEC) || defined(PCX_GENERIC_WITH_PW)
 // ---------------------------------------------------------------------------
 // Persistent workers with the logic phase DECOUPLED from the render phase (round 6).
 //
@@ -1804,6 +1813,8 @@ __global__ __launch_bounds__(16 * WAVE) void pcx_generic_step_pw(const Consts k_
     }
   }
 }
+
+#endif  // pcx_generic_step_pw
 
 }  // namespace gen
 }  // namespace pcx

@@ -88,13 +88,42 @@ def test_run_time_build_compiles_without_a_device_and_is_cached(tmp_path):
   assert scan.scan_kernel(files[0], 'pcx_scrolly_maze_step', [(i, l) for i, l in enumerate(lines, 1)]) == []
 
 
-def test_shipped_levels_and_other_shapes_are_refused_without_a_compile(tmp_path):
-  for name in ('scrolly_maze_L0', 'scrolly_maze_L2', 'scrolly_custom_B', 'scrolly_custom_G', 'warehouse_L0'):
+def test_shipped_levels_and_other_games_are_refused_without_a_compile(tmp_path):
+  # (unoccluded layers: the raw-mask render path exists with a run-time shape only -- such levels keep the shape-generic instance)
+  for name in ('scrolly_maze_L0', 'scrolly_maze_L2', 'warehouse_L0', 'better_scrolly_maze_L1', 'scrolly_custom_A_unoccluded', 'scrolly_maze_L1_unoccluded'):
     rc, size, log, dt = check(helpers.load_template(name), tmp_path)
     assert rc == N.E_UNSUPPORTED and size == 0 and log == '' and dt < 5.0, (name, rc, log)
+  # a board whose planes are not whole dwords (3 x 7 cells): the static-shape code paths do not take it
+  t = helpers.load_template('scrolly_custom_D')
+  t.rows, t.cols = 3, 7
+  rc, size, log, _ = check(t, tmp_path)
+  assert rc != 0 and size == 0
   assert not os.path.exists(tmp_path) or not os.listdir(tmp_path)
   with pytest.raises(NotImplementedError):
     helpers.load_template('scrolly_maze_L1').prebuild()
+
+
+OTHER_SHAPES = ['scrolly_custom_A', 'scrolly_custom_B', 'scrolly_custom_C', 'scrolly_custom_D', 'scrolly_custom_E', 'scrolly_custom_F', 'scrolly_custom_G']
+
+
+def test_levels_of_other_shapes_get_one_instance_with_the_shape_as_template_arguments(tmp_path):
+  """Other boards, one to six sprites, other z-orders (oracle/custom_levels.py): libpcx.so steps them with
+  the shape-generic instances (every stride a run-time value: 36-60 k instructions for four to six sprites); the run-time
+  build is ONE instance with the shape as template arguments and the constants compiled in (launch shape 21)."""
+  from concurrent.futures import ThreadPoolExecutor
+  os.environ['PCX_JIT_CACHE'] = str(tmp_path)
+  try:
+    def one(name):
+      ct, keep = helpers.load_template(name).to_ctypes()
+      log, n = ctypes.create_string_buffer(8192), ctypes.c_int64(0)
+      return N.lib().pcx_scrolly_maze_specialise_check(ctypes.byref(ct), log, len(log), ctypes.byref(n)), int(n.value), log.value.decode()
+    with ThreadPoolExecutor(4) as pool:
+      results = list(pool.map(one, OTHER_SHAPES))
+  finally:
+    del os.environ['PCX_JIT_CACHE']
+  for name, (rc, size, log) in zip(OTHER_SHAPES, results):
+    assert rc == 0 and 8192 < size < 131072, (name, rc, log[:1500])  # (a third of the shape-generic instance's code)
+  assert len(os.listdir(tmp_path)) == len(OTHER_SHAPES)
 
 
 def test_a_level_with_six_coin_words_builds_the_cooperative_instance_only(tmp_path):
@@ -202,3 +231,25 @@ def test_a_large_batch_takes_the_run_time_instance_by_itself_and_equals_the_othe
     for name in ('reward', 'reward_set', 'discount', 'done', 'frame'):
       np.testing.assert_array_equal(hip.eng.buffers[name].tensor[off:off + K].cpu().numpy(), orc.read(name), err_msg=name)
   assert not hip.eng.buffers['error'].tensor.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', OTHER_SHAPES)
+def test_run_time_instances_of_other_shapes_match_the_reference_and_the_oracle(name, monkeypatch):
+  """The reference's trace of the level and 96 steps of 1,100 environments against the oracle, single steps and launches left to
+  the engine, through the instance compiled for the level (PCX_SM_JIT=1 whatever the batch): launch shape 21."""
+  _, HipAdapter, Knobs, OracleAdapter, assert_same, raw_shape_of = _gpu()
+  monkeypatch.setenv('PCX_SM_JIT', '1')
+  helpers.replay_trace(HipAdapter, helpers.load_trace(name))
+  t = helpers.load_template(name)
+  B = 1100
+  hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
+  hip.reset(); orc.reset()
+  assert_same(hip, orc, 'frame 0')
+  t0 = 0
+  while t0 < 96:
+    n = 1 if t0 < 24 else 8
+    hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
+    assert raw_shape_of(hip) == 21
+    t0 += n
+    assert_same(hip, orc, '%s after step %d' % (name, t0))

@@ -26,7 +26,7 @@ python tools/env_sweep.py --game scrolly_maze --batches 1048576 --steps 40 --var
 echo "# pcx_generic_step (specialised build): what the engine settles on (auto: the tuner picks waves per workgroup and the render loop),"
 echo "# owner codes / masks forced, the round-5 build (no sprite registers, masks), the logic phase alone (PCX_DEBUG=2), pcx_generic_step_pw"
 export PCX_FORCE_GENERIC=1
-V="auto;codes:PCX_GENERIC_CODES=1;masks:PCX_GENERIC_CODES=0;r5_build:!PCX_GENERIC_SPEC_DEFS=-DPCX_X_NO_SPRITE_REGS,PCX_GENERIC_CODES=0;logic:PCX_DEBUG=2;pw_l6r2:PCX_GENERIC_PW=1,PCX_GENERIC_PW_LOGIC=6,PCX_GENERIC_PW_RENDER=2;w1:PCX_GENERIC_WAVES=1;w2:PCX_GENERIC_WAVES=2;w4:PCX_GENERIC_WAVES=4"
+V="auto;codes:PCX_GENERIC_CODES=1;masks:PCX_GENERIC_CODES=0;r5_build:!PCX_GENERIC_SPEC_DEFS=-DPCX_X_NO_SPRITE_REGS,PCX_GENERIC_CODES=0;logic:PCX_DEBUG=2;pw_l6r2:!PCX_GENERIC_PW=1,PCX_GENERIC_PW_LOGIC=6,PCX_GENERIC_PW_RENDER=2;w1:PCX_GENERIC_WAVES=1;w2:PCX_GENERIC_WAVES=2;w4:PCX_GENERIC_WAVES=4"
 python tools/env_sweep.py --fixture warehouse_L0 --batches 262144 --variants "$V" 2>&1 | $Q
 python tools/env_sweep.py --fixture walkers_scroll_groups --cardinal-fields 2 --batches 262144 --variants "$V" 2>&1 | $Q
 python tools/env_sweep.py --fixture directives_z_order --batches 262144 --variants "$V" 2>&1 | $Q
