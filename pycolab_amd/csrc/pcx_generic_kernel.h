@@ -60,9 +60,6 @@ struct Consts {
   int32_t l_wcorner;              // fused croppers: [MAX_FUSED_CROPPERS][lane] window corners (pcx_stream.h WCORNER_NONE)
   int32_t l_inbox;                // where the group's scalar state words land by LDS-DMA: [IB_ROWS + (NS + 3) / 4][lane], over what the render phase reads later
   int32_t l_bdcode;               // owner codes (pcx_stream.h stream_codes): the backdrop's code dwords [QW], a staged table (-1: more than 16 characters)
-  int32_t state_quad;             // the state words' layout in HBM (round 6): 1 = quad-interleaved, word w of environment e at
-                                  // state[(e / 64) * state_unit + (w / 4) * 256 + (e % 64) * 4 + w % 4] -- a group's rows leave in 16-byte
-                                  // stores (the specialised build) and come in by LDS-DMA with a 16-byte lane stride; 0 = Ptrs::state_row
   int32_t l_codes;                // pcx_generic_step rendering from owner codes (round 6): the group's code dwords [64][QW | 1], laid over the per-lane
                                   // arrays that are dead by the time the logic phase writes them (-1: not laid out -- unoccluded layers, more than 16 characters)
   uint8_t chars[PCX_MAX_CHARS];   // character of layer plane 1 + i
@@ -1194,10 +1191,7 @@ __device__ __forceinline__ void dma_state_rows(const Consts& k, const Ptrs& P, c
     const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)stream::lds_byte_address(lds));
     const uint32_t vo = 4u * (uint32_t)lane;
     const int64_t bpw = P.state_row;
-    auto row = [&](int word, int lds_word) {
-      if (k.state_quad) stream::lds_dma_row(sb + (word >> 2) * (4 * WAVE) + (word & 3), 4u * vo, l0 + 4u * (uint32_t)(lds_word + off));  // (lane stride 16 bytes)
-      else stream::lds_dma_row(sb + (int64_t)word * bpw, vo, l0 + 4u * (uint32_t)(lds_word + off));
-    };
+    auto row = [&](int word, int lds_word) { stream::lds_dma_row(sb + (int64_t)word * bpw, vo, l0 + 4u * (uint32_t)(lds_word + off)); };
     for (int w = 0; w < W_SPRITES; ++w) row(w, k.l_inbox + w * WAVE);
     for (int s = 0; s < k.NS; ++s) row(W_SPRITES + s, k.l_pos + s * WAVE);
     for (int w = 0; w < (k.NS + 3) / 4; ++w) row(k.w_sflags + w, k.l_inbox + (IB_SFLAGS + w) * WAVE);
@@ -1388,7 +1382,6 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
     if (timing) c_sec[1] = __builtin_readcyclecounter() - t_play;  // update groups
     const unsigned long long t_wb = timing ? __builtin_readcyclecounter() : 0ull;
     // ---- _apply_and_clear_plot + state write-back ---------------------------
-    uint32_t zw0 = 0, zw1 = 0;
     if (k.zdyn) {  // engine.py:796-835; the repaint it asks for (:632-637) is the render phase below
       apply_z_updates(x);
       uint32_t z0 = 0, z1 = 0;
@@ -1396,26 +1389,27 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
         const uint32_t t = l.zord[z * WAVE + lane] & 0xFu;
         if (z < 8) z0 |= t << (4 * z); else z1 |= t << (4 * (z - 8));
       }
-      zw0 = z0; zw1 = z1;
+      st[k.w_z * srow] = z0;  // (before WB is declared: two words of the games that change the z-order)
+      st[(k.w_z + 1) * srow] = z1;
     }
     flags = (x.game_over ? F_OVER : 0u) | ((x.err & 7u) << F_ERR_SHIFT) | ((uint32_t)((dxv + 1) & 0xFF) << 8);
-    // The state words go home.  Quad layout (Consts::state_quad) in the specialised build: every word is parked in a register list
-    // (indices are compile-time constants once the loops below are unrolled) and the group's rows leave as NW / 4 16-byte stores --
-    // a quarter of the instructions that otherwise wait their turn behind the CU's plane stores (profiles/r06_generic.md section 3).
-#ifdef PCX_GENERIC_SPEC
-    constexpr bool QUADX = spec::K.state_quad != 0;
-    constexpr int NWQ = ((spec::K.NW + 3) & ~3) > 0 ? ((spec::K.NW + 3) & ~3) : 4;
-    RegList<uint32_t, QUADX ? NWQ : 1> wbq{};
-#endif
-    uint32_t* const stq = P.state + (env0 >> 6) * P.state_unit + lane * 4;  // (quad layout: word w at stq[(w / 4) * 256 + w % 4])
-    auto WB = [&](int w, uint32_t v) {
-#ifdef PCX_GENERIC_SPEC
-      if constexpr (QUADX) { reg_put(wbq, w, v); return; }
-#endif
-      if (k.state_quad) stq[(w >> 2) * (4 * WAVE) + (w & 3)] = v;
-      else st[w * srow] = v;
+#if defined(PCX_GENERIC_SPEC) && defined(PCX_X_WB4)
+    // TIMING EXPERIMENT ONLY (results are wrong: the state never advances): the state words leave in 16-byte stores, four
+    // words per lane and instruction, into the second half of a doubled allocation -- what a quad-interleaved state layout would cost
+    RegList<uint32_t, 4> wbq{};
+    int wbi = 0;
+    uint32_t* const wb_base = P.state + (size_t)k.NW * bp + ((size_t)(env0 >> 6) * (size_t)((k.NW + 3) / 4 + 1)) * 256 + lane * 4;
+    auto WB = [&](int, uint32_t v) {
+      reg_put(wbq, wbi & 3, v);
+      if ((wbi & 3) == 3) *reinterpret_cast<uint4*>(wb_base + (size_t)(wbi >> 2) * 256) = make_uint4(wbq.head, wbq.tail.head, wbq.tail.tail.head, wbq.tail.tail.tail.head);
+      ++wbi;
     };
-    if (k.zdyn) { WB(k.w_z, zw0); WB(k.w_z + 1, zw1); }
+#else
+    auto WB = [&](int w, uint32_t v) { st[w * srow] = v; };
+#endif
+#ifdef PCX_X_WB_PRIO  // (experiment: the logic wave's row stores at raised issue priority against the streaming waves of its SIMD)
+    __builtin_amdgcn_s_setprio(3);
+#endif
     WB(W_RNG, draws);
     if (k.w_next >= 0) WB(k.w_next, (uint32_t)x.next);
     WB(W_FRAME, (uint32_t)x.frame);
@@ -1430,31 +1424,24 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
       for (int j = 0; j < 4; ++j) if (4 * w + j < k.NS) f |= (sflg(x, 4 * w + j) & 0xFF) << (8 * j);
       WB((k.w_sflags + w), f);
     }
-    PCX_SPEC_UNROLL
     for (int i2 = 0; i2 < ndw; ++i2) WB((k.w_drapes + i2), l.cur[i2 * WAVE + lane]);
     if (k.has_scroll) {
       WB(k.w_scroll, x.registered);
-      PCX_SPEC_UNROLL
       for (int d = 0; d < k.ND; ++d) WB((k.w_scroll + 1 + d), l.corner[d * WAVE + lane]);
-      PCX_SPEC_UNROLL
       for (int s = 0; s < k.NS; ++s) {
         WB((k.w_scroll + 1 + k.ND + 2 * s), l.pmask[s * WAVE + lane]);
         WB((k.w_scroll + 2 + k.ND + 2 * s), l.pframe[s * WAVE + lane]);
       }
     }
-#ifdef PCX_GENERIC_SPEC
-    if constexpr (QUADX) {
-#pragma unroll
-      for (int g = 0; g < NWQ / 4; ++g)
-        *reinterpret_cast<uint4*>(stq + g * (4 * WAVE)) = make_uint4(reg_get(wbq, 4 * g), reg_get(wbq, 4 * g + 1), reg_get(wbq, 4 * g + 2), reg_get(wbq, 4 * g + 3));
-    }
-#endif
     out.reward[env] = x.reward;
     out.reward_set[env] = (uint8_t)x.reward_set;
     out.discount[env] = x.discount;
     out.done[env] = (uint8_t)x.game_over;
     out.frame[env] = x.frame;
     out.error[env] = (uint8_t)x.err;
+#ifdef PCX_X_WB_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
     if (timing) c_sec[2] = __builtin_readcyclecounter() - t_wb;  // write-back
     const unsigned long long t_occ = timing ? __builtin_readcyclecounter() : 0ull;
