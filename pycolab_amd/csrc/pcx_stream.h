@@ -455,6 +455,7 @@ __device__ __forceinline__ void stream_planes_mode(const PlaneMap<NS, ND, NB>& p
   for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
   const int role = two_pass ? pass : -1;  // 0: the uint8 planes, 1: the float32 planes, -1: both
   e = e_0; q = q_0; voff = voff_0; eF = eF_0; foff = foff_0;
+  uint32_t ids_pf = cell_ids != nullptr ? cell_ids[q_0] : 0u;  // (the first iteration's coin ids; later ones are fetched an iteration ahead)
   int hw_it = -1;  // channels last: the iteration whose floats wait in the other exchange area
   uint32_t hw_sel = 0;
 #pragma unroll 1
@@ -469,6 +470,8 @@ __device__ __forceinline__ void stream_planes_mode(const PlaneMap<NS, ND, NB>& p
       eF = wrap ? eF + FWP : eF;
       foff = wrap ? foff + wrap_foff : foff;
     }
+    const uint32_t ids_now = ids_pf;  // (rotated BEFORE a skipped lane leaves the iteration: its next one must not see stale ids)
+    if (cell_ids != nullptr) ids_pf = cell_ids[q];  // (q: the NEXT iteration's dword already, always inside the table)
     // (channels last: a skipped lane still takes part in the exchange below -- its stores are predicated instead)
     const bool skipped = any_skip && skip[e_now] != 0;
     if (skipped && !hwc) continue;
@@ -503,14 +506,22 @@ __device__ __forceinline__ void stream_planes_mode(const PlaneMap<NS, ND, NB>& p
     for (int dd = 0; dd < ND; ++dd) {
       uint32_t bits;
       if (cell_ids != nullptr) {  // (uniform; resolved at compile time where the caller passes a constant)
-        const uint32_t ids = cell_ids[q_now];
-        bits = 0;
-        if (ids != 0xFFFFFFFFu) {
+        // Round 6: BRANCH-FREE, all four mask words requested at once, the dword's ids fetched an iteration ahead (ids_now).  The
+        // four `if (id != 0xFF)` of rounds 2-5 compiled to four divergent branches, each with its own ds_read + s_waitcnt: with 92
+        // coins on 4,005 cells nearly every wave iteration (256 cells) holds a coin, so a wave paid five to six DEPENDENT LDS round
+        // trips per iteration -- ~1,200 cycles for eight stores, one wave per SIMD: the latency bound of
+        // pcx_better_scrolly_step (profiles/r06_tuning.md section 6).
+        uint32_t w4[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t id = (ids >> (8 * j)) & 0xFFu;
-            if (id != 0xFFu) bits |= ((flat[eF_now + (id >> 5)] >> (id & 31)) & 1u) << j;
-          }
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t id = (ids_now >> (8 * j)) & 0xFFu;
+          w4[j] = flat[eF_now + (id == 0xFFu ? 0u : id >> 5)];
+        }
+        bits = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t id = (ids_now >> (8 * j)) & 0xFFu;
+          bits |= (id == 0xFFu ? 0u : (w4[j] >> (id & 31)) & 1u) << j;
         }
       } else {
         bits = (flat[dd * WAVE * FWP + eF_now + (q_now >> 3)] >> ((q_now & 7) * 4)) & 0xFu;

@@ -34,9 +34,10 @@ def knobs(monkeypatch, shape):
   monkeypatch.setenv('PCX_GENERIC_PW_DYNAMIC', str(dynamic))
 
 
-# every game in the plain shape, and every other shape on three of the games (the shapes differ in scheduling, which no game's
+# every other game in the plain shape (round 6: the shape is opt-in; the games left out are stepped by the other shapes below),
+# and every other shape on three of the games (the shapes differ in scheduling, which no game's
 # rules touch: fifteen games x five shapes re-proved the same code 75 times and cost the GPU suite two minutes)
-CASES = [(name, '6x2') for name in GAMES] + [(GAMES[(3 * i + j) % len(GAMES)], shape) for i, shape in enumerate(s for s in sorted(SHAPES) if s != '6x2')
+CASES = [(name, '6x2') for name in GAMES[::2] + ['marauders']] + [(GAMES[(3 * i + j) % len(GAMES)], shape) for i, shape in enumerate(s for s in sorted(SHAPES) if s != '6x2')
                                              for j in range(3)]
 
 

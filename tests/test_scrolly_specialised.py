@@ -187,7 +187,7 @@ def test_cooperative_shape_on_the_run_time_instance_matches_oracle(B, jit):
     hip, orc = HipAdapter(t, B), OracleAdapter(t, B)
     hip.reset(); orc.reset()
     t0 = 0
-    for n in (1, 1, 1, 7, 64, 3, 1, 60):
+    for n in ((1, 1, 1, 7, 64, 3, 1, 60) if B < 10000 else (1, 1, 7, 33, 1)):  # (the largest batch: fewer steps, the oracle is what it waits for)
       hip.step_hashed(0x5EED, t0, n); orc.step_hashed(0x5EED, t0, n)
       if os.environ.get('PCX_COOP_BELOW') != '0':  # (a suite run with the cooperative shape forced off compares results only)
         assert raw_shape_of(hip) == (12 if n > 1 else 10)
