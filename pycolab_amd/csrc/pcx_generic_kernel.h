@@ -940,10 +940,18 @@ __device__ __forceinline__ void render_planes(const Consts& k, const L& l, const
   for (int t = 0; t < NTC; ++t) {
     src[t] = ch4[t] = plane[t] = 0;
     if (t >= NT) continue;
-    const uint32_t kind = l.things[t * T_WORDS + T_KIND], idx = l.things[t * T_WORDS + T_IDX];
+    // (the specialised build: from the constants -- whether thing t is a sprite or a drape is then known where the loop below
+    // branches on it, its LDS reads are all requested at the top of an iteration instead of one thing after the other, each behind
+    // its own s_waitcnt: the "LDS-latency-bound per wave" of profiles/r06_generic.md section 2)
+#ifdef PCX_GENERIC_SPEC
+    auto tw = [&](int f) { return spec::TAB[spec::K.l_things + t * T_WORDS + f]; };
+#else
+    auto tw = [&](int f) { return l.things[t * T_WORDS + f]; };
+#endif
+    const uint32_t kind = tw(T_KIND), idx = tw(T_IDX);
     src[t] = uni32(kind == 0 ? (0x80000000u | (idx * WAVE)) : idx * WAVE * (uint32_t)FWP);
-    ch4[t] = uni32(l.things[t * T_WORDS + T_CH] * 0x01010101u);
-    plane[t] = uni32((1 + l.things[t * T_WORDS + T_LAYER]) * (uint32_t)pitch);
+    ch4[t] = uni32(tw(T_CH) * 0x01010101u);
+    plane[t] = uni32((1 + tw(T_LAYER)) * (uint32_t)pitch);
   }
   constexpr int MAXB = 8;
   const int NB = k.n_bchars;
