@@ -113,7 +113,7 @@ namespace spec {
 #if defined(PCX_GENERIC_SPEC) && defined(PCX_SPEC_SREGS)
 #define PCX_SREGS 1
 #endif
-#if defined(PCX_GENERIC_SPEC) && defined(PCX_X_PROBE_UNROLL)
+#if defined(PCX_GENERIC_SPEC) && (defined(PCX_X_PROBE_UNROLL) || defined(PCX_X_EGO_UNROLL))  // (EGO: only the egocentric walker's eight neighbours)
 #define PCX_PROBE_UNROLL _Pragma("unroll")
 #else
 #define PCX_PROBE_UNROLL _Pragma("unroll 1")
