@@ -953,6 +953,29 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
     uint8_t* const obase = uniform_ptr(fw.out + (size_t)env0 * ostride);
     const uint32_t pad = (uint32_t)(fw.rule.pad_char & 0xFF);
     const uint32_t magic_qw = 0xFFFFFFFFu / qw, magic_cols = 0xFFFFFFFFu / (uint32_t)cols;  // floor(2^32 / d) or one less
+    // (round 6) what the loop needs of the window's feature stack, read ONCE: `fw` lives in global memory that the loop's own stores
+    // may alias as far as the compiler knows, so `fw.feat` / `fw.feat_skip` inside the loop were a global load + s_waitcnt vmcnt(0)
+    // per iteration -- and vmcnt counts the plane stores too: every iteration waited for all of its predecessor's stores to land
+    float* const feat_out = fw.feat;
+    const int feat_skip_w = feat_out ? fw.feat_skip : 0, feat_depth_w = feat_out ? fw.feat_depth : 0, feat_hwc_w = feat_out ? fw.feat_hwc : 0;
+    // ... and the stack's characters as packed dwords (the loops over the layers read them per iteration: the same wait)
+    constexpr int FCW = (crop::MAX_FUSED_FEATURES + 3) / 4;
+    uint32_t fchw[FCW];
+#pragma unroll
+    for (int i = 0; i < FCW; ++i) {
+      fchw[i] = 0;
+      if (feat_out)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * i + j < crop::MAX_FUSED_FEATURES) fchw[i] |= (uint32_t)fw.feat_ch[4 * i + j] << (8 * j);
+      fchw[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)fchw[i]);
+    }
+    auto feat_char = [&](uint32_t kk) {  // (kk is wave-uniform: a scalar select chain)
+      uint32_t w = fchw[0];
+#pragma unroll
+      for (int i = 1; i < FCW; ++i) w = (kk >> 2) == (uint32_t)i ? fchw[i] : w;
+      return (w >> (8u * (kk & 3u))) & 0xFFu;
+    };
     // plane bases in SGPRs, one shared 32-bit lane offset (as in the board loop)
     uint8_t* pb_s[NS > 0 ? NS : 1];
     uint8_t* pb_d[ND > 0 ? ND : 1];
@@ -1059,7 +1082,7 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
       if (active) {
         const uint32_t voff = e * ostride + 4u * q;
         auto put = [&](uint8_t* base, uint32_t v) { saddr_store_dword<true>(voff, v, base); };  // (compute-bound loop)
-        const int fskip = fw.feat ? fw.feat_skip : 0;
+        const int fskip = feat_skip_w;
         if (fskip < 2) put(obase, od);
         if (fskip < 1) {
 #pragma unroll
@@ -1070,17 +1093,17 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
           for (int b = 0; b < NB; ++b)
             if (b < nbv) put(pb_b[b], eq01(od, bchar_ch4[b]));
         }
-        if (fw.feat) {
+        if (feat_out) {
           // crop -> post-process in this launch: the window's feature stack (rendering.py:610-661 on the cropped
           // observation): layer k of the window is (window board == feat_ch[k]), as float32.  The window's cells
           // are rows x cols exactly (no plane padding in the array): its last dword may hold fewer than four.
-          const uint32_t wcells = (uint32_t)(rows * cols), depth = (uint32_t)fw.feat_depth;
+          const uint32_t wcells = (uint32_t)(rows * cols), depth = (uint32_t)feat_depth_w;
           const uint32_t valid = wcells - 4u * q >= 4u ? 4u : wcells - 4u * q;
-          uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(fw.feat) + (size_t)env0 * depth * wcells * 4u);
+          uint8_t* const fbase = uniform_ptr(reinterpret_cast<uint8_t*>(feat_out) + (size_t)env0 * depth * wcells * 4u);
           const uint32_t fenv = e * depth * wcells * 4u;
-          if (!fw.feat_hwc) {
+          if (!feat_hwc_w) {
             for (uint32_t kk = 0; kk < depth; ++kk) {
-              const uint32_t m = eq01(od, (uint32_t)fw.feat_ch[kk] * 0x01010101u);
+              const uint32_t m = eq01(od, feat_char(kk) * 0x01010101u);
               const uint32_t fo = fenv + (kk * wcells + 4u * q) * 4u;
               if (valid == 4u) {
                 f32x4 f;
@@ -1094,7 +1117,7 @@ __device__ __forceinline__ void stream_windows(const crop::FusedCrops* fc, const
             for (uint32_t j = 0; j < valid; ++j) {
               const uint32_t ch = (od >> (8u * j)) & 0xFFu;
               float* const cellp = reinterpret_cast<float*>(fbase + fenv + (4u * q + j) * depth * 4u);
-              for (uint32_t kk = 0; kk < depth; ++kk) cellp[kk] = ch == (uint32_t)fw.feat_ch[kk] ? 1.0f : 0.0f;
+              for (uint32_t kk = 0; kk < depth; ++kk) cellp[kk] = ch == feat_char(kk) ? 1.0f : 0.0f;
             }
           }
         }
