@@ -499,9 +499,16 @@ __device__ __forceinline__ void stream_planes_mode(const PlaneMap<NS, ND, NB>& p
         }
       }
     };
-    // every LDS read of the iteration is issued up front
+    // every LDS read of the iteration is issued up front -- the sprites' descriptors and the backdrop-only masks BEFORE the drapes'
+    // bits (round 6): where `cell_ids` is a run-time pointer the drape section is a basic block of its own, and reads that follow
+    // it in the source were a second LDS round trip per iteration
     uint32_t d = backdrop4[q_now];
     uint32_t md[ND > 0 ? ND : 1], ms[NS > 0 ? NS : 1], mb[NB > 0 ? NB : 1];
+    uint2 sdv[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sdv[s] = sdesc[s * WAVE + e_now];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) mb[b] = bdmask[b * QWv + q_now];
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) {
       uint32_t bits;
@@ -532,12 +539,7 @@ __device__ __forceinline__ void stream_planes_mode(const PlaneMap<NS, ND, NB>& p
       md[dd] = hi8 - m01;   // 0x01 -> 0xFF per byte
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const uint2 sd = sdesc[s * WAVE + e_now];
-      ms[s] = sd.x == q_now ? sd.y : 0u;
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) mb[b] = bdmask[b * QWv + q_now];
+    for (int s = 0; s < NS; ++s) ms[s] = sdv[s].x == q_now ? sdv[s].y : 0u;
     uint32_t uni = 0;
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) {
