@@ -62,6 +62,7 @@ FIXTURES = {'scrolly_maze': 'scrolly_maze_L%d', 'warehouse': 'warehouse_L%d', 'm
 def cpu_worker(args):
   """TEST INFRASTRUCTURE use of the oracle: timed CPU baseline leg only."""
   template_path, batch, steps, offset = args
+  os.environ['PCX_ORACLE_THREADS'] = '1'  # (one process per core here: the oracle's own threads over environments stay off)
   from oracle import binding
   from pycolab_amd.compiler import GameTemplate
   t = GameTemplate.load(template_path)

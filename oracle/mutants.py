@@ -383,8 +383,8 @@ MUTANTS = [
            killed_by=['crop:better_scrolly_custom_A', 'crop:better_scrolly_custom_B']),
     Mutant('finished_environments_keep_playing', 'engine.py:619-624 / SURVEY 8(d): a finished episode is rebuilt at the next step',
            'pcx_oracle.c',
-           '    if (env->game_over) {\n      if (auto_reset) rc = env_showtime(e, b);\n      else frozen_step(e, b);\n    } else {',
-           '    if (0) {\n    } else {',
+           '      if (env->game_over) { if (c->auto_reset) rc = env_showtime(e, b); else frozen_step(e, b); }\n      else rc = env_play(',
+           '      rc = env_play(',
            killed_by=['crop:better_scrolly_custom_A', 'crop:better_scrolly_custom_B']),
     Mutant('centroid_of_an_invisible_sprite', 'cropping.py:551-560: an invisible sprite has no centroid',
            'pcx_oracle.c',
@@ -553,7 +553,7 @@ def build(mutant, out_dir):
       f.write(text)
     srcs.append(p)
   so = os.path.join(out_dir, 'liboracle_%s.so' % mutant.name)
-  subprocess.check_call([os.environ.get('CC', 'gcc'), '-O1', '-fPIC', '-std=c11', '-w', '-shared', '-I', HERE,
+  subprocess.check_call([os.environ.get('CC', 'gcc'), '-O1', '-fPIC', '-std=c11', '-pthread', '-w', '-shared', '-I', HERE,
                          '-I', os.path.join(HERE, '..', 'include'), '-o', so] + srcs)
   return so
 

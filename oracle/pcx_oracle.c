@@ -8,7 +8,12 @@
  * tricks of the HIP path, so that the two implementations are independent.
  *
  * Each function cites the reference lines it follows (paths under pycolab/).
+ * "One environment at a time" is about the algorithm: the loops over the (independent) environments of a batch are split
+ * over short-lived host threads (for_envs below) so that the test suites do not wait for a single core.
  */
+#ifndef _POSIX_C_SOURCE
+#define _POSIX_C_SOURCE 200809L /* sysconf, pthreads under -std=c11 */
+#endif
 #include "pcx_oracle.h"
 
 #include <limits.h>
@@ -21,6 +26,55 @@ const char* pcxo_last_error(void) { return g_err; }
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof g_err, "%s", msg);
   return code;
+}
+/* Environments are independent (engine.py:102-104: one Engine = one environment; the only random draw is counter-based), so
+ * the loops over them are split over host threads: the GPU suite waits for this oracle, not for the GPU.  The threads live for
+ * ONE call (created and joined inside it) -- a pool that outlives the call, OpenMP's included, does not survive fork(), and the
+ * test harness forks worker processes after the oracle has been used (tests/test_gate_digests.py, oracle/ref_live.py).
+ * PCX_ORACLE_THREADS caps their number (1: everything on the calling thread); batches below OX_PAR_MIN stay there anyway.
+ * An error inside a worker: its message lives in that thread's g_err -- the first code is kept and its message copied over. */
+#include <pthread.h>
+#include <unistd.h>
+#define OX_PAR_MIN 256
+#define OX_MAX_THREADS 32
+static pthread_mutex_t g_err_mu = PTHREAD_MUTEX_INITIALIZER;
+static char g_err_shared[512];
+static void keep_error(int* first, int rc) {
+  if (!rc) return;
+  pthread_mutex_lock(&g_err_mu);
+  if (!*first) { *first = rc; snprintf(g_err_shared, sizeof g_err_shared, "%s", g_err); }
+  pthread_mutex_unlock(&g_err_mu);
+}
+static int finish_error(int first) {
+  if (first) snprintf(g_err, sizeof g_err, "%s", g_err_shared);
+  return first;
+}
+typedef void (*ox_range_fn)(int64_t lo, int64_t hi, void* ctx);
+typedef struct { ox_range_fn fn; int64_t lo, hi; void* ctx; } ox_job;
+static void* ox_job_main(void* p) { ox_job* j = (ox_job*)p; j->fn(j->lo, j->hi, j->ctx); return NULL; }
+static void for_envs(int64_t n, ox_range_fn fn, void* ctx) {
+  int nt = 1;
+  if (n >= OX_PAR_MIN) {
+    long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    nt = cores > OX_MAX_THREADS ? OX_MAX_THREADS : cores < 1 ? 1 : (int)cores;
+    const char* cap = getenv("PCX_ORACLE_THREADS");
+    if (cap && atoi(cap) >= 1 && atoi(cap) < nt) nt = atoi(cap);
+    if ((int64_t)nt > n / 64) nt = (int)(n / 64);
+    if (nt < 1) nt = 1;
+  }
+  if (nt == 1) { fn(0, n, ctx); return; }
+  ox_job jobs[OX_MAX_THREADS];
+  pthread_t th[OX_MAX_THREADS];
+  int started[OX_MAX_THREADS];
+  for (int i = 0; i < nt; ++i) {
+    jobs[i].fn = fn; jobs[i].ctx = ctx; jobs[i].lo = n * i / nt; jobs[i].hi = n * (i + 1) / nt;
+    started[i] = i > 0 && pthread_create(&th[i], NULL, ox_job_main, &jobs[i]) == 0;
+  }
+  fn(jobs[0].lo, jobs[0].hi, ctx);
+  for (int i = 1; i < nt; ++i) {
+    if (started[i]) pthread_join(th[i], NULL);
+    else fn(jobs[i].lo, jobs[i].hi, ctx);  /* (no thread to be had: the range on the calling thread) */
+  }
 }
 
 /* Error bits reported per environment (the reference would have raised). */
@@ -1028,45 +1082,50 @@ void pcxo_engine_destroy(pcxo_engine* e) {
   free(e);
 }
 
+typedef struct { pcxo_engine* e; const uint8_t* mask; int first; } ox_reset_ctx;
+static void ox_reset_range(int64_t lo, int64_t hi, void* p) {
+  ox_reset_ctx* c = (ox_reset_ctx*)p;
+  for (int64_t b = lo; b < hi; ++b)
+    if (!c->mask || c->mask[b]) keep_error(&c->first, env_showtime(c->e, b));
+}
 int pcxo_engine_reset(pcxo_engine* e, const uint8_t* env_mask) {
-  for (int64_t b = 0; b < e->batch; ++b)
-    if (!env_mask || env_mask[b]) {
-      int rc = env_showtime(e, b);
-      if (rc) return rc;
-    }
+  ox_reset_ctx c = {e, env_mask, 0};
+  for_envs(e->batch, ox_reset_range, &c);
+  if (c.first) return finish_error(c.first);
   e->showtime = 1;
   return 0;
 }
 
+/* environments [lo, hi): T steps each (an environment's steps are ordered, the environments are not); actions from the tape
+ * (T == 1) or from the counter hash */
+typedef struct { pcxo_engine* e; const int32_t* actions; int auto_reset; uint64_t seed; int64_t env_offset, t0; int T; int first; } ox_step_ctx;
+static void ox_step_range(int64_t lo, int64_t hi, void* p) {
+  ox_step_ctx* c = (ox_step_ctx*)p;
+  pcxo_engine* e = c->e;
+  const int n = e->t.n_actions;
+  for (int64_t b = lo; b < hi; ++b)
+    for (int t = 0; t < c->T && !c->first; ++t) {
+      ox_env* env = &e->envs[b];
+      int rc = 0;
+      if (env->game_over) { if (c->auto_reset) rc = env_showtime(e, b); else frozen_step(e, b); }
+      else rc = env_play(e, b, c->actions ? c->actions[b]
+                                          : (int)(pcxo_action_hash(c->seed, (uint64_t)(c->env_offset + b), (uint64_t)(c->t0 + t)) % (uint32_t)n));
+      keep_error(&c->first, rc);
+    }
+}
 int pcxo_engine_step(pcxo_engine* e, const int32_t* actions, int auto_reset) {
   if (!e->showtime) return fail(PCX_E_STATE, "oracle: step before reset");
-  for (int64_t b = 0; b < e->batch; ++b) {
-    ox_env* env = &e->envs[b];
-    int rc = 0;
-    if (env->game_over) {
-      if (auto_reset) rc = env_showtime(e, b);
-      else frozen_step(e, b);
-    } else {
-      rc = env_play(e, b, actions[b]);
-    }
-    if (rc) return rc;
-  }
-  return 0;
+  ox_step_ctx c = {e, actions, auto_reset, 0, 0, 0, 1, 0};
+  for_envs(e->batch, ox_step_range, &c);
+  return finish_error(c.first);
 }
 
 int pcxo_engine_step_hashed(pcxo_engine* e, uint64_t seed, int64_t env_offset,
                             int64_t t0, int T, int auto_reset) {
   if (!e->showtime) return fail(PCX_E_STATE, "oracle: step before reset");
-  int n = e->t.n_actions;
-  for (int t = 0; t < T; ++t)
-    for (int64_t b = 0; b < e->batch; ++b) {
-      ox_env* env = &e->envs[b];
-      int rc = 0;
-      if (env->game_over) { if (auto_reset) rc = env_showtime(e, b); else frozen_step(e, b); }
-      else rc = env_play(e, b, (int)(pcxo_action_hash(seed, (uint64_t)(env_offset + b), (uint64_t)(t0 + t)) % (uint32_t)n));
-      if (rc) return rc;
-    }
-  return 0;
+  ox_step_ctx c = {e, NULL, auto_reset, seed, env_offset, t0, T, 0};
+  for_envs(e->batch, ox_step_range, &c);
+  return finish_error(c.first);
 }
 
 int pcxo_engine_buffers(pcxo_engine* e, pcx_buffers* out) {
