@@ -435,7 +435,16 @@ __device__ __forceinline__ bool blocked_at(Ctx& x, int thing, int vr, int vc, in
   if (!on_board(x.k, r, c)) return (tfield(x, thing, T_FLAGS) & TF_CONFINED) != 0;  // EDGE
   const int cell = r * x.k.C + c;
   const int back = (x.l.backdrop4[cell >> 2] >> ((cell & 3) * 8)) & 0xFF;
-  const uint32_t impt = tfield(x, thing, T_IMPT), imp_back = tfield_v(x, thing, T_IMP0 + ((back >> 5) & 3));
+  const uint32_t impt = tfield(x, thing, T_IMPT);
+#ifdef PCX_GENERIC_SPEC
+  // (the walker's four impassable words are constants here: the word of the lane's backdrop character is a select among them, not
+  // a second LDS read that depends on the first -- a probe is ONE LDS round trip)
+  const uint32_t i0 = tfield(x, thing, T_IMP0), i1 = tfield(x, thing, T_IMP1), i2 = tfield(x, thing, T_IMP2), i3 = tfield(x, thing, T_IMP3);
+  const int iw = (back >> 5) & 3;
+  const uint32_t imp_back = iw == 0 ? i0 : iw == 1 ? i1 : iw == 2 ? i2 : i3;
+#else
+  const uint32_t imp_back = tfield_v(x, thing, T_IMP0 + ((back >> 5) & 3));
+#endif
   const uint32_t m = present_at(x, r, c);
   if (m) return (impt >> top_thing(x, m)) & 1u;  // the thing in front decides
   if (back >= 128) return false;  // impassable sets are ASCII (compiler.py); anything else is passable

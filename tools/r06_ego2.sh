@@ -9,11 +9,13 @@ PCX_FORCE_GENERIC=1 python -m pytest tests/test_hip_parity.py -m gpu -q -k "walk
 cat $OUT/tests.txt
 {
 export PCX_FORCE_GENERIC=1
-V="auto;loop:!PCX_GENERIC_SPEC_DEFS=-DPCX_X_NO_EGO_UNROLL"
+V="auto"
 for rep in 1 2; do
 python tools/env_sweep.py --fixture walkers_scroll_groups --cardinal-fields 2 --batches 262144 --variants "$V" 2>&1 | grep -v amdgpu.ids
 done
 python tools/env_sweep.py --fixture walkers_scroll_margins --batches 262144 --variants "$V" 2>&1 | grep -v amdgpu.ids
 python tools/env_sweep.py --fixture walkers_hidden --batches 262144 --variants "$V" 2>&1 | grep -v amdgpu.ids
+python tools/env_sweep.py --fixture warehouse_L0 --batches 262144 --variants "$V" 2>&1 | grep -v amdgpu.ids
+python tools/env_sweep.py --fixture marauders_custom_A --batches 32768 --variants "$V" 2>&1 | grep -v amdgpu.ids
 } > $OUT/r06_generic_ego_default.txt 2>&1
 cat $OUT/r06_generic_ego_default.txt
