@@ -44,7 +44,9 @@
 extern "C" {
 #endif
 
-#define PCX_ABI_VERSION 3u  /* 3: pcx_epilogue_desc grew (round 3), PCX_DIR_NEXT_CHAPTER, checkpoints carry a template hash */
+#define PCX_ABI_VERSION 4u  /* 3: pcx_epilogue_desc grew (round 3), PCX_DIR_NEXT_CHAPTER, checkpoints carry a template hash;
+                               4: pcx_template::reward_is_float / n_plot_words, pcx_engine_plot_words / pcx_engine_set_plot_words,
+                                  the programs of examples/ordeal.py */
 
 #define PCX_MAX_CHARS 32    /* distinct characters (layers) in one game   */
 #define PCX_MAX_SPRITES 16
@@ -98,6 +100,11 @@ enum pcx_program {
   PCX_PROG_BS_PLAYER = 60,    /* PlayerSprite.update    :258-272 */
   PCX_PROG_BS_PATROLLER = 61, /* PatrollerSprite.update :284-301 */
   PCX_PROG_BS_CASH = 62,      /* CashDrape.update       :311-320 */
+  /* examples/ordeal.py (a Story of three games; the entities keep 'has_sword' / 'last_position' in the Plot) */
+  PCX_PROG_OD_PLAYER = 70,     /* PlayerSprite.update     :210-264; param[0] = the_plot.this_chapter as a chapter code:
+                                  0 'castle', 1 'cavern', 2 'kansas' (the keys sorted), -1 anything else */
+  PCX_PROG_OD_DRAGONDUCK = 71, /* DragonduckSprite.update :143-192 */
+  PCX_PROG_OD_SWORD = 72,      /* SwordDrape.update       :121-126 */
   /* prefab-only entities driven by an action->motion table */
   PCX_PROG_WALKER = 50,  /* MazeWalker subclass: action a -> motion table  */
   PCX_PROG_SCROLLY = 51, /* Scrolly subclass: action a -> motion table     */
@@ -165,9 +172,20 @@ typedef struct pcx_directive {
   uint8_t move_this;   /* Z_ORDER                                            */
   uint8_t in_front_of; /* Z_ORDER: a thing's character, 0 = None (to the back) */
   int32_t selector;    /* value of the entity's directive field that triggers it (> 0) */
-  int32_t reward;      /* ADD_REWARD                                         */
+  int32_t reward;      /* ADD_REWARD (the bits of a float32 where pcx_template::reward_is_float) */
   float discount;      /* TERMINATE, in [0, 1]                               */
 } pcx_directive;
+
+/* Plot words.  The reference's Plot is a dict that entities use as a blackboard (plot.py:27-60) and that a Story hands
+ * from one game to the next (storytelling.py:449-450: `new_plot.update(old_plot)`); examples/ordeal.py:113-264 keeps
+ * 'has_sword' and 'last_position' there and reads the_plot.prior_chapter.  On this path the entries device programs use
+ * are PCX_PLOT_WORDS int32 words per environment.  They start every episode from what pcx_engine_set_plot_words staged
+ * (zeros / "nothing there" values until it is called) and pcx_engine_plot_words reads them back -- that pair is how a
+ * host-side Story carries them across a change of chapter.  The ordeal programs' words: */
+#define PCX_PLOT_WORDS 4
+#define PCX_PLOT_OD_HAS_SWORD 0      /* the_plot.get('has_sword'): 0 / 1                                   */
+#define PCX_PLOT_OD_LAST_POSITION 1  /* the_plot['last_position']: row | col << 16, -1 while there is none */
+#define PCX_PLOT_OD_PRIOR_CHAPTER 2  /* the_plot.prior_chapter as a chapter code (PCX_PROG_OD_PLAYER), -1 None */
 
 /* A whole game as built by ascii_art_to_game(), before its_showtime(). */
 typedef struct pcx_template {
@@ -191,6 +209,10 @@ typedef struct pcx_template {
   int32_t param[8];       /* game-specific constants                          */
   int32_t n_directives;
   pcx_directive directives[PCX_MAX_DIRECTIVES];
+  int32_t reward_is_float; /* the rewards are Python floats (plot.py:200-226 sums anything `+=`-able; examples/ordeal.py:123,
+                              187-190 adds +-1.0): pcx_buffers::reward then holds the bits of a float32 per environment
+                              and so does pcx_directive::reward */
+  int32_t n_plot_words;    /* how many plot words the template's programs use (0: none; informational)          */
 } pcx_template;
 
 /* Device (or host, for the oracle) pointers to what play() returns, batched.
@@ -203,7 +225,7 @@ typedef struct pcx_buffers {
    * (uint8 0/1).  Shape [batch][1+n_chars][pitch], pitch = pcx_engine_plane_pitch()
    * (== rows*cols whenever rows*cols is a multiple of 4). */
   uint8_t* planes;
-  int32_t* reward;      /* [batch] summed reward (0 when reward_set == 0)      */
+  int32_t* reward;      /* [batch] summed reward (0 when reward_set == 0); float32 bits where pcx_template::reward_is_float */
   uint8_t* reward_set;  /* [batch] 0 => the reference would return None       */
   float* discount;      /* [batch]                                             */
   uint8_t* done;        /* [batch] Engine.game_over                            */
@@ -303,6 +325,15 @@ int pcx_engine_import_state(pcx_engine* e, const void* state_host, uint64_t byte
  * PCX_CHAPTER_NONE for None, PCX_CHAPTER_UNSET where no entity has -- a host-side Story
  * (storytelling.py:425-470) reads it when an environment's game ends.  Synchronous. */
 int pcx_engine_next_chapter(pcx_engine* e, int32_t* next_host);
+
+/* Plot words (see PCX_PLOT_WORDS above).  pcx_engine_plot_words: host copy of int32[PCX_PLOT_WORDS][batch], the words as
+ * the last step left them.  pcx_engine_set_plot_words: the words environments START their next episode with, from host
+ * int32[PCX_PLOT_WORDS][batch] -- only where mask_host[b] != 0 (NULL: everywhere); it takes effect at the environment's
+ * next reset (pcx_engine_reset or an auto-reset) and stays until set again.  What the reference does with
+ * `new_plot.update(old_plot)` before the new game's its_showtime() (storytelling.py:449-466).  Backends whose programs
+ * keep nothing in the Plot answer PCX_E_UNSUPPORTED.  Synchronous. */
+int pcx_engine_plot_words(pcx_engine* e, int32_t* words_host);
+int pcx_engine_set_plot_words(pcx_engine* e, const int32_t* words_host, const uint8_t* mask_host);
 
 /* Convenience synchronous copies (host <-> device) for thin FFI hosts. */
 int pcx_memcpy_d2h(void* dst_host, const void* src_dev, uint64_t bytes);

@@ -24,6 +24,8 @@ _SYMS = [
     ('pcxo_engine_buffers', N.c_i32, [ctypes.c_void_p, ctypes.POINTER(N.Buffers)]),
     ('pcxo_engine_read_things', N.c_i32, [ctypes.c_void_p, N.c_i64, N.c_i64, ctypes.c_void_p, ctypes.c_void_p]),
     ('pcxo_engine_next_chapter', N.c_i32, [ctypes.c_void_p, ctypes.c_void_p]),
+    ('pcxo_engine_plot_words', N.c_i32, [ctypes.c_void_p, ctypes.c_void_p]),
+    ('pcxo_engine_set_plot_words', N.c_i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ('pcxo_action_hash', N.c_u32, [N.c_u64, N.c_u64, N.c_u64]),
     ('pcxo_last_error', ctypes.c_char_p, []),
     ('pcxo_cropper_create', N.c_i32, [ctypes.c_void_p, ctypes.POINTER(N.CropperDesc), ctypes.POINTER(ctypes.c_void_p)]),
@@ -89,7 +91,7 @@ class OracleEngine(object):
       return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     self.planes = view(b.planes, (B, 1 + L, R, C), np.uint8)
-    self.reward = view(b.reward, (B,), np.int32)
+    self.reward = view(b.reward, (B,), np.float32 if getattr(template, 'reward_is_float', False) else np.int32)
     self.reward_set = view(b.reward_set, (B,), np.uint8)
     self.discount = view(b.discount, (B,), np.float32)
     self.done = view(b.done, (B,), np.uint8)
@@ -115,6 +117,20 @@ class OracleEngine(object):
     out = np.zeros((self.batch,), np.int32)
     _check(lib().pcxo_engine_next_chapter(self._h, out.ctypes.data))
     return out
+
+  def plot_words(self):
+    """int32 [PLOT_WORDS, batch] (include/pcx.h pcx_engine_plot_words)."""
+    out = np.zeros((N.PLOT_WORDS, self.batch), np.int32)
+    _check(lib().pcxo_engine_plot_words(self._h, out.ctypes.data))
+    return out
+
+  def set_plot_words(self, words, mask=None):
+    words = np.ascontiguousarray(words, np.int32).reshape(N.PLOT_WORDS, self.batch)
+    ptr = None
+    if mask is not None:
+      mask = np.ascontiguousarray(mask, np.uint8)
+      ptr = mask.ctypes.data
+    _check(lib().pcxo_engine_set_plot_words(self._h, words.ctypes.data, ptr))
 
   def sprites(self):
     ns = len(self.template.sprites)

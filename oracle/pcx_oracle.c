@@ -119,6 +119,7 @@ typedef struct {
   /* Plot._EngineDirectives (plot.py:69-104) */
   int reward_set;
   int64_t reward;
+  double rewardf; /* ... where the game's rewards are Python floats (pcx_template::reward_is_float; ordeal.py:123, 187-190) */
   float discount;
   int game_over;
   /* protocols/scrolling.py state (:198-241), one set per scrolling group X;
@@ -142,6 +143,9 @@ typedef struct {
   /* Plot._next_chapter as the game's entities left it (plot.py:299-324): a chapter index,
    * PCX_CHAPTER_NONE for None, PCX_CHAPTER_UNSET while only the Story has written it */
   int32_t next_chapter;
+  /* the Plot's dict entries that device programs use and a Story hands on (include/pcx.h PCX_PLOT_WORDS;
+   * storytelling.py:449-450, examples/ordeal.py:121-126, 236-264) */
+  int32_t pw[PCX_PLOT_WORDS];
 } ox_plot;
 
 typedef struct {
@@ -173,6 +177,7 @@ struct pcxo_engine {
   uint8_t* done;
   int32_t* frame;
   uint8_t* error;
+  int32_t* plot_in; /* [PCX_PLOT_WORDS][batch]: what an environment's next episode starts with (pcxo_engine_set_plot_words); NULL: defaults */
 };
 
 static inline int cells(const pcxo_engine* e) { return e->t.rows * e->t.cols; }
@@ -202,6 +207,7 @@ static int thing_id(const pcxo_engine* e, int ch) {
 static void plot_clear_directives(ox_plot* p) {
   p->reward_set = 0;
   p->reward = 0;
+  p->rewardf = 0.0;
   p->discount = 1.0f;
   p->game_over = 0;
   p->n_z_updates = 0;
@@ -213,8 +219,13 @@ static void plot_terminate(ox_plot* p, float discount) {
 }
 /* plot.py:200-226 */
 static void plot_add_reward(ox_plot* p, int64_t r) {
-  if (!p->reward_set) { p->reward_set = 1; p->reward = r; }
-  else p->reward += r;
+  if (!p->reward_set) { p->reward_set = 1; p->reward = r; p->rewardf = (double)r; }
+  else { p->reward += r; p->rewardf += (double)r; }
+}
+/* ... of a float (the sum is a Python float: a double) */
+static void plot_add_rewardf(ox_plot* p, double r) {
+  if (!p->reward_set) { p->reward_set = 1; p->rewardf = r; }
+  else p->rewardf += r;
 }
 
 /* ---- protocols/scrolling.py ---------------------------------------------- */
@@ -807,6 +818,94 @@ static void prog_em_downbolt(ox_ctx* x, int id) {
  * values 0..7 index MOTION9, anything else -- None included -- is `_stay`.
  * Restates the test entities of tests/test_things.py:203-295 with integer
  * actions. */
+/* ---- examples/ordeal.py ------------------------------------------------------- */
+/* The Plot entries these three classes share live in plot.pw[] (include/pcx.h PCX_PLOT_OD_*); chapter codes are the
+ * Story's keys sorted: 0 'castle', 1 'cavern', 2 'kansas'. */
+enum { OD_CASTLE = 0, OD_CAVERN = 1, OD_KANSAS = 2 };
+
+/* ordeal.py:121-126 SwordDrape.update */
+static void prog_od_sword(ox_ctx* x, int di) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_drape* d = &env->drapes[di];
+  int pid = thing_id(e, 'P');
+  if (pid < 0 || pid >= PCX_MAX_SPRITES) { env->error |= OX_ERR_INDEX; return; } /* things['P'] */
+  const ox_sprite* P = &env->sprites[pid];
+  if (d->curtain[P->row * e->t.cols + P->col]) { /* :122 (a confined MazeWalker's position is on the board) */
+    env->plot.pw[PCX_PLOT_OD_HAS_SWORD] = 1;     /* :123 */
+    plot_add_rewardf(&env->plot, 1.0);           /* :124 */
+  }
+  if (env->plot.pw[PCX_PLOT_OD_HAS_SWORD]) memset(d->curtain, 0, cells(e)); /* :126 */
+}
+
+/* ordeal.py:143-192 DragonduckSprite.update */
+static void prog_od_dragonduck(ox_ctx* x, int id) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_sprite* s = &env->sprites[id];
+  if (env->plot.frame == 0) return; /* :144 */
+  int pid = thing_id(e, 'P');
+  if (pid < 0 || pid >= PCX_MAX_SPRITES) { env->error |= OX_ERR_INDEX; return; }
+  const ox_sprite* P = &env->sprites[pid];
+  /* :147-170: the four comparisons name one of the eight motions, or none when the two stand on the same cell */
+  int dr = s->row > P->row ? -1 : s->row < P->row ? 1 : 0;
+  int dc = s->col < P->col ? 1 : s->col > P->col ? -1 : 0;
+  if (dr || dc) mw_move(e, env, id, x->board, dr, dc);
+  if (layer_at(x, 'P', s->row, s->col)) { /* :177: the layer of the last repaint */
+    env->plot.next_chapter = PCX_CHAPTER_NONE; /* :179 */
+    plot_terminate(&env->plot, 0.0f);          /* :180 */
+    ox_plot* p = &env->plot;
+    if (p->pw[PCX_PLOT_OD_HAS_SWORD]) {        /* :182-184 */
+      plot_add_rewardf(p, 1.0);
+      p->z_move[p->n_z_updates] = id; p->z_front[p->n_z_updates] = pid; p->n_z_updates++;
+    } else {                                   /* :186-187 */
+      plot_add_rewardf(p, -1.0);
+      p->z_move[p->n_z_updates] = pid; p->z_front[p->n_z_updates] = id; p->n_z_updates++;
+    }
+  }
+}
+
+/* ordeal.py:210-264 PlayerSprite.update; param[0]: the_plot.this_chapter as a chapter code */
+static void prog_od_player(ox_ctx* x, int id) {
+  pcxo_engine* e = x->e;
+  ox_env* env = x->env;
+  ox_sprite* s = &env->sprites[id];
+  ox_plot* p = &env->plot;
+  const int chap = e->t.sprites[id].param[0];
+  const int lim_r = e->t.rows - 1, lim_c = e->t.cols - 1; /* :207: corner - 1 */
+  const int a = x->action;
+  if (a == 0) {        /* :216-221 */
+    if (chap == OD_KANSAS && s->row <= 0) { p->next_chapter = OD_CASTLE; plot_terminate(p, 0.0f); }
+    else mw_move(e, env, id, x->board, -1, 0);
+  } else if (a == 1) { /* :223-228 */
+    if (chap == OD_CASTLE && s->row >= lim_r) { p->next_chapter = OD_KANSAS; plot_terminate(p, 0.0f); }
+    else mw_move(e, env, id, x->board, 1, 0);
+  } else if (a == 2) { /* :230-235 */
+    if (chap == OD_CAVERN && s->col <= 0) { p->next_chapter = OD_KANSAS; plot_terminate(p, 0.0f); }
+    else mw_move(e, env, id, x->board, 0, -1);
+  } else if (a == 3) { /* :237-242 */
+    if (chap == OD_KANSAS && s->col >= lim_c) { p->next_chapter = OD_CAVERN; plot_terminate(p, 0.0f); }
+    else mw_move(e, env, id, x->board, 0, 1);
+  } else if (a == 4) { /* :244-246 */
+    p->next_chapter = PCX_CHAPTER_NONE;
+    plot_terminate(p, 0.0f);
+  } else if (p->frame == 0) { /* :252-266: line up with where the last game was left */
+    const int prior = p->pw[PCX_PLOT_OD_PRIOR_CHAPTER], lp = p->pw[PCX_PLOT_OD_LAST_POSITION];
+    const int lr = (int16_t)(lp & 0xFFFF), lc = (int16_t)((uint32_t)lp >> 16);
+    int tr = 0, tc = 0, go = 1;
+    if (prior == OD_KANSAS && chap == OD_CASTLE) { tr = lim_r; tc = lc; }
+    else if (prior == OD_CASTLE && chap == OD_KANSAS) { tr = 0; tc = lc; }
+    else if (prior == OD_KANSAS && chap == OD_CAVERN) { tr = lr; tc = 0; }
+    else if (prior == OD_CAVERN && chap == OD_KANSAS) { tr = lr; tc = lim_c; }
+    else go = 0;
+    if (go) {
+      if (lp == -1) env->error |= OX_ERR_INDEX; /* the_plot['last_position']: KeyError */
+      else mw_teleport(e, s, tr, tc);
+    }
+  }
+  p->pw[PCX_PLOT_OD_LAST_POSITION] = (int32_t)(((uint32_t)s->row & 0xFFFFu) | ((uint32_t)s->col << 16)); /* :269 */
+}
+
 static int walker_action(int action, const int32_t* param) {
   if (action < 0) return 8;
   unsigned a = param[1] ? ((unsigned)action >> param[0]) & (unsigned)param[1] : (unsigned)action;
@@ -836,7 +935,10 @@ static void issue_directives(ox_ctx* x, int id, int ch, const int32_t* param) {
     if (d->ch != ch || d->selector != sel) continue;
     ox_plot* p = &x->env->plot;
     switch (d->kind) {
-      case PCX_DIR_ADD_REWARD: plot_add_reward(p, d->reward); break;
+      case PCX_DIR_ADD_REWARD:
+        if (e->t.reward_is_float) { float f; memcpy(&f, &d->reward, 4); plot_add_rewardf(p, (double)f); }
+        else plot_add_reward(p, d->reward);
+        break;
       case PCX_DIR_TERMINATE: plot_terminate(p, d->discount); break;
       case PCX_DIR_NEXT_CHAPTER: p->next_chapter = d->reward; break; /* plot.py:299-324: the last call stands */
       case PCX_DIR_Z_ORDER: /* plot.py:173-174: appended, applied after the last group */
@@ -880,6 +982,9 @@ static int run_program(ox_ctx* x, int id) {
     case PCX_PROG_EM_DOWNBOLT: prog_em_downbolt(x, id); break;
     case PCX_PROG_WALKER: prog_walker(x, id); break;
     case PCX_PROG_SCROLLY: prog_scrolly(x, di); break;
+    case PCX_PROG_OD_PLAYER: prog_od_player(x, id); break;
+    case PCX_PROG_OD_DRAGONDUCK: prog_od_dragonduck(x, id); break;
+    case PCX_PROG_OD_SWORD: prog_od_sword(x, di); break;
     case PCX_PROG_STATIC: break;
     default: return -1;
   }
@@ -957,6 +1062,10 @@ static void env_init(pcxo_engine* e, int64_t b) {
   env->plot.kv[EM_LAST_PLAYER_SHOT] = env->plot.kv[EM_LAST_MARAUDER_SHOT] = EM_NEVER;
   env->plot.frame = -1;
   env->plot.next_chapter = PCX_CHAPTER_UNSET; /* a new Engine has a new Plot */
+  /* ... into which a Story copies the old one's entries before its_showtime() (storytelling.py:449-450) */
+  env->plot.pw[PCX_PLOT_OD_LAST_POSITION] = env->plot.pw[PCX_PLOT_OD_PRIOR_CHAPTER] = -1;
+  if (e->plot_in)
+    for (int w = 0; w < PCX_PLOT_WORDS; ++w) env->plot.pw[w] = e->plot_in[(size_t)w * e->batch + b];
   plot_clear_directives(&env->plot);
   memcpy(env->z_id, e->z_id, sizeof env->z_id);
   env->game_over = 0;
@@ -966,6 +1075,7 @@ static void env_init(pcxo_engine* e, int64_t b) {
 static void publish(pcxo_engine* e, int64_t b) {
   ox_env* env = &e->envs[b];
   e->reward[b] = (int32_t)env->plot.reward;
+  if (e->t.reward_is_float) { float f = (float)env->plot.rewardf; memcpy(&e->reward[b], &f, 4); } /* the lane is a float32 */
   e->reward_set[b] = (uint8_t)env->plot.reward_set;
   e->discount[b] = env->plot.discount;
   e->done[b] = (uint8_t)env->game_over;
@@ -1078,7 +1188,7 @@ void pcxo_engine_destroy(pcxo_engine* e) {
   }
   for (int i = 0; i < PCX_MAX_DRAPES; ++i) { free(e->init_curtain[i]); free(e->init_pattern[i]); }
   free(e->backdrop); free(e->planes); free(e->reward); free(e->reward_set);
-  free(e->discount); free(e->done); free(e->frame); free(e->error);
+  free(e->discount); free(e->done); free(e->frame); free(e->error); free(e->plot_in);
   free(e);
 }
 
@@ -1133,6 +1243,23 @@ int pcxo_engine_buffers(pcxo_engine* e, pcx_buffers* out) {
   out->rows = e->t.rows; out->cols = e->t.cols; out->n_chars = e->t.n_chars;
   out->planes = e->planes; out->reward = e->reward; out->reward_set = e->reward_set;
   out->discount = e->discount; out->done = e->done; out->frame = e->frame; out->error = e->error;
+  return 0;
+}
+
+int pcxo_engine_plot_words(pcxo_engine* e, int32_t* out) {
+  for (int w = 0; w < PCX_PLOT_WORDS; ++w)
+    for (int64_t b = 0; b < e->batch; ++b) out[(size_t)w * e->batch + b] = e->envs[b].plot.pw[w];
+  return 0;
+}
+int pcxo_engine_set_plot_words(pcxo_engine* e, const int32_t* words, const uint8_t* mask) {
+  if (!e->plot_in) {
+    e->plot_in = (int32_t*)calloc((size_t)e->batch * PCX_PLOT_WORDS, sizeof(int32_t));
+    for (int64_t b = 0; b < e->batch; ++b)
+      e->plot_in[(size_t)PCX_PLOT_OD_LAST_POSITION * e->batch + b] = e->plot_in[(size_t)PCX_PLOT_OD_PRIOR_CHAPTER * e->batch + b] = -1;
+  }
+  for (int w = 0; w < PCX_PLOT_WORDS; ++w)
+    for (int64_t b = 0; b < e->batch; ++b)
+      if (!mask || mask[b]) e->plot_in[(size_t)w * e->batch + b] = words[(size_t)w * e->batch + b];
   return 0;
 }
 

@@ -12,7 +12,7 @@ c_u8, c_i32, c_i64, c_u32, c_u64 = (ctypes.c_uint8, ctypes.c_int32,
                                     ctypes.c_uint64)
 c_u8_p = ctypes.POINTER(ctypes.c_uint8)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_CHARS = 32
 MAX_SPRITES = 16
 MAX_DRAPES = 8
@@ -32,6 +32,9 @@ PROG_WM_BOX, PROG_WM_JUDGE, PROG_WM_PLAYER = 30, 31, 32
 PROG_HW_ROLLING, PROG_HW_SLIDING = 40, 41
 PROG_WALKER, PROG_SCROLLY, PROG_STATIC = 50, 51, 52
 PROG_BS_PLAYER, PROG_BS_PATROLLER, PROG_BS_CASH = 60, 61, 62
+PROG_OD_PLAYER, PROG_OD_DRAGONDUCK, PROG_OD_SWORD = 70, 71, 72  # examples/ordeal.py
+PLOT_WORDS = 4
+PLOT_OD_HAS_SWORD, PLOT_OD_LAST_POSITION, PLOT_OD_PRIOR_CHAPTER = 0, 1, 2
 
 CROP_FIXED, CROP_SCROLLING = 1, 2
 
@@ -77,7 +80,8 @@ class Template(ctypes.Structure):
               ('group_of', c_u8 * MAX_THINGS),
               ('n_groups', c_i32), ('n_actions', c_i32),
               ('param', c_i32 * 8),
-              ('n_directives', c_i32), ('directives', Directive * MAX_DIRECTIVES)]
+              ('n_directives', c_i32), ('directives', Directive * MAX_DIRECTIVES),
+              ('reward_is_float', c_i32), ('n_plot_words', c_i32)]
 
 
 class Buffers(ctypes.Structure):
@@ -140,6 +144,8 @@ SYMBOLS = [
     ('pcx_engine_error_poll', c_i32, [_VP, _VP, ctypes.POINTER(c_i32)]),
     ('pcx_engine_errors_seen', c_i32, [_VP, _VP, c_i32]),
     ('pcx_engine_next_chapter', c_i32, [_VP, _VP]),
+    ('pcx_engine_plot_words', c_i32, [_VP, _VP]),
+    ('pcx_engine_set_plot_words', c_i32, [_VP, _VP, _VP]),
     ('pcx_engine_state_size', c_i32, [_VP, c_i32, ctypes.POINTER(c_u64)]),
     ('pcx_engine_export_state', c_i32, [_VP, _VP, c_u64, c_i32]),
     ('pcx_engine_import_state', c_i32, [_VP, _VP, c_u64]),

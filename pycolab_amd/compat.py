@@ -12,7 +12,7 @@ import sys
 import types
 
 _SUBMODULES = ['ascii_art', 'engine', 'things', 'plot', 'rendering', 'human_ui',
-               'cropping', 'prefab_parts', 'prefab_parts.sprites',
+               'cropping', 'storytelling', 'prefab_parts', 'prefab_parts.sprites',
                'prefab_parts.drapes', 'protocols', 'protocols.scrolling',
                'protocols.logging']
 

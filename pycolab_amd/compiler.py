@@ -29,14 +29,16 @@ def _impassable_bits(chars):
   return bytes(bits)
 
 
-def _directive(ch, selector, call, things_by_char):
+def _directive(ch, selector, call, things_by_char, float_rewards=False):
   """One ('add_reward', r) / ('terminate_episode'[, d]) / ('change_z_order', a, b) /
   ('next_chapter', key) entry as a pcx_directive tuple, checked the way plot.py and engine.py check it."""
   name, args = call[0], tuple(call[1:])
   if name == 'add_reward':
     (reward,) = args
+    if float_rewards:  # pcx_template::reward_is_float: the table holds the bits of a float32
+      return (ch, N.DIR_ADD_REWARD, 0, 0, selector, int(np.array([reward], np.float32).view(np.int32)[0]), 0.0)
     if int(reward) != reward:
-      raise ValueError('device rewards are integers')
+      raise ValueError('device rewards are integers (float32 ones: `pcx_float_rewards = True` on an entity class of the game)')
     return (ch, N.DIR_ADD_REWARD, 0, 0, selector, int(reward), 0.0)
   if name == 'terminate_episode':
     discount = float(args[0]) if args else 0.0
@@ -84,6 +86,9 @@ class GameTemplate(object):
     self.n_actions = 0
     self.param = [0] * 8
     self.directives = []        # (ch, kind, move_this, in_front_of, selector, reward, discount)
+    self.reward_is_float = False  # include/pcx.h pcx_template::reward_is_float
+    self.n_plot_words = 0         # ... n_plot_words
+    self.chapter_keys = None      # host only: the Story keys behind the chapter codes the programs assign to next_chapter
 
   # -- construction from a host Engine ---------------------------------------
   @classmethod
@@ -137,13 +142,22 @@ class GameTemplate(object):
           if ent._have_margins:
             d['margins'] = (int(ent._scroll_margins[0]), int(ent._scroll_margins[1]))
         t.drapes.append(d)
+    # examples/ordeal.py: float rewards, Plot entries in the plot words, the player told which chapter it is in
+    if any(p in programs.ORDEAL_PROGRAMS for p in progs):
+      t.reward_is_float, t.n_plot_words, t.chapter_keys = True, 3, list(programs.ORDEAL_CHAPTERS)
+      this = eng.the_plot.this_chapter
+      for s in t.sprites:
+        if s['program'] == N.PROG_OD_PLAYER:
+          s['param'] = [t.chapter_keys.index(this) if this in t.chapter_keys else -1, 0, 0, 0]
+    t.reward_is_float = t.reward_is_float or any(
+        getattr(type(ent), 'pcx_float_rewards', False) for ent in eng._sprites_and_drapes.values())
     # plot directives of tabled entities (prefab_parts/tabled.py), in z-order of the entities
     for ch, ent in eng._sprites_and_drapes.items():
       for selector, calls in sorted(getattr(ent, 'pcx_directives', {}).items()):
         if int(selector) <= 0:
           raise ValueError('directive selector values must be positive (0 means "no directive")')
         for call in calls:
-          t.directives.append(_directive(ord(ch), int(selector), call, eng._sprites_and_drapes))
+          t.directives.append(_directive(ord(ch), int(selector), call, eng._sprites_and_drapes, t.reward_is_float))
     if len(t.directives) > N.MAX_DIRECTIVES:
       raise ValueError('at most {} plot directives per game'.format(N.MAX_DIRECTIVES))
     if len(t.sprites) > N.MAX_SPRITES or len(t.drapes) > N.MAX_DRAPES:
@@ -159,7 +173,9 @@ class GameTemplate(object):
     t.group_of = group_of
     t.game = programs.infer_game(progs)
     t.n_actions = programs.N_ACTIONS[t.game]
-    if t.game == N.GAME_WALKERS:
+    if t.n_plot_words:
+      t.n_actions = programs.ORDEAL_N_ACTIONS
+    if t.game == N.GAME_WALKERS and not t.n_plot_words:
       # tabled entities read bit fields of the action: "ordinary" actions (what
       # the benchmark / hashed-action tests draw from) cover every field
       top = 0
@@ -180,6 +196,8 @@ class GameTemplate(object):
                 schedule=list(self.schedule), group_of=list(self.group_of),
                 n_groups=self.n_groups, n_actions=self.n_actions,
                 param=list(self.param), directives=[list(d) for d in self.directives], sprites=[], drapes=[])
+    if self.reward_is_float or self.n_plot_words:  # (only where they say something: the earlier fixtures stay byte-identical)
+      meta.update(reward_is_float=bool(self.reward_is_float), n_plot_words=int(self.n_plot_words), chapter_keys=self.chapter_keys)
     arrays = {'backdrop': self.backdrop}
     for s in self.sprites:
       m = dict(s)
@@ -208,6 +226,8 @@ class GameTemplate(object):
     t.group_of, t.n_groups = meta['group_of'], meta['n_groups']
     t.n_actions, t.param = meta['n_actions'], meta['param']
     t.directives = [tuple(d) for d in meta.get('directives', [])]
+    t.reward_is_float, t.n_plot_words = bool(meta.get('reward_is_float', False)), int(meta.get('n_plot_words', 0))
+    t.chapter_keys = meta.get('chapter_keys')
     t.backdrop = np.ascontiguousarray(z['backdrop'], dtype=np.uint8)
     n = t.rows * t.cols
     for s in meta['sprites']:
@@ -232,7 +252,7 @@ class GameTemplate(object):
     def norm(t):
       return (t.game, t.rows, t.cols, bool(t.occlusion_in_layers), t.chars,
               t.backdrop.tobytes(), t.z_order, t.schedule, list(t.group_of),
-              t.n_groups, t.n_actions, list(t.param), [tuple(d) for d in t.directives],
+              t.n_groups, t.n_actions, list(t.param), [tuple(d) for d in t.directives], bool(t.reward_is_float), int(t.n_plot_words),
               [sorted((k, (v if not isinstance(v, (list, tuple)) else tuple(v)))
                       for k, v in s.items()) for s in t.sprites],
               [sorted((k, (v.tobytes() if isinstance(v, np.ndarray) else
@@ -326,4 +346,5 @@ class GameTemplate(object):
       d = ct.directives[i]
       d.ch, d.kind, d.move_this, d.in_front_of = ch, kind, move_this, in_front_of
       d.selector, d.reward, d.discount = selector, reward, discount
+    ct.reward_is_float, ct.n_plot_words = int(bool(self.reward_is_float)), int(self.n_plot_words)
     return ct, keep

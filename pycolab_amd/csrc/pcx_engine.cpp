@@ -95,6 +95,9 @@ int Backend::set_epilogue(const pcx_epilogue_desc* d) {
   return set_error(PCX_E_UNSUPPORTED, "%s has no fused feature-array epilogue", kernel_name());
 }
 
+int Backend::set_plot_words(const int32_t*, const uint8_t*) {
+  return set_error(PCX_E_UNSUPPORTED, "pcx_engine_set_plot_words: this template's programs keep nothing in the Plot");
+}
 int Backend::set_fused_croppers(const crop::FusedCrops* fc) {
   if (!fc || fc->n <= 0) return 0;
   return set_error(PCX_E_UNSUPPORTED, "%s cannot run croppers itself", kernel_name());
@@ -334,6 +337,23 @@ int pcx_engine_next_chapter(pcx_engine* e, int32_t* next_host) {
   PCX_HIP(hipDeviceSynchronize());
   PCX_HIP(hipMemcpy(next_host, words, (size_t)e->batch * 4, hipMemcpyDeviceToHost));
   return 0;
+}
+
+int pcx_engine_plot_words(pcx_engine* e, int32_t* words_host) {
+  if (!e || !words_host) return set_error(PCX_E_INVALID, "pcx_engine_plot_words: bad arguments");
+  PCX_HIP(hipSetDevice(e->device));
+  const int32_t* words = e->backend->plot_words();
+  if (!words) return set_error(PCX_E_UNSUPPORTED, "pcx_engine_plot_words: this template's programs keep nothing in the Plot");
+  PCX_HIP(hipDeviceSynchronize());
+  PCX_HIP(hipMemcpy2D(words_host, (size_t)e->batch * 4, words, (size_t)e->backend->batch_pad() * 4, (size_t)e->batch * 4, PCX_PLOT_WORDS,
+                      hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pcx_engine_set_plot_words(pcx_engine* e, const int32_t* words_host, const uint8_t* mask_host) {
+  if (!e || !words_host) return set_error(PCX_E_INVALID, "pcx_engine_set_plot_words: bad arguments");
+  PCX_HIP(hipSetDevice(e->device));
+  return e->backend->set_plot_words(words_host, mask_host);
 }
 
 int pcx_engine_errors_seen(pcx_engine* e, uint8_t* errors_host, int32_t clear) {

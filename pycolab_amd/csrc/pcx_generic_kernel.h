@@ -44,6 +44,7 @@ struct Consts {
   int32_t occl;  // Engine(..., occlusion_in_layers)
   int32_t n_dir, zdyn, w_z;  // plot directives; any change_z_order among them; state offset of the z-order words
   int32_t w_next;            // state offset of the_plot.next_chapter (-1: no entity assigns it)
+  int32_t reward_float;      // pcx_template::reward_is_float: the reward lane and the directives' rewards are float32 bits
   int32_t l_dir, l_zord, l_zabove, l_zabove_s, l_zabove_d, l_zq, l_ztmp;
   int32_t has_scroll, w_scroll;  // any Scrolly drape / egocentric walker; state offset of the protocol words
   int32_t n_sgroups;             // distinct scrolling groups among the things
@@ -83,6 +84,9 @@ struct Ptrs {
   int32_t feat_depth, feat_skip;
   uint8_t feat_ch[PCX_POST_MAX_DEPTH];
   int32_t use_codes;  // pcx_generic_step: this launch renders from owner codes (Consts::l_codes) instead of masks -- plain steps without fused croppers / epilogue
+  // include/pcx.h pcx_engine_set_plot_words: int32 [PCX_PLOT_WORDS][bpad] the plot words (state words W_V0..3) a new episode starts
+  // with -- what a Story's `new_plot.update(old_plot)` left there (storytelling.py:449-450); null: the template's
+  const int32_t* plot_in;
 };
 
 // A build of this file for ONE template (round 4): PCX_GENERIC_SPEC names a header that defines `static constexpr
@@ -616,7 +620,13 @@ __device__ __forceinline__ void prog_scrolly(Ctx& x, int thing) {
 }
 
 __device__ __forceinline__ void terminate(Ctx& x, float discount = 0.0f) { x.game_over = 1; x.discount = discount; }  // plot.py:176-198
-__device__ __forceinline__ void add_reward(Ctx& x, int r) { x.reward_set = 1; x.reward += r; }  // plot.py:200-226
+// plot.py:200-226.  x.reward holds the sum in the template's reward type: an int32, or the bits of a float32 (reward_float)
+__device__ __forceinline__ void add_reward_bits(Ctx& x, uint32_t bits) {  // ... a pcx_directive's reward word
+  x.reward_set = 1;
+  if (x.k.reward_float) x.reward = __float_as_int(__int_as_float(x.reward) + __uint_as_float(bits));
+  else x.reward += (int)bits;
+}
+__device__ __forceinline__ void add_reward(Ctx& x, int r) { add_reward_bits(x, x.k.reward_float ? __float_as_uint((float)r) : (uint32_t)r); }
 
 // Plot directives of a tabled entity (include/pcx.h pcx_directive): issued
 // before it moves, in table order, when its directive field of the action
@@ -630,7 +640,7 @@ __device__ __forceinline__ void issue_directives(Ctx& x, int thing) {
     const uint32_t* d = x.l.dir + i * D_WORDS;
     if ((int)(d[D_WHO] & 0xFF) != thing || d[D_SEL] != sel) continue;
     switch ((d[D_WHO] >> 8) & 0xFF) {
-      case PCX_DIR_ADD_REWARD: add_reward(x, (int)d[D_REWARD]); break;
+      case PCX_DIR_ADD_REWARD: add_reward_bits(x, d[D_REWARD]); break;
       case PCX_DIR_TERMINATE: terminate(x, __uint_as_float(d[D_DISCOUNT])); break;
       case PCX_DIR_NEXT_CHAPTER: x.next = (int)d[D_REWARD]; break;  // plot.py:299-324: the last assignment stands
       case PCX_DIR_Z_ORDER:
@@ -690,7 +700,77 @@ __device__ __forceinline__ void prog_bs_patroller(Ctx& x, int thing) {  // :284-
   request_move(x, 0, (f & 4u) ? 1 : -1, 2);  // ... then :298-301, in after_move()
 }
 // what follows the move in a program's update()
+// ---- examples/ordeal.py ---------------------------------------------------------
+// The Plot entries of its three classes are the plot words x.v[] (include/pcx.h PCX_PLOT_OD_*); chapter codes: the keys sorted.
+enum : int { OD_CASTLE = 0, OD_CAVERN = 1, OD_KANSAS = 2 };
+__device__ __forceinline__ void queue_z(Ctx& x, int move, int front) {  // the_plot.change_z_order (plot.py:136-174)
+  if (x.nzq < MAX_ZQ) x.l.zq[x.nzq++ * WAVE + x.lane] = (uint32_t)move | ((uint32_t)front << 8);
+  else x.err |= ERR_INDEX;
+}
+__device__ __forceinline__ void od_battle(Ctx& x, int thing) {  // ordeal.py:177-187, where the dragonduck stands after its move
+  int r, c;
+  sprite_true(x, tfield(x, thing, T_IDX), r, c);
+  if (!layer_at(x, x.k.ip, r, c)) return;  // layers['P'] of the last repaint
+  x.next = PCX_CHAPTER_NONE;
+  terminate(x);
+  if (x.v[PCX_PLOT_OD_HAS_SWORD]) { add_reward(x, 1); queue_z(x, thing, x.k.ip); }
+  else { add_reward(x, -1); queue_z(x, x.k.ip, thing); }
+}
+__device__ __forceinline__ void od_save_position(Ctx& x, int thing) {  // ordeal.py:269
+  int r, c;
+  sprite_true(x, tfield(x, thing, T_IDX), r, c);
+  x.v[PCX_PLOT_OD_LAST_POSITION] = (int32_t)pack_pos(r, c);
+}
+__device__ __forceinline__ void prog_od_sword(Ctx& x, int thing) {  // :121-126
+  const int d = tfield(x, thing, T_IDX);
+  int pr, pc;
+  sprite_true(x, tfield(x, x.k.ip, T_IDX), pr, pc);
+  const uint32_t w = drape_rows(x, x.l.cur, d)[(size_t)(pr * x.k.RW + (pc >> 5)) * WAVE];
+  if ((w >> (pc & 31)) & 1) { x.v[PCX_PLOT_OD_HAS_SWORD] = 1; add_reward(x, 1); }
+  if (x.v[PCX_PLOT_OD_HAS_SWORD])
+    for (int i = 0; i < x.k.R * x.k.RW; ++i) drape_rows(x, x.l.cur, d)[(size_t)i * WAVE] = 0;
+}
+__device__ __forceinline__ void prog_od_dragonduck(Ctx& x, int thing) {  // :143-192
+  if (x.frame == 0) return;
+  int r, c, pr, pc;
+  sprite_true(x, tfield(x, thing, T_IDX), r, c);
+  sprite_true(x, tfield(x, x.k.ip, T_IDX), pr, pc);
+  const int dr = r > pr ? -1 : r < pr ? 1 : 0, dc = c < pc ? 1 : c > pc ? -1 : 0;  // :147-170: one of the eight motions, or none
+  if (dr | dc) request_move(x, dr, dc, 3);  // ... then the battle, in after_move()
+  else od_battle(x, thing);
+}
+__device__ __forceinline__ void prog_od_player(Ctx& x, int thing) {  // :210-269
+  const int a = x.action, chap = (int)tfield(x, thing, T_P0), lim_r = x.k.R - 1, lim_c = x.k.C - 1;
+  int r, c;
+  sprite_true(x, tfield(x, thing, T_IDX), r, c);
+  if ((unsigned)a <= 3u) {
+    const bool leave = a == 0 ? (chap == OD_KANSAS && r <= 0) : a == 1 ? (chap == OD_CASTLE && r >= lim_r)
+                     : a == 2 ? (chap == OD_CAVERN && c <= 0) : (chap == OD_KANSAS && c >= lim_c);
+    if (leave) { x.next = a == 0 ? OD_CASTLE : a == 3 ? OD_CAVERN : OD_KANSAS; terminate(x); }
+    else { request_move(x, a == 0 ? -1 : a == 1 ? 1 : 0, a == 2 ? -1 : a == 3 ? 1 : 0, 4); return; }  // ... then :269, in after_move()
+  } else if (a == 4) {
+    x.next = PCX_CHAPTER_NONE;
+    terminate(x);
+  } else if (x.frame == 0) {  // :252-266: line up with where the last game was left
+    const int prior = x.v[PCX_PLOT_OD_PRIOR_CHAPTER], lp = x.v[PCX_PLOT_OD_LAST_POSITION];
+    const int lr = pos_r((uint32_t)lp), lc = pos_c((uint32_t)lp);
+    int tr = 0, tc = 0;
+    bool go = true;
+    if (prior == OD_KANSAS && chap == OD_CASTLE) { tr = lim_r; tc = lc; }
+    else if (prior == OD_CASTLE && chap == OD_KANSAS) { tr = 0; tc = lc; }
+    else if (prior == OD_KANSAS && chap == OD_CAVERN) { tr = lr; tc = 0; }
+    else if (prior == OD_CAVERN && chap == OD_KANSAS) { tr = lr; tc = lim_c; }
+    else go = false;
+    if (go) {
+      if (lp == -1) x.err |= ERR_INDEX;  // the_plot['last_position']: KeyError
+      else teleport(x, tfield(x, thing, T_IDX), tr, tc);
+    }
+  }
+  od_save_position(x, thing);
+}
 __device__ __forceinline__ void after_move(Ctx& x, int thing) {
+  if (x.mv_post == 3) { od_battle(x, thing); return; }
+  if (x.mv_post == 4) { od_save_position(x, thing); return; }
   if (x.mv_post == 2) {  // better_scrolly_maze.py:298-301: the patroller catches the player
     int r, c, pr, pc;
     sprite_true(x, tfield(x, thing, T_IDX), r, c);
@@ -1293,7 +1373,7 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
     int dxv;
     if (do_reset) {  // engine.py:520-581: fresh template state, pre-showtime render
       x.frame = (int)l.init[W_FRAME];
-      for (int j = 0; j < 4; ++j) x.v[j] = (int32_t)l.init[W_V0 + j];
+      for (int j = 0; j < 4; ++j) x.v[j] = P.plot_in ? P.plot_in[(size_t)j * bp + env] : (int32_t)l.init[W_V0 + j];
       dxv = (int)((l.init[W_FLAGS] >> 8) & 0xFF) - 1;
       PCX_SPEC_UNROLL
       for (int s = 0; s < k.NS; ++s) {
@@ -1375,6 +1455,9 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
           case PCX_PROG_BS_PLAYER: prog_bs_player(x, thing); break;
           case PCX_PROG_BS_PATROLLER: prog_bs_patroller(x, thing); break;
           case PCX_PROG_BS_CASH: prog_bs_cash(x, thing); break;
+          case PCX_PROG_OD_PLAYER: prog_od_player(x, thing); break;
+          case PCX_PROG_OD_DRAGONDUCK: prog_od_dragonduck(x, thing); break;
+          case PCX_PROG_OD_SWORD: prog_od_sword(x, thing); break;
           case PCX_PROG_WALKER: prog_walker(x, thing); break;
           case PCX_PROG_SCROLLY: prog_scrolly(x, thing); break;
           default: break;  // PCX_PROG_STATIC

@@ -172,6 +172,9 @@ class Backend {
   // include/pcx.h pcx_engine_next_chapter: device int32[bpad] the entities' the_plot.next_chapter
   // assignments live in, or null where the backend's entities never assign it
   virtual const int32_t* next_chapter_words() const { return nullptr; }
+  // include/pcx.h pcx_engine_plot_words: device int32 [PCX_PLOT_WORDS][batch_pad()], null where the programs keep nothing in the Plot
+  virtual const int32_t* plot_words() const { return nullptr; }
+  virtual int set_plot_words(const int32_t* words_host, const uint8_t* mask_host);  // include/pcx.h pcx_engine_set_plot_words
   // include/pcx.h pcx_engine_export_state: every device array of the backend that carries an
   // episode from one launch to the next (state words incl. RNG counters, the croppers' sprite track)
   virtual void persistent_arrays(std::vector<std::pair<void*, size_t>>& out) = 0;

@@ -17,6 +17,7 @@ when PyTorch-ROCm is available, NumPy arrays otherwise.
 """
 
 import collections
+import contextlib
 import ctypes
 
 import numpy as np
@@ -27,6 +28,33 @@ from pycolab_amd import device as dev
 from pycolab_amd import plot
 from pycolab_amd import rendering
 from pycolab_amd import things
+
+
+_DEFAULTS = dict(batch=1, device=0)
+
+
+@contextlib.contextmanager
+def defaults(batch=None, device=None):
+  """Engines built inside the block start with this batch size / GPU -- for game files that build their engines where
+  the caller cannot reach them to `configure()`: `with engine.defaults(batch=4096): story = ordeal.make_game()` (the
+  chapters of examples/ordeal.py:82-110 are built inside its Story).  A `Story` remembers the defaults it was built
+  under and builds its chapters under them later."""
+  saved = dict(_DEFAULTS)
+  if batch is not None:
+    if int(batch) < 1:
+      raise ValueError('batch must be >= 1')
+    _DEFAULTS['batch'] = int(batch)
+  if device is not None:
+    _DEFAULTS['device'] = int(device)
+  try:
+    yield
+  finally:
+    _DEFAULTS.clear()
+    _DEFAULTS.update(saved)
+
+
+def current_defaults():
+  return dict(_DEFAULTS)
 
 
 class Engine(object):
@@ -43,8 +71,8 @@ class Engine(object):
     self._update_groups = collections.defaultdict(list)
     self._current_update_group = ''
     # batched runtime
-    self._batch = 1
-    self._device_id = 0
+    self._batch = _DEFAULTS['batch']
+    self._device_id = _DEFAULTS['device']
     self._auto_reset = False
     self._seed = 0
     self._env_offset = 0
@@ -241,14 +269,15 @@ class Engine(object):
     # a multi-GPU consumer gathers it with a single collective and no packing
     # pass (pycolab_amd.distributed.ScalarGather)
     self._packed = None
+    rdt = np.float32 if template.reward_is_float else np.int32  # pcx_template::reward_is_float: the lane holds float32 bits
     if dev.torch_module() is not None:
       self._packed = mk((10 * B,), np.uint8)
       cut = self._packed.tensor
       view = lambda lo, hi, dt: dev.DeviceBuffer.view_of(cut[lo:hi], dt, self._device_id)
-      self._bufs.update(reward=view(0, 4 * B, np.int32), discount=view(4 * B, 8 * B, np.float32),
+      self._bufs.update(reward=view(0, 4 * B, rdt), discount=view(4 * B, 8 * B, np.float32),
                         reward_set=view(8 * B, 9 * B, np.uint8), done=view(9 * B, 10 * B, np.uint8))
     else:
-      self._bufs.update(reward=mk((B,), np.int32), discount=mk((B,), np.float32),
+      self._bufs.update(reward=mk((B,), rdt), discount=mk((B,), np.float32),
                         reward_set=mk((B,), np.uint8), done=mk((B,), np.uint8))
     self._actions = mk((B,), np.int32)
     ext = N.Buffers(batch=B, rows=R, cols=C, n_chars=L,
@@ -262,9 +291,48 @@ class Engine(object):
       from pycolab_amd import cropping
       request, self._fuse_request = self._fuse_request, None
       cropping.fuse_croppers(self, *request)
+    if template.n_plot_words and self._batch == 1:
+      self._plot_to_device()  # what a Story copied into this game's Plot (storytelling.py:449-450) is what its programs start from
     N.check(lib.pcx_engine_reset(self._native, None, dev.current_stream(self._device_id)))
     self._steps_launched += 1
     return self._result()
+
+  # ---- plot words: the Plot entries device programs use (include/pcx.h PCX_PLOT_WORDS; examples/ordeal.py) ----------
+  def plot_words(self):
+    """int32 [PLOT_WORDS, batch]: the plot words as the last step left them (`pcx_engine_plot_words`).  Synchronises."""
+    self._b  # (raises after close())
+    out = np.empty((N.PLOT_WORDS, self._batch), np.int32)
+    N.check(N.lib().pcx_engine_plot_words(self._native, out.ctypes.data))
+    return out
+
+  def set_plot_words(self, words, env_mask=None):
+    """The plot words the environments selected by `env_mask` (host bool [batch]; None: all) start their NEXT episode
+    with (`pcx_engine_set_plot_words`) -- a Story's `new_plot.update(old_plot)` for device programs."""
+    self._b
+    words = np.ascontiguousarray(words, np.int32).reshape(N.PLOT_WORDS, self._batch)
+    mask = None if env_mask is None else np.ascontiguousarray(env_mask, np.uint8)
+    N.check(N.lib().pcx_engine_set_plot_words(self._native, words.ctypes.data, None if mask is None else mask.ctypes.data))
+
+  def _plot_to_device(self):
+    """Batch 1, examples/ordeal.py: the Plot dict's 'has_sword' / 'last_position' and the_plot.prior_chapter -> plot words."""
+    plot_, keys = self._the_plot, self._template.chapter_keys or []
+    words = np.zeros((N.PLOT_WORDS, 1), np.int32)
+    words[N.PLOT_OD_HAS_SWORD] = int(bool(plot_.get('has_sword')))
+    lp = plot_.get('last_position')
+    words[N.PLOT_OD_LAST_POSITION] = -1 if lp is None else (int(lp[0]) & 0xFFFF) | (int(lp[1]) << 16)
+    words[N.PLOT_OD_PRIOR_CHAPTER] = keys.index(plot_.prior_chapter) if plot_.prior_chapter in keys else -1
+    self.set_plot_words(words)
+
+  def _plot_from_device(self):
+    """... and back after every step, so that `the_plot['has_sword']` reads as in the reference and travels with the dict."""
+    words = self.plot_words()[:, 0]
+    if words[N.PLOT_OD_HAS_SWORD]:
+      dict.__setitem__(self._the_plot, 'has_sword', True)
+    lp = int(words[N.PLOT_OD_LAST_POSITION])
+    if lp != -1:
+      r, c = lp & 0xFFFF, (lp >> 16) & 0xFFFF
+      dict.__setitem__(self._the_plot, 'last_position',
+                       things.Sprite.Position(r - 0x10000 if r >= 0x8000 else r, c - 0x10000 if c >= 0x8000 else c))
 
   def play(self, actions):
     """engine.py:583-639: one step of every environment.
@@ -383,7 +451,15 @@ class Engine(object):
     return out
 
   def _assigns_next_chapter(self):
-    return any(d[1] == N.DIR_NEXT_CHAPTER for d in self.template.directives)
+    t = self.template
+    return any(d[1] == N.DIR_NEXT_CHAPTER for d in t.directives) or any(
+        s['program'] in (N.PROG_OD_PLAYER, N.PROG_OD_DRAGONDUCK) for s in t.sprites)  # examples/ordeal.py:177-246
+
+  def chapter_key(self, code):
+    """The Story key behind a chapter code the entities assigned (`entities_next_chapter`): the code itself (an integer
+    key or list index) unless the template's programs name chapters by a key table (examples/ordeal.py: strings)."""
+    keys = self.template.chapter_keys
+    return int(code) if keys is None else keys[int(code)]
 
   def export_state(self, with_observation=False):
     """A checkpoint of every environment's episode as a NumPy uint8 array
@@ -508,7 +584,7 @@ class Engine(object):
       stale._planes_stale = True  # (a post-processor or cropper that would read the engine's planes raises instead)
       if self._batch == 1:
         self.check_errors()
-        return stale, (int(sc['reward'][0]) if sc['reward_set'][0] else None), float(sc['discount'][0])
+        return stale, (self._reward_type(sc['reward'][0]) if sc['reward_set'][0] else None), float(sc['discount'][0])
       pick = lambda k: (self._b[k].tensor if self._b[k].tensor is not None else self._b[k].numpy())
       return stale, pick('reward'), pick('discount')
     if self._batch == 1:
@@ -516,7 +592,9 @@ class Engine(object):
       self.check_errors()
       p = self.planes_view(host=True)[0]
       layers = {chr(c): p[1 + k].astype(np.bool_) for k, c in enumerate(L)}
-      reward = int(sc['reward'][0]) if sc['reward_set'][0] else None
+      reward = self._reward_type(sc['reward'][0]) if sc['reward_set'][0] else None
+      if self._template.n_plot_words:
+        self._plot_from_device()
       return self._tag(rendering.Observation(board=p[0], layers=layers)), reward, float(sc['discount'][0])
     arr = self.planes_view()
     layers = {chr(c): arr[:, 1 + k] for k, c in enumerate(L)}
@@ -524,6 +602,9 @@ class Engine(object):
                       else self._b[k].numpy())
     return (self._tag(rendering.Observation(board=arr[:, 0], layers=layers)),
             pick('reward'), pick('discount'))
+
+  def _reward_type(self, value):
+    return float(value) if self._template.reward_is_float else int(value)
 
   def _tag(self, observation):
     observation._source = self

@@ -43,7 +43,7 @@ class Plot(dict):
     v = self._device_next()
     if v is not None and v != self._device_next_at_set:
       from pycolab_amd import _native as N
-      return None if v == N.CHAPTER_NONE else v
+      return None if v == N.CHAPTER_NONE else self._engine.chapter_key(v)  # (examples/ordeal.py names chapters by strings)
     return self._next_chapter
 
   def _device_next(self):

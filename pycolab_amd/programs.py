@@ -36,6 +36,9 @@ NAMES = {
     'better_scrolly_maze.player': N.PROG_BS_PLAYER,
     'better_scrolly_maze.patroller': N.PROG_BS_PATROLLER,
     'better_scrolly_maze.cash': N.PROG_BS_CASH,
+    'ordeal.player': N.PROG_OD_PLAYER,
+    'ordeal.dragonduck': N.PROG_OD_DRAGONDUCK,
+    'ordeal.sword': N.PROG_OD_SWORD,
     'walker': N.PROG_WALKER,
     'scrolly': N.PROG_SCROLLY,
     'static': N.PROG_STATIC,
@@ -53,6 +56,13 @@ GAME_OF_PROGRAM = {
     N.PROG_BS_PLAYER: N.GAME_BETTER_SCROLLY, N.PROG_BS_PATROLLER: N.GAME_BETTER_SCROLLY,
     N.PROG_BS_CASH: N.GAME_BETTER_SCROLLY,
 }
+
+# examples/ordeal.py: the programs of its three classes run in the table-driven kernel (GAME_WALKERS); they keep Plot
+# entries in the engine's plot words, add float rewards, and name the Story's chapters by code = index among these keys
+# (include/pcx.h PCX_PROG_OD_PLAYER)
+ORDEAL_PROGRAMS = (N.PROG_OD_PLAYER, N.PROG_OD_DRAGONDUCK, N.PROG_OD_SWORD)
+ORDEAL_CHAPTERS = ('castle', 'cavern', 'kansas')
+ORDEAL_N_ACTIONS = 5  # ordeal.py:216-246: 0 N, 1 S, 2 W, 3 E, 4 quit
 
 # Number of "ordinary" actions per game (quit excluded): SURVEY.md section 8(d).
 N_ACTIONS = {N.GAME_SCROLLY_MAZE: 5, N.GAME_MARAUDERS: 4, N.GAME_WAREHOUSE: 5,

@@ -51,6 +51,18 @@ class Story(object):
     if self._auto_advance and first_chapter is None:
       first_chapter = 0
     self._chapters, self._croppers = _normalise(chapters, first_chapter, croppers)
+    # the chapters are built later, under the engine defaults this Story was built under (`engine.defaults(batch=...)`
+    # around an unchanged `make_game()`: examples/ordeal.py:82-110), and know their key from the start -- a device
+    # program that asks the_plot.this_chapter (ordeal.py:216-262) has it compiled in
+    self._defaults = engine.current_defaults()
+    builders = dict(self._chapters)
+
+    def build(key):
+      with engine.defaults(**self._defaults):
+        game = builders[key]()
+      game.the_plot._this_chapter = key
+      return game
+    self._chapters = {key: (lambda key=key: build(key)) for key in builders}
     facts = _collect_facts(self._chapters, self._croppers)
     (self._chars_sprites, self._chars_drapes, self._chars_backdrops, (self._rows, self._cols), self._batch) = facts
     self._first_chapter = first_chapter
@@ -80,6 +92,7 @@ class Story(object):
       self._chapter_of = np.full((self._batch,), self._keys.index(first_chapter), np.int32)  # -1: story over
       self._next_override = None
       self._entity_next_at_override = {}
+      self._reward_float = False
       self._union = sorted(self._chars_sprites | self._chars_drapes | self._chars_backdrops)
       self._current_game = self._engine_for(first_chapter)
 
@@ -154,6 +167,10 @@ class Story(object):
       game._auto_reset = True  # environments that are not in this chapter run unobserved
       self._croppers[key].set_engine(game)
       self._engines[key] = game
+      if game.template.reward_is_float and not self._reward_float:  # (ordeal.py:123, 187-190 adds floats)
+        self._reward_float = True
+        if hasattr(self, '_reward'):
+          self._reward = self._reward.astype(np.float64)
     return self._engines[key]
 
   def set_next_chapter(self, key):
@@ -187,8 +204,8 @@ class Story(object):
       later = entity and (before is None or before[env] != assigned[env])  # an entity spoke after the host did
       if not later:
         return self._next_override[env]
-    if entity:
-      return None if assigned[env] == _N.CHAPTER_NONE else int(assigned[env])
+    if entity:  # (a chapter code: the key itself, or an index into the key table of the programs -- examples/ordeal.py)
+      return None if assigned[env] == _N.CHAPTER_NONE else self._engines[self._keys[chapter_index]].chapter_key(assigned[env])
     if not self._auto_advance:
       return None
     nxt = self._keys[chapter_index] + 1
@@ -199,7 +216,7 @@ class Story(object):
     torch = dev.torch_module()
     L = len(self._union)
     self._planes = torch.zeros((B, 1 + L, self._rows, self._cols), dtype=torch.uint8, device='cuda:%d' % self._current_game._device_id)
-    self._reward = np.zeros((B,), np.int64)
+    self._reward = np.zeros((B,), np.float64 if self._reward_float else np.int64)
     self._reward_set = np.zeros((B,), bool)
     self._discount = np.ones((B,), np.float32)
     first = self._keys.index(self._first_chapter)
@@ -213,7 +230,8 @@ class Story(object):
 
   def _scalars(self, key):
     sc = self._engines[key]._read_scalars()  # one synchronisation: the story decides on the host
-    return sc['reward'].astype(np.int64), sc['reward_set'].astype(bool), sc['discount'], sc['done'].astype(bool)
+    rtype = np.float64 if self._engines[key].template.reward_is_float else np.int64
+    return sc['reward'].astype(rtype), sc['reward_set'].astype(bool), sc['discount'], sc['done'].astype(bool)
 
   def _absorb(self, key, obs, members):
     """Takes chapter `key`'s results for the environments in `members`."""
@@ -240,10 +258,16 @@ class Story(object):
     it there; repeats while first frames terminate (storytelling.py:391-470)."""
     while any(m.any() for m in finished.values()):
       starts = collections.defaultdict(lambda: np.zeros((self._batch,), bool))
+      carry = None  # plot words that travel with the environments (storytelling.py:449-450: new_plot.update(old_plot))
       for key, mask in finished.items():
         ci = self._keys.index(key)
         eng = self._engines[key]
         assigned = eng.entities_next_chapter() if mask.any() and eng._assigns_next_chapter() else None
+        if mask.any() and eng.template.n_plot_words:
+          carry = _fresh_plot_words(self._batch) if carry is None else carry
+          carry[:, mask] = eng.plot_words()[:, mask]
+          keys = eng.template.chapter_keys or []
+          carry[_N.PLOT_OD_PRIOR_CHAPTER, mask] = keys.index(key) if key in keys else -1  # new_plot.prior_chapter (:453)
         for env in np.flatnonzero(mask):
           nxt = self._next_of(env, ci, assigned)
           if nxt is None:
@@ -256,7 +280,12 @@ class Story(object):
       finished = {}
       for key, mask in starts.items():
         game = self._engine_for(key)
+        if key not in self._started and game.template.n_plot_words:
+          game.its_showtime()  # (creates the device engine; the environments of `mask` start over below, with their plot words)
+          self._started.add(key)
         if key in self._started:
+          if game.template.n_plot_words:
+            game.set_plot_words(_fresh_plot_words(self._batch) if carry is None else carry, mask)
           obs, _, _ = game.reset(mask)
         else:  # the engine's first reset covers every environment; only `mask` is looked at
           obs, _, _ = game.its_showtime()
@@ -280,6 +309,8 @@ class Story(object):
     if restart.any():  # a new story for these environments: frame 0 of the first chapter is their step
       first = self._first_chapter  # (after the engines have stepped: a restarted environment must not be stepped too)
       self._chapter_of[restart] = self._keys.index(first)
+      if self._engines[first].template.n_plot_words:  # a new story has a new Plot
+        self._engines[first].set_plot_words(_fresh_plot_words(self._batch), restart)
       obs, _, _ = self._engines[first].reset(restart)
       self._absorb(first, obs, restart)
       finished[first] = finished.get(first, np.zeros_like(live)) | self._finished(first, restart)[first]
@@ -290,7 +321,7 @@ class Story(object):
     layers = {ch: self._planes[:, 1 + k] for k, ch in enumerate(self._union)}
     obs = rendering.Observation(board=self._planes[:, 0], layers=layers)
     self._game_over = bool((self._chapter_of < 0).all())
-    return obs, np.where(self._reward_set, self._reward, 0).astype(np.int32), self._discount.copy()
+    return obs, np.where(self._reward_set, self._reward, 0).astype(np.float32 if self._reward_float else np.int32), self._discount.copy()
 
   @property
   def reward_set(self):
@@ -378,6 +409,13 @@ class Story(object):
       game.close()
 
 
+def _fresh_plot_words(batch):
+  """The plot words of a new Plot (include/pcx.h PCX_PLOT_OD_*): no sword, no last position, no prior chapter."""
+  words = np.zeros((_N.PLOT_WORDS, batch), np.int32)
+  words[_N.PLOT_OD_LAST_POSITION] = words[_N.PLOT_OD_PRIOR_CHAPTER] = -1
+  return words
+
+
 def is_fictional(thing):
   """True iff `thing` is one of the stand-ins `Story.things` returns
   (storytelling.py:473-483)."""
@@ -445,8 +483,14 @@ def _collect_facts(chapters, croppers):
     game = chapters[key]()
     cropper = croppers[key]
     cropper.set_engine(game)
-    kinds = {ch: isinstance(thing, things.Sprite) for ch, thing in game.things.items()}
-    chars_backdrops.update(game.backdrop.palette)
+    if game.backdrop is None and game._template is not None:  # Engine.from_template: the compiled game is all there is
+      t = game._template
+      kinds = {chr(sp['ch']): True for sp in t.sprites}
+      kinds.update({chr(dr['ch']): False for dr in t.drapes})
+      chars_backdrops.update(chr(c) for c in np.unique(t.backdrop))
+    else:
+      kinds = {ch: isinstance(thing, things.Sprite) for ch, thing in game.things.items()}
+      chars_backdrops.update(game.backdrop.palette)
     observation, _, _ = game.its_showtime()
     board = cropper.crop(observation).board
     shapes.add(tuple(board.shape[-2:]))

@@ -305,7 +305,7 @@ def test_baked_level_constants_header_is_what_the_library_plans():
 @pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason='needs the reference sources')
 def test_every_reference_example_builds_on_the_host_and_the_unported_ones_fail_loudly():
   """All 18 example files of the reference load UNCHANGED against this package (pycolab_amd/compat.py) and build their
-  game through the mirrored construction API; the five games of the hot path compile to templates, every other one
+  game through the mirrored construction API; the five games of the hot path and the Story of examples/ordeal.py compile to templates, every other one
   stops at the template compiler with UnsupportedEntityError naming the entity class that has no device program --
   never a silent fallback, never a different error (out of scope, and loudly so)."""
   import glob
@@ -321,6 +321,24 @@ def test_every_reference_example_builds_on_the_host_and_the_unported_ones_fail_l
     make = module.make_game
     params = list(inspect.signature(make).parameters)
     args = [np.random.RandomState(0) if p in ('rng', 'random_state') else 0 for p in params]
+    if rel == 'ordeal.py':
+      # a Story of three games (its constructor starts every chapter once on the device, storytelling.py:556-624): the
+      # chapter builders are caught on their way in and compiled one by one -- to the very templates the GPU tests step
+      import types
+      caught, real = {}, module.storytelling
+      module.storytelling = types.SimpleNamespace(Story=lambda chapters, **kw: caught.update(chapters))
+      try:
+        make()
+      finally:
+        module.storytelling = real
+      assert sorted(caught) == ['castle', 'cavern', 'kansas']
+      for key, build in caught.items():
+        game = build()
+        game.the_plot._this_chapter = key
+        t = GameTemplate.from_engine(game)
+        assert t == helpers.load_template('ordeal_' + key) and t.reward_is_float and t.n_plot_words == 3
+      compiled.add(rel)
+      continue
     try:
       game = make(*args)
       GameTemplate.from_engine(game)
@@ -331,5 +349,5 @@ def test_every_reference_example_builds_on_the_host_and_the_unported_ones_fail_l
     except (TypeError, AttributeError, ValueError):
       # make_game() of a research example wants arguments this loop does not know how to make up
       assert rel.startswith('research'), rel
-  assert compiled == hot_path, compiled
-  assert len(refused) >= 11 and 'ordeal.py' in refused and 'shockwave.py' in refused, refused
+  assert compiled == hot_path | {'ordeal.py'}, compiled  # (round 6: SURVEY section 8 f-4's cited game has its device programs)
+  assert len(refused) >= 10 and 'shockwave.py' in refused, refused
