@@ -56,7 +56,10 @@ FIXTURES = {'scrolly_maze': 'scrolly_maze_L%d', 'warehouse': 'warehouse_L%d', 'm
             'warehouse_generic': 'warehouse_L%d',
             # round 6: a scrolly_maze level of one's own on the example's board -- pcx_scrolly_maze_step compiles its instances for it at
             # pcx_engine_create (launch_shape 7) -- next to the shipped level with the same number of coin words (level 1: launch_shape 5)
-            'scrolly_custom_H': 'scrolly_custom_H'}
+            'scrolly_custom_H': 'scrolly_custom_H',
+            # round 6: the Kansas chapter of examples/ordeal.py (10x45 board, float rewards, Plot entries in the plot words) -- one
+            # engine of the example's Story, stepped by pcx_generic_step
+            'ordeal_kansas': 'ordeal_kansas'}
 
 
 def cpu_worker(args):
@@ -604,7 +607,8 @@ def main():
                                # pcx_generic_step (built for the template at run time: launch_shape 31) at VERDICT r3's fixtures
                                measure_config('marauders_custom_A', 0, 32768, 200, 30, device),
                                measure_config('walkers_scroll_groups', 0, 262144, 100, 30, device, cardinal_fields=2),
-                               measure_config('warehouse_generic', 0, 262144, 100, 30, device)]
+                               measure_config('warehouse_generic', 0, 262144, 100, 30, device),
+                               measure_config('ordeal_kansas', 0, 262144, 100, 30, device)]
       # config 2's 11 us per play() against what a launch costs on this box at all
       line['launch_floor_us'] = {'value': launch_floor_us(device), 'what': 'a near-empty kernel (pcx_device_fill_probe over 1 KiB), 1,000 '
                                  'launches back to back on one stream, best of three: the floor under config 2\'s ms_per_step'}

@@ -40,7 +40,7 @@ class Mutant(object):
 # trace, test_cropping), 'reftest:<name>' (the reference's own known-answer tests, tests/golden/reftests),
 # 'engine_test:<what>' (tests/engine_test.py:169-295 restated in test_reference_known_answers), 'raise:<name>'
 # (tests/golden/raises: where the reference raised, test_raise_parity), 'story:<name>' (the reference's own Story over
-# three chapter games, test_story_oracle), 'live:<maker>:<seed>' (a random unwalled level next to the live reference,
+# three chapter games, test_story_oracle), 'ordeal:trace' (the reference's examples/ordeal.py, test_ordeal_oracle), 'live:<maker>:<seed>' (a random unwalled level next to the live reference,
 # test_reference_live_random_levels)
 MUTANTS = [
     Mutant('kill_test_on_true_positions', 'examples/scrolly_maze.py:304 compares VIRTUAL positions',
@@ -268,8 +268,8 @@ MUTANTS = [
            killed_by=['engine_test:reward', 'trace:better_scrolly_custom_A']),
     Mutant('second_reward_replaces_the_first', 'plot.py:200-226: rewards of one step ADD UP',
            'pcx_oracle.c',
-           '  else p->reward += r;',
-           '  else p->reward = r;',
+           '  else { p->reward += r; p->rewardf += (double)r; }',
+           '  else { p->reward = r; p->rewardf = (double)r; }',
            killed_by=['engine_test:reward', 'trace:directives_reward_discount']),
     Mutant('invisible_sprites_painted', 'engine.py:751-757: only visible sprites are painted',
            'pcx_oracle.c',
@@ -443,6 +443,67 @@ MUTANTS = [
            '      case PCX_DIR_NEXT_CHAPTER: p->next_chapter = d->reward; break; /* plot.py:299-324: the last call stands */',
            '      case PCX_DIR_NEXT_CHAPTER: if (p->next_chapter == PCX_CHAPTER_UNSET) p->next_chapter = d->reward; break;',
            killed_by=['story:story_entity_chapters']),
+    # ---- examples/ordeal.py (round 6): killed by the trace of the reference's own ordeal Story (oracle/gen_ordeal_golden.py)
+    Mutant('ordeal_sword_stays_while_stood_on', 'examples/ordeal.py:122-126: the sword vanishes in the frame it is picked up (the flag is read right after it is set)',
+           'pcx_oracle.c',
+           '  if (env->plot.pw[PCX_PLOT_OD_HAS_SWORD]) memset(d->curtain, 0, cells(e)); /* :126 */',
+           '  if (env->plot.pw[PCX_PLOT_OD_HAS_SWORD] && !d->curtain[P->row * e->t.cols + P->col]) memset(d->curtain, 0, cells(e));',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_battle_where_the_dragonduck_stood', 'examples/ordeal.py:177: layers[P][self.position] AFTER the move',
+           'pcx_oracle.c',
+           '  if (dr || dc) mw_move(e, env, id, x->board, dr, dc);\n  if (layer_at(x, \'P\', s->row, s->col)) {',
+           '  const int was_r = s->row, was_c = s->col;\n  if (dr || dc) mw_move(e, env, id, x->board, dr, dc);\n  if (layer_at(x, \'P\', was_r, was_c)) {',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_battle_on_true_positions', 'examples/ordeal.py:172-177: the battle looks at the LAYER of the last repaint, not at where the player is now',
+           'pcx_oracle.c',
+           "  if (layer_at(x, 'P', s->row, s->col)) { /* :177: the layer of the last repaint */",
+           '  if (s->row == P->row && s->col == P->col) {',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_dragonduck_moves_at_frame_0', 'examples/ordeal.py:144: nothing on the first frame',
+           'pcx_oracle.c',
+           '  if (env->plot.frame == 0) return; /* :144 */',
+           '',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_sword_does_not_matter', 'examples/ordeal.py:182-187: with the sword the dragonduck dies',
+           'pcx_oracle.c',
+           '    if (p->pw[PCX_PLOT_OD_HAS_SWORD]) {        /* :182-184 */',
+           '    if (0) {',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_z_order_the_other_way', 'examples/ordeal.py:184, 187: the winner is drawn in front',
+           'pcx_oracle.c',
+           '      p->z_move[p->n_z_updates] = id; p->z_front[p->n_z_updates] = pid; p->n_z_updates++;\n    } else {',
+           '      p->z_move[p->n_z_updates] = pid; p->z_front[p->n_z_updates] = id; p->n_z_updates++;\n    } else {',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_leaves_kansas_one_row_early', 'examples/ordeal.py:217: position.row <= 0',
+           'pcx_oracle.c',
+           '    if (chap == OD_KANSAS && s->row <= 0) {',
+           '    if (chap == OD_KANSAS && s->row <= 1) {',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_no_teleport_on_entry', 'examples/ordeal.py:252-266: the player lines up with where the last game was left',
+           'pcx_oracle.c',
+           '      else mw_teleport(e, s, tr, tc);',
+           '      else (void)tr;',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_teleport_swaps_row_and_column', 'examples/ordeal.py:255-266: (limits.row, last.col) / (last.row, 0)',
+           'pcx_oracle.c',
+           '    else if (prior == OD_KANSAS && chap == OD_CAVERN) { tr = lr; tc = 0; }',
+           '    else if (prior == OD_KANSAS && chap == OD_CAVERN) { tr = lc; tc = 0; }',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_position_not_saved_when_leaving', 'examples/ordeal.py:269: the position is saved on EVERY update, the one that ends the game included',
+           'pcx_oracle.c',
+           '  p->pw[PCX_PLOT_OD_LAST_POSITION] = (int32_t)(((uint32_t)s->row & 0xFFFFu) | ((uint32_t)s->col << 16)); /* :269 */',
+           '  if (!p->game_over) p->pw[PCX_PLOT_OD_LAST_POSITION] = (int32_t)(((uint32_t)s->row & 0xFFFFu) | ((uint32_t)s->col << 16));',
+           killed_by=[], equivalent='the update that ends a chapter does not move the player: the position it would save is the one the previous update saved'),
+    Mutant('ordeal_plot_does_not_travel', 'storytelling.py:449-450: new_plot.update(old_plot)',
+           'pcx_oracle.c',
+           '    for (int w = 0; w < PCX_PLOT_WORDS; ++w) env->plot.pw[w] = e->plot_in[(size_t)w * e->batch + b];',
+           '    env->plot.pw[PCX_PLOT_OD_PRIOR_CHAPTER] = e->plot_in[(size_t)PCX_PLOT_OD_PRIOR_CHAPTER * e->batch + b], env->plot.pw[PCX_PLOT_OD_LAST_POSITION] = e->plot_in[(size_t)PCX_PLOT_OD_LAST_POSITION * e->batch + b];',
+           killed_by=['ordeal:trace']),
+    Mutant('ordeal_rewards_are_integers', 'examples/ordeal.py:124: add_reward(1.0) -- a float',
+           'pcx_oracle.c',
+           '  if (e->t.reward_is_float) { float f = (float)env->plot.rewardf; memcpy(&e->reward[b], &f, 4); } /* the lane is a float32 */',
+           '',
+           killed_by=['ordeal:trace']),
     Mutant('unoccluded_backdrop_layers_show_what_is_on_top', 'rendering.py:220-233: unoccluded backdrop layers are the RAW backdrop',
            'pcx_oracle.c',
            '      for (int i = 0; i < n; ++i) layer[i] = e->backdrop[i] == e->t.chars[k];\n    }\n  }\n  for (int z = 0;',
@@ -600,6 +661,9 @@ def fixture_passes(fixture):
     elif kind == 'story':
       from tests import test_story_oracle
       test_story_oracle.test_oracle_story_matches_reference_story(name)
+    elif kind == 'ordeal':  # the reference's examples/ordeal.py Story (test_ordeal_oracle)
+      from tests import test_ordeal_oracle
+      test_ordeal_oracle.test_oracle_ordeal_matches_the_reference_trace()
     elif kind == 'raise':
       from tests import test_raise_parity
       if name == 'fixed_crop_overhang':
@@ -617,7 +681,7 @@ def all_fixtures():
   from tests import test_oracle_golden, test_cropping, test_reference_known_answers, test_raise_parity, test_story_oracle
   from oracle import ref_live
   return (['trace:' + n for n in test_oracle_golden.ALL_TRACES] + ['crop:' + n for n in test_cropping.CROPPED] +
-          ['reftest:' + n for n in test_reference_known_answers.NAMES] + ['engine_test:z_order', 'engine_test:reward'] + ['story:' + n for n in sorted(test_story_oracle.STORIES)] +
+          ['reftest:' + n for n in test_reference_known_answers.NAMES] + ['engine_test:z_order', 'engine_test:reward'] + ['story:' + n for n in sorted(test_story_oracle.STORIES)] + ['ordeal:trace'] +
           ['raise:' + n for n in test_raise_parity.STEPPED + ('fixed_crop_overhang',)] +
           # (not fixtures: random unwalled levels next to the reference stepped live, where it can be imported)
           (['live:%s:%d' % (m, k) for m in ('random_open_warehouse', 'random_open_better_scrolly') for k in range(12)]

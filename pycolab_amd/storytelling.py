@@ -25,6 +25,16 @@ device -- a `('next_chapter', key)` directive of a tabled entity, per environmen
 as examples/ordeal.py:177-235 does from inside `update()` -- or from the host
 (`story.the_plot.next_chapter = k` at batch 1, `story.set_next_chapter(k_or_array)`
 at batch > 1).
+
+Round 6: examples/ordeal.py itself.  The Plot entries its entities keep (`has_sword`,
+`last_position`) and `the_plot.prior_chapter` are plot words on the device
+(include/pcx.h PCX_PLOT_WORDS): what `new_plot.update(old_plot)` does for the
+reference (storytelling.py:449-453) is, here, `plot_words()` of the engine an
+environment leaves staged with `set_plot_words()` for the masked reset of the
+engine it enters; rewards are float32 where a chapter's template says so; the
+chapter codes its programs assign map to the Story's string keys through the
+template's key table; chapters are built under the `engine.defaults(batch=...)`
+the Story itself was built under.
 """
 
 import collections
@@ -205,7 +215,10 @@ class Story(object):
       if not later:
         return self._next_override[env]
     if entity:  # (a chapter code: the key itself, or an index into the key table of the programs -- examples/ordeal.py)
-      return None if assigned[env] == _N.CHAPTER_NONE else self._engines[self._keys[chapter_index]].chapter_key(assigned[env])
+      if assigned[env] == _N.CHAPTER_NONE:
+        return None
+      eng = getattr(self, '_engines', {}).get(self._keys[chapter_index])
+      return int(assigned[env]) if eng is None else eng.chapter_key(assigned[env])
     if not self._auto_advance:
       return None
     nxt = self._keys[chapter_index] + 1

@@ -1,6 +1,6 @@
 """Every committed golden fixture is what its generator produces from the
 reference TODAY: the generators (oracle/gen_templates.py, gen_golden.py,
-harvest_reference_tests.py, gen_story_golden.py, gen_raise_golden.py; a sample of gen_digests.py) are re-run against
+harvest_reference_tests.py, gen_story_golden.py, gen_ordeal_golden.py, gen_raise_golden.py; a sample of gen_digests.py) are re-run against
 /root/reference into a scratch directory and every array of every file must
 equal the committed one.  Runs where the reference exists (the build
 container); the GPU box has no /root/reference and skips it."""
@@ -14,7 +14,7 @@ import pytest
 from tests import helpers
 
 REFERENCE = os.environ.get('PCX_REFERENCE', '/root/reference')
-GENERATORS = ['gen_templates.py', 'harvest_reference_tests.py', 'gen_story_golden.py', 'gen_golden.py', 'gen_raise_golden.py']
+GENERATORS = ['gen_templates.py', 'harvest_reference_tests.py', 'gen_story_golden.py', 'gen_ordeal_golden.py', 'gen_golden.py', 'gen_raise_golden.py']
 
 
 @pytest.fixture(scope='module')

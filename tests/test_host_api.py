@@ -351,3 +351,30 @@ def test_every_reference_example_builds_on_the_host_and_the_unported_ones_fail_l
       assert rel.startswith('research'), rel
   assert compiled == hot_path | {'ordeal.py'}, compiled  # (round 6: SURVEY section 8 f-4's cited game has its device programs)
   assert len(refused) >= 10 and 'shockwave.py' in refused, refused
+
+
+def test_engine_defaults_reach_engines_built_out_of_the_callers_sight():
+  """`engine.defaults(batch=...)`: game files that build their engines inside `make_game()` -- the chapters of
+  examples/ordeal.py:82-110 are built inside its Story -- cannot be `configure()`d by the caller; the block's batch size
+  and device are what `Engine.__init__` starts from, nested blocks restore what was there, and `configure()` still wins."""
+  from pycolab_amd import ascii_art, engine
+  art = ['#####', '#P  #', '#####']
+  build = lambda: ascii_art.ascii_art_to_game(art, what_lies_beneath=' ', sprites={'P': ascii_art.Partial(tabled_walker(), impassable='#')})
+  assert build().batch == 1
+  with engine.defaults(batch=4096, device=0):
+    assert engine.current_defaults() == dict(batch=4096, device=0)
+    assert build().batch == 4096
+    with engine.defaults(batch=8):
+      assert build().batch == 8
+    assert build().batch == 4096
+    assert build().configure(batch=2).batch == 2
+  assert build().batch == 1 and engine.current_defaults() == dict(batch=1, device=0)
+  with pytest.raises(ValueError):
+    with engine.defaults(batch=0):
+      pass
+  assert engine.current_defaults() == dict(batch=1, device=0)
+
+
+def tabled_walker():
+  from pycolab_amd.prefab_parts import tabled
+  return tabled.TabledWalker

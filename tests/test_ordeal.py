@@ -135,3 +135,45 @@ def test_ordeal_chapter_kernels_match_the_oracle_on_hashed_actions(key, build, m
     assert rewards == {1.0, -1.0}
   eng.close()
   orc.close()
+
+
+def test_ordeal_checkpoint_carries_the_plot_words_and_what_resets_start_from(monkeypatch):
+  """`Engine.export_state()` of a chapter engine holds the plot words (state words) AND the staged words its auto-resets
+  start from (`pcx_engine_set_plot_words`): a fresh engine that imports the checkpoint continues bit for bit, resets
+  included."""
+  from pycolab_amd.engine import Engine
+  helpers.force_generic(monkeypatch, 'table-driven')
+  t = helpers.load_template('ordeal_castle')
+  B, seed = 256, 0xC4EC
+  rng = np.random.RandomState(5)
+  words = np.zeros((N.PLOT_WORDS, B), np.int32)
+  words[N.PLOT_OD_HAS_SWORD] = rng.randint(0, 2, B)
+  words[N.PLOT_OD_LAST_POSITION] = rng.randint(0, t.rows, B) | (rng.randint(6, 9, B) << 16)
+  words[N.PLOT_OD_PRIOR_CHAPTER] = 2  # from Kansas: the player enters through the gate, in the column it left
+  a = Engine.from_template(t, batch=B, auto_reset=True)
+  a.its_showtime()
+  a.set_plot_words(words)
+  a.reset()
+  a.step_hashed(seed, 0, 24)
+  blob = a.export_state()
+  b = Engine.from_template(t, batch=B, auto_reset=True)
+  b.its_showtime()
+  b.import_state(blob)
+  np.testing.assert_array_equal(b.plot_words(), a.plot_words())
+  resets = 0
+  for step in range(24, 72):
+    a.step_hashed(seed, step, 1)
+    b.step_hashed(seed, step, 1)
+    np.testing.assert_array_equal(helpers.to_np(b.planes_view()), helpers.to_np(a.planes_view()), err_msg='step %d' % step)
+    np.testing.assert_array_equal(b.plot_words(), a.plot_words(), err_msg='step %d' % step)
+    sa, sb = a._read_scalars(), b._read_scalars()
+    for k in sa:
+      np.testing.assert_array_equal(sb[k], sa[k], err_msg='step %d %s' % (step, k))
+    fresh = sa['frame'] == 0
+    resets += int(fresh.sum())
+    # an environment that started over did so from ITS staged words: with the sword where it was staged, behind the gate's column
+    np.testing.assert_array_equal(a.plot_words()[N.PLOT_OD_HAS_SWORD][fresh], words[N.PLOT_OD_HAS_SWORD][fresh])
+    np.testing.assert_array_equal(a.plot_words()[N.PLOT_OD_LAST_POSITION][fresh] >> 16, words[N.PLOT_OD_LAST_POSITION][fresh] >> 16)
+  assert resets > B // 4
+  a.close()
+  b.close()
