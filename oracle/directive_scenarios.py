@@ -64,6 +64,22 @@ SCENARIOS = {
             'R': dict(kind='sprite', motion=None, directive=(2, 3),
                       calls={1: [('terminate_episode', 0.0625)], 2: [('add_reward', 1)], 3: [('terminate_episode',)]}),
         }),
+    # plot.py:200-226: add_reward sums anything `+=`-able -- here Python floats, as examples/ordeal.py:123, 187-190 adds them
+    # (round 6: pcx_template::reward_is_float, a float32 reward lane).  The values are dyadic, so the reference's double
+    # sums and the lane's float32 sums agree to the bit; a walker so that the board moves too.
+    'directives_float_rewards': dict(
+        art=['.........',
+             '..Q.w.R..',
+             '.........'],
+        beneath='.', z_order='QwR', schedule=[['Q', 'w'], ['R']], float_rewards=True,
+        entities={
+            'Q': dict(kind='sprite', motion=None, directive=(0, 3),
+                      calls={1: [('add_reward', 0.5)], 2: [('add_reward', -1.25), ('add_reward', 2.0)], 3: [('terminate_episode', 0.5), ('add_reward', 0.125)]}),
+            'w': dict(kind='walker', impassable='', confined=True, motion=(4, 15), directive=(8, 3),
+                      calls={1: [('add_reward', 2.75)], 2: [('add_reward', -0.375)], 3: [('add_reward', 1)]}),
+            'R': dict(kind='sprite', motion=None, directive=(2, 3),
+                      calls={1: [('add_reward', 1024.5)], 2: [('add_reward', -0.0625)], 3: [('terminate_episode',)]}),
+        }),
 }
 
 MOTION_NAMES = ['n', 'ne', 'e', 'se', 's', 'sw', 'w', 'nw', 'stay']
@@ -75,6 +91,8 @@ def build_twin(spec, ascii_art, tabled):
   sprites, drapes = {}, {}
   for ch, e in spec['entities'].items():
     kw = dict(directive_field=e['directive'], directives=e['calls'])
+    if spec.get('float_rewards'):
+      kw['float_rewards'] = True
     if e['kind'] == 'walker':
       sprites[ch] = P(tabled.TabledWalker, impassable=e['impassable'], confined_to_board=e['confined'],
                       action_field=e['motion'], **kw)

@@ -110,7 +110,9 @@ def record(obs, reward, discount, game, chars, sprite_chars):
     for c in chars:  # occluded layers are board == c
       assert np.array_equal(obs.layers[c], obs.board == ord(c)), c
   assert set(obs.layers.keys()) == set(chars)
-  return (obs.board.copy(), 0 if reward is None else int(reward),
+  if isinstance(reward, float):  # a game whose entities add Python floats (directives_float_rewards; plot.py:200-226)
+    assert float(np.float32(reward)) == reward, reward  # (the fixture's values are exact in the float32 lane)
+  return (obs.board.copy(), 0 if reward is None else (reward if isinstance(reward, float) else int(reward)),
           0 if reward is None else 1, float(discount), int(game.game_over),
           sprite_states(game, sprite_chars),
           np.stack([obs.layers[c] for c in chars]).astype(np.uint8) if UNOCCLUDED else None)
@@ -345,7 +347,8 @@ def run(name, make_game, E, T, n_ordinary, quit_action, seed, template_name, see
       path, template=np.frombuffer(template_name.encode(), np.uint8),
       chars=np.array([ord(c) for c in chars], np.uint8),
       sprite_chars=np.array([ord(c) for c in sprite_chars], np.uint8),
-      actions=actions, boards=sw(boards, np.uint8), reward=sw(rewards, np.int32),
+      actions=actions, boards=sw(boards, np.uint8),
+      reward=sw(rewards, np.float32 if any(isinstance(r, float) for env in rewards for r in env) else np.int32),
       reward_set=sw(rsets, np.uint8), discount=sw(discounts, np.float32),
       done=sw(dones, np.uint8), sprites=sw(sprites, np.int16), **extra)
   nd = int(np.array(dones).sum())
@@ -433,7 +436,7 @@ def main():
   # Plot directives (add_reward / terminate_episode(discount) / change_z_order)
   # issued by the reference's own test entities: tests/engine_test.py:169-295
   from oracle import directive_scenarios as ds
-  seeds = {'directives_reward_discount': 151, 'directives_z_order': 152, 'directives_two_discounts': 153}  # fixed per scenario
+  seeds = {'directives_reward_discount': 151, 'directives_z_order': 152, 'directives_two_discounts': 153, 'directives_float_rewards': 154}  # fixed per scenario
   for name, spec in sorted(ds.SCENARIOS.items()):
     run(name, lambda spec=spec: ds.build_reference(spec, ref_art, tt), E=24, T=160, n_ordinary=9, quit_action=99,
         seed=seeds[name], template_name=name, ref_action=lambda a, spec=spec: ds.reference_action(spec, a),

@@ -150,7 +150,7 @@ class GameTemplate(object):
         if s['program'] == N.PROG_OD_PLAYER:
           s['param'] = [t.chapter_keys.index(this) if this in t.chapter_keys else -1, 0, 0, 0]
     t.reward_is_float = t.reward_is_float or any(
-        getattr(type(ent), 'pcx_float_rewards', False) for ent in eng._sprites_and_drapes.values())
+        getattr(ent, 'pcx_float_rewards', False) for ent in eng._sprites_and_drapes.values())
     # plot directives of tabled entities (prefab_parts/tabled.py), in z-order of the entities
     for ch, ent in eng._sprites_and_drapes.items():
       for selector, calls in sorted(getattr(ent, 'pcx_directives', {}).items()):

@@ -165,7 +165,10 @@ int pcx_engine_create(const pcx_template* t, int64_t batch, int device_id, pcx_e
     return set_error(PCX_E_INVALID, "pcx_engine_create: malformed template");
   PCX_HIP(hipSetDevice(device_id));
   pcx::Backend* b = nullptr;
-  switch (t->game) {
+  // a float32 reward lane (pcx_template::reward_is_float) is the table-driven kernel's: the hand-written kernels add integers
+  if (t->reward_is_float && t->game == PCX_GAME_SCROLLY_MAZE)
+    return set_error(PCX_E_UNSUPPORTED, "pcx_engine_create: pcx_scrolly_maze_step has no float32 reward lane (reward_is_float)");
+  switch (t->reward_is_float ? PCX_GAME_WALKERS : t->game) {
     case PCX_GAME_SCROLLY_MAZE: b = pcx::make_scrolly_maze_backend(); break;
     // hand-written kernels for the shipped shapes; anything else of the same
     // game (other boards, occlusion_in_layers=False) takes the table-driven one

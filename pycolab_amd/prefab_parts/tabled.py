@@ -26,6 +26,12 @@ under the value its directive field of the action holds (0 = none):
     ('change_z_order', 'c', None)        ... all the way to the back
     ('next_chapter', 2)                  the_plot.next_chapter = 2         plot.py:299-324
     ('next_chapter', None)               ... = None: the Story ends after this game
+
+Rewards are integers unless an entity of the game is built with
+`float_rewards=True`: the game's reward lane is then a float32
+(include/pcx.h pcx_template::reward_is_float) and `('add_reward', 0.5)` is
+what the reference's `the_plot.add_reward(0.5)` is (plot.py:200-226 sums
+anything `+=`-able; examples/ordeal.py:123 adds 1.0).
 """
 
 from pycolab_amd.prefab_parts import drapes
@@ -44,12 +50,13 @@ class TabledWalker(sprites.MazeWalker):
 
   def __init__(self, corner, position, character, impassable,
                confined_to_board=False, egocentric_scroller=False,
-               scrolling_group='', action_field=(0, 0), directive_field=(0, 0), directives=None):
+               scrolling_group='', action_field=(0, 0), directive_field=(0, 0), directives=None, float_rewards=False):
     super(TabledWalker, self).__init__(
         corner, position, character, impassable, confined_to_board,
         egocentric_scroller, scrolling_group)
     self.pcx_param = _params(action_field, directive_field)
     self.pcx_directives = directives or {}
+    self.pcx_float_rewards = bool(float_rewards)
 
 
 class TabledScrolly(drapes.Scrolly):
@@ -57,22 +64,24 @@ class TabledScrolly(drapes.Scrolly):
 
   def __init__(self, curtain, character, board_shape, whole_pattern,
                board_northwest_corner, scroll_margins=(2, 3),
-               scrolling_group='', action_field=(0, 0), directive_field=(0, 0), directives=None):
+               scrolling_group='', action_field=(0, 0), directive_field=(0, 0), directives=None, float_rewards=False):
     super(TabledScrolly, self).__init__(
         curtain, character, board_shape, whole_pattern,
         board_northwest_corner, scroll_margins, scrolling_group)
     self.pcx_param = _params(action_field, directive_field)
     self.pcx_directives = directives or {}
+    self.pcx_float_rewards = bool(float_rewards)
 
 
 class StaticDrape(drapes.things.Drape):
   """A drape that never changes (it may still issue plot directives)."""
   pcx_program = 'static'
 
-  def __init__(self, curtain, character, directive_field=(0, 0), directives=None):
+  def __init__(self, curtain, character, directive_field=(0, 0), directives=None, float_rewards=False):
     super(StaticDrape, self).__init__(curtain, character)
     self.pcx_param = _params((0, 0), directive_field)
     self.pcx_directives = directives or {}
+    self.pcx_float_rewards = bool(float_rewards)
 
 
 class StaticSprite(sprites.things.Sprite):
@@ -80,7 +89,8 @@ class StaticSprite(sprites.things.Sprite):
   reference's `tt.TestSprite` (tests/test_things.py:133-164)."""
   pcx_program = 'static'
 
-  def __init__(self, corner, position, character, directive_field=(0, 0), directives=None):
+  def __init__(self, corner, position, character, directive_field=(0, 0), directives=None, float_rewards=False):
     super(StaticSprite, self).__init__(corner, position, character)
     self.pcx_param = _params((0, 0), directive_field)
     self.pcx_directives = directives or {}
+    self.pcx_float_rewards = bool(float_rewards)

@@ -103,6 +103,7 @@ class Story(object):
       self._next_override = None
       self._entity_next_at_override = {}
       self._reward_float = False
+      self._scalar_cache = {}
       self._union = sorted(self._chars_sprites | self._chars_drapes | self._chars_backdrops)
       self._current_game = self._engine_for(first_chapter)
 
@@ -242,6 +243,15 @@ class Story(object):
     return self._batched_result()
 
   def _scalars(self, key):
+    eng = self._engines[key]
+    cached = self._scalar_cache.get(key)
+    if cached is not None and cached[0] == eng._steps_launched:  # (the same launch: _absorb and _finished read it once)
+      return cached[1]
+    out = self._scalars_now(key)
+    self._scalar_cache[key] = (eng._steps_launched, out)
+    return out
+
+  def _scalars_now(self, key):
     sc = self._engines[key]._read_scalars()  # one synchronisation: the story decides on the host
     rtype = np.float64 if self._engines[key].template.reward_is_float else np.int64
     return sc['reward'].astype(rtype), sc['reward_set'].astype(bool), sc['discount'], sc['done'].astype(bool)

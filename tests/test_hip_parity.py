@@ -25,7 +25,7 @@ ALL_GAMES = LEVELS + ['warehouse_L0', 'warehouse_L1', 'warehouse_L2', 'hello_wor
                       # run-time-shape instances of pcx_warehouse_step / pcx_better_scrolly_step
                       'warehouse_custom_C', 'warehouse_custom_D', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C', 'better_scrolly_custom_D', 'better_scrolly_custom_E',
                       # Plot directives incl. change_z_order on the device (engine.py:796-835)
-                      'directives_z_order', 'directives_reward_discount', 'directives_two_discounts']
+                      'directives_z_order', 'directives_reward_discount', 'directives_two_discounts', 'directives_float_rewards']
 
 
 class OracleAdapter(binding.OracleEngine):

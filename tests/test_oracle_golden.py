@@ -26,7 +26,7 @@ ALL_TRACES = ['scrolly_maze_L0', 'scrolly_maze_L1', 'scrolly_maze_L2', 'warehous
               'warehouse_custom_C', 'warehouse_custom_D', 'better_scrolly_custom_A', 'better_scrolly_custom_B', 'better_scrolly_custom_C', 'better_scrolly_custom_D', 'better_scrolly_custom_E',
               # Plot directives from inside update(): add_reward, terminate_episode(discount), change_z_order
               # (oracle/directive_scenarios.py; reference: tests/engine_test.py:169-295)
-              'directives_z_order', 'directives_reward_discount', 'directives_two_discounts']
+              'directives_z_order', 'directives_reward_discount', 'directives_two_discounts', 'directives_float_rewards']
 
 
 @pytest.mark.parametrize('name', ALL_TRACES)

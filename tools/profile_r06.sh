@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_r06
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ROWS=${*:-headline scrolly_131072 scrolly_262144 scrolly_custom_H_131072 scrolly_L1_131072 scrolly_4096 marauders_32768 marauders_262144 warehouse_262144 better_scrolly_65536 hello_world_1048576 marauders_custom_A walkers warehouse_generic}
+ROWS=${*:-headline scrolly_131072 scrolly_262144 scrolly_custom_H_131072 scrolly_L1_131072 scrolly_4096 marauders_32768 marauders_262144 warehouse_262144 better_scrolly_65536 hello_world_1048576 marauders_custom_A walkers warehouse_generic ordeal_kansas}
 for row in $ROWS; do
   D=$OUT/$row
   mkdir -p $D

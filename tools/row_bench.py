@@ -2,7 +2,7 @@
 """One row of bench.py's line by itself (what tools/profile_r06.sh runs under rocprofv3, so that the only step kernel in a
 trace is the row's own): prints the row's JSON.
   python tools/row_bench.py headline | scrolly_131072 | scrolly_262144 | scrolly_custom_H_131072 | scrolly_L1_131072 | scrolly_4096 | marauders_32768 | marauders_262144 |
-                            warehouse_262144 | better_scrolly_65536 | hello_world_1048576 | marauders_custom_A | walkers | warehouse_generic"""
+                            warehouse_262144 | better_scrolly_65536 | hello_world_1048576 | marauders_custom_A | walkers | warehouse_generic | ordeal_kansas"""
 import json
 import os
 import sys
@@ -26,6 +26,7 @@ ROWS = {  # name -> measure_config arguments (game, level, batch, steps, warmup)
     'marauders_custom_A': ('marauders_custom_A', 0, 32768, 200, 30, {}),
     'walkers': ('walkers_scroll_groups', 0, 262144, 100, 30, {'cardinal_fields': 2}),
     'warehouse_generic': ('warehouse_generic', 0, 262144, 100, 30, {}),
+    'ordeal_kansas': ('ordeal_kansas', 0, 262144, 100, 30, {}),
 }
 
 
