@@ -499,6 +499,11 @@ MUTANTS = [
            '    for (int w = 0; w < PCX_PLOT_WORDS; ++w) env->plot.pw[w] = e->plot_in[(size_t)w * e->batch + b];',
            '    env->plot.pw[PCX_PLOT_OD_PRIOR_CHAPTER] = e->plot_in[(size_t)PCX_PLOT_OD_PRIOR_CHAPTER * e->batch + b], env->plot.pw[PCX_PLOT_OD_LAST_POSITION] = e->plot_in[(size_t)PCX_PLOT_OD_LAST_POSITION * e->batch + b];',
            killed_by=['ordeal:trace']),
+    Mutant('float_directive_rewards_truncated', 'plot.py:200-226: add_reward sums what it is given -- 0.5 stays 0.5',
+           'pcx_oracle.c',
+           'plot_add_rewardf(p, (double)f); }',
+           'plot_add_rewardf(p, (double)(int)f); }',
+           killed_by=['trace:directives_float_rewards']),
     Mutant('ordeal_rewards_are_integers', 'examples/ordeal.py:124: add_reward(1.0) -- a float',
            'pcx_oracle.c',
            '  if (e->t.reward_is_float) { float f = (float)env->plot.rewardf; memcpy(&e->reward[b], &f, 4); } /* the lane is a float32 */',

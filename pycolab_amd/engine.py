@@ -328,11 +328,15 @@ class Engine(object):
     words = self.plot_words()[:, 0]
     if words[N.PLOT_OD_HAS_SWORD]:
       dict.__setitem__(self._the_plot, 'has_sword', True)
+    else:  # (the entry exists only once the sword has been picked up: ordeal.py:123; gone again after a reset in place)
+      dict.pop(self._the_plot, 'has_sword', None)
     lp = int(words[N.PLOT_OD_LAST_POSITION])
     if lp != -1:
       r, c = lp & 0xFFFF, (lp >> 16) & 0xFFFF
       dict.__setitem__(self._the_plot, 'last_position',
                        things.Sprite.Position(r - 0x10000 if r >= 0x8000 else r, c - 0x10000 if c >= 0x8000 else c))
+    else:
+      dict.pop(self._the_plot, 'last_position', None)
 
   def play(self, actions):
     """engine.py:583-639: one step of every environment.
@@ -584,6 +588,8 @@ class Engine(object):
       stale._planes_stale = True  # (a post-processor or cropper that would read the engine's planes raises instead)
       if self._batch == 1:
         self.check_errors()
+        if self._template.n_plot_words:
+          self._plot_from_device()
         return stale, (self._reward_type(sc['reward'][0]) if sc['reward_set'][0] else None), float(sc['discount'][0])
       pick = lambda k: (self._b[k].tensor if self._b[k].tensor is not None else self._b[k].numpy())
       return stale, pick('reward'), pick('discount')
