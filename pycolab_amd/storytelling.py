@@ -104,6 +104,11 @@ class Story(object):
       self._entity_next_at_override = {}
       self._reward_float = False
       self._scalar_cache = {}
+      # Layers with occlusion are `board == character` (rendering.py:177-179) and a cropper that never pads keeps them so:
+      # while every chapter so far is like that the story assembles only the BOARD per chapter (one select per live chapter)
+      # and derives all layers of the union in one compare (`_flush_layers`); the first chapter that is not ends that
+      self._layers_from_board = True
+      self._layers_stale = False
       self._union = sorted(self._chars_sprites | self._chars_drapes | self._chars_backdrops)
       self._current_game = self._engine_for(first_chapter)
 
@@ -178,6 +183,9 @@ class Story(object):
       game._auto_reset = True  # environments that are not in this chapter run unobserved
       self._croppers[key].set_engine(game)
       self._engines[key] = game
+      if not game.template.occlusion_in_layers or getattr(self._croppers[key], '_pad_char', None) is not None:
+        self._flush_layers()
+        self._layers_from_board = False
       if game.template.reward_is_float and not self._reward_float:  # (ordeal.py:123, 187-190 adds floats)
         self._reward_float = True
         if hasattr(self, '_reward'):
@@ -264,6 +272,12 @@ class Story(object):
     self._reward_set[members] |= rset[members]
     self._discount[members] = discount[members]
     cropped = self._croppers[key].crop(obs)
+    if self._layers_from_board:
+      if members.any():
+        sel = torch.from_numpy(members).to(self._planes.device)[:, None, None]
+        self._planes[:, 0] = torch.where(sel, _as_tensor(cropped.board, self._planes), self._planes[:, 0])
+        self._layers_stale = True
+      return
     idx = torch.from_numpy(np.flatnonzero(members)).to(self._planes.device)
     if idx.numel() == 0:
       return
@@ -271,6 +285,15 @@ class Story(object):
     self._planes[idx, 1:] = 0
     for ch, layer in cropped.layers.items():
       self._planes[idx, 1 + self._union.index(ch)] = _as_tensor(layer, self._planes)[idx].to(torch.uint8)
+
+  def _flush_layers(self):
+    """The layers of the union's characters from the assembled boards (see `_layers_from_board`)."""
+    if getattr(self, '_layers_stale', False):
+      torch = dev.torch_module()
+      if not hasattr(self, '_union_codes'):
+        self._union_codes = torch.tensor([ord(c) for c in self._union], dtype=torch.uint8, device=self._planes.device)[None, :, None, None]
+      self._planes[:, 1:].copy_(self._planes[:, :1] == self._union_codes)
+      self._layers_stale = False
 
   def _finished(self, key, members):
     _, _, _, done = self._scalars(key)
@@ -291,7 +314,29 @@ class Story(object):
           carry[:, mask] = eng.plot_words()[:, mask]
           keys = eng.template.chapter_keys or []
           carry[_N.PLOT_OD_PRIOR_CHAPTER, mask] = keys.index(key) if key in keys else -1  # new_plot.prior_chapter (:453)
-        for env in np.flatnonzero(mask):
+        envs = np.flatnonzero(mask)
+        if self._next_override is None and envs.size:
+          # nobody on the host spoke (the common case): `_next_of` for all of them at once -- the entities' word through
+          # the chapter's key table, else the next chapter of a list
+          if assigned is None:
+            codes = np.full(envs.shape, _N.CHAPTER_UNSET, np.int64)
+          else:
+            codes = assigned[envs].astype(np.int64)
+          follow = None
+          if self._auto_advance:
+            follow = self._keys[ci] + 1 if (self._keys[ci] + 1) in self._chapters else None
+          for code in np.unique(codes):
+            these = envs[codes == code]
+            nxt = follow if code == _N.CHAPTER_UNSET else None if code == _N.CHAPTER_NONE else eng.chapter_key(code)
+            if nxt is None:
+              self._chapter_of[these] = -1
+            else:
+              if nxt not in self._chapters:
+                raise KeyError('no chapter {!r} was supplied to the Story constructor'.format(nxt))
+              self._chapter_of[these] = self._keys.index(nxt)
+              starts[nxt][these] = True
+          continue
+        for env in envs:
           nxt = self._next_of(env, ci, assigned)
           if nxt is None:
             self._chapter_of[env] = -1
@@ -341,6 +386,7 @@ class Story(object):
     return self._batched_result()
 
   def _batched_result(self):
+    self._flush_layers()
     layers = {ch: self._planes[:, 1 + k] for k, ch in enumerate(self._union)}
     obs = rendering.Observation(board=self._planes[:, 0], layers=layers)
     self._game_over = bool((self._chapter_of < 0).all())
