@@ -309,8 +309,10 @@ def measure_step_n(game, level, batch, steps, device, repeats=3):
   ms = median(runs)
   eng.check_errors()
   bps = int(N.lib().pcx_engine_bytes_per_step(eng._native))
-  out = {'workload': 'examples/%s, %d envs, Engine.step_n(tape of %d steps): several steps per launch, every step writes its '
-                     'observation' % (fixture, batch, steps),
+  how = ('several steps per launch' if shape in (12, 13) else
+         'single-step launches (the engine walks steps inside a launch only where that pays: up to 655,360 environments, profiles/r06_stepn_crossover.txt)')
+  out = {'workload': 'examples/%s, %d envs, Engine.step_n(tape of %d steps): %s, every step writes its '
+                     'observation' % (fixture, batch, steps, how),
          'ms_per_step': ms, 'ms_per_step_min_max': [min(runs), max(runs)], 'env_steps_per_s': batch / (ms * 1e-3),
          'kernel': kernel, 'launch_shape': shape, 'algorithmic_bytes_per_env_step': bps,
          'hbm_frac': bps * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': source}
@@ -598,6 +600,7 @@ def main():
                                measure_step_n('scrolly_maze', 0, 4096, 1000, device),
                                # the headline batch through Engine.step_n: launches of up to 64 steps in which every persistent
                                # worker keeps its units from step to step (launch shape 13); every step still writes its observation
+                               measure_step_n('scrolly_maze', 0, 131072, 256, device),
                                measure_step_n('scrolly_maze', 0, 1048576, 128, device),
                                measure_config('marauders', 0, 32768, 200, 20, device, cpu_seconds=0 if args.no_cpu_baseline else 4.0),
                                measure_config('marauders', 0, 262144, 50, 10, device),

@@ -246,7 +246,10 @@ def test_headline_batch_default_shape_equals_one_workgroup_per_group_shape_every
   for t0 in range(T // 2):  # single-step launches: the shape Engine.play() takes ...
     hip.step_hashed(0xC0FFEE, t0, 1)
     assert raw_shape_of(hip) in (3, 5)  # (5: the constants-compiled-in instance; as tests/test_gate_digests.py)
-  hip.step_hashed(0xC0FFEE, T // 2, T - T // 2)  # ... then one launch of twelve steps, every worker on its own units
+  # ... then one launch of twelve steps, every worker on its own units (PCX_FUSE_STEPS=2: above ~650,000 environments step_n
+  # issues single-step launches by itself -- tickets and stealing win there, profiles/r06_stepn_crossover.txt)
+  with Knobs(PCX_FUSE_STEPS=2):
+    hip.step_hashed(0xC0FFEE, T // 2, T - T // 2)
   assert raw_shape_of(hip) == 13
   planes = hip.eng.planes_view()
   with Knobs(PCX_SM_SHAPE=0):
