@@ -177,15 +177,22 @@ def time_steps(eng, row, lo, hi, barrier, after_step=None):
   import torch
   barrier()
   ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  trace = [] if os.environ.get('PCX_BENCH_TRACE') else None  # (diagnosis only: an event after every launch, printed to stderr)
   t0 = time.perf_counter()
   ev0.record()
   for t in range(lo, hi):
     eng.step(row(t))
     if after_step is not None:
       after_step()
+    if trace is not None:
+      trace.append(torch.cuda.Event(enable_timing=True))
+      trace[-1].record()
   ev1.record()
   barrier()
   wall = time.perf_counter() - t0
+  if trace:
+    marks = [ev0] + trace
+    sys.stderr.write('steps [%d, %d) per launch, ms: %s\n' % (lo, hi, ' '.join('%.3f' % marks[i].elapsed_time(marks[i + 1]) for i in range(len(trace)))))
   return wall, ev0.elapsed_time(ev1) / (hi - lo)
 
 
