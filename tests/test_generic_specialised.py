@@ -19,7 +19,9 @@ from tests import helpers
 GENERIC = ['warehouse_L0', 'warehouse_L2', 'warehouse_custom_B', 'warehouse_L0_unoccluded', 'marauders', 'marauders_custom_A',
            'marauders_unoccluded', 'walkers_room', 'walkers_hidden', 'walkers_scroll_groups', 'walkers_scroll_always', 'walkers_scroll_margins',
            'directives_z_order', 'directives_reward_discount', 'hello_world', 'hello_custom_A', 'better_scrolly_maze_L1',
-           'better_scrolly_custom_B']
+           'better_scrolly_custom_B',
+           # round 6: a float32 reward lane (tabled entities adding Python floats; the three chapters of examples/ordeal.py: tests/test_ordeal.py)
+           'directives_float_rewards', 'ordeal_castle']
 
 
 def check(template, cache):
@@ -177,7 +179,7 @@ def test_specialised_build_matches_oracle_and_table_driven_build(name, monkeypat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['warehouse_L0', 'marauders_custom_A', 'walkers_scroll_groups', 'directives_z_order'])
+@pytest.mark.parametrize('name', ['warehouse_L0', 'marauders_custom_A', 'walkers_scroll_groups', 'directives_z_order', 'directives_float_rewards', 'ordeal_castle'])
 def test_specialised_build_tapes_and_environments_left_alone(name, monkeypatch, tmp_path):
   B, T = 500, 90
   t, spec, table, orc = engines(name, B, monkeypatch, tmp_path)
