@@ -18,3 +18,5 @@ grep -E "passed|failed" $OUT/r06_gpu_suite.txt
 tail -c 300 $OUT/r06_bench_n1.json
 (timeout 300 python tools/ordeal_story_bench.py --batch 16384) 2>&1 | grep -v amdgpu.ids > $OUT/r06_ordeal_story.txt
 cat $OUT/r06_ordeal_story.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -2 > $OUT/r06_smoke.txt
+cat $OUT/r06_smoke.txt
