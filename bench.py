@@ -283,6 +283,14 @@ def measure_config(game, level, batch, steps, warmup, device, repeats=3, raises=
   return out
 
 
+def guarded(fn, *args, **kw):
+  """A secondary row of the line must not cost the headline its line: what went wrong stands in its place."""
+  try:
+    return fn(*args, **kw)
+  except Exception as e:  # pylint: disable=broad-except
+    return {'workload': '%s%r' % (fn.__name__, args[:3]), 'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+
+
 def measure_step_n(game, level, batch, steps, device, repeats=3):
   """BASELINE config 2 through `Engine.step_n(tape)`: the launches take several steps each at this batch size (the
   cooperative instance walks them with the state words in registers; include/pcx.h pcx_engine_step_n) -- every step
@@ -599,35 +607,38 @@ def main():
       # BASELINE configs 2-4 on the same GPU, same run (their own kernels and rooflines), then the other two
       # hand-written kernels: SURVEY 8 f-1 (better_scrolly_maze, 45x89 board) and config 1's game on the GPU
       # (+ config 5's per-GPU shard sizes: 131,072 environments = 1,048,576 over eight GPUs, and 262,144 = over four)
-      line['other_configs'] = [measure_config('scrolly_maze', 0, 131072, 200, 20, device),
-                               measure_config('scrolly_maze', 0, 262144, 200, 20, device),
-                               measure_config('scrolly_custom_H', 0, 131072, 200, 20, device),
-                               measure_config('scrolly_maze', 1, 131072, 200, 20, device),
-                               measure_config('scrolly_maze', 0, 4096, 200, 20, device),
-                               measure_step_n('scrolly_maze', 0, 4096, 1000, device),
+      line['other_configs'] = [guarded(measure_config, 'scrolly_maze', 0, 131072, 200, 20, device),
+                               guarded(measure_config, 'scrolly_maze', 0, 262144, 200, 20, device),
+                               guarded(measure_config, 'scrolly_custom_H', 0, 131072, 200, 20, device),
+                               guarded(measure_config, 'scrolly_maze', 1, 131072, 200, 20, device),
+                               guarded(measure_config, 'scrolly_maze', 0, 4096, 200, 20, device),
+                               guarded(measure_step_n, 'scrolly_maze', 0, 4096, 1000, device),
                                # the headline batch through Engine.step_n: launches of up to 64 steps in which every persistent
                                # worker keeps its units from step to step (launch shape 13); every step still writes its observation
-                               measure_step_n('scrolly_maze', 0, 131072, 256, device),
-                               measure_step_n('scrolly_maze', 0, 1048576, 128, device),
-                               measure_config('marauders', 0, 32768, 200, 20, device, cpu_seconds=0 if args.no_cpu_baseline else 4.0),
-                               measure_config('marauders', 0, 262144, 50, 10, device),
-                               measure_config('warehouse', 0, 262144, 100, 10, device, cpu_seconds=0 if args.no_cpu_baseline else 4.0),
-                               measure_config('better_scrolly_maze', 0, 65536, 50, 10, device),
-                               measure_config('hello_world', 0, 1048576, 50, 10, device),
+                               guarded(measure_step_n, 'scrolly_maze', 0, 131072, 256, device),
+                               guarded(measure_step_n, 'scrolly_maze', 0, 1048576, 128, device),
+                               guarded(measure_config, 'marauders', 0, 32768, 200, 20, device, cpu_seconds=0 if args.no_cpu_baseline else 4.0),
+                               guarded(measure_config, 'marauders', 0, 262144, 50, 10, device),
+                               guarded(measure_config, 'warehouse', 0, 262144, 100, 10, device, cpu_seconds=0 if args.no_cpu_baseline else 4.0),
+                               guarded(measure_config, 'better_scrolly_maze', 0, 65536, 50, 10, device),
+                               guarded(measure_config, 'hello_world', 0, 1048576, 50, 10, device),
                                # pcx_generic_step (built for the template at run time: launch_shape 31) at VERDICT r3's fixtures
-                               measure_config('marauders_custom_A', 0, 32768, 200, 30, device),
-                               measure_config('walkers_scroll_groups', 0, 262144, 100, 30, device, cardinal_fields=2),
-                               measure_config('warehouse_generic', 0, 262144, 100, 30, device),
-                               measure_config('ordeal_kansas', 0, 262144, 100, 30, device)]
+                               guarded(measure_config, 'marauders_custom_A', 0, 32768, 200, 30, device),
+                               guarded(measure_config, 'walkers_scroll_groups', 0, 262144, 100, 30, device, cardinal_fields=2),
+                               guarded(measure_config, 'warehouse_generic', 0, 262144, 100, 30, device),
+                               guarded(measure_config, 'ordeal_kansas', 0, 262144, 100, 30, device)]
       # config 2's 11 us per play() against what a launch costs on this box at all
-      line['launch_floor_us'] = {'value': launch_floor_us(device), 'what': 'a near-empty kernel (pcx_device_fill_probe over 1 KiB), 1,000 '
+      line['launch_floor_us'] = {'value': guarded(launch_floor_us, device), 'what': 'a near-empty kernel (pcx_device_fill_probe over 1 KiB), 1,000 '
                                  'launches back to back on one stream, best of three: the floor under config 2\'s ms_per_step'}
     if not args.no_cpu_baseline:  # (rank 0's host cores, N > 1 included)
       # north_star: "the reference CPU Engine timed on the same box's host cores (core count stated) in the same run" --
       # the imported reference where it is available (kind "reference"), with the C restatement of it ("port") next to
       # it; the port alone where it is not
-      port = cpu_baseline(template_path)
-      ref = cpu_reference_python(args.game, args.level) if args.game in ('scrolly_maze', 'warehouse', 'marauders', 'hello_world', 'better_scrolly_maze') else None
+      port = guarded(cpu_baseline, template_path)
+      ref = guarded(cpu_reference_python, args.game, args.level) if args.game in ('scrolly_maze', 'warehouse', 'marauders', 'hello_world', 'better_scrolly_maze') else None
+      if ref is not None and 'error' in ref and 'error' not in port:  # (the reference leg failed: the port alone, as where oracle/_ref is absent)
+        sys.stderr.write('bench.py: the reference leg of the CPU baseline failed: %s\n' % ref['error'])
+        ref = None
       if ref is not None:
         line['cpu_baseline'] = ref
         line['cpu_baseline_port'] = port
