@@ -538,6 +538,26 @@ __device__ __forceinline__ void update_curtain(Ctx& x, int thing) {
   const int cr = pos_r(cw), cc = pos_c(cw);
   if (cr < 0 || cc < 0 || cr + x.k.R > PR || cc + C > PC) { x.err |= ERR_INDEX; return; }
   const uint64_t m = C >= 64 ? ~0ull : ((1ull << C) - 1ull);
+#ifndef PCX_X_CURTAIN_ROW_BY_ROW
+  // four rows' pattern words in flight (twelve LDS reads), then their four row stores: row by row every row waited for its own
+  // reads -- the tables and the per-lane arrays are one LDS allocation, the compiler keeps reads and writes in program order
+  const int wi = cc >> 5, sh = cc & 31, R = x.k.R;
+  for (int r0 = 0; r0 < R; r0 += 4) {
+    uint32_t w0[4], w1[4], w2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t* row = pat + (cr + (r0 + j < R ? r0 + j : R - 1)) * PRW;
+      w0[j] = row[wi]; w1[j] = row[wi + 1]; w2[j] = row[sh ? wi + 2 : wi];  // (the third word only counts where the window is not word-aligned)
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (r0 + j >= R) break;
+      uint64_t bits = ((uint64_t)w0[j] | ((uint64_t)w1[j] << 32)) >> sh;
+      if (sh) bits |= (uint64_t)w2[j] << (64 - sh);
+      row_put(x, x.l.cur, d, r0 + j, bits & m);
+    }
+  }
+#else
   for (int r = 0; r < x.k.R; ++r) {
     const uint32_t* row = pat + (cr + r) * PRW;
     const int wi = cc >> 5, sh = cc & 31;
@@ -546,6 +566,7 @@ __device__ __forceinline__ void update_curtain(Ctx& x, int thing) {
     if (sh) bits |= (uint64_t)row[wi + 2] << (64 - sh);
     row_put(x, x.l.cur, d, r, bits & m);
   }
+#endif
 }
 // drapes.py:487-659 _maybe_move
 __device__ __forceinline__ void maybe_move(Ctx& x, int thing, int dr, int dc) {
@@ -1561,6 +1582,28 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
       // that every flat word is written once (no read-modify-write of LDS)
       uint64_t acc = 0;
       int have = 0, wi = 0;
+#ifndef PCX_X_OCCL_WORD_BY_WORD
+      // (eight row words in flight, then their flat words: word by word every LDS read waited for itself behind the store before it)
+      const uint32_t* const src = drape_rows(x, l.cur, d);
+      const int nw = k.R * k.RW;
+      int w = 0;  // which 32 columns of its row the word holds
+      for (int i0 = 0; i0 < nw; i0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(i0 + j < nw ? i0 + j : i0) * WAVE];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (i0 + j >= nw) break;
+          const int nb = C - 32 * w < 32 ? C - 32 * w : 32;
+          uint32_t bits = v[j];
+          if (nb < 32) bits &= (1u << nb) - 1u;
+          acc |= (uint64_t)bits << have;
+          have += nb;
+          if (have >= 32) { l.flat[GFLAT(d, wi, lane)] = (uint32_t)acc; ++wi; acc >>= 32; have -= 32; }
+          w = w + 1 == k.RW ? 0 : w + 1;
+        }
+      }
+#else
       for (int r = 0; r < k.R; ++r)
         for (int w = 0; w < k.RW; ++w) {  // up to 32 columns of row r at a time
           const int nb = C - 32 * w < 32 ? C - 32 * w : 32;
@@ -1570,6 +1613,7 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
           have += nb;
           if (have >= 32) { l.flat[GFLAT(d, wi, lane)] = (uint32_t)acc; ++wi; acc >>= 32; have -= 32; }
         }
+#endif
       for (; wi < FW; ++wi) { l.flat[GFLAT(d, wi, lane)] = (uint32_t)acc; acc = 0; }
     }
     if (timing) c_sec[4] = __builtin_readcyclecounter() - t_occ;  // flat vectors built
@@ -1585,7 +1629,20 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
       for (int u = 0; u < k.NT; ++u) {
         if (!((above >> u) & 1) || tfield(x, u, T_KIND) != 1) continue;
         const uint32_t du = tfield(x, u, T_IDX);
+#ifndef PCX_X_OCCL_WORD_BY_WORD
+        for (int w0 = 0; w0 < FW; w0 += 4) {  // (four words of both curtains in flight)
+          uint32_t mine[4], theirs[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int w = w0 + j < FW ? w0 + j : w0;
+            mine[j] = l.flat[GFLAT(d, w, lane)]; theirs[j] = l.flat[GFLAT(du, w, lane)];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (w0 + j < FW) l.flat[GFLAT(d, w0 + j, lane)] = mine[j] & ~theirs[j];
+        }
+#else
         for (int w = 0; w < FW; ++w) l.flat[GFLAT(d, w, lane)] &= ~l.flat[GFLAT(du, w, lane)];
+#endif
       }
     }
     if (timing) c_sec[5] = __builtin_readcyclecounter() - t_occ;  // + curtains over curtains
@@ -1660,6 +1717,32 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
       slot_free();
       const int CP = k.QW | 1;
       uint32_t* const cd = l.codes + lane * CP;
+#ifndef PCX_X_OCCL_WORD_BY_WORD
+      // eight code dwords -- the 32 cells of ONE flat word per curtain -- at a time: their backdrop dwords in flight together, every
+      // curtain's word read once (dword by dword it was read eight times, each read waiting behind the store of the dword before)
+      for (int q0 = 0; q0 < k.QW; q0 += 8) {
+        uint32_t dw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dw[j] = l.bdcode[q0 + j < k.QW ? q0 + j : q0];
+        PCX_SPEC_UNROLL
+        for (int t = 0; t < k.NT; ++t) {
+          if (tfield(x, t, T_KIND) != 1) continue;
+          const uint32_t word = l.flat[GFLAT(tfield(x, t, T_IDX), q0 >> 3, lane)];
+          const uint32_t cbytes = code_of_layer(k.L, tfield(x, t, T_LAYER)) * 0x01010101u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t bits = (word >> (j * 4)) & 0xFu;
+            const uint32_t m01 = (bits * 0x00204081u) & 0x01010101u;
+            uint32_t hi8 = m01 << 8;
+            asm("" : "+v"(hi8));  // (keeps (x << 8) - x from becoming a quarter-rate multiply)
+            const uint32_t m = hi8 - m01;
+            dw[j] = (dw[j] & ~m) | (cbytes & m);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (q0 + j < k.QW) cd[q0 + j] = dw[j];
+      }
+#else
       for (int q = 0; q < k.QW; ++q) {
         uint32_t d = l.bdcode[q];
         PCX_SPEC_UNROLL
@@ -1674,6 +1757,7 @@ __device__ __forceinline__ void logic_phase(const Consts& k, const L& l, const P
         }
         cd[q] = d;
       }
+#endif
       uint8_t* const cb = reinterpret_cast<uint8_t*>(cd);
       for (int s = 0; s < k.NS; ++s) {
         const uint2 cs = l.sdesc[s * WAVE + lane];
