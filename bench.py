@@ -283,6 +283,42 @@ def measure_config(game, level, batch, steps, warmup, device, repeats=3, raises=
   return out
 
 
+def measure_story(batch, steps, device):
+  """SURVEY 8 f-4's cited game, examples/ordeal.py, as ONE batched `storytelling.Story` (every environment in its own chapter;
+  three chapter engines stepped by pcx_generic_step, chapter changes and plot words carried on the host): the 16 stories recorded
+  from the reference (tests/golden/traces/ordeal_story.npz: data) tiled over the batch, timed per play() with the host side
+  included; the last row is compared with the trace."""
+  import numpy as np
+  import torch
+  from pycolab_amd import cropping, storytelling
+  from pycolab_amd.compiler import GameTemplate
+  from pycolab_amd.engine import Engine
+  tr = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'traces', 'ordeal_story.npz')))
+  T, E = tr['actions'].shape
+  T = min(T, steps)
+  keys = ('castle', 'cavern', 'kansas')
+  load = lambda k: GameTemplate.load(os.path.join(ROOT, 'tests', 'golden', 'templates', 'ordeal_%s.npz' % k))
+  story = storytelling.Story(chapters={k: (lambda k=k: Engine.from_template(load(k), batch=batch, device=device)) for k in keys},
+                             croppers=dict(castle=None, cavern=None, kansas=cropping.ScrollingCropper(rows=8, cols=15, to_track='P', scroll_margins=(2, 3))),
+                             first_chapter='kansas', auto_reset=True)  # examples/ordeal.py:82-110 make_game()
+  tile = np.arange(batch) % E
+  actions = torch.from_numpy(np.ascontiguousarray(tr['actions'][:T, tile])).to('cuda:%d' % device)
+  story.its_showtime()
+  torch.cuda.synchronize(device)
+  t0 = time.perf_counter()
+  for t in range(T):
+    obs, reward, discount = story.play(actions[t])
+  torch.cuda.synchronize(device)
+  wall = time.perf_counter() - t0
+  equal = bool(np.array_equal(obs.board.cpu().numpy(), tr['boards'][T][tile]) and np.array_equal(reward, tr['reward'][T][tile]) and
+               np.array_equal(discount, tr['discount'][T][tile]))
+  story.close()
+  return {'workload': 'examples/ordeal.py as one batched storytelling.Story (tests/golden/templates/ordeal_*), %d envs, %d steps of the '
+                      'recorded tapes' % (batch, T), 'ms_per_step': wall / T * 1e3, 'env_steps_per_s': batch * T / wall,
+          'kernel': 'pcx_generic_step x 3 chapter engines + host-side chapter changes', 'last_row_equals_reference_trace': equal,
+          'note': 'host-bound: one launch per live chapter per play(), chapter changes decided on the host'}
+
+
 def guarded(fn, *args, **kw):
   """A secondary row of the line must not cost the headline its line: what went wrong stands in its place."""
   try:
@@ -626,7 +662,8 @@ def main():
                                guarded(measure_config, 'marauders_custom_A', 0, 32768, 200, 30, device),
                                guarded(measure_config, 'walkers_scroll_groups', 0, 262144, 100, 30, device, cardinal_fields=2),
                                guarded(measure_config, 'warehouse_generic', 0, 262144, 100, 30, device),
-                               guarded(measure_config, 'ordeal_kansas', 0, 262144, 100, 30, device)]
+                               guarded(measure_config, 'ordeal_kansas', 0, 262144, 100, 30, device),
+                               guarded(measure_story, 65536, 160, device)]
       # config 2's 11 us per play() against what a launch costs on this box at all
       line['launch_floor_us'] = {'value': guarded(launch_floor_us, device), 'what': 'a near-empty kernel (pcx_device_fill_probe over 1 KiB), 1,000 '
                                  'launches back to back on one stream, best of three: the floor under config 2\'s ms_per_step'}
